@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Benchmark of the distance hot path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of kernel 1 over the whole synthetic database: all
+self-vs-self core/accessory distances, sketches already resident in HBM,
+output [n_pairs, 2] float32 in PopPUNK row order on rank 0.
+
+  N = 1 : BASELINE configs[2]'s workload on one GPU -- 10 000 synthetic genomes,
+          s = 1024 (sketchsize64 16, bbits 14), k = 13,17,21,25,29 -> 49 995 000 pairs.
+  N > 1 : weak scaling -- round(10 000 * sqrt(N)) genomes, so every GPU still owns
+          ~49 995 000 pairs; the pair space is band-split over the ranks and the
+          distance blocks are gathered to rank 0 with grouped RCCL send/recv
+          inside the timed region (--strong keeps 10 000 genomes instead).
+
+Rank 0 prints ONE JSON line (see the driver contract) carrying `roofline`
+(dominant kernel, HIP-event timed inside libppk_hip.so on its own stream) and
+`cpu_baseline` (the oracle, timed on this host on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_PAIR = 17928          # 2*5*16*14*8 operand bytes + 8 B result
+VALU_OPS_PER_PAIR = 2400             # 5 k * 16 blocks * (28 v_bitop3 + 2 v_bcnt)
+HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9   # CUs * SIMDs * lanes/clk * max clock
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=10000, help="genomes at 1 GPU")
+    ap.add_argument("--strong", action="store_true", help="keep --n genomes for every N")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--tile", type=str, default="", help="TQ,NW override (experiments)")
+    return ap.parse_args()
+
+
+def cpu_baseline(sk, kmers, tbl, seconds):
+    """Time the CPU oracle (oracle/ppk_oracle.c, `port`) on a bounded self-vs-self sample."""
+    from oracle import oracle
+    threads = max(1, min(os.cpu_count() or 1, oracle.max_threads()))
+    probe = min(sk.shape[0], 400)
+    t0 = time.perf_counter()
+    oracle.query(sk[:probe], None, kmers, 16, 14, tbl, threads=threads)
+    dt = max(time.perf_counter() - t0, 1e-4)
+    rate = probe * (probe - 1) / 2 / dt
+    n_s = int(min(sk.shape[0], max(probe, (2 * rate * seconds) ** 0.5)))
+    t0 = time.perf_counter()
+    oracle.query(sk[:n_s], None, kmers, 16, 14, tbl, threads=threads)
+    dt = time.perf_counter() - t0
+    pairs = n_s * (n_s - 1) // 2
+    return {"value": pairs / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
+            "sample": "first %d of the %d synthetic genomes self-vs-self (%d pairs, %.1f s), "
+                      "oracle/ppk_oracle.c -O3 -mavx2 -fopenmp" % (n_s, sk.shape[0], pairs, dt)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from poppunk_amd import _lib, engine, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
+                     "--nproc-per-node %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (there is no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    lib = _lib.lib()
+    if args.tile:
+        tq, nw = (int(x) for x in args.tile.split(","))
+        _lib.check(lib.ppk_set_tile(tq, nw), "ppk_set_tile")
+
+    n = args.n if (args.strong or world == 1) else int(round(args.n * world ** 0.5))
+    kmers = np.asarray(synth.DEFAULT_KMERS, dtype=np.int32)
+    sk, _ = synth.make_sketches(n, kmers, sketchsize64=16, bbits=14)
+    tbl = synth.random_match_table(kmers)
+    ref = engine.SketchDB(sk, 16, 14, device=local_rank)
+
+    bounds = engine.shard_bounds(n, 0, world)
+    rows = [engine.rows_in_band(n, 0, bounds[i], bounds[i + 1]) for i in range(world)]
+    total_pairs = int(sum(rows))
+    qb, qe = bounds[rank], bounds[rank + 1]
+    local = torch.empty((rows[rank], 2), dtype=torch.float32, device=dev)
+    full = None
+    if world > 1 and rank == 0:
+        full = torch.empty((total_pairs, 2), dtype=torch.float32, device=dev)
+
+    def step():
+        engine.dist(ref, None, kmers, tbl, q_begin=qb, q_end=qe, out=local)
+        if world > 1:
+            gather(local, full)
+
+    offs = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
+
+    def gather(loc, dst):
+        if rank == 0:
+            dst[offs[0]:offs[1]].copy_(loc)
+            ops = [dist.P2POp(dist.irecv, dst[offs[s]:offs[s + 1]], s)
+                   for s in range(1, world) if rows[s] > 0]
+        else:
+            ops = [dist.P2POp(dist.isend, loc, 0)] if rows[rank] > 0 else []
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    lib.ppk_prof_enable(1)
+    lib.ppk_prof_read(None, None, 1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    lib.ppk_prof_enable(0)
+    import ctypes as C
+    kms, kn = C.c_double(0), C.c_longlong(0)
+    lib.ppk_prof_read(C.byref(kms), C.byref(kn), 1)
+    kernel_ms = kms.value / max(kn.value, 1)
+    kname = lib.ppk_last_kernel_name().decode()
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = total_pairs * args.steps / elapsed
+        achieved = ALGO_BYTES_PER_PAIR * rows[0] / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get("n%d" % n)
+            except Exception:
+                traffic = None
+        roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "kernel": kname, "kernel_ms": round(kernel_ms, 4),
+                "pairs_per_launch": rows[0],
+                "note": "algorithmic bytes (17928 B/pair) / HIP-event kernel time; LDS+SGPR "
+                        "tiling re-uses every sketch row, so frac > 1 is the reuse factor and the "
+                        "real limiter is integer VALU issue",
+                "valu_frac": round(VALU_OPS_PER_PAIR * rows[0] / (kernel_ms * 1e-3) /
+                                   VALU_PEAK_LANE_OPS, 4) if kernel_ms > 0 else 0.0}
+        cpu = None
+        if not args.no_cpu and world == 1:
+            cpu = cpu_baseline(sk, kmers, tbl, args.cpu_seconds)
+        line = {
+            "metric": "genome-pair distances/sec (10k self, s=1024, k=13-29)",
+            "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "u64",
+            "data": "synthetic",
+            "config": {"workload": "%d synthetic genomes self-vs-self, s=1024 (sketchsize64=16, "
+                                   "bbits=14), k=13,17,21,25,29, %d pairs, output [n_pairs,2] f32 "
+                                   "on rank 0" % (n, total_pairs),
+                       "n_genomes": n, "pairs": total_pairs,
+                       "parallelism": "band-split x%d + p2p gather" % world if world > 1 else "1 GPU"},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        if cpu:
+            line["speedup_vs_cpu"] = value / cpu["value"]
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

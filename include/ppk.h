@@ -1,0 +1,190 @@
+/*
+ * ppk.h -- C ABI of libppk_hip.so, the MI355X (gfx950) core/accessory distance
+ * engine for PopPUNK.  Plain pointers and sizes only; no exceptions cross this
+ * boundary (every call returns 0 on success, a PPK_ERR_* code otherwise, and
+ * ppk_last_error() gives the message for the calling thread).
+ *
+ * Each entry point names the reference interface it replaces
+ * (paths relative to the bacpop/PopPUNK checkout; [EXT] = the un-vendored
+ * pp-sketchlib dependency that PopPUNK reaches through that call site).
+ *
+ * Conventions
+ *  - Sketches on the host: uint64 [n][nk][sketchsize64*bbits], i.e. for every
+ *    sample the per-k datasets of the sketch HDF5 file (PopPUNK/web.py:14-61)
+ *    concatenated in klist order.  Word [blk*bbits + b] holds bit b of bins
+ *    64*blk .. 64*blk+63.
+ *  - Distance rows (PopPUNK/utils.py:199-226, src/boundary.cpp:22-37):
+ *      self    : row <-> (i<j), row-major upper triangle ("condensed");
+ *                sample i is the "query", sample j the "ref";
+ *      non-self: row = q*n_ref + r.
+ *  - "d_" arguments are device pointers on the database's device; `stream` is
+ *    a hipStream_t passed as void* (NULL = the default stream).  Device entry
+ *    points only enqueue work; they do not synchronise.
+ */
+#ifndef PPK_H
+#define PPK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PPK_OK 0
+#define PPK_ERR_ARG 1      /* bad argument                                   */
+#define PPK_ERR_HIP 2      /* a HIP runtime call failed / no usable device   */
+#define PPK_ERR_CAPACITY 3 /* caller-provided output too small               */
+#define PPK_ERR_STATE 4    /* call sequence error                            */
+
+/* flags of ppk_query / ppk_dist_dev: the random_correct and jaccard booleans of
+ * pp_sketchlib.queryDatabase (PopPUNK/sketchlib.py:528-537,:547-566) */
+#define PPK_FLAG_RANDOM_CORRECT 1
+#define PPK_FLAG_JACCARD 2
+/* output raw equal-bin counts, uint32 [n_pairs][nk] (parity testing: the
+ * integer half of the path must be bit-identical to the CPU) */
+#define PPK_FLAG_COUNTS 4
+
+const char *ppk_last_error(void);
+const char *ppk_version(void); /* replaces pp_sketchlib.version (PopPUNK/sketchlib.py:34) */
+int ppk_device_count(int *n);
+
+/* ------------------------------------------------------------------------
+ * Resident sketch database: the flat bin-sketch array of one sample list,
+ * copied to HBM once and re-laid out as [k][word][sample] so that a
+ * wavefront reads 64 samples' copies of one word with one coalesced access.
+ * Replaces the per-call HDF5 -> Reference objects -> device copy that
+ * pp_sketchlib.queryDatabase does internally [EXT] (call sites
+ * PopPUNK/sketchlib.py:528-537,:584-593).
+ * `clu` (nullable) gives each sample's random-match cluster id (the
+ * /random group written by pp_sketchlib.addRandom, PopPUNK/sketchlib.py:437-473).
+ * `src_on_device` != 0: `sk` is already a device pointer on `device_id`.
+ */
+typedef struct ppk_db ppk_db;
+
+int ppk_db_create(int device_id, const uint64_t *sk, size_t n, size_t nk,
+                  size_t sketchsize64, size_t bbits, const uint16_t *clu,
+                  int src_on_device, void *stream, ppk_db **out);
+void ppk_db_destroy(ppk_db *db);
+size_t ppk_db_size(const ppk_db *db);
+
+/* Number of distance rows for rows q in [q_begin, q_end) (self: n_qry == 0). */
+size_t ppk_rows_in_band(size_t n_ref, size_t n_qry, size_t q_begin, size_t q_end);
+/* Split the query axis into n_parts bands of (nearly) equal pair count, band
+ * edges multiples of 64: bounds[0..n_parts] (the pair-tile split of the N^2
+ * space across GPUs). */
+int ppk_band_split(size_t n_ref, size_t n_qry, int n_parts, size_t *bounds);
+
+/* ------------------------------------------------------------------------
+ * Kernel 1 on resident sketches: match counts at each k -> Jaccard ->
+ * random-match correction -> regression of log J on k -> (core, accessory).
+ * Replaces the hot loop inside pp_sketchlib.queryDatabase [EXT]
+ * (PopPUNK/sketchlib.py:528-537 self, :584-593 ref x query).
+ *   qry == NULL        : self comparison of `ref`
+ *   kmers              : host int32 [nk] (klist)
+ *   random_tbl         : host float [nk][n_clu][n_clu] or NULL
+ *   [q_begin, q_end)   : band of query rows to compute (a GPU's share)
+ *   d_out              : device; float [rows][2] (core, accessory), or
+ *                        float [rows][nk] with PPK_FLAG_JACCARD, or
+ *                        uint32 [rows][nk] with PPK_FLAG_COUNTS;
+ *                        rows = ppk_rows_in_band(...), band-relative.
+ *   d_n_failed         : device uint64 (nullable), incremented by the number
+ *                        of pairs with < 2 usable k (they get (0,0)).
+ */
+int ppk_dist_dev(const ppk_db *ref, const ppk_db *qry, const int32_t *kmers,
+                 const float *random_tbl, size_t n_clu, int flags,
+                 size_t q_begin, size_t q_end, void *d_out,
+                 unsigned long long *d_n_failed, void *stream);
+
+/* Fused kernel 1 + boundary: distances never leave the CU; each wavefront
+ * ballots the edge predicate and a compaction pass emits the edge list in
+ * reference row order.  Replaces queryDatabase -> (X/scale) ->
+ * poppunk_refine.assignThreshold -> generateTuples
+ * (PopPUNK/models.py:1065-1091, PopPUNK/network.py:1180-1184) or
+ * -> poppunk_refine.edgeThreshold (PopPUNK/refine.py:535), without the
+ * [n_pairs,2] matrix.  `inclusive` != 0 selects edgeThreshold's `<= 0`
+ * predicate (src/boundary.cpp:88), 0 selects assign == -1 (`< 0`,
+ * src/boundary.cpp:70-76 with within_label -1, PopPUNK/models.py:801).
+ * Edges are int64 pairs (i,j), i<j; self: sample indices; non-self:
+ * (r, n_ref + q) (src/boundary.cpp:113-114).
+ *   d_edges / cap      : device int64 [cap][2]
+ *   d_n_edges          : device uint64, receives the total edge count of the
+ *                        band (may exceed cap; only the first cap are stored)
+ */
+int ppk_dist_edges_dev(const ppk_db *ref, const ppk_db *qry, const int32_t *kmers,
+                       const float *random_tbl, size_t n_clu, int flags,
+                       size_t q_begin, size_t q_end, int slope, float x_max,
+                       float y_max, float scale_x, float scale_y, int inclusive,
+                       long long *d_edges, size_t cap,
+                       unsigned long long *d_n_edges,
+                       unsigned long long *d_n_failed, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Kernel 2 on a resident [n_rows][2] float32 distance buffer.
+ */
+/* replaces poppunk_refine.assignThreshold (src/python_bindings.cpp:18-25,:79-83;
+ * src/boundary.cpp:60-80): out float [n_rows] in {-1, 0, +1} */
+int ppk_assign_threshold_dev(const float *d_dist, size_t n_rows, int slope,
+                             float x_max, float y_max, float *d_out, void *stream);
+
+/* replaces poppunk_refine.edgeThreshold (src/python_bindings.cpp:27-32,:85-90;
+ * src/boundary.cpp:82-95) when n_ref == 0 (self/condensed rows), and the
+ * assignThreshold + generateTuples(non-self) pair when n_ref > 0
+ * (row = q*n_ref + r -> (r, n_ref+q)).  Stable: edges come out in row order. */
+int ppk_edge_threshold_dev(const float *d_dist, size_t n_rows, size_t n_ref,
+                           int slope, float x_max, float y_max, int inclusive,
+                           long long *d_edges, size_t cap,
+                           unsigned long long *d_n_edges, void *stream);
+
+/* replaces poppunk_refine.generateTuples (src/python_bindings.cpp:34-40,:92-96;
+ * src/boundary.cpp:97-123): rows with assignments[row] == within_label. */
+int ppk_generate_tuples_dev(const int32_t *d_assign, size_t n_rows, int within_label,
+                            int self, size_t num_ref, long long int_offset,
+                            long long *d_edges, size_t cap,
+                            unsigned long long *d_n_edges, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Host-buffer convenience wrappers (what a pybind11/ctypes drop-in binds):
+ * upload, run on `devices[0..n_dev)` (the pair space is band-split across
+ * them), copy back.  Blocking.
+ */
+/* replaces pp_sketchlib.queryDatabase(ref_db_name, query_db_name, rList, qList,
+ * klist, random_correct, jaccard, num_threads, use_gpu, device_id) after the
+ * HDF5 read (PopPUNK/sketchlib.py:528-537; positional order pinned by
+ * test/test-update-gpu.py:85-86).  n_qry == 0 => self.  out: float
+ * [n_pairs][2] or [n_pairs][nk] (PPK_FLAG_JACCARD) or uint32 (PPK_FLAG_COUNTS). */
+int ppk_query(const uint64_t *ref_sk, size_t n_ref, const uint64_t *qry_sk,
+              size_t n_qry, const int32_t *kmers, size_t nk, size_t sketchsize64,
+              size_t bbits, const float *random_tbl, const uint16_t *ref_clu,
+              const uint16_t *qry_clu, size_t n_clu, int flags, const int *devices,
+              int n_dev, void *out, unsigned long long *n_failed);
+
+int ppk_assign_threshold(const float *dist, size_t n_rows, int slope, float x_max,
+                         float y_max, int device_id, float *out);
+
+/* Edge lists have a data-dependent size: *n_edges always receives the total;
+ * PPK_ERR_CAPACITY is returned when it exceeds cap (nothing is written). */
+int ppk_edge_threshold(const float *dist, size_t n_rows, size_t n_ref, int slope,
+                       float x_max, float y_max, int inclusive, int device_id,
+                       long long *ij_out, size_t cap, size_t *n_edges);
+int ppk_generate_tuples(const int32_t *assignments, size_t n_rows, int within_label,
+                        int self, size_t num_ref, long long int_offset, int device_id,
+                        long long *ij_out, size_t cap, size_t *n_edges);
+
+/* ------------------------------------------------------------------------
+ * Measurement hooks (bench.py): when enabled, the dominant kernel of each
+ * ppk_dist*_dev call is bracketed by hipEvents on its own stream.
+ */
+int ppk_prof_enable(int on);
+/* Sum of elapsed ms and number of bracketed launches since the last reset;
+ * synchronises the recorded events. */
+int ppk_prof_read(double *total_ms, long long *n_launches, int reset);
+/* name of the kernel variant the last ppk_dist*_dev call launched */
+const char *ppk_last_kernel_name(void);
+/* Tuning override for experiments: "TQ,NW" of the pair-tile (0,0 = auto). */
+int ppk_set_tile(int tq, int nw);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PPK_H */

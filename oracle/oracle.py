@@ -1,0 +1,201 @@
+"""ctypes front-end of the CPU oracle -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module (see oracle/ppk_oracle.c for the parity status of each half).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libppk_oracle.so")
+
+FLAG_RANDOM_CORRECT = 1
+FLAG_JACCARD = 2
+
+
+def build(force=False):
+    """Compile the C restatement (gcc; see oracle/Makefile)."""
+    if force or not os.path.exists(_SO) or (
+            os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_HERE, "ppk_oracle.c"))):
+        subprocess.run(["make", "-C", _HERE, "-B", "libppk_oracle.so"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_SO)
+        c = ctypes
+        u64p, f32p, i32p, u16p, i64p, u32p, f64p = (
+            c.POINTER(c.c_uint64), c.POINTER(c.c_float), c.POINTER(c.c_int32),
+            c.POINTER(c.c_uint16), c.POINTER(c.c_int64), c.POINTER(c.c_uint32),
+            c.POINTER(c.c_double))
+        _lib.ppk_oracle_match_counts.argtypes = [u64p, c.c_size_t, u64p, c.c_size_t, c.c_size_t,
+                                                 c.c_size_t, c.c_size_t, u32p, c.c_int]
+        _lib.ppk_oracle_match_counts.restype = c.c_int
+        _lib.ppk_oracle_query.argtypes = [u64p, c.c_size_t, u64p, c.c_size_t, i32p, c.c_size_t,
+                                          c.c_size_t, c.c_size_t, f32p, u16p, u16p, c.c_size_t,
+                                          c.c_int, c.c_int, f32p]
+        _lib.ppk_oracle_query.restype = c.c_long
+        _lib.ppk_oracle_fit.argtypes = [f64p, i32p, c.c_size_t, c.c_size_t, f32p,
+                                        c.POINTER(c.c_int)]
+        _lib.ppk_oracle_fit.restype = None
+        _lib.ppk_oracle_assign_threshold.argtypes = [f32p, c.c_size_t, c.c_int, c.c_float,
+                                                     c.c_float, f32p, c.c_int]
+        _lib.ppk_oracle_assign_threshold.restype = None
+        _lib.ppk_oracle_edge_threshold.argtypes = [f32p, c.c_size_t, c.c_size_t, c.c_int,
+                                                   c.c_float, c.c_float, c.c_int, i64p,
+                                                   c.c_size_t]
+        _lib.ppk_oracle_edge_threshold.restype = c.c_size_t
+        _lib.ppk_oracle_generate_tuples.argtypes = [i32p, c.c_size_t, c.c_int, c.c_int,
+                                                    c.c_size_t, c.c_int64, i64p, c.c_size_t]
+        _lib.ppk_oracle_generate_tuples.restype = c.c_size_t
+        _lib.ppk_oracle_rows_to_samples.argtypes = [c.c_size_t]
+        _lib.ppk_oracle_rows_to_samples.restype = c.c_size_t
+        _lib.ppk_oracle_max_threads.restype = c.c_int
+    return _lib
+
+
+def _p(a, ct):
+    return a.ctypes.data_as(ctypes.POINTER(ct)) if a is not None else None
+
+
+def _check_sk(sk):
+    sk = np.ascontiguousarray(sk, dtype=np.uint64)
+    assert sk.ndim == 3, "sketches are [sample][k][sketchsize64*bbits] uint64"
+    return sk
+
+
+def n_pairs(n_ref, n_qry):
+    return n_ref * (n_ref - 1) // 2 if n_qry == 0 else n_ref * n_qry
+
+
+def match_counts(ref_sk, qry_sk, sketchsize64, bbits, threads=1):
+    """uint32 [n_pairs, nk] equal-bin counts; qry_sk=None -> self (condensed order)."""
+    ref_sk = _check_sk(ref_sk)
+    n_ref, nk, words = ref_sk.shape
+    assert words == sketchsize64 * bbits
+    n_qry = 0
+    if qry_sk is not None:
+        qry_sk = _check_sk(qry_sk)
+        n_qry = qry_sk.shape[0]
+    out = np.zeros((n_pairs(n_ref, n_qry), nk), dtype=np.uint32)
+    lib().ppk_oracle_match_counts(_p(ref_sk, ctypes.c_uint64), n_ref,
+                                  _p(qry_sk, ctypes.c_uint64), n_qry, nk, sketchsize64, bbits,
+                                  _p(out, ctypes.c_uint32), threads)
+    return out
+
+
+def query(ref_sk, qry_sk, kmers, sketchsize64, bbits, random_tbl=None, ref_clu=None,
+          qry_clu=None, random_correct=True, jaccard=False, threads=1):
+    """float32 [n_pairs, 2] (core, accessory) or [n_pairs, nk] Jaccards; returns (out, n_failed)."""
+    ref_sk = _check_sk(ref_sk)
+    n_ref, nk, words = ref_sk.shape
+    assert words == sketchsize64 * bbits
+    kmers = np.ascontiguousarray(kmers, dtype=np.int32)
+    assert kmers.shape == (nk,)
+    n_qry = 0
+    if qry_sk is not None:
+        qry_sk = _check_sk(qry_sk)
+        n_qry = qry_sk.shape[0]
+    n_clu = 0
+    if random_tbl is not None:
+        random_tbl = np.ascontiguousarray(random_tbl, dtype=np.float32)
+        assert random_tbl.ndim == 3 and random_tbl.shape[0] == nk
+        n_clu = random_tbl.shape[1]
+        if ref_clu is not None:
+            ref_clu = np.ascontiguousarray(ref_clu, dtype=np.uint16)
+        if qry_clu is not None:
+            qry_clu = np.ascontiguousarray(qry_clu, dtype=np.uint16)
+    flags = (FLAG_RANDOM_CORRECT if random_correct else 0) | (FLAG_JACCARD if jaccard else 0)
+    out = np.zeros((n_pairs(n_ref, n_qry), nk if jaccard else 2), dtype=np.float32)
+    failed = lib().ppk_oracle_query(_p(ref_sk, ctypes.c_uint64), n_ref,
+                                    _p(qry_sk, ctypes.c_uint64), n_qry,
+                                    _p(kmers, ctypes.c_int32), nk, sketchsize64, bbits,
+                                    _p(random_tbl, ctypes.c_float), _p(ref_clu, ctypes.c_uint16),
+                                    _p(qry_clu, ctypes.c_uint16), n_clu, flags, threads,
+                                    _p(out, ctypes.c_float))
+    if failed < 0:
+        raise RuntimeError("oracle query failed")
+    return out, int(failed)
+
+
+def fit(jac, kmers, nbins):
+    jac = np.ascontiguousarray(jac, dtype=np.float64)
+    kmers = np.ascontiguousarray(kmers, dtype=np.int32)
+    out = np.zeros(2, dtype=np.float32)
+    failed = ctypes.c_int(0)
+    lib().ppk_oracle_fit(_p(jac, ctypes.c_double), _p(kmers, ctypes.c_int32), len(kmers), nbins,
+                         _p(out, ctypes.c_float), ctypes.byref(failed))
+    return out, bool(failed.value)
+
+
+def assign_threshold(dist, slope, x_max, y_max, threads=1):
+    dist = np.ascontiguousarray(dist, dtype=np.float32)
+    out = np.zeros(dist.shape[0], dtype=np.float32)
+    lib().ppk_oracle_assign_threshold(_p(dist, ctypes.c_float), dist.shape[0], slope,
+                                      np.float32(x_max), np.float32(y_max),
+                                      _p(out, ctypes.c_float), threads)
+    return out
+
+
+def edge_threshold(dist, slope, x_max, y_max, n_ref=0, inclusive=True):
+    """int64 [n_edges, 2]; n_ref=0 -> self/condensed, else row = q*n_ref + r -> (r, n_ref+q)."""
+    dist = np.ascontiguousarray(dist, dtype=np.float32)
+    cap = dist.shape[0]
+    ij = np.zeros((max(cap, 1), 2), dtype=np.int64)
+    ne = lib().ppk_oracle_edge_threshold(_p(dist, ctypes.c_float), dist.shape[0], n_ref, slope,
+                                         np.float32(x_max), np.float32(y_max), int(inclusive),
+                                         _p(ij, ctypes.c_int64), cap)
+    return ij[:ne].copy()
+
+
+def generate_tuples(assignments, within_label, self=True, num_ref=0, int_offset=0):
+    a = np.ascontiguousarray(assignments, dtype=np.int32)
+    cap = a.shape[0]
+    ij = np.zeros((max(cap, 1), 2), dtype=np.int64)
+    ne = lib().ppk_oracle_generate_tuples(_p(a, ctypes.c_int32), cap, within_label, int(self),
+                                          num_ref, int_offset, _p(ij, ctypes.c_int64), cap)
+    return ij[:ne].copy()
+
+
+def max_threads():
+    return int(lib().ppk_oracle_max_threads())
+
+
+# ---- independent numpy restatement for SMALL cases (cross-checks the C code) -----------------
+def deslice(sk_words, sketchsize64, bbits):
+    """Bit-sliced words [.., sketchsize64*bbits] -> bin values [.., 64*sketchsize64] (row a2)."""
+    w = np.asarray(sk_words, dtype=np.uint64).reshape(sk_words.shape[:-1] + (sketchsize64, bbits))
+    bit = np.arange(64, dtype=np.uint64)
+    bins = np.zeros(w.shape[:-1] + (64,), dtype=np.uint32)
+    for b in range(bbits):
+        plane = ((w[..., b][..., None] >> bit) & np.uint64(1)).astype(np.uint32)
+        bins |= plane << np.uint32(b)
+    return bins.reshape(sk_words.shape[:-1] + (64 * sketchsize64,))
+
+
+def match_counts_numpy(ref_sk, qry_sk, sketchsize64, bbits):
+    """Equal-bin counts by comparing de-sliced bin VALUES (not the bitwise trick)."""
+    rb = deslice(np.asarray(ref_sk), sketchsize64, bbits)
+    n_ref = rb.shape[0]
+    if qry_sk is None:
+        rows = []
+        for i in range(n_ref):
+            for j in range(i + 1, n_ref):
+                rows.append((rb[j] == rb[i]).sum(axis=-1))
+        return np.asarray(rows, dtype=np.uint32).reshape(-1, rb.shape[1])
+    qb = deslice(np.asarray(qry_sk), sketchsize64, bbits)
+    rows = []
+    for q in range(qb.shape[0]):
+        for r in range(n_ref):
+            rows.append((rb[r] == qb[q]).sum(axis=-1))
+    return np.asarray(rows, dtype=np.uint32).reshape(-1, rb.shape[1])

@@ -1,0 +1,362 @@
+/*
+ * ppk_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C CPU restatement of the PopPUNK distance hot path, used only as the
+ * checker for the HIP path (tests/, __graft_entry__.smoke(), and the
+ * cpu_baseline leg of bench.py).  Nothing under poppunk_amd/ may call it.
+ *
+ * Parity status
+ * -------------
+ *  - Kernel 1 (bin match -> Jaccard -> random-match correction -> regression):
+ *    the reference implementation lives in the third-party dependency
+ *    pp-sketchlib (>= 2.0.1; /root/reference/PopPUNK/__init__.py:9-11,
+ *    environment.yml:22), which is NOT vendored under /root/reference and is
+ *    not installable here.  This file restates its published algorithm
+ *    (bindash-style b-bit one-permutation MinHash comparison; SURVEY.md
+ *    section 8a rows a2-a6).  It is pinned only against what the reference tree
+ *    itself holds: the model equation and clamp of
+ *    PopPUNK/sketchlib.py:635-670 (fitKmerCurve; golden vectors in
+ *    tests/golden/fit_kmer_curve.json), the J < 5/s rule of
+ *    docs/sketching.rst:161-165, the row order of PopPUNK/utils.py:199-226
+ *    (tests/golden/row_order.json) and the real sketch of
+ *    test/json_sketch.txt (tests/golden/json_sketch.npz).  Equality with the
+ *    upstream pp-sketchlib binary is UNVERIFIED: "parity unpinned" for the
+ *    numerical values of kernel 1.
+ *  - Kernel 2 (boundary assignment / edge list): restates
+ *    /root/reference/src/boundary.cpp:18-123.  That file needs Eigen, which is
+ *    absent from this image, so it cannot be compiled here without a stand-in
+ *    header; it is pinned by the known-answer values recorded in SURVEY.md
+ *    Appendix B (captured from the unmodified reference source during the
+ *    survey) and by the structure of test/test-refine.py:47-82.
+ *
+ * Build: see oracle/Makefile  (gcc -O3 -fopenmp -ffp-contract=off).
+ * -ffp-contract=off matters: line_dist must be evaluated as un-fused float32
+ * ("FMA sensitivity").
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define PPK_FLAG_RANDOM_CORRECT 1
+#define PPK_FLAG_JACCARD 2
+
+/* ---- a3: bin match ------------------------------------------------------
+ * pp-sketchlib calc_intersize [EXT]; SURVEY.md 8a row a3.  Words are
+ * bit-sliced: word [blk*bbits + b] holds bit b of bins 64*blk..64*blk+63
+ * (row a2), so 64 bins are equal iff all bbits XORs are zero at that bit. */
+static inline uint32_t match_count(const uint64_t *a, const uint64_t *b,
+                                   size_t sketchsize64, size_t bbits) {
+  uint32_t same = 0;
+  for (size_t blk = 0; blk < sketchsize64; blk++) {
+    uint64_t bits = ~(uint64_t)0;
+    for (size_t j = 0; j < bbits; j++) {
+      bits &= ~(a[blk * bbits + j] ^ b[blk * bbits + j]);
+    }
+    same += (uint32_t)__builtin_popcountll(bits);
+  }
+  return same;
+}
+
+/* ---- a4: collision adjustment + observed Jaccard -------------------------
+ * expected = maxnbits >> bbits; 0 whenever 64*sketchsize64 < 2^bbits.
+ * Integer arithmetic (size_t) as in the bindash-derived source [EXT]. */
+static inline double jaccard_obs(uint32_t same, size_t sketchsize64,
+                                 size_t bbits) {
+  const size_t maxnbits = sketchsize64 * 64;
+  const size_t expected = maxnbits >> bbits;
+  size_t intersize = same;
+  if (expected) {
+    size_t ret = same > expected ? same - expected : 0;
+    intersize = ret * maxnbits / (maxnbits - expected);
+  }
+  return (double)intersize / (double)maxnbits;
+}
+
+/* ---- a5: random-match correction: observed_excess(obs, exp, 1) ---------- */
+static inline double observed_excess(double obs, double expd) {
+  double diff = obs > expd ? obs - expd : 0.0;
+  return diff / (1.0 - expd);
+}
+
+/* ---- a6: regression of log J on k ---------------------------------------
+ * Model pr = (1-a)(1-c)^k  (PopPUNK/sketchlib.py:482,:652-654):
+ * log J = log(1-a) + k log(1-c).  Points are used up to (not including) the
+ * first k whose J < 5/nbins (docs/sketching.rst:161-165; truncation at the
+ * first failing k is the pp-sketchlib CPU behaviour [EXT]).  Fewer than two
+ * usable points -> (0,0) and the pair is counted as a failed fit.
+ * core = 1-exp(slope), accessory = 1-exp(intercept), each only if the
+ * parameter is < 0, else 0 (clamp as in sketchlib.py:660-670).
+ * Returns 1 if the fit failed. */
+static int fit_pair(const double *jac, const int32_t *kmers, size_t nk,
+                    size_t nbins, float *core, float *acc) {
+  const double tol = 5.0 / (double)nbins;
+  size_t n = nk;
+  for (size_t i = 0; i < nk; i++) {
+    if (jac[i] < tol) {
+      n = i;
+      break;
+    }
+  }
+  if (n < 2) {
+    *core = 0.0f;
+    *acc = 0.0f;
+    return 1;
+  }
+  double sx = 0, sxx = 0, sy = 0, sxy = 0;
+  for (size_t i = 0; i < n; i++) {
+    const double x = (double)kmers[i];
+    const double y = log(jac[i]);
+    sx += x;
+    sxx += x * x;
+    sy += y;
+    sxy += x * y;
+  }
+  const double dn = (double)n;
+  const double slope = (dn * sxy - sx * sy) / (dn * sxx - sx * sx);
+  const double intercept = (sy - slope * sx) / dn;
+  *core = slope < 0 ? (float)(1.0 - exp(slope)) : 0.0f;
+  *acc = intercept < 0 ? (float)(1.0 - exp(intercept)) : 0.0f;
+  return 0;
+}
+
+void ppk_oracle_fit(const double *jac, const int32_t *kmers, size_t nk,
+                    size_t nbins, float *core_acc /* [2] */, int *failed) {
+  *failed = fit_pair(jac, kmers, nk, nbins, &core_acc[0], &core_acc[1]);
+}
+
+/* Pair enumeration (a7; PopPUNK/utils.py:199-226, src/boundary.cpp:22-37):
+ *  self    : row <-> (i<j) row-major upper triangle ("condensed"); the
+ *            "query" is sample i, the "ref" is sample j.
+ *  non-self: row = q*n_ref + r. */
+static inline size_t n_pairs_of(size_t n_ref, size_t n_qry) {
+  return n_qry == 0 ? n_ref * (n_ref - 1) / 2 : n_ref * n_qry;
+}
+
+/* Match counts only: counts[row*nk + k].  Sketch layout: [sample][k][word],
+ * word = sketchsize64*bbits uint64 (one HDF5 dataset per (sample,k):
+ * PopPUNK/web.py:14-61). */
+int ppk_oracle_match_counts(const uint64_t *ref_sk, size_t n_ref,
+                            const uint64_t *qry_sk, size_t n_qry, size_t nk,
+                            size_t sketchsize64, size_t bbits,
+                            uint32_t *counts, int num_threads) {
+  const size_t words = sketchsize64 * bbits;
+  const size_t stride = nk * words;
+  if (num_threads < 1) num_threads = 1;
+  if (n_qry == 0) {
+#pragma omp parallel for schedule(dynamic, 8) num_threads(num_threads)
+    for (long i = 0; i < (long)n_ref; i++) {
+      size_t row = (size_t)i * n_ref - ((size_t)i * ((size_t)i + 1)) / 2;
+      for (size_t j = (size_t)i + 1; j < n_ref; j++, row++) {
+        for (size_t k = 0; k < nk; k++) {
+          counts[row * nk + k] =
+              match_count(ref_sk + j * stride + k * words,
+                          ref_sk + (size_t)i * stride + k * words,
+                          sketchsize64, bbits);
+        }
+      }
+    }
+  } else {
+#pragma omp parallel for schedule(dynamic, 8) num_threads(num_threads)
+    for (long q = 0; q < (long)n_qry; q++) {
+      for (size_t r = 0; r < n_ref; r++) {
+        const size_t row = (size_t)q * n_ref + r;
+        for (size_t k = 0; k < nk; k++) {
+          counts[row * nk + k] =
+              match_count(ref_sk + r * stride + k * words,
+                          qry_sk + (size_t)q * stride + k * words,
+                          sketchsize64, bbits);
+        }
+      }
+    }
+  }
+  return 0;
+}
+
+/* Full kernel-1 path.  random_tbl is [nk][n_clu][n_clu] float32 (the table
+ * pp_sketchlib.addRandom leaves in the ref DB's /random group, row a5);
+ * ref_clu/qry_clu give each sample's cluster id.  out is [n_pairs][2]
+ * (core, accessory) float32, or [n_pairs][nk] Jaccards when
+ * PPK_FLAG_JACCARD is set (PopPUNK/sketchlib.py:547-566).
+ * Returns the number of failed fits (>= 0). */
+long ppk_oracle_query(const uint64_t *ref_sk, size_t n_ref,
+                      const uint64_t *qry_sk, size_t n_qry,
+                      const int32_t *kmers, size_t nk, size_t sketchsize64,
+                      size_t bbits, const float *random_tbl,
+                      const uint16_t *ref_clu, const uint16_t *qry_clu,
+                      size_t n_clu, int flags, int num_threads, float *out) {
+  const size_t words = sketchsize64 * bbits;
+  const size_t stride = nk * words;
+  const size_t nbins = sketchsize64 * 64;
+  const int self = (n_qry == 0);
+  const size_t nq = self ? n_ref : n_qry;
+  const uint64_t *qs = self ? ref_sk : qry_sk;
+  const uint16_t *qc = self ? ref_clu : qry_clu;
+  const int rc = (flags & PPK_FLAG_RANDOM_CORRECT) && random_tbl != NULL;
+  const int want_j = flags & PPK_FLAG_JACCARD;
+  const size_t ocols = want_j ? nk : 2;
+  long failed = 0;
+  if (nk > 64) return -1;
+  if (num_threads < 1) num_threads = 1;
+#pragma omp parallel for schedule(dynamic, 8) num_threads(num_threads) reduction(+ : failed)
+  for (long q = 0; q < (long)nq; q++) {
+    const size_t r0 = self ? (size_t)q + 1 : 0;
+    size_t row = self ? (size_t)q * n_ref - ((size_t)q * ((size_t)q + 1)) / 2
+                      : (size_t)q * n_ref;
+    for (size_t r = r0; r < n_ref; r++, row++) {
+      double jac[64];
+      for (size_t k = 0; k < nk; k++) {
+        const uint32_t same =
+            match_count(ref_sk + r * stride + k * words,
+                        qs + (size_t)q * stride + k * words, sketchsize64, bbits);
+        double j = jaccard_obs(same, sketchsize64, bbits);
+        double jr = 0.0;
+        if (rc) {
+          const size_t cr = ref_clu ? ref_clu[r] : 0;
+          const size_t cq = qc ? qc[q] : 0;
+          jr = (double)random_tbl[(k * n_clu + cr) * n_clu + cq];
+        }
+        jac[k] = observed_excess(j, jr);
+      }
+      if (want_j) {
+        for (size_t k = 0; k < nk; k++) out[row * ocols + k] = (float)jac[k];
+      } else {
+        failed += fit_pair(jac, kmers, nk, nbins, &out[row * 2], &out[row * 2 + 1]);
+      }
+    }
+  }
+  return failed;
+}
+
+/* ---- a8: line_dist (src/boundary.cpp:42-58), float32, un-fused ---------- */
+static inline float line_dist(float x0, float y0, float x_max, float y_max,
+                              int slope) {
+  float side = 0;
+  if (slope == 2) {
+    if (x_max == 0 || y_max == 0) {
+      side = sqrtf(x0 * x0 + y0 * y0);
+    } else {
+      const float t0 = y0 * x_max;
+      const float t1 = x0 * y_max;
+      const float t2 = x_max * y_max;
+      side = (t0 + t1) - t2;
+    }
+  } else if (slope == 0) {
+    side = x0 - x_max;
+  } else if (slope == 1) {
+    side = y0 - y_max;
+  }
+  return side;
+}
+
+/* ---- a9: assign_threshold (src/boundary.cpp:60-80) ---------------------- */
+void ppk_oracle_assign_threshold(const float *dist, size_t n_rows, int slope,
+                                 float x_max, float y_max, float *out,
+                                 int num_threads) {
+  if (num_threads < 1) num_threads = 1;
+#pragma omp parallel for schedule(static) num_threads(num_threads)
+  for (long row = 0; row < (long)n_rows; row++) {
+    const float d = line_dist(dist[2 * row], dist[2 * row + 1], x_max, y_max, slope);
+    out[row] = d == 0 ? 0.0f : (d > 0 ? 1.0f : -1.0f);
+  }
+}
+
+/* condensed index math (src/boundary.cpp:18-31), integer-exact restatement:
+ * row i is the largest i with start(i) = i*n - i(i+1)/2 <= k. */
+static inline size_t samples_of_rows(size_t n_rows) {
+  size_t n = (size_t)(0.5 * (1.0 + sqrt(1.0 + 8.0 * (double)n_rows)));
+  while (n * (n - 1) / 2 > n_rows) n--;
+  while ((n + 1) * n / 2 <= n_rows) n++;
+  return n;
+}
+static inline size_t row_start(size_t i, size_t n) {
+  return i * n - i * (i + 1) / 2;
+}
+static inline size_t cond_row_idx(size_t k, size_t n) {
+  double d = sqrt((double)(4 * n * (n - 1)) - 8.0 * (double)k - 7.0);
+  long i = (long)n - 2 - (long)floor(d / 2.0 - 0.5);
+  if (i < 0) i = 0;
+  if (i > (long)n - 2) i = (long)n - 2;
+  while (i > 0 && row_start((size_t)i, n) > k) i--;
+  while ((size_t)i + 2 < n && row_start((size_t)i + 1, n) <= k) i++;
+  return (size_t)i;
+}
+
+size_t ppk_oracle_rows_to_samples(size_t n_rows) { return samples_of_rows(n_rows); }
+
+/* ---- a10: edge_iterate (src/boundary.cpp:82-95); `inclusive` selects the
+ * `<= 0` predicate of edgeThreshold, otherwise `< 0` (assign == -1, row a12).
+ * Self/condensed when n_ref == 0 (n_samples derived from n_rows), else
+ * non-self with row = q*n_ref + r -> (r, n_ref + q) (boundary.cpp:113-114).
+ * ij_out is [cap][2] int64; returns the number of edges found (may exceed
+ * cap, in which case only the first cap are stored). */
+size_t ppk_oracle_edge_threshold(const float *dist, size_t n_rows, size_t n_ref,
+                                 int slope, float x_max, float y_max,
+                                 int inclusive, int64_t *ij_out, size_t cap) {
+  const int self = (n_ref == 0);
+  const size_t n = self ? samples_of_rows(n_rows) : 0;
+  size_t ne = 0;
+  for (size_t row = 0; row < n_rows; row++) {
+    const float d = line_dist(dist[2 * row], dist[2 * row + 1], x_max, y_max, slope);
+    if (inclusive ? (d <= 0) : (d < 0)) {
+      if (ne < cap) {
+        int64_t i, j;
+        if (self) {
+          i = (int64_t)cond_row_idx(row, n);
+          j = (int64_t)(row - row_start((size_t)i, n) + (size_t)i + 1);
+        } else {
+          i = (int64_t)(row % n_ref);
+          j = (int64_t)(row / n_ref + n_ref);
+        }
+        ij_out[2 * ne] = i;
+        ij_out[2 * ne + 1] = j;
+      }
+      ne++;
+    }
+  }
+  return ne;
+}
+
+/* ---- a11: generate_tuples (src/boundary.cpp:97-123) ---------------------- */
+size_t ppk_oracle_generate_tuples(const int32_t *assignments, size_t n_rows,
+                                  int within_label, int self, size_t num_ref,
+                                  int64_t int_offset, int64_t *ij_out, size_t cap) {
+  const size_t n = self ? samples_of_rows(n_rows) : 0;
+  size_t ne = 0;
+  for (size_t row = 0; row < n_rows; row++) {
+    if (assignments[row] == within_label) {
+      if (ne < cap) {
+        int64_t i, j;
+        if (self) {
+          const size_t ii = cond_row_idx(row, n);
+          i = (int64_t)ii + int_offset;
+          j = (int64_t)(row - row_start(ii, n) + ii + 1) + int_offset;
+        } else {
+          i = (int64_t)(row % num_ref) + int_offset;
+          j = (int64_t)(row / num_ref + num_ref) + int_offset;
+        }
+        if (i > j) {
+          int64_t t = i;
+          i = j;
+          j = t;
+        }
+        ij_out[2 * ne] = i;
+        ij_out[2 * ne + 1] = j;
+      }
+      ne++;
+    }
+  }
+  return ne;
+}
+
+int ppk_oracle_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}

@@ -1,0 +1,86 @@
+"""ctypes binding of libppk_hip.so (the C ABI declared in include/ppk.h).
+
+There is no CPU fallback: if the HIP library is missing or cannot be loaded the
+import of this module's `lib()` raises, and every product entry point fails.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "csrc", "libppk_hip.so")
+
+OK, ERR_ARG, ERR_HIP, ERR_CAPACITY, ERR_STATE = 0, 1, 2, 3, 4
+FLAG_RANDOM_CORRECT, FLAG_JACCARD, FLAG_COUNTS = 1, 2, 4
+
+# every symbol include/ppk.h declares: name -> (restype, argtypes)
+_u64p, _f32p, _i32p, _u16p = (C.POINTER(C.c_uint64), C.POINTER(C.c_float), C.POINTER(C.c_int32),
+                              C.POINTER(C.c_uint16))
+_llp, _ullp, _szp, _intp = (C.POINTER(C.c_longlong), C.POINTER(C.c_ulonglong),
+                            C.POINTER(C.c_size_t), C.POINTER(C.c_int))
+_vp, _sz = C.c_void_p, C.c_size_t
+
+SIGNATURES = {
+    "ppk_last_error": (C.c_char_p, []),
+    "ppk_version": (C.c_char_p, []),
+    "ppk_device_count": (C.c_int, [_intp]),
+    "ppk_db_create": (C.c_int, [C.c_int, _vp, _sz, _sz, _sz, _sz, _vp, C.c_int, _vp,
+                                C.POINTER(_vp)]),
+    "ppk_db_destroy": (None, [_vp]),
+    "ppk_db_size": (_sz, [_vp]),
+    "ppk_rows_in_band": (_sz, [_sz, _sz, _sz, _sz]),
+    "ppk_band_split": (C.c_int, [_sz, _sz, C.c_int, _szp]),
+    "ppk_dist_dev": (C.c_int, [_vp, _vp, _i32p, _f32p, _sz, C.c_int, _sz, _sz, _vp, _vp, _vp]),
+    "ppk_dist_edges_dev": (C.c_int, [_vp, _vp, _i32p, _f32p, _sz, C.c_int, _sz, _sz, C.c_int,
+                                     C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, _vp,
+                                     _sz, _vp, _vp, _vp]),
+    "ppk_assign_threshold_dev": (C.c_int, [_vp, _sz, C.c_int, C.c_float, C.c_float, _vp, _vp]),
+    "ppk_edge_threshold_dev": (C.c_int, [_vp, _sz, _sz, C.c_int, C.c_float, C.c_float, C.c_int,
+                                         _vp, _sz, _vp, _vp]),
+    "ppk_generate_tuples_dev": (C.c_int, [_vp, _sz, C.c_int, C.c_int, _sz, C.c_longlong, _vp,
+                                          _sz, _vp, _vp]),
+    "ppk_query": (C.c_int, [_u64p, _sz, _u64p, _sz, _i32p, _sz, _sz, _sz, _f32p, _u16p, _u16p,
+                            _sz, C.c_int, _intp, C.c_int, _vp, _ullp]),
+    "ppk_assign_threshold": (C.c_int, [_f32p, _sz, C.c_int, C.c_float, C.c_float, C.c_int,
+                                       _f32p]),
+    "ppk_edge_threshold": (C.c_int, [_f32p, _sz, _sz, C.c_int, C.c_float, C.c_float, C.c_int,
+                                     C.c_int, _llp, _sz, _szp]),
+    "ppk_generate_tuples": (C.c_int, [_i32p, _sz, C.c_int, C.c_int, _sz, C.c_longlong, C.c_int,
+                                      _llp, _sz, _szp]),
+    "ppk_prof_enable": (C.c_int, [C.c_int]),
+    "ppk_prof_read": (C.c_int, [C.POINTER(C.c_double), _llp, C.c_int]),
+    "ppk_last_kernel_name": (C.c_char_p, []),
+    "ppk_set_tile": (C.c_int, [C.c_int, C.c_int]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libppk_hip.so; raises RuntimeError (never falls back) when it is unavailable."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError(
+                "poppunk_amd: HIP extension %s not built (run __graft_entry__.build() / "
+                "make -C poppunk_amd/csrc); there is no CPU fallback" % SO_PATH)
+        try:
+            handle = C.CDLL(SO_PATH)
+        except OSError as e:
+            raise RuntimeError("poppunk_amd: cannot load %s: %s" % (SO_PATH, e))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)      # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def last_error():
+    return lib().ppk_last_error().decode("utf-8", "replace")
+
+
+def check(rc, what="ppk call"):
+    """C status -> RuntimeError, as pybind11 turns std::runtime_error into RuntimeError
+    (src/python_bindings.cpp:54-56)."""
+    if rc != OK:
+        raise RuntimeError("%s failed (%d): %s" % (what, rc, last_error()))

@@ -1,0 +1,651 @@
+// C-ABI entry points of libppk_hip.so (declared in include/ppk.h).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "ppk_internal.h"
+
+// launchers defined in ppk_dist.hip
+int ppk_launch_transpose(const uint64_t *d_in, uint64_t *d_out, size_t n, size_t cols, size_t npad,
+                         hipStream_t s);
+int ppk_launch_dist(const ppk_db *ref, const ppk_db *qry_or_null, const int32_t *kmers,
+                    const float *d_rtab, size_t n_clu, int flags, size_t q_begin, size_t q_end,
+                    void *d_out, unsigned long long *d_n_failed, uint64_t *d_mask, int slope,
+                    float x_max, float y_max, float scale_x, float scale_y, int inclusive,
+                    double *d_lut, hipStream_t s);
+
+// ---- errors ---------------------------------------------------------------
+static thread_local std::string g_err;
+void ppk_set_error(const std::string &msg) { g_err = msg; }
+int ppk_fail(int code, const std::string &msg) {
+  g_err = msg;
+  return code;
+}
+extern "C" const char *ppk_last_error(void) { return g_err.c_str(); }
+extern "C" const char *ppk_version(void) { return "poppunk_amd 0.1.0 (gfx950)"; }
+
+extern "C" int ppk_device_count(int *n) {
+  if (!n) return ppk_fail(PPK_ERR_ARG, "n is NULL");
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) {
+    *n = 0;
+    return ppk_fail(PPK_ERR_HIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+  }
+  *n = c;
+  return PPK_OK;
+}
+
+// ---- profiling hooks ---------------------------------------------------------
+namespace {
+struct Prof {
+  std::mutex mu;
+  bool on = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  hipEvent_t cur_start = nullptr;
+  double total_ms = 0.0;
+  long long launches = 0;
+  std::string kernel_name;
+} g_prof;
+
+void prof_fold_locked() {
+  for (auto &pr : g_prof.pending) {
+    float ms = 0.0f;
+    if (hipEventSynchronize(pr.second) == hipSuccess &&
+        hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+      g_prof.total_ms += ms;
+      g_prof.launches += 1;
+    }
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
+  g_prof.pending.clear();
+}
+}  // namespace
+
+void ppk_set_kernel_name(const char *name) {
+  std::lock_guard<std::mutex> lk(g_prof.mu);
+  g_prof.kernel_name = name;
+}
+
+void ppk_prof_begin(hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_prof.mu);
+  if (!g_prof.on) return;
+  if (g_prof.pending.size() >= 512) prof_fold_locked();
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return;
+  (void)hipEventRecord(e, s);
+  g_prof.cur_start = e;
+}
+
+void ppk_prof_end(hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_prof.mu);
+  if (!g_prof.on || !g_prof.cur_start) return;
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return;
+  (void)hipEventRecord(e, s);
+  g_prof.pending.emplace_back(g_prof.cur_start, e);
+  g_prof.cur_start = nullptr;
+}
+
+extern "C" int ppk_prof_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_prof.mu);
+  g_prof.on = on != 0;
+  return PPK_OK;
+}
+
+extern "C" int ppk_prof_read(double *total_ms, long long *n_launches, int reset) {
+  std::lock_guard<std::mutex> lk(g_prof.mu);
+  prof_fold_locked();
+  if (total_ms) *total_ms = g_prof.total_ms;
+  if (n_launches) *n_launches = g_prof.launches;
+  if (reset) {
+    g_prof.total_ms = 0.0;
+    g_prof.launches = 0;
+  }
+  return PPK_OK;
+}
+
+extern "C" const char *ppk_last_kernel_name(void) {
+  static thread_local std::string copy;
+  std::lock_guard<std::mutex> lk(g_prof.mu);
+  copy = g_prof.kernel_name;
+  return copy.c_str();
+}
+
+// ---- geometry helpers -----------------------------------------------------------
+static inline size_t row_start_self(size_t q, size_t n) { return q * n - (q * (q + 1)) / 2; }
+
+extern "C" size_t ppk_rows_in_band(size_t n_ref, size_t n_qry, size_t q_begin, size_t q_end) {
+  if (q_end <= q_begin) return 0;
+  if (n_qry == 0) {
+    if (q_end > n_ref) q_end = n_ref;
+    if (q_begin >= q_end) return 0;
+    return row_start_self(q_end, n_ref) - row_start_self(q_begin, n_ref);
+  }
+  if (q_end > n_qry) q_end = n_qry;
+  if (q_begin >= q_end) return 0;
+  return (q_end - q_begin) * n_ref;
+}
+
+extern "C" int ppk_band_split(size_t n_ref, size_t n_qry, int n_parts, size_t *bounds) {
+  if (n_parts < 1 || !bounds) return ppk_fail(PPK_ERR_ARG, "bad band split arguments");
+  const size_t nq = n_qry ? n_qry : n_ref;
+  const size_t total = ppk_rows_in_band(n_ref, n_qry, 0, nq);
+  bounds[0] = 0;
+  for (int p = 1; p < n_parts; ++p) {
+    const double target = (double)total * (double)p / (double)n_parts;
+    size_t q;
+    if (n_qry == 0) {
+      // rows before q: q*n - q(q+1)/2 = target  ->  q = ((2n-1) - sqrt((2n-1)^2 - 8 target)) / 2
+      const double b = 2.0 * (double)n_ref - 1.0;
+      const double disc = b * b - 8.0 * target;
+      q = (size_t)((b - std::sqrt(disc > 0 ? disc : 0.0)) / 2.0);
+    } else {
+      q = (size_t)(target / (double)n_ref);
+    }
+    q = (q + 32) / 64 * 64;  // band edges on 64-query tile boundaries
+    if (q > nq) q = nq;
+    if (q < bounds[p - 1]) q = bounds[p - 1];
+    bounds[p] = q;
+  }
+  bounds[n_parts] = nq;
+  return PPK_OK;
+}
+
+// ---- resident sketch database --------------------------------------------------
+extern "C" int ppk_db_create(int device_id, const uint64_t *sk, size_t n, size_t nk,
+                             size_t sketchsize64, size_t bbits, const uint16_t *clu,
+                             int src_on_device, void *stream, ppk_db **out) {
+  if (!out) return ppk_fail(PPK_ERR_ARG, "out is NULL");
+  *out = nullptr;
+  if (!sk || n == 0 || nk == 0 || sketchsize64 == 0 || bbits == 0 || bbits > 64)
+    return ppk_fail(PPK_ERR_ARG, "ppk_db_create: empty or invalid sketch dimensions");
+  if (sketchsize64 * 64 >= ((size_t)1 << 31))
+    return ppk_fail(PPK_ERR_ARG, "ppk_db_create: sketch too large");
+  DeviceGuard guard(device_id);
+  if (!guard.ok) return ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(device_id));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+
+  ppk_db *db = new ppk_db();
+  db->device = device_id;
+  db->n = n;
+  db->npad = (n + PPK_NPAD - 1) / PPK_NPAD * PPK_NPAD;
+  db->nk = nk;
+  db->s64 = sketchsize64;
+  db->bbits = bbits;
+  db->words = sketchsize64 * bbits;
+  db->d_skT = nullptr;
+  db->d_clu = nullptr;
+  const size_t cols = nk * db->words;
+  const size_t in_bytes = n * cols * sizeof(uint64_t);
+  const size_t out_bytes = db->npad * cols * sizeof(uint64_t);
+
+  auto bail = [&](int code, const std::string &msg) {
+    if (db->d_skT) (void)hipFree(db->d_skT);
+    if (db->d_clu) (void)hipFree(db->d_clu);
+    delete db;
+    return ppk_fail(code, msg);
+  };
+  hipError_t e = hipMalloc(reinterpret_cast<void **>(&db->d_skT), out_bytes);
+  if (e != hipSuccess) return bail(PPK_ERR_HIP, std::string("hipMalloc(sketches): ") + hipGetErrorString(e));
+
+  const uint64_t *d_in = sk;
+  uint64_t *d_stage = nullptr;
+  if (!src_on_device) {
+    e = hipMalloc(reinterpret_cast<void **>(&d_stage), in_bytes);
+    if (e != hipSuccess) return bail(PPK_ERR_HIP, std::string("hipMalloc(stage): ") + hipGetErrorString(e));
+    e = hipMemcpyAsync(d_stage, sk, in_bytes, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) {
+      (void)hipFree(d_stage);
+      return bail(PPK_ERR_HIP, std::string("hipMemcpy(sketches): ") + hipGetErrorString(e));
+    }
+    d_in = d_stage;
+  }
+  int rc = ppk_launch_transpose(d_in, db->d_skT, n, cols, db->npad, s);
+  if (rc == PPK_OK && clu) {
+    e = hipMalloc(reinterpret_cast<void **>(&db->d_clu), db->npad * sizeof(uint16_t));
+    if (e == hipSuccess) e = hipMemsetAsync(db->d_clu, 0, db->npad * sizeof(uint16_t), s);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(db->d_clu, clu, n * sizeof(uint16_t),
+                         src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) rc = PPK_ERR_HIP;
+  }
+  // the staging copy must outlive the transpose; the host-source path blocks here
+  if (d_stage) {
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(d_stage);
+  }
+  if (rc != PPK_OK) return bail(rc, std::string("ppk_db_create failed: ") + g_err);
+  *out = db;
+  return PPK_OK;
+}
+
+extern "C" void ppk_db_destroy(ppk_db *db) {
+  if (!db) return;
+  DeviceGuard guard(db->device);
+  if (db->d_skT) (void)hipFree(db->d_skT);
+  if (db->d_clu) (void)hipFree(db->d_clu);
+  delete db;
+}
+
+extern "C" size_t ppk_db_size(const ppk_db *db) { return db ? db->n : 0; }
+
+// ---- kernel 1, device entry points -------------------------------------------------
+namespace {
+
+int check_pair(const ppk_db *ref, const ppk_db *qry, const int32_t *kmers, size_t q_begin,
+               size_t q_end) {
+  if (!ref || !kmers) return ppk_fail(PPK_ERR_ARG, "ref database / kmers missing");
+  if (qry) {
+    if (qry->device != ref->device) return ppk_fail(PPK_ERR_ARG, "ref and query databases on different devices");
+    if (qry->nk != ref->nk || qry->s64 != ref->s64 || qry->bbits != ref->bbits)
+      return ppk_fail(PPK_ERR_ARG, "ref and query sketches have different k-mer lists or sketch sizes");
+  }
+  const size_t nq = qry ? qry->n : ref->n;
+  if (q_begin > q_end || q_end > nq) return ppk_fail(PPK_ERR_ARG, "query band out of range");
+  return PPK_OK;
+}
+
+// Scratch that must live until the enqueued work is done: freed with
+// hipFreeAsync-like semantics by parking it on the stream via a host callback
+// would cost a thread hop; device entry points instead keep one grow-only
+// scratch per device (single-threaded use per device, like the reference's
+// one-call-at-a-time binding).
+struct Scratch {
+  void *p = nullptr;
+  size_t bytes = 0;
+};
+Scratch g_scratch[64][3];  // [device][slot]
+
+int scratch_get(int dev, int slot, size_t bytes, void **out) {
+  if (dev < 0 || dev >= 64) return ppk_fail(PPK_ERR_ARG, "device id out of range");
+  Scratch &s = g_scratch[dev][slot];
+  if (s.bytes < bytes) {
+    if (s.p) {
+      (void)hipDeviceSynchronize();  // earlier launches may still read the old block
+      (void)hipFree(s.p);
+      s.p = nullptr;
+      s.bytes = 0;
+    }
+    const size_t want = bytes + bytes / 4 + 4096;
+    hipError_t e = hipMalloc(&s.p, want);
+    if (e != hipSuccess) return ppk_fail(PPK_ERR_HIP, std::string("hipMalloc(scratch): ") + hipGetErrorString(e));
+    s.bytes = want;
+  }
+  *out = s.p;
+  return PPK_OK;
+}
+
+enum { SLOT_LUT = 0, SLOT_MASK = 1, SLOT_WS = 2 };
+
+// random table (host) -> device copy placed after the LUT in the LUT scratch
+int stage_tables(const ppk_db *ref, const float *random_tbl, size_t n_clu, int flags, hipStream_t s,
+                 double **d_lut, float **d_rtab) {
+  const size_t nbins = ref->s64 * 64;
+  const size_t C = n_clu ? n_clu : 1;
+  const size_t lut_bytes = C * C * ref->nk * (nbins + 1) * sizeof(double);
+  const size_t tab_bytes = C * C * ref->nk * sizeof(float);
+  void *base = nullptr;
+  int rc = scratch_get(ref->device, SLOT_LUT, lut_bytes + tab_bytes + 256, &base);
+  if (rc != PPK_OK) return rc;
+  *d_lut = static_cast<double *>(base);
+  *d_rtab = nullptr;
+  if ((flags & PPK_FLAG_RANDOM_CORRECT) && random_tbl) {
+    float *t = reinterpret_cast<float *>(static_cast<char *>(base) + ((lut_bytes + 255) / 256) * 256);
+    PPK_HIP(hipMemcpyAsync(t, random_tbl, tab_bytes, hipMemcpyHostToDevice, s));
+    *d_rtab = t;
+  }
+  return PPK_OK;
+}
+
+}  // namespace
+
+extern "C" int ppk_dist_dev(const ppk_db *ref, const ppk_db *qry, const int32_t *kmers,
+                            const float *random_tbl, size_t n_clu, int flags, size_t q_begin,
+                            size_t q_end, void *d_out, unsigned long long *d_n_failed,
+                            void *stream) {
+  int rc = check_pair(ref, qry, kmers, q_begin, q_end);
+  if (rc != PPK_OK) return rc;
+  if (q_begin == q_end) return PPK_OK;
+  if (!d_out) return ppk_fail(PPK_ERR_ARG, "d_out is NULL");
+  DeviceGuard guard(ref->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  double *d_lut = nullptr;
+  float *d_rtab = nullptr;
+  rc = stage_tables(ref, random_tbl, n_clu, flags, s, &d_lut, &d_rtab);
+  if (rc != PPK_OK) return rc;
+  return ppk_launch_dist(ref, qry, kmers, d_rtab, d_rtab ? n_clu : 1, flags, q_begin, q_end, d_out,
+                         d_n_failed, nullptr, 2, 0.f, 0.f, 1.f, 1.f, 1, d_lut, s);
+}
+
+extern "C" int ppk_dist_edges_dev(const ppk_db *ref, const ppk_db *qry, const int32_t *kmers,
+                                  const float *random_tbl, size_t n_clu, int flags, size_t q_begin,
+                                  size_t q_end, int slope, float x_max, float y_max, float scale_x,
+                                  float scale_y, int inclusive, long long *d_edges, size_t cap,
+                                  unsigned long long *d_n_edges, unsigned long long *d_n_failed,
+                                  void *stream) {
+  int rc = check_pair(ref, qry, kmers, q_begin, q_end);
+  if (rc != PPK_OK) return rc;
+  if (!d_n_edges) return ppk_fail(PPK_ERR_ARG, "d_n_edges is NULL");
+  if (slope < 0 || slope > 2) return ppk_fail(PPK_ERR_ARG, "slope must be 0, 1 or 2");
+  if (flags & (PPK_FLAG_JACCARD | PPK_FLAG_COUNTS))
+    return ppk_fail(PPK_ERR_ARG, "edge output excludes the jaccard/counts flags");
+  DeviceGuard guard(ref->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (q_begin == q_end) {
+    PPK_HIP(hipMemsetAsync(d_n_edges, 0, sizeof(unsigned long long), s));
+    return PPK_OK;
+  }
+  double *d_lut = nullptr;
+  float *d_rtab = nullptr;
+  rc = stage_tables(ref, random_tbl, n_clu, flags, s, &d_lut, &d_rtab);
+  if (rc != PPK_OK) return rc;
+  const size_t n_rtiles = (ref->n + 63) / 64;
+  const size_t n_words = (q_end - q_begin) * n_rtiles;
+  void *d_mask = nullptr, *d_ws = nullptr;
+  rc = scratch_get(ref->device, SLOT_MASK, n_words * sizeof(uint64_t), &d_mask);
+  if (rc != PPK_OK) return rc;
+  rc = scratch_get(ref->device, SLOT_WS, ppk_compact_ws_bytes(n_words), &d_ws);
+  if (rc != PPK_OK) return rc;
+  PPK_HIP(hipMemsetAsync(d_mask, 0, n_words * sizeof(uint64_t), s));
+  rc = ppk_launch_dist(ref, qry, kmers, d_rtab, d_rtab ? n_clu : 1, flags, q_begin, q_end, nullptr,
+                       d_n_failed, static_cast<uint64_t *>(d_mask), slope, x_max, y_max, scale_x,
+                       scale_y, inclusive, d_lut, s);
+  if (rc != PPK_OK) return rc;
+  EdgeGeom g = {};
+  g.layout = qry ? EDGE_TILED_NONSELF : EDGE_TILED_SELF;
+  g.n_ref = ref->n;
+  g.q_begin = q_begin;
+  g.n_rtiles = n_rtiles;
+  g.int_offset = 0;
+  return ppk_launch_compact(static_cast<const uint64_t *>(d_mask), n_words, g, d_ws, d_edges, cap,
+                            d_n_edges, s);
+}
+
+// ---- kernel 2, device entry points -------------------------------------------------
+extern "C" int ppk_assign_threshold_dev(const float *d_dist, size_t n_rows, int slope, float x_max,
+                                        float y_max, float *d_out, void *stream) {
+  if (slope < 0 || slope > 2) return ppk_fail(PPK_ERR_ARG, "slope must be 0, 1 or 2");
+  if (n_rows && (!d_dist || !d_out)) return ppk_fail(PPK_ERR_ARG, "NULL distance/output buffer");
+  return ppk_launch_assign(d_dist, n_rows, slope, x_max, y_max, d_out, static_cast<hipStream_t>(stream));
+}
+
+static size_t samples_of_rows(size_t n_rows) {
+  size_t n = (size_t)(0.5 * (1.0 + std::sqrt(1.0 + 8.0 * (double)n_rows)));
+  while (n > 1 && n * (n - 1) / 2 > n_rows) --n;
+  while ((n + 1) * n / 2 <= n_rows) ++n;
+  return n;
+}
+
+static int edges_from_mask(int dev, size_t n_rows, const EdgeGeom &g, uint64_t *d_mask,
+                           long long *d_edges, size_t cap, unsigned long long *d_n_edges,
+                           hipStream_t s) {
+  void *d_ws = nullptr;
+  const size_t n_words = ppk_mask_words_linear(n_rows);
+  int rc = scratch_get(dev, SLOT_WS, ppk_compact_ws_bytes(n_words), &d_ws);
+  if (rc != PPK_OK) return rc;
+  return ppk_launch_compact(d_mask, n_words, g, d_ws, d_edges, cap, d_n_edges, s);
+}
+
+extern "C" int ppk_edge_threshold_dev(const float *d_dist, size_t n_rows, size_t n_ref, int slope,
+                                      float x_max, float y_max, int inclusive, long long *d_edges,
+                                      size_t cap, unsigned long long *d_n_edges, void *stream) {
+  if (slope < 0 || slope > 2) return ppk_fail(PPK_ERR_ARG, "slope must be 0, 1 or 2");
+  if (!d_n_edges) return ppk_fail(PPK_ERR_ARG, "d_n_edges is NULL");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int dev = 0;
+  PPK_HIP(hipGetDevice(&dev));
+  EdgeGeom g = {};
+  g.n_rows = n_rows;
+  if (n_ref == 0) {
+    g.layout = EDGE_LINEAR_SELF;
+    g.n_samples = samples_of_rows(n_rows);
+    if (g.n_samples * (g.n_samples - 1) / 2 != n_rows)
+      return ppk_fail(PPK_ERR_ARG, "row count is not n(n-1)/2 for any n (self/condensed matrix expected)");
+  } else {
+    g.layout = EDGE_LINEAR_NONSELF;
+    g.n_ref = n_ref;
+    if (n_rows % n_ref) return ppk_fail(PPK_ERR_ARG, "row count is not a multiple of n_ref");
+  }
+  void *d_mask = nullptr;
+  int rc = scratch_get(dev, SLOT_MASK, ppk_mask_words_linear(n_rows) * sizeof(uint64_t) + 8, &d_mask);
+  if (rc != PPK_OK) return rc;
+  rc = ppk_launch_mask_from_dist(d_dist, n_rows, slope, x_max, y_max, inclusive,
+                                 static_cast<uint64_t *>(d_mask), s);
+  if (rc != PPK_OK) return rc;
+  return edges_from_mask(dev, n_rows, g, static_cast<uint64_t *>(d_mask), d_edges, cap, d_n_edges, s);
+}
+
+extern "C" int ppk_generate_tuples_dev(const int32_t *d_assign, size_t n_rows, int within_label,
+                                       int self, size_t num_ref, long long int_offset,
+                                       long long *d_edges, size_t cap,
+                                       unsigned long long *d_n_edges, void *stream) {
+  if (!d_n_edges) return ppk_fail(PPK_ERR_ARG, "d_n_edges is NULL");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int dev = 0;
+  PPK_HIP(hipGetDevice(&dev));
+  EdgeGeom g = {};
+  g.n_rows = n_rows;
+  g.int_offset = int_offset;
+  if (self) {
+    g.layout = EDGE_LINEAR_SELF;
+    // src/boundary.cpp:104 derives n from the row count the same way
+    g.n_samples = samples_of_rows(n_rows);
+  } else {
+    if (num_ref == 0) return ppk_fail(PPK_ERR_ARG, "num_ref must be > 0 when self is false");
+    g.layout = EDGE_LINEAR_NONSELF;
+    g.n_ref = num_ref;
+  }
+  void *d_mask = nullptr;
+  int rc = scratch_get(dev, SLOT_MASK, ppk_mask_words_linear(n_rows) * sizeof(uint64_t) + 8, &d_mask);
+  if (rc != PPK_OK) return rc;
+  rc = ppk_launch_mask_from_assign(d_assign, n_rows, within_label, static_cast<uint64_t *>(d_mask), s);
+  if (rc != PPK_OK) return rc;
+  return edges_from_mask(dev, n_rows, g, static_cast<uint64_t *>(d_mask), d_edges, cap, d_n_edges, s);
+}
+
+// ---- host-buffer wrappers -------------------------------------------------------------
+extern "C" int ppk_query(const uint64_t *ref_sk, size_t n_ref, const uint64_t *qry_sk, size_t n_qry,
+                         const int32_t *kmers, size_t nk, size_t sketchsize64, size_t bbits,
+                         const float *random_tbl, const uint16_t *ref_clu, const uint16_t *qry_clu,
+                         size_t n_clu, int flags, const int *devices, int n_dev, void *out,
+                         unsigned long long *n_failed) {
+  if (n_failed) *n_failed = 0;
+  if (!ref_sk || !kmers || !out || n_ref == 0 || nk == 0)
+    return ppk_fail(PPK_ERR_ARG, "ppk_query: missing sketches / kmers / output");
+  if (n_qry && !qry_sk) return ppk_fail(PPK_ERR_ARG, "ppk_query: n_qry > 0 but no query sketches");
+  const int default_dev = 0;
+  if (!devices || n_dev < 1) {
+    devices = &default_dev;
+    n_dev = 1;
+  }
+  const bool self = (n_qry == 0);
+  const size_t nq = self ? n_ref : n_qry;
+  const size_t cols = (flags & (PPK_FLAG_JACCARD | PPK_FLAG_COUNTS)) ? nk : 2;
+  if (ppk_rows_in_band(n_ref, n_qry, 0, nq) == 0) return PPK_OK;  // a single self sample: no pairs
+
+  std::vector<size_t> bounds(n_dev + 1);
+  int rc = ppk_band_split(n_ref, n_qry, n_dev, bounds.data());
+  if (rc != PPK_OK) return rc;
+
+  struct Part {
+    ppk_db *ref = nullptr, *qry = nullptr;
+    void *d_out = nullptr;
+    unsigned long long *d_failed = nullptr;
+    hipStream_t s = nullptr;
+    size_t rows = 0, row0 = 0;
+  };
+  std::vector<Part> parts(n_dev);
+  auto cleanup = [&]() {
+    for (int d = 0; d < n_dev; ++d) {
+      Part &p = parts[d];
+      DeviceGuard g(devices[d]);
+      if (p.s) (void)hipStreamSynchronize(p.s);
+      if (p.d_out) (void)hipFree(p.d_out);
+      if (p.d_failed) (void)hipFree(p.d_failed);
+      if (p.ref) ppk_db_destroy(p.ref);
+      if (p.qry) ppk_db_destroy(p.qry);
+      if (p.s) (void)hipStreamDestroy(p.s);
+    }
+  };
+  size_t row0 = 0;
+  for (int d = 0; d < n_dev && rc == PPK_OK; ++d) {
+    Part &p = parts[d];
+    p.rows = ppk_rows_in_band(n_ref, n_qry, bounds[d], bounds[d + 1]);
+    p.row0 = row0;
+    row0 += p.rows;
+    if (p.rows == 0) continue;
+    DeviceGuard g(devices[d]);
+    if (!g.ok) {
+      rc = ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(devices[d]));
+      break;
+    }
+    if (hipStreamCreate(&p.s) != hipSuccess) {
+      rc = ppk_fail(PPK_ERR_HIP, "hipStreamCreate failed");
+      break;
+    }
+    rc = ppk_db_create(devices[d], ref_sk, n_ref, nk, sketchsize64, bbits, ref_clu, 0, p.s, &p.ref);
+    if (rc == PPK_OK && !self)
+      rc = ppk_db_create(devices[d], qry_sk, n_qry, nk, sketchsize64, bbits, qry_clu, 0, p.s, &p.qry);
+    if (rc != PPK_OK) break;
+    if (hipMalloc(&p.d_out, p.rows * cols * 4) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&p.d_failed), sizeof(unsigned long long)) != hipSuccess) {
+      rc = ppk_fail(PPK_ERR_HIP, "hipMalloc(output) failed");
+      break;
+    }
+    (void)hipMemsetAsync(p.d_failed, 0, sizeof(unsigned long long), p.s);
+    rc = ppk_dist_dev(p.ref, p.qry, kmers, random_tbl, n_clu, flags, bounds[d], bounds[d + 1],
+                      p.d_out, p.d_failed, p.s);
+    if (rc != PPK_OK) break;
+    if (hipMemcpyAsync(static_cast<char *>(out) + p.row0 * cols * 4, p.d_out, p.rows * cols * 4,
+                       hipMemcpyDeviceToHost, p.s) != hipSuccess) {
+      rc = ppk_fail(PPK_ERR_HIP, "hipMemcpy(output) failed");
+      break;
+    }
+  }
+  if (rc == PPK_OK) {
+    for (int d = 0; d < n_dev; ++d) {
+      Part &p = parts[d];
+      if (!p.s) continue;
+      DeviceGuard g(devices[d]);
+      hipError_t e = hipStreamSynchronize(p.s);
+      if (e != hipSuccess) {
+        rc = ppk_fail(PPK_ERR_HIP, std::string("kernel execution failed: ") + hipGetErrorString(e));
+        break;
+      }
+      unsigned long long f = 0;
+      if (hipMemcpy(&f, p.d_failed, sizeof(f), hipMemcpyDeviceToHost) == hipSuccess && n_failed)
+        *n_failed += f;
+    }
+  }
+  const std::string keep = g_err;
+  cleanup();
+  if (rc != PPK_OK) g_err = keep;
+  return rc;
+}
+
+extern "C" int ppk_assign_threshold(const float *dist, size_t n_rows, int slope, float x_max,
+                                    float y_max, int device_id, float *out) {
+  if (n_rows == 0) return PPK_OK;
+  if (!dist || !out) return ppk_fail(PPK_ERR_ARG, "NULL distance/output buffer");
+  DeviceGuard guard(device_id);
+  if (!guard.ok) return ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(device_id));
+  float *d_dist = nullptr, *d_out = nullptr;
+  PPK_HIP(hipMalloc(reinterpret_cast<void **>(&d_dist), n_rows * 8));
+  if (hipMalloc(reinterpret_cast<void **>(&d_out), n_rows * 4) != hipSuccess) {
+    (void)hipFree(d_dist);
+    return ppk_fail(PPK_ERR_HIP, "hipMalloc failed");
+  }
+  int rc = PPK_OK;
+  if (hipMemcpy(d_dist, dist, n_rows * 8, hipMemcpyHostToDevice) != hipSuccess)
+    rc = ppk_fail(PPK_ERR_HIP, "hipMemcpy H2D failed");
+  if (rc == PPK_OK) rc = ppk_assign_threshold_dev(d_dist, n_rows, slope, x_max, y_max, d_out, nullptr);
+  if (rc == PPK_OK && hipMemcpy(out, d_out, n_rows * 4, hipMemcpyDeviceToHost) != hipSuccess)
+    rc = ppk_fail(PPK_ERR_HIP, "hipMemcpy D2H failed");
+  (void)hipFree(d_dist);
+  (void)hipFree(d_out);
+  return rc;
+}
+
+namespace {
+// Shared tail of the host edge wrappers: run `enqueue` twice at most -- the
+// edge count is data dependent, so first with cap 0 (count only), then, if the
+// caller's buffer is big enough, again into a device buffer of exactly that size.
+template <typename F>
+int host_edges(int device_id, long long *ij_out, size_t cap, size_t *n_edges, F enqueue) {
+  if (!n_edges) return ppk_fail(PPK_ERR_ARG, "n_edges is NULL");
+  unsigned long long *d_n = nullptr;
+  PPK_HIP(hipMalloc(reinterpret_cast<void **>(&d_n), sizeof(unsigned long long)));
+  int rc = enqueue(nullptr, 0, d_n);
+  unsigned long long n = 0;
+  if (rc == PPK_OK && hipMemcpy(&n, d_n, sizeof(n), hipMemcpyDeviceToHost) != hipSuccess)
+    rc = ppk_fail(PPK_ERR_HIP, "hipMemcpy D2H failed");
+  if (rc == PPK_OK) {
+    *n_edges = (size_t)n;
+    if (n > cap) {
+      rc = ppk_fail(PPK_ERR_CAPACITY, "edge buffer too small: need " + std::to_string(n));
+    } else if (n > 0) {
+      if (!ij_out) rc = ppk_fail(PPK_ERR_ARG, "ij_out is NULL");
+      long long *d_e = nullptr;
+      if (rc == PPK_OK && hipMalloc(reinterpret_cast<void **>(&d_e), n * 16) != hipSuccess)
+        rc = ppk_fail(PPK_ERR_HIP, "hipMalloc(edges) failed");
+      if (rc == PPK_OK) rc = enqueue(d_e, (size_t)n, d_n);
+      if (rc == PPK_OK && hipMemcpy(ij_out, d_e, n * 16, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = ppk_fail(PPK_ERR_HIP, "hipMemcpy D2H failed");
+      if (d_e) (void)hipFree(d_e);
+    }
+  }
+  (void)hipFree(d_n);
+  (void)device_id;
+  return rc;
+}
+}  // namespace
+
+extern "C" int ppk_edge_threshold(const float *dist, size_t n_rows, size_t n_ref, int slope,
+                                  float x_max, float y_max, int inclusive, int device_id,
+                                  long long *ij_out, size_t cap, size_t *n_edges) {
+  if (n_edges) *n_edges = 0;
+  if (n_rows == 0) return PPK_OK;
+  if (!dist) return ppk_fail(PPK_ERR_ARG, "dist is NULL");
+  DeviceGuard guard(device_id);
+  if (!guard.ok) return ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(device_id));
+  float *d_dist = nullptr;
+  PPK_HIP(hipMalloc(reinterpret_cast<void **>(&d_dist), n_rows * 8));
+  int rc = PPK_OK;
+  if (hipMemcpy(d_dist, dist, n_rows * 8, hipMemcpyHostToDevice) != hipSuccess)
+    rc = ppk_fail(PPK_ERR_HIP, "hipMemcpy H2D failed");
+  if (rc == PPK_OK)
+    rc = host_edges(device_id, ij_out, cap, n_edges,
+                    [&](long long *d_e, size_t c, unsigned long long *d_n) {
+                      return ppk_edge_threshold_dev(d_dist, n_rows, n_ref, slope, x_max, y_max,
+                                                    inclusive, d_e, c, d_n, nullptr);
+                    });
+  (void)hipFree(d_dist);
+  return rc;
+}
+
+extern "C" int ppk_generate_tuples(const int32_t *assignments, size_t n_rows, int within_label,
+                                   int self, size_t num_ref, long long int_offset, int device_id,
+                                   long long *ij_out, size_t cap, size_t *n_edges) {
+  if (n_edges) *n_edges = 0;
+  if (n_rows == 0) return PPK_OK;
+  if (!assignments) return ppk_fail(PPK_ERR_ARG, "assignments is NULL");
+  DeviceGuard guard(device_id);
+  if (!guard.ok) return ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(device_id));
+  int32_t *d_a = nullptr;
+  PPK_HIP(hipMalloc(reinterpret_cast<void **>(&d_a), n_rows * 4));
+  int rc = PPK_OK;
+  if (hipMemcpy(d_a, assignments, n_rows * 4, hipMemcpyHostToDevice) != hipSuccess)
+    rc = ppk_fail(PPK_ERR_HIP, "hipMemcpy H2D failed");
+  if (rc == PPK_OK)
+    rc = host_edges(device_id, ij_out, cap, n_edges,
+                    [&](long long *d_e, size_t c, unsigned long long *d_n) {
+                      return ppk_generate_tuples_dev(d_a, n_rows, within_label, self, num_ref,
+                                                     int_offset, d_e, c, d_n, nullptr);
+                    });
+  (void)hipFree(d_a);
+  return rc;
+}

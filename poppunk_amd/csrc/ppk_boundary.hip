@@ -1,0 +1,301 @@
+// Kernel 2: boundary assignment and edge-list compaction on gfx950.
+//
+//  - assign_kernel            : src/boundary.cpp:60-80  (assign_threshold)
+//  - mask_from_dist_kernel    : the predicate of src/boundary.cpp:82-95 (edge_iterate),
+//                               one wavefront __ballot -> one uint64 of 64 rows
+//  - mask_from_assign_kernel  : the predicate of src/boundary.cpp:97-123 (generate_tuples)
+//  - compaction (count / scan / expand): replaces the serial push_back loops;
+//    stable, so the edge list equals the reference's element for element.
+//
+// All of this is an HBM stream (8 B in + 4 B out per row for assign; 8 B in +
+// 1 bit out, then 16 B per edge, for edges); nothing here is MFMA work.
+#include "ppk_internal.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWordsPerThread = 8;
+constexpr int kWordsPerBlock = kBlock * kWordsPerThread;  // 2048 mask words = 131072 rows
+
+__global__ void __launch_bounds__(kBlock)
+assign_kernel(const float2 *__restrict__ dist, size_t n_rows, int slope, float x_max,
+              float y_max, float *__restrict__ out) {
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t row = (size_t)blockIdx.x * kBlock + threadIdx.x; row < n_rows; row += stride) {
+    const float2 d = dist[row];
+    const float s = ppk_line_dist(d.x, d.y, x_max, y_max, slope);
+    out[row] = (s == 0.0f) ? 0.0f : (s > 0.0f ? 1.0f : -1.0f);
+  }
+}
+
+// One wavefront covers 64 consecutive rows; its ballot IS the mask word.
+__global__ void __launch_bounds__(kBlock)
+mask_from_dist_kernel(const float2 *__restrict__ dist, size_t n_rows, int slope, float x_max,
+                      float y_max, int inclusive, uint64_t *__restrict__ mask, size_t n_words) {
+  const size_t wstride = (size_t)gridDim.x * (kBlock / 64);
+  const int lane = threadIdx.x & 63;
+  for (size_t w = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); w < n_words;
+       w += wstride) {
+    const size_t row = w * 64 + lane;
+    bool pred = false;
+    if (row < n_rows) {
+      const float2 d = dist[row];
+      const float s = ppk_line_dist(d.x, d.y, x_max, y_max, slope);
+      pred = inclusive ? (s <= 0.0f) : (s < 0.0f);
+    }
+    const uint64_t m = __ballot(pred);
+    if (lane == 0) mask[w] = m;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+mask_from_assign_kernel(const int32_t *__restrict__ assign, size_t n_rows, int within_label,
+                        uint64_t *__restrict__ mask, size_t n_words) {
+  const size_t wstride = (size_t)gridDim.x * (kBlock / 64);
+  const int lane = threadIdx.x & 63;
+  for (size_t w = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); w < n_words;
+       w += wstride) {
+    const size_t row = w * 64 + lane;
+    const bool pred = (row < n_rows) && (assign[row] == within_label);
+    const uint64_t m = __ballot(pred);
+    if (lane == 0) mask[w] = m;
+  }
+}
+
+__device__ __forceinline__ unsigned block_reduce_sum(unsigned v, unsigned *sh) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) sh[wave] = v;
+  __syncthreads();
+  unsigned t = 0;
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < kBlock / 64; ++i) t += sh[i];
+  }
+  return t;  // valid on thread 0
+}
+
+// Pass 1: set bits per block of kWordsPerBlock mask words.
+__global__ void __launch_bounds__(kBlock)
+mask_count_kernel(const uint64_t *__restrict__ mask, size_t n_words,
+                  unsigned long long *__restrict__ block_sums) {
+  __shared__ unsigned sh[kBlock / 64];
+  const size_t w0 = ((size_t)blockIdx.x * kBlock + threadIdx.x) * kWordsPerThread;
+  unsigned c = 0;
+#pragma unroll
+  for (int i = 0; i < kWordsPerThread; ++i) {
+    const size_t w = w0 + i;
+    if (w < n_words) c += __popcll(mask[w]);
+  }
+  const unsigned t = block_reduce_sum(c, sh);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = t;
+}
+
+// Pass 2: exclusive scan of the block sums by ONE workgroup (the array is
+// n_words/2048 long: 38k entries at 100k genomes), total -> *n_edges.
+__global__ void __launch_bounds__(1024)
+scan_block_sums_kernel(unsigned long long *__restrict__ block_sums, size_t n_blocks,
+                       unsigned long long *__restrict__ n_edges) {
+  __shared__ unsigned long long sh[1024];
+  const size_t per = (n_blocks + 1023) / 1024;
+  const size_t b0 = (size_t)threadIdx.x * per;
+  const size_t b1 = b0 + per < n_blocks ? b0 + per : n_blocks;
+  unsigned long long s = 0;
+  for (size_t b = b0; b < b1; ++b) s += block_sums[b];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  // Hillis-Steele inclusive scan over 1024 partials
+  for (int o = 1; o < 1024; o <<= 1) {
+    unsigned long long v = (threadIdx.x >= (unsigned)o) ? sh[threadIdx.x - o] : 0ull;
+    __syncthreads();
+    sh[threadIdx.x] += v;
+    __syncthreads();
+  }
+  unsigned long long run = (threadIdx.x == 0) ? 0ull : sh[threadIdx.x - 1];
+  for (size_t b = b0; b < b1; ++b) {
+    const unsigned long long v = block_sums[b];
+    block_sums[b] = run;
+    run += v;
+  }
+  if (threadIdx.x == 1023) *n_edges = sh[1023];
+}
+
+__device__ __forceinline__ size_t cond_row_start(size_t i, size_t n) {
+  return i * n - (i * (i + 1)) / 2;
+}
+
+// (i, j) of condensed row k (src/boundary.cpp:22-31): double sqrt estimate,
+// then an integer fix-up so the result is exact for every n.
+__device__ __forceinline__ size_t cond_row_idx(size_t k, size_t n) {
+  const double d = sqrt((double)(4 * n * (n - 1)) - 8.0 * (double)k - 7.0);
+  long long i = (long long)n - 2 - (long long)floor(d / 2.0 - 0.5);
+  if (i < 0) i = 0;
+  if (i > (long long)n - 2) i = (long long)n - 2;
+  while (i > 0 && cond_row_start((size_t)i, n) > k) --i;
+  while ((size_t)i + 2 < n && cond_row_start((size_t)i + 1, n) <= k) ++i;
+  return (size_t)i;
+}
+
+// Pass 3: every thread re-counts its 8 words, a block-level exclusive scan gives
+// its output offset, and it writes one (i,j) per set bit -- in row order.
+__global__ void __launch_bounds__(kBlock)
+mask_expand_kernel(const uint64_t *__restrict__ mask, size_t n_words,
+                   const unsigned long long *__restrict__ block_offsets, EdgeGeom g,
+                   longlong2 *__restrict__ edges, size_t cap) {
+  __shared__ unsigned sh_wave[kBlock / 64];
+  const size_t w0 = ((size_t)blockIdx.x * kBlock + threadIdx.x) * kWordsPerThread;
+  uint64_t m[kWordsPerThread];
+  unsigned c = 0;
+#pragma unroll
+  for (int i = 0; i < kWordsPerThread; ++i) {
+    const size_t w = w0 + i;
+    m[i] = (w < n_words) ? mask[w] : 0ull;
+    c += __popcll(m[i]);
+  }
+  // exclusive scan of c over the block: wave scan + wave totals
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned inc = c;
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned v = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += v;
+  }
+  if (lane == 63) sh_wave[wave] = inc;
+  __syncthreads();
+  unsigned wave_off = 0;
+  for (int i = 0; i < wave; ++i) wave_off += sh_wave[i];
+  size_t pos = (size_t)block_offsets[blockIdx.x] + wave_off + (inc - c);
+  if (c == 0) return;
+
+#pragma unroll
+  for (int i = 0; i < kWordsPerThread; ++i) {
+    uint64_t bits = m[i];
+    if (!bits) continue;
+    const size_t w = w0 + i;
+    if (g.layout == EDGE_LINEAR_SELF) {
+      const size_t n = g.n_samples;
+      const size_t row0 = w * 64;
+      size_t ii = cond_row_idx(row0, n);
+      size_t rs = cond_row_start(ii, n);
+      while (bits) {
+        const int t = __builtin_ctzll(bits);
+        bits &= bits - 1;
+        const size_t row = row0 + t;
+        while (row >= rs + (n - 1 - ii)) {
+          rs += n - 1 - ii;
+          ++ii;
+        }
+        if (pos < cap) {
+          longlong2 e;
+          e.x = (long long)ii + g.int_offset;
+          e.y = (long long)(ii + 1 + (row - rs)) + g.int_offset;
+          edges[pos] = e;
+        }
+        ++pos;
+      }
+    } else if (g.layout == EDGE_LINEAR_NONSELF) {
+      const size_t row0 = w * 64;
+      while (bits) {
+        const int t = __builtin_ctzll(bits);
+        bits &= bits - 1;
+        const size_t row = row0 + t;
+        if (pos < cap) {
+          long long a = (long long)(row % g.n_ref) + g.int_offset;
+          long long b = (long long)(row / g.n_ref + g.n_ref) + g.int_offset;
+          longlong2 e;
+          e.x = a < b ? a : b;
+          e.y = a < b ? b : a;
+          edges[pos] = e;
+        }
+        ++pos;
+      }
+    } else {
+      const size_t q = g.q_begin + w / g.n_rtiles;
+      const size_t r0 = (w % g.n_rtiles) * 64;
+      while (bits) {
+        const int t = __builtin_ctzll(bits);
+        bits &= bits - 1;
+        const size_t r = r0 + t;
+        if (pos < cap) {
+          longlong2 e;
+          if (g.layout == EDGE_TILED_SELF) {
+            e.x = (long long)q + g.int_offset;  // q < r by construction of the mask
+            e.y = (long long)r + g.int_offset;
+          } else {
+            e.x = (long long)r + g.int_offset;
+            e.y = (long long)(g.n_ref + q) + g.int_offset;
+          }
+          edges[pos] = e;
+        }
+        ++pos;
+      }
+    }
+  }
+}
+
+inline unsigned grid_for(size_t items, size_t per_block, unsigned cap_blocks) {
+  size_t b = (items + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > cap_blocks) b = cap_blocks;
+  return (unsigned)b;
+}
+
+}  // namespace
+
+size_t ppk_mask_words_linear(size_t n_rows) { return (n_rows + 63) / 64; }
+
+size_t ppk_compact_ws_bytes(size_t n_words) {
+  const size_t nb = (n_words + kWordsPerBlock - 1) / kWordsPerBlock;
+  return (nb + 1) * sizeof(unsigned long long);
+}
+
+int ppk_launch_assign(const float *d_dist, size_t n_rows, int slope, float x_max, float y_max,
+                      float *d_out, hipStream_t s) {
+  if (n_rows == 0) return PPK_OK;
+  // memory-bound stream: cap the grid at 256 CUs x 8 blocks and grid-stride
+  const unsigned grid = grid_for(n_rows, kBlock, 2048);
+  hipLaunchKernelGGL(assign_kernel, dim3(grid), dim3(kBlock), 0, s,
+                     reinterpret_cast<const float2 *>(d_dist), n_rows, slope, x_max, y_max, d_out);
+  PPK_HIP(hipGetLastError());
+  return PPK_OK;
+}
+
+int ppk_launch_mask_from_dist(const float *d_dist, size_t n_rows, int slope, float x_max,
+                              float y_max, int inclusive, uint64_t *d_mask, hipStream_t s) {
+  const size_t n_words = ppk_mask_words_linear(n_rows);
+  if (n_words == 0) return PPK_OK;
+  const unsigned grid = grid_for(n_words, kBlock / 64, 4096);
+  hipLaunchKernelGGL(mask_from_dist_kernel, dim3(grid), dim3(kBlock), 0, s,
+                     reinterpret_cast<const float2 *>(d_dist), n_rows, slope, x_max, y_max,
+                     inclusive, d_mask, n_words);
+  PPK_HIP(hipGetLastError());
+  return PPK_OK;
+}
+
+int ppk_launch_mask_from_assign(const int32_t *d_assign, size_t n_rows, int within_label,
+                                uint64_t *d_mask, hipStream_t s) {
+  const size_t n_words = ppk_mask_words_linear(n_rows);
+  if (n_words == 0) return PPK_OK;
+  const unsigned grid = grid_for(n_words, kBlock / 64, 4096);
+  hipLaunchKernelGGL(mask_from_assign_kernel, dim3(grid), dim3(kBlock), 0, s, d_assign, n_rows,
+                     within_label, d_mask, n_words);
+  PPK_HIP(hipGetLastError());
+  return PPK_OK;
+}
+
+int ppk_launch_compact(const uint64_t *d_mask, size_t n_words, const EdgeGeom &g, void *d_ws,
+                       long long *d_edges, size_t cap, unsigned long long *d_n_edges,
+                       hipStream_t s) {
+  if (n_words == 0) {
+    PPK_HIP(hipMemsetAsync(d_n_edges, 0, sizeof(unsigned long long), s));
+    return PPK_OK;
+  }
+  const size_t nb = (n_words + kWordsPerBlock - 1) / kWordsPerBlock;
+  if (nb > 0x7fffffffull) return ppk_fail(PPK_ERR_ARG, "edge mask too large for one launch");
+  unsigned long long *block_sums = static_cast<unsigned long long *>(d_ws);
+  hipLaunchKernelGGL(mask_count_kernel, dim3((unsigned)nb), dim3(kBlock), 0, s, d_mask, n_words,
+                     block_sums);
+  hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, block_sums, nb, d_n_edges);
+  hipLaunchKernelGGL(mask_expand_kernel, dim3((unsigned)nb), dim3(kBlock), 0, s, d_mask, n_words,
+                     block_sums, g, reinterpret_cast<longlong2 *>(d_edges), cap);
+  PPK_HIP(hipGetLastError());
+  return PPK_OK;
+}

@@ -1,0 +1,494 @@
+// Kernel 1: all-vs-all / ref x query core+accessory distances on gfx950 (CDNA4).
+//
+// Replaces the hot loop of pp_sketchlib.queryDatabase [EXT] (call sites
+// PopPUNK/sketchlib.py:528-537,:584-593); arithmetic per SURVEY.md 8a rows a3-a7.
+//
+// Mapping to the hardware (this is integer set-intersection: no MFMA anywhere):
+//  * sketches are resident as [k][word][sample]; a wavefront's 64 lanes own 64
+//    consecutive REF samples, so one word of 64 refs is one coalesced 512-B row;
+//  * a workgroup stages the ref rows of a few 64-bin blocks through LDS
+//    (register-prefetched one chunk ahead, read back with conflict-free
+//    ds_read_b64), shared by its NW wavefronts;
+//  * each wavefront compares those 64 refs against TQ QUERY samples whose words
+//    are wave-uniform: they arrive through the scalar unit (s_load_dwordx16 from
+//    the same [k][word][sample] array) and feed the VALU as SGPR operands, so a
+//    bin-plane compare-and-accumulate is ONE v_bitop3_b32 per 32 bins per pair:
+//        bits = bits & ~(ref ^ qry)            (truth table 0x90)
+//    and a 64-bin block costs 28 v_bitop3 + 2 v_bcnt per pair;
+//  * per-k match counts are packed into a 64/128-bit shift register per pair,
+//    and after the last k the lane regresses log J on k in fp64 (log J comes
+//    from a device-built table indexed by (cluster pair, k, count): the count
+//    is an integer in [0, nbins], so the table is exact, not an approximation),
+//    then writes float2 rows -- consecutive lanes are consecutive refs, which
+//    are consecutive rows in both PopPUNK row orders (utils.py:199-226);
+//  * with MODE_MASK the lane applies the boundary instead (src/boundary.cpp:42-58)
+//    and the wavefront's __ballot is stored as one uint64 of an edge bitmask.
+#include "ppk_internal.h"
+
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned __int128 u128;
+
+enum { MODE_DIST = 0, MODE_JACCARD = 1, MODE_COUNTS = 2, MODE_MASK = 3 };
+
+struct DistParams {
+  size_t npad_r, npad_q;  // padded sample counts of the two resident arrays
+  size_t n_ref;           // refs (lane axis)
+  size_t q_begin, q_end;  // band of query rows
+  size_t row_base;        // first distance row of the band
+  size_t lut_kstride;     // nbins + 1
+  size_t lut_cpstride;    // nk * (nbins + 1)
+  size_t n_rtiles;        // ceil(n_ref / 64)
+  size_t q_tile0;         // first query tile of the band (units of QT)
+  int self, nk, s64, bbits;
+  int cnt_bits;           // bits per packed count
+  int n_clu;
+  int random_correct;
+  int slope, inclusive;   // MODE_MASK
+  float x_max, y_max, scale_x, scale_y;
+  int kmers[PPK_MAX_NK];
+};
+
+// ---- small device helpers --------------------------------------------------
+
+// a4: collision adjustment + observed Jaccard (integer part as in the source).
+__device__ __forceinline__ double jaccard_obs(uint32_t same, size_t s64, size_t bbits) {
+  const size_t maxnbits = s64 * 64;
+  const size_t expected = maxnbits >> bbits;
+  size_t inter = same;
+  if (expected) {
+    const size_t ret = same > expected ? same - expected : 0;
+    inter = ret * maxnbits / (maxnbits - expected);
+  }
+  return (double)inter / (double)maxnbits;
+}
+
+// a5: observed_excess(obs, exp, 1)
+__device__ __forceinline__ double observed_excess(double obs, double expd) {
+  const double diff = obs > expd ? obs - expd : 0.0;
+  return diff / (1.0 - expd);
+}
+
+// ---- layout + table kernels -------------------------------------------------
+
+// [n][cols] -> [cols][npad] (cols = nk*words), padding samples zero-filled.
+__global__ void __launch_bounds__(256)
+transpose_kernel(const uint64_t *__restrict__ in, uint64_t *__restrict__ out, size_t n,
+                 size_t cols, size_t npad) {
+  __shared__ uint64_t tile[32][33];
+  const size_t c0 = (size_t)blockIdx.x * 32, s0 = (size_t)blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const size_t s = s0 + i, c = c0 + tx;
+    tile[i][tx] = (s < n && c < cols) ? in[s * cols + c] : 0ull;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const size_t c = c0 + i, s = s0 + tx;
+    if (c < cols && s < npad) out[c * npad + s] = tile[tx][i];
+  }
+}
+
+// LUT[(cr*C + cq)][k][count] = log J, or +1.0 when J < 5/nbins (the point and
+// every later k are dropped from the fit; docs/sketching.rst:161-165).
+__global__ void __launch_bounds__(256)
+lut_kernel(double *__restrict__ lut, const float *__restrict__ rtab, int nk, int n_clu,
+           size_t nbins, size_t s64, size_t bbits, int random_correct, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const size_t per = nbins + 1;
+  const uint32_t c = (uint32_t)(idx % per);
+  const size_t k = (idx / per) % nk;
+  const size_t cp = idx / (per * nk);
+  double jr = 0.0;
+  if (random_correct) jr = (double)rtab[(k * n_clu + cp / n_clu) * n_clu + cp % n_clu];
+  const double j = observed_excess(jaccard_obs(c, s64, bbits), jr);
+  const double tol = 5.0 / (double)nbins;
+  lut[idx] = (j < tol) ? 1.0 : log(j);
+}
+
+// ---- the pair-tile kernel ----------------------------------------------------
+
+template <typename PackT>
+__device__ __forceinline__ void fit_packed(PackT pk, const double *__restrict__ lutp,
+                                           const DistParams &p, float &core, float &acc,
+                                           bool &failed) {
+  // a6: OLS of log J on k over the leading run of usable points, fp64.
+  double sx = 0.0, sxx = 0.0, sy = 0.0, sxy = 0.0;
+  int n = 0;
+  bool open = true;
+  const uint32_t cmask = (1u << p.cnt_bits) - 1u;
+  for (int k = 0; k < p.nk; ++k) {
+    const uint32_t c = (uint32_t)(pk >> (p.cnt_bits * k)) & cmask;
+    const double y = lutp[(size_t)k * p.lut_kstride + c];
+    open = open && (y <= 0.0);
+    if (open) {
+      const double x = (double)p.kmers[k];
+      sx += x;
+      sxx += x * x;
+      sy += y;
+      sxy += x * y;
+      ++n;
+    }
+  }
+  if (n < 2) {
+    core = 0.0f;
+    acc = 0.0f;
+    failed = true;
+    return;
+  }
+  const double dn = (double)n;
+  const double slope = (dn * sxy - sx * sy) / (dn * sxx - sx * sx);
+  const double icpt = (sy - slope * sx) / dn;
+  core = slope < 0.0 ? (float)(1.0 - exp(slope)) : 0.0f;
+  acc = icpt < 0.0 ? (float)(1.0 - exp(icpt)) : 0.0f;
+  failed = false;
+}
+
+template <int TQ, int NW, int BBITS, int MODE, typename PackT>
+__global__ void __launch_bounds__(NW * 64)
+dist_kernel(const uint64_t *__restrict__ refT, const uint32_t *__restrict__ qryT,
+            const double *__restrict__ lut, const uint16_t *__restrict__ ref_clu,
+            const uint16_t *__restrict__ qry_clu, const float *__restrict__ rtab,
+            void *__restrict__ out, unsigned long long *__restrict__ n_failed,
+            uint64_t *__restrict__ mask_out, const DistParams p) {
+  constexpr int QT = TQ * NW;                 // queries per workgroup tile
+  constexpr int RPW = 7;                      // staged rows per wavefront per chunk
+  constexpr int CH = (BBITS > 0) ? (RPW * NW) / BBITS : 1;  // 64-bin blocks per chunk
+  constexpr int ROWS = (BBITS > 0) ? CH * BBITS : 64;       // LDS rows per chunk
+  static_assert(BBITS == 0 || CH * BBITS == RPW * NW, "chunk must tile evenly over waves");
+  __shared__ u32x2 lds[ROWS * 64];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const size_t rt = blockIdx.x;
+  const size_t r = rt * 64 + lane;
+  const size_t q0 = (p.q_tile0 + blockIdx.y) * QT;
+  const size_t qw0 = q0 + (size_t)wave * TQ;
+  // self mode: a tile entirely on or below the diagonal holds no pair (r > q needed)
+  if (p.self && rt * 64 + 63 <= q0) return;
+  const bool wave_active = !(p.self && rt * 64 + 63 <= qw0) && qw0 < p.q_end && qw0 + TQ > p.q_begin;
+
+  const int bbits = (BBITS > 0) ? BBITS : p.bbits;
+  const int words = p.s64 * bbits;
+  const int cpk = (p.s64 + CH - 1) / CH;   // chunks per k
+  const int total = p.nk * cpk;
+
+  uint32_t cnt[TQ];
+  PackT packed[TQ];
+#pragma unroll
+  for (int j = 0; j < TQ; ++j) {
+    cnt[j] = 0;
+    packed[j] = 0;
+  }
+
+  // ---- chunk staging: global -> VGPR (one chunk ahead) -> LDS ----------------
+  uint64_t pre[RPW];
+  auto load_chunk = [&](int k, int c) {
+    if constexpr (BBITS > 0) {
+      const int nrows = min(CH, p.s64 - c * CH) * BBITS;
+      const size_t grow0 = (size_t)k * words + (size_t)c * CH * BBITS;
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) {
+        const int row = i * NW + wave;
+        pre[i] = (row < nrows) ? refT[(grow0 + row) * p.npad_r + r] : 0ull;
+      }
+    }
+  };
+  auto store_chunk = [&]() {
+    if constexpr (BBITS > 0) {
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) {
+        const int row = i * NW + wave;
+        u32x2 v;
+        v.x = (uint32_t)pre[i];
+        v.y = (uint32_t)(pre[i] >> 32);
+        lds[row * 64 + lane] = v;
+      }
+    }
+  };
+
+  int k = 0, c = 0;
+  load_chunk(0, 0);
+  for (int g = 0; g < total; ++g) {
+    __syncthreads();  // every wave is done reading the previous chunk
+    if constexpr (BBITS > 0) {
+      store_chunk();
+    } else {
+      // generic bbits: one 64-bin block per chunk, staged without prefetch
+      const size_t grow0 = (size_t)k * words + (size_t)c * bbits;
+      for (int row = wave; row < bbits; row += NW) {
+        const uint64_t v = refT[(grow0 + row) * p.npad_r + r];
+        u32x2 t;
+        t.x = (uint32_t)v;
+        t.y = (uint32_t)(v >> 32);
+        lds[row * 64 + lane] = t;
+      }
+    }
+    __syncthreads();
+    int kn = k, cn = c + 1;
+    if (cn == cpk) {
+      cn = 0;
+      kn = k + 1;
+    }
+    if (g + 1 < total) load_chunk(kn, cn);
+
+    if (wave_active) {
+      const int nblk = min(CH, p.s64 - c * CH);
+#pragma unroll
+      for (int blk = 0; blk < CH; ++blk) {
+        if (blk < nblk) {
+          // wave-uniform query words for this 64-bin block: SGPR operands
+          const uint32_t *__restrict__ qp =
+              qryT + 2 * (((size_t)k * words + (size_t)(c * CH + blk) * bbits) * p.npad_q + qw0);
+          const u32x2 *lrow = lds + (blk * bbits) * 64 + lane;
+          uint32_t lo[TQ], hi[TQ];
+          if constexpr (BBITS > 0) {
+#pragma unroll
+            for (int b = 0; b < BBITS; ++b) {
+              const u32x2 a = lrow[b * 64];
+              const uint32_t *qb = qp + (size_t)b * 2 * p.npad_q;
+#pragma unroll
+              for (int j = 0; j < TQ; ++j) {
+                const uint32_t s0 = qb[2 * j], s1 = qb[2 * j + 1];
+                if (b == 0) {
+                  lo[j] = ~(a.x ^ s0);
+                  hi[j] = ~(a.y ^ s1);
+                } else {
+                  lo[j] = __builtin_amdgcn_bitop3_b32(lo[j], a.x, s0, 0x90);
+                  hi[j] = __builtin_amdgcn_bitop3_b32(hi[j], a.y, s1, 0x90);
+                }
+              }
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < TQ; ++j) {
+              lo[j] = 0xffffffffu;
+              hi[j] = 0xffffffffu;
+            }
+            for (int b = 0; b < bbits; ++b) {
+              const u32x2 a = lrow[b * 64];
+              const uint32_t *qb = qp + (size_t)b * 2 * p.npad_q;
+#pragma unroll
+              for (int j = 0; j < TQ; ++j) {
+                lo[j] = __builtin_amdgcn_bitop3_b32(lo[j], a.x, qb[2 * j], 0x90);
+                hi[j] = __builtin_amdgcn_bitop3_b32(hi[j], a.y, qb[2 * j + 1], 0x90);
+              }
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < TQ; ++j) cnt[j] += __popc(lo[j]) + __popc(hi[j]);
+        }
+      }
+    }
+
+    if (c == cpk - 1) {
+      // ---- end of one k: consume the counts --------------------------------
+      if (wave_active) {
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) {
+          if constexpr (MODE == MODE_DIST || MODE == MODE_MASK) {
+            packed[j] |= (PackT)cnt[j] << (p.cnt_bits * k);
+          } else {
+            const size_t q = qw0 + j;
+            const bool valid = r < p.n_ref && q >= p.q_begin && q < p.q_end && (!p.self || r > q);
+            if (valid) {
+              const size_t row = (p.self ? q * p.n_ref - (q * (q + 1)) / 2 + (r - q - 1)
+                                         : q * p.n_ref + r) - p.row_base;
+              if constexpr (MODE == MODE_COUNTS) {
+                static_cast<uint32_t *>(out)[row * p.nk + k] = cnt[j];
+              } else {
+                double jr = 0.0;
+                if (p.random_correct) {
+                  const int cr = ref_clu ? ref_clu[r] : 0;
+                  const int cq = qry_clu ? qry_clu[q] : 0;
+                  jr = (double)rtab[((size_t)k * p.n_clu + cr) * p.n_clu + cq];
+                }
+                static_cast<float *>(out)[row * p.nk + k] =
+                    (float)observed_excess(jaccard_obs(cnt[j], p.s64, bbits), jr);
+              }
+            }
+          }
+          cnt[j] = 0;
+        }
+      }
+    }
+    k = kn;
+    c = cn;
+  }
+
+  // ---- epilogue: regression (+ boundary) per pair ---------------------------
+  if constexpr (MODE == MODE_DIST || MODE == MODE_MASK) {
+    if (!wave_active) return;
+    const int cr = (ref_clu && r < p.n_ref) ? ref_clu[r] : 0;
+#pragma unroll
+    for (int j = 0; j < TQ; ++j) {
+      const size_t q = qw0 + j;   // wave-uniform
+      if (q < p.q_begin || q >= p.q_end) continue;
+      const bool valid = r < p.n_ref && (!p.self || r > q);
+      const int cq = qry_clu ? qry_clu[q] : 0;
+      const double *lutp = lut + (size_t)(cr * p.n_clu + cq) * p.lut_cpstride;
+      float core = 0.0f, acc = 0.0f;
+      bool failed = false;
+      if (valid) fit_packed<PackT>(packed[j], lutp, p, core, acc, failed);
+      if (n_failed) {
+        const uint64_t fm = __ballot(valid && failed);
+        if (fm && lane == 0) atomicAdd(n_failed, (unsigned long long)__popcll(fm));
+      }
+      if constexpr (MODE == MODE_DIST) {
+        if (valid) {
+          const size_t row = (p.self ? q * p.n_ref - (q * (q + 1)) / 2 + (r - q - 1)
+                                     : q * p.n_ref + r) - p.row_base;
+          float2 v;
+          v.x = core;
+          v.y = acc;
+          static_cast<float2 *>(out)[row] = v;
+        }
+      } else {
+        bool pred = false;
+        if (valid) {
+          // RefineFit.assign pre-scales X/scale in float32 (PopPUNK/models.py:1085-1089)
+          const float xs = __fdiv_rn(core, p.scale_x), ys = __fdiv_rn(acc, p.scale_y);
+          const float s = ppk_line_dist(xs, ys, p.x_max, p.y_max, p.slope);
+          pred = p.inclusive ? (s <= 0.0f) : (s < 0.0f);
+        }
+        const uint64_t m = __ballot(pred);
+        if (lane == 0) mask_out[(q - p.q_begin) * p.n_rtiles + rt] = m;
+      }
+    }
+  }
+}
+
+// ---- host-side launch ------------------------------------------------------
+
+namespace {
+
+int g_tile_tq = 0, g_tile_nw = 0;
+
+template <int TQ, int NW, int BBITS, int MODE, typename PackT>
+int launch_variant(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const float *d_rtab,
+                   void *d_out, unsigned long long *d_n_failed, uint64_t *d_mask, DistParams &p,
+                   hipStream_t s, const char *name) {
+  constexpr int QT = TQ * NW;
+  p.q_tile0 = p.q_begin / QT;
+  const size_t q_tiles = (p.q_end + QT - 1) / QT - p.q_tile0;
+  if (q_tiles == 0 || p.n_rtiles == 0) return PPK_OK;
+  if (q_tiles > 65535) return ppk_fail(PPK_ERR_ARG, "query band too tall for one launch");
+  dim3 grid((unsigned)p.n_rtiles, (unsigned)q_tiles);
+  // cluster ids only matter when a multi-cluster random-match table is in use
+  const bool use_clu = p.random_correct && p.n_clu > 1;
+  const uint16_t *rclu = use_clu ? ref->d_clu : nullptr;
+  const uint16_t *qclu = use_clu ? qry->d_clu : nullptr;
+  ppk_set_kernel_name(name);
+  ppk_prof_begin(s);
+  hipLaunchKernelGGL((dist_kernel<TQ, NW, BBITS, MODE, PackT>), grid, dim3(NW * 64), 0, s,
+                     ref->d_skT, reinterpret_cast<const uint32_t *>(qry->d_skT), d_lut, rclu, qclu,
+                     d_rtab, d_out, d_n_failed, d_mask, p);
+  ppk_prof_end(s);
+  PPK_HIP(hipGetLastError());
+  return PPK_OK;
+}
+
+template <int MODE, typename PackT>
+int launch_tiles(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const float *d_rtab,
+                 void *d_out, unsigned long long *d_n_failed, uint64_t *d_mask, DistParams &p,
+                 hipStream_t s) {
+  int tq = g_tile_tq, nw = g_tile_nw;
+  if (tq == 0) {
+    tq = 16;
+    nw = 4;
+  }
+  if (p.bbits != 14) {
+    return launch_variant<8, 4, 0, MODE, PackT>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask,
+                                                p, s, "dist_kernel<8,4,generic>");
+  }
+  if constexpr ((MODE == MODE_DIST || MODE == MODE_MASK) && sizeof(PackT) == 8) {
+    if (tq == 16 && nw == 4)
+      return launch_variant<16, 4, 14, MODE, PackT>(ref, qry, d_lut, d_rtab, d_out, d_n_failed,
+                                                    d_mask, p, s, "dist_kernel<16,4,14>");
+    if (tq == 8 && nw == 8)
+      return launch_variant<8, 8, 14, MODE, PackT>(ref, qry, d_lut, d_rtab, d_out, d_n_failed,
+                                                   d_mask, p, s, "dist_kernel<8,8,14>");
+  }
+  return launch_variant<8, 4, 14, MODE, PackT>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p,
+                                               s, "dist_kernel<8,4,14>");
+}
+
+}  // namespace
+
+int ppk_set_tile(int tq, int nw) {
+  if (!((tq == 0 && nw == 0) || (tq == 16 && nw == 4) || (tq == 8 && nw == 8) ||
+        (tq == 8 && nw == 4)))
+    return ppk_fail(PPK_ERR_ARG, "supported tiles: (16,4) (8,8) (8,4) or (0,0)=auto");
+  g_tile_tq = tq;
+  g_tile_nw = nw;
+  return PPK_OK;
+}
+
+int ppk_launch_transpose(const uint64_t *d_in, uint64_t *d_out, size_t n, size_t cols, size_t npad,
+                         hipStream_t s) {
+  dim3 grid((unsigned)((cols + 31) / 32), (unsigned)(npad / 32));
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, s, d_in, d_out, n, cols, npad);
+  PPK_HIP(hipGetLastError());
+  return PPK_OK;
+}
+
+// Enqueue kernel 1 for one band.  d_scratch must hold lut_bytes (+ table).
+// mode_mask: d_mask non-null selects the fused boundary/bitmask output.
+int ppk_launch_dist(const ppk_db *ref, const ppk_db *qry_or_null, const int32_t *kmers,
+                    const float *d_rtab, size_t n_clu, int flags, size_t q_begin, size_t q_end,
+                    void *d_out, unsigned long long *d_n_failed, uint64_t *d_mask, int slope,
+                    float x_max, float y_max, float scale_x, float scale_y, int inclusive,
+                    double *d_lut, hipStream_t s) {
+  const ppk_db *qry = qry_or_null ? qry_or_null : ref;
+  DistParams p = {};
+  p.self = qry_or_null ? 0 : 1;
+  p.npad_r = ref->npad;
+  p.npad_q = qry->npad;
+  p.n_ref = ref->n;
+  p.q_begin = q_begin;
+  p.q_end = q_end;
+  p.row_base = p.self ? q_begin * ref->n - (q_begin * (q_begin + 1)) / 2 : q_begin * ref->n;
+  p.nk = (int)ref->nk;
+  p.s64 = (int)ref->s64;
+  p.bbits = (int)ref->bbits;
+  const size_t nbins = ref->s64 * 64;
+  p.lut_kstride = nbins + 1;
+  p.lut_cpstride = (size_t)p.nk * (nbins + 1);
+  p.n_rtiles = (ref->n + 63) / 64;
+  p.n_clu = (int)(n_clu ? n_clu : 1);
+  p.random_correct = (flags & PPK_FLAG_RANDOM_CORRECT) && d_rtab ? 1 : 0;
+  p.slope = slope;
+  p.inclusive = inclusive;
+  p.x_max = x_max;
+  p.y_max = y_max;
+  p.scale_x = scale_x;
+  p.scale_y = scale_y;
+  int bits = 1;
+  while (((size_t)1 << bits) <= nbins) ++bits;
+  p.cnt_bits = bits;
+  for (int k = 0; k < p.nk && k < PPK_MAX_NK; ++k) p.kmers[k] = kmers[k];
+
+  const bool want_counts = flags & PPK_FLAG_COUNTS;
+  const bool want_jac = flags & PPK_FLAG_JACCARD;
+  if (want_counts)
+    return launch_tiles<MODE_COUNTS, uint64_t>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
+  if (want_jac)
+    return launch_tiles<MODE_JACCARD, uint64_t>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
+
+  if (p.nk > PPK_MAX_NK || p.nk * p.cnt_bits > 128)
+    return ppk_fail(PPK_ERR_ARG, "nk * count bits > 128 (or nk > 32) is not supported by the fused path");
+  // log-J table, built on the device for this (random table, k list)
+  {
+    const size_t total = (size_t)p.n_clu * p.n_clu * p.lut_cpstride;
+    hipLaunchKernelGGL(lut_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_lut,
+                       d_rtab, p.nk, p.n_clu, nbins, ref->s64, ref->bbits, p.random_correct, total);
+    PPK_HIP(hipGetLastError());
+  }
+  const bool wide = p.nk * p.cnt_bits > 64;
+  if (d_mask) {
+    return wide ? launch_tiles<MODE_MASK, u128>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s)
+                : launch_tiles<MODE_MASK, uint64_t>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
+  }
+  return wide ? launch_tiles<MODE_DIST, u128>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s)
+              : launch_tiles<MODE_DIST, uint64_t>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
+}

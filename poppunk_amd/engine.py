@@ -1,0 +1,298 @@
+"""Device-level engine: resident sketch databases, kernel launches on torch
+tensors/streams, and the band-sharded multi-GPU path.
+
+PyTorch is plumbing here (device memory, streams, torch.distributed over
+RCCL); all arithmetic happens in libppk_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+FLAG_RANDOM_CORRECT = _lib.FLAG_RANDOM_CORRECT
+FLAG_JACCARD = _lib.FLAG_JACCARD
+FLAG_COUNTS = _lib.FLAG_COUNTS
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _stream_ptr(device):
+    torch = _torch()
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def rows_in_band(n_ref, n_qry, q_begin, q_end):
+    return int(_lib.lib().ppk_rows_in_band(n_ref, n_qry, q_begin, q_end))
+
+
+def band_split(n_ref, n_qry, n_parts):
+    """Query-axis band edges giving n_parts (nearly) equal pair counts (multiples of 64)."""
+    bounds = (C.c_size_t * (n_parts + 1))()
+    _lib.check(_lib.lib().ppk_band_split(n_ref, n_qry, n_parts, bounds), "ppk_band_split")
+    return [int(b) for b in bounds]
+
+
+class SketchDB:
+    """One sample list's bin-sketches resident in HBM on one GPU (ppk_db).
+
+    sketches: numpy uint64 [n, nk, sketchsize64*bbits] (host) or a torch int64 CUDA
+    tensor of the same shape already on `device`.
+    clusters: optional uint16 [n] random-match cluster ids.
+    """
+
+    def __init__(self, sketches, sketchsize64, bbits, clusters=None, device=0):
+        lib = _lib.lib()
+        torch = _torch()
+        self.device = int(device)
+        self.sketchsize64 = int(sketchsize64)
+        self.bbits = int(bbits)
+        self._h = C.c_void_p()
+        on_dev = hasattr(sketches, "is_cuda")
+        if on_dev:
+            if not sketches.is_cuda or sketches.dtype != torch.int64 or not sketches.is_contiguous():
+                raise ValueError("device sketches must be a contiguous int64 CUDA tensor")
+            if sketches.device.index != self.device:
+                raise ValueError("sketch tensor is on a different device")
+            n, nk, words = sketches.shape
+            src = C.c_void_p(sketches.data_ptr())
+        else:
+            sketches = np.ascontiguousarray(sketches, dtype=np.uint64)
+            if sketches.ndim != 3:
+                raise ValueError("sketches must be [n, nk, sketchsize64*bbits]")
+            n, nk, words = sketches.shape
+            src = C.c_void_p(sketches.ctypes.data)
+        if words != self.sketchsize64 * self.bbits:
+            raise ValueError("sketch word count %d != sketchsize64*bbits = %d"
+                             % (words, self.sketchsize64 * self.bbits))
+        self.n, self.nk = int(n), int(nk)
+        clu_ptr = None
+        self._clu_keep = None
+        if clusters is not None:
+            if on_dev:
+                c = clusters.to(device="cuda:%d" % self.device, dtype=torch.int16).contiguous()
+                clu_ptr = C.c_void_p(c.data_ptr())
+            else:
+                c = np.ascontiguousarray(clusters, dtype=np.uint16)
+                if c.shape != (n,):
+                    raise ValueError("clusters must be [n]")
+                clu_ptr = C.c_void_p(c.ctypes.data)
+            self._clu_keep = c
+        with torch.cuda.device(self.device):
+            rc = lib.ppk_db_create(self.device, src, n, nk, self.sketchsize64, self.bbits, clu_ptr,
+                                   1 if on_dev else 0, _stream_ptr(self.device), C.byref(self._h))
+            _lib.check(rc, "ppk_db_create")
+            if on_dev:
+                torch.cuda.current_stream(self.device).synchronize()   # source tensor may be freed
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _lib.lib().ppk_db_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return self.n
+
+
+def _prep_tables(kmers, random_tbl, nk):
+    kmers = np.ascontiguousarray(kmers, dtype=np.int32)
+    if kmers.shape != (nk,):
+        raise ValueError("klist length %d does not match the sketches' %d k-mer lengths"
+                         % (kmers.size, nk))
+    n_clu = 0
+    tbl_ptr = None
+    if random_tbl is not None:
+        random_tbl = np.ascontiguousarray(random_tbl, dtype=np.float32)
+        if random_tbl.ndim != 3 or random_tbl.shape[0] != nk or random_tbl.shape[1] != random_tbl.shape[2]:
+            raise ValueError("random table must be [nk, n_clu, n_clu]")
+        n_clu = random_tbl.shape[1]
+        tbl_ptr = random_tbl.ctypes.data_as(C.POINTER(C.c_float))
+    return kmers, random_tbl, tbl_ptr, n_clu
+
+
+def _check_pair(ref, qry):
+    if qry is not None and (qry.nk != ref.nk or qry.sketchsize64 != ref.sketchsize64
+                            or qry.bbits != ref.bbits or qry.device != ref.device):
+        raise ValueError("ref and query databases are incompatible")
+
+
+def dist(ref, qry=None, kmers=None, random_tbl=None, random_correct=True, jaccard=False,
+         counts=False, q_begin=0, q_end=None, out=None):
+    """Enqueue kernel 1 for query rows [q_begin, q_end) on the current stream.
+
+    Returns (out, n_failed): out is a CUDA tensor float32 [rows,2] (core, accessory),
+    float32 [rows,nk] (jaccard) or int32 [rows,nk] (counts); n_failed a 1-element
+    int64 CUDA tensor (pairs with < 2 usable k-mer lengths).
+    """
+    torch = _torch()
+    lib = _lib.lib()
+    _check_pair(ref, qry)
+    nq = qry.n if qry is not None else ref.n
+    q_end = nq if q_end is None else int(q_end)
+    kmers, random_tbl, tbl_ptr, n_clu = _prep_tables(kmers, random_tbl, ref.nk)
+    rows = rows_in_band(ref.n, qry.n if qry is not None else 0, q_begin, q_end)
+    flags = (FLAG_RANDOM_CORRECT if random_correct else 0) | (FLAG_JACCARD if jaccard else 0) \
+        | (FLAG_COUNTS if counts else 0)
+    cols = ref.nk if (jaccard or counts) else 2
+    dev = "cuda:%d" % ref.device
+    with torch.cuda.device(ref.device):
+        if out is None:
+            out = torch.empty((rows, cols), dtype=torch.int32 if counts else torch.float32,
+                              device=dev)
+        elif out.numel() != rows * cols or not out.is_contiguous() or out.element_size() != 4:
+            raise ValueError("out has the wrong size")
+        n_failed = torch.zeros(1, dtype=torch.int64, device=dev)
+        rc = lib.ppk_dist_dev(ref._h, qry._h if qry is not None else None,
+                              kmers.ctypes.data_as(C.POINTER(C.c_int32)), tbl_ptr, n_clu, flags,
+                              q_begin, q_end, C.c_void_p(out.data_ptr()),
+                              C.c_void_p(n_failed.data_ptr()), _stream_ptr(ref.device))
+        _lib.check(rc, "ppk_dist_dev")
+    return out, n_failed
+
+
+def dist_edges(ref, qry=None, kmers=None, random_tbl=None, random_correct=True, slope=2,
+               x_max=0.0, y_max=0.0, scale=(1.0, 1.0), inclusive=True, q_begin=0, q_end=None,
+               cap=None):
+    """Fused kernel 1 + boundary + compaction.  Returns (edges int64 [n_edges,2] CUDA, n_failed).
+
+    The edge count is data dependent: the call runs with a capacity guess and is
+    re-run with the exact size only if the guess was too small."""
+    torch = _torch()
+    lib = _lib.lib()
+    _check_pair(ref, qry)
+    nq = qry.n if qry is not None else ref.n
+    q_end = nq if q_end is None else int(q_end)
+    kmers, random_tbl, tbl_ptr, n_clu = _prep_tables(kmers, random_tbl, ref.nk)
+    rows = rows_in_band(ref.n, qry.n if qry is not None else 0, q_begin, q_end)
+    flags = FLAG_RANDOM_CORRECT if random_correct else 0
+    dev = "cuda:%d" % ref.device
+    if cap is None:
+        cap = min(rows, max(1 << 20, rows // 8))
+    with torch.cuda.device(ref.device):
+        while True:
+            edges = torch.empty((max(cap, 1), 2), dtype=torch.int64, device=dev)
+            n_edges = torch.zeros(1, dtype=torch.int64, device=dev)
+            n_failed = torch.zeros(1, dtype=torch.int64, device=dev)
+            rc = lib.ppk_dist_edges_dev(ref._h, qry._h if qry is not None else None,
+                                        kmers.ctypes.data_as(C.POINTER(C.c_int32)), tbl_ptr, n_clu,
+                                        flags, q_begin, q_end, int(slope), float(x_max),
+                                        float(y_max), float(scale[0]), float(scale[1]),
+                                        1 if inclusive else 0, C.c_void_p(edges.data_ptr()), cap,
+                                        C.c_void_p(n_edges.data_ptr()),
+                                        C.c_void_p(n_failed.data_ptr()), _stream_ptr(ref.device))
+            _lib.check(rc, "ppk_dist_edges_dev")
+            n = int(n_edges.item())
+            if n <= cap:
+                return edges[:n], n_failed
+            cap = n
+
+
+def assign_threshold_dev(dist_t, slope, x_max, y_max, out=None):
+    """poppunk_refine.assignThreshold on a resident float32 [n,2] CUDA tensor."""
+    torch = _torch()
+    if not (dist_t.is_cuda and dist_t.dtype == torch.float32 and dist_t.is_contiguous()
+            and dist_t.dim() == 2 and dist_t.shape[1] == 2):
+        raise TypeError("distMat must be a C-contiguous float32 [n,2] CUDA tensor")
+    n = dist_t.shape[0]
+    with torch.cuda.device(dist_t.device):
+        if out is None:
+            out = torch.empty(n, dtype=torch.float32, device=dist_t.device)
+        rc = _lib.lib().ppk_assign_threshold_dev(C.c_void_p(dist_t.data_ptr()), n, int(slope),
+                                                 float(x_max), float(y_max),
+                                                 C.c_void_p(out.data_ptr()),
+                                                 _stream_ptr(dist_t.device.index))
+        _lib.check(rc, "ppk_assign_threshold_dev")
+    return out
+
+
+def edge_threshold_dev(dist_t, slope, x_max, y_max, n_ref=0, inclusive=True, cap=None):
+    """poppunk_refine.edgeThreshold on a resident float32 [n,2] CUDA tensor -> int64 [m,2]."""
+    torch = _torch()
+    if not (dist_t.is_cuda and dist_t.dtype == torch.float32 and dist_t.is_contiguous()
+            and dist_t.dim() == 2 and dist_t.shape[1] == 2):
+        raise TypeError("distMat must be a C-contiguous float32 [n,2] CUDA tensor")
+    n = dist_t.shape[0]
+    if cap is None:
+        cap = min(n, max(1 << 20, n // 8))
+    with torch.cuda.device(dist_t.device):
+        while True:
+            edges = torch.empty((max(cap, 1), 2), dtype=torch.int64, device=dist_t.device)
+            n_edges = torch.zeros(1, dtype=torch.int64, device=dist_t.device)
+            rc = _lib.lib().ppk_edge_threshold_dev(C.c_void_p(dist_t.data_ptr()), n, int(n_ref),
+                                                   int(slope), float(x_max), float(y_max),
+                                                   1 if inclusive else 0,
+                                                   C.c_void_p(edges.data_ptr()), cap,
+                                                   C.c_void_p(n_edges.data_ptr()),
+                                                   _stream_ptr(dist_t.device.index))
+            _lib.check(rc, "ppk_edge_threshold_dev")
+            m = int(n_edges.item())
+            if m <= cap:
+                return edges[:m]
+            cap = m
+
+
+# ---- multi-GPU: one process per GPU, band-sharded pair space, gather to rank 0 -------------
+
+def shard_bounds(n_ref, n_qry, world_size):
+    return band_split(n_ref, n_qry, world_size)
+
+
+def gather_bands(local, rows_per_rank, cols, dtype, device, rank, world_size, dst=0, group=None):
+    """Gather variable-height row blocks to `dst` with grouped point-to-point
+    send/recv (RCCL over xGMI on GPUs: each peer streams over its own link into the
+    final matrix, so rank `dst` receives every band directly at its row offset and
+    no staging copy or re-ordering pass is needed).  Returns the full tensor on
+    `dst`, None elsewhere."""
+    torch = _torch()
+    import torch.distributed as dist_
+    if world_size == 1:
+        return local
+    if rank == dst:
+        total = int(sum(rows_per_rank))
+        full = torch.empty((total, cols), dtype=dtype, device=device)
+        offs = np.concatenate([[0], np.cumsum(rows_per_rank)]).astype(np.int64)
+        full[offs[dst]:offs[dst + 1]].copy_(local)
+        ops = []
+        for src in range(world_size):
+            if src == dst or rows_per_rank[src] == 0:
+                continue
+            ops.append(dist_.P2POp(dist_.irecv, full[offs[src]:offs[src + 1]], src, group))
+        if ops:
+            for req in dist_.batch_isend_irecv(ops):
+                req.wait()
+        return full
+    if rows_per_rank[rank] > 0:
+        for req in dist_.batch_isend_irecv([dist_.P2POp(dist_.isend, local.contiguous(), dst, group)]):
+            req.wait()
+    return None
+
+
+def query_sharded(ref, qry, kmers, random_tbl, rank, world_size, random_correct=True,
+                  gather=True, band_fn=None, group=None):
+    """Config 3/4 shape: every rank holds the full resident sketches, computes its band
+    of query rows and (optionally) the bands are gathered into the PopPUNK-ordered
+    matrix on rank 0.  `band_fn(q_begin, q_end) -> tensor` overrides the HIP launch
+    (used by the CPU gloo tests to exercise the sharding/gather logic)."""
+    n_qry = qry.n if qry is not None else 0
+    bounds = shard_bounds(ref.n, n_qry, world_size)
+    rows = [rows_in_band(ref.n, n_qry, bounds[i], bounds[i + 1]) for i in range(world_size)]
+    qb, qe = bounds[rank], bounds[rank + 1]
+    if band_fn is not None:
+        local = band_fn(qb, qe)
+    else:
+        local, _ = dist(ref, qry, kmers, random_tbl, random_correct=random_correct, q_begin=qb,
+                        q_end=qe)
+    if not gather:
+        return local, rows
+    full = gather_bands(local, rows, local.shape[1], local.dtype, local.device, rank, world_size,
+                        0, group)
+    return full, rows

@@ -1,0 +1,88 @@
+"""Drop-in for the kernel-2 functions of the reference's `poppunk_refine`
+extension (src/python_bindings.cpp:79-96), backed by libppk_hip.so.
+
+    assignThreshold(distMat, slope, x_max, y_max, num_threads=1) -> float32 [n]
+    edgeThreshold(distMat, slope, x_max, y_max)                  -> list[(i, j)]
+    generateTuples(assignments, within_label, self=True, num_ref=0, int_offset=0)
+                                                                 -> list[(i, j)]
+
+As in the pybind11 module, `distMat` must already be a C-contiguous float32
+[n, 2] array (`py::arg("distMat").noconvert()`, src/python_bindings.cpp:82,:89):
+anything else raises TypeError rather than being converted.  The `*_array`
+variants return int64 [m, 2] numpy arrays instead of Python tuples.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+_DEVICE = 0
+
+
+def set_device(device_id):
+    global _DEVICE
+    _DEVICE = int(device_id)
+
+
+def _check_dist(distMat):
+    if not (isinstance(distMat, np.ndarray) and distMat.dtype == np.float32 and distMat.ndim == 2
+            and distMat.shape[1] == 2 and distMat.flags["C_CONTIGUOUS"]):
+        raise TypeError("distMat must be a C-contiguous float32 numpy array of shape [n, 2] "
+                        "(no implicit conversion)")
+    return distMat
+
+
+def assignThreshold(distMat, slope, x_max, y_max, num_threads=1):
+    """-1 (within), 0 (on the line), +1 per row (src/boundary.cpp:60-80)."""
+    d = _check_dist(distMat)
+    out = np.empty(d.shape[0], dtype=np.float32)
+    rc = _lib.lib().ppk_assign_threshold(d.ctypes.data_as(C.POINTER(C.c_float)), d.shape[0],
+                                         int(slope), float(x_max), float(y_max), _DEVICE,
+                                         out.ctypes.data_as(C.POINTER(C.c_float)))
+    _lib.check(rc, "assignThreshold")
+    return out
+
+
+def _edges(call):
+    n_edges = C.c_size_t(0)
+    rc = call(None, 0, C.byref(n_edges))
+    if rc not in (_lib.OK, _lib.ERR_CAPACITY):
+        _lib.check(rc, "edge list")
+    n = int(n_edges.value)
+    ij = np.empty((n, 2), dtype=np.int64)
+    if n:
+        rc = call(ij.ctypes.data_as(C.POINTER(C.c_longlong)), n, C.byref(n_edges))
+        _lib.check(rc, "edge list")
+    return ij
+
+
+def edgeThreshold_array(distMat, slope, x_max, y_max, n_ref=0, inclusive=True):
+    d = _check_dist(distMat)
+    lib = _lib.lib()
+    return _edges(lambda p, cap, ne: lib.ppk_edge_threshold(
+        d.ctypes.data_as(C.POINTER(C.c_float)), d.shape[0], int(n_ref), int(slope), float(x_max),
+        float(y_max), 1 if inclusive else 0, _DEVICE, p, cap, ne))
+
+
+def edgeThreshold(distMat, slope, x_max, y_max):
+    """Rows with line_dist <= 0 as (i, j) tuples, condensed order (src/boundary.cpp:82-95)."""
+    return [tuple(e) for e in edgeThreshold_array(distMat, slope, x_max, y_max).tolist()]
+
+
+def generateTuples_array(assignments, within_label, self=True, num_ref=0, int_offset=0):
+    # pybind converts any int-like sequence to std::vector<int> (python_bindings.cpp:34-36);
+    # callers pass float32 -1/0/1 vectors, numpy ints and Python lists
+    a = np.ascontiguousarray(np.asarray(assignments).astype(np.int32, copy=False))
+    if a.ndim != 1:
+        raise TypeError("assignments must be one-dimensional")
+    lib = _lib.lib()
+    return _edges(lambda p, cap, ne: lib.ppk_generate_tuples(
+        a.ctypes.data_as(C.POINTER(C.c_int32)), a.shape[0], int(within_label), 1 if self else 0,
+        int(num_ref), int(int_offset), _DEVICE, p, cap, ne))
+
+
+def generateTuples(assignments, within_label, self=True, num_ref=0, int_offset=0):
+    """Rows with assignments == within_label as (i, j), i < j (src/boundary.cpp:97-123)."""
+    return [tuple(e) for e in
+            generateTuples_array(assignments, within_label, self, num_ref, int_offset).tolist()]

@@ -1,0 +1,122 @@
+"""Drop-in for the one pp_sketchlib entry point on the hot path.
+
+`queryDatabase` keeps the keyword names of PopPUNK/sketchlib.py:528-537 and the
+positional order pinned by test/test-update-gpu.py:85-86 and
+scripts/poppunk_iterate.py:202-213:
+
+    queryDatabase(ref_db_name, query_db_name, rList, qList, klist,
+                  random_correct, jaccard, num_threads, use_gpu, device_id)
+
+Behind it the sketches named by rList/qList are loaded (poppunk_amd.sketchdb),
+handed to libppk_hip.so through the C ABI (include/ppk.h: ppk_query) and the
+result comes back as the float32 [n_pairs, 2] (or [n_pairs, nk]) array the
+reference returns.  The computation always runs on the MI355X: `use_gpu` and
+`num_threads` are accepted for signature compatibility only (there is no CPU
+path in this package), `device_id` selects the GPU.  The environment variable
+PPK_DEVICES="0,1,..." band-splits one call over several GPUs of the node.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+from . import _lib, sketchdb
+
+version = "2.1.4+poppunk_amd.0.1.0"   # >= the minimum PopPUNK asks for (PopPUNK/__init__.py:9-11)
+
+
+def _devices(device_id):
+    env = os.environ.get("PPK_DEVICES", "").strip()
+    if env:
+        return [int(x) for x in env.split(",") if x.strip() != ""]
+    return [int(device_id)]
+
+
+def query_arrays(ref_sk, qry_sk, klist, sketchsize64, bbits, random_table=None, ref_clusters=None,
+                 qry_clusters=None, random_correct=True, jaccard=False, counts=False, devices=(0,)):
+    """ppk_query on in-memory sketch arrays [n, nk, words]; qry_sk=None => self."""
+    lib = _lib.lib()
+    ref_sk = np.ascontiguousarray(ref_sk, dtype=np.uint64)
+    n_ref, nk, words = ref_sk.shape
+    if words != sketchsize64 * bbits:
+        raise RuntimeError("sketch word count does not match sketchsize64*bbits")
+    kmers = np.ascontiguousarray(klist, dtype=np.int32).ravel()
+    if kmers.size != nk:
+        raise RuntimeError("klist does not match the sketches")
+    n_qry = 0
+    qptr = None
+    if qry_sk is not None:
+        qry_sk = np.ascontiguousarray(qry_sk, dtype=np.uint64)
+        if qry_sk.shape[1:] != ref_sk.shape[1:]:
+            raise RuntimeError("query and reference sketches have different shapes")
+        n_qry = qry_sk.shape[0]
+        qptr = qry_sk.ctypes.data_as(C.POINTER(C.c_uint64))
+    n_pairs = n_ref * (n_ref - 1) // 2 if qry_sk is None else n_ref * n_qry
+    flags = (_lib.FLAG_RANDOM_CORRECT if random_correct else 0) | \
+        (_lib.FLAG_JACCARD if jaccard else 0) | (_lib.FLAG_COUNTS if counts else 0)
+    cols = nk if (jaccard or counts) else 2
+    out = np.zeros((n_pairs, cols), dtype=np.uint32 if counts else np.float32)
+    tptr = rcp = qcp = None
+    n_clu = 0
+    if random_table is not None and random_correct:
+        random_table = np.ascontiguousarray(random_table, dtype=np.float32)
+        n_clu = random_table.shape[1]
+        tptr = random_table.ctypes.data_as(C.POINTER(C.c_float))
+        if n_clu > 1:
+            if ref_clusters is None or (qry_sk is not None and qry_clusters is None):
+                raise RuntimeError("a multi-cluster random table needs per-sample cluster ids")
+            ref_clusters = np.ascontiguousarray(ref_clusters, dtype=np.uint16)
+            if ref_clusters.max(initial=0) >= n_clu:
+                raise RuntimeError("cluster id out of range of the random table")
+            rcp = ref_clusters.ctypes.data_as(C.POINTER(C.c_uint16))
+            if qry_sk is not None:
+                qry_clusters = np.ascontiguousarray(qry_clusters, dtype=np.uint16)
+                if qry_clusters.max(initial=0) >= n_clu:
+                    raise RuntimeError("cluster id out of range of the random table")
+                qcp = qry_clusters.ctypes.data_as(C.POINTER(C.c_uint16))
+    devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+    n_failed = C.c_ulonglong(0)
+    if n_pairs == 0:
+        return out, 0
+    rc = lib.ppk_query(ref_sk.ctypes.data_as(C.POINTER(C.c_uint64)), n_ref, qptr, n_qry,
+                       kmers.ctypes.data_as(C.POINTER(C.c_int32)), nk, sketchsize64, bbits, tptr,
+                       rcp, qcp, n_clu, flags, devs, len(devices),
+                       C.c_void_p(out.ctypes.data), C.byref(n_failed))
+    _lib.check(rc, "ppk_query")
+    return out, int(n_failed.value)
+
+
+def queryDatabase(ref_db_name, query_db_name, rList, qList, klist, random_correct=True,
+                  jaccard=False, num_threads=1, use_gpu=False, device_id=0):
+    """See module docstring.  Returns numpy float32 [n_pairs, 2] (core, accessory), or
+    [n_pairs, len(klist)] Jaccard distances when jaccard=True; rows ordered as
+    PopPUNK.utils.iterDistRows (utils.py:199-226)."""
+    klist = [int(k) for k in np.asarray(klist).ravel()]
+    rList = [str(x) for x in rList]
+    qList = [str(x) for x in qList]
+    self_query = (ref_db_name == query_db_name) and (rList == qList)
+    ref = sketchdb.load(ref_db_name, rList, klist)
+    if self_query:
+        qry_sk = None
+        qry_clu = None
+    else:
+        qry = sketchdb.load(query_db_name, qList, klist)
+        if qry.sketchsize64 != ref.sketchsize64 or qry.bbits != ref.bbits:
+            raise RuntimeError("query and reference sketches have different sketch sizes")
+        qry_sk = qry.sketches
+        qry_clu = qry.clusters
+    table = ref.random_table
+    if random_correct and table is None:
+        # the reference refuses a DB without random matches at construction time
+        # (PopPUNK/sketchlib.py:461-466); distances without correction are still defined
+        sys.stderr.write("poppunk_amd: no random-match table in %s; random_correct ignored\n"
+                         % ref_db_name)
+    out, n_failed = query_arrays(ref.sketches, qry_sk, klist, ref.sketchsize64, ref.bbits, table,
+                                 ref.clusters, qry_clu, random_correct=random_correct,
+                                 jaccard=jaccard, devices=_devices(device_id))
+    if n_failed:
+        sys.stderr.write("poppunk_amd: fitting k-mer gradient failed for %d pair(s) "
+                         "(fewer than two k-mer lengths above the 5/s Jaccard floor); "
+                         "distances set to 0. Check for low quality genomes\n" % n_failed)
+    return out

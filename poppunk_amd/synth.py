@@ -1,0 +1,95 @@
+"""Synthetic bin-sketch generator.
+
+Sketching genomes is out of scope (pp_sketchlib.constructDatabase,
+PopPUNK/sketchlib.py:348-434), so benchmark and test inputs are synthesised
+directly as sketches with the on-disk shape of PopPUNK/web.py:14-61:
+per (sample, k) one uint64 vector of length sketchsize64*bbits, bit-sliced so
+that word [blk*bbits + b] holds bit b of bins 64*blk .. 64*blk+63.
+
+Population model: N/cluster_size clusters; per cluster and per k a root vector
+of uniform bbits-bit values; each member re-draws each bin independently with
+probability p_k = 1 - sqrt((1-a)(1-c)^k), a~U(0,0.3), c~U(0,0.02) per cluster,
+so same-cluster pairs have E[J_k] ~ (1-a)(1-c)^k (the model of
+PopPUNK/sketchlib.py:482) and different-cluster pairs match only by chance.
+"""
+import numpy as np
+
+DEFAULT_SEED = 20260928
+DEFAULT_KMERS = (13, 17, 21, 25, 29)      # --min-k 13 --max-k 29 --k-step 4 (__main__.py:77-79)
+
+
+def bitslice(bins, bbits):
+    """bin values [..., 64*sketchsize64] -> bit-sliced words [..., sketchsize64*bbits] uint64."""
+    bins = np.asarray(bins)
+    nb = bins.shape[-1]
+    assert nb % 64 == 0
+    s64 = nb // 64
+    b = bins.reshape(bins.shape[:-1] + (s64, 64)).astype(np.uint32)
+    out = np.empty(bins.shape[:-1] + (s64, bbits), dtype=np.uint64)
+    for bit in range(bbits):
+        plane = ((b >> np.uint32(bit)) & np.uint32(1)).astype(np.uint8)
+        packed = np.packbits(plane, axis=-1, bitorder="little")          # [..., s64, 8]
+        out[..., bit] = np.ascontiguousarray(packed).view("<u8")[..., 0]
+    return out.reshape(bins.shape[:-1] + (s64 * bbits,))
+
+
+def random_match_table(kmers, genome_length=2_000_000, n_clu=1):
+    """J_r(k) of docs/sketching.rst:107-114 (with exponent +l; the doc prints -l)."""
+    k = np.asarray(kmers, dtype=np.float64)
+    # r = 1 - (1 - 2*4^-k)^l, evaluated with log1p/expm1 so large k does not cancel to 0
+    r = -np.expm1(float(genome_length) * np.log1p(-2.0 * 4.0 ** (-k)))
+    jr = r / (2.0 - r)                                   # = r^2 / (2r - r^2)
+    tbl = np.repeat(jr[:, None, None], n_clu, axis=1)
+    tbl = np.repeat(tbl, n_clu, axis=2)
+    return np.ascontiguousarray(tbl, dtype=np.float32)
+
+
+def make_sketches(n, kmers=DEFAULT_KMERS, sketchsize64=16, bbits=14, cluster_size=50,
+                  seed=DEFAULT_SEED, chunk=4096, related=True):
+    """Return (sketches uint64 [n, nk, sketchsize64*bbits], cluster_of_sample int32 [n]).
+
+    related=True  : one "species" -- every cluster root is itself a mutated copy of a
+                    species root (between-cluster a~U(0.1,0.4), c~U(0.005,0.02)), so every
+                    pair has J well above the 5/s floor and goes through the full
+                    regression (the realistic PopPUNK case, and the honest benchmark case).
+    related=False : clusters are unrelated (SURVEY.md 8d as written): different-cluster pairs
+                    match only by chance, which exercises the failed-fit path.
+    """
+    rng = np.random.Generator(np.random.PCG64(seed))
+    kmers = np.asarray(kmers, dtype=np.int64)
+    nk = len(kmers)
+    nbins = 64 * sketchsize64
+    n_clusters = max(1, n // cluster_size)
+
+    def redraw_prob(a, c):
+        return 1.0 - np.sqrt((1.0 - a)[:, None] * (1.0 - c)[:, None] ** kmers[None, :])
+
+    a = rng.uniform(0.0, 0.3, size=n_clusters)
+    c = rng.uniform(0.0, 0.02, size=n_clusters)
+    p = redraw_prob(a, c)                                   # p[g, k]: per-member re-draw prob.
+    roots = rng.integers(0, 1 << bbits, size=(n_clusters, nk, nbins), dtype=np.uint16)
+    if related:
+        species = rng.integers(0, 1 << bbits, size=(nk, nbins), dtype=np.uint16)
+        pb = redraw_prob(rng.uniform(0.1, 0.4, size=n_clusters),
+                         rng.uniform(0.005, 0.02, size=n_clusters))
+        keep = rng.random(size=roots.shape, dtype=np.float32) >= pb[:, :, None].astype(np.float32)
+        roots = np.where(keep, species[None], roots)
+    member = np.arange(n) % n_clusters
+    out = np.empty((n, nk, sketchsize64 * bbits), dtype=np.uint64)
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        g = member[s:e]
+        bins = roots[g].copy()
+        redraw = rng.random(size=bins.shape, dtype=np.float32) < p[g][:, :, None].astype(np.float32)
+        fresh = rng.integers(0, 1 << bbits, size=bins.shape, dtype=np.uint16)
+        bins[redraw] = fresh[redraw]
+        out[s:e] = bitslice(bins, bbits)
+    return out, member.astype(np.int32)
+
+
+def boundary_for_quantile(dist, q=0.02):
+    """A slope-2 boundary (x_max, y_max) through the q-quantile of each distance column."""
+    d = np.asarray(dist, dtype=np.float64)
+    x = float(np.quantile(d[:, 0], q))
+    y = float(np.quantile(d[:, 1], q))
+    return 2.0 * max(x, 1e-4), 2.0 * max(y, 1e-4)

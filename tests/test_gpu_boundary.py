@@ -1,0 +1,179 @@
+"""Kernel 2 parity on a real MI355X: assignThreshold / edgeThreshold / generateTuples and the
+fused distance->edge path vs the CPU oracle (bit-exact: float32 compares and index math)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from poppunk_amd import engine, poppunk_refine, pp_sketchlib, synth
+
+pytestmark = pytest.mark.gpu
+
+KMERS = np.asarray(synth.DEFAULT_KMERS, dtype=np.int32)
+
+
+def grid10():
+    # test/test-refine.py:47-50
+    x = np.arange(0, 1, 0.1, dtype=np.float32)
+    y = np.arange(0, 1, 0.1, dtype=np.float32)
+    xv, yv = np.meshgrid(x, y)
+    return np.ascontiguousarray(np.hstack((xv.reshape(-1, 1), yv.reshape(-1, 1))), dtype=np.float32)
+
+
+def test_known_answers_grid(golden_dir):
+    ka = json.load(open(os.path.join(golden_dir, "boundary_known_answers.json")))
+    d = grid10()
+    for slope in (0, 1, 2):
+        a = poppunk_refine.assignThreshold(d, slope, 0.5, 0.5, 2)
+        w, o, out = ka["grid10"]["counts_within_online_outside"][str(slope)]
+        assert ((a == -1).sum(), (a == 0).sum(), (a == 1).sum()) == (w, o, out)
+        assert np.array_equal(a, oracle.assign_threshold(d, slope, 0.5, 0.5))
+    a2 = poppunk_refine.assignThreshold(d, 2, 0.5, 0.5)
+    assert np.flatnonzero(a2 == 0).tolist() == ka["grid10"]["slope2_online_rows"]
+
+
+def test_known_answers_tuples(golden_dir):
+    ka = json.load(open(os.path.join(golden_dir, "boundary_known_answers.json")))
+    assert poppunk_refine.generateTuples([-1] * 10, -1) == \
+        [tuple(t) for t in ka["condensed_n5_all_rows"]]
+    assert poppunk_refine.generateTuples([-1] * 6, -1, self=False, num_ref=3) == \
+        [tuple(t) for t in ka["generate_tuples_nonself_numref3_2queries_all"]]
+    assert poppunk_refine.generateTuples([-1] * 3, -1, self=True, num_ref=0, int_offset=10) == \
+        [tuple(t) for t in ka["generate_tuples_self_n3_offset10"]]
+    # edgeThreshold on an all-within 5-sample matrix gives the same condensed order
+    d = np.zeros((10, 2), dtype=np.float32)
+    assert poppunk_refine.edgeThreshold(d, 2, 0.5, 0.5) == \
+        [tuple(t) for t in ka["condensed_n5_all_rows"]]
+
+
+@pytest.mark.parametrize("samples", [2, 3, 100, 363])
+@pytest.mark.parametrize("slope", [0, 1, 2])
+def test_random_matrix_like_test_refine(samples, slope):
+    """test/test-refine.py:64-82 with a seeded matrix, compared element for element."""
+    rng = np.random.Generator(np.random.PCG64(100 + samples))
+    d = rng.random((samples * (samples - 1) // 2, 2)).astype(np.float32)
+    a = poppunk_refine.assignThreshold(d, slope, 0.5, 0.5)
+    assert np.array_equal(a, oracle.assign_threshold(d, slope, 0.5, 0.5))
+    e = poppunk_refine.edgeThreshold_array(d, slope, 0.5, 0.5)
+    assert np.array_equal(e, oracle.edge_threshold(d, slope, 0.5, 0.5))
+    # assign == -1 -> generateTuples is the exclusive variant
+    t = poppunk_refine.generateTuples_array(a, -1)
+    assert np.array_equal(t, oracle.generate_tuples(a.astype(np.int32), -1))
+    assert np.array_equal(t, oracle.edge_threshold(d, slope, 0.5, 0.5, inclusive=False))
+    # python-tuple form and membership, as the reference test checks it
+    tl = poppunk_refine.generateTuples([int(x) for x in a], -1)
+    assert tl == [tuple(x) for x in t.tolist()]
+
+
+def test_points_on_and_near_the_line():
+    """FMA sensitivity: points on / within 1 ulp of the slope-2 line
+    must classify exactly like the un-fused float32 CPU evaluation."""
+    rng = np.random.Generator(np.random.PCG64(20260928))
+    x_max, y_max = np.float32(0.0123), np.float32(0.217)
+    n = 1 << 20
+    x = (rng.random(n) * float(x_max)).astype(np.float32)
+    y = ((1.0 - x.astype(np.float64) / float(x_max)) * float(y_max)).astype(np.float32)
+    jitter = rng.integers(-1, 2, size=n)
+    y = np.where(jitter > 0, np.nextafter(y, np.float32(1)), np.where(jitter < 0, np.nextafter(y, np.float32(-1)), y)).astype(np.float32)
+    d = np.ascontiguousarray(np.stack([x, y], axis=1))
+    a = poppunk_refine.assignThreshold(d, 2, float(x_max), float(y_max))
+    want = oracle.assign_threshold(d, 2, float(x_max), float(y_max), threads=4)
+    assert np.array_equal(a, want)
+    assert (want == 0).sum() > 1000 and (want == -1).sum() > 1000 and (want == 1).sum() > 1000
+    # numpy float32 restatement of ((y0*x_max)+(x0*y_max))-(x_max*y_max), un-fused
+    s = (y * x_max + x * y_max) - x_max * y_max
+    assert np.array_equal(np.sign(s).astype(np.float32), want)
+
+
+def test_degenerate_boundary_sqrt_branch():
+    d = np.asarray([[0, 0], [0.1, 0.2], [0, 0.3]], dtype=np.float32)
+    for xm, ym in ((0.0, 0.5), (0.5, 0.0)):
+        assert np.array_equal(poppunk_refine.assignThreshold(d, 2, xm, ym),
+                              oracle.assign_threshold(d, 2, xm, ym))
+
+
+def test_generate_tuples_nonself_and_labels():
+    rng = np.random.Generator(np.random.PCG64(5))
+    num_ref, num_q = 37, 23
+    a = rng.integers(0, 4, size=num_ref * num_q).astype(np.int32)
+    for label in (0, 3):
+        got = poppunk_refine.generateTuples_array(a, label, self=False, num_ref=num_ref, int_offset=5)
+        want = oracle.generate_tuples(a, label, self=False, num_ref=num_ref, int_offset=5)
+        assert np.array_equal(got, want)
+    assert poppunk_refine.generateTuples(a, 9, self=False, num_ref=num_ref) == []
+
+
+def test_noconvert_type_errors():
+    d64 = np.zeros((10, 2), dtype=np.float64)
+    with pytest.raises(TypeError):
+        poppunk_refine.assignThreshold(d64, 2, 0.5, 0.5)
+    with pytest.raises(TypeError):
+        poppunk_refine.edgeThreshold(np.zeros((2, 10), dtype=np.float32).T, 2, 0.5, 0.5)
+    with pytest.raises(RuntimeError):
+        poppunk_refine.edgeThreshold(np.zeros((4, 2), dtype=np.float32), 2, 0.5, 0.5)  # 4 != n(n-1)/2
+
+
+def test_large_stream_and_edge_order():
+    """n = 3000 samples -> 4.5e6 rows: many compaction blocks; edges must come out in row order."""
+    n = 3000
+    rng = np.random.Generator(np.random.PCG64(1))
+    d = rng.random((n * (n - 1) // 2, 2)).astype(np.float32) * np.float32(0.2)
+    e = poppunk_refine.edgeThreshold_array(d, 2, 0.05, 0.06)
+    want = oracle.edge_threshold(d, 2, 0.05, 0.06)
+    assert len(want) > 10000 and np.array_equal(e, want)
+    a = poppunk_refine.assignThreshold(d, 2, 0.05, 0.06)
+    assert np.array_equal(a, oracle.assign_threshold(d, 2, 0.05, 0.06, threads=4))
+
+
+@pytest.mark.parametrize("inclusive", [True, False])
+@pytest.mark.parametrize("slope", [0, 1, 2])
+def test_fused_edges_equal_two_step(slope, inclusive):
+    sk, _ = synth.make_sketches(500, KMERS, cluster_size=25)
+    tbl = synth.random_match_table(KMERS)
+    # the invariant is fused == two-step on the SAME distances, so the two-step input is the
+    # GPU matrix (its agreement with the oracle is test_gpu_dist.py's job)
+    dist, _ = pp_sketchlib.query_arrays(sk, None, KMERS, 16, 14, tbl)
+    odist, _ = oracle.query(sk, None, KMERS, 16, 14, tbl, threads=4)
+    assert np.abs(dist - odist).max() <= 1e-6
+    x_max, y_max = synth.boundary_for_quantile(dist, 0.1)
+    scale = (np.float32(dist[:, 0].max()), np.float32(dist[:, 1].max()))
+    scaled = np.ascontiguousarray(dist / np.asarray(scale, dtype=np.float32))   # models.py:1085
+    assert scaled.dtype == np.float32
+    xs, ys = x_max / float(scale[0]), y_max / float(scale[1])
+    want = oracle.edge_threshold(scaled, slope, xs, ys, inclusive=inclusive)
+    db = engine.SketchDB(sk, 16, 14, device=0)
+    got, _ = engine.dist_edges(db, None, KMERS, tbl, slope=slope, x_max=xs, y_max=ys, scale=scale,
+                               inclusive=inclusive)
+    assert len(want) > 100
+    assert np.array_equal(got.cpu().numpy(), want)
+    # band-split edge lists concatenate to the whole (multi-GPU config 5 shape)
+    b = engine.band_split(500, 0, 4)
+    parts = [engine.dist_edges(db, None, KMERS, tbl, slope=slope, x_max=xs, y_max=ys, scale=scale,
+                               inclusive=inclusive, q_begin=b[i], q_end=b[i + 1], cap=16)[0]
+             for i in range(4)]
+    import torch
+    assert np.array_equal(torch.cat(parts).cpu().numpy(), want)
+    db.close()
+
+
+def test_fused_edges_ref_query():
+    sk, _ = synth.make_sketches(400, KMERS, cluster_size=20)
+    tbl = synth.random_match_table(KMERS)
+    ref, qry = sk[:290], sk[290:]
+    dist, _ = pp_sketchlib.query_arrays(ref, qry, KMERS, 16, 14, tbl)
+    x_max, y_max = synth.boundary_for_quantile(dist, 0.1)
+    want = oracle.edge_threshold(dist, 2, x_max, y_max, n_ref=290, inclusive=False)
+    rdb, qdb = engine.SketchDB(ref, 16, 14), engine.SketchDB(qry, 16, 14)
+    got, _ = engine.dist_edges(rdb, qdb, KMERS, tbl, slope=2, x_max=x_max, y_max=y_max,
+                               inclusive=False)
+    assert len(want) > 100 and np.array_equal(got.cpu().numpy(), want)
+    # the unfused device path gives the same list
+    dd, _ = engine.dist(rdb, qdb, KMERS, tbl)
+    e2 = engine.edge_threshold_dev(dd, 2, x_max, y_max, n_ref=290, inclusive=False)
+    assert np.array_equal(e2.cpu().numpy(), want)
+    a = engine.assign_threshold_dev(dd, 2, x_max, y_max)
+    assert np.array_equal(a.cpu().numpy(), oracle.assign_threshold(dist, 2, x_max, y_max))
+    rdb.close()
+    qdb.close()

@@ -1,0 +1,239 @@
+"""Kernel 1 parity on a real MI355X: HIP path (through the C ABI) vs the CPU oracle.
+
+Integer half (match counts): bit-exact.  Regressed distances: |d| <= 1e-6 (the
+tolerance BASELINE.json's north_star states; fp64 regression on both sides, the
+only difference is the device libm's log/exp vs glibc's).
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from poppunk_amd import _lib, engine, pp_sketchlib, synth
+
+pytestmark = pytest.mark.gpu
+
+KMERS = np.asarray(synth.DEFAULT_KMERS, dtype=np.int32)
+TOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def sk300():
+    sk, member = synth.make_sketches(300, KMERS, cluster_size=30)
+    return sk, member
+
+
+@pytest.fixture(scope="module")
+def tbl1():
+    return synth.random_match_table(KMERS)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 63, 64, 65, 129, 300])
+def test_counts_self_bit_exact(sk300, n):
+    sk = sk300[0][:n]
+    got, _ = pp_sketchlib.query_arrays(sk, None, KMERS, 16, 14, counts=True)
+    want = oracle.match_counts(sk, None, 16, 14, threads=4)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("nr,nq", [(1, 1), (5, 3), (64, 64), (65, 17), (130, 70), (257, 9)])
+def test_counts_ref_query_bit_exact(sk300, nr, nq):
+    sk = sk300[0]
+    ref, qry = sk[:nr], sk[300 - nq:]
+    got, _ = pp_sketchlib.query_arrays(ref, qry, KMERS, 16, 14, counts=True)
+    want = oracle.match_counts(ref, qry, 16, 14, threads=4)
+    assert np.array_equal(got, want)
+
+
+def test_identical_and_disjoint_sketches():
+    rng = np.random.Generator(np.random.PCG64(7))
+    bins = rng.integers(0, 1 << 14, size=(3, 5, 1024), dtype=np.uint16)
+    bins[1] = bins[0]                                  # identical pair -> all 1024 bins match
+    bins[2] = (bins[0] + 1) & 0x3FFF                   # no bin equal
+    sk = synth.bitslice(bins, 14)
+    got, _ = pp_sketchlib.query_arrays(sk, None, KMERS, 16, 14, counts=True)
+    assert np.array_equal(got[0], np.full(5, 1024))     # (0,1)
+    assert np.array_equal(got[1], np.zeros(5))          # (0,2)
+    d, failed = pp_sketchlib.query_arrays(sk, None, KMERS, 16, 14, None, random_correct=False)
+    assert np.array_equal(d[0], [0.0, 0.0])             # identical genomes: J=1 at every k
+    assert failed == 2 and np.array_equal(d[1:], np.zeros((2, 2)))
+
+
+@pytest.mark.parametrize("tile", [(16, 4), (8, 8), (8, 4)])
+def test_distances_self(sk300, tbl1, tile):
+    sk = sk300[0]
+    lib = _lib.lib()
+    _lib.check(lib.ppk_set_tile(*tile))
+    try:
+        got, gf = pp_sketchlib.query_arrays(sk, None, KMERS, 16, 14, tbl1)
+    finally:
+        lib.ppk_set_tile(0, 0)
+    want, wf = oracle.query(sk, None, KMERS, 16, 14, tbl1, threads=4)
+    assert gf == wf
+    assert np.abs(got - want).max() <= TOL
+    assert got.dtype == np.float32 and got.flags["C_CONTIGUOUS"]
+
+
+def test_distances_ref_query(sk300, tbl1):
+    sk = sk300[0]
+    ref, qry = sk[:171], sk[171:]
+    got, gf = pp_sketchlib.query_arrays(ref, qry, KMERS, 16, 14, tbl1)
+    want, wf = oracle.query(ref, qry, KMERS, 16, 14, tbl1, threads=4)
+    assert gf == wf and np.abs(got - want).max() <= TOL
+
+
+def test_no_random_correction(sk300):
+    sk = sk300[0][:120]
+    got, _ = pp_sketchlib.query_arrays(sk, None, KMERS, 16, 14, None, random_correct=False)
+    want, _ = oracle.query(sk, None, KMERS, 16, 14, None, random_correct=False, threads=4)
+    assert np.abs(got - want).max() <= TOL
+
+
+def test_jaccard_mode(sk300, tbl1):
+    sk = sk300[0][:150]
+    for rc in (True, False):
+        got, _ = pp_sketchlib.query_arrays(sk, None, KMERS, 16, 14, tbl1, random_correct=rc,
+                                           jaccard=True)
+        want, _ = oracle.query(sk, None, KMERS, 16, 14, tbl1, random_correct=rc, jaccard=True,
+                               threads=4)
+        assert got.shape == (150 * 149 // 2, 5)
+        assert np.abs(got - want).max() <= 1e-7
+
+
+def test_multi_cluster_random_table(sk300):
+    sk, member = sk300
+    rng = np.random.Generator(np.random.PCG64(11))
+    n_clu = 3
+    tbl = synth.random_match_table(KMERS, n_clu=n_clu)
+    tbl = (tbl * rng.uniform(0.5, 3.0, size=tbl.shape)).astype(np.float32)
+    clu = (member % n_clu).astype(np.uint16)
+    got, gf = pp_sketchlib.query_arrays(sk, None, KMERS, 16, 14, tbl, clu)
+    want, wf = oracle.query(sk, None, KMERS, 16, 14, tbl, clu, clu, threads=4)
+    assert gf == wf and np.abs(got - want).max() <= TOL
+    ref, qry = sk[:200], sk[200:]
+    got, gf = pp_sketchlib.query_arrays(ref, qry, KMERS, 16, 14, tbl, clu[:200], clu[200:])
+    want, wf = oracle.query(ref, qry, KMERS, 16, 14, tbl, clu[:200], clu[200:], threads=4)
+    assert gf == wf and np.abs(got - want).max() <= TOL
+
+
+def test_unrelated_clusters_failed_fits(tbl1):
+    """Different-cluster pairs match only by chance -> < 2 usable k -> (0,0), counted."""
+    sk, _ = synth.make_sketches(200, KMERS, cluster_size=20, related=False)
+    got, gf = pp_sketchlib.query_arrays(sk, None, KMERS, 16, 14, tbl1)
+    want, wf = oracle.query(sk, None, KMERS, 16, 14, tbl1, threads=4)
+    assert gf == wf and gf > 0
+    assert np.abs(got - want).max() <= TOL
+
+
+def test_bands_concatenate_to_whole(sk300, tbl1):
+    """The multi-GPU split: any band partition of the query axis reproduces the matrix."""
+    import torch
+    sk = sk300[0]
+    db = engine.SketchDB(sk, 16, 14, device=0)
+    whole, _ = engine.dist(db, None, KMERS, tbl1)
+    for parts in (2, 3, 8):
+        b = engine.band_split(300, 0, parts)
+        pieces = [engine.dist(db, None, KMERS, tbl1, q_begin=b[i], q_end=b[i + 1])[0]
+                  for i in range(parts)]
+        assert torch.equal(torch.cat(pieces), whole)
+    # un-aligned band edges are allowed as well
+    pieces = [engine.dist(db, None, KMERS, tbl1, q_begin=a, q_end=e)[0]
+              for a, e in ((0, 37), (37, 38), (38, 201), (201, 300))]
+    assert torch.equal(torch.cat(pieces), whole)
+    want, _ = oracle.query(sk, None, KMERS, 16, 14, tbl1, threads=4)
+    assert np.abs(whole.cpu().numpy() - want).max() <= TOL
+    db.close()
+
+
+def test_host_query_multi_device_split(sk300, tbl1):
+    """ppk_query's band loop with a device list (the same GPU twice on a 1-GPU box)."""
+    sk = sk300[0][:200]
+    one, _ = pp_sketchlib.query_arrays(sk, None, KMERS, 16, 14, tbl1, devices=(0,))
+    two, _ = pp_sketchlib.query_arrays(sk, None, KMERS, 16, 14, tbl1, devices=(0, 0, 0))
+    assert np.array_equal(one, two)
+
+
+def test_config1_real_sketch_and_default_sketch_size(golden_dir):
+    """BASELINE config 1 shape: s = 9984 (sketchsize64 156), k = 13..28 step 3 -> 6 k-mer
+    lengths x 14-bit counts = 84 bits -> the 128-bit packed path.  The real sketch of
+    test/json_sketch.txt must match itself in all 9984 bins at every k -> (0, 0)."""
+    import os
+    z = np.load(os.path.join(golden_dir, "json_sketch.npz"))
+    kmers = z["kmers"]
+    s64, bbits = int(z["sketchsize64"]), int(z["bbits"])
+    real = z["sketch"][None]                                   # [1, 6, 2184]
+    syn, _ = synth.make_sketches(28, kmers, sketchsize64=s64, bbits=bbits, cluster_size=7, seed=5)
+    sk = np.concatenate([real, real, syn])                     # sample 0 == sample 1
+    tbl = synth.random_match_table(kmers)
+    counts, _ = pp_sketchlib.query_arrays(sk, None, kmers, s64, bbits, counts=True)
+    assert np.array_equal(counts, oracle.match_counts(sk, None, s64, bbits, threads=4))
+    assert np.array_equal(counts[0], np.full(6, 9984))
+    got, gf = pp_sketchlib.query_arrays(sk, None, kmers, s64, bbits, tbl)
+    want, wf = oracle.query(sk, None, kmers, s64, bbits, tbl, threads=4)
+    assert gf == wf and np.abs(got - want).max() <= TOL
+    assert np.array_equal(got[0], [0.0, 0.0])
+
+
+@pytest.mark.parametrize("s64,bbits", [(4, 8), (3, 14), (20, 10), (300, 14)])
+def test_other_sketch_shapes(s64, bbits):
+    """Generic-bbits kernel, odd block counts (chunk tail), and 64*s64 >= 2^bbits, where the
+    collision adjustment of row a4 is non-zero."""
+    kmers = np.asarray([13, 17, 21, 25], dtype=np.int32)
+    sk, _ = synth.make_sketches(90, kmers, sketchsize64=s64, bbits=bbits, cluster_size=9, seed=3)
+    tbl = synth.random_match_table(kmers)
+    counts, _ = pp_sketchlib.query_arrays(sk, None, kmers, s64, bbits, counts=True)
+    assert np.array_equal(counts, oracle.match_counts(sk, None, s64, bbits, threads=4))
+    got, gf = pp_sketchlib.query_arrays(sk, None, kmers, s64, bbits, tbl)
+    want, wf = oracle.query(sk, None, kmers, s64, bbits, tbl, threads=4)
+    assert gf == wf and np.abs(got - want).max() <= TOL
+
+
+def test_two_kmers_minimum():
+    kmers = np.asarray([13, 29], dtype=np.int32)
+    sk, _ = synth.make_sketches(70, kmers, cluster_size=10, seed=9)
+    got, gf = pp_sketchlib.query_arrays(sk, None, kmers, 16, 14, None, random_correct=False)
+    want, wf = oracle.query(sk, None, kmers, 16, 14, None, random_correct=False, threads=4)
+    assert gf == wf and np.abs(got - want).max() <= TOL
+
+
+# ---- BASELINE sizes: size-independent properties ---------------------------------------
+
+@pytest.fixture(scope="module")
+def big():
+    sk, _ = synth.make_sketches(10000, KMERS)
+    return sk
+
+
+def test_full_size_properties_10k(big, tbl1):
+    """configs[2] workload (10 000 self, 49 995 000 pairs).  The oracle cannot cover it in
+    seconds, so: (1) a ref x query run of a sample against the whole DB must equal the
+    matching rows of the self run (two different tilings/row orders of the same pairs);
+    (2) an oracle spot check on rows of scattered queries; (3) checksum of band results
+    equals the checksum of the whole."""
+    import torch
+    db = engine.SketchDB(big, 16, 14, device=0)
+    n = 10000
+    whole, nf = engine.dist(db, None, KMERS, tbl1)
+    assert whole.shape == (n * (n - 1) // 2, 2)
+    assert torch.isfinite(whole).all()
+    assert float(whole.min()) >= 0.0 and float(whole.max()) <= 1.0
+
+    qsel = np.asarray([0, 1, 63, 64, 4999, 9936, 9998], dtype=np.int64)
+    qdb = engine.SketchDB(big[qsel], 16, 14, device=0)
+    sub, _ = engine.dist(db, qdb, KMERS, tbl1)                  # row = qi*n + r
+    sub = sub.cpu().numpy().reshape(len(qsel), n, 2)
+    w = whole.cpu().numpy()
+    for a, q in enumerate(qsel):
+        start = q * n - q * (q + 1) // 2
+        assert np.array_equal(sub[a, q + 1:], w[start:start + n - 1 - q])    # pairs (q, r>q)
+    want, _ = oracle.query(big, big[qsel[:3]], KMERS, 16, 14, tbl1, threads=8)
+    assert np.abs(sub[:3].reshape(-1, 2) - want).max() <= TOL
+
+    b = engine.band_split(n, 0, 8)
+    s = 0.0
+    for i in range(8):
+        piece, _ = engine.dist(db, None, KMERS, tbl1, q_begin=b[i], q_end=b[i + 1])
+        s += float(piece.double().sum())
+    assert abs(s - float(whole.double().sum())) <= 1e-6 * abs(s)
+    db.close()
+    qdb.close()
