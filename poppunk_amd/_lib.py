@@ -55,6 +55,26 @@ SIGNATURES = {
 _lib = None
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  The PyTorch-ROCm wheel bundles its own
+    libamdhip64 (SONAME libamdhip64.so.7, the name libppk_hip.so NEEDs).  If
+    libppk_hip.so were loaded first it would pull /opt/rocm's copy, and a later
+    `import torch` would load the wheel's copy next to it: two runtimes fighting over
+    the device ("No HIP GPUs are available").  So the wheel's copy is loaded first,
+    by path, and both libppk_hip.so and torch then resolve to that one instance.
+    Without torch installed, /opt/rocm's runtime is used."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def lib():
     """Load libppk_hip.so; raises RuntimeError (never falls back) when it is unavailable."""
     global _lib
@@ -63,6 +83,7 @@ def lib():
             raise RuntimeError(
                 "poppunk_amd: HIP extension %s not built (run __graft_entry__.build() / "
                 "make -C poppunk_amd/csrc); there is no CPU fallback" % SO_PATH)
+        _preload_hip_runtime()
         try:
             handle = C.CDLL(SO_PATH)
         except OSError as e:
