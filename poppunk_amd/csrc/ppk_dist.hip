@@ -4,17 +4,23 @@
 // PopPUNK/sketchlib.py:528-537,:584-593); arithmetic per SURVEY.md 8a rows a3-a7.
 //
 // Mapping to the hardware (this is integer set-intersection: no MFMA anywhere):
-//  * sketches are resident as [k][word][sample]; a wavefront's 64 lanes own 64
-//    consecutive REF samples, so one word of 64 refs is one coalesced 512-B row;
-//  * a workgroup stages the ref rows of a few 64-bin blocks through LDS
-//    (register-prefetched one chunk ahead, read back with conflict-free
-//    ds_read_b64), shared by its NW wavefronts;
-//  * each wavefront compares those 64 refs against TQ QUERY samples whose words
-//    are wave-uniform: they arrive through the scalar unit (s_load_dwordx16 from
-//    the same [k][word][sample] array) and feed the VALU as SGPR operands, so a
-//    bin-plane compare-and-accumulate is ONE v_bitop3_b32 per 32 bins per pair:
+//  * sketches are resident as [k][word][sample], so one bit-plane word of 256
+//    consecutive samples is one contiguous 2-KB row;
+//  * a bin-plane compare-and-accumulate is ONE v_bitop3_b32 per 32 bins per pair:
 //        bits = bits & ~(ref ^ qry)            (truth table 0x90)
-//    and a 64-bin block costs 28 v_bitop3 + 2 v_bcnt per pair;
+//    and a 64-bin block costs 28 v_bitop3 + 2 v_bcnt per pair (2400 VALU/pair);
+//  * dist_kernel_v2 (the hot path, bbits = 14): an 8-wavefront workgroup owns a
+//    256-ref x 32-query pair tile.  Per 64-bin block its 14 ref rows (28 KB) and
+//    14 query rows (3.5 KB) are copied HBM/L2 -> LDS by global_load_lds_dwordx4
+//    (LDS-DMA: no VGPR round trip), double-buffered so the copy of block b+1
+//    runs under the compare of block b with ONE s_barrier per block.  Each lane
+//    owns 4 refs (two ds_read_b128 per plane, conflict-free) x the wavefront's
+//    4 queries (two broadcast ds_read_b128), i.e. a 4x4 register tile: every
+//    operand is a VGPR (measured on MI355X: v_bitop3 with an SGPR operand issues
+//    at ~4.2 clk, all-VGPR at ~2.8 clk; tools/ubench_valu.hip);
+//  * dist_kernel (v1; generic bbits and A/B experiments): 64 refs per wavefront
+//    staged through LDS, query words through the scalar unit (s_load_dwordx16)
+//    as SGPR operands;
 //  * per-k match counts are packed into a 64/128-bit shift register per pair,
 //    and after the last k the lane regresses log J on k in fp64 (log J comes
 //    from a device-built table indexed by (cluster pair, k, count): the count
@@ -358,6 +364,228 @@ dist_kernel(const uint64_t *__restrict__ refT, const uint32_t *__restrict__ qryT
   }
 }
 
+
+// ---- v2: 256 x 32 pair tile, LDS-DMA double buffer, 4x4 register tile ----------------------
+
+#define PPK_GPTR(p) ((const __attribute__((address_space(1))) void *)(p))
+#define PPK_LPTR(p) ((__attribute__((address_space(3))) void *)(p))
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// spread the 32 bits of x to the even bit positions of a 64-bit word (wave-uniform: SALU)
+__device__ __forceinline__ uint64_t spread_even(uint32_t v) {
+  uint64_t x = v;
+  x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+  x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+  x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+  x = (x | (x << 2)) & 0x3333333333333333ull;
+  x = (x | (x << 1)) & 0x5555555555555555ull;
+  return x;
+}
+
+constexpr int V2_NW = 8, V2_R = 4, V2_TQ = 4, V2_RT = 256, V2_QT = 32, V2_BB = 14;
+
+template <int MODE, typename PackT>
+__global__ void __launch_bounds__(V2_NW * 64, 4)
+dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ qryT,
+               const double *__restrict__ lut, const uint16_t *__restrict__ ref_clu,
+               const uint16_t *__restrict__ qry_clu, const float *__restrict__ rtab,
+               void *__restrict__ out, unsigned long long *__restrict__ n_failed,
+               uint64_t *__restrict__ mask_out, const DistParams p) {
+  constexpr int NW = V2_NW, R = V2_R, TQ = V2_TQ, BB = V2_BB;
+  constexpr int REF_U4 = BB * 128;            // 14 rows x 256 samples x 8 B = 28 KB
+  constexpr int QRY_U4 = BB * 16;             // 14 rows x 32 samples x 8 B = 3.5 KB
+  constexpr int CHUNK_U4 = REF_U4 + QRY_U4;   // one 64-bin block of the tile
+  __shared__ u32x4 lds[2 * CHUNK_U4];         // double buffer: 63 KB -> 2 workgroups / CU
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const size_t rt = blockIdx.x;
+  const size_t r0 = rt * V2_RT;
+  const size_t q0 = (p.q_tile0 + blockIdx.y) * V2_QT;
+  const size_t qw0 = q0 + (size_t)wave * TQ;
+  if (p.self && r0 + (V2_RT - 1) <= q0) return;   // no pair with r > q in this tile
+  const bool wave_active =
+      !(p.self && r0 + (V2_RT - 1) <= qw0) && qw0 < p.q_end && qw0 + TQ > p.q_begin;
+  // lane l owns refs r0 + {2l, 2l+1, 128+2l, 128+2l+1}: two conflict-free ds_read_b128 per plane
+  size_t rr[R];
+  rr[0] = r0 + 2 * lane;
+  rr[1] = rr[0] + 1;
+  rr[2] = rr[0] + 128;
+  rr[3] = rr[0] + 129;
+
+  const int total = p.nk * p.s64;             // one chunk per (k, 64-bin block)
+
+  auto issue_dma = [&](int g, int buf) {
+    const size_t grow0 = (size_t)g * BB;      // (k*s64 + blk)*14 = k*words + blk*14
+    u32x4 *base = lds + buf * CHUNK_U4;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int i = wave + NW * t;            // 32 one-KB pieces per chunk, 4 per wavefront
+      if (i < 2 * BB) {
+        const uint64_t *src = refT + (grow0 + (i >> 1)) * p.npad_r + r0 + (i & 1) * 128 + lane * 2;
+        __builtin_amdgcn_global_load_lds(PPK_GPTR(src), PPK_LPTR(base + i * 64), 16, 0, 0);
+      } else {
+        const int j = i - 2 * BB;             // 4 query rows per piece: 16 lanes x 16 B each
+        const int plane = 4 * j + (lane >> 4);
+        if (plane < BB) {
+          const uint64_t *src = qryT + (grow0 + plane) * p.npad_q + q0 + 2 * (lane & 15);
+          __builtin_amdgcn_global_load_lds(PPK_GPTR(src), PPK_LPTR(base + REF_U4 + j * 64), 16, 0, 0);
+        }
+      }
+    }
+  };
+
+  uint32_t cnt[R][TQ];
+  PackT packed[R][TQ];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int q = 0; q < TQ; ++q) {
+      cnt[r][q] = 0;
+      packed[r][q] = 0;
+    }
+
+  issue_dma(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  int k = 0, blk = 0;
+  for (int g = 0; g < total; ++g) {
+    const int buf = g & 1;
+    // the other buffer was last read in iteration g-1, which every wave left through the barrier
+    if (g + 1 < total) issue_dma(g + 1, buf ^ 1);
+
+    if (wave_active) {
+      const u32x4 *rp = lds + buf * CHUNK_U4 + lane;
+      const u32x4 *qp = lds + buf * CHUNK_U4 + REF_U4 + wave * 2;
+      uint32_t lo[R][TQ], hi[R][TQ];
+#pragma unroll
+      for (int b = 0; b < BB; ++b) {
+        const u32x4 a0 = rp[b * 128], a1 = rp[b * 128 + 64];
+        const u32x4 s0 = qp[b * 16], s1 = qp[b * 16 + 1];
+        const uint32_t ax[R] = {a0.x, a0.z, a1.x, a1.z}, ay[R] = {a0.y, a0.w, a1.y, a1.w};
+        const uint32_t sx[TQ] = {s0.x, s0.z, s1.x, s1.z}, sy[TQ] = {s0.y, s0.w, s1.y, s1.w};
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int q = 0; q < TQ; ++q) {
+            if (b == 0) {
+              lo[r][q] = ~(ax[r] ^ sx[q]);
+              hi[r][q] = ~(ay[r] ^ sy[q]);
+            } else {
+              lo[r][q] = __builtin_amdgcn_bitop3_b32(lo[r][q], ax[r], sx[q], 0x90);
+              hi[r][q] = __builtin_amdgcn_bitop3_b32(hi[r][q], ay[r], sy[q], 0x90);
+            }
+          }
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int q = 0; q < TQ; ++q) cnt[r][q] += __popc(lo[r][q]) + __popc(hi[r][q]);
+
+      if (blk == p.s64 - 1) {
+        // ---- end of one k: consume the counts ----------------------------------
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int q = 0; q < TQ; ++q) {
+            if constexpr (MODE == MODE_DIST || MODE == MODE_MASK) {
+              packed[r][q] |= (PackT)cnt[r][q] << (p.cnt_bits * k);
+            } else {
+              const size_t qq = qw0 + q, rf = rr[r];
+              const bool valid = rf < p.n_ref && qq >= p.q_begin && qq < p.q_end && (!p.self || rf > qq);
+              if (valid) {
+                const size_t row = (p.self ? qq * p.n_ref - (qq * (qq + 1)) / 2 + (rf - qq - 1)
+                                           : qq * p.n_ref + rf) - p.row_base;
+                if constexpr (MODE == MODE_COUNTS) {
+                  static_cast<uint32_t *>(out)[row * p.nk + k] = cnt[r][q];
+                } else {
+                  double jr = 0.0;
+                  if (p.random_correct) {
+                    const int cr = ref_clu ? ref_clu[rf] : 0;
+                    const int cq = qry_clu ? qry_clu[qq] : 0;
+                    jr = (double)rtab[((size_t)k * p.n_clu + cr) * p.n_clu + cq];
+                  }
+                  static_cast<float *>(out)[row * p.nk + k] =
+                      (float)observed_excess(jaccard_obs(cnt[r][q], p.s64, BB), jr);
+                }
+              }
+            }
+            cnt[r][q] = 0;
+          }
+      }
+    }
+    if (++blk == p.s64) {
+      blk = 0;
+      ++k;
+    }
+    // my DMA pieces have landed; after the barrier everyone's have, and everyone has
+    // finished reading `buf` (all ds_read results were consumed above)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+
+  // ---- epilogue: regression (+ boundary) per pair ---------------------------
+  if constexpr (MODE == MODE_DIST || MODE == MODE_MASK) {
+    if (!wave_active) return;
+    int cr[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) cr[r] = (ref_clu && rr[r] < p.n_ref) ? ref_clu[rr[r]] : 0;
+#pragma unroll
+    for (int q = 0; q < TQ; ++q) {
+      const size_t qq = qw0 + q;   // wave-uniform
+      if (qq < p.q_begin || qq >= p.q_end) continue;
+      const int cq = qry_clu ? qry_clu[qq] : 0;
+      const size_t rowq = (p.self ? qq * p.n_ref - (qq * (qq + 1)) / 2 - qq - 1 : qq * p.n_ref) - p.row_base;
+      uint64_t ball[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const size_t rf = rr[r];
+        const bool valid = rf < p.n_ref && (!p.self || rf > qq);
+        const double *lutp = lut + (size_t)(cr[r] * p.n_clu + cq) * p.lut_cpstride;
+        float core = 0.0f, acc = 0.0f;
+        bool failed = false;
+        if (valid) fit_packed<PackT>(packed[r][q], lutp, p, core, acc, failed);
+        if (n_failed) {
+          const uint64_t fm = __ballot(valid && failed);
+          if (fm && lane == 0) atomicAdd(n_failed, (unsigned long long)__popcll(fm));
+        }
+        if constexpr (MODE == MODE_DIST) {
+          if (valid) {
+            float2 v;
+            v.x = core;
+            v.y = acc;
+            static_cast<float2 *>(out)[rowq + rf] = v;
+          }
+        } else {
+          bool pred = false;
+          if (valid) {
+            const float xs = __fdiv_rn(core, p.scale_x), ys = __fdiv_rn(acc, p.scale_y);
+            const float s = ppk_line_dist(xs, ys, p.x_max, p.y_max, p.slope);
+            pred = p.inclusive ? (s <= 0.0f) : (s < 0.0f);
+          }
+          ball[r] = __ballot(pred);
+        }
+      }
+      if constexpr (MODE == MODE_MASK) {
+        // ball[0]/ball[1]: even/odd refs of r0..r0+127; ball[2]/ball[3]: of r0+128..r0+255.
+        // Interleave them into the [q][ref/64] bitmask words the compaction pass reads.
+        if (lane == 0) {
+          uint64_t *mrow = mask_out + (qq - p.q_begin) * p.n_rtiles + rt * 4;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const uint64_t e = ball[2 * h], o = ball[2 * h + 1];
+            const uint64_t w0 = spread_even((uint32_t)e) | (spread_even((uint32_t)o) << 1);
+            const uint64_t w1 = spread_even((uint32_t)(e >> 32)) | (spread_even((uint32_t)(o >> 32)) << 1);
+            if (rt * 4 + 2 * h < p.n_rtiles) mrow[2 * h] = w0;
+            if (rt * 4 + 2 * h + 1 < p.n_rtiles) mrow[2 * h + 1] = w1;
+          }
+        }
+      }
+    }
+  }
+}
+
 // ---- host-side launch ------------------------------------------------------
 
 namespace {
@@ -389,28 +617,46 @@ int launch_variant(const ppk_db *ref, const ppk_db *qry, const double *d_lut, co
 }
 
 template <int MODE, typename PackT>
+int launch_v2(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const float *d_rtab,
+              void *d_out, unsigned long long *d_n_failed, uint64_t *d_mask, DistParams &p,
+              hipStream_t s) {
+  p.q_tile0 = p.q_begin / V2_QT;
+  const size_t q_tiles = (p.q_end + V2_QT - 1) / V2_QT - p.q_tile0;
+  const size_t r_tiles = (p.n_ref + V2_RT - 1) / V2_RT;
+  if (q_tiles == 0 || r_tiles == 0) return PPK_OK;
+  if (q_tiles > 65535) return ppk_fail(PPK_ERR_ARG, "query band too tall for one launch");
+  const bool use_clu = p.random_correct && p.n_clu > 1;
+  ppk_set_kernel_name("dist_kernel_v2<256x32,lds-dma>");
+  ppk_prof_begin(s);
+  hipLaunchKernelGGL((dist_kernel_v2<MODE, PackT>), dim3((unsigned)r_tiles, (unsigned)q_tiles),
+                     dim3(V2_NW * 64), 0, s, ref->d_skT, qry->d_skT, d_lut,
+                     use_clu ? ref->d_clu : nullptr, use_clu ? qry->d_clu : nullptr, d_rtab, d_out,
+                     d_n_failed, d_mask, p);
+  ppk_prof_end(s);
+  PPK_HIP(hipGetLastError());
+  return PPK_OK;
+}
+
+template <int MODE, typename PackT>
 int launch_tiles(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const float *d_rtab,
                  void *d_out, unsigned long long *d_n_failed, uint64_t *d_mask, DistParams &p,
                  hipStream_t s) {
-  int tq = g_tile_tq, nw = g_tile_nw;
-  if (tq == 0) {
-    tq = 16;
-    nw = 4;
-  }
-  if (p.bbits != 14) {
+  if (p.bbits != 14)
     return launch_variant<8, 4, 0, MODE, PackT>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask,
                                                 p, s, "dist_kernel<8,4,generic>");
-  }
-  if constexpr ((MODE == MODE_DIST || MODE == MODE_MASK) && sizeof(PackT) == 8) {
-    if (tq == 16 && nw == 4)
+  // v1 tiles are kept for A/B measurements of the plain distance mode only
+  if constexpr (MODE == MODE_DIST && sizeof(PackT) == 8) {
+    if (g_tile_tq == 16 && g_tile_nw == 4)
       return launch_variant<16, 4, 14, MODE, PackT>(ref, qry, d_lut, d_rtab, d_out, d_n_failed,
                                                     d_mask, p, s, "dist_kernel<16,4,14>");
-    if (tq == 8 && nw == 8)
+    if (g_tile_tq == 8 && g_tile_nw == 8)
       return launch_variant<8, 8, 14, MODE, PackT>(ref, qry, d_lut, d_rtab, d_out, d_n_failed,
                                                    d_mask, p, s, "dist_kernel<8,8,14>");
+    if (g_tile_tq == 8 && g_tile_nw == 4)
+      return launch_variant<8, 4, 14, MODE, PackT>(ref, qry, d_lut, d_rtab, d_out, d_n_failed,
+                                                   d_mask, p, s, "dist_kernel<8,4,14>");
   }
-  return launch_variant<8, 4, 14, MODE, PackT>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p,
-                                               s, "dist_kernel<8,4,14>");
+  return launch_v2<MODE, PackT>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
 }
 
 }  // namespace
@@ -418,7 +664,7 @@ int launch_tiles(const ppk_db *ref, const ppk_db *qry, const double *d_lut, cons
 int ppk_set_tile(int tq, int nw) {
   if (!((tq == 0 && nw == 0) || (tq == 16 && nw == 4) || (tq == 8 && nw == 8) ||
         (tq == 8 && nw == 4)))
-    return ppk_fail(PPK_ERR_ARG, "supported tiles: (16,4) (8,8) (8,4) or (0,0)=auto");
+    return ppk_fail(PPK_ERR_ARG, "supported v1 tiles: (16,4) (8,8) (8,4); (0,0) = v2 (default)");
   g_tile_tq = tq;
   g_tile_nw = nw;
   return PPK_OK;
