@@ -29,6 +29,8 @@
 //    are consecutive rows in both PopPUNK row orders (utils.py:199-226);
 //  * with MODE_MASK the lane applies the boundary instead (src/boundary.cpp:42-58)
 //    and the wavefront's __ballot is stored as one uint64 of an edge bitmask.
+#include <cstdlib>
+
 #include "ppk_internal.h"
 
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -51,6 +53,7 @@ struct DistParams {
   int random_correct;
   int slope, inclusive;   // MODE_MASK
   float x_max, y_max, scale_x, scale_y;
+  int ablate;             // measurement only (PPK_ABLATE): 1 = skip epilogue, 2 = skip compare
   int kmers[PPK_MAX_NK];
 };
 
@@ -455,7 +458,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
     // the other buffer was last read in iteration g-1, which every wave left through the barrier
     if (g + 1 < total) issue_dma(g + 1, buf ^ 1);
 
-    if (wave_active) {
+    if (wave_active && !(p.ablate & 2)) {
       const u32x4 *rp = lds + buf * CHUNK_U4 + lane;
       const u32x4 *qp = lds + buf * CHUNK_U4 + REF_U4 + wave * 2;
       uint32_t lo[R][TQ], hi[R][TQ];
@@ -527,7 +530,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
 
   // ---- epilogue: regression (+ boundary) per pair ---------------------------
   if constexpr (MODE == MODE_DIST || MODE == MODE_MASK) {
-    if (!wave_active) return;
+    if (!wave_active || (p.ablate & 1)) return;
     int cr[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) cr[r] = (ref_clu && rr[r] < p.n_ref) ? ref_clu[rr[r]] : 0;
@@ -713,6 +716,10 @@ int ppk_launch_dist(const ppk_db *ref, const ppk_db *qry_or_null, const int32_t 
   while (((size_t)1 << bits) <= nbins) ++bits;
   p.cnt_bits = bits;
   for (int k = 0; k < p.nk && k < PPK_MAX_NK; ++k) p.kmers[k] = kmers[k];
+  {
+    const char *ab = getenv("PPK_ABLATE");
+    p.ablate = ab ? atoi(ab) : 0;
+  }
 
   const bool want_counts = flags & PPK_FLAG_COUNTS;
   const bool want_jac = flags & PPK_FLAG_JACCARD;

@@ -1,0 +1,91 @@
+"""CPU tests: libppk_hip.so loads without a GPU and exports every symbol include/ppk.h
+declares; the host-only entry points behave; compute entry points fail loudly without a device."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from poppunk_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "ppk.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ppk_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    lib = _lib.lib()
+    names = header_functions()
+    assert len(names) >= 20
+    raw = C.CDLL(_lib.SO_PATH)
+    for n in names:
+        assert hasattr(raw, n), "libppk_hip.so does not export %s" % n
+        assert n in _lib.SIGNATURES, "%s is declared in ppk.h but not bound in _lib.py" % n
+    for n in _lib.SIGNATURES:
+        assert n in names, "%s is bound but not declared in include/ppk.h" % n
+    assert lib.ppk_version().startswith(b"poppunk_amd")
+
+
+def test_no_torch_types_in_the_abi():
+    src = open(os.path.join(ROOT, "include", "ppk.h")).read()
+    assert "torch" not in src.lower() and "at::" not in src
+    assert 'extern "C"' in src
+
+
+def test_band_geometry_host_functions():
+    lib = _lib.lib()
+    n = 10000
+    assert lib.ppk_rows_in_band(n, 0, 0, n) == n * (n - 1) // 2
+    assert lib.ppk_rows_in_band(n, 0, 0, 1) == n - 1
+    assert lib.ppk_rows_in_band(n, 0, n - 1, n) == 0
+    assert lib.ppk_rows_in_band(n, 50000, 10, 20) == 10 * n
+    assert lib.ppk_rows_in_band(n, 0, 5, 5) == 0
+    for parts in (1, 2, 3, 8):
+        for n_ref, n_qry in ((10000, 0), (777, 0), (10000, 50000), (5, 3), (64, 0)):
+            b = (C.c_size_t * (parts + 1))()
+            assert lib.ppk_band_split(n_ref, n_qry, parts, b) == 0
+            b = list(b)
+            nq = n_qry or n_ref
+            assert b[0] == 0 and b[-1] == nq and b == sorted(b)
+            assert all(x % 64 == 0 for x in b[1:-1])
+            rows = [lib.ppk_rows_in_band(n_ref, n_qry, b[i], b[i + 1]) for i in range(parts)]
+            assert sum(rows) == lib.ppk_rows_in_band(n_ref, n_qry, 0, nq)
+    # 8-way split of the 10k self job is balanced to a few percent
+    b = (C.c_size_t * 9)()
+    lib.ppk_band_split(10000, 0, 8, b)
+    rows = [lib.ppk_rows_in_band(10000, 0, b[i], b[i + 1]) for i in range(8)]
+    assert max(rows) / (sum(rows) / 8) < 1.05
+
+
+def test_argument_errors_are_reported_not_raised_across_the_abi():
+    lib = _lib.lib()
+    assert lib.ppk_band_split(10, 0, 0, None) == _lib.ERR_ARG
+    assert b"band split" in lib.ppk_last_error()
+    assert lib.ppk_set_tile(3, 3) == _lib.ERR_ARG
+    assert lib.ppk_set_tile(0, 0) == _lib.OK
+    h = C.c_void_p()
+    assert lib.ppk_db_create(0, None, 0, 0, 0, 0, None, 0, None, C.byref(h)) == _lib.ERR_ARG
+    with pytest.raises(RuntimeError):
+        _lib.check(_lib.ERR_ARG, "x")
+
+
+def test_missing_extension_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "SO_PATH", "/nonexistent/libppk_hip.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.lib()
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="only meaningful on a box without a GPU")
+def test_compute_without_a_gpu_is_an_error_not_a_fallback():
+    from poppunk_amd import poppunk_refine, pp_sketchlib, synth
+    sk, _ = synth.make_sketches(8, [13, 17], cluster_size=4)
+    with pytest.raises(RuntimeError):
+        pp_sketchlib.query_arrays(sk, None, [13, 17], 16, 14)
+    with pytest.raises(RuntimeError):
+        poppunk_refine.assignThreshold(np.zeros((3, 2), dtype=np.float32), 2, 0.5, 0.5)

@@ -1,0 +1,79 @@
+"""CPU tests of the multi-GPU path's host logic: world_size-2 gloo process group, the pair
+space band-split over ranks, bands computed independently, gathered to rank 0 with the same
+grouped send/recv the RCCL path uses.  The band compute is the CPU oracle here (the HIP launch
+needs a GPU); what is under test is sharding, row offsets and the gather."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, n_ref, n_qry, ret):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from oracle import oracle
+    from poppunk_amd import engine, synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    kmers = np.asarray([13, 17, 21], dtype=np.int32)
+    sk, _ = synth.make_sketches(n_ref + n_qry, kmers, cluster_size=8, seed=4)
+    ref_sk = sk[:n_ref]
+    qry_sk = sk[n_ref:] if n_qry else None
+    tbl = synth.random_match_table(kmers)
+
+    class DB:                      # the two attributes query_sharded needs from a SketchDB
+        def __init__(self, n):
+            self.n = n
+
+    def band_fn(qb, qe):
+        # rows of queries [qb, qe): ref x query sub-problem, re-ordered to the band's rows
+        if qe <= qb:
+            return torch.empty((0, 2), dtype=torch.float32)
+        if qry_sk is None:
+            full, _ = oracle.query(ref_sk, None, kmers, 16, 14, tbl)
+            n = n_ref
+            start = qb * n - qb * (qb + 1) // 2
+            stop = qe * n - qe * (qe + 1) // 2 if qe < n else n * (n - 1) // 2
+            return torch.from_numpy(full[start:stop].copy())
+        out, _ = oracle.query(ref_sk, qry_sk[qb:qe], kmers, 16, 14, tbl)
+        return torch.from_numpy(out)
+
+    full, rows = engine.query_sharded(DB(n_ref), DB(n_qry) if n_qry else None, kmers, tbl, rank,
+                                      world, band_fn=band_fn)
+    if rank == 0:
+        want, _ = oracle.query(ref_sk, qry_sk, kmers, 16, 14, tbl)
+        ok = full is not None and np.array_equal(full.numpy(), want) and sum(rows) == len(want)
+        ret.put(bool(ok))
+    else:
+        assert full is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_ref,n_qry", [(200, 0), (130, 70), (40, 0)])
+def test_band_split_and_gather_world2(n_ref, n_qry):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_ref, n_qry, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert ret.get(timeout=5) is True

@@ -1,0 +1,112 @@
+"""CPU tests of the host-side mirror of the reference interface: argument handling and error
+behaviour of sketchlib.queryDatabase (PopPUNK/sketchlib.py:475-632), the noconvert rule of
+poppunk_refine (src/python_bindings.cpp:82,:89), the sketch database files and the synthetic
+generator.  No GPU compute is triggered here."""
+import numpy as np
+import pytest
+
+from poppunk_amd import poppunk_refine, pp_sketchlib, sketchdb, sketchlib, synth
+
+
+def make_db(tmp_path, name, n, kmers=(13, 17, 21), with_random=True):
+    sk, member = synth.make_sketches(n, kmers, cluster_size=4, seed=n)
+    names = ["%s_%d" % (name, i) for i in range(n)]
+    prefix = str(tmp_path / name)
+    db_name = prefix + "/" + name
+    sketchdb.save_npz(db_name, names, kmers, sk, 16, 14,
+                      random_table=synth.random_match_table(kmers) if with_random else None,
+                      clusters=np.zeros(n, dtype=np.uint16) if with_random else None)
+    return prefix, names, sk
+
+
+def test_self_query_requires_same_db(tmp_path):
+    p1, n1, _ = make_db(tmp_path, "a", 6)
+    p2, _, _ = make_db(tmp_path, "b", 6)
+    with pytest.raises(RuntimeError, match="Must use same db for self query"):
+        sketchlib.queryDatabase(n1, n1, p1, p2, [13, 17, 21], self=True)
+
+
+def test_overlapping_names_exit(tmp_path, capsys):
+    p1, n1, _ = make_db(tmp_path, "a", 6)
+    with pytest.raises(SystemExit) as e:
+        sketchlib.queryDatabase(n1, n1[:2], p1, p1, [13, 17, 21], self=False)
+    assert e.value.code == 1
+    assert "Unique names are required" in capsys.readouterr().err
+
+
+def test_sketchdb_roundtrip_subset_and_order(tmp_path):
+    prefix, names, sk = make_db(tmp_path, "db", 9)
+    db_name = prefix + "/db"
+    pick = [names[5], names[0], names[7]]
+    got = sketchdb.load(db_name, pick, [21, 13])
+    assert got.sketches.shape == (3, 2, 224)
+    assert np.array_equal(got.sketches[0, 0], sk[5, 2]) and np.array_equal(got.sketches[1, 1], sk[0, 0])
+    assert got.random_table.shape == (2, 1, 1) and got.clusters.shape == (3,)
+    assert got.sketchsize64 == 16 and got.bbits == 14
+    with pytest.raises(RuntimeError, match="not found"):
+        sketchdb.load(db_name, ["nope"], [13])
+    with pytest.raises(RuntimeError, match="k-mer length 15"):
+        sketchdb.load(db_name, pick, [15])
+    with pytest.raises(RuntimeError, match="not found"):
+        sketchdb.load(str(tmp_path / "missing" / "missing"), pick, [13])
+
+
+def test_query_arrays_argument_checks():
+    sk, _ = synth.make_sketches(4, [13, 17], cluster_size=2)
+    with pytest.raises(RuntimeError, match="klist"):
+        pp_sketchlib.query_arrays(sk, None, [13, 17, 21], 16, 14)
+    with pytest.raises(RuntimeError, match="sketchsize64"):
+        pp_sketchlib.query_arrays(sk, None, [13, 17], 15, 14)
+    with pytest.raises(RuntimeError, match="cluster ids"):
+        pp_sketchlib.query_arrays(sk, None, [13, 17], 16, 14,
+                                  random_table=np.zeros((2, 2, 2), dtype=np.float32))
+    with pytest.raises(RuntimeError, match="out of range"):
+        pp_sketchlib.query_arrays(sk, None, [13, 17], 16, 14,
+                                  random_table=np.zeros((2, 2, 2), dtype=np.float32),
+                                  ref_clusters=np.array([0, 1, 2, 0]))
+    # a single sample has no pairs: empty result without touching the device
+    out, failed = pp_sketchlib.query_arrays(sk[:1], None, [13, 17], 16, 14)
+    assert out.shape == (0, 2) and failed == 0
+
+
+def test_refine_noconvert_and_empty_inputs():
+    with pytest.raises(TypeError):
+        poppunk_refine.assignThreshold(np.zeros((4, 2)), 2, 0.5, 0.5)             # float64
+    with pytest.raises(TypeError):
+        poppunk_refine.assignThreshold(np.zeros((4, 3), dtype=np.float32), 2, 0.5, 0.5)
+    with pytest.raises(TypeError):
+        poppunk_refine.edgeThreshold([[0.0, 0.0]], 2, 0.5, 0.5)                   # list
+    with pytest.raises(TypeError):
+        poppunk_refine.generateTuples(np.zeros((2, 2)), -1)
+    empty = np.zeros((0, 2), dtype=np.float32)
+    assert poppunk_refine.assignThreshold(empty, 2, 0.5, 0.5).shape == (0,)
+    assert poppunk_refine.edgeThreshold(empty, 2, 0.5, 0.5) == []
+    assert poppunk_refine.generateTuples([], -1) == []
+
+
+def test_iterDistRows_contract():
+    names = ["a", "b", "c", "d"]
+    assert list(sketchlib.iterDistRows(names, names, True)) == \
+        [("b", "a"), ("c", "a"), ("d", "a"), ("c", "b"), ("d", "b"), ("d", "c")]
+    assert list(sketchlib.iterDistRows(["r0", "r1"], ["q0", "q1", "q2"], False)) == \
+        [("r0", "q0"), ("r1", "q0"), ("r0", "q1"), ("r1", "q1"), ("r0", "q2"), ("r1", "q2")]
+    with pytest.raises(RuntimeError):
+        list(sketchlib.iterDistRows(names, names[:2], True))
+
+
+def test_synthetic_generator_properties():
+    kmers = synth.DEFAULT_KMERS
+    a, ma = synth.make_sketches(120, kmers, cluster_size=30)
+    b, _ = synth.make_sketches(120, kmers, cluster_size=30)
+    assert np.array_equal(a, b) and a.dtype == np.uint64 and a.shape == (120, 5, 224)
+    tbl = synth.random_match_table(kmers)
+    assert tbl.shape == (5, 1, 1) and np.all(np.diff(tbl.ravel()) < 0) and 0.02 < tbl[0, 0, 0] < 0.04
+    assert np.isfinite(tbl).all()
+    bins = np.arange(128, dtype=np.uint16).reshape(1, 128) * 101 % (1 << 14)
+    w = synth.bitslice(bins, 14)
+    assert w.shape == (1, 28)
+    # word [blk*14 + b] bit i == bit b of bin 64*blk + i
+    for blk in range(2):
+        for bit in range(14):
+            for i in (0, 1, 37, 63):
+                assert ((int(w[0, blk * 14 + bit]) >> i) & 1) == ((int(bins[0, 64 * blk + i]) >> bit) & 1)
