@@ -53,7 +53,7 @@ struct DistParams {
   int random_correct;
   int slope, inclusive;   // MODE_MASK
   float x_max, y_max, scale_x, scale_y;
-  int ablate;             // measurement only (PPK_ABLATE): 1 = skip epilogue, 2 = skip compare
+  int ablate;             // measurement only (PPK_ABLATE): 1 skip epilogue, 2 skip compare, 4 skip DMA, 8 skip barriers
   int kmers[PPK_MAX_NK];
 };
 
@@ -418,23 +418,37 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
 
   const int total = p.nk * p.s64;             // one chunk per (k, 64-bin block)
 
-  auto issue_dma = [&](int g, int buf) {
-    const size_t grow0 = (size_t)g * BB;      // (k*s64 + blk)*14 = k*words + blk*14
+  // Per-lane DMA source pointers, advanced by one 64-bin block (14 rows) per chunk: each
+  // wavefront copies 4 of the chunk's 32 one-KB pieces (28 ref pieces: row i/2, half i%2;
+  // 4 query pieces: 4 rows x 16 lanes each).
+  const uint64_t *dsrc[4];
+  size_t dstep[4];
+  int doff[4];
+  bool dact[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int i = wave + NW * t;
+    if (i < 2 * BB) {
+      dsrc[t] = refT + (size_t)(i >> 1) * p.npad_r + r0 + (i & 1) * 128 + lane * 2;
+      dstep[t] = (size_t)BB * p.npad_r;
+      doff[t] = i * 64;
+      dact[t] = true;
+    } else {
+      const int j = i - 2 * BB;
+      const int plane = 4 * j + (lane >> 4);
+      dsrc[t] = qryT + (size_t)(plane < BB ? plane : 0) * p.npad_q + q0 + 2 * (lane & 15);
+      dstep[t] = (size_t)BB * p.npad_q;
+      doff[t] = REF_U4 + j * 64;
+      dact[t] = plane < BB;
+    }
+  }
+  auto issue_dma = [&](int buf) {
     u32x4 *base = lds + buf * CHUNK_U4;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const int i = wave + NW * t;            // 32 one-KB pieces per chunk, 4 per wavefront
-      if (i < 2 * BB) {
-        const uint64_t *src = refT + (grow0 + (i >> 1)) * p.npad_r + r0 + (i & 1) * 128 + lane * 2;
-        __builtin_amdgcn_global_load_lds(PPK_GPTR(src), PPK_LPTR(base + i * 64), 16, 0, 0);
-      } else {
-        const int j = i - 2 * BB;             // 4 query rows per piece: 16 lanes x 16 B each
-        const int plane = 4 * j + (lane >> 4);
-        if (plane < BB) {
-          const uint64_t *src = qryT + (grow0 + plane) * p.npad_q + q0 + 2 * (lane & 15);
-          __builtin_amdgcn_global_load_lds(PPK_GPTR(src), PPK_LPTR(base + REF_U4 + j * 64), 16, 0, 0);
-        }
-      }
+      if (dact[t])
+        __builtin_amdgcn_global_load_lds(PPK_GPTR(dsrc[t]), PPK_LPTR(base + doff[t]), 16, 0, 0);
+      dsrc[t] += dstep[t];
     }
   };
 
@@ -448,7 +462,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
       packed[r][q] = 0;
     }
 
-  issue_dma(0, 0);
+  issue_dma(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
@@ -456,7 +470,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
   for (int g = 0; g < total; ++g) {
     const int buf = g & 1;
     // the other buffer was last read in iteration g-1, which every wave left through the barrier
-    if (g + 1 < total) issue_dma(g + 1, buf ^ 1);
+    if (g + 1 < total && !(p.ablate & 4)) issue_dma(buf ^ 1);
 
     if (wave_active && !(p.ablate & 2)) {
       const u32x4 *rp = lds + buf * CHUNK_U4 + lane;
@@ -481,10 +495,14 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
             }
           }
       }
+      // cnt += popc(lo) + popc(hi) as two chained v_bcnt_u32_b32 (the accumulate operand is free)
 #pragma unroll
       for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int q = 0; q < TQ; ++q) cnt[r][q] += __popc(lo[r][q]) + __popc(hi[r][q]);
+        for (int q = 0; q < TQ; ++q) {
+          asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[r][q]) : "v"(lo[r][q]));
+          asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[r][q]) : "v"(hi[r][q]));
+        }
 
       if (blk == p.s64 - 1) {
         // ---- end of one k: consume the counts ----------------------------------
@@ -524,8 +542,10 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
     }
     // my DMA pieces have landed; after the barrier everyone's have, and everyone has
     // finished reading `buf` (all ds_read results were consumed above)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if (!(p.ablate & 8)) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
   }
 
   // ---- epilogue: regression (+ boundary) per pair ---------------------------
