@@ -32,6 +32,7 @@
 #include <cstdlib>
 
 #include "ppk_internal.h"
+#include "ppk_block_asm.inc"
 
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned __int128 u128;
@@ -53,8 +54,12 @@ struct DistParams {
   int random_correct;
   int slope, inclusive;   // MODE_MASK
   float x_max, y_max, scale_x, scale_y;
+  int xcd_map;            // 1: XCD-aware tile order (v2)
+  unsigned r_tiles, q_tiles;   // v2 tile grid
   int ablate;             // measurement only (PPK_ABLATE): 1 skip epilogue, 2 skip compare, 4 skip DMA, 8 skip barriers
   int kmers[PPK_MAX_NK];
+  // all-points-usable fast path of the regression: sums of k, 1/(n*sum k^2 - (sum k)^2), 1/n
+  double sx_all, inv_den_all, inv_n_all;
 };
 
 // ---- small device helpers --------------------------------------------------
@@ -122,32 +127,51 @@ __device__ __forceinline__ void fit_packed(PackT pk, const double *__restrict__ 
                                            const DistParams &p, float &core, float &acc,
                                            bool &failed) {
   // a6: OLS of log J on k over the leading run of usable points, fp64.
-  double sx = 0.0, sxx = 0.0, sy = 0.0, sxy = 0.0;
-  int n = 0;
-  bool open = true;
   const uint32_t cmask = (1u << p.cnt_bits) - 1u;
+  double sy = 0.0, sxy = 0.0;
+  bool all_ok = p.nk >= 2;
   for (int k = 0; k < p.nk; ++k) {
     const uint32_t c = (uint32_t)(pk >> (p.cnt_bits * k)) & cmask;
     const double y = lutp[(size_t)k * p.lut_kstride + c];
-    open = open && (y <= 0.0);
-    if (open) {
-      const double x = (double)p.kmers[k];
-      sx += x;
-      sxx += x * x;
-      sy += y;
-      sxy += x * y;
-      ++n;
+    all_ok = all_ok && (y <= 0.0);
+    sy += y;
+    sxy += (double)p.kmers[k] * y;
+  }
+  double slope, icpt;
+  if (__all(all_ok)) {
+    // every k usable in every lane of the wavefront (the overwhelmingly common case):
+    // the k-only sums are launch constants
+    slope = ((double)p.nk * sxy - p.sx_all * sy) * p.inv_den_all;
+    icpt = (sy - slope * p.sx_all) * p.inv_n_all;
+  } else {
+    double sx = 0.0, sxx = 0.0;
+    sy = 0.0;
+    sxy = 0.0;
+    int n = 0;
+    bool open = true;
+    for (int k = 0; k < p.nk; ++k) {
+      const uint32_t c = (uint32_t)(pk >> (p.cnt_bits * k)) & cmask;
+      const double y = lutp[(size_t)k * p.lut_kstride + c];
+      open = open && (y <= 0.0);
+      if (open) {
+        const double x = (double)p.kmers[k];
+        sx += x;
+        sxx += x * x;
+        sy += y;
+        sxy += x * y;
+        ++n;
+      }
     }
+    if (n < 2) {
+      core = 0.0f;
+      acc = 0.0f;
+      failed = true;
+      return;
+    }
+    const double dn = (double)n;
+    slope = (dn * sxy - sx * sy) / (dn * sxx - sx * sx);
+    icpt = (sy - slope * sx) / dn;
   }
-  if (n < 2) {
-    core = 0.0f;
-    acc = 0.0f;
-    failed = true;
-    return;
-  }
-  const double dn = (double)n;
-  const double slope = (dn * sxy - sx * sy) / (dn * sxx - sx * sx);
-  const double icpt = (sy - slope * sx) / dn;
   core = slope < 0.0 ? (float)(1.0 - exp(slope)) : 0.0f;
   acc = icpt < 0.0 ? (float)(1.0 - exp(icpt)) : 0.0f;
   failed = false;
@@ -402,9 +426,24 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const size_t rt = blockIdx.x;
+  // Tile order.  Workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only).
+  // Each XCD has a private 4 MB L2, so XCD x is given the ref tiles rt = x, x+8, ... and walks
+  // the query tiles with its few ref tiles innermost: the ~64 workgroups resident on an XCD then
+  // share the same ref rows through that L2 instead of every XCD streaming every ref tile.
+  size_t rt, qt;
+  if (p.xcd_map) {
+    const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+    if (xcd >= p.r_tiles) return;
+    const unsigned nloc = (p.r_tiles - xcd + 7u) >> 3;   // ref tiles owned by this XCD
+    qt = j / nloc;
+    rt = xcd + 8u * (j % nloc);
+    if (qt >= p.q_tiles) return;
+  } else {
+    rt = blockIdx.x % p.r_tiles;
+    qt = blockIdx.x / p.r_tiles;
+  }
   const size_t r0 = rt * V2_RT;
-  const size_t q0 = (p.q_tile0 + blockIdx.y) * V2_QT;
+  const size_t q0 = (p.q_tile0 + qt) * V2_QT;
   const size_t qw0 = q0 + (size_t)wave * TQ;
   if (p.self && r0 + (V2_RT - 1) <= q0) return;   // no pair with r > q in this tile
   const bool wave_active =
@@ -418,37 +457,42 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
 
   const int total = p.nk * p.s64;             // one chunk per (k, 64-bin block)
 
-  // Per-lane DMA source pointers, advanced by one 64-bin block (14 rows) per chunk: each
-  // wavefront copies 4 of the chunk's 32 one-KB pieces (28 ref pieces: row i/2, half i%2;
-  // 4 query pieces: 4 rows x 16 lanes each).
-  const uint64_t *dsrc[4];
+  // DMA sources: each wavefront copies 4 of the chunk's 32 one-KB pieces (28 ref pieces: row
+  // i/2, half i%2; 4 query pieces: 4 rows x 16 lanes each).  A piece's address is a
+  // wave-uniform base (SGPR pair, advanced by one 64-bin block = 14 rows per chunk) plus a
+  // per-lane 32-bit byte offset, i.e. the saddr+voffset form of global_load_lds_dwordx4.
+  const char *dbase[4];
   size_t dstep[4];
   int doff[4];
-  bool dact[4];
+  bool dref[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int i = wave + NW * t;
-    if (i < 2 * BB) {
-      dsrc[t] = refT + (size_t)(i >> 1) * p.npad_r + r0 + (i & 1) * 128 + lane * 2;
-      dstep[t] = (size_t)BB * p.npad_r;
+    dref[t] = i < 2 * BB;
+    if (dref[t]) {
+      dbase[t] = reinterpret_cast<const char *>(refT + (size_t)(i >> 1) * p.npad_r + r0 + (i & 1) * 128);
+      dstep[t] = (size_t)BB * p.npad_r * 8;
       doff[t] = i * 64;
-      dact[t] = true;
     } else {
       const int j = i - 2 * BB;
-      const int plane = 4 * j + (lane >> 4);
-      dsrc[t] = qryT + (size_t)(plane < BB ? plane : 0) * p.npad_q + q0 + 2 * (lane & 15);
-      dstep[t] = (size_t)BB * p.npad_q;
+      dbase[t] = reinterpret_cast<const char *>(qryT + (size_t)(4 * j) * p.npad_q + q0);
+      dstep[t] = (size_t)BB * p.npad_q * 8;
       doff[t] = REF_U4 + j * 64;
-      dact[t] = plane < BB;
     }
   }
+  const uint32_t voff_ref = lane * 16;
+  const uint32_t voff_qry = (uint32_t)((lane >> 4) * p.npad_q * 8) + (lane & 15) * 16;
+  const bool qlane_ok = (4 * 3 + (lane >> 4)) < BB;   // the last query piece holds rows 12, 13 only
   auto issue_dma = [&](int buf) {
     u32x4 *base = lds + buf * CHUNK_U4;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      if (dact[t])
-        __builtin_amdgcn_global_load_lds(PPK_GPTR(dsrc[t]), PPK_LPTR(base + doff[t]), 16, 0, 0);
-      dsrc[t] += dstep[t];
+      if (dref[t]) {
+        __builtin_amdgcn_global_load_lds(PPK_GPTR(dbase[t] + voff_ref), PPK_LPTR(base + doff[t]), 16, 0, 0);
+      } else if (wave != NW - 1 || qlane_ok) {
+        __builtin_amdgcn_global_load_lds(PPK_GPTR(dbase[t] + voff_qry), PPK_LPTR(base + doff[t]), 16, 0, 0);
+      }
+      dbase[t] += dstep[t];
     }
   };
 
@@ -473,36 +517,21 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
     if (g + 1 < total && !(p.ablate & 4)) issue_dma(buf ^ 1);
 
     if (wave_active && !(p.ablate & 2)) {
-      const u32x4 *rp = lds + buf * CHUNK_U4 + lane;
-      const u32x4 *qp = lds + buf * CHUNK_U4 + REF_U4 + wave * 2;
-      uint32_t lo[R][TQ], hi[R][TQ];
-#pragma unroll
-      for (int b = 0; b < BB; ++b) {
-        const u32x4 a0 = rp[b * 128], a1 = rp[b * 128 + 64];
-        const u32x4 s0 = qp[b * 16], s1 = qp[b * 16 + 1];
-        const uint32_t ax[R] = {a0.x, a0.z, a1.x, a1.z}, ay[R] = {a0.y, a0.w, a1.y, a1.w};
-        const uint32_t sx[TQ] = {s0.x, s0.z, s1.x, s1.z}, sy[TQ] = {s0.y, s0.w, s1.y, s1.w};
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-          for (int q = 0; q < TQ; ++q) {
-            if (b == 0) {
-              lo[r][q] = ~(ax[r] ^ sx[q]);
-              hi[r][q] = ~(ay[r] ^ sy[q]);
-            } else {
-              lo[r][q] = __builtin_amdgcn_bitop3_b32(lo[r][q], ax[r], sx[q], 0x90);
-              hi[r][q] = __builtin_amdgcn_bitop3_b32(hi[r][q], ay[r], sy[q], 0x90);
-            }
-          }
-      }
-      // cnt += popc(lo) + popc(hi) as two chained v_bcnt_u32_b32 (the accumulate operand is free)
-#pragma unroll
-      for (int r = 0; r < R; ++r)
-#pragma unroll
-        for (int q = 0; q < TQ; ++q) {
-          asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[r][q]) : "v"(lo[r][q]));
-          asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(cnt[r][q]) : "v"(hi[r][q]));
-        }
+      // One 64-bin block of the 4x4 register tile: 14 x (4 ds_read_b128 + 32 v_bitop3) + 32
+      // v_bcnt, as the generated bank-aware instruction stream (tools/gen_block_asm.py).
+      const uint32_t rp =
+          (uint32_t)(size_t)(__attribute__((address_space(3))) void *)(lds + buf * CHUNK_U4 + lane);
+      const uint32_t qp = (uint32_t)(size_t)(__attribute__((address_space(3))) void *)(
+          lds + buf * CHUNK_U4 + REF_U4 + wave * 2);
+      asm volatile(PPK_BLOCK_ASM
+                   : [c0] "+v"(cnt[0][0]), [c1] "+v"(cnt[0][1]), [c2] "+v"(cnt[0][2]),
+                     [c3] "+v"(cnt[0][3]), [c4] "+v"(cnt[1][0]), [c5] "+v"(cnt[1][1]),
+                     [c6] "+v"(cnt[1][2]), [c7] "+v"(cnt[1][3]), [c8] "+v"(cnt[2][0]),
+                     [c9] "+v"(cnt[2][1]), [c10] "+v"(cnt[2][2]), [c11] "+v"(cnt[2][3]),
+                     [c12] "+v"(cnt[3][0]), [c13] "+v"(cnt[3][1]), [c14] "+v"(cnt[3][2]),
+                     [c15] "+v"(cnt[3][3])
+                   : [rp] "v"(rp), [qp] "v"(qp)
+                   : "memory", PPK_BLOCK_CLOBBERS);
 
       if (blk == p.s64 - 1) {
         // ---- end of one k: consume the counts ----------------------------------
@@ -647,11 +676,20 @@ int launch_v2(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const f
   const size_t q_tiles = (p.q_end + V2_QT - 1) / V2_QT - p.q_tile0;
   const size_t r_tiles = (p.n_ref + V2_RT - 1) / V2_RT;
   if (q_tiles == 0 || r_tiles == 0) return PPK_OK;
-  if (q_tiles > 65535) return ppk_fail(PPK_ERR_ARG, "query band too tall for one launch");
   const bool use_clu = p.random_correct && p.n_clu > 1;
+  p.r_tiles = (unsigned)r_tiles;
+  p.q_tiles = (unsigned)q_tiles;
+  {
+    const char *m = getenv("PPK_MAP");
+    p.xcd_map = m ? atoi(m) : 0;  // measured: no gain (L2 hit rate is already 83%, kernel is VALU/LDS bound)
+  }
+  // XCD-aware order: 8 interleaved streams, each as long as the busiest XCD's tile list
+  const size_t per_xcd = ((r_tiles + 7) / 8) * q_tiles;
+  const size_t n_blocks = p.xcd_map ? per_xcd * 8 : r_tiles * q_tiles;
+  if (n_blocks > 0x7fffffffull) return ppk_fail(PPK_ERR_ARG, "tile grid too large for one launch");
   ppk_set_kernel_name("dist_kernel_v2<256x32,lds-dma>");
   ppk_prof_begin(s);
-  hipLaunchKernelGGL((dist_kernel_v2<MODE, PackT>), dim3((unsigned)r_tiles, (unsigned)q_tiles),
+  hipLaunchKernelGGL((dist_kernel_v2<MODE, PackT>), dim3((unsigned)n_blocks),
                      dim3(V2_NW * 64), 0, s, ref->d_skT, qry->d_skT, d_lut,
                      use_clu ? ref->d_clu : nullptr, use_clu ? qry->d_clu : nullptr, d_rtab, d_out,
                      d_n_failed, d_mask, p);
@@ -736,6 +774,16 @@ int ppk_launch_dist(const ppk_db *ref, const ppk_db *qry_or_null, const int32_t 
   while (((size_t)1 << bits) <= nbins) ++bits;
   p.cnt_bits = bits;
   for (int k = 0; k < p.nk && k < PPK_MAX_NK; ++k) p.kmers[k] = kmers[k];
+  {
+    double sx = 0.0, sxx = 0.0;
+    for (int k = 0; k < p.nk && k < PPK_MAX_NK; ++k) {
+      sx += (double)kmers[k];
+      sxx += (double)kmers[k] * (double)kmers[k];
+    }
+    p.sx_all = sx;
+    p.inv_den_all = 1.0 / ((double)p.nk * sxx - sx * sx);
+    p.inv_n_all = 1.0 / (double)p.nk;
+  }
   {
     const char *ab = getenv("PPK_ABLATE");
     p.ablate = ab ? atoi(ab) : 0;

@@ -1,0 +1,125 @@
+#!/usr/bin/env python3
+"""Times the BASELINE.json configurations that fit one MI355X (run through gpurun):
+
+  C2  1 000 self                          (kernel 1, resident)
+  C3  10 000 self on 1 GPU                (kernel 1, resident; the bench.py workload)
+  C4  50 000 queries x 10 000 refs        (kernel 1, ref sketches resident)
+  C5s 100 000 self, one 1/8 band, fused distance -> boundary -> edge list (the share one
+      GPU of an 8-GPU node would own), plus 30 000 self whole
+  K2  assignThreshold / edgeThreshold streams over the resident 10k distance matrix
+  H   host-buffer ppk_query (PCIe-inclusive) on 10 000 self
+
+Writes one JSON document to stdout (and to the path given as argv[1]).
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from poppunk_amd import engine, pp_sketchlib, synth  # noqa: E402
+
+KMERS = np.asarray(synth.DEFAULT_KMERS, dtype=np.int32)
+TBL = synth.random_match_table(KMERS)
+
+
+def timed(fn, reps=5, warm=1):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def main():
+    out = {}
+    sk10, _ = synth.make_sketches(10000, KMERS)
+    db10 = engine.SketchDB(sk10, 16, 14)
+
+    # C2
+    db1 = engine.SketchDB(sk10[:1000], 16, 14)
+    o = torch.empty((499500, 2), dtype=torch.float32, device="cuda")
+    t = timed(lambda: engine.dist(db1, None, KMERS, TBL, out=o), reps=50, warm=3)
+    out["C2_1k_self"] = {"pairs": 499500, "ms": t * 1e3, "pairs_per_s": 499500 / t}
+
+    # C3 on one GPU
+    o = torch.empty((49995000, 2), dtype=torch.float32, device="cuda")
+    t = timed(lambda: engine.dist(db10, None, KMERS, TBL, out=o), reps=10, warm=2)
+    out["C3_10k_self_1gpu"] = {"pairs": 49995000, "ms": t * 1e3, "pairs_per_s": 49995000 / t}
+    dist10 = o
+
+    # K2 on the resident 10k matrix
+    d_host = dist10.cpu().numpy()
+    x_max, y_max = synth.boundary_for_quantile(d_host[::50], 0.02)
+    a = torch.empty(49995000, dtype=torch.float32, device="cuda")
+    t = timed(lambda: engine.assign_threshold_dev(dist10, 2, x_max, y_max, out=a), reps=20, warm=2)
+    out["K2_assign_10k"] = {"rows": 49995000, "ms": t * 1e3, "GBps": 49995000 * 12 / t / 1e9}
+    e = engine.edge_threshold_dev(dist10, 2, x_max, y_max)
+    t = timed(lambda: engine.edge_threshold_dev(dist10, 2, x_max, y_max, cap=len(e) + 16), reps=10)
+    out["K2_edges_10k"] = {"rows": 49995000, "edges": int(len(e)), "ms": t * 1e3,
+                           "GBps": (49995000 * 8 + len(e) * 16) / t / 1e9}
+    fe, _ = engine.dist_edges(db10, None, KMERS, TBL, slope=2, x_max=x_max, y_max=y_max)
+    assert torch.equal(fe, e), "fused edges differ from two-step edges"
+    t = timed(lambda: engine.dist_edges(db10, None, KMERS, TBL, slope=2, x_max=x_max, y_max=y_max,
+                                        cap=len(e) + 16), reps=5)
+    out["C3_10k_fused_edges"] = {"pairs": 49995000, "edges": int(len(e)), "ms": t * 1e3,
+                                 "pairs_per_s": 49995000 / t}
+    del a, o, dist10
+    torch.cuda.empty_cache()
+
+    # H: host buffers in, host buffer out (PCIe inclusive), 10k self
+    t0 = time.perf_counter()
+    h, _ = pp_sketchlib.query_arrays(sk10, None, KMERS, 16, 14, TBL)
+    t = time.perf_counter() - t0
+    out["H_10k_self_host_buffers"] = {"pairs": 49995000, "ms": t * 1e3, "pairs_per_s": 49995000 / t,
+                                      "note": "upload 89.6 MB + kernel + 400 MB download to pageable memory"}
+    del h
+
+    # C4: 50k queries x 10k refs
+    skq, _ = synth.make_sketches(50000, KMERS, seed=7)
+    dbq = engine.SketchDB(skq, 16, 14)
+    o = torch.empty((500000000, 2), dtype=torch.float32, device="cuda")
+    t = timed(lambda: engine.dist(db10, dbq, KMERS, TBL, out=o), reps=3, warm=1)
+    out["C4_50k_x_10k"] = {"pairs": 500000000, "ms": t * 1e3, "pairs_per_s": 5e8 / t}
+    del o, dbq, skq
+    torch.cuda.empty_cache()
+
+    # C5: fused edges, 30k whole and one band of 100k
+    sk30, _ = synth.make_sketches(30000, KMERS, seed=11)
+    db30 = engine.SketchDB(sk30, 16, 14)
+    n = 30000
+    probe, _ = engine.dist(db30, None, KMERS, TBL, q_begin=0, q_end=64)
+    x_max, y_max = synth.boundary_for_quantile(probe.cpu().numpy(), 0.02)
+    e, _ = engine.dist_edges(db30, None, KMERS, TBL, slope=2, x_max=x_max, y_max=y_max)
+    t = timed(lambda: engine.dist_edges(db30, None, KMERS, TBL, slope=2, x_max=x_max, y_max=y_max,
+                                        cap=len(e) + 16), reps=3, warm=0)
+    out["C5_30k_fused_edges"] = {"pairs": n * (n - 1) // 2, "edges": int(len(e)), "ms": t * 1e3,
+                                 "pairs_per_s": n * (n - 1) // 2 / t}
+    del db30, sk30
+    sk100, _ = synth.make_sketches(100000, KMERS, seed=13)
+    db100 = engine.SketchDB(sk100, 16, 14)
+    b = engine.band_split(100000, 0, 8)
+    rows = engine.rows_in_band(100000, 0, b[3], b[4])
+    e, _ = engine.dist_edges(db100, None, KMERS, TBL, slope=2, x_max=x_max, y_max=y_max,
+                             q_begin=b[3], q_end=b[4])
+    t = timed(lambda: engine.dist_edges(db100, None, KMERS, TBL, slope=2, x_max=x_max, y_max=y_max,
+                                        q_begin=b[3], q_end=b[4], cap=len(e) + 16), reps=2, warm=0)
+    out["C5_100k_band_4of8_fused_edges"] = {"pairs": rows, "edges": int(len(e)), "ms": t * 1e3,
+                                            "pairs_per_s": rows / t, "band": [b[3], b[4]]}
+    txt = json.dumps(out, indent=1)
+    print(txt)
+    if len(sys.argv) > 1:
+        open(sys.argv[1], "w").write(txt)
+
+
+if __name__ == "__main__":
+    main()

@@ -167,6 +167,55 @@ void run2(uint32_t *d, const uint64_t *in, int wg_per_cu) {
          pair_blocks / (ms * 1e-3) / 80 / 1e9);
 }
 
+#include "../poppunk_amd/csrc/ppk_block_asm.inc"
+// k3: the generated fixed-register block (bank-aware), same LDS layout as k2<4,4,NW>
+template <int NW>
+__global__ void __launch_bounds__(NW * 64, 4) k3(uint32_t *out, const uint64_t *in, int iters) {
+  constexpr int RT = 256, QT = NW * 4;
+  __shared__ u32x4 ref[14 * RT / 2];
+  __shared__ u32x4 qry[14 * 16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 14 * RT / 2; i += NW * 64) { uint64_t v = in[i], w = in[i + 3]; ref[i] = u32x4{(uint32_t)v, (uint32_t)(v >> 32), (uint32_t)w, (uint32_t)(w >> 32)}; }
+  for (int i = threadIdx.x; i < 14 * 16; i += NW * 64) { uint64_t v = in[i + 7], w = in[i + 11]; qry[i] = u32x4{(uint32_t)v, (uint32_t)(v >> 32), (uint32_t)w, (uint32_t)(w >> 32)}; }
+  __syncthreads();
+  uint32_t c[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) c[i] = 0;
+  const uint32_t rp = (uint32_t)(size_t)(__attribute__((address_space(3))) void *)(ref + lane);
+  const uint32_t qp = (uint32_t)(size_t)(__attribute__((address_space(3))) void *)(qry + (wave % 8) * 2);
+  for (int it = 0; it < iters; ++it) {
+    asm volatile(PPK_BLOCK_ASM
+                 : [c0] "+v"(c[0]), [c1] "+v"(c[1]), [c2] "+v"(c[2]), [c3] "+v"(c[3]), [c4] "+v"(c[4]),
+                   [c5] "+v"(c[5]), [c6] "+v"(c[6]), [c7] "+v"(c[7]), [c8] "+v"(c[8]), [c9] "+v"(c[9]),
+                   [c10] "+v"(c[10]), [c11] "+v"(c[11]), [c12] "+v"(c[12]), [c13] "+v"(c[13]),
+                   [c14] "+v"(c[14]), [c15] "+v"(c[15])
+                 : [rp] "v"(rp), [qp] "v"(qp)
+                 : "memory", PPK_BLOCK_CLOBBERS);
+  }
+  uint32_t acc = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc += c[i] * (i + 1);
+  out[blockIdx.x * NW * 64 + threadIdx.x] = acc;
+}
+template <int NW>
+void run3(uint32_t *d, const uint64_t *in, int wg_per_cu) {
+  const int iters = 400;
+  const int blocks = 256 * wg_per_cu;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  hipLaunchKernelGGL((k3<NW>), dim3(blocks), dim3(NW * 64), 0, 0, d, in, 4);
+  (void)hipDeviceSynchronize();
+  (void)hipEventRecord(e0);
+  hipLaunchKernelGGL((k3<NW>), dim3(blocks), dim3(NW * 64), 0, 0, d, in, iters);
+  (void)hipEventRecord(e1);
+  (void)hipEventSynchronize(e1);
+  float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+  const double ops = (double)blocks * NW * iters * (30.0 * 16);
+  const double pair_blocks = (double)blocks * NW * 64 * 16 * iters;
+  printf("asm  R=4 TQ=4 NW=%d wg/CU=%d (waves/SIMD=%.1f): %.3f ms, %.2f clk per VALU op -> %.2f Gpairs/s equiv\n",
+         NW, wg_per_cu, wg_per_cu * NW / 4.0, ms, ms * 1e-3 * 2.4e9 / (ops / 1024.0), pair_blocks / (ms * 1e-3) / 80 / 1e9);
+}
+
 int main() {
   uint32_t *d; uint64_t *in;
   (void)hipMalloc(&d, 256 * 8 * 512 * 4);
@@ -189,5 +238,7 @@ int main() {
     run2<4, 8, 4, 0>(d, in, w);
     run2<4, 4, 8, 1>(d, in, w);
   }
+  for (int w : {1, 2, 4}) { run3<4>(d, in, w); }
+  for (int w : {1, 2}) { run3<8>(d, in, w); }
   return 0;
 }
