@@ -449,11 +449,8 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
   const bool wave_active =
       !(p.self && r0 + (V2_RT - 1) <= qw0) && qw0 < p.q_end && qw0 + TQ > p.q_begin;
   // lane l owns refs r0 + {2l, 2l+1, 128+2l, 128+2l+1}: two conflict-free ds_read_b128 per plane
-  size_t rr[R];
-  rr[0] = r0 + 2 * lane;
-  rr[1] = rr[0] + 1;
-  rr[2] = rr[0] + 128;
-  rr[3] = rr[0] + 129;
+  // (recomputed where needed rather than kept live across the compare loop)
+  auto ref_of = [&](int r) -> size_t { return r0 + 2 * lane + (r & 1) + (r >> 1) * 128; };
 
   const int total = p.nk * p.s64;             // one chunk per (k, 64-bin block)
 
@@ -542,7 +539,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
             if constexpr (MODE == MODE_DIST || MODE == MODE_MASK) {
               packed[r][q] |= (PackT)cnt[r][q] << (p.cnt_bits * k);
             } else {
-              const size_t qq = qw0 + q, rf = rr[r];
+              const size_t qq = qw0 + q, rf = ref_of(r);
               const bool valid = rf < p.n_ref && qq >= p.q_begin && qq < p.q_end && (!p.self || rf > qq);
               if (valid) {
                 const size_t row = (p.self ? qq * p.n_ref - (qq * (qq + 1)) / 2 + (rf - qq - 1)
@@ -582,7 +579,8 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
     if (!wave_active || (p.ablate & 1)) return;
     int cr[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) cr[r] = (ref_clu && rr[r] < p.n_ref) ? ref_clu[rr[r]] : 0;
+    for (int r = 0; r < R; ++r) cr[r] = (ref_clu && ref_of(r) < p.n_ref) ? ref_clu[ref_of(r)] : 0;
+    unsigned n_fail_wave = 0;   // failed fits of this wavefront: ONE atomic at the end
 #pragma unroll
     for (int q = 0; q < TQ; ++q) {
       const size_t qq = qw0 + q;   // wave-uniform
@@ -592,16 +590,13 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
       uint64_t ball[R];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        const size_t rf = rr[r];
+        const size_t rf = ref_of(r);
         const bool valid = rf < p.n_ref && (!p.self || rf > qq);
         const double *lutp = lut + (size_t)(cr[r] * p.n_clu + cq) * p.lut_cpstride;
         float core = 0.0f, acc = 0.0f;
         bool failed = false;
         if (valid) fit_packed<PackT>(packed[r][q], lutp, p, core, acc, failed);
-        if (n_failed) {
-          const uint64_t fm = __ballot(valid && failed);
-          if (fm && lane == 0) atomicAdd(n_failed, (unsigned long long)__popcll(fm));
-        }
+        n_fail_wave += (unsigned)__popcll(__ballot(valid && failed));
         if constexpr (MODE == MODE_DIST) {
           if (valid) {
             float2 v;
@@ -635,6 +630,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
         }
       }
     }
+    if (n_failed && n_fail_wave && lane == 0) atomicAdd(n_failed, (unsigned long long)n_fail_wave);
   }
 }
 
