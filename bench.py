@@ -12,7 +12,8 @@ output [n_pairs, 2] float32 in PopPUNK row order on rank 0.
   N > 1 : weak scaling -- round(10 000 * sqrt(N)) genomes, so every GPU still owns
           ~49 995 000 pairs; the pair space is band-split over the ranks and the
           distance blocks are gathered to rank 0 with grouped RCCL send/recv
-          inside the timed region (--strong keeps 10 000 genomes instead).
+          inside the timed region, pipelined under the compute in --chunks
+          sub-bands (--strong keeps 10 000 genomes instead).
 
 Rank 0 prints ONE JSON line (see the driver contract) carrying `roofline`
 (dominant kernel, HIP-event timed inside libppk_hip.so on its own stream) and
@@ -46,6 +47,8 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--tile", type=str, default="", help="TQ,NW override (experiments)")
+    ap.add_argument("--chunks", type=int, default=4,
+                    help="sub-bands per rank: the gather of chunk c overlaps the compute of c+1")
     return ap.parse_args()
 
 
@@ -106,32 +109,12 @@ def main():
     tbl = synth.random_match_table(kmers)
     ref = engine.SketchDB(sk, 16, 14, device=local_rank)
 
-    bounds = engine.shard_bounds(n, 0, world)
-    rows = [engine.rows_in_band(n, 0, bounds[i], bounds[i + 1]) for i in range(world)]
-    total_pairs = int(sum(rows))
-    qb, qe = bounds[rank], bounds[rank + 1]
-    local = torch.empty((rows[rank], 2), dtype=torch.float32, device=dev)
-    full = None
-    if world > 1 and rank == 0:
-        full = torch.empty((total_pairs, 2), dtype=torch.float32, device=dev)
+    job = engine.ShardedQuery(ref, None, rank, world, n_chunks=args.chunks if world > 1 else 1)
+    rows = job.band_rows
+    total_pairs = int(job.total_rows)
 
     def step():
-        engine.dist(ref, None, kmers, tbl, q_begin=qb, q_end=qe, out=local)
-        if world > 1:
-            gather(local, full)
-
-    offs = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
-
-    def gather(loc, dst):
-        if rank == 0:
-            dst[offs[0]:offs[1]].copy_(loc)
-            ops = [dist.P2POp(dist.irecv, dst[offs[s]:offs[s + 1]], s)
-                   for s in range(1, world) if rows[s] > 0]
-        else:
-            ops = [dist.P2POp(dist.isend, loc, 0)] if rows[rank] > 0 else []
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
+        job.run(kmers, tbl)
 
     def barrier():
         if world > 1:
@@ -163,7 +146,8 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = total_pairs * args.steps / elapsed
-        achieved = ALGO_BYTES_PER_PAIR * rows[0] / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        per_launch = rows[0] / job.n_chunks          # pairs one launch of the dominant kernel covers
+        achieved = ALGO_BYTES_PER_PAIR * per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):
@@ -174,16 +158,16 @@ def main():
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "kernel": kname, "kernel_ms": round(kernel_ms, 4),
-                "pairs_per_launch": rows[0],
+                "pairs_per_launch": per_launch,
                 "note": "achieved = algorithmic bytes (17928 B/pair x pairs per launch) / HIP-event "
                         "kernel time.  LDS + register tiling re-uses every sketch row ~250x, so frac "
                         "> 1 is the reuse factor (traffic = PMC-measured HBM bytes per launch) and "
                         "the real limiter is integer VALU issue: valu_frac = 2400 VALU lane-ops/pair "
                         "vs 256 CU x 4 SIMD x 32 lanes x 2.4 GHz; valu_frac_measured_peak = vs the "
                         "55.6 T lane-ops/s a pure v_bitop3 stream sustains on this chip",
-                "valu_frac": round(VALU_OPS_PER_PAIR * rows[0] / (kernel_ms * 1e-3) /
+                "valu_frac": round(VALU_OPS_PER_PAIR * per_launch / (kernel_ms * 1e-3) /
                                    VALU_PEAK_LANE_OPS, 4) if kernel_ms > 0 else 0.0,
-                "valu_frac_measured_peak": round(VALU_OPS_PER_PAIR * rows[0] / (kernel_ms * 1e-3) /
+                "valu_frac_measured_peak": round(VALU_OPS_PER_PAIR * per_launch / (kernel_ms * 1e-3) /
                                                  VALU_MEASURED_LANE_OPS, 4) if kernel_ms > 0 else 0.0}
         cpu = None
         if not args.no_cpu and world == 1:
@@ -198,7 +182,7 @@ def main():
                                    "bbits=14), k=13,17,21,25,29, %d pairs, output [n_pairs,2] f32 "
                                    "on rank 0" % (n, total_pairs),
                        "n_genomes": n, "pairs": total_pairs,
-                       "parallelism": "band-split x%d + p2p gather" % world if world > 1 else "1 GPU"},
+                       "parallelism": "band-split x%d, %d-chunk pipelined p2p gather to rank 0" % (world, args.chunks) if world > 1 else "1 GPU"},
             "roofline": roof, "cpu_baseline": cpu,
         }
         if cpu:

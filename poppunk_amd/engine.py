@@ -276,6 +276,90 @@ def gather_bands(local, rows_per_rank, cols, dtype, device, rank, world_size, ds
     return None
 
 
+def sub_bands(q_begin, q_end, n_chunks):
+    """Cut a band of query rows into n_chunks contiguous sub-bands (edges on 64-query tiles)."""
+    edges = [q_begin]
+    for c in range(1, n_chunks):
+        e = q_begin + (q_end - q_begin) * c // n_chunks
+        e = min(q_end, (e + 32) // 64 * 64)
+        edges.append(max(e, edges[-1]))
+    edges.append(q_end)
+    return edges
+
+
+class ShardedQuery:
+    """The N-GPU distance job of BASELINE configs 3/4: one process per GPU, every rank holds
+    the full resident sketches, the pair space is band-split over ranks, and the distance
+    blocks are gathered into the PopPUNK-ordered matrix on rank 0.
+
+    The gather is pipelined under the compute: each rank's band is cut into `n_chunks`
+    sub-bands; as soon as sub-band c has been enqueued its block is handed to an asynchronous
+    send (RCCL runs it on its own stream after the producing kernel), while the next
+    sub-band computes.  Rank 0 posts, per chunk, ONE grouped receive from all peers, each
+    landing directly at its row offset of the final matrix (a band is a contiguous row
+    range, so there is no staging copy or reorder).  On xGMI every peer has its own link to
+    the root, so the seven inbound streams run in parallel.
+
+    `band_fn(q_begin, q_end, out)` overrides the HIP launch (CPU gloo tests)."""
+
+    def __init__(self, ref, qry, rank, world_size, n_chunks=4, cols=2, dtype=None, device=None,
+                 group=None):
+        torch = _torch()
+        self.ref, self.qry = ref, qry
+        self.rank, self.world = rank, world_size
+        self.group = group
+        self.n_qry = qry.n if qry is not None else 0
+        self.bounds = shard_bounds(ref.n, self.n_qry, world_size)
+        self.chunks = [sub_bands(self.bounds[r], self.bounds[r + 1], n_chunks)
+                       for r in range(world_size)]
+        self.rows = [[rows_in_band(ref.n, self.n_qry, ch[c], ch[c + 1]) for c in range(n_chunks)]
+                     for ch in self.chunks]
+        self.n_chunks = n_chunks
+        self.cols = cols
+        self.band_rows = [sum(r) for r in self.rows]
+        self.total_rows = sum(self.band_rows)
+        dtype = dtype or torch.float32
+        if device is None:
+            device = "cuda:%d" % ref.device
+        # rank 0 owns the full matrix and computes its own band in place; peers own a band
+        n_local = self.total_rows if rank == 0 else self.band_rows[rank]
+        self.out = torch.empty((n_local, cols), dtype=dtype, device=device)
+        self.band_off = [0]
+        for r in range(world_size):
+            self.band_off.append(self.band_off[-1] + self.band_rows[r])
+
+    def _chunk_view(self, r, c):
+        """Rows of chunk c of rank r's band inside self.out (rank 0: global offsets)."""
+        start = sum(self.rows[r][:c]) + (self.band_off[r] if self.rank == 0 else 0)
+        return self.out[start:start + self.rows[r][c]]
+
+    def run(self, kmers=None, random_tbl=None, random_correct=True, band_fn=None):
+        """One whole-job step.  Returns the full matrix on rank 0 (None elsewhere)."""
+        import torch.distributed as dist_
+        pending = []
+        for c in range(self.n_chunks):
+            qb, qe = self.chunks[self.rank][c], self.chunks[self.rank][c + 1]
+            view = self._chunk_view(self.rank, c)
+            if view.shape[0]:
+                if band_fn is not None:
+                    band_fn(qb, qe, view)
+                else:
+                    dist(self.ref, self.qry, kmers, random_tbl, random_correct=random_correct,
+                         q_begin=qb, q_end=qe, out=view)
+            if self.world == 1:
+                continue
+            if self.rank == 0:
+                ops = [dist_.P2POp(dist_.irecv, self._chunk_view(s, c), s, self.group)
+                       for s in range(1, self.world) if self.rows[s][c] > 0]
+            else:
+                ops = [dist_.P2POp(dist_.isend, view, 0, self.group)] if view.shape[0] else []
+            if ops:
+                pending.extend(dist_.batch_isend_irecv(ops))
+        for req in pending:
+            req.wait()
+        return self.out if self.rank == 0 else None
+
+
 def query_sharded(ref, qry, kmers, random_tbl, rank, world_size, random_correct=True,
                   gather=True, band_fn=None, group=None):
     """Config 3/4 shape: every rank holds the full resident sketches, computes its band

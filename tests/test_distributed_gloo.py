@@ -35,9 +35,10 @@ def _worker(rank, world, port, n_ref, n_qry, ret):
     qry_sk = sk[n_ref:] if n_qry else None
     tbl = synth.random_match_table(kmers)
 
-    class DB:                      # the two attributes query_sharded needs from a SketchDB
+    class DB:                      # the attributes the sharding code needs from a SketchDB
         def __init__(self, n):
             self.n = n
+            self.device = 0
 
     def band_fn(qb, qe):
         # rows of queries [qb, qe): ref x query sub-problem, re-ordered to the band's rows
@@ -54,12 +55,19 @@ def _worker(rank, world, port, n_ref, n_qry, ret):
 
     full, rows = engine.query_sharded(DB(n_ref), DB(n_qry) if n_qry else None, kmers, tbl, rank,
                                       world, band_fn=band_fn)
+    # the pipelined job bench.py runs: sub-bands sent while the next one computes
+    job = engine.ShardedQuery(DB(n_ref), DB(n_qry) if n_qry else None, rank, world, n_chunks=3,
+                              device="cpu")
+    piped = job.run(band_fn=lambda qb, qe, out: out.copy_(band_fn(qb, qe)))
+    piped2 = job.run(band_fn=lambda qb, qe, out: out.copy_(band_fn(qb, qe)))   # reusable
     if rank == 0:
         want, _ = oracle.query(ref_sk, qry_sk, kmers, 16, 14, tbl)
         ok = full is not None and np.array_equal(full.numpy(), want) and sum(rows) == len(want)
+        ok = ok and np.array_equal(piped.numpy(), want) and np.array_equal(piped2.numpy(), want)
+        ok = ok and job.total_rows == len(want) and sum(job.band_rows) == len(want)
         ret.put(bool(ok))
     else:
-        assert full is None
+        assert full is None and piped is None
     dist.barrier()
     dist.destroy_process_group()
 
