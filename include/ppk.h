@@ -144,6 +144,29 @@ int ppk_generate_tuples_dev(const int32_t *d_assign, size_t n_rows, int within_l
                             unsigned long long *d_n_edges, void *stream);
 
 /* ------------------------------------------------------------------------
+ * Boundary sweeps of --fit-model refine (SURVEY.md 8f "next" rows), on a
+ * resident self/condensed [n_rows][2] float32 distance buffer.  Outputs are
+ * three int64 arrays (i, j, offset index), element for element the vectors
+ * the reference returns; *d_n_out receives the total (only the first cap
+ * entries are stored).  These two entry points synchronise the stream once
+ * (the intermediate candidate count sizes a sort).
+ */
+/* replaces poppunk_refine.thresholdIterate1D (src/python_bindings.cpp:49-60;
+ * src/boundary.cpp:154-210; caller PopPUNK/refine.py:190-200).  `offsets`
+ * (host, sorted ascending) are distances along the line (x0,y0)->(x1,y1). */
+int ppk_threshold_iterate_1d_dev(const float *d_dist, size_t n_rows, const double *offsets,
+                                 size_t n_off, int slope, float x0, float y0, float x1,
+                                 float y1, long long *d_i, long long *d_j, long long *d_off,
+                                 size_t cap, unsigned long long *d_n_out, void *stream);
+/* replaces poppunk_refine.thresholdIterate2D (src/python_bindings.cpp:62-73;
+ * src/boundary.cpp:212-237; caller PopPUNK/refine.py:587-593).  `x_max`
+ * (host, sorted ascending), fixed y_max, slope 2. */
+int ppk_threshold_iterate_2d_dev(const float *d_dist, size_t n_rows, const float *x_max,
+                                 size_t n_off, float y_max, long long *d_i, long long *d_j,
+                                 long long *d_off, size_t cap, unsigned long long *d_n_out,
+                                 void *stream);
+
+/* ------------------------------------------------------------------------
  * Host-buffer convenience wrappers (what a pybind11/ctypes drop-in binds):
  * upload, run on `devices[0..n_dev)` (the pair space is band-split across
  * them), copy back.  Blocking.
@@ -170,6 +193,15 @@ int ppk_edge_threshold(const float *dist, size_t n_rows, size_t n_ref, int slope
 int ppk_generate_tuples(const int32_t *assignments, size_t n_rows, int within_label,
                         int self, size_t num_ref, long long int_offset, int device_id,
                         long long *ij_out, size_t cap, size_t *n_edges);
+
+/* host-buffer forms of the two sweeps (PPK_ERR_CAPACITY when *n_out > cap) */
+int ppk_threshold_iterate_1d(const float *dist, size_t n_rows, const double *offsets,
+                             size_t n_off, int slope, float x0, float y0, float x1, float y1,
+                             int device_id, long long *i_out, long long *j_out,
+                             long long *off_out, size_t cap, size_t *n_out);
+int ppk_threshold_iterate_2d(const float *dist, size_t n_rows, const float *x_max, size_t n_off,
+                             float y_max, int device_id, long long *i_out, long long *j_out,
+                             long long *off_out, size_t cap, size_t *n_out);
 
 /* ------------------------------------------------------------------------
  * Measurement hooks (bench.py): when enabled, the dominant kernel of each

@@ -61,6 +61,16 @@ def lib():
         _lib.ppk_oracle_rows_to_samples.argtypes = [c.c_size_t]
         _lib.ppk_oracle_rows_to_samples.restype = c.c_size_t
         _lib.ppk_oracle_max_threads.restype = c.c_int
+        _lib.ppk_oracle_threshold_iterate_1d.argtypes = [f32p, c.c_size_t, f64p, c.c_size_t, c.c_int,
+                                                        c.c_float, c.c_float, c.c_float, c.c_float,
+                                                        i64p, i64p, i64p, c.c_size_t]
+        _lib.ppk_oracle_threshold_iterate_1d.restype = c.c_size_t
+        _lib.ppk_oracle_threshold_iterate_2d.argtypes = [f32p, c.c_size_t, f32p, c.c_size_t,
+                                                        c.c_float, i64p, i64p, i64p, c.c_size_t]
+        _lib.ppk_oracle_threshold_iterate_2d.restype = c.c_size_t
+        _lib.ppk_oracle_boundary_of_offset.argtypes = [c.c_double, c.c_int, c.c_float, c.c_float,
+                                                      c.c_float, c.c_float, f32p]
+        _lib.ppk_oracle_boundary_of_offset.restype = None
     return _lib
 
 
@@ -165,6 +175,43 @@ def generate_tuples(assignments, within_label, self=True, num_ref=0, int_offset=
     ne = lib().ppk_oracle_generate_tuples(_p(a, ctypes.c_int32), cap, within_label, int(self),
                                           num_ref, int_offset, _p(ij, ctypes.c_int64), cap)
     return ij[:ne].copy()
+
+
+def threshold_iterate_1d(dist, offsets, slope, x0, y0, x1, y1):
+    """(i, j, offset_idx) int64 arrays, as poppunk_refine.thresholdIterate1D (boundary.cpp:154-210)."""
+    dist = np.ascontiguousarray(dist, dtype=np.float32)
+    offsets = np.ascontiguousarray(offsets, dtype=np.float64)
+    cap = dist.shape[0]
+    i = np.zeros(max(cap, 1), dtype=np.int64)
+    j = np.zeros(max(cap, 1), dtype=np.int64)
+    o = np.zeros(max(cap, 1), dtype=np.int64)
+    ne = lib().ppk_oracle_threshold_iterate_1d(_p(dist, ctypes.c_float), cap, _p(offsets, ctypes.c_double),
+                                               len(offsets), slope, np.float32(x0), np.float32(y0),
+                                               np.float32(x1), np.float32(y1), _p(i, ctypes.c_int64),
+                                               _p(j, ctypes.c_int64), _p(o, ctypes.c_int64), cap)
+    return i[:ne].copy(), j[:ne].copy(), o[:ne].copy()
+
+
+def threshold_iterate_2d(dist, x_max, y_max):
+    """(i, j, offset_idx) as poppunk_refine.thresholdIterate2D (boundary.cpp:212-237)."""
+    dist = np.ascontiguousarray(dist, dtype=np.float32)
+    x_max = np.ascontiguousarray(x_max, dtype=np.float32)
+    cap = dist.shape[0] * max(len(x_max), 1)
+    i = np.zeros(max(cap, 1), dtype=np.int64)
+    j = np.zeros(max(cap, 1), dtype=np.int64)
+    o = np.zeros(max(cap, 1), dtype=np.int64)
+    ne = lib().ppk_oracle_threshold_iterate_2d(_p(dist, ctypes.c_float), dist.shape[0],
+                                               _p(x_max, ctypes.c_float), len(x_max), np.float32(y_max),
+                                               _p(i, ctypes.c_int64), _p(j, ctypes.c_int64),
+                                               _p(o, ctypes.c_int64), cap)
+    return i[:ne].copy(), j[:ne].copy(), o[:ne].copy()
+
+
+def boundary_of_offset(offset, slope, x0, y0, x1, y1):
+    xy = np.zeros(2, dtype=np.float32)
+    lib().ppk_oracle_boundary_of_offset(float(offset), slope, np.float32(x0), np.float32(y0),
+                                        np.float32(x1), np.float32(y1), _p(xy, ctypes.c_float))
+    return float(xy[0]), float(xy[1])
 
 
 def max_threads():

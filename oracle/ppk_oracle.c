@@ -353,6 +353,113 @@ size_t ppk_oracle_generate_tuples(const int32_t *assignments, size_t n_rows,
   return ne;
 }
 
+/* ---- next row: threshold_iterate_1D (src/boundary.cpp:154-210) --------------------------
+ * Boundary o passes through (x0,y0) + offsets[o] * unit(x1-x0, y1-y0); rows are ordered by
+ * their line distance to boundary 0 (stable), and for each offset in turn the sweep emits
+ * rows while they are within (<= 0) the CURRENT boundary.  The reference reads
+ * boundary_order[sorted_idx] one past the end when every row is within the last boundary
+ * (undefined behaviour, :206); this restatement stops at the end instead.
+ * Outputs i/j/offset index per emitted row; returns the number emitted (<= cap stored). */
+static void boundary_of_offset(double offset, int slope, float x0, float y0, float dx, float dy,
+                               float ds, float gradient, float *x_max, float *y_max) {
+  /* float x_intercept = x0 + offsets[o] * (dx / ds): the product and sum are done in double
+   * (offsets is a double vector), the result is narrowed to float */
+  const float x_int = (float)((double)x0 + offset * (double)(dx / ds));
+  const float y_int = (float)((double)y0 + offset * (double)(dy / ds));
+  if (slope == 2) {
+    *x_max = x_int + y_int * gradient;
+    *y_max = y_int + x_int / gradient;
+  } else if (slope == 0) {
+    *x_max = x_int;
+    *y_max = 0;
+  } else {
+    *x_max = 0;
+    *y_max = y_int;
+  }
+}
+
+void ppk_oracle_boundary_of_offset(double offset, int slope, float x0, float y0, float x1,
+                                   float y1, float *xy /* [2] */) {
+  const float dx = x1 - x0, dy = y1 - y0;
+  const float ds = sqrtf(dx * dx + dy * dy);
+  boundary_of_offset(offset, slope, x0, y0, dx, dy, ds, dy / dx, &xy[0], &xy[1]);
+}
+
+typedef struct {
+  float d;
+  long idx;
+} dist_idx;
+
+static int cmp_dist_idx(const void *a, const void *b) {
+  const dist_idx *x = (const dist_idx *)a, *y = (const dist_idx *)b;
+  if (x->d < y->d) return -1;
+  if (x->d > y->d) return 1;
+  return (x->idx > y->idx) - (x->idx < y->idx); /* stable: ties keep row order */
+}
+
+size_t ppk_oracle_threshold_iterate_1d(const float *dist, size_t n_rows, const double *offsets,
+                                       size_t n_off, int slope, float x0, float y0, float x1,
+                                       float y1, int64_t *i_out, int64_t *j_out,
+                                       int64_t *off_out, size_t cap) {
+  const float dx = x1 - x0, dy = y1 - y0;
+  const float ds = sqrtf(dx * dx + dy * dy);
+  const float gradient = dy / dx;
+  const size_t n = samples_of_rows(n_rows);
+  dist_idx *order = (dist_idx *)malloc((n_rows ? n_rows : 1) * sizeof(dist_idx));
+  size_t sorted_idx = 0, ne = 0;
+  for (size_t o = 0; o < n_off; o++) {
+    float x_max, y_max;
+    boundary_of_offset(offsets[o], slope, x0, y0, dx, dy, ds, gradient, &x_max, &y_max);
+    if (o == 0) {
+      for (size_t r = 0; r < n_rows; r++) {
+        order[r].d = line_dist(dist[2 * r], dist[2 * r + 1], x_max, y_max, slope);
+        order[r].idx = (long)r;
+      }
+      qsort(order, n_rows, sizeof(dist_idx), cmp_dist_idx);
+    }
+    while (sorted_idx < n_rows) {
+      const size_t row = (size_t)order[sorted_idx].idx;
+      if (!(line_dist(dist[2 * row], dist[2 * row + 1], x_max, y_max, slope) <= 0)) break;
+      if (ne < cap) {
+        const size_t i = cond_row_idx(row, n);
+        i_out[ne] = (int64_t)i;
+        j_out[ne] = (int64_t)(row - row_start(i, n) + i + 1);
+        off_out[ne] = (int64_t)o;
+      }
+      ne++;
+      sorted_idx++;
+    }
+  }
+  free(order);
+  return ne;
+}
+
+/* ---- next row: threshold_iterate_2D (src/boundary.cpp:212-237) --------------------------
+ * For each x_max[o] (with fixed y_max, slope 2): rows within boundary o that were NOT within
+ * boundary o-1, in row order. */
+size_t ppk_oracle_threshold_iterate_2d(const float *dist, size_t n_rows, const float *x_max,
+                                       size_t n_off, float y_max, int64_t *i_out,
+                                       int64_t *j_out, int64_t *off_out, size_t cap) {
+  const size_t n = samples_of_rows(n_rows);
+  size_t ne = 0;
+  for (size_t o = 0; o < n_off; o++) {
+    for (size_t row = 0; row < n_rows; row++) {
+      if (line_dist(dist[2 * row], dist[2 * row + 1], x_max[o], y_max, 2) <= 0) {
+        if (o == 0 || line_dist(dist[2 * row], dist[2 * row + 1], x_max[o - 1], y_max, 2) > 0) {
+          if (ne < cap) {
+            const size_t i = cond_row_idx(row, n);
+            i_out[ne] = (int64_t)i;
+            j_out[ne] = (int64_t)(row - row_start(i, n) + i + 1);
+            off_out[ne] = (int64_t)o;
+          }
+          ne++;
+        }
+      }
+    }
+  }
+  return ne;
+}
+
 int ppk_oracle_max_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

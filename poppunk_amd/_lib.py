@@ -46,6 +46,16 @@ SIGNATURES = {
                                      C.c_int, _llp, _sz, _szp]),
     "ppk_generate_tuples": (C.c_int, [_i32p, _sz, C.c_int, C.c_int, _sz, C.c_longlong, C.c_int,
                                       _llp, _sz, _szp]),
+    "ppk_threshold_iterate_1d_dev": (C.c_int, [_vp, _sz, C.POINTER(C.c_double), _sz, C.c_int,
+                                               C.c_float, C.c_float, C.c_float, C.c_float, _vp,
+                                               _vp, _vp, _sz, _vp, _vp]),
+    "ppk_threshold_iterate_2d_dev": (C.c_int, [_vp, _sz, _f32p, _sz, C.c_float, _vp, _vp, _vp,
+                                               _sz, _vp, _vp]),
+    "ppk_threshold_iterate_1d": (C.c_int, [_f32p, _sz, C.POINTER(C.c_double), _sz, C.c_int,
+                                           C.c_float, C.c_float, C.c_float, C.c_float, C.c_int,
+                                           _llp, _llp, _llp, _sz, _szp]),
+    "ppk_threshold_iterate_2d": (C.c_int, [_f32p, _sz, _f32p, _sz, C.c_float, C.c_int, _llp,
+                                           _llp, _llp, _sz, _szp]),
     "ppk_prof_enable": (C.c_int, [C.c_int]),
     "ppk_prof_read": (C.c_int, [C.POINTER(C.c_double), _llp, C.c_int]),
     "ppk_last_kernel_name": (C.c_char_p, []),

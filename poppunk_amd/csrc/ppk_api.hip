@@ -258,10 +258,11 @@ struct Scratch {
   void *p = nullptr;
   size_t bytes = 0;
 };
-Scratch g_scratch[64][3];  // [device][slot]
+Scratch g_scratch[64][SLOT_COUNT];  // [device][slot]
 
 int scratch_get(int dev, int slot, size_t bytes, void **out) {
-  if (dev < 0 || dev >= 64) return ppk_fail(PPK_ERR_ARG, "device id out of range");
+  if (dev < 0 || dev >= 64 || slot < 0 || slot >= SLOT_COUNT)
+    return ppk_fail(PPK_ERR_ARG, "device id out of range");
   Scratch &s = g_scratch[dev][slot];
   if (s.bytes < bytes) {
     if (s.p) {
@@ -279,7 +280,6 @@ int scratch_get(int dev, int slot, size_t bytes, void **out) {
   return PPK_OK;
 }
 
-enum { SLOT_LUT = 0, SLOT_MASK = 1, SLOT_WS = 2 };
 
 // random table (host) -> device copy placed after the LUT in the LUT scratch
 int stage_tables(const ppk_db *ref, const float *random_tbl, size_t n_clu, int flags, hipStream_t s,
@@ -302,6 +302,8 @@ int stage_tables(const ppk_db *ref, const float *random_tbl, size_t n_clu, int f
 }
 
 }  // namespace
+
+int ppk_scratch_get(int dev, int slot, size_t bytes, void **out) { return scratch_get(dev, slot, bytes, out); }
 
 extern "C" int ppk_dist_dev(const ppk_db *ref, const ppk_db *qry, const int32_t *kmers,
                             const float *random_tbl, size_t n_clu, int flags, size_t q_begin,

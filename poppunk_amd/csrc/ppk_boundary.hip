@@ -191,6 +191,36 @@ mask_expand_kernel(const uint64_t *__restrict__ mask, size_t n_words,
         }
         ++pos;
       }
+    } else if (g.layout == EDGE_ROWS) {
+      unsigned long long *rows = reinterpret_cast<unsigned long long *>(edges);
+      while (bits) {
+        const int t = __builtin_ctzll(bits);
+        bits &= bits - 1;
+        if (pos < cap) rows[pos] = (unsigned long long)(w * 64 + t);
+        ++pos;
+      }
+    } else if (g.layout == EDGE_COO_SEGMENTS) {
+      long long *oi = reinterpret_cast<long long *>(edges);
+      const size_t n = g.n_samples;
+      const size_t seg = w / g.seg_words;
+      const size_t row0 = (w % g.seg_words) * 64;
+      size_t ii = cond_row_idx(row0 < g.n_rows ? row0 : g.n_rows - 1, n);
+      size_t rs = cond_row_start(ii, n);
+      while (bits) {
+        const int t = __builtin_ctzll(bits);
+        bits &= bits - 1;
+        const size_t row = row0 + t;
+        while (row >= rs + (n - 1 - ii)) {
+          rs += n - 1 - ii;
+          ++ii;
+        }
+        if (pos < cap) {
+          oi[pos] = (long long)ii;
+          g.coo_j[pos] = (long long)(ii + 1 + (row - rs));
+          g.coo_seg[pos] = (long long)seg;
+        }
+        ++pos;
+      }
     } else if (g.layout == EDGE_LINEAR_NONSELF) {
       const size_t row0 = w * 64;
       while (bits) {

@@ -55,7 +55,9 @@ enum EdgeLayout {
   EDGE_LINEAR_SELF = 0,     // bit b of word w <-> condensed row 64*w + b
   EDGE_LINEAR_NONSELF = 1,  // row = q*n_ref + r
   EDGE_TILED_SELF = 2,      // word (q - q_begin)*n_rtiles + rt, bit = r - 64*rt
-  EDGE_TILED_NONSELF = 3
+  EDGE_TILED_NONSELF = 3,
+  EDGE_ROWS = 4,            // linear; emit the row index itself (uint64 array)
+  EDGE_COO_SEGMENTS = 5     // seg_words-long linear self masks back to back; emit i[], j[], segment[]
 };
 
 struct EdgeGeom {
@@ -66,6 +68,9 @@ struct EdgeGeom {
   size_t q_begin;    // tiled layouts
   size_t n_rtiles;   // tiled layouts
   long long int_offset;
+  size_t seg_words;         // EDGE_COO_SEGMENTS: mask words per segment
+  long long *coo_j;         // EDGE_COO_SEGMENTS: second and third output arrays (first = d_edges)
+  long long *coo_seg;
 };
 
 // Workspace sizes / launchers; all enqueue on `s` and never synchronise.
@@ -80,6 +85,11 @@ int ppk_launch_compact(const uint64_t *d_mask, size_t n_words, const EdgeGeom &g
                        hipStream_t s);
 int ppk_launch_assign(const float *d_dist, size_t n_rows, int slope, float x_max, float y_max,
                       float *d_out, hipStream_t s);
+
+// grow-only per-device scratch (ppk_api.hip)
+enum { SLOT_LUT = 0, SLOT_MASK = 1, SLOT_WS = 2, SLOT_ITER_A = 3, SLOT_ITER_B = 4, SLOT_ITER_C = 5,
+       SLOT_COUNT = 6 };
+int ppk_scratch_get(int dev, int slot, size_t bytes, void **out);
 
 // line_dist of src/boundary.cpp:42-58: float32, un-fused, evaluated as
 // ((y0*x_max) + (x0*y_max)) - (x_max*y_max)  (SURVEY.md Appendix B).

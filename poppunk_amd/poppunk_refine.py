@@ -5,6 +5,9 @@ extension (src/python_bindings.cpp:79-96), backed by libppk_hip.so.
     edgeThreshold(distMat, slope, x_max, y_max)                  -> list[(i, j)]
     generateTuples(assignments, within_label, self=True, num_ref=0, int_offset=0)
                                                                  -> list[(i, j)]
+    thresholdIterate1D(distMat, offsets, slope, x0, y0, x1, y1, num_threads=1)
+                                                                 -> (i_vec, j_vec, offset_idx)
+    thresholdIterate2D(distMat, x_max, y_max)                    -> (i_vec, j_vec, offset_idx)
 
 As in the pybind11 module, `distMat` must already be a C-contiguous float32
 [n, 2] array (`py::arg("distMat").noconvert()`, src/python_bindings.cpp:82,:89):
@@ -86,3 +89,57 @@ def generateTuples(assignments, within_label, self=True, num_ref=0, int_offset=0
     """Rows with assignments == within_label as (i, j), i < j (src/boundary.cpp:97-123)."""
     return [tuple(e) for e in
             generateTuples_array(assignments, within_label, self, num_ref, int_offset).tolist()]
+
+
+def _coo(call):
+    n_out = C.c_size_t(0)
+    rc = call(None, None, None, 0, C.byref(n_out))
+    if rc not in (_lib.OK, _lib.ERR_CAPACITY):
+        _lib.check(rc, "threshold iterate")
+    n = int(n_out.value)
+    i = np.empty(n, dtype=np.int64)
+    j = np.empty(n, dtype=np.int64)
+    o = np.empty(n, dtype=np.int64)
+    if n:
+        ll = C.POINTER(C.c_longlong)
+        rc = call(i.ctypes.data_as(ll), j.ctypes.data_as(ll), o.ctypes.data_as(ll), n, C.byref(n_out))
+        _lib.check(rc, "threshold iterate")
+    return i, j, o
+
+
+def thresholdIterate1D_arrays(distMat, offsets, slope, x0, y0, x1, y1):
+    d = _check_dist(distMat)
+    off = np.ascontiguousarray(offsets, dtype=np.float64).ravel()
+    if np.any(np.diff(off) < 0):
+        # src/python_bindings.cpp:54-56
+        raise RuntimeError("Offsets to thresholdIterate1D must be sorted")
+    lib = _lib.lib()
+    return _coo(lambda pi, pj, po, cap, n: lib.ppk_threshold_iterate_1d(
+        d.ctypes.data_as(C.POINTER(C.c_float)), d.shape[0], off.ctypes.data_as(C.POINTER(C.c_double)),
+        off.size, int(slope), float(x0), float(y0), float(x1), float(y1), _DEVICE, pi, pj, po, cap, n))
+
+
+def thresholdIterate1D(distMat, offsets, slope, x0, y0, x1, y1, num_threads=1):
+    """Move a boundary along the line (x0,y0)->(x1,y1): for each (sorted) offset the edges that
+    newly fall within it, as three lists (i, j, offset index) (src/boundary.cpp:154-210)."""
+    i, j, o = thresholdIterate1D_arrays(distMat, offsets, slope, x0, y0, x1, y1)
+    return i.tolist(), j.tolist(), o.tolist()
+
+
+def thresholdIterate2D_arrays(distMat, x_max, y_max):
+    d = _check_dist(distMat)
+    xm = np.ascontiguousarray(x_max, dtype=np.float32).ravel()
+    if np.any(np.diff(xm) < 0):
+        # src/python_bindings.cpp:66-69
+        raise RuntimeError("x_max range to thresholdIterate2D must be sorted")
+    lib = _lib.lib()
+    return _coo(lambda pi, pj, po, cap, n: lib.ppk_threshold_iterate_2d(
+        d.ctypes.data_as(C.POINTER(C.c_float)), d.shape[0], xm.ctypes.data_as(C.POINTER(C.c_float)),
+        xm.size, float(y_max), _DEVICE, pi, pj, po, cap, n))
+
+
+def thresholdIterate2D(distMat, x_max, y_max):
+    """Edges entering the slope-2 boundary (x_max[o], y_max) that were outside (x_max[o-1], y_max)
+    (src/boundary.cpp:212-237)."""
+    i, j, o = thresholdIterate2D_arrays(distMat, x_max, y_max)
+    return i.tolist(), j.tolist(), o.tolist()

@@ -177,3 +177,87 @@ def test_fused_edges_ref_query():
     assert np.array_equal(a.cpu().numpy(), oracle.assign_threshold(dist, 2, x_max, y_max))
     rdb.close()
     qdb.close()
+
+
+# ---- "next" rows: the boundary sweeps ----------------------------------------
+
+@pytest.mark.parametrize("slope", [0, 1, 2])
+@pytest.mark.parametrize("samples", [3, 100, 700])
+def test_threshold_iterate_1d(samples, slope):
+    """poppunk_refine.thresholdIterate1D (boundary.cpp:154-210) element for element, plus the
+    reference test's own check (test/test-refine.py:84-110): edges with offset index <= o are
+    exactly the rows assignThreshold puts within (<= 0) boundary o."""
+    rng = np.random.Generator(np.random.PCG64(7 + samples))
+    d = (rng.random((samples * (samples - 1) // 2, 2)) * 0.6).astype(np.float32)
+    offsets = np.linspace(-0.05, 0.25, 12) * np.sqrt(2)
+    x0, y0, x1, y1 = 0.1, 0.12, 0.3, 0.36
+    gi, gj, go = poppunk_refine.thresholdIterate1D_arrays(d, offsets, slope, x0, y0, x1, y1)
+    wi, wj, wo = oracle.threshold_iterate_1d(d, offsets, slope, x0, y0, x1, y1)
+    assert len(wi) > 0 or samples == 3
+    assert np.array_equal(gi, wi) and np.array_equal(gj, wj) and np.array_equal(go, wo)
+    for oi, off in enumerate(offsets):
+        xm, ym = oracle.boundary_of_offset(off, slope, x0, y0, x1, y1)
+        a = poppunk_refine.assignThreshold(d, slope, xm, ym)
+        want = set(map(tuple, oracle.edge_threshold(d, slope, xm, ym).tolist()))
+        assert want == {(int(a_), int(b_)) for a_, b_, c_ in zip(gi, gj, go) if c_ <= oi}
+        assert len(want) == int((a <= 0).sum())
+    # list-returning form, as pybind returns it
+    li, lj, lo = poppunk_refine.thresholdIterate1D(d, list(offsets), slope, x0, y0, x1, y1, 2)
+    assert li == gi.tolist() and lj == gj.tolist() and lo == go.tolist()
+
+
+def test_threshold_iterate_1d_edge_cases():
+    rng = np.random.Generator(np.random.PCG64(99))
+    d = (rng.random((4950, 2)) * 0.5).astype(np.float32)
+    with pytest.raises(RuntimeError, match="must be sorted"):
+        poppunk_refine.thresholdIterate1D(d, [0.1, 0.0], 2, 0.2, 0.2, 0.3, 0.3)
+    # nothing within any boundary
+    i, j, o = poppunk_refine.thresholdIterate1D(d + np.float32(5), [0.0, 0.1], 2, 0.2, 0.2, 0.3, 0.3)
+    assert i == [] and j == [] and o == []
+    # every row within the last boundary (where the reference reads one past the end)
+    gi, gj, go = poppunk_refine.thresholdIterate1D_arrays(d, [0.0, 3.0], 2, 0.2, 0.2, 0.3, 0.3)
+    wi, wj, wo = oracle.threshold_iterate_1d(d, [0.0, 3.0], 2, 0.2, 0.2, 0.3, 0.3)
+    assert len(gi) == 4950 and np.array_equal(gi, wi) and np.array_equal(gj, wj) and np.array_equal(go, wo)
+    # a sweep that moves towards the origin (boundaries shrink): the exact sequential path
+    off = np.linspace(0.0, 0.2, 5)
+    gi, gj, go = poppunk_refine.thresholdIterate1D_arrays(d, off, 2, 0.3, 0.3, 0.1, 0.1)
+    wi, wj, wo = oracle.threshold_iterate_1d(d, off, 2, 0.3, 0.3, 0.1, 0.1)
+    assert len(wi) > 0 and np.array_equal(gi, wi) and np.array_equal(gj, wj) and np.array_equal(go, wo)
+    # duplicate distances: ties must keep row order (stable sort)
+    dd = np.repeat(d[:100], 3, axis=0)[:276]      # 24 samples -> 276 rows
+    gi, gj, go = poppunk_refine.thresholdIterate1D_arrays(dd, off, 2, 0.1, 0.1, 0.3, 0.3)
+    wi, wj, wo = oracle.threshold_iterate_1d(dd, off, 2, 0.1, 0.1, 0.3, 0.3)
+    assert np.array_equal(gi, wi) and np.array_equal(gj, wj) and np.array_equal(go, wo)
+
+
+@pytest.mark.parametrize("samples", [3, 100, 700])
+def test_threshold_iterate_2d(samples):
+    """poppunk_refine.thresholdIterate2D (boundary.cpp:212-237), and test-refine.py:112-138."""
+    rng = np.random.Generator(np.random.PCG64(17 + samples))
+    d = (rng.random((samples * (samples - 1) // 2, 2)) * 0.6).astype(np.float32)
+    x_max = np.asarray([0.1, 0.2, 0.3, 0.45], dtype=np.float32)
+    y_max = 0.2
+    gi, gj, go = poppunk_refine.thresholdIterate2D_arrays(d, x_max, y_max)
+    wi, wj, wo = oracle.threshold_iterate_2d(d, x_max, y_max)
+    assert np.array_equal(gi, wi) and np.array_equal(gj, wj) and np.array_equal(go, wo)
+    for oi, xm in enumerate(x_max):
+        want = set(map(tuple, oracle.edge_threshold(d, 2, float(xm), y_max).tolist()))
+        assert want == {(int(a_), int(b_)) for a_, b_, c_ in zip(gi, gj, go) if c_ <= oi}
+    with pytest.raises(RuntimeError, match="must be sorted"):
+        poppunk_refine.thresholdIterate2D(d, [0.2, 0.1], 0.2)
+
+
+def test_threshold_iterate_on_real_distances():
+    """The --fit-model refine shape: 40 offsets over a resident distance matrix."""
+    sk, _ = synth.make_sketches(3000, KMERS, cluster_size=30)
+    tbl = synth.random_match_table(KMERS)
+    dist, _ = pp_sketchlib.query_arrays(sk, None, KMERS, 16, 14, tbl)
+    scale = dist.max(axis=0)
+    x = np.ascontiguousarray(dist / scale)
+    m0 = np.quantile(x, 0.01, axis=0)
+    m1 = np.quantile(x, 0.5, axis=0)
+    offsets = np.linspace(0.0, float(np.linalg.norm(m1 - m0)), 40)
+    gi, gj, go = poppunk_refine.thresholdIterate1D_arrays(x, offsets, 2, m0[0], m0[1], m1[0], m1[1])
+    wi, wj, wo = oracle.threshold_iterate_1d(x, offsets, 2, m0[0], m0[1], m1[0], m1[1])
+    assert len(wi) > 10000
+    assert np.array_equal(gi, wi) and np.array_equal(gj, wj) and np.array_equal(go, wo)
