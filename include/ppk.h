@@ -194,6 +194,39 @@ int ppk_generate_tuples(const int32_t *assignments, size_t n_rows, int within_la
                         int self, size_t num_ref, long long int_offset, int device_id,
                         long long *ij_out, size_t cap, size_t *n_edges);
 
+/* ------------------------------------------------------------------------
+ * Long <-> square distance transforms and k nearest neighbours (SURVEY.md 8f
+ * rank 2).  "Long" = condensed upper triangle in PopPUNK row order; element e
+ * of a long vector is read at d_long[e*stride + col], so a column of the
+ * resident [n_pairs][2] matrix is used in place (stride 2, col 0/1).
+ */
+/* replaces pp_sketchlib.longToSquare(distVec, num_threads) [EXT]
+ * (PopPUNK/utils.py:393-396): symmetric n x n, zero diagonal */
+int ppk_long_to_square_dev(const float *d_long, size_t stride, size_t col, size_t n,
+                           float *d_square, void *stream);
+/* replaces pp_sketchlib.longToSquareMulti(distVec, query_ref_distVec,
+ * query_query_distVec, num_threads) [EXT] (PopPUNK/utils.py:398-405):
+ * (n_ref+n_qry)^2 matrix from the ref-ref, query-ref (row = q*n_ref + r) and
+ * query-query long vectors */
+int ppk_long_to_square_multi_dev(const float *d_rr, const float *d_qr, const float *d_qq,
+                                 size_t stride, size_t col, size_t n_ref, size_t n_qry,
+                                 float *d_square, void *stream);
+/* replaces pp_sketchlib.squareToLong(distMat, num_threads) [EXT]
+ * (PopPUNK/network.py:2133-2134) */
+int ppk_square_to_long_dev(const float *d_square, size_t n, float *d_long, void *stream);
+/* replaces poppunk_refine.get_kNN_distances(distMat, kNN, dist_col, num_threads)
+ * (src/extend.cpp:248-289): per row the kNN smallest entries other than the row
+ * itself, ties by column index; outputs [n*kNN] (i, j, dist) */
+int ppk_knn_dev(const float *d_square, size_t n, int knn, long long *d_i, long long *d_j,
+                float *d_dist, void *stream);
+/* host-buffer forms */
+int ppk_long_to_square(const float *vec, size_t n, int device_id, float *square);
+int ppk_long_to_square_multi(const float *rr, const float *qr, const float *qq, size_t n_ref,
+                             size_t n_qry, int device_id, float *square);
+int ppk_square_to_long(const float *square, size_t n, int device_id, float *vec);
+int ppk_knn(const float *square, size_t n, int knn, int device_id, long long *i_out,
+            long long *j_out, float *dist_out);
+
 /* host-buffer forms of the two sweeps (PPK_ERR_CAPACITY when *n_out > cap) */
 int ppk_threshold_iterate_1d(const float *dist, size_t n_rows, const double *offsets,
                              size_t n_off, int slope, float x0, float y0, float x1, float y1,

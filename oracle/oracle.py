@@ -246,3 +246,49 @@ def match_counts_numpy(ref_sk, qry_sk, sketchsize64, bbits):
         for r in range(n_ref):
             rows.append((rb[r] == qb[q]).sum(axis=-1))
     return np.asarray(rows, dtype=np.uint32).reshape(-1, rb.shape[1])
+
+
+# ---- numpy/scipy restatements of the long <-> square transforms and kNN ----
+def long_to_square(vec):
+    """pp_sketchlib.longToSquare [EXT]: condensed (PopPUNK row order) -> symmetric, zero diagonal.
+    scipy.spatial.distance.squareform uses the same row-major upper-triangle order."""
+    from scipy.spatial.distance import squareform
+    v = np.asarray(vec, dtype=np.float32).reshape(-1)
+    if v.size == 0:
+        return np.zeros((1, 1), dtype=np.float32)
+    return squareform(v.astype(np.float64), checks=False).astype(np.float32)
+
+
+def long_to_square_multi(rr, qr, qq):
+    """pp_sketchlib.longToSquareMulti [EXT] (PopPUNK/utils.py:398-405)."""
+    a, c = long_to_square(rr), long_to_square(qq)
+    n_ref, n_qry = a.shape[0], c.shape[0]
+    b = np.asarray(qr, dtype=np.float32).reshape(n_qry, n_ref)       # row = q*n_ref + r
+    out = np.zeros((n_ref + n_qry, n_ref + n_qry), dtype=np.float32)
+    out[:n_ref, :n_ref] = a
+    out[n_ref:, n_ref:] = c
+    out[n_ref:, :n_ref] = b
+    out[:n_ref, n_ref:] = b.T
+    return out
+
+
+def square_to_long(sq):
+    sq = np.asarray(sq, dtype=np.float32)
+    iu = np.triu_indices(sq.shape[0], k=1)
+    return sq[iu]
+
+
+def knn(sq, k):
+    """poppunk_refine.get_kNN_distances (src/extend.cpp:248-289): stable sort of each row, the row
+    itself skipped, first k kept; slots that cannot be filled stay (i, 0, 0.0)."""
+    sq = np.asarray(sq, dtype=np.float32)
+    n = sq.shape[0]
+    oi = np.repeat(np.arange(n, dtype=np.int64), k)
+    oj = np.zeros(n * k, dtype=np.int64)
+    od = np.zeros(n * k, dtype=np.float32)
+    for i in range(n):
+        order = np.argsort(sq[i], kind="stable")
+        order = order[order != i][:k]
+        oj[i * k:i * k + len(order)] = order
+        od[i * k:i * k + len(order)] = sq[i, order]
+    return oi, oj, od

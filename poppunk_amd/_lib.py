@@ -56,6 +56,14 @@ SIGNATURES = {
                                            _llp, _llp, _llp, _sz, _szp]),
     "ppk_threshold_iterate_2d": (C.c_int, [_f32p, _sz, _f32p, _sz, C.c_float, C.c_int, _llp,
                                            _llp, _llp, _sz, _szp]),
+    "ppk_long_to_square_dev": (C.c_int, [_vp, _sz, _sz, _sz, _vp, _vp]),
+    "ppk_long_to_square_multi_dev": (C.c_int, [_vp, _vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp]),
+    "ppk_square_to_long_dev": (C.c_int, [_vp, _sz, _vp, _vp]),
+    "ppk_knn_dev": (C.c_int, [_vp, _sz, C.c_int, _vp, _vp, _vp, _vp]),
+    "ppk_long_to_square": (C.c_int, [_f32p, _sz, C.c_int, _f32p]),
+    "ppk_long_to_square_multi": (C.c_int, [_f32p, _f32p, _f32p, _sz, _sz, C.c_int, _f32p]),
+    "ppk_square_to_long": (C.c_int, [_f32p, _sz, C.c_int, _f32p]),
+    "ppk_knn": (C.c_int, [_f32p, _sz, C.c_int, C.c_int, _llp, _llp, _f32p]),
     "ppk_prof_enable": (C.c_int, [C.c_int]),
     "ppk_prof_read": (C.c_int, [C.POINTER(C.c_double), _llp, C.c_int]),
     "ppk_last_kernel_name": (C.c_char_p, []),

@@ -1,0 +1,295 @@
+// long <-> square distance transforms and k nearest neighbours, on
+// resident buffers.
+//
+//  - ppk_long_to_square_dev        : pp_sketchlib.longToSquare [EXT] (call sites
+//                                    PopPUNK/utils.py:393-396, models.py:1217,1357, mandrake.py:165)
+//  - ppk_long_to_square_multi_dev  : pp_sketchlib.longToSquareMulti [EXT] (PopPUNK/utils.py:398-405)
+//  - ppk_square_to_long_dev        : pp_sketchlib.squareToLong [EXT] (PopPUNK/network.py:2133-2134)
+//  - ppk_knn_dev                   : poppunk_refine.get_kNN_distances (src/extend.cpp:248-289;
+//                                    callers PopPUNK/models.py:1215-1222, assign.py:680-686, mandrake.py:67)
+//
+// The transforms are pure HBM streams (4 B read, 4-8 B written per element).  A 64x64 tile of
+// the upper triangle is read once with coalesced rows into LDS and written twice, as itself and
+// transposed, so both triangles are written with full 256-B rows.
+#include <hipcub/hipcub.hpp>
+
+#include "ppk_internal.h"
+
+namespace {
+
+constexpr int T = 64;
+
+__device__ __forceinline__ size_t cond_index(size_t i, size_t j, size_t n) {  // i < j
+  return i * n - (i * (i + 1)) / 2 + (j - i - 1);
+}
+
+// grid: (n/T) x (n/T) tiles, only bj >= bi do work.  vec element e lives at vec[e*stride + col].
+__global__ void __launch_bounds__(256)
+long_to_square_kernel(const float *__restrict__ vec, size_t stride, size_t col, size_t n,
+                      float *__restrict__ out, size_t ld, size_t off) {
+  __shared__ float tile[T][T + 1];
+  const size_t bi = blockIdx.y, bj = blockIdx.x;
+  if (bj < bi) return;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
+  for (int r = ty; r < T; r += 4) {
+    const size_t i = bi * T + r, j = bj * T + tx;
+    float v = 0.0f;
+    if (i < n && j < n && i != j) {
+      const size_t a = i < j ? i : j, b = i < j ? j : i;
+      v = vec[cond_index(a, b, n) * stride + col];
+    }
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+  for (int r = ty; r < T; r += 4) {
+    const size_t i = bi * T + r, j = bj * T + tx;
+    if (i < n && j < n) out[(off + i) * ld + off + j] = tile[r][tx];
+  }
+  if (bj != bi) {
+    for (int r = ty; r < T; r += 4) {
+      const size_t j = bj * T + r, i = bi * T + tx;      // transposed tile: row j, column i
+      if (i < n && j < n) out[(off + j) * ld + off + i] = tile[tx][r];
+    }
+  }
+}
+
+// query x ref block of longToSquareMulti: qr[q*n_ref + r] -> out[n_ref+q][r] and out[r][n_ref+q]
+__global__ void __launch_bounds__(256)
+qr_block_kernel(const float *__restrict__ qr, size_t stride, size_t col, size_t n_ref, size_t n_qry,
+                float *__restrict__ out, size_t ld) {
+  __shared__ float tile[T][T + 1];
+  const size_t bq = blockIdx.y, br = blockIdx.x;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int k = ty; k < T; k += 4) {
+    const size_t q = bq * T + k, r = br * T + tx;
+    float v = 0.0f;
+    if (q < n_qry && r < n_ref) v = qr[(q * n_ref + r) * stride + col];
+    tile[k][tx] = v;
+    if (q < n_qry && r < n_ref) out[(n_ref + q) * ld + r] = v;
+  }
+  __syncthreads();
+  for (int k = ty; k < T; k += 4) {
+    const size_t r = br * T + k, q = bq * T + tx;
+    if (q < n_qry && r < n_ref) out[r * ld + n_ref + q] = tile[tx][k];
+  }
+}
+
+__global__ void __launch_bounds__(256)
+square_to_long_kernel(const float *__restrict__ sq, size_t n, float *__restrict__ out) {
+  // one block per row i: copies sq[i][i+1 .. n) to its condensed position (contiguous both sides)
+  const size_t i = blockIdx.x;
+  const size_t base = cond_index(i, i + 1, n);
+  for (size_t j = i + 1 + threadIdx.x; j < n; j += 256) out[base + (j - i - 1)] = sq[i * n + j];
+}
+
+__global__ void __launch_bounds__(256)
+knn_init_kernel(float *__restrict__ keys, int *__restrict__ vals, int *__restrict__ seg, size_t n,
+                const float *__restrict__ sq) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e < n * n) {
+    keys[e] = sq[e] + 0.0f;          // -0.0 -> +0.0 so that radix order equals operator<
+    vals[e] = (int)(e % n);
+  }
+  if (e <= n) seg[e] = (int)(e * n);
+}
+
+// first kNN sorted entries of each row that are not the row itself (src/extend.cpp:266-279)
+__global__ void __launch_bounds__(64)
+knn_pick_kernel(const float *__restrict__ skeys, const int *__restrict__ svals, size_t n, int knn,
+                long long *__restrict__ oi, long long *__restrict__ oj, float *__restrict__ od) {
+  const size_t i = blockIdx.x;
+  const int lane = threadIdx.x;
+  // the self entry is somewhere in the first knn+1 .. positions; a wavefront scans 64 at a time
+  int written = 0;
+  for (size_t base = 0; base < n && written < knn; base += 64) {
+    const size_t pos = base + lane;
+    const bool ok = pos < n && (size_t)svals[i * n + pos] != i;
+    const uint64_t m = __ballot(ok);
+    const int rank = written + __popcll(m & ((1ull << lane) - 1ull));
+    if (ok && rank < knn) {
+      oi[i * knn + rank] = (long long)i;
+      oj[i * knn + rank] = svals[i * n + pos];
+      od[i * knn + rank] = skeys[i * n + pos];
+    }
+    written += __popcll(m);
+  }
+  // fewer than knn other samples: the reference leaves i in i_vec and zeros elsewhere
+  for (int k = (written < knn ? written : knn) + lane; k < knn; k += 64) {
+    oi[i * knn + k] = (long long)i;
+    oj[i * knn + k] = 0;
+    od[i * knn + k] = 0.0f;
+  }
+}
+
+}  // namespace
+
+extern "C" int ppk_long_to_square_dev(const float *d_long, size_t stride, size_t col, size_t n,
+                                      float *d_square, void *stream) {
+  if (n == 0) return PPK_OK;
+  if (!d_long || !d_square || stride == 0 || col >= stride)
+    return ppk_fail(PPK_ERR_ARG, "ppk_long_to_square_dev: bad arguments");
+  const unsigned nt = (unsigned)((n + T - 1) / T);
+  hipLaunchKernelGGL(long_to_square_kernel, dim3(nt, nt), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     d_long, stride, col, n, d_square, n, (size_t)0);
+  PPK_HIP(hipGetLastError());
+  return PPK_OK;
+}
+
+extern "C" int ppk_long_to_square_multi_dev(const float *d_rr, const float *d_qr, const float *d_qq,
+                                            size_t stride, size_t col, size_t n_ref, size_t n_qry,
+                                            float *d_square, void *stream) {
+  if (!d_rr || !d_qr || !d_qq || !d_square || stride == 0 || col >= stride || n_ref == 0 || n_qry == 0)
+    return ppk_fail(PPK_ERR_ARG, "ppk_long_to_square_multi_dev: bad arguments");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t ld = n_ref + n_qry;
+  const unsigned ntr = (unsigned)((n_ref + T - 1) / T), ntq = (unsigned)((n_qry + T - 1) / T);
+  hipLaunchKernelGGL(long_to_square_kernel, dim3(ntr, ntr), dim3(256), 0, s, d_rr, stride, col, n_ref,
+                     d_square, ld, (size_t)0);
+  hipLaunchKernelGGL(long_to_square_kernel, dim3(ntq, ntq), dim3(256), 0, s, d_qq, stride, col, n_qry,
+                     d_square, ld, n_ref);
+  hipLaunchKernelGGL(qr_block_kernel, dim3(ntr, ntq), dim3(256), 0, s, d_qr, stride, col, n_ref, n_qry,
+                     d_square, ld);
+  PPK_HIP(hipGetLastError());
+  return PPK_OK;
+}
+
+extern "C" int ppk_square_to_long_dev(const float *d_square, size_t n, float *d_long, void *stream) {
+  if (n < 2) return PPK_OK;
+  if (!d_square || !d_long) return ppk_fail(PPK_ERR_ARG, "ppk_square_to_long_dev: bad arguments");
+  hipLaunchKernelGGL(square_to_long_kernel, dim3((unsigned)(n - 1)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), d_square, n, d_long);
+  PPK_HIP(hipGetLastError());
+  return PPK_OK;
+}
+
+extern "C" int ppk_knn_dev(const float *d_square, size_t n, int knn, long long *d_i, long long *d_j,
+                           float *d_dist, void *stream) {
+  if (n == 0 || knn <= 0) return PPK_OK;
+  if (!d_square || !d_i || !d_j || !d_dist) return ppk_fail(PPK_ERR_ARG, "ppk_knn_dev: bad arguments");
+  if (n * n > 0x7fffffffull) return ppk_fail(PPK_ERR_ARG, "ppk_knn_dev: matrix too large for one segmented sort (n <= 46340)");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int dev = 0;
+  PPK_HIP(hipGetDevice(&dev));
+  const size_t nn = n * n;
+  void *p_a = nullptr, *p_c = nullptr;
+  const size_t o_kin = 0, o_kout = o_kin + nn * 4, o_vin = o_kout + nn * 4, o_vout = o_vin + nn * 4;
+  const size_t o_seg = o_vout + nn * 4, o_end = o_seg + (n + 1) * 4 + 256;
+  int rc = ppk_scratch_get(dev, SLOT_ITER_B, o_end, &p_a);
+  if (rc != PPK_OK) return rc;
+  char *A = static_cast<char *>(p_a);
+  float *kin = reinterpret_cast<float *>(A + o_kin), *kout = reinterpret_cast<float *>(A + o_kout);
+  int *vin = reinterpret_cast<int *>(A + o_vin), *vout = reinterpret_cast<int *>(A + o_vout);
+  int *seg = reinterpret_cast<int *>(A + o_seg);
+  hipLaunchKernelGGL(knn_init_kernel, dim3((unsigned)((nn + n + 256) / 256)), dim3(256), 0, s, kin, vin,
+                     seg, n, d_square);
+  size_t tmp = 0;
+  PPK_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, tmp, kin, kout, vin, vout, (int)nn, (int)n,
+                                                      seg, seg + 1, 0, 32, s));
+  rc = ppk_scratch_get(dev, SLOT_ITER_C, tmp + 256, &p_c);
+  if (rc != PPK_OK) return rc;
+  PPK_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(p_c, tmp, kin, kout, vin, vout, (int)nn, (int)n,
+                                                      seg, seg + 1, 0, 32, s));
+  hipLaunchKernelGGL(knn_pick_kernel, dim3((unsigned)n), dim3(64), 0, s, kout, vout, n, knn, d_i, d_j,
+                     d_dist);
+  PPK_HIP(hipGetLastError());
+  return PPK_OK;
+}
+
+// ---- host-buffer forms (what the pybind functions would bind) --------------------------------
+namespace {
+struct DevBuf {
+  void *p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  int alloc(size_t bytes) {
+    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) return ppk_fail(PPK_ERR_HIP, "hipMalloc failed");
+    return PPK_OK;
+  }
+};
+int h2d(void *d, const void *h, size_t bytes) {
+  if (bytes && hipMemcpy(d, h, bytes, hipMemcpyHostToDevice) != hipSuccess)
+    return ppk_fail(PPK_ERR_HIP, "hipMemcpy H2D failed");
+  return PPK_OK;
+}
+int d2h(void *h, const void *d, size_t bytes) {
+  if (bytes && hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost) != hipSuccess)
+    return ppk_fail(PPK_ERR_HIP, "hipMemcpy D2H failed");
+  return PPK_OK;
+}
+}  // namespace
+
+extern "C" int ppk_long_to_square(const float *vec, size_t n, int device_id, float *square) {
+  if (n == 0) return PPK_OK;
+  if (!vec || !square) return ppk_fail(PPK_ERR_ARG, "NULL buffer");
+  DeviceGuard guard(device_id);
+  if (!guard.ok) return ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(device_id));
+  const size_t rows = n * (n - 1) / 2;
+  DevBuf a, b;
+  int rc = a.alloc(rows * 4);
+  if (rc == PPK_OK) rc = b.alloc(n * n * 4);
+  if (rc == PPK_OK) rc = h2d(a.p, vec, rows * 4);
+  if (rc == PPK_OK) rc = ppk_long_to_square_dev(static_cast<float *>(a.p), 1, 0, n, static_cast<float *>(b.p), nullptr);
+  if (rc == PPK_OK) rc = d2h(square, b.p, n * n * 4);
+  return rc;
+}
+
+extern "C" int ppk_long_to_square_multi(const float *rr, const float *qr, const float *qq, size_t n_ref,
+                                        size_t n_qry, int device_id, float *square) {
+  if (!rr || !qr || !qq || !square || n_ref == 0 || n_qry == 0) return ppk_fail(PPK_ERR_ARG, "NULL buffer / empty input");
+  DeviceGuard guard(device_id);
+  if (!guard.ok) return ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(device_id));
+  const size_t n_rr = n_ref * (n_ref - 1) / 2, n_qr = n_ref * n_qry, n_qq = n_qry * (n_qry - 1) / 2;
+  const size_t n = n_ref + n_qry;
+  DevBuf a, b, c, d;
+  int rc = a.alloc(n_rr * 4);
+  if (rc == PPK_OK) rc = b.alloc(n_qr * 4);
+  if (rc == PPK_OK) rc = c.alloc(n_qq * 4);
+  if (rc == PPK_OK) rc = d.alloc(n * n * 4);
+  if (rc == PPK_OK) rc = h2d(a.p, rr, n_rr * 4);
+  if (rc == PPK_OK) rc = h2d(b.p, qr, n_qr * 4);
+  if (rc == PPK_OK) rc = h2d(c.p, qq, n_qq * 4);
+  if (rc == PPK_OK)
+    rc = ppk_long_to_square_multi_dev(static_cast<float *>(a.p), static_cast<float *>(b.p),
+                                      static_cast<float *>(c.p), 1, 0, n_ref, n_qry,
+                                      static_cast<float *>(d.p), nullptr);
+  if (rc == PPK_OK) rc = d2h(square, d.p, n * n * 4);
+  return rc;
+}
+
+extern "C" int ppk_square_to_long(const float *square, size_t n, int device_id, float *vec) {
+  if (n < 2) return PPK_OK;
+  if (!vec || !square) return ppk_fail(PPK_ERR_ARG, "NULL buffer");
+  DeviceGuard guard(device_id);
+  if (!guard.ok) return ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(device_id));
+  const size_t rows = n * (n - 1) / 2;
+  DevBuf a, b;
+  int rc = a.alloc(n * n * 4);
+  if (rc == PPK_OK) rc = b.alloc(rows * 4);
+  if (rc == PPK_OK) rc = h2d(a.p, square, n * n * 4);
+  if (rc == PPK_OK) rc = ppk_square_to_long_dev(static_cast<float *>(a.p), n, static_cast<float *>(b.p), nullptr);
+  if (rc == PPK_OK) rc = d2h(vec, b.p, rows * 4);
+  return rc;
+}
+
+extern "C" int ppk_knn(const float *square, size_t n, int knn, int device_id, long long *i_out,
+                       long long *j_out, float *dist_out) {
+  if (n == 0 || knn <= 0) return PPK_OK;
+  if (!square || !i_out || !j_out || !dist_out) return ppk_fail(PPK_ERR_ARG, "NULL buffer");
+  DeviceGuard guard(device_id);
+  if (!guard.ok) return ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(device_id));
+  const size_t m = n * (size_t)knn;
+  DevBuf a, bi, bj, bd;
+  int rc = a.alloc(n * n * 4);
+  if (rc == PPK_OK) rc = bi.alloc(m * 8);
+  if (rc == PPK_OK) rc = bj.alloc(m * 8);
+  if (rc == PPK_OK) rc = bd.alloc(m * 4);
+  if (rc == PPK_OK) rc = h2d(a.p, square, n * n * 4);
+  if (rc == PPK_OK)
+    rc = ppk_knn_dev(static_cast<float *>(a.p), n, knn, static_cast<long long *>(bi.p),
+                     static_cast<long long *>(bj.p), static_cast<float *>(bd.p), nullptr);
+  if (rc == PPK_OK) rc = d2h(i_out, bi.p, m * 8);
+  if (rc == PPK_OK) rc = d2h(j_out, bj.p, m * 8);
+  if (rc == PPK_OK) rc = d2h(dist_out, bd.p, m * 4);
+  return rc;
+}

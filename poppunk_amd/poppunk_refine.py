@@ -143,3 +143,23 @@ def thresholdIterate2D(distMat, x_max, y_max):
     (src/boundary.cpp:212-237)."""
     i, j, o = thresholdIterate2D_arrays(distMat, x_max, y_max)
     return i.tolist(), j.tolist(), o.tolist()
+
+
+def get_kNN_distances(distMat, kNN, dist_col=0, num_threads=1):
+    """k nearest neighbours of every row of a square float32 distance matrix, ties by column
+    index, the row itself skipped: (i_vec, j_vec, dists) lists of length n*kNN
+    (src/extend.cpp:248-289; `dist_col` is unused there too)."""
+    if not (isinstance(distMat, np.ndarray) and distMat.dtype == np.float32 and distMat.ndim == 2
+            and distMat.shape[0] == distMat.shape[1] and distMat.flags["C_CONTIGUOUS"]):
+        raise TypeError("distMat must be a C-contiguous square float32 numpy array")
+    n, k = distMat.shape[0], int(kNN)
+    i = np.zeros(n * max(k, 0), dtype=np.int64)
+    j = np.zeros(n * max(k, 0), dtype=np.int64)
+    d = np.zeros(n * max(k, 0), dtype=np.float32)
+    if n and k > 0:
+        ll = C.POINTER(C.c_longlong)
+        rc = _lib.lib().ppk_knn(distMat.ctypes.data_as(C.POINTER(C.c_float)), n, k, _DEVICE,
+                                i.ctypes.data_as(ll), j.ctypes.data_as(ll),
+                                d.ctypes.data_as(C.POINTER(C.c_float)))
+        _lib.check(rc, "get_kNN_distances")
+    return i.tolist(), j.tolist(), d.tolist()

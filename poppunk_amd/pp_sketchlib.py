@@ -120,3 +120,61 @@ def queryDatabase(ref_db_name, query_db_name, rList, qList, klist, random_correc
                          "(fewer than two k-mer lengths above the 5/s Jaccard floor); "
                          "distances set to 0. Check for low quality genomes\n" % n_failed)
     return out
+
+
+def _f32(a, what):
+    a = np.asarray(a)
+    if a.dtype != np.float32:
+        raise TypeError("%s must be float32" % what)
+    return np.ascontiguousarray(a)
+
+
+def _n_of_rows(rows):
+    n = int(round((1 + (1 + 8 * rows) ** 0.5) / 2))
+    if n * (n - 1) // 2 != rows:
+        raise RuntimeError("long-form vector length %d is not n(n-1)/2" % rows)
+    return n
+
+
+def longToSquare(distVec, num_threads=1):
+    """Condensed long-form distances -> symmetric square matrix with a zero diagonal
+    (pp_sketchlib.longToSquare; call sites PopPUNK/utils.py:393-396)."""
+    v = _f32(distVec, "distVec").reshape(-1)
+    n = _n_of_rows(v.size) if v.size else 0
+    out = np.zeros((n, n), dtype=np.float32)
+    if n:
+        _lib.check(_lib.lib().ppk_long_to_square(v.ctypes.data_as(C.POINTER(C.c_float)), n, _devices(0)[0],
+                                                 out.ctypes.data_as(C.POINTER(C.c_float))), "longToSquare")
+    return out
+
+
+def longToSquareMulti(distVec, query_ref_distVec, query_query_distVec, num_threads=1):
+    """(n_ref + n_query)^2 square matrix from ref-ref, query-ref and query-query long vectors
+    (pp_sketchlib.longToSquareMulti; PopPUNK/utils.py:398-405)."""
+    rr = _f32(distVec, "distVec").reshape(-1)
+    qr = _f32(query_ref_distVec, "query_ref_distVec").reshape(-1)
+    qq = _f32(query_query_distVec, "query_query_distVec").reshape(-1)
+    n_ref, n_qry = _n_of_rows(rr.size), _n_of_rows(qq.size)
+    if qr.size != n_ref * n_qry:
+        raise RuntimeError("query-ref vector has %d rows, expected %d" % (qr.size, n_ref * n_qry))
+    out = np.zeros((n_ref + n_qry, n_ref + n_qry), dtype=np.float32)
+    fp = C.POINTER(C.c_float)
+    _lib.check(_lib.lib().ppk_long_to_square_multi(rr.ctypes.data_as(fp), qr.ctypes.data_as(fp),
+                                                   qq.ctypes.data_as(fp), n_ref, n_qry, _devices(0)[0],
+                                                   out.ctypes.data_as(fp)), "longToSquareMulti")
+    return out
+
+
+def squareToLong(distMat, num_threads=1):
+    """Upper triangle of a square matrix in PopPUNK's long order (pp_sketchlib.squareToLong;
+    PopPUNK/network.py:2133-2134)."""
+    m = _f32(distMat, "distMat")
+    if m.ndim != 2 or m.shape[0] != m.shape[1]:
+        raise RuntimeError("distMat must be square")
+    n = m.shape[0]
+    out = np.zeros(n * (n - 1) // 2, dtype=np.float32)
+    if n > 1:
+        fp = C.POINTER(C.c_float)
+        _lib.check(_lib.lib().ppk_square_to_long(m.ctypes.data_as(fp), n, _devices(0)[0],
+                                                 out.ctypes.data_as(fp)), "squareToLong")
+    return out
