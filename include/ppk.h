@@ -143,6 +143,14 @@ int ppk_generate_tuples_dev(const int32_t *d_assign, size_t n_rows, int within_l
                             long long *d_edges, size_t cap,
                             unsigned long long *d_n_edges, void *stream);
 
+/* Distance-QC edge lists: replaces the numpy masks +
+ * generateTuples of qcDistMat (PopPUNK/qc.py:332-337 mode 0: core > max_pi or
+ * accessory > max_a; qc.py:349-354 mode 1: core == 0 or accessory == 0) on the
+ * resident matrix; n_ref == 0 self, else row = q*n_ref + r. */
+int ppk_qc_edges_dev(const float *d_dist, size_t n_rows, size_t n_ref, int mode, float max_pi,
+                     float max_a, long long *d_edges, size_t cap,
+                     unsigned long long *d_n_edges, void *stream);
+
 /* ------------------------------------------------------------------------
  * Boundary sweeps of --fit-model refine (SURVEY.md 8f "next" rows), on a
  * resident self/condensed [n_rows][2] float32 distance buffer.  Outputs are

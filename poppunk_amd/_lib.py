@@ -64,6 +64,7 @@ SIGNATURES = {
     "ppk_long_to_square_multi": (C.c_int, [_f32p, _f32p, _f32p, _sz, _sz, C.c_int, _f32p]),
     "ppk_square_to_long": (C.c_int, [_f32p, _sz, C.c_int, _f32p]),
     "ppk_knn": (C.c_int, [_f32p, _sz, C.c_int, C.c_int, _llp, _llp, _f32p]),
+    "ppk_qc_edges_dev": (C.c_int, [_vp, _sz, _sz, C.c_int, C.c_float, C.c_float, _vp, _sz, _vp, _vp]),
     "ppk_prof_enable": (C.c_int, [C.c_int]),
     "ppk_prof_read": (C.c_int, [C.POINTER(C.c_double), _llp, C.c_int]),
     "ppk_last_kernel_name": (C.c_char_p, []),

@@ -421,6 +421,34 @@ extern "C" int ppk_edge_threshold_dev(const float *d_dist, size_t n_rows, size_t
   return edges_from_mask(dev, n_rows, g, static_cast<uint64_t *>(d_mask), d_edges, cap, d_n_edges, s);
 }
 
+extern "C" int ppk_qc_edges_dev(const float *d_dist, size_t n_rows, size_t n_ref, int mode,
+                                float max_pi, float max_a, long long *d_edges, size_t cap,
+                                unsigned long long *d_n_edges, void *stream) {
+  if (!d_n_edges) return ppk_fail(PPK_ERR_ARG, "d_n_edges is NULL");
+  if (mode != 0 && mode != 1) return ppk_fail(PPK_ERR_ARG, "mode must be 0 (long) or 1 (zero)");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int dev = 0;
+  PPK_HIP(hipGetDevice(&dev));
+  EdgeGeom g = {};
+  g.n_rows = n_rows;
+  if (n_ref == 0) {
+    g.layout = EDGE_LINEAR_SELF;
+    g.n_samples = samples_of_rows(n_rows);
+    if (g.n_samples * (g.n_samples - 1) / 2 != n_rows)
+      return ppk_fail(PPK_ERR_ARG, "row count is not n(n-1)/2 for any n (self/condensed matrix expected)");
+  } else {
+    g.layout = EDGE_LINEAR_NONSELF;
+    g.n_ref = n_ref;
+    if (n_rows % n_ref) return ppk_fail(PPK_ERR_ARG, "row count is not a multiple of n_ref");
+  }
+  void *d_mask = nullptr;
+  int rc = scratch_get(dev, SLOT_MASK, ppk_mask_words_linear(n_rows) * sizeof(uint64_t) + 8, &d_mask);
+  if (rc != PPK_OK) return rc;
+  rc = ppk_launch_mask_from_qc(d_dist, n_rows, mode, max_pi, max_a, static_cast<uint64_t *>(d_mask), s);
+  if (rc != PPK_OK) return rc;
+  return edges_from_mask(dev, n_rows, g, static_cast<uint64_t *>(d_mask), d_edges, cap, d_n_edges, s);
+}
+
 extern "C" int ppk_generate_tuples_dev(const int32_t *d_assign, size_t n_rows, int within_label,
                                        int self, size_t num_ref, long long int_offset,
                                        long long *d_edges, size_t cap,

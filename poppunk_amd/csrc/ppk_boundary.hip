@@ -48,6 +48,26 @@ mask_from_dist_kernel(const float2 *__restrict__ dist, size_t n_rows, int slope,
   }
 }
 
+// qcDistMat's row predicates (PopPUNK/qc.py:332,:349): mode 0 = distance too long
+// (core > max_pi | acc > max_a), mode 1 = zero distance (core == 0 | acc == 0)
+__global__ void __launch_bounds__(kBlock)
+mask_from_qc_kernel(const float2 *__restrict__ dist, size_t n_rows, int mode, float max_pi,
+                    float max_a, uint64_t *__restrict__ mask, size_t n_words) {
+  const size_t wstride = (size_t)gridDim.x * (kBlock / 64);
+  const int lane = threadIdx.x & 63;
+  for (size_t w = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); w < n_words;
+       w += wstride) {
+    const size_t row = w * 64 + lane;
+    bool pred = false;
+    if (row < n_rows) {
+      const float2 d = dist[row];
+      pred = mode == 0 ? (d.x > max_pi || d.y > max_a) : (d.x == 0.0f || d.y == 0.0f);
+    }
+    const uint64_t m = __ballot(pred);
+    if (lane == 0) mask[w] = m;
+  }
+}
+
 __global__ void __launch_bounds__(kBlock)
 mask_from_assign_kernel(const int32_t *__restrict__ assign, size_t n_rows, int within_label,
                         uint64_t *__restrict__ mask, size_t n_words) {
@@ -296,6 +316,18 @@ int ppk_launch_mask_from_dist(const float *d_dist, size_t n_rows, int slope, flo
   hipLaunchKernelGGL(mask_from_dist_kernel, dim3(grid), dim3(kBlock), 0, s,
                      reinterpret_cast<const float2 *>(d_dist), n_rows, slope, x_max, y_max,
                      inclusive, d_mask, n_words);
+  PPK_HIP(hipGetLastError());
+  return PPK_OK;
+}
+
+int ppk_launch_mask_from_qc(const float *d_dist, size_t n_rows, int mode, float max_pi, float max_a,
+                            uint64_t *d_mask, hipStream_t s) {
+  const size_t n_words = ppk_mask_words_linear(n_rows);
+  if (n_words == 0) return PPK_OK;
+  const unsigned grid = grid_for(n_words, kBlock / 64, 4096);
+  hipLaunchKernelGGL(mask_from_qc_kernel, dim3(grid), dim3(kBlock), 0, s,
+                     reinterpret_cast<const float2 *>(d_dist), n_rows, mode, max_pi, max_a, d_mask,
+                     n_words);
   PPK_HIP(hipGetLastError());
   return PPK_OK;
 }

@@ -78,6 +78,8 @@ size_t ppk_mask_words_linear(size_t n_rows);
 size_t ppk_compact_ws_bytes(size_t n_words);
 int ppk_launch_mask_from_dist(const float *d_dist, size_t n_rows, int slope, float x_max,
                               float y_max, int inclusive, uint64_t *d_mask, hipStream_t s);
+int ppk_launch_mask_from_qc(const float *d_dist, size_t n_rows, int mode, float max_pi, float max_a,
+                            uint64_t *d_mask, hipStream_t s);
 int ppk_launch_mask_from_assign(const int32_t *d_assign, size_t n_rows, int within_label,
                                 uint64_t *d_mask, hipStream_t s);
 int ppk_launch_compact(const uint64_t *d_mask, size_t n_words, const EdgeGeom &g, void *d_ws,

@@ -240,6 +240,29 @@ def edge_threshold_dev(dist_t, slope, x_max, y_max, n_ref=0, inclusive=True, cap
             cap = m
 
 
+def qc_edges_dev(dist_t, max_pi_dist, max_a_dist, n_ref=0, zero=False, cap=None):
+    """qcDistMat's outlier edge lists on a resident float32 [n,2] CUDA tensor
+    (PopPUNK/qc.py:332-337 long distances; :349-354 zero distances) -> int64 [m,2]."""
+    torch = _torch()
+    n = dist_t.shape[0]
+    if cap is None:
+        cap = min(n, max(1 << 20, n // 8))
+    with torch.cuda.device(dist_t.device):
+        while True:
+            edges = torch.empty((max(cap, 1), 2), dtype=torch.int64, device=dist_t.device)
+            n_edges = torch.zeros(1, dtype=torch.int64, device=dist_t.device)
+            rc = _lib.lib().ppk_qc_edges_dev(C.c_void_p(dist_t.data_ptr()), n, int(n_ref),
+                                             1 if zero else 0, float(max_pi_dist), float(max_a_dist),
+                                             C.c_void_p(edges.data_ptr()), cap,
+                                             C.c_void_p(n_edges.data_ptr()),
+                                             _stream_ptr(dist_t.device.index))
+            _lib.check(rc, "ppk_qc_edges_dev")
+            m = int(n_edges.item())
+            if m <= cap:
+                return edges[:m]
+            cap = m
+
+
 # ---- multi-GPU: one process per GPU, band-sharded pair space, gather to rank 0 -------------
 
 def shard_bounds(n_ref, n_qry, world_size):

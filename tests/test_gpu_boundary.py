@@ -261,3 +261,30 @@ def test_threshold_iterate_on_real_distances():
     wi, wj, wo = oracle.threshold_iterate_1d(x, offsets, 2, m0[0], m0[1], m1[0], m1[1])
     assert len(wi) > 10000
     assert np.array_equal(gi, wi) and np.array_equal(gj, wj) and np.array_equal(go, wo)
+
+
+def test_qc_edges_on_device():
+    """qcDistMat's masks + generateTuples (PopPUNK/qc.py:332-337,:349-354) on the resident matrix."""
+    import torch
+    rng = np.random.Generator(np.random.PCG64(8))
+    n = 400
+    d = (rng.random((n * (n - 1) // 2, 2)) * np.asarray([0.06, 0.7])).astype(np.float32)
+    d[rng.integers(0, len(d), 500), 0] = 0.0
+    d[rng.integers(0, len(d), 300), 1] = 0.0
+    dt = torch.from_numpy(d).cuda()
+    max_pi, max_a = 0.05, 0.6
+    long_rows = np.where((d[:, 0] > np.float32(max_pi)) | (d[:, 1] > np.float32(max_a)), 0, 1)
+    want = oracle.generate_tuples(long_rows.astype(np.int32), 0)
+    got = engine.qc_edges_dev(dt, max_pi, max_a).cpu().numpy()
+    assert len(want) > 100 and np.array_equal(got, want)
+    zero_rows = np.where((d[:, 0] == 0) | (d[:, 1] == 0), 0, 1)
+    want = oracle.generate_tuples(zero_rows.astype(np.int32), 0)
+    got = engine.qc_edges_dev(dt, max_pi, max_a, zero=True).cpu().numpy()
+    assert len(want) > 500 and np.array_equal(got, want)
+    # ref x query layout (poppunk_assign QC, qc.py:406-407)
+    nr = 37
+    dq = d[:nr * 50]
+    want = oracle.generate_tuples(np.where((dq[:, 0] > np.float32(max_pi)) | (dq[:, 1] > np.float32(max_a)), 0, 1)
+                                  .astype(np.int32), 0, self=False, num_ref=nr)
+    got = engine.qc_edges_dev(torch.from_numpy(dq).cuda(), max_pi, max_a, n_ref=nr).cpu().numpy()
+    assert np.array_equal(got, want)
