@@ -288,3 +288,40 @@ def test_qc_edges_on_device():
                                   .astype(np.int32), 0, self=False, num_ref=nr)
     got = engine.qc_edges_dev(torch.from_numpy(dq).cuda(), max_pi, max_a, n_ref=nr).cpu().numpy()
     assert np.array_equal(got, want)
+
+
+def test_end_to_end_clusters_recover_the_synthetic_population(tmp_path):
+    """Whole path: sketches -> fused distance/boundary -> edge list -> connected components
+    (the hand-off network.construct_network_from_edge_list + printClusters consume): planted
+    clusters (members share ~96 % of bins, different clusters ~25 %) are recovered by an
+    accessory threshold; and the dense matrix survives the .dists.pkl/.npy round trip."""
+    from poppunk_amd import distfile
+    rng = np.random.Generator(np.random.PCG64(21))
+    n, csize, nbins = 600, 20, 1024
+    n_clu = n // csize
+    species = rng.integers(0, 1 << 14, size=(5, nbins), dtype=np.uint16)
+    roots = np.where(rng.random((n_clu, 5, nbins)) < 0.5, species[None],
+                     rng.integers(0, 1 << 14, size=(n_clu, 5, nbins), dtype=np.uint16))
+    member = np.arange(n) % n_clu
+    bins = roots[member].copy()
+    redraw = rng.random(bins.shape) < 0.02
+    bins[redraw] = rng.integers(0, 1 << 14, size=int(redraw.sum()), dtype=np.uint16)
+    sk = synth.bitslice(bins, 14)
+    tbl = synth.random_match_table(KMERS)
+    db = engine.SketchDB(sk, 16, 14)
+    dist, n_failed = engine.dist(db, None, KMERS, tbl)
+    d = dist.cpu().numpy()
+    assert int(n_failed.item()) == 0
+    same = np.asarray([member[i] == member[j] for i in range(n) for j in range(i + 1, n)])
+    assert d[same, 1].max() < 0.15 and d[~same, 1].min() > 0.5      # accessory separates them
+    edges, _ = engine.dist_edges(db, None, KMERS, tbl, slope=1, x_max=0.0, y_max=0.3, inclusive=False)
+    assert len(edges) == int(same.sum())
+    n_comp, labels = distfile.clusters_from_edges(n, edges.cpu().numpy())
+    assert n_comp == n_clu
+    for g in range(n_clu):
+        assert len(set(labels[member == g])) == 1
+    names = ["s%d" % i for i in range(n)]
+    distfile.storePickle(names, names, True, d, str(tmp_path / "x.dists"))
+    _, _, self_flag, back = distfile.readPickle(str(tmp_path / "x.dists"), enforce_self=True)
+    assert self_flag and np.array_equal(back, d)
+    db.close()

@@ -110,3 +110,30 @@ def test_synthetic_generator_properties():
         for bit in range(14):
             for i in (0, 1, 37, 63):
                 assert ((int(w[0, blk * 14 + bit]) >> i) & 1) == ((int(bins[0, 64 * blk + i]) >> bit) & 1)
+
+
+def test_dists_pickle_roundtrip_and_layout(tmp_path):
+    """`.dists.pkl/.npy` as PopPUNK/utils.py:135-196 writes and reads them."""
+    import pickle
+    from poppunk_amd import distfile
+    names = ["a", "b", "c"]
+    X = np.arange(6, dtype=np.float32).reshape(3, 2)
+    prefix = str(tmp_path / "db.dists")
+    distfile.storePickle(names, names, True, X, prefix)
+    with open(prefix + ".pkl", "rb") as f:
+        assert pickle.load(f) == [names, names, True]            # exactly the reference's payload
+    assert np.array_equal(np.load(prefix + ".npy"), X)
+    r, q, s, Y = distfile.readPickle(prefix, enforce_self=True)
+    assert (r, q, s) == (names, names, True) and np.array_equal(X, Y) and Y.dtype == np.float32
+    assert distfile.readPickle(prefix, distances=False)[3] is None
+    distfile.storePickle(names, ["q"], False, None, prefix)
+    with pytest.raises(SystemExit):
+        distfile.readPickle(prefix, enforce_self=True)
+
+
+def test_clusters_from_edges():
+    from poppunk_amd import distfile
+    n_comp, labels = distfile.clusters_from_edges(6, [(0, 1), (1, 2), (4, 5)])
+    assert n_comp == 3
+    assert labels[0] == labels[1] == labels[2] and labels[4] == labels[5] and labels[3] not in (labels[0], labels[4])
+    assert distfile.clusters_from_edges(3, np.zeros((0, 2), dtype=np.int64))[0] == 3
