@@ -237,3 +237,32 @@ def test_full_size_properties_10k(big, tbl1):
     assert abs(s - float(whole.double().sum())) <= 1e-6 * abs(s)
     db.close()
     qdb.close()
+
+
+def test_row_index_math_beyond_32_bits(big, tbl1):
+    """n = 70 000 self -> 2.45e9 rows (> 2^31): a band deep in the matrix must land on the right
+    64-bit row offsets.  The database is the 10k set tiled 7x (duplicates have J = 1)."""
+    import torch
+    n = 70000
+    sk = np.tile(big, (7, 1, 1))
+    db = engine.SketchDB(sk, 16, 14, device=0)
+    qb, qe = 60000, 60064
+    band, _ = engine.dist(db, None, KMERS, tbl1, q_begin=qb, q_end=qe)
+    rows = engine.rows_in_band(n, 0, qb, qe)
+    assert band.shape[0] == rows == sum(n - 1 - q for q in range(qb, qe))
+    want, _ = oracle.query(sk, sk[qb:qe], KMERS, 16, 14, tbl1, threads=8)      # row = qi*n + r
+    want = want.reshape(qe - qb, n, 2)
+    got = band.cpu().numpy()
+    off = 0
+    for a, q in enumerate(range(qb, qe)):
+        cnt = n - 1 - q
+        assert np.abs(got[off:off + cnt] - want[a, q + 1:]).max() <= TOL
+        off += cnt
+    # fused edges of a band carry 64-bit-safe (i, j): identical genomes (core 0) are 10 000 apart
+    eb, ee = 20032, 20096
+    e, _ = engine.dist_edges(db, None, KMERS, tbl1, slope=0, x_max=1e-9, y_max=0.0, q_begin=eb, q_end=ee)
+    e = e.cpu().numpy()
+    dup = {(q, q + 10000 * m) for q in range(eb, ee) for m in range(1, 7) if q + 10000 * m < n}
+    assert len(dup) == 64 * 4 and dup <= set(map(tuple, e.tolist()))
+    assert np.all(e[:, 0] >= eb) and np.all(e[:, 0] < ee) and np.all(e[:, 1] > e[:, 0]) and np.all(e[:, 1] < n)
+    db.close()
