@@ -227,6 +227,13 @@ int ppk_square_to_long_dev(const float *d_square, size_t n, float *d_long, void 
  * itself, ties by column index; outputs [n*kNN] (i, j, dist) */
 int ppk_knn_dev(const float *d_square, size_t n, int knn, long long *d_i, long long *d_j,
                 float *d_dist, void *stream);
+/* the same on a rows x cols block of distances (e.g. one band of a ref x query result,
+ * element (i, c) at d_block[(i*n_cols + c)*stride + col]); row i is sample self_offset + i,
+ * whose own column is skipped.  Lets k nearest neighbours be taken band by band straight
+ * from kernel 1 without ever holding the n x n matrix. */
+int ppk_knn_rect_dev(const float *d_block, size_t stride, size_t col, size_t n_rows,
+                     size_t n_cols, size_t self_offset, int knn, long long *d_i, long long *d_j,
+                     float *d_dist, void *stream);
 /* host-buffer forms */
 int ppk_long_to_square(const float *vec, size_t n, int device_id, float *square);
 int ppk_long_to_square_multi(const float *rr, const float *qr, const float *qq, size_t n_ref,

@@ -82,40 +82,43 @@ square_to_long_kernel(const float *__restrict__ sq, size_t n, float *__restrict_
   for (size_t j = i + 1 + threadIdx.x; j < n; j += 256) out[base + (j - i - 1)] = sq[i * n + j];
 }
 
+// keys/values of a rows x cols block; element (i, c) is src[(i*cols + c)*stride + col]
 __global__ void __launch_bounds__(256)
-knn_init_kernel(float *__restrict__ keys, int *__restrict__ vals, int *__restrict__ seg, size_t n,
-                const float *__restrict__ sq) {
+knn_init_kernel(float *__restrict__ keys, int *__restrict__ vals, int *__restrict__ seg,
+                size_t n_rows, size_t n_cols, const float *__restrict__ src, size_t stride,
+                size_t col) {
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (e < n * n) {
-    keys[e] = sq[e] + 0.0f;          // -0.0 -> +0.0 so that radix order equals operator<
-    vals[e] = (int)(e % n);
+  if (e < n_rows * n_cols) {
+    keys[e] = src[e * stride + col] + 0.0f;   // -0.0 -> +0.0 so that radix order equals operator<
+    vals[e] = (int)(e % n_cols);
   }
-  if (e <= n) seg[e] = (int)(e * n);
+  if (e <= n_rows) seg[e] = (int)(e * n_cols);
 }
 
-// first kNN sorted entries of each row that are not the row itself (src/extend.cpp:266-279)
+// first kNN sorted entries of each row that are not the row's own sample (src/extend.cpp:266-279)
 __global__ void __launch_bounds__(64)
-knn_pick_kernel(const float *__restrict__ skeys, const int *__restrict__ svals, size_t n, int knn,
-                long long *__restrict__ oi, long long *__restrict__ oj, float *__restrict__ od) {
+knn_pick_kernel(const float *__restrict__ skeys, const int *__restrict__ svals, size_t n_cols,
+                size_t self_offset, int knn, long long *__restrict__ oi, long long *__restrict__ oj,
+                float *__restrict__ od) {
   const size_t i = blockIdx.x;
+  const size_t self = self_offset + i;
   const int lane = threadIdx.x;
-  // the self entry is somewhere in the first knn+1 .. positions; a wavefront scans 64 at a time
   int written = 0;
-  for (size_t base = 0; base < n && written < knn; base += 64) {
+  for (size_t base = 0; base < n_cols && written < knn; base += 64) {
     const size_t pos = base + lane;
-    const bool ok = pos < n && (size_t)svals[i * n + pos] != i;
+    const bool ok = pos < n_cols && (size_t)svals[i * n_cols + pos] != self;
     const uint64_t m = __ballot(ok);
     const int rank = written + __popcll(m & ((1ull << lane) - 1ull));
     if (ok && rank < knn) {
-      oi[i * knn + rank] = (long long)i;
-      oj[i * knn + rank] = svals[i * n + pos];
-      od[i * knn + rank] = skeys[i * n + pos];
+      oi[i * knn + rank] = (long long)self;
+      oj[i * knn + rank] = svals[i * n_cols + pos];
+      od[i * knn + rank] = skeys[i * n_cols + pos];
     }
     written += __popcll(m);
   }
   // fewer than knn other samples: the reference leaves i in i_vec and zeros elsewhere
   for (int k = (written < knn ? written : knn) + lane; k < knn; k += 64) {
-    oi[i * knn + k] = (long long)i;
+    oi[i * knn + k] = (long long)self;
     oj[i * knn + k] = 0;
     od[i * knn + k] = 0.0f;
   }
@@ -162,37 +165,45 @@ extern "C" int ppk_square_to_long_dev(const float *d_square, size_t n, float *d_
   return PPK_OK;
 }
 
-extern "C" int ppk_knn_dev(const float *d_square, size_t n, int knn, long long *d_i, long long *d_j,
-                           float *d_dist, void *stream) {
-  if (n == 0 || knn <= 0) return PPK_OK;
-  if (!d_square || !d_i || !d_j || !d_dist) return ppk_fail(PPK_ERR_ARG, "ppk_knn_dev: bad arguments");
-  if (n * n > 0x7fffffffull) return ppk_fail(PPK_ERR_ARG, "ppk_knn_dev: matrix too large for one segmented sort (n <= 46340)");
+extern "C" int ppk_knn_rect_dev(const float *d_block, size_t stride, size_t col, size_t n_rows,
+                                size_t n_cols, size_t self_offset, int knn, long long *d_i,
+                                long long *d_j, float *d_dist, void *stream) {
+  if (n_rows == 0 || n_cols == 0 || knn <= 0) return PPK_OK;
+  if (!d_block || !d_i || !d_j || !d_dist || stride == 0 || col >= stride)
+    return ppk_fail(PPK_ERR_ARG, "ppk_knn_rect_dev: bad arguments");
+  if (n_rows * n_cols > 0x7fffffffull)
+    return ppk_fail(PPK_ERR_ARG, "ppk_knn_rect_dev: block too large for one segmented sort (rows*cols < 2^31)");
   hipStream_t s = static_cast<hipStream_t>(stream);
   int dev = 0;
   PPK_HIP(hipGetDevice(&dev));
-  const size_t nn = n * n;
+  const size_t nn = n_rows * n_cols;
   void *p_a = nullptr, *p_c = nullptr;
   const size_t o_kin = 0, o_kout = o_kin + nn * 4, o_vin = o_kout + nn * 4, o_vout = o_vin + nn * 4;
-  const size_t o_seg = o_vout + nn * 4, o_end = o_seg + (n + 1) * 4 + 256;
+  const size_t o_seg = o_vout + nn * 4, o_end = o_seg + (n_rows + 1) * 4 + 256;
   int rc = ppk_scratch_get(dev, SLOT_ITER_B, o_end, &p_a);
   if (rc != PPK_OK) return rc;
   char *A = static_cast<char *>(p_a);
   float *kin = reinterpret_cast<float *>(A + o_kin), *kout = reinterpret_cast<float *>(A + o_kout);
   int *vin = reinterpret_cast<int *>(A + o_vin), *vout = reinterpret_cast<int *>(A + o_vout);
   int *seg = reinterpret_cast<int *>(A + o_seg);
-  hipLaunchKernelGGL(knn_init_kernel, dim3((unsigned)((nn + n + 256) / 256)), dim3(256), 0, s, kin, vin,
-                     seg, n, d_square);
+  hipLaunchKernelGGL(knn_init_kernel, dim3((unsigned)((nn + n_rows + 256) / 256)), dim3(256), 0, s, kin,
+                     vin, seg, n_rows, n_cols, d_block, stride, col);
   size_t tmp = 0;
-  PPK_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, tmp, kin, kout, vin, vout, (int)nn, (int)n,
-                                                      seg, seg + 1, 0, 32, s));
+  PPK_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, tmp, kin, kout, vin, vout, (int)nn,
+                                                      (int)n_rows, seg, seg + 1, 0, 32, s));
   rc = ppk_scratch_get(dev, SLOT_ITER_C, tmp + 256, &p_c);
   if (rc != PPK_OK) return rc;
-  PPK_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(p_c, tmp, kin, kout, vin, vout, (int)nn, (int)n,
-                                                      seg, seg + 1, 0, 32, s));
-  hipLaunchKernelGGL(knn_pick_kernel, dim3((unsigned)n), dim3(64), 0, s, kout, vout, n, knn, d_i, d_j,
-                     d_dist);
+  PPK_HIP(hipcub::DeviceSegmentedRadixSort::SortPairs(p_c, tmp, kin, kout, vin, vout, (int)nn,
+                                                      (int)n_rows, seg, seg + 1, 0, 32, s));
+  hipLaunchKernelGGL(knn_pick_kernel, dim3((unsigned)n_rows), dim3(64), 0, s, kout, vout, n_cols,
+                     self_offset, knn, d_i, d_j, d_dist);
   PPK_HIP(hipGetLastError());
   return PPK_OK;
+}
+
+extern "C" int ppk_knn_dev(const float *d_square, size_t n, int knn, long long *d_i, long long *d_j,
+                           float *d_dist, void *stream) {
+  return ppk_knn_rect_dev(d_square, 1, 0, n, n, 0, knn, d_i, d_j, d_dist, stream);
 }
 
 // ---- host-buffer forms (what the pybind functions would bind) --------------------------------

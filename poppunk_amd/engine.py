@@ -263,6 +263,36 @@ def qc_edges_dev(dist_t, max_pi_dist, max_a_dist, n_ref=0, zero=False, cap=None)
             cap = m
 
 
+def knn_from_sketches(db, kmers, random_tbl, knn, dist_col=0, random_correct=True,
+                      band_items=1 << 29):
+    """k nearest neighbours of every sample straight from the resident sketches (what
+    get_kNN_distances(longToSquare(queryDatabase(...)[:, dist_col])) gives, PopPUNK/models.py:
+    1215-1222) without materialising the n x n matrix: bands of query rows are computed against
+    all refs (row = q*n + r), their k smallest entries taken on the device, and the band buffer
+    re-used.  Returns CUDA tensors (i, j, dist) of length n*knn."""
+    torch = _torch()
+    lib = _lib.lib()
+    n = db.n
+    dev = "cuda:%d" % db.device
+    band = max(64, min(n, (band_items // max(n, 1)) // 64 * 64))
+    oi = torch.empty(n * knn, dtype=torch.int64, device=dev)
+    oj = torch.empty(n * knn, dtype=torch.int64, device=dev)
+    od = torch.empty(n * knn, dtype=torch.float32, device=dev)
+    buf = torch.empty((min(band, n) * n, 2), dtype=torch.float32, device=dev)
+    with torch.cuda.device(db.device):
+        for qb in range(0, n, band):
+            qe = min(n, qb + band)
+            block = buf[:(qe - qb) * n]
+            dist(db, db, kmers, random_tbl, random_correct=random_correct, q_begin=qb, q_end=qe,
+                 out=block)
+            rc = lib.ppk_knn_rect_dev(C.c_void_p(block.data_ptr()), 2, int(dist_col), qe - qb, n, qb,
+                                      int(knn), C.c_void_p(oi[qb * knn:].data_ptr()),
+                                      C.c_void_p(oj[qb * knn:].data_ptr()),
+                                      C.c_void_p(od[qb * knn:].data_ptr()), _stream_ptr(db.device))
+            _lib.check(rc, "ppk_knn_rect_dev")
+    return oi, oj, od
+
+
 # ---- multi-GPU: one process per GPU, band-sharded pair space, gather to rank 0 -------------
 
 def shard_bounds(n_ref, n_qry, world_size):

@@ -51,3 +51,23 @@ def test_knn(n, k):
     assert len(gi) == n * k
     with pytest.raises(TypeError):
         poppunk_refine.get_kNN_distances(sq.astype(np.float64), k)
+
+
+def test_knn_straight_from_sketches():
+    """engine.knn_from_sketches == get_kNN_distances(longToSquare(dist[:, col])) without the square
+    matrix (band by band; several bands forced by a small band_items)."""
+    from poppunk_amd import engine, synth
+    kmers = np.asarray(synth.DEFAULT_KMERS, dtype=np.int32)
+    sk, _ = synth.make_sketches(500, kmers, cluster_size=25, seed=4)
+    tbl = synth.random_match_table(kmers)
+    dist, _ = pp_sketchlib.query_arrays(sk, None, kmers, 16, 14, tbl)
+    db = engine.SketchDB(sk, 16, 14)
+    for col, k in ((0, 5), (1, 3)):
+        sq = oracle.long_to_square(dist[:, col])
+        wi, wj, wd = oracle.knn(sq, k)
+        gi, gj, gd = engine.knn_from_sketches(db, kmers, tbl, k, dist_col=col, band_items=500 * 128)
+        assert np.array_equal(gi.cpu().numpy(), wi)
+        assert np.array_equal(gd.cpu().numpy(), wd)
+        # ties between equal distances resolve by column index in both
+        assert np.array_equal(gj.cpu().numpy(), wj)
+    db.close()
