@@ -45,7 +45,13 @@ extern "C" {
  * integer half of the path must be bit-identical to the CPU) */
 #define PPK_FLAG_COUNTS 4
 
+/* Threading: like the bindings it replaces, the library expects one call at a time per
+ * device (PopPUNK calls it from the main thread, blocking).  Device entry points share
+ * grow-only per-device scratch (log-J table, edge bitmask, sort buffers), so two calls
+ * may only be in flight on one device if they are ordered on the same stream. */
 const char *ppk_last_error(void);
+/* frees the per-device scratch (synchronises each device that holds any) */
+int ppk_release_scratch(void);
 const char *ppk_version(void); /* replaces pp_sketchlib.version (PopPUNK/sketchlib.py:34) */
 int ppk_device_count(int *n);
 

@@ -22,6 +22,7 @@ _vp, _sz = C.c_void_p, C.c_size_t
 SIGNATURES = {
     "ppk_last_error": (C.c_char_p, []),
     "ppk_version": (C.c_char_p, []),
+    "ppk_release_scratch": (C.c_int, []),
     "ppk_device_count": (C.c_int, [_intp]),
     "ppk_db_create": (C.c_int, [C.c_int, _vp, _sz, _sz, _sz, _sz, _vp, C.c_int, _vp,
                                 C.POINTER(_vp)]),

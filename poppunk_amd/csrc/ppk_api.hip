@@ -305,6 +305,21 @@ int stage_tables(const ppk_db *ref, const float *random_tbl, size_t n_clu, int f
 
 int ppk_scratch_get(int dev, int slot, size_t bytes, void **out) { return scratch_get(dev, slot, bytes, out); }
 
+extern "C" int ppk_release_scratch(void) {
+  for (int d = 0; d < 64; ++d) {
+    bool any = false;
+    for (int k = 0; k < SLOT_COUNT; ++k) any = any || g_scratch[d][k].p;
+    if (!any) continue;
+    DeviceGuard guard(d);
+    (void)hipDeviceSynchronize();
+    for (int k = 0; k < SLOT_COUNT; ++k) {
+      if (g_scratch[d][k].p) (void)hipFree(g_scratch[d][k].p);
+      g_scratch[d][k] = Scratch();
+    }
+  }
+  return PPK_OK;
+}
+
 extern "C" int ppk_dist_dev(const ppk_db *ref, const ppk_db *qry, const int32_t *kmers,
                             const float *random_tbl, size_t n_clu, int flags, size_t q_begin,
                             size_t q_end, void *d_out, unsigned long long *d_n_failed,
