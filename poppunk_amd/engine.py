@@ -263,6 +263,41 @@ def qc_edges_dev(dist_t, max_pi_dist, max_a_dist, n_ref=0, zero=False, cap=None)
             cap = m
 
 
+def threshold_iterate_1d_dev(dist_t, offsets, slope, x0, y0, x1, y1, cap=None):
+    """poppunk_refine.thresholdIterate1D on a resident float32 [n,2] CUDA tensor ->
+    (i, j, offset_idx) int64 CUDA tensors (src/boundary.cpp:154-210)."""
+    torch = _torch()
+    off = np.ascontiguousarray(offsets, dtype=np.float64).ravel()
+    n = dist_t.shape[0]
+    if cap is None:
+        cap = min(n, max(1 << 20, n // 8))
+    with torch.cuda.device(dist_t.device):
+        while True:
+            buf = torch.empty((3, max(cap, 1)), dtype=torch.int64, device=dist_t.device)
+            n_out = torch.zeros(1, dtype=torch.int64, device=dist_t.device)
+            rc = _lib.lib().ppk_threshold_iterate_1d_dev(
+                C.c_void_p(dist_t.data_ptr()), n, off.ctypes.data_as(C.POINTER(C.c_double)), off.size,
+                int(slope), float(x0), float(y0), float(x1), float(y1), C.c_void_p(buf[0].data_ptr()),
+                C.c_void_p(buf[1].data_ptr()), C.c_void_p(buf[2].data_ptr()), cap,
+                C.c_void_p(n_out.data_ptr()), _stream_ptr(dist_t.device.index))
+            _lib.check(rc, "ppk_threshold_iterate_1d_dev")
+            m = int(n_out.item())
+            if m <= cap:
+                return buf[0, :m], buf[1, :m], buf[2, :m]
+            cap = m
+
+
+def long_to_square_dev(dist_t, col, n):
+    """pp_sketchlib.longToSquare of one column of the resident [n_pairs,2] matrix -> [n,n] CUDA."""
+    torch = _torch()
+    out = torch.empty((n, n), dtype=torch.float32, device=dist_t.device)
+    with torch.cuda.device(dist_t.device):
+        rc = _lib.lib().ppk_long_to_square_dev(C.c_void_p(dist_t.data_ptr()), dist_t.shape[1], int(col), n,
+                                               C.c_void_p(out.data_ptr()), _stream_ptr(dist_t.device.index))
+        _lib.check(rc, "ppk_long_to_square_dev")
+    return out
+
+
 def knn_from_sketches(db, kmers, random_tbl, knn, dist_col=0, random_correct=True,
                       band_items=1 << 29):
     """k nearest neighbours of every sample straight from the resident sketches (what

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Regenerates every measured artefact under gpurun_out/r01 (run through gpurun from the repo root):
+#   tools/collect_profiles.sh     then copy into profiles/ with tools/pmc_summary.py / the snippet in DESIGN.md
+set -u
+OUT=gpurun_out/r01
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:-/root/repo}"
+B="python bench.py --steps 20 --warmup 3 --no-cpu"
+S="python bench.py --steps 3 --warmup 1 --no-cpu"
+timeout 1500 python tools/measure_configs.py $OUT/configs.json > $OUT/configs.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- $B > $OUT/bench_under_rocprof.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o f -- $S > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_write -o w -- $S > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY --output-format csv -d $OUT/pmc_sq -o s -- $S > /dev/null 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM GRBM_GUI_ACTIVE SQ_ACTIVE_INST_LDS --output-format csv -d $OUT/pmc_lds -o l -- $S > /dev/null 2>&1
+python bench.py > $OUT/bench.json 2> $OUT/bench.err
+./tools/ubench_valu.out > $OUT/ubench_valu.txt 2>&1
+./tools/ubench_bank.out > $OUT/ubench_bank.txt 2>&1
+./tools/ubench_lds_tile.out > $OUT/ubench_lds_tile.txt 2>&1
+tail -1 $OUT/bench.json | cut -c1-300

@@ -73,7 +73,33 @@ def main():
                                         cap=len(e) + 16), reps=5)
     out["C3_10k_fused_edges"] = {"pairs": 49995000, "edges": int(len(e)), "ms": t * 1e3,
                                  "pairs_per_s": 49995000 / t}
-    del a, o, dist10
+    # "next" rows on the resident 10k matrix: refine's 40-offset sweep, long->square, kNN
+    scale = torch.tensor([float(d_host[:, 0].max()), float(d_host[:, 1].max())], device="cuda")
+    xs = (dist10 / scale).contiguous()
+    xh = xs.cpu().numpy()
+    m0 = np.quantile(xh[::20], 0.01, axis=0)
+    m1 = np.quantile(xh[::20], 0.30, axis=0)
+    offs = np.linspace(0.0, float(np.linalg.norm(m1 - m0)), 40)
+    ti = engine.threshold_iterate_1d_dev(xs, offs, 2, m0[0], m0[1], m1[0], m1[1])
+    t = timed(lambda: engine.threshold_iterate_1d_dev(xs, offs, 2, m0[0], m0[1], m1[0], m1[1],
+                                                      cap=len(ti[0]) + 16), reps=5)
+    out["TI1_40_offsets_10k"] = {"rows": 49995000, "emitted": int(len(ti[0])), "ms": t * 1e3}
+    try:
+        from oracle import oracle
+        t0 = time.perf_counter()
+        wi, wj, wo = oracle.threshold_iterate_1d(xh, offs, 2, m0[0], m0[1], m1[0], m1[1])
+        out["TI1_40_offsets_10k"]["cpu_oracle_ms"] = (time.perf_counter() - t0) * 1e3
+        out["TI1_40_offsets_10k"]["equal_to_oracle"] = bool(
+            np.array_equal(ti[0].cpu().numpy(), wi) and np.array_equal(ti[1].cpu().numpy(), wj)
+            and np.array_equal(ti[2].cpu().numpy(), wo))
+    except Exception as e:   # the oracle is optional for this tool
+        out["TI1_40_offsets_10k"]["cpu_oracle_ms"] = str(e)
+    t = timed(lambda: engine.long_to_square_dev(dist10, 0, 10000), reps=10)
+    out["longToSquare_10k"] = {"elements": 10000 * 10000, "ms": t * 1e3,
+                               "GBps": (49995000 * 4 + 1e8 * 4) / t / 1e9}
+    t = timed(lambda: engine.knn_from_sketches(db10, KMERS, TBL, 5), reps=2, warm=1)
+    out["kNN5_from_sketches_10k"] = {"pairs_computed": 10000 * 10000, "ms": t * 1e3}
+    del a, o, dist10, xs
     torch.cuda.empty_cache()
 
     # H: host buffers in, host buffer out (PCIe inclusive), 10k self
