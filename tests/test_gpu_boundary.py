@@ -325,3 +325,19 @@ def test_end_to_end_clusters_recover_the_synthetic_population(tmp_path):
     _, _, self_flag, back = distfile.readPickle(str(tmp_path / "x.dists"), enforce_self=True)
     assert self_flag and np.array_equal(back, d)
     db.close()
+
+
+def test_nan_and_inf_rows_follow_the_reference_branches():
+    """src/boundary.cpp:66-78: NaN is neither == 0 nor > 0, so the else branch gives -1, while
+    edge_iterate's `<= 0` is false for NaN (no edge); +inf is outside, -inf within."""
+    d = np.asarray([[np.nan, 0.1], [0.1, np.nan], [np.inf, 0.1], [-np.inf, 0.0], [0.0, 0.0],
+                    [0.5, 0.0]], dtype=np.float32)                     # 6 rows = 4 samples
+    for slope in (0, 1, 2):
+        a = poppunk_refine.assignThreshold(d, slope, 0.5, 0.5)
+        assert np.array_equal(a, oracle.assign_threshold(d, slope, 0.5, 0.5))
+        assert np.array_equal(poppunk_refine.edgeThreshold_array(d, slope, 0.5, 0.5),
+                              oracle.edge_threshold(d, slope, 0.5, 0.5))
+    a2 = poppunk_refine.assignThreshold(d, 2, 0.5, 0.5)
+    assert a2[0] == -1 and a2[1] == -1 and a2[2] == 1 and a2[3] == -1 and a2[4] == -1 and a2[5] == 0
+    e = poppunk_refine.edgeThreshold(d, 2, 0.5, 0.5)
+    assert (0, 1) not in e and (0, 2) not in e and (1, 2) in e and (2, 3) in e   # rows 0,1 NaN; 3,5 within/on

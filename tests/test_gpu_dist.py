@@ -266,3 +266,81 @@ def test_row_index_math_beyond_32_bits(big, tbl1):
     assert len(dup) == 64 * 4 and dup <= set(map(tuple, e.tolist()))
     assert np.all(e[:, 0] >= eb) and np.all(e[:, 0] < ee) and np.all(e[:, 1] > e[:, 0]) and np.all(e[:, 1] < n)
     db.close()
+
+
+def test_config4_shape_50k_queries_x_10k_refs(big, tbl1):
+    """BASELINE configs[3] at full size: 50 000 queries x 10 000 refs (5e8 pairs), refs resident.
+    The queries are the 10k set tiled 5x, so the result must be 5 identical 10k x 10k blocks
+    (row = q*n_ref + r), each block symmetric with a zero diagonal and equal, on its upper
+    triangle, to the self run of the 10k set -- three different tilings of the same pairs."""
+    import torch
+    n = 10000
+    ref = engine.SketchDB(big, 16, 14, device=0)
+    qry = engine.SketchDB(np.tile(big, (5, 1, 1)), 16, 14, device=0)
+    out, nf = engine.dist(ref, qry, KMERS, tbl1)
+    assert out.shape == (5 * n * n, 2) and int(nf.item()) == 0
+    blocks = out.view(5, n, n, 2)
+    for b in range(1, 5):
+        assert torch.equal(blocks[b], blocks[0])
+    sq = blocks[0]
+    assert torch.equal(sq, sq.transpose(0, 1).contiguous())
+    assert float(sq.diagonal(dim1=0, dim2=1).abs().max()) == 0.0
+    self_run, _ = engine.dist(ref, None, KMERS, tbl1)
+    iu = torch.triu_indices(n, n, offset=1, device=out.device)
+    assert torch.equal(sq[iu[0], iu[1]], self_run)
+    # and the long <-> square kernels agree with that
+    for col in (0, 1):
+        assert torch.equal(engine.long_to_square_dev(self_run, col, n), sq[:, :, col].contiguous())
+    ref.close()
+    qry.close()
+
+
+def test_config5_shape_100k_self_fused_boundary_band(big, tbl1):
+    """BASELINE configs[4] at full size: 100 000 genomes self, distances never materialised,
+    boundary applied in-kernel, edge list compacted on the device -- for the band one of 8 GPUs
+    owns.  The 100k set is the 10k set tiled 10x, so every edge (i, j) must satisfy the boundary
+    on the 10k matrix entry (i mod 10k, j mod 10k), the edge count must be what that matrix
+    predicts, and two half-bands must concatenate to the band."""
+    import torch
+    n10, n = 10000, 100000
+    db10 = engine.SketchDB(big, 16, 14, device=0)
+    d10, _ = engine.dist(db10, None, KMERS, tbl1)
+    d10 = d10.cpu().numpy()
+    x_max, y_max = synth.boundary_for_quantile(d10[::97], 0.02)
+    within10 = oracle.assign_threshold(d10, 2, x_max, y_max, threads=8) <= 0        # condensed 10k
+    sq = np.zeros((n10, n10), dtype=bool)
+    iu = np.triu_indices(n10, 1)
+    sq[iu] = within10
+    sq |= sq.T
+    np.fill_diagonal(sq, True)                      # identical genomes (same index mod 10k): (0,0)
+    db = engine.SketchDB(np.tile(big, (10, 1, 1)), 16, 14, device=0)
+    b = engine.band_split(n, 0, 8)
+    qb, qe = b[5], b[6]
+    e, nf = engine.dist_edges(db, None, KMERS, tbl1, slope=2, x_max=x_max, y_max=y_max,
+                              q_begin=qb, q_end=qe)
+    e = e.cpu().numpy()
+    assert int(nf.item()) == 0 and len(e) > 100000
+    assert np.all(e[:, 0] >= qb) and np.all(e[:, 0] < qe) and np.all(e[:, 1] > e[:, 0]) and np.all(e[:, 1] < n)
+    assert np.all(sq[e[:, 0] % n10, e[:, 1] % n10])                       # every edge is a true edge
+    # expected count: for each query row q, refs r in (q, n) with sq[q%10k, r%10k]
+    rowsum = sq.sum(axis=1).astype(np.int64)
+    csum = np.concatenate([np.zeros((n10, 1), dtype=np.int64), np.cumsum(sq, axis=1)], axis=1)
+    want = 0
+    for q in range(qb, qe):
+        full_blocks_after = (n - 1 - q) // n10                            # whole 10k periods after q
+        rem_end = (q + 1) % n10 + (n - 1 - q) % n10                       # remainder window (may wrap)
+        s = (q + 1) % n10
+        if rem_end <= n10:
+            part = csum[q % n10, rem_end] - csum[q % n10, s]
+        else:
+            part = (csum[q % n10, n10] - csum[q % n10, s]) + csum[q % n10, rem_end - n10]
+        want += full_blocks_after * rowsum[q % n10] + part
+    assert len(e) == want
+    order_ok = np.all((e[1:, 0] > e[:-1, 0]) | ((e[1:, 0] == e[:-1, 0]) & (e[1:, 1] > e[:-1, 1])))
+    assert order_ok                                                       # reference row order
+    mid = (qb + qe) // 2 // 64 * 64
+    e1, _ = engine.dist_edges(db, None, KMERS, tbl1, slope=2, x_max=x_max, y_max=y_max, q_begin=qb, q_end=mid)
+    e2, _ = engine.dist_edges(db, None, KMERS, tbl1, slope=2, x_max=x_max, y_max=y_max, q_begin=mid, q_end=qe)
+    assert np.array_equal(np.concatenate([e1.cpu().numpy(), e2.cpu().numpy()]), e)
+    db.close()
+    db10.close()
