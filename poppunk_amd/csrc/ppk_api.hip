@@ -360,6 +360,27 @@ extern "C" int ppk_dist_edges_dev(const ppk_db *ref, const ppk_db *qry, const in
   float *d_rtab = nullptr;
   rc = stage_tables(ref, random_tbl, n_clu, flags, s, &d_lut, &d_rtab);
   if (rc != PPK_OK) return rc;
+  {
+    // nk * count-bits > 128: no fused path; distances (pre-divided by scale) go to scratch and the
+    // row-linear edge kernel runs on them -- whole matrices only (band edge lists need the fused path)
+    const size_t nbins = ref->s64 * 64;
+    int bits = 1;
+    while (((size_t)1 << bits) <= nbins) ++bits;
+    if (ref->nk > PPK_MAX_NK || ref->nk * (size_t)bits > 128) {
+      const size_t nq = qry ? qry->n : ref->n;
+      if (q_begin != 0 || q_end != nq)
+        return ppk_fail(PPK_ERR_ARG, "edge lists of a band need nk * count bits <= 128 (the fused path)");
+      const size_t rows = ppk_rows_in_band(ref->n, qry ? qry->n : 0, 0, nq);
+      void *d_dist = nullptr;
+      rc = scratch_get(ref->device, SLOT_ITER_B, rows * 8 + 8, &d_dist);
+      if (rc != PPK_OK) return rc;
+      rc = ppk_launch_dist(ref, qry, kmers, d_rtab, d_rtab ? n_clu : 1, flags, 0, nq, d_dist, d_n_failed,
+                           nullptr, slope, x_max, y_max, scale_x, scale_y, inclusive, d_lut, s);
+      if (rc != PPK_OK) return rc;
+      return ppk_edge_threshold_dev(static_cast<float *>(d_dist), rows, qry ? ref->n : 0, slope, x_max,
+                                    y_max, inclusive, d_edges, cap, d_n_edges, stream);
+    }
+  }
   const size_t n_rtiles = (ref->n + 63) / 64;
   const size_t n_words = (q_end - q_begin) * n_rtiles;
   void *d_mask = nullptr, *d_ws = nullptr;

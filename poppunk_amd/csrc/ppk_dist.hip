@@ -634,6 +634,80 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
   }
 }
 
+
+// ---- generic fallback: counts -> distances when nk * count-bits does not fit 128 bits ---------
+// (e.g. 17 k-mer lengths at s = 10 000).  dist_kernel* write the raw counts, this kernel does
+// a4-a6 per row with the expression order of the CPU statement.
+__global__ void __launch_bounds__(256)
+regress_counts_kernel(const uint32_t *__restrict__ counts, size_t n_rows, size_t row_base, int self,
+                      size_t n_ref, int nk, const int *__restrict__ kmers, size_t s64, size_t bbits,
+                      const float *__restrict__ rtab, int n_clu,
+                      const uint16_t *__restrict__ ref_clu, const uint16_t *__restrict__ qry_clu,
+                      float scale_x, float scale_y, float2 *__restrict__ out,
+                      unsigned long long *__restrict__ n_failed) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  bool failed = false;
+  if (i < n_rows) {
+    size_t q = 0, r = 0;
+    if (rtab && n_clu > 1) {
+      const size_t row = row_base + i;
+      if (self) {
+        // condensed row -> (q, r): largest q with q*n - q(q+1)/2 <= row
+        const double d = sqrt((double)(4 * n_ref * (n_ref - 1)) - 8.0 * (double)row - 7.0);
+        long long qi = (long long)n_ref - 2 - (long long)floor(d / 2.0 - 0.5);
+        if (qi < 0) qi = 0;
+        while (qi > 0 && (size_t)qi * n_ref - ((size_t)qi * ((size_t)qi + 1)) / 2 > row) --qi;
+        while ((size_t)(qi + 1) * n_ref - ((size_t)(qi + 1) * ((size_t)qi + 2)) / 2 <= row) ++qi;
+        q = (size_t)qi;
+        r = row - (q * n_ref - (q * (q + 1)) / 2) + q + 1;
+      } else {
+        q = row / n_ref;
+        r = row % n_ref;
+      }
+    }
+    const double tol = 5.0 / (double)(s64 * 64);
+    double sx = 0.0, sxx = 0.0, sy = 0.0, sxy = 0.0;
+    int n = 0;
+    bool open = true;
+    for (int k = 0; k < nk; ++k) {
+      double jr = 0.0;
+      if (rtab) {
+        const int cr = (n_clu > 1 && ref_clu) ? ref_clu[r] : 0;
+        const int cq = (n_clu > 1 && qry_clu) ? qry_clu[q] : 0;
+        jr = (double)rtab[((size_t)k * n_clu + cr) * n_clu + cq];
+      }
+      const double j = observed_excess(jaccard_obs(counts[i * nk + k], s64, bbits), jr);
+      open = open && !(j < tol);
+      if (open) {
+        const double x = (double)kmers[k], y = log(j);
+        sx += x;
+        sxx += x * x;
+        sy += y;
+        sxy += x * y;
+        ++n;
+      }
+    }
+    float core = 0.0f, acc = 0.0f;
+    if (n < 2) {
+      failed = true;
+    } else {
+      const double dn = (double)n;
+      const double slope = (dn * sxy - sx * sy) / (dn * sxx - sx * sx);
+      const double icpt = (sy - slope * sx) / dn;
+      core = slope < 0.0 ? (float)(1.0 - exp(slope)) : 0.0f;
+      acc = icpt < 0.0 ? (float)(1.0 - exp(icpt)) : 0.0f;
+    }
+    float2 v;
+    v.x = __fdiv_rn(core, scale_x);
+    v.y = __fdiv_rn(acc, scale_y);
+    out[i] = v;
+  }
+  if (n_failed) {
+    const uint64_t fm = __ballot(failed);
+    if (fm && (threadIdx.x & 63) == 0) atomicAdd(n_failed, (unsigned long long)__popcll(fm));
+  }
+}
+
 // ---- host-side launch ------------------------------------------------------
 
 namespace {
@@ -792,8 +866,29 @@ int ppk_launch_dist(const ppk_db *ref, const ppk_db *qry_or_null, const int32_t 
   if (want_jac)
     return launch_tiles<MODE_JACCARD, uint64_t>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
 
-  if (p.nk > PPK_MAX_NK || p.nk * p.cnt_bits > 128)
-    return ppk_fail(PPK_ERR_ARG, "nk * count bits > 128 (or nk > 32) is not supported by the fused path");
+  if (p.nk > PPK_MAX_NK || p.nk * p.cnt_bits > 128) {
+    // the packed per-pair state does not fit: raw counts to scratch, then a generic regression pass
+    int dev = ref->device;
+    const size_t rows = p.self ? (q_end * ref->n - (q_end * (q_end + 1)) / 2) - p.row_base
+                               : (q_end - q_begin) * ref->n;
+    if (d_mask) return ppk_fail(PPK_ERR_STATE, "internal: counts fallback is resolved by the caller");
+    void *p_cnt = nullptr;
+    int rc = ppk_scratch_get(dev, SLOT_ITER_A, rows * (size_t)p.nk * 4 + (size_t)p.nk * 4 + 256, &p_cnt);
+    if (rc != PPK_OK) return rc;
+    uint32_t *d_cnt = static_cast<uint32_t *>(p_cnt);
+    int *d_kmers = reinterpret_cast<int *>(d_cnt + rows * (size_t)p.nk);
+    PPK_HIP(hipMemcpyAsync(d_kmers, kmers, (size_t)p.nk * 4, hipMemcpyHostToDevice, s));
+    rc = launch_tiles<MODE_COUNTS, uint64_t>(ref, qry, d_lut, d_rtab, d_cnt, nullptr, nullptr, p, s);
+    if (rc != PPK_OK) return rc;
+    const bool use_clu = p.random_correct && p.n_clu > 1;
+    hipLaunchKernelGGL(regress_counts_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, d_cnt,
+                       rows, p.row_base, p.self, p.n_ref, p.nk, d_kmers, ref->s64, ref->bbits,
+                       p.random_correct ? d_rtab : nullptr, p.n_clu, use_clu ? ref->d_clu : nullptr,
+                       use_clu ? qry->d_clu : nullptr, scale_x, scale_y, static_cast<float2 *>(d_out),
+                       d_n_failed);
+    PPK_HIP(hipGetLastError());
+    return PPK_OK;
+  }
   // log-J table, built on the device for this (random table, k list)
   {
     const size_t total = (size_t)p.n_clu * p.n_clu * p.lut_cpstride;

@@ -344,3 +344,32 @@ def test_config5_shape_100k_self_fused_boundary_band(big, tbl1):
     assert np.array_equal(np.concatenate([e1.cpu().numpy(), e2.cpu().numpy()]), e)
     db.close()
     db10.close()
+
+
+@pytest.mark.parametrize("s64,kstep", [(16, 1), (156, 1)])
+def test_many_kmer_lengths_counts_fallback(s64, kstep):
+    """--k-step 1 (17 k-mer lengths): 17 x 11 (or 14) count bits > 128, so the packed per-pair
+    state does not fit and the generic counts -> regression path runs; same answers."""
+    kmers = np.arange(13, 30, kstep, dtype=np.int32)
+    n = 150 if s64 == 16 else 40
+    sk, member = synth.make_sketches(n, kmers, sketchsize64=s64, bbits=14, cluster_size=10, seed=6)
+    rng = np.random.Generator(np.random.PCG64(2))
+    tbl = (synth.random_match_table(kmers, n_clu=2) * rng.uniform(0.5, 2.0, size=(len(kmers), 2, 2))).astype(np.float32)
+    clu = (member % 2).astype(np.uint16)
+    got, gf = pp_sketchlib.query_arrays(sk, None, kmers, s64, 14, tbl, clu)
+    want, wf = oracle.query(sk, None, kmers, s64, 14, tbl, clu, clu, threads=4)
+    assert gf == wf and np.abs(got - want).max() <= TOL
+    ref, qry = sk[:n - 30], sk[n - 30:]
+    got, gf = pp_sketchlib.query_arrays(ref, qry, kmers, s64, 14, tbl, clu[:n - 30], clu[n - 30:])
+    want, wf = oracle.query(ref, qry, kmers, s64, 14, tbl, clu[:n - 30], clu[n - 30:], threads=4)
+    assert gf == wf and np.abs(got - want).max() <= TOL
+    # fused-API edge list of the whole matrix falls back to distances + row-linear compaction
+    db = engine.SketchDB(sk, s64, 14, clusters=clu)
+    d, _ = engine.dist(db, None, kmers, tbl)
+    dn = d.cpu().numpy()
+    x_max, y_max = synth.boundary_for_quantile(dn, 0.2)
+    e, _ = engine.dist_edges(db, None, kmers, tbl, slope=2, x_max=x_max, y_max=y_max)
+    assert np.array_equal(e.cpu().numpy(), oracle.edge_threshold(dn, 2, x_max, y_max))
+    with pytest.raises(RuntimeError, match="band"):
+        engine.dist_edges(db, None, kmers, tbl, slope=2, x_max=x_max, y_max=y_max, q_begin=0, q_end=n // 2)
+    db.close()
