@@ -409,20 +409,28 @@ __device__ __forceinline__ uint64_t spread_even(uint32_t v) {
   return x;
 }
 
-constexpr int V2_NW = 8, V2_R = 4, V2_TQ = 4, V2_RT = 256, V2_QT = 32, V2_BB = 14;
+constexpr int V2_R = 4, V2_TQ = 4, V2_RT = 256, V2_BB = 14;
 
-template <int MODE, typename PackT>
-__global__ void __launch_bounds__(V2_NW * 64, 4)
+// NW = wavefronts per workgroup: 8 (256 x 32 tile, 2 workgroups per CU) or 16 (256 x 64 tile,
+// 1 workgroup per CU: half the ref traffic per pair, one s_barrier over 16 wavefronts)
+template <int NW, int MODE, typename PackT>
+__global__ void __launch_bounds__(NW * 64, 4)
 dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ qryT,
                const double *__restrict__ lut, const uint16_t *__restrict__ ref_clu,
                const uint16_t *__restrict__ qry_clu, const float *__restrict__ rtab,
                void *__restrict__ out, unsigned long long *__restrict__ n_failed,
                uint64_t *__restrict__ mask_out, const DistParams p) {
-  constexpr int NW = V2_NW, R = V2_R, TQ = V2_TQ, BB = V2_BB;
+  constexpr int R = V2_R, TQ = V2_TQ, BB = V2_BB;
+  constexpr int V2_QT = NW * TQ;              // queries per workgroup tile (32 or 64)
   constexpr int REF_U4 = BB * 128;            // 14 rows x 256 samples x 8 B = 28 KB
-  constexpr int QRY_U4 = BB * 16;             // 14 rows x 32 samples x 8 B = 3.5 KB
+  constexpr int QRY_U4 = BB * (V2_QT / 2);    // 14 rows x QT samples x 8 B = 3.5 / 7 KB
   constexpr int CHUNK_U4 = REF_U4 + QRY_U4;   // one 64-bin block of the tile
-  __shared__ u32x4 lds[2 * CHUNK_U4];         // double buffer: 63 KB -> 2 workgroups / CU
+  constexpr int LPP = V2_QT / 2;              // lanes (16 B each) per query row
+  constexpr int PPP = 64 / LPP;               // query rows per one-KB DMA piece
+  constexpr int NQP = (BB + PPP - 1) / PPP;   // query pieces per chunk
+  constexpr int NPIECE = 2 * BB + NQP;        // 28 ref pieces + query pieces
+  constexpr int PW = (NPIECE + NW - 1) / NW;  // DMA pieces per wavefront per chunk
+  __shared__ u32x4 lds[2 * CHUNK_U4];         // double buffer: 63 KB (2 WG/CU) or 70 KB (1 WG/CU)
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -454,39 +462,46 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
 
   const int total = p.nk * p.s64;             // one chunk per (k, 64-bin block)
 
-  // DMA sources: each wavefront copies 4 of the chunk's 32 one-KB pieces (28 ref pieces: row
-  // i/2, half i%2; 4 query pieces: 4 rows x 16 lanes each).  A piece's address is a
-  // wave-uniform base (SGPR pair, advanced by one 64-bin block = 14 rows per chunk) plus a
-  // per-lane 32-bit byte offset, i.e. the saddr+voffset form of global_load_lds_dwordx4.
-  const char *dbase[4];
-  size_t dstep[4];
-  int doff[4];
-  bool dref[4];
+  // DMA sources: each wavefront copies PW of the chunk's one-KB pieces (28 ref pieces: row i/2,
+  // half i%2; then the query pieces: PPP rows x LPP lanes each).  A piece's address is a
+  // wave-uniform base (advanced by one 64-bin block = 14 rows per chunk) plus a per-lane 32-bit
+  // byte offset, i.e. the saddr+voffset form of global_load_lds_dwordx4.
+  const char *dbase[PW];
+  size_t dstep[PW];
+  int doff[PW];
+  int dkind[PW];   // 0 = ref piece, 1 = query piece, 2 = none
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
+  for (int t = 0; t < PW; ++t) {
     const int i = wave + NW * t;
-    dref[t] = i < 2 * BB;
-    if (dref[t]) {
+    dbase[t] = nullptr;
+    dstep[t] = 0;
+    doff[t] = 0;
+    if (i < 2 * BB) {
+      dkind[t] = 0;
       dbase[t] = reinterpret_cast<const char *>(refT + (size_t)(i >> 1) * p.npad_r + r0 + (i & 1) * 128);
       dstep[t] = (size_t)BB * p.npad_r * 8;
       doff[t] = i * 64;
-    } else {
+    } else if (i < NPIECE) {
       const int j = i - 2 * BB;
-      dbase[t] = reinterpret_cast<const char *>(qryT + (size_t)(4 * j) * p.npad_q + q0);
+      dkind[t] = 1;
+      dbase[t] = reinterpret_cast<const char *>(qryT + (size_t)(PPP * j) * p.npad_q + q0);
       dstep[t] = (size_t)BB * p.npad_q * 8;
       doff[t] = REF_U4 + j * 64;
+    } else {
+      dkind[t] = 2;
     }
   }
   const uint32_t voff_ref = lane * 16;
-  const uint32_t voff_qry = (uint32_t)((lane >> 4) * p.npad_q * 8) + (lane & 15) * 16;
-  const bool qlane_ok = (4 * 3 + (lane >> 4)) < BB;   // the last query piece holds rows 12, 13 only
+  const uint32_t voff_qry = (uint32_t)((lane / LPP) * p.npad_q * 8) + (lane % LPP) * 16;
+  // the last query piece may hold fewer than PPP rows (14 is not a multiple of 4)
+  const bool qlane_ok = (PPP * (NQP - 1) + lane / LPP) < BB;
   auto issue_dma = [&](int buf) {
     u32x4 *base = lds + buf * CHUNK_U4;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      if (dref[t]) {
+    for (int t = 0; t < PW; ++t) {
+      if (dkind[t] == 0) {
         __builtin_amdgcn_global_load_lds(PPK_GPTR(dbase[t] + voff_ref), PPK_LPTR(base + doff[t]), 16, 0, 0);
-      } else if (wave != NW - 1 || qlane_ok) {
+      } else if (dkind[t] == 1 && (wave + NW * t != NPIECE - 1 || qlane_ok)) {
         __builtin_amdgcn_global_load_lds(PPK_GPTR(dbase[t] + voff_qry), PPK_LPTR(base + doff[t]), 16, 0, 0);
       }
       dbase[t] += dstep[t];
@@ -520,15 +535,19 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
           (uint32_t)(size_t)(__attribute__((address_space(3))) void *)(lds + buf * CHUNK_U4 + lane);
       const uint32_t qp = (uint32_t)(size_t)(__attribute__((address_space(3))) void *)(
           lds + buf * CHUNK_U4 + REF_U4 + wave * 2);
-      asm volatile(PPK_BLOCK_ASM
-                   : [c0] "+v"(cnt[0][0]), [c1] "+v"(cnt[0][1]), [c2] "+v"(cnt[0][2]),
-                     [c3] "+v"(cnt[0][3]), [c4] "+v"(cnt[1][0]), [c5] "+v"(cnt[1][1]),
-                     [c6] "+v"(cnt[1][2]), [c7] "+v"(cnt[1][3]), [c8] "+v"(cnt[2][0]),
-                     [c9] "+v"(cnt[2][1]), [c10] "+v"(cnt[2][2]), [c11] "+v"(cnt[2][3]),
-                     [c12] "+v"(cnt[3][0]), [c13] "+v"(cnt[3][1]), [c14] "+v"(cnt[3][2]),
-                     [c15] "+v"(cnt[3][3])
-                   : [rp] "v"(rp), [qp] "v"(qp)
-                   : "memory", PPK_BLOCK_CLOBBERS);
+#define PPK_BLOCK_OPERANDS                                                                   \
+  [c0] "+v"(cnt[0][0]), [c1] "+v"(cnt[0][1]), [c2] "+v"(cnt[0][2]), [c3] "+v"(cnt[0][3]),       \
+      [c4] "+v"(cnt[1][0]), [c5] "+v"(cnt[1][1]), [c6] "+v"(cnt[1][2]), [c7] "+v"(cnt[1][3]),   \
+      [c8] "+v"(cnt[2][0]), [c9] "+v"(cnt[2][1]), [c10] "+v"(cnt[2][2]), [c11] "+v"(cnt[2][3]), \
+      [c12] "+v"(cnt[3][0]), [c13] "+v"(cnt[3][1]), [c14] "+v"(cnt[3][2]), [c15] "+v"(cnt[3][3])
+      if constexpr (NW == 8) {
+        asm volatile(PPK_BLOCK_ASM_Q32 : PPK_BLOCK_OPERANDS : [rp] "v"(rp), [qp] "v"(qp)
+                     : "memory", PPK_BLOCK_CLOBBERS);
+      } else {
+        asm volatile(PPK_BLOCK_ASM_Q64 : PPK_BLOCK_OPERANDS : [rp] "v"(rp), [qp] "v"(qp)
+                     : "memory", PPK_BLOCK_CLOBBERS);
+      }
+#undef PPK_BLOCK_OPERANDS
 
       if (blk == p.s64 - 1) {
         // ---- end of one k: consume the counts ----------------------------------
@@ -738,10 +757,11 @@ int launch_variant(const ppk_db *ref, const ppk_db *qry, const double *d_lut, co
   return PPK_OK;
 }
 
-template <int MODE, typename PackT>
+template <int NW, int MODE, typename PackT>
 int launch_v2(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const float *d_rtab,
               void *d_out, unsigned long long *d_n_failed, uint64_t *d_mask, DistParams &p,
               hipStream_t s) {
+  constexpr int V2_QT = NW * V2_TQ;
   p.q_tile0 = p.q_begin / V2_QT;
   const size_t q_tiles = (p.q_end + V2_QT - 1) / V2_QT - p.q_tile0;
   const size_t r_tiles = (p.n_ref + V2_RT - 1) / V2_RT;
@@ -757,10 +777,10 @@ int launch_v2(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const f
   const size_t per_xcd = ((r_tiles + 7) / 8) * q_tiles;
   const size_t n_blocks = p.xcd_map ? per_xcd * 8 : r_tiles * q_tiles;
   if (n_blocks > 0x7fffffffull) return ppk_fail(PPK_ERR_ARG, "tile grid too large for one launch");
-  ppk_set_kernel_name("dist_kernel_v2<256x32,lds-dma>");
+  ppk_set_kernel_name(NW == 8 ? "dist_kernel_v2<256x32,lds-dma>" : "dist_kernel_v2<256x64,lds-dma>");
   ppk_prof_begin(s);
-  hipLaunchKernelGGL((dist_kernel_v2<MODE, PackT>), dim3((unsigned)n_blocks),
-                     dim3(V2_NW * 64), 0, s, ref->d_skT, qry->d_skT, d_lut,
+  hipLaunchKernelGGL((dist_kernel_v2<NW, MODE, PackT>), dim3((unsigned)n_blocks),
+                     dim3(NW * 64), 0, s, ref->d_skT, qry->d_skT, d_lut,
                      use_clu ? ref->d_clu : nullptr, use_clu ? qry->d_clu : nullptr, d_rtab, d_out,
                      d_n_failed, d_mask, p);
   ppk_prof_end(s);
@@ -787,14 +807,18 @@ int launch_tiles(const ppk_db *ref, const ppk_db *qry, const double *d_lut, cons
       return launch_variant<8, 4, 14, MODE, PackT>(ref, qry, d_lut, d_rtab, d_out, d_n_failed,
                                                    d_mask, p, s, "dist_kernel<8,4,14>");
   }
-  return launch_v2<MODE, PackT>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
+  if constexpr (MODE == MODE_DIST && sizeof(PackT) == 8) {
+    if (g_tile_tq == 4 && g_tile_nw == 16)   // experiment: 16-wavefront workgroups
+      return launch_v2<16, MODE, PackT>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
+  }
+  return launch_v2<8, MODE, PackT>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
 }
 
 }  // namespace
 
 int ppk_set_tile(int tq, int nw) {
   if (!((tq == 0 && nw == 0) || (tq == 16 && nw == 4) || (tq == 8 && nw == 8) ||
-        (tq == 8 && nw == 4)))
+        (tq == 8 && nw == 4) || (tq == 4 && nw == 16)))
     return ppk_fail(PPK_ERR_ARG, "supported v1 tiles: (16,4) (8,8) (8,4); (0,0) = v2 (default)");
   g_tile_tq = tq;
   g_tile_nw = nw;

@@ -59,7 +59,7 @@ def test_identical_and_disjoint_sketches():
     assert failed == 2 and np.array_equal(d[1:], np.zeros((2, 2)))
 
 
-@pytest.mark.parametrize("tile", [(16, 4), (8, 8), (8, 4)])
+@pytest.mark.parametrize("tile", [(16, 4), (8, 8), (8, 4), (4, 16)])
 def test_distances_self(sk300, tbl1, tile):
     sk = sk300[0]
     lib = _lib.lib()
