@@ -1,0 +1,26 @@
+"""The N-rank sharded job (bench.py's ShardedQuery) with REAL HIP compute: two processes share
+the box's one GPU, so the transport is gloo (RCCL refuses two ranks per GPU) -- everything else
+(band split, sub-band pipelining, direct placement into the PopPUNK-ordered matrix on rank 0)
+is the code path the 8-GPU run uses."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_ranks_one_gpu_matches_single_launch():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tools", "two_ranks_one_gpu.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "RESULT equal=True" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -1,0 +1,25 @@
+"""Debugging aid: the N-rank sharded job with REAL HIP compute on a 1-GPU box (both ranks on GPU 0,
+gloo backend because RCCL refuses two ranks per GPU).  Rank 0 compares the gathered matrix with
+a single-launch result.   torchrun --nproc-per-node 2 tools/two_ranks_one_gpu.py"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.distributed as dist
+from poppunk_amd import engine, synth
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+K = np.asarray(synth.DEFAULT_KMERS, dtype=np.int32); T = synth.random_match_table(K)
+sk, _ = synth.make_sketches(3000, K)
+db = engine.SketchDB(sk, 16, 14, device=0)
+job = engine.ShardedQuery(db, None, rank, world, n_chunks=3)
+full = job.run(K, T)
+full = job.run(K, T)          # reusable
+torch.cuda.synchronize()
+if rank == 0:
+    whole, _ = engine.dist(db, None, K, T)
+    print("RESULT equal=%s rows=%d bands=%s" % (bool(torch.equal(full, whole)), full.shape[0], job.band_rows))
+dist.barrier()
+dist.destroy_process_group()
