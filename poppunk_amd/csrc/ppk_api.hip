@@ -326,7 +326,8 @@ extern "C" int ppk_dist_dev(const ppk_db *ref, const ppk_db *qry, const int32_t 
                             void *stream) {
   int rc = check_pair(ref, qry, kmers, q_begin, q_end);
   if (rc != PPK_OK) return rc;
-  if (q_begin == q_end) return PPK_OK;
+  // an empty band (also: the last self row, which pairs with nothing) is a no-op
+  if (ppk_rows_in_band(ref->n, qry ? qry->n : 0, q_begin, q_end) == 0) return PPK_OK;
   if (!d_out) return ppk_fail(PPK_ERR_ARG, "d_out is NULL");
   DeviceGuard guard(ref->device);
   hipStream_t s = static_cast<hipStream_t>(stream);
