@@ -56,7 +56,8 @@ struct DistParams {
   float x_max, y_max, scale_x, scale_y;
   int xcd_map;            // 1: XCD-aware tile order (v2)
   unsigned r_tiles, q_tiles;   // v2 tile grid
-  int ablate;             // measurement only (PPK_ABLATE): 1 skip epilogue, 2 skip compare, 4 skip DMA, 8 skip barriers
+  int ablate;             // measurement only (PPK_ABLATE): 1 skip epilogue, 2 skip compare, 4 skip DMA, 8 skip barriers,
+                          // 16 no LUT gathers, 32 no exp, 64 no stores
   int kmers[PPK_MAX_NK];
   // all-points-usable fast path of the regression: sums of k, 1/(n*sum k^2 - (sum k)^2), 1/n
   double sx_all, inv_den_all, inv_n_all;
@@ -132,7 +133,7 @@ __device__ __forceinline__ void fit_packed(PackT pk, const double *__restrict__ 
   bool all_ok = p.nk >= 2;
   for (int k = 0; k < p.nk; ++k) {
     const uint32_t c = (uint32_t)(pk >> (p.cnt_bits * k)) & cmask;
-    const double y = lutp[(size_t)k * p.lut_kstride + c];
+    const double y = (p.ablate & 16) ? -1e-3 * (double)c : lutp[(size_t)k * p.lut_kstride + c];
     all_ok = all_ok && (y <= 0.0);
     sy += y;
     sxy += (double)p.kmers[k] * y;
@@ -171,6 +172,12 @@ __device__ __forceinline__ void fit_packed(PackT pk, const double *__restrict__ 
     const double dn = (double)n;
     slope = (dn * sxy - sx * sy) / (dn * sxx - sx * sx);
     icpt = (sy - slope * sx) / dn;
+  }
+  if (p.ablate & 32) {   // measurement only: no exp
+    core = (float)slope;
+    acc = (float)icpt;
+    failed = false;
+    return;
   }
   core = slope < 0.0 ? (float)(1.0 - exp(slope)) : 0.0f;
   acc = icpt < 0.0 ? (float)(1.0 - exp(icpt)) : 0.0f;
@@ -617,7 +624,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
         if (valid) fit_packed<PackT>(packed[r][q], lutp, p, core, acc, failed);
         n_fail_wave += (unsigned)__popcll(__ballot(valid && failed));
         if constexpr (MODE == MODE_DIST) {
-          if (valid) {
+          if (valid && !((p.ablate & 64) && core != 12345.0f)) {
             float2 v;
             v.x = core;
             v.y = acc;
