@@ -54,6 +54,11 @@ struct DistParams {
   int random_correct;
   int slope, inclusive;   // MODE_MASK
   float x_max, y_max, scale_x, scale_y;
+  int strip;              // v2 MODE_DIST, self: 1 = "strip" launch -- the ragged last refs act as the
+                          // query axis against all smaller samples on the lane axis (valid iff rf < qq)
+  unsigned rt0;           // first ref tile of this launch
+  size_t r_limit;         // lane samples >= r_limit are not computed by this launch
+  size_t rf_lo, rf_hi;    // strip: the band filter applies to the lane sample
   int xcd_map;            // 1: XCD-aware tile order (v2)
   unsigned r_tiles, q_tiles;   // v2 tile grid
   int ablate;             // measurement only (PPK_ABLATE): 1 skip epilogue, 2 skip compare, 4 skip DMA, 8 skip barriers,
@@ -420,7 +425,7 @@ constexpr int V2_R = 4, V2_TQ = 4, V2_RT = 256, V2_BB = 14;
 
 // NW = wavefronts per workgroup: 8 (256 x 32 tile, 2 workgroups per CU) or 16 (256 x 64 tile,
 // 1 workgroup per CU: half the ref traffic per pair, one s_barrier over 16 wavefronts)
-template <int NW, int MODE, typename PackT>
+template <int NW, int MODE, typename PackT, bool STRIP>
 __global__ void __launch_bounds__(NW * 64, 4)
 dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ qryT,
                const double *__restrict__ lut, const uint16_t *__restrict__ ref_clu,
@@ -457,12 +462,14 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
     rt = blockIdx.x % p.r_tiles;
     qt = blockIdx.x / p.r_tiles;
   }
+  rt += p.rt0;
   const size_t r0 = rt * V2_RT;
   const size_t q0 = (p.q_tile0 + qt) * V2_QT;
   const size_t qw0 = q0 + (size_t)wave * TQ;
-  if (p.self && r0 + (V2_RT - 1) <= q0) return;   // no pair with r > q in this tile
+  const bool tri = p.self && !STRIP;              // upper-triangle launch: pairs need r > q
+  if (tri && r0 + (V2_RT - 1) <= q0) return;      // no pair with r > q in this tile
   const bool wave_active =
-      !(p.self && r0 + (V2_RT - 1) <= qw0) && qw0 < p.q_end && qw0 + TQ > p.q_begin;
+      !(tri && r0 + (V2_RT - 1) <= qw0) && qw0 < p.q_end && qw0 + TQ > p.q_begin;
   // lane l owns refs r0 + {2l, 2l+1, 128+2l, 128+2l+1}: two conflict-free ds_read_b128 per plane
   // (recomputed where needed rather than kept live across the compare loop)
   auto ref_of = [&](int r) -> size_t { return r0 + 2 * lane + (r & 1) + (r >> 1) * 128; };
@@ -566,7 +573,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
               packed[r][q] |= (PackT)cnt[r][q] << (p.cnt_bits * k);
             } else {
               const size_t qq = qw0 + q, rf = ref_of(r);
-              const bool valid = rf < p.n_ref && qq >= p.q_begin && qq < p.q_end && (!p.self || rf > qq);
+              const bool valid = rf < p.r_limit && qq >= p.q_begin && qq < p.q_end && (!p.self || rf > qq);
               if (valid) {
                 const size_t row = (p.self ? qq * p.n_ref - (qq * (qq + 1)) / 2 + (rf - qq - 1)
                                            : qq * p.n_ref + rf) - p.row_base;
@@ -617,8 +624,11 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const size_t rf = ref_of(r);
-        const bool valid = rf < p.n_ref && (!p.self || rf > qq);
-        const double *lutp = lut + (size_t)(cr[r] * p.n_clu + cq) * p.lut_cpstride;
+        bool valid = rf < p.r_limit && (!p.self || rf > qq);
+        if constexpr (STRIP) valid = rf < qq && rf >= p.rf_lo && rf < p.rf_hi;
+        // table index = (cluster of the ref = larger sample, cluster of the query = smaller sample);
+        // in a strip launch the lane holds the smaller sample
+        const double *lutp = lut + (size_t)(STRIP ? cq * p.n_clu + cr[r] : cr[r] * p.n_clu + cq) * p.lut_cpstride;
         float core = 0.0f, acc = 0.0f;
         bool failed = false;
         if (valid) fit_packed<PackT>(packed[r][q], lutp, p, core, acc, failed);
@@ -628,7 +638,10 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
             float2 v;
             v.x = core;
             v.y = acc;
-            static_cast<float2 *>(out)[rowq + rf] = v;
+            // strip launch: the lane sample is the smaller index, i.e. the row's "query"
+            const size_t row = STRIP ? rf * p.n_ref - (rf * (rf + 1)) / 2 + (qq - rf - 1) - p.row_base
+                                     : rowq + rf;
+            static_cast<float2 *>(out)[row] = v;
           }
         } else {
           bool pred = false;
@@ -764,14 +777,10 @@ int launch_variant(const ppk_db *ref, const ppk_db *qry, const double *d_lut, co
   return PPK_OK;
 }
 
-template <int NW, int MODE, typename PackT>
-int launch_v2(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const float *d_rtab,
-              void *d_out, unsigned long long *d_n_failed, uint64_t *d_mask, DistParams &p,
-              hipStream_t s) {
-  constexpr int V2_QT = NW * V2_TQ;
-  p.q_tile0 = p.q_begin / V2_QT;
-  const size_t q_tiles = (p.q_end + V2_QT - 1) / V2_QT - p.q_tile0;
-  const size_t r_tiles = (p.n_ref + V2_RT - 1) / V2_RT;
+template <int NW, int MODE, typename PackT, bool STRIP>
+int launch_v2_grid(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const float *d_rtab,
+                   void *d_out, unsigned long long *d_n_failed, uint64_t *d_mask, DistParams &p,
+                   size_t r_tiles, size_t q_tiles, hipStream_t s) {
   if (q_tiles == 0 || r_tiles == 0) return PPK_OK;
   const bool use_clu = p.random_correct && p.n_clu > 1;
   p.r_tiles = (unsigned)r_tiles;
@@ -784,15 +793,72 @@ int launch_v2(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const f
   const size_t per_xcd = ((r_tiles + 7) / 8) * q_tiles;
   const size_t n_blocks = p.xcd_map ? per_xcd * 8 : r_tiles * q_tiles;
   if (n_blocks > 0x7fffffffull) return ppk_fail(PPK_ERR_ARG, "tile grid too large for one launch");
-  ppk_set_kernel_name(NW == 8 ? "dist_kernel_v2<256x32,lds-dma>" : "dist_kernel_v2<256x64,lds-dma>");
-  ppk_prof_begin(s);
-  hipLaunchKernelGGL((dist_kernel_v2<NW, MODE, PackT>), dim3((unsigned)n_blocks),
+  hipLaunchKernelGGL((dist_kernel_v2<NW, MODE, PackT, STRIP>), dim3((unsigned)n_blocks),
                      dim3(NW * 64), 0, s, ref->d_skT, qry->d_skT, d_lut,
                      use_clu ? ref->d_clu : nullptr, use_clu ? qry->d_clu : nullptr, d_rtab, d_out,
                      d_n_failed, d_mask, p);
-  ppk_prof_end(s);
   PPK_HIP(hipGetLastError());
   return PPK_OK;
+}
+
+template <int NW, int MODE, typename PackT>
+int launch_v2(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const float *d_rtab,
+              void *d_out, unsigned long long *d_n_failed, uint64_t *d_mask, DistParams &p,
+              hipStream_t s) {
+  constexpr int V2_QT = NW * V2_TQ;
+  p.strip = 0;
+  p.rt0 = 0;
+  p.r_limit = p.n_ref;
+  p.rf_lo = 0;
+  p.rf_hi = p.n_ref;
+  p.q_tile0 = p.q_begin / V2_QT;
+  const size_t q_tiles = (p.q_end + V2_QT - 1) / V2_QT - p.q_tile0;
+  ppk_set_kernel_name(NW == 8 ? "dist_kernel_v2<256x32,lds-dma>" : "dist_kernel_v2<256x64,lds-dma>");
+
+  // Ragged right edge of the self job: when n_ref is a little over a multiple of 256, the last
+  // ref tile would pair its few valid refs with EVERY query tile (n = 10 000: 16 refs, 313 tiles,
+  // 4.5 % of all compare work).  Those refs are handled instead by a "strip" launch in which
+  // they sit on the query axis (a single query tile) against all smaller samples on the lane
+  // axis, writing the same condensed rows.
+  const size_t rem = p.n_ref % V2_RT;
+  bool split = false;
+  if constexpr (MODE == MODE_DIST) {
+    split = p.self && rem != 0 && rem <= 96 && p.n_ref > V2_RT;
+    const char *e = getenv("PPK_STRIP");
+    if (e && atoi(e) == 0) split = false;
+  }
+  // only the dominant (upper-triangle) launch is bracketed by the profiling events
+  int rc = PPK_OK;
+  if (!split) {
+    ppk_prof_begin(s);
+    rc = launch_v2_grid<NW, MODE, PackT, false>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p,
+                                                (p.n_ref + V2_RT - 1) / V2_RT, q_tiles, s);
+    ppk_prof_end(s);
+  } else {
+    const size_t band_lo = p.q_begin, band_hi = p.q_end;
+    p.r_limit = p.n_ref - rem;
+    ppk_prof_begin(s);
+    rc = launch_v2_grid<NW, MODE, PackT, false>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p,
+                                                p.r_limit / V2_RT, q_tiles, s);
+    ppk_prof_end(s);
+    if constexpr (MODE == MODE_DIST) {
+      if (rc == PPK_OK) {
+        DistParams ps = p;
+        ps.strip = 1;
+        ps.r_limit = p.n_ref;
+        ps.rf_lo = band_lo;
+        ps.rf_hi = band_hi;
+        ps.q_begin = p.n_ref - rem;          // the strip samples are this launch's query axis
+        ps.q_end = p.n_ref;
+        ps.q_tile0 = ps.q_begin / V2_QT;
+        ps.rt0 = (unsigned)(band_lo / V2_RT);  // only lane tiles that intersect the band's rows
+        const size_t rt_hi = ((band_hi < p.n_ref ? band_hi : p.n_ref) + V2_RT - 1) / V2_RT;
+        rc = launch_v2_grid<NW, MODE, PackT, true>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask,
+                                                   ps, rt_hi - ps.rt0, (rem + V2_QT - 1) / V2_QT, s);
+      }
+    }
+  }
+  return rc;
 }
 
 template <int MODE, typename PackT>
