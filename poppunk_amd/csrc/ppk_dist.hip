@@ -54,11 +54,14 @@ struct DistParams {
   int random_correct;
   int slope, inclusive;   // MODE_MASK
   float x_max, y_max, scale_x, scale_y;
-  int strip;              // v2 MODE_DIST, self: 1 = "strip" launch -- the ragged last refs act as the
-                          // query axis against all smaller samples on the lane axis (valid iff rf < qq)
-  unsigned rt0;           // first ref tile of this launch
-  size_t r_limit;         // lane samples >= r_limit are not computed by this launch
-  size_t rf_lo, rf_hi;    // strip: the band filter applies to the lane sample
+  // v2 MODE_DIST, self job with a ragged right edge: the first n_strip blocks of the grid are
+  // "strip" tiles -- the last (n_ref mod 256) refs sit on the query axis against all smaller
+  // samples on the lane axis (valid iff lane sample < strip sample); the rest are the triangle.
+  unsigned n_strip;       // number of strip blocks (0 = none)
+  unsigned strip_rt0;     // first lane tile of the strip (band start / 256)
+  unsigned strip_r_tiles; // lane tiles the strip covers
+  size_t strip_begin;     // first strip sample (= r_limit of the triangle part)
+  size_t r_limit;         // triangle part: lane samples >= r_limit are left to the strip
   int xcd_map;            // 1: XCD-aware tile order (v2)
   unsigned r_tiles, q_tiles;   // v2 tile grid
   int ablate;             // measurement only (PPK_ABLATE): 1 skip epilogue, 2 skip compare, 4 skip DMA, 8 skip barriers,
@@ -425,7 +428,7 @@ constexpr int V2_R = 4, V2_TQ = 4, V2_RT = 256, V2_BB = 14;
 
 // NW = wavefronts per workgroup: 8 (256 x 32 tile, 2 workgroups per CU) or 16 (256 x 64 tile,
 // 1 workgroup per CU: half the ref traffic per pair, one s_barrier over 16 wavefronts)
-template <int NW, int MODE, typename PackT, bool STRIP>
+template <int NW, int MODE, typename PackT>
 __global__ void __launch_bounds__(NW * 64, 4)
 dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ qryT,
                const double *__restrict__ lut, const uint16_t *__restrict__ ref_clu,
@@ -451,25 +454,36 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
   // the query tiles with its few ref tiles innermost: the ~64 workgroups resident on an XCD then
   // share the same ref rows through that L2 instead of every XCD streaming every ref tile.
   size_t rt, qt;
-  if (p.xcd_map) {
-    const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
-    if (xcd >= p.r_tiles) return;
-    const unsigned nloc = (p.r_tiles - xcd + 7u) >> 3;   // ref tiles owned by this XCD
-    qt = j / nloc;
-    rt = xcd + 8u * (j % nloc);
-    if (qt >= p.q_tiles) return;
+  const bool strip = blockIdx.x < p.n_strip;      // workgroup-uniform
+  // the band of query rows this tile filters on, and where its query tiles start
+  size_t qb = p.q_begin, qe = p.q_end, q_tile0 = p.q_tile0;
+  if (strip) {
+    // strip tiles come first in the grid so that their serial latency overlaps everything else
+    rt = p.strip_rt0 + blockIdx.x % p.strip_r_tiles;
+    qt = blockIdx.x / p.strip_r_tiles;
+    qb = p.strip_begin;
+    qe = p.n_ref;
+    q_tile0 = p.strip_begin / V2_QT;
   } else {
-    rt = blockIdx.x % p.r_tiles;
-    qt = blockIdx.x / p.r_tiles;
+    const unsigned b = blockIdx.x - p.n_strip;
+    if (p.xcd_map) {
+      const unsigned xcd = b & 7u, j = b >> 3;
+      if (xcd >= p.r_tiles) return;
+      const unsigned nloc = (p.r_tiles - xcd + 7u) >> 3;   // ref tiles owned by this XCD
+      qt = j / nloc;
+      rt = xcd + 8u * (j % nloc);
+      if (qt >= p.q_tiles) return;
+    } else {
+      rt = b % p.r_tiles;
+      qt = b / p.r_tiles;
+    }
   }
-  rt += p.rt0;
   const size_t r0 = rt * V2_RT;
-  const size_t q0 = (p.q_tile0 + qt) * V2_QT;
+  const size_t q0 = (q_tile0 + qt) * V2_QT;
   const size_t qw0 = q0 + (size_t)wave * TQ;
-  const bool tri = p.self && !STRIP;              // upper-triangle launch: pairs need r > q
+  const bool tri = p.self && !strip;              // upper-triangle tile: pairs need r > q
   if (tri && r0 + (V2_RT - 1) <= q0) return;      // no pair with r > q in this tile
-  const bool wave_active =
-      !(tri && r0 + (V2_RT - 1) <= qw0) && qw0 < p.q_end && qw0 + TQ > p.q_begin;
+  const bool wave_active = !(tri && r0 + (V2_RT - 1) <= qw0) && qw0 < qe && qw0 + TQ > qb;
   // lane l owns refs r0 + {2l, 2l+1, 128+2l, 128+2l+1}: two conflict-free ds_read_b128 per plane
   // (recomputed where needed rather than kept live across the compare loop)
   auto ref_of = [&](int r) -> size_t { return r0 + 2 * lane + (r & 1) + (r >> 1) * 128; };
@@ -573,7 +587,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
               packed[r][q] |= (PackT)cnt[r][q] << (p.cnt_bits * k);
             } else {
               const size_t qq = qw0 + q, rf = ref_of(r);
-              const bool valid = rf < p.r_limit && qq >= p.q_begin && qq < p.q_end && (!p.self || rf > qq);
+              const bool valid = rf < p.r_limit && qq >= qb && qq < qe && (!p.self || rf > qq);
               if (valid) {
                 const size_t row = (p.self ? qq * p.n_ref - (qq * (qq + 1)) / 2 + (rf - qq - 1)
                                            : qq * p.n_ref + rf) - p.row_base;
@@ -617,7 +631,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
 #pragma unroll
     for (int q = 0; q < TQ; ++q) {
       const size_t qq = qw0 + q;   // wave-uniform
-      if (qq < p.q_begin || qq >= p.q_end) continue;
+      if (qq < qb || qq >= qe) continue;
       const int cq = qry_clu ? qry_clu[qq] : 0;
       const size_t rowq = (p.self ? qq * p.n_ref - (qq * (qq + 1)) / 2 - qq - 1 : qq * p.n_ref) - p.row_base;
       uint64_t ball[R];
@@ -625,10 +639,10 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
       for (int r = 0; r < R; ++r) {
         const size_t rf = ref_of(r);
         bool valid = rf < p.r_limit && (!p.self || rf > qq);
-        if constexpr (STRIP) valid = rf < qq && rf >= p.rf_lo && rf < p.rf_hi;
+        if (strip) valid = rf < qq && rf >= p.q_begin && rf < p.q_end;   // band filter on the lane sample
         // table index = (cluster of the ref = larger sample, cluster of the query = smaller sample);
         // in a strip launch the lane holds the smaller sample
-        const double *lutp = lut + (size_t)(STRIP ? cq * p.n_clu + cr[r] : cr[r] * p.n_clu + cq) * p.lut_cpstride;
+        const double *lutp = lut + (size_t)(strip ? cq * p.n_clu + cr[r] : cr[r] * p.n_clu + cq) * p.lut_cpstride;
         float core = 0.0f, acc = 0.0f;
         bool failed = false;
         if (valid) fit_packed<PackT>(packed[r][q], lutp, p, core, acc, failed);
@@ -639,7 +653,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
             v.x = core;
             v.y = acc;
             // strip launch: the lane sample is the smaller index, i.e. the row's "query"
-            const size_t row = STRIP ? rf * p.n_ref - (rf * (rf + 1)) / 2 + (qq - rf - 1) - p.row_base
+            const size_t row = strip ? rf * p.n_ref - (rf * (rf + 1)) / 2 + (qq - rf - 1) - p.row_base
                                      : rowq + rf;
             static_cast<float2 *>(out)[row] = v;
           }
@@ -657,7 +671,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
         // ball[0]/ball[1]: even/odd refs of r0..r0+127; ball[2]/ball[3]: of r0+128..r0+255.
         // Interleave them into the [q][ref/64] bitmask words the compaction pass reads.
         if (lane == 0) {
-          uint64_t *mrow = mask_out + (qq - p.q_begin) * p.n_rtiles + rt * 4;
+          uint64_t *mrow = mask_out + (qq - qb) * p.n_rtiles + rt * 4;
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             const uint64_t e = ball[2 * h], o = ball[2 * h + 1];
@@ -777,88 +791,62 @@ int launch_variant(const ppk_db *ref, const ppk_db *qry, const double *d_lut, co
   return PPK_OK;
 }
 
-template <int NW, int MODE, typename PackT, bool STRIP>
-int launch_v2_grid(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const float *d_rtab,
-                   void *d_out, unsigned long long *d_n_failed, uint64_t *d_mask, DistParams &p,
-                   size_t r_tiles, size_t q_tiles, hipStream_t s) {
-  if (q_tiles == 0 || r_tiles == 0) return PPK_OK;
+template <int NW, int MODE, typename PackT>
+int launch_v2(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const float *d_rtab,
+              void *d_out, unsigned long long *d_n_failed, uint64_t *d_mask, DistParams &p,
+              hipStream_t s) {
+  constexpr int V2_QT = NW * V2_TQ;
+  p.q_tile0 = p.q_begin / V2_QT;
+  const size_t q_tiles = (p.q_end + V2_QT - 1) / V2_QT - p.q_tile0;
+  size_t r_tiles = (p.n_ref + V2_RT - 1) / V2_RT;
+  p.r_limit = p.n_ref;
+  p.n_strip = 0;
+  p.strip_rt0 = 0;
+  p.strip_r_tiles = 1;
+  p.strip_begin = p.n_ref;
+
+  // Ragged right edge of the self job: when n_ref is a little over a multiple of 256, the last
+  // ref tile would pair its few valid refs with EVERY query tile (n = 10 000: 16 refs, 313 tiles,
+  // 4.5 % of all compare work).  Those refs are handled instead by "strip" tiles in which they
+  // sit on the query axis against all smaller samples on the lane axis, writing the same
+  // condensed rows; the strip tiles lead the same grid.
+  const size_t rem = p.n_ref % V2_RT;
+  if constexpr (MODE == MODE_DIST) {
+    bool split = p.self && rem != 0 && rem <= 96 && p.n_ref > V2_RT;
+    const char *e = getenv("PPK_STRIP");
+    if (e && atoi(e) == 0) split = false;
+    if (split) {
+      p.r_limit = p.n_ref - rem;
+      p.strip_begin = p.r_limit;
+      r_tiles = p.r_limit / V2_RT;
+      p.strip_rt0 = (unsigned)(p.q_begin / V2_RT);          // lane tiles intersecting the band's rows
+      const size_t rt_hi = ((p.q_end < p.n_ref ? p.q_end : p.n_ref) + V2_RT - 1) / V2_RT;
+      p.strip_r_tiles = (unsigned)(rt_hi - p.strip_rt0);
+      p.n_strip = p.strip_r_tiles * (unsigned)((rem + V2_QT - 1) / V2_QT);
+    }
+  }
+  if (q_tiles == 0 || (r_tiles == 0 && p.n_strip == 0)) return PPK_OK;
   const bool use_clu = p.random_correct && p.n_clu > 1;
-  p.r_tiles = (unsigned)r_tiles;
-  p.q_tiles = (unsigned)q_tiles;
+  p.r_tiles = (unsigned)(r_tiles ? r_tiles : 1);
+  p.q_tiles = (unsigned)(r_tiles ? q_tiles : 0);
   {
     const char *m = getenv("PPK_MAP");
     p.xcd_map = m ? atoi(m) : 0;  // measured: no gain (L2 hit rate is already 83%, kernel is VALU/LDS bound)
   }
   // XCD-aware order: 8 interleaved streams, each as long as the busiest XCD's tile list
   const size_t per_xcd = ((r_tiles + 7) / 8) * q_tiles;
-  const size_t n_blocks = p.xcd_map ? per_xcd * 8 : r_tiles * q_tiles;
+  const size_t n_tri = r_tiles ? (p.xcd_map ? per_xcd * 8 : r_tiles * q_tiles) : 0;
+  const size_t n_blocks = n_tri + p.n_strip;
   if (n_blocks > 0x7fffffffull) return ppk_fail(PPK_ERR_ARG, "tile grid too large for one launch");
-  hipLaunchKernelGGL((dist_kernel_v2<NW, MODE, PackT, STRIP>), dim3((unsigned)n_blocks),
+  ppk_set_kernel_name(NW == 8 ? "dist_kernel_v2<256x32,lds-dma>" : "dist_kernel_v2<256x64,lds-dma>");
+  ppk_prof_begin(s);
+  hipLaunchKernelGGL((dist_kernel_v2<NW, MODE, PackT>), dim3((unsigned)n_blocks),
                      dim3(NW * 64), 0, s, ref->d_skT, qry->d_skT, d_lut,
                      use_clu ? ref->d_clu : nullptr, use_clu ? qry->d_clu : nullptr, d_rtab, d_out,
                      d_n_failed, d_mask, p);
+  ppk_prof_end(s);
   PPK_HIP(hipGetLastError());
   return PPK_OK;
-}
-
-template <int NW, int MODE, typename PackT>
-int launch_v2(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const float *d_rtab,
-              void *d_out, unsigned long long *d_n_failed, uint64_t *d_mask, DistParams &p,
-              hipStream_t s) {
-  constexpr int V2_QT = NW * V2_TQ;
-  p.strip = 0;
-  p.rt0 = 0;
-  p.r_limit = p.n_ref;
-  p.rf_lo = 0;
-  p.rf_hi = p.n_ref;
-  p.q_tile0 = p.q_begin / V2_QT;
-  const size_t q_tiles = (p.q_end + V2_QT - 1) / V2_QT - p.q_tile0;
-  ppk_set_kernel_name(NW == 8 ? "dist_kernel_v2<256x32,lds-dma>" : "dist_kernel_v2<256x64,lds-dma>");
-
-  // Ragged right edge of the self job: when n_ref is a little over a multiple of 256, the last
-  // ref tile would pair its few valid refs with EVERY query tile (n = 10 000: 16 refs, 313 tiles,
-  // 4.5 % of all compare work).  Those refs are handled instead by a "strip" launch in which
-  // they sit on the query axis (a single query tile) against all smaller samples on the lane
-  // axis, writing the same condensed rows.
-  const size_t rem = p.n_ref % V2_RT;
-  bool split = false;
-  if constexpr (MODE == MODE_DIST) {
-    split = p.self && rem != 0 && rem <= 96 && p.n_ref > V2_RT;
-    const char *e = getenv("PPK_STRIP");
-    if (e && atoi(e) == 0) split = false;
-  }
-  // only the dominant (upper-triangle) launch is bracketed by the profiling events
-  int rc = PPK_OK;
-  if (!split) {
-    ppk_prof_begin(s);
-    rc = launch_v2_grid<NW, MODE, PackT, false>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p,
-                                                (p.n_ref + V2_RT - 1) / V2_RT, q_tiles, s);
-    ppk_prof_end(s);
-  } else {
-    const size_t band_lo = p.q_begin, band_hi = p.q_end;
-    p.r_limit = p.n_ref - rem;
-    ppk_prof_begin(s);
-    rc = launch_v2_grid<NW, MODE, PackT, false>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p,
-                                                p.r_limit / V2_RT, q_tiles, s);
-    ppk_prof_end(s);
-    if constexpr (MODE == MODE_DIST) {
-      if (rc == PPK_OK) {
-        DistParams ps = p;
-        ps.strip = 1;
-        ps.r_limit = p.n_ref;
-        ps.rf_lo = band_lo;
-        ps.rf_hi = band_hi;
-        ps.q_begin = p.n_ref - rem;          // the strip samples are this launch's query axis
-        ps.q_end = p.n_ref;
-        ps.q_tile0 = ps.q_begin / V2_QT;
-        ps.rt0 = (unsigned)(band_lo / V2_RT);  // only lane tiles that intersect the band's rows
-        const size_t rt_hi = ((band_hi < p.n_ref ? band_hi : p.n_ref) + V2_RT - 1) / V2_RT;
-        rc = launch_v2_grid<NW, MODE, PackT, true>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask,
-                                                   ps, rt_hi - ps.rt0, (rem + V2_QT - 1) / V2_QT, s);
-      }
-    }
-  }
-  return rc;
 }
 
 template <int MODE, typename PackT>
