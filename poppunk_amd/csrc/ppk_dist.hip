@@ -474,8 +474,12 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
       rt = xcd + 8u * (j % nloc);
       if (qt >= p.q_tiles) return;
     } else {
-      rt = b % p.r_tiles;
+      // Workgroup b is dispatched to XCD b % 8.  With rt = b % r_tiles and r_tiles a multiple of 8
+      // every ref tile would stay on one XCD, and in the triangular job high ref tiles carry more
+      // query tiles than low ones: XCD 7 would get ~40 % more work than XCD 0.  Skewing each
+      // query-tile row by its index rotates the ref tiles over the XCDs.
       qt = b / p.r_tiles;
+      rt = (b % p.r_tiles + qt) % p.r_tiles;
     }
   }
   const size_t r0 = rt * V2_RT;
@@ -812,7 +816,7 @@ int launch_v2(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const f
   // condensed rows; the strip tiles lead the same grid.
   const size_t rem = p.n_ref % V2_RT;
   if constexpr (MODE == MODE_DIST) {
-    bool split = p.self && rem != 0 && rem <= 96 && p.n_ref > V2_RT;
+    bool split = p.self && rem != 0 && rem <= 224 && p.n_ref > V2_RT;
     const char *e = getenv("PPK_STRIP");
     if (e && atoi(e) == 0) split = false;
     if (split) {
