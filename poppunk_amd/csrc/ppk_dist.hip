@@ -64,8 +64,8 @@ struct DistParams {
   size_t r_limit;         // triangle part: lane samples >= r_limit are left to the strip
   int xcd_map;            // 1: XCD-aware tile order (v2)
   unsigned r_tiles, q_tiles;   // v2 tile grid
-  int ablate;             // measurement only (PPK_ABLATE): 1 skip epilogue, 2 skip compare, 4 skip DMA, 8 skip barriers,
-                          // 16 no LUT gathers, 32 no exp, 64 no stores
+  int ablate;             // measurement only (PPK_ABLATE): 1 skip epilogue, 2 skip compare, 4 skip DMA, 8 skip barriers
+
   int kmers[PPK_MAX_NK];
   // all-points-usable fast path of the regression: sums of k, 1/(n*sum k^2 - (sum k)^2), 1/n
   double sx_all, inv_den_all, inv_n_all;
@@ -141,7 +141,7 @@ __device__ __forceinline__ void fit_packed(PackT pk, const double *__restrict__ 
   bool all_ok = p.nk >= 2;
   for (int k = 0; k < p.nk; ++k) {
     const uint32_t c = (uint32_t)(pk >> (p.cnt_bits * k)) & cmask;
-    const double y = (p.ablate & 16) ? -1e-3 * (double)c : lutp[(size_t)k * p.lut_kstride + c];
+    const double y = lutp[(size_t)k * p.lut_kstride + c];
     all_ok = all_ok && (y <= 0.0);
     sy += y;
     sxy += (double)p.kmers[k] * y;
@@ -181,15 +181,88 @@ __device__ __forceinline__ void fit_packed(PackT pk, const double *__restrict__ 
     slope = (dn * sxy - sx * sy) / (dn * sxx - sx * sx);
     icpt = (sy - slope * sx) / dn;
   }
-  if (p.ablate & 32) {   // measurement only: no exp
-    core = (float)slope;
-    acc = (float)icpt;
-    failed = false;
-    return;
-  }
   core = slope < 0.0 ? (float)(1.0 - exp(slope)) : 0.0f;
   acc = icpt < 0.0 ? (float)(1.0 - exp(icpt)) : 0.0f;
   failed = false;
+}
+
+
+// e^x for x <= 0 (the fitted slope / intercept), fp64: n = rint(x log2 e), r = x - n ln 2 in two
+// parts, degree-11 Taylor polynomial on |r| <= 0.347 (truncation 6e-15 relative), scaled by 2^n.
+// A third of the instructions of the library exp (no overflow / NaN / +x handling needed here);
+// the result is rounded to float32 by the caller, which this error changes for ~2 in 1e7 values.
+__device__ __forceinline__ double exp_nonpos(double x) {
+  const double n = __builtin_rint(x * 1.4426950408889634074);
+  double r = __builtin_fma(n, -6.93147180369123816490e-01, x);
+  r = __builtin_fma(n, -1.90821492927058770002e-10, r);
+  double q = 2.50521083854417187751e-08;              // 1/11!
+  q = __builtin_fma(q, r, 2.75573192239858906526e-07);  // 1/10!
+  q = __builtin_fma(q, r, 2.75573192239858906526e-06);  // 1/9!
+  q = __builtin_fma(q, r, 2.48015873015873015873e-05);  // 1/8!
+  q = __builtin_fma(q, r, 1.98412698412698412698e-04);  // 1/7!
+  q = __builtin_fma(q, r, 1.38888888888888888889e-03);  // 1/6!
+  q = __builtin_fma(q, r, 8.33333333333333333333e-03);  // 1/5!
+  q = __builtin_fma(q, r, 4.16666666666666666667e-02);  // 1/4!
+  q = __builtin_fma(q, r, 1.66666666666666666667e-01);  // 1/3!
+  q = __builtin_fma(q, r, 0.5);
+  q = __builtin_fma(q, r, 1.0);
+  q = __builtin_fma(q, r, 1.0);
+  return __builtin_ldexp(q, (int)n);
+}
+
+// a6 for NR of the refs a lane holds against one query (v2 epilogue).  All NR x nk table gathers
+// are issued before the first is consumed: the table look-ups are the only memory latency in the
+// epilogue.
+template <typename PackT, int NR>
+__device__ __forceinline__ void fit_rows(const PackT (&pk)[NR], const double *const (&lutp)[NR],
+                                         const DistParams &p, float (&core)[NR], float (&acc)[NR],
+                                         bool (&failed)[NR]) {
+  constexpr int KU = 5;   // k per gather batch (the default k list has 5)
+  const uint32_t cmask = (1u << p.cnt_bits) - 1u;
+  double sy[NR], sxy[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) sy[r] = sxy[r] = 0.0;
+  bool all_ok = p.nk >= 2;
+  for (int k0 = 0; k0 < p.nk; k0 += KU) {
+    double y[NR][KU];
+#pragma unroll
+    for (int i = 0; i < KU; ++i) {
+      const int k = (k0 + i < p.nk) ? k0 + i : p.nk - 1;   // wave-uniform; surplus slots re-read the last k
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const uint32_t c = (uint32_t)(pk[r] >> (p.cnt_bits * k)) & cmask;
+        y[r][i] = lutp[r][(size_t)k * p.lut_kstride + c];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < KU; ++i) {
+      const bool live = k0 + i < p.nk;
+      const double x = live ? (double)p.kmers[k0 + i < p.nk ? k0 + i : 0] : 0.0;
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const double yv = live ? y[r][i] : 0.0;
+        all_ok = all_ok && (yv <= 0.0);
+        sy[r] += yv;
+        sxy[r] = __builtin_fma(x, yv, sxy[r]);
+      }
+    }
+  }
+  if (__all(all_ok)) {
+    // every k usable in every lane of the wavefront (the overwhelmingly common case): the k-only
+    // sums are launch constants
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const double slope = ((double)p.nk * sxy[r] - p.sx_all * sy[r]) * p.inv_den_all;
+      const double icpt = (sy[r] - slope * p.sx_all) * p.inv_n_all;
+      core[r] = slope < 0.0 ? (float)(1.0 - exp_nonpos(slope)) : 0.0f;
+      acc[r] = icpt < 0.0 ? (float)(1.0 - exp_nonpos(icpt)) : 0.0f;
+      failed[r] = false;
+    }
+    return;
+  }
+  // some lane has a k below the 5/nbins floor: the general fit, one pair at a time
+#pragma unroll 1
+  for (int r = 0; r < NR; ++r) fit_packed<PackT>(pk[r], lutp[r], p, core[r], acc[r], failed[r]);
 }
 
 template <int TQ, int NW, int BBITS, int MODE, typename PackT>
@@ -641,34 +714,67 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
       const int cq = qry_clu ? qry_clu[qq] : 0;
       const size_t rowq = (p.self ? qq * p.n_ref - (qq * (qq + 1)) / 2 - qq - 1 : qq * p.n_ref) - p.row_base;
       uint64_t ball[R];
+      bool valid[R], failed[R];
+      float core[R], acc[R];
+      // the fit runs for every lane (counts of padding samples index the table like any other);
+      // `valid` only gates what is written.  Two refs (2 x nk gathers in flight) at a time.
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const size_t rf = ref_of(r);
-        bool valid = rf < p.r_limit && (!p.self || rf > qq);
-        if (strip) valid = rf < qq && rf >= p.q_begin && rf < p.q_end;   // band filter on the lane sample
-        // table index = (cluster of the ref = larger sample, cluster of the query = smaller sample);
-        // in a strip launch the lane holds the smaller sample
-        const double *lutp = lut + (size_t)(strip ? cq * p.n_clu + cr[r] : cr[r] * p.n_clu + cq) * p.lut_cpstride;
-        float core = 0.0f, acc = 0.0f;
-        bool failed = false;
-        if (valid) fit_packed<PackT>(packed[r][q], lutp, p, core, acc, failed);
-        n_fail_wave += (unsigned)__popcll(__ballot(valid && failed));
-        if constexpr (MODE == MODE_DIST) {
-          if (valid && !((p.ablate & 64) && core != 12345.0f)) {
-            float2 v;
-            v.x = core;
-            v.y = acc;
-            // strip launch: the lane sample is the smaller index, i.e. the row's "query"
-            const size_t row = strip ? rf * p.n_ref - (rf * (rf + 1)) / 2 + (qq - rf - 1) - p.row_base
-                                     : rowq + rf;
-            static_cast<float2 *>(out)[row] = v;
+      for (int h = 0; h < 2; ++h) {
+        const double *lutp[2];
+        PackT pk[2];
+        float c2[2], a2[2];
+        bool f2[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int r = 2 * h + j;
+          const size_t rf = ref_of(r);
+          valid[r] = rf < p.r_limit && (!p.self || rf > qq);
+          if (strip) valid[r] = rf < qq && rf >= p.q_begin && rf < p.q_end;   // band filter on the lane sample
+          // table index = (cluster of the ref = larger sample, cluster of the query = smaller sample);
+          // in a strip launch the lane holds the smaller sample
+          lutp[j] = lut + (size_t)(strip ? cq * p.n_clu + cr[r] : cr[r] * p.n_clu + cq) * p.lut_cpstride;
+          pk[j] = packed[r][q];
+        }
+        fit_rows<PackT, 2>(pk, lutp, p, c2, a2, f2);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          core[2 * h + j] = c2[j];
+          acc[2 * h + j] = a2[j];
+          failed[2 * h + j] = f2[j];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) n_fail_wave += (unsigned)__popcll(__ballot(valid[r] && failed[r]));
+      if constexpr (MODE == MODE_DIST) {
+        // refs 2l and 2l+1 are adjacent rows: one 16-byte store when both are written
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const size_t rf = ref_of(2 * h);
+          // strip launch: the lane sample is the smaller index, i.e. the row's "query"
+          const size_t row0 = strip ? rf * p.n_ref - (rf * (rf + 1)) / 2 + (qq - rf - 1) - p.row_base : rowq + rf;
+          const size_t row1 = strip ? (rf + 1) * p.n_ref - ((rf + 1) * (rf + 2)) / 2 + (qq - rf - 2) - p.row_base
+                                    : row0 + 1;
+          float2 *o = static_cast<float2 *>(out);
+          if (valid[2 * h] && valid[2 * h + 1] && !strip) {
+            float4 v;
+            v.x = core[2 * h];
+            v.y = acc[2 * h];
+            v.z = core[2 * h + 1];
+            v.w = acc[2 * h + 1];
+            __builtin_memcpy(o + row0, &v, 16);
+          } else {
+            if (valid[2 * h]) o[row0] = make_float2(core[2 * h], acc[2 * h]);
+            if (valid[2 * h + 1]) o[row1] = make_float2(core[2 * h + 1], acc[2 * h + 1]);
           }
-        } else {
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
           bool pred = false;
-          if (valid) {
-            const float xs = __fdiv_rn(core, p.scale_x), ys = __fdiv_rn(acc, p.scale_y);
-            const float s = ppk_line_dist(xs, ys, p.x_max, p.y_max, p.slope);
-            pred = p.inclusive ? (s <= 0.0f) : (s < 0.0f);
+          if (valid[r]) {
+            const float xs = __fdiv_rn(core[r], p.scale_x), ys = __fdiv_rn(acc[r], p.scale_y);
+            const float sd = ppk_line_dist(xs, ys, p.x_max, p.y_max, p.slope);
+            pred = p.inclusive ? (sd <= 0.0f) : (sd < 0.0f);
           }
           ball[r] = __ballot(pred);
         }

@@ -23,38 +23,56 @@ Register map (all clobbered by the block):
 import os
 import sys
 
-ACC, A0, A1, S0, S1 = 96, 72, 76, 80, 88     # v72..v127 (all multiples of 4: bank = component)
 BB = 14
+
+
+class Map:
+    """Fixed-register map for a 4-ref x TQ-query tile (all bases multiples of 4: bank = component)."""
+
+    def __init__(self, tq):
+        self.TQ = tq
+        self.A0, self.A1 = 72, 76
+        self.S0 = 80
+        self.S1 = self.S0 + 2 * tq
+        self.ACC = self.S1 + 2 * tq
+        self.END = self.ACC + 8 * tq       # one past the last clobbered register
+
+    def lo_acc(self, r, q):
+        return self.ACC + 2 * (self.TQ * r + q) + 1
+
+    def hi_acc(self, r, q):
+        return self.ACC + 2 * (self.TQ * r + q)
+
+    def a_reg(self, r, hi):      # r in 0..3 -> register of ref r's lo/hi dword
+        base = self.A0 if r < 2 else self.A1
+        return base + 2 * (r & 1) + (1 if hi else 0)
+
+    def s_reg(self, plane, q, hi):
+        base = self.S0 if (plane & 1) == 0 else self.S1
+        return base + 2 * q + (1 if hi else 0)
+
+
 REF_PLANE_BYTES = 2048      # 256 samples x 8 B
 REF_HALF_BYTES = 1024
 
 
-def lo_acc(r, q):
-    return ACC + 2 * (4 * r + q) + 1
-
-
-def hi_acc(r, q):
-    return ACC + 2 * (4 * r + q)
-
-
-def a_reg(r, hi):           # r in 0..3 -> register of ref r's lo/hi dword
-    base = A0 if r < 2 else A1
-    return base + 2 * (r & 1) + (1 if hi else 0)
-
-
-def s_reg(plane, q, hi):
-    base = S0 if (plane & 1) == 0 else S1
-    return base + 2 * q + (1 if hi else 0)
-
-
-def gen(QRY_PLANE_BYTES):
+def gen(QRY_PLANE_BYTES, TQ=4):
+    """TQ = 4: counters %[c0]..%[c15], one per pair (p = 4r + q).
+    TQ = 8: counters %[c0]..%[c15], two pairs per counter (pair p = 8r + q -> counter p >> 1,
+    16-bit half p & 1; a block adds at most 64 and a k at most 16 * 64 per pair ... callers
+    must drain the counters before a half can reach 65536)."""
+    m = Map(TQ)
+    A0, A1, S0, S1 = m.A0, m.A1, m.S0, m.S1
+    lo_acc, hi_acc, a_reg, s_reg = m.lo_acc, m.hi_acc, m.a_reg, m.s_reg
+    NS = TQ // 2                 # ds_read_b128 per query plane
     out = []
     emit = out.append
 
     def load_s(plane):
         base = S0 if (plane & 1) == 0 else S1
-        emit("ds_read_b128 v[%d:%d], %%[qp] offset:%d" % (base, base + 3, plane * QRY_PLANE_BYTES))
-        emit("ds_read_b128 v[%d:%d], %%[qp] offset:%d" % (base + 4, base + 7, plane * QRY_PLANE_BYTES + 16))
+        for i in range(NS):
+            emit("ds_read_b128 v[%d:%d], %%[qp] offset:%d"
+                 % (base + 4 * i, base + 4 * i + 3, plane * QRY_PLANE_BYTES + 16 * i))
 
     def load_a0(plane):
         emit("ds_read_b128 v[%d:%d], %%[rp] offset:%d" % (A0, A0 + 3, plane * REF_PLANE_BYTES))
@@ -64,7 +82,7 @@ def gen(QRY_PLANE_BYTES):
 
     def ops(plane, rs):
         for r in rs:
-            for q in range(4):
+            for q in range(TQ):
                 for hi in (0, 1):
                     acc = hi_acc(r, q) if hi else lo_acc(r, q)
                     a, s = a_reg(r, hi), s_reg(plane, q, hi)
@@ -81,13 +99,13 @@ def gen(QRY_PLANE_BYTES):
         last = b == BB - 1
         if not last:
             load_s(b + 1)
-            emit("s_waitcnt lgkmcnt(3)")      # s(b) x2 and a0(b) have landed; a1(b), s(b+1) x2 may be pending
+            emit("s_waitcnt lgkmcnt(%d)" % (NS + 1))   # s(b) and a0(b) have landed; a1(b), s(b+1) may be pending
         else:
             emit("s_waitcnt lgkmcnt(1)")      # only a1(b) may be pending
         ops(b, (0, 1))
         if not last:
             load_a0(b + 1)
-            emit("s_waitcnt lgkmcnt(3)")      # a1(b) landed; s(b+1) x2, a0(b+1) may be pending
+            emit("s_waitcnt lgkmcnt(%d)" % (NS + 1))   # a1(b) landed; s(b+1), a0(b+1) may be pending
         else:
             emit("s_waitcnt lgkmcnt(0)")
         ops(b, (2, 3))
@@ -95,22 +113,33 @@ def gen(QRY_PLANE_BYTES):
             load_a1(b + 1)
     # popcount-accumulate into the compiler-visible counters %[c0] .. %[c15]
     for r in range(4):
-        for q in range(4):
-            p = 4 * r + q
-            emit("v_bcnt_u32_b32 %%[c%d], v%d, %%[c%d]" % (p, lo_acc(r, q), p))
-            emit("v_bcnt_u32_b32 %%[c%d], v%d, %%[c%d]" % (p, hi_acc(r, q), p))
+        for q in range(TQ):
+            p = TQ * r + q
+            if TQ == 4:
+                emit("v_bcnt_u32_b32 %%[c%d], v%d, %%[c%d]" % (p, lo_acc(r, q), p))
+                emit("v_bcnt_u32_b32 %%[c%d], v%d, %%[c%d]" % (p, hi_acc(r, q), p))
+            elif (p & 1) == 0:
+                emit("v_bcnt_u32_b32 %%[c%d], v%d, %%[c%d]" % (p >> 1, lo_acc(r, q), p >> 1))
+                emit("v_bcnt_u32_b32 %%[c%d], v%d, %%[c%d]" % (p >> 1, hi_acc(r, q), p >> 1))
+            else:
+                t = A0 + (p >> 1) % 8        # operand registers are dead by now: scratch
+                emit("v_bcnt_u32_b32 v%d, v%d, 0" % (t, lo_acc(r, q)))
+                emit("v_bcnt_u32_b32 v%d, v%d, v%d" % (t, hi_acc(r, q), t))
+                emit("v_lshl_add_u32 %%[c%d], v%d, 16, %%[c%d]" % (p >> 1, t, p >> 1))
     return out
 
 
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
     dst = os.path.join(os.path.dirname(here), "poppunk_amd", "csrc", "ppk_block_asm.inc")
-    clob = ", ".join('"v%d"' % i for i in range(A0, ACC + 32))
+    m4, m8 = Map(4), Map(8)
+    clob = ", ".join('"v%d"' % i for i in range(m4.A0, m4.END))
+    clob8 = ", ".join('"v%d"' % i for i in range(m8.A0, m8.END))
     with open(dst, "w") as f:
         f.write("// GENERATED by tools/gen_block_asm.py -- do not edit.  One 64-bin block (14 planes) of the\n"
                 "// 4x4 register tile with bank-aware fixed VGPRs v%d..v%d; see the generator for the map.\n"
                 "// _Q32 / _Q64: 32 or 64 queries per workgroup tile (query plane stride 256 / 512 bytes).\n"
-                % (A0, ACC + 31))
+                % (m4.A0, m4.END - 1))
         for name, stride in (("PPK_BLOCK_ASM_Q32", 256), ("PPK_BLOCK_ASM_Q64", 512)):
             lines = gen(stride)
             f.write("#define %s \\\n" % name)
@@ -120,6 +149,15 @@ def main():
             print("wrote", name, len(lines), "instructions")
         f.write("#define PPK_BLOCK_ASM PPK_BLOCK_ASM_Q32\n")
         f.write("#define PPK_BLOCK_CLOBBERS %s\n" % clob)
+        f.write("// 4x8 register tile (v%d..v%d): 16 counters, two 16-bit pair counts each\n" % (m8.A0, m8.END - 1))
+        for name, stride in (("PPK_BLOCK8_ASM_Q32", 256), ("PPK_BLOCK8_ASM_Q64", 512)):
+            lines = gen(stride, 8)
+            f.write("#define %s \\\n" % name)
+            for ln in lines:
+                f.write('  "%s\\n" \\\n' % ln)
+            f.write("  \"\"\n")
+            print("wrote", name, len(lines), "instructions")
+        f.write("#define PPK_BLOCK8_CLOBBERS %s\n" % clob8)
 
 
 if __name__ == "__main__":
