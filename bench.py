@@ -40,8 +40,9 @@ VALU_MEASURED_LANE_OPS = 55.6e12     # tools/ubench_valu.hip: v_bitop3_b32 v,v,v
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20,
+                    help="untimed steps (the GPU clock needs ~50 ms of load to ramp up)")
     ap.add_argument("--genomes", dest="n", type=int, default=10000, help="genomes at 1 GPU")
     ap.add_argument("--strong", action="store_true", help="keep --n genomes for every N")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")

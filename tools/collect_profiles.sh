@@ -5,8 +5,8 @@ set -u
 OUT=gpurun_out/r01
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:-/root/repo}"
-B="python bench.py --steps 20 --warmup 3 --no-cpu"
-S="python bench.py --steps 3 --warmup 1 --no-cpu"
+B="python bench.py --steps 100 --warmup 20 --no-cpu"
+S="python bench.py --steps 5 --warmup 2 --no-cpu"
 timeout 1500 python tools/measure_configs.py $OUT/configs.json > $OUT/configs.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- $B > $OUT/bench_under_rocprof.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o f -- $S > /dev/null 2>&1
@@ -17,4 +17,6 @@ python bench.py > $OUT/bench.json 2> $OUT/bench.err
 ./tools/ubench_valu.out > $OUT/ubench_valu.txt 2>&1
 ./tools/ubench_bank.out > $OUT/ubench_bank.txt 2>&1
 ./tools/ubench_lds_tile.out > $OUT/ubench_lds_tile.txt 2>&1
+./tools/ubench_pipe.out > $OUT/ubench_pipe.txt 2>&1
+./tools/watch_clocks.sh > $OUT/power_clocks.txt 2>&1
 tail -1 $OUT/bench.json | cut -c1-300

@@ -30,9 +30,14 @@ TBL = synth.random_match_table(KMERS)
 
 
 def timed(fn, reps=5, warm=1):
-    for _ in range(warm):
+    # warm-up by count AND by time: the GPU clock needs ~50 ms of load to ramp (it then settles
+    # near 2.0 GHz under this kernel, power-limited at ~1.29 kW: profiles/r01/power_clocks.txt)
+    t_w = time.perf_counter()
+    i = 0
+    while i < warm or time.perf_counter() - t_w < 0.08:
         fn()
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        i += 1
     t0 = time.perf_counter()
     for _ in range(reps):
         fn()

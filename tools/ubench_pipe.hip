@@ -216,6 +216,16 @@ int main() {
       printf("db_create failed: %s\n", ppk_last_error());
       return 1;
     }
+    // optional: the exact sketches bench.py uses (raw uint64 [10000][1120] written by
+    // `python -c "from poppunk_amd import synth; ..."`), to compare with the Python-driven timing
+    if (const char *f = getenv("PPK_SKETCH_FILE")) {
+      FILE *fp = fopen(f, "rb");
+      if (fp) {
+        size_t got = fread(h.data(), 8, (size_t)10000 * words, fp);
+        fclose(fp);
+        printf("loaded %zu words from %s\n", got, f);
+      }
+    }
     if (ppk_db_create(0, h.data(), 10000, 5, 16, 14, nullptr, 0, nullptr, &dbs)) return 1;
     (void)hipMalloc(&d_out, n * n * 8);
   }

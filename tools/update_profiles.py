@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Copies what tools/collect_profiles.sh measured (gpurun_out/r01) into the tracked profiles/ tree:
+
+  profiles/r01/bench_kernel_stats.csv    rocprofv3 --kernel-trace --stats summary of `python bench.py`
+  profiles/r01/bench_pmc_counters.json   per-launch averages of every PMC counter collected (one pass per group)
+  profiles/pmc_traffic.json              HBM-side bytes per launch of the dominant kernel, read by bench.py
+  profiles/r01/{bench_default.json, configs_1gpu.json, ubench_*.txt, power_clocks.txt}
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "r01")
+DST = os.path.join(ROOT, "profiles", "r01")
+KERNEL = "dist_kernel_v2"
+
+
+def main():
+    os.makedirs(DST, exist_ok=True)
+    shutil.copy(os.path.join(SRC, "kt", "kt_kernel_stats.csv"), os.path.join(DST, "bench_kernel_stats.csv"))
+    line = [l for l in open(os.path.join(SRC, "bench.json")) if l.startswith("{")][-1]
+    open(os.path.join(DST, "bench_default.json"), "w").write(line)
+    shutil.copy(os.path.join(SRC, "configs.json"), os.path.join(DST, "configs_1gpu.json"))
+    for f in glob.glob(os.path.join(SRC, "ubench_*.txt")) + [os.path.join(SRC, "power_clocks.txt")]:
+        if os.path.exists(f):
+            shutil.copy(f, DST)
+    counters = {}
+    kname = None
+    for d in sorted(glob.glob(os.path.join(SRC, "pmc_*"))):
+        for f in glob.glob(os.path.join(d, "*_counter_collection.csv")):
+            agg = collections.defaultdict(list)
+            for r in csv.DictReader(open(f)):
+                if KERNEL in r["Kernel_Name"]:
+                    kname = r["Kernel_Name"].split("(")[0]
+                    agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            for c, v in agg.items():
+                counters[c] = {"avg_per_launch": sum(v) / len(v), "launches": len(v), "pass": os.path.basename(d)}
+    bench = json.loads(line)
+    doc = {"command": "rocprofv3 --pmc <counters> --output-format csv -- python bench.py --steps 5 --warmup 2 --no-cpu "
+                      " (one pass per counter group; tools/collect_profiles.sh)",
+           "kernel": "%s  (%d genomes self, %d pairs per launch)" % (kname, bench["config"]["n_genomes"], bench["config"]["pairs"]),
+           "counters": dict(sorted(counters.items()))}
+    json.dump(doc, open(os.path.join(DST, "bench_pmc_counters.json"), "w"), indent=1)
+    fetch, write = counters["FETCH_SIZE"]["avg_per_launch"], counters["WRITE_SIZE"]["avg_per_launch"]
+    traffic = {"n%d" % bench["config"]["n_genomes"]: (2.0 * fetch + write) * 1024.0,
+               "how": "2 x FETCH_SIZE (gfx950 rocprofv3 reports half the bytes of a 16 B/lane stream: "
+                      "MI355X_MICROARCH.md HBM section) + WRITE_SIZE, KB -> bytes, averaged per launch of "
+                      "dist_kernel_v2; separate --pmc passes (profiles/r01/bench_pmc_counters.json)",
+               "fetch_size_kb": fetch, "write_size_kb": write}
+    json.dump(traffic, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+    for r in csv.DictReader(open(os.path.join(DST, "bench_kernel_stats.csv"))):
+        if KERNEL in r["Name"]:
+            print("rocprof: %s calls=%s avg=%.4f ms" % (KERNEL, r["Calls"], float(r["AverageNs"]) / 1e6))
+    print("bench : kernel_ms=%.4f ms_per_step=%.4f value=%.3f Gpairs/s" %
+          (bench["roofline"]["kernel_ms"], bench["ms_per_step"], bench["value"] / 1e9))
+    print("traffic per launch: %.3f GB" % (traffic["n%d" % bench["config"]["n_genomes"]] / 1e9))
+
+
+if __name__ == "__main__":
+    sys.exit(main())
