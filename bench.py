@@ -53,11 +53,35 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cpus():
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota
+    (a container that sees 256 hardware threads but has a 16-CPU quota is throttled beyond 16:
+    tools/cpu_scaling.py measured 277 Mpairs/s in a 16 ms burst on 64 threads, 27 Mpairs/s
+    sustained on 128)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota:
+        n = min(n, max(1, int(quota)))
+    return max(1, n)
+
+
 def cpu_baseline(sk, kmers, tbl, seconds):
     """Time the CPU oracle (oracle/ppk_oracle.c, `port`) on a bounded self-vs-self sample,
-    repeated until about `seconds` of CPU work has been done."""
+    repeated until about `seconds` of wall time has been spent, on every CPU the process may use."""
     from oracle import oracle
-    threads = max(1, min(os.cpu_count() or 1, oracle.max_threads()))
+    threads = max(1, min(usable_cpus(), oracle.max_threads()))
     probe = min(sk.shape[0], 400)
     t0 = time.perf_counter()
     oracle.query(sk[:probe], None, kmers, 16, 14, tbl, threads=threads)
@@ -71,11 +95,20 @@ def cpu_baseline(sk, kmers, tbl, seconds):
         oracle.query(sk[:n_s], None, kmers, 16, 14, tbl, threads=threads)
         total += time.perf_counter() - t0
         reps += 1
+    # one thread, on a smaller sample (~2 s): the per-core rate (SURVEY.md 8d asks for both)
+    n_1 = int(min(n_s, max(200, (2 * (rate / max(threads, 1)) * 2.0) ** 0.5)))
+    t0 = time.perf_counter()
+    oracle.query(sk[:n_1], None, kmers, 16, 14, tbl, threads=1)
+    one = n_1 * (n_1 - 1) / 2 / max(time.perf_counter() - t0, 1e-6)
     return {"value": pairs * reps / total, "unit": "pairs/s", "cores": threads, "kind": "port",
+            "single_thread_value": one,
+            "host_hw_threads": os.cpu_count(),
             "sample": "first %d of the %d synthetic genomes self-vs-self (%d pairs) x %d passes = "
-                      "%.1f s of CPU work; oracle/ppk_oracle.c gcc -O3 -mavx2 -fopenmp "
-                      "(in-repo restatement of the pp-sketchlib CPU path, not the upstream binary)"
-                      % (n_s, sk.shape[0], pairs, reps, total)}
+                      "%.1f s wall on %d threads (= the CPUs the container may use: affinity capped "
+                      "by the cgroup quota; the host has %d hardware threads); oracle/ppk_oracle.c "
+                      "gcc -O3 -mavx2 -fopenmp (in-repo restatement of the pp-sketchlib CPU path, "
+                      "not the upstream binary)"
+                      % (n_s, sk.shape[0], pairs, reps, total, threads, os.cpu_count() or 0)}
 
 
 def main():
@@ -99,7 +132,11 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("PPK_BENCH_BACKEND", "nccl")   # "gloo": debugging aid with PPK_BENCH_ONE_GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     lib = _lib.lib()
     if args.tile:
@@ -141,10 +178,11 @@ def main():
     kernel_ms = kms.value / max(kn.value, 1)
     kname = lib.ppk_last_kernel_name().decode()
 
+    compute_ms = kms.value / args.steps          # kernel time per step on this rank (HIP events)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, compute_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, compute_ms = float(t[0].item()), float(t[1].item())
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -188,6 +226,14 @@ def main():
                        "parallelism": "band-split x%d, %d-chunk pipelined p2p gather to rank 0" % (world, args.chunks) if world > 1 else "1 GPU"},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if world > 1:
+            # where an N-GPU step goes: the slowest rank's kernel time, and what the root receives
+            line["multi_gpu"] = {
+                "compute_ms_per_step_max_rank": round(compute_ms, 4),
+                "gathered_bytes_per_step": int(sum(job.band_rows[1:])) * 8,
+                "note": "value includes the p2p gather of every peer's distance block into the "
+                        "PopPUNK-ordered matrix on rank 0 (pipelined under compute in %d chunks); "
+                        "the root's inbound xGMI links bound it" % args.chunks}
         if cpu:
             line["speedup_vs_cpu"] = value / cpu["value"]
         print(json.dumps(line))

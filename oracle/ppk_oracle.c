@@ -202,30 +202,43 @@ long ppk_oracle_query(const uint64_t *ref_sk, size_t n_ref,
   long failed = 0;
   if (nk > 64) return -1;
   if (num_threads < 1) num_threads = 1;
-#pragma omp parallel for schedule(dynamic, 8) num_threads(num_threads) reduction(+ : failed)
-  for (long q = 0; q < (long)nq; q++) {
-    const size_t r0 = self ? (size_t)q + 1 : 0;
-    size_t row = self ? (size_t)q * n_ref - ((size_t)q * ((size_t)q + 1)) / 2
-                      : (size_t)q * n_ref;
-    for (size_t r = r0; r < n_ref; r++, row++) {
-      double jac[64];
-      for (size_t k = 0; k < nk; k++) {
-        const uint32_t same =
-            match_count(ref_sk + r * stride + k * words,
-                        qs + (size_t)q * stride + k * words, sketchsize64, bbits);
-        double j = jaccard_obs(same, sketchsize64, bbits);
-        double jr = 0.0;
-        if (rc) {
-          const size_t cr = ref_clu ? ref_clu[r] : 0;
-          const size_t cq = qc ? qc[q] : 0;
-          jr = (double)random_tbl[(k * n_clu + cr) * n_clu + cq];
+  /* Cache blocking only (the arithmetic per pair is untouched): a thread takes QB consecutive
+   * query samples and walks the refs in tiles of RB, so a ref tile (RB x stride x 8 B, ~570 KB at
+   * s = 1024, nk = 5) is compared against all QB queries while it sits in L2.  Without it every
+   * query re-streams the whole database from DRAM and 16 threads are memory-bound. */
+  enum { QB = 8, RB = 64 };
+  const long nqb = ((long)nq + QB - 1) / QB;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(num_threads) reduction(+ : failed)
+  for (long qb = 0; qb < nqb; qb++) {
+    const size_t q_lo = (size_t)qb * QB;
+    const size_t q_hi = q_lo + QB < nq ? q_lo + QB : nq;
+    for (size_t rt = self ? q_lo + 1 : 0; rt < n_ref; rt += RB) {
+      const size_t rt_hi = rt + RB < n_ref ? rt + RB : n_ref;
+      for (size_t q = q_lo; q < q_hi; q++) {
+        const size_t r0 = self ? (q + 1 > rt ? q + 1 : rt) : rt;
+        if (r0 >= rt_hi) continue;
+        size_t row = self ? q * n_ref - (q * (q + 1)) / 2 + (r0 - q - 1) : q * n_ref + r0;
+        for (size_t r = r0; r < rt_hi; r++, row++) {
+          double jac[64];
+          for (size_t k = 0; k < nk; k++) {
+            const uint32_t same =
+                match_count(ref_sk + r * stride + k * words,
+                            qs + q * stride + k * words, sketchsize64, bbits);
+            double j = jaccard_obs(same, sketchsize64, bbits);
+            double jr = 0.0;
+            if (rc) {
+              const size_t cr = ref_clu ? ref_clu[r] : 0;
+              const size_t cq = qc ? qc[q] : 0;
+              jr = (double)random_tbl[(k * n_clu + cr) * n_clu + cq];
+            }
+            jac[k] = observed_excess(j, jr);
+          }
+          if (want_j) {
+            for (size_t k = 0; k < nk; k++) out[row * ocols + k] = (float)jac[k];
+          } else {
+            failed += fit_pair(jac, kmers, nk, nbins, &out[row * 2], &out[row * 2 + 1]);
+          }
         }
-        jac[k] = observed_excess(j, jr);
-      }
-      if (want_j) {
-        for (size_t k = 0; k < nk; k++) out[row * ocols + k] = (float)jac[k];
-      } else {
-        failed += fit_pair(jac, kmers, nk, nbins, &out[row * 2], &out[row * 2 + 1]);
       }
     }
   }

@@ -5,8 +5,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from poppunk_amd import _lib, engine, synth
 lib = _lib.lib()
-def kms(fn, reps=3):
-    fn(); torch.cuda.synchronize()
+import time
+def kms(fn, reps=5):
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.1:      # clock ramp
+        fn(); torch.cuda.synchronize()
     lib.ppk_prof_enable(1); lib.ppk_prof_read(None, None, 1)
     for _ in range(reps): fn()
     torch.cuda.synchronize(); lib.ppk_prof_enable(0)
@@ -14,7 +17,7 @@ def kms(fn, reps=3):
     return ms.value / max(n.value, 1)
 for kmers in ([13, 16, 19, 22, 25, 28], [13, 17, 21, 25]):
     K = np.asarray(kmers, dtype=np.int32); T = synth.random_match_table(K)
-    n = 2000
+    n = int(os.environ.get('N', '4000'))
     sk, _ = synth.make_sketches(n, K, sketchsize64=156, bbits=14, cluster_size=50)
     db = engine.SketchDB(sk, 156, 14)
     t = kms(lambda: engine.dist(db, None, K, T))
