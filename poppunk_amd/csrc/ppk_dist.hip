@@ -63,6 +63,7 @@ struct DistParams {
   size_t strip_begin;     // first strip sample (= r_limit of the triangle part)
   size_t r_limit;         // triangle part: lane samples >= r_limit are left to the strip
   int xcd_map;            // 1: XCD-aware tile order (v2)
+  int lut32;              // the whole log-J table is addressable with 32-bit byte offsets
   unsigned r_tiles, q_tiles;   // v2 tile grid
   int ablate;             // measurement only (PPK_ABLATE): 1 skip epilogue, 2 skip compare, 4 skip DMA, 8 skip barriers
 
@@ -263,6 +264,53 @@ __device__ __forceinline__ void fit_rows(const PackT (&pk)[NR], const double *co
   // some lane has a k below the 5/nbins floor: the general fit, one pair at a time
 #pragma unroll 1
   for (int r = 0; r < NR; ++r) fit_packed<PackT>(pk[r], lutp[r], p, core[r], acc[r], failed[r]);
+}
+
+
+// The same fit for a compile-time number of k (the default k list has 5): straight-line code,
+// counts unpacked with uniform shifts, table look-ups as uniform base + 32-bit lane offset
+// (the saddr form of global_load).  Returns false -- nothing written -- when some lane of the
+// wavefront has an unusable k, and the caller takes the general path.
+template <typename PackT, int NR, int NK>
+__device__ __forceinline__ bool fit_rows_fixed(const PackT (&pk)[NR], const double *__restrict__ lut,
+                                               const uint32_t (&loff)[NR], const DistParams &p,
+                                               float (&core)[NR], float (&acc)[NR]) {
+  const uint32_t cmask = (1u << p.cnt_bits) - 1u;
+  const uint32_t kstride = (uint32_t)p.lut_kstride;
+  const char *base = reinterpret_cast<const char *>(lut);
+  double y[NR][NK];
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const uint32_t c = (uint32_t)(pk[r] >> (p.cnt_bits * k)) & cmask;
+      const uint32_t boff = (loff[r] + (uint32_t)k * kstride + c) * 8u;
+      y[r][k] = *reinterpret_cast<const double *>(base + boff);
+    }
+  }
+  double sy[NR], sxy[NR];
+  bool all_ok = true;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) sy[r] = sxy[r] = 0.0;
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    const double x = (double)p.kmers[k];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      all_ok = all_ok && (y[r][k] <= 0.0);
+      sy[r] += y[r][k];
+      sxy[r] = __builtin_fma(x, y[r][k], sxy[r]);
+    }
+  }
+  if (!__all(all_ok)) return false;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const double slope = ((double)NK * sxy[r] - p.sx_all * sy[r]) * p.inv_den_all;
+    const double icpt = (sy[r] - slope * p.sx_all) * p.inv_n_all;
+    core[r] = slope < 0.0 ? (float)(1.0 - exp_nonpos(slope)) : 0.0f;
+    acc[r] = icpt < 0.0 ? (float)(1.0 - exp_nonpos(icpt)) : 0.0f;
+  }
+  return true;
 }
 
 template <int TQ, int NW, int BBITS, int MODE, typename PackT>
@@ -721,9 +769,10 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const double *lutp[2];
+        uint32_t loff[2];
         PackT pk[2];
         float c2[2], a2[2];
-        bool f2[2];
+        bool f2[2] = {false, false};
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int r = 2 * h + j;
@@ -732,10 +781,13 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
           if (strip) valid[r] = rf < qq && rf >= p.q_begin && rf < p.q_end;   // band filter on the lane sample
           // table index = (cluster of the ref = larger sample, cluster of the query = smaller sample);
           // in a strip launch the lane holds the smaller sample
-          lutp[j] = lut + (size_t)(strip ? cq * p.n_clu + cr[r] : cr[r] * p.n_clu + cq) * p.lut_cpstride;
+          const size_t cp = (size_t)(strip ? cq * p.n_clu + cr[r] : cr[r] * p.n_clu + cq) * p.lut_cpstride;
+          lutp[j] = lut + cp;
+          loff[j] = (uint32_t)cp;
           pk[j] = packed[r][q];
         }
-        fit_rows<PackT, 2>(pk, lutp, p, c2, a2, f2);
+        if (!(p.nk == 5 && p.lut32 && fit_rows_fixed<PackT, 2, 5>(pk, lut, loff, p, c2, a2)))
+          fit_rows<PackT, 2>(pk, lutp, p, c2, a2, f2);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           core[2 * h + j] = c2[j];
@@ -1051,6 +1103,7 @@ int ppk_launch_dist(const ppk_db *ref, const ppk_db *qry_or_null, const int32_t 
     p.inv_den_all = 1.0 / ((double)p.nk * sxx - sx * sx);
     p.inv_n_all = 1.0 / (double)p.nk;
   }
+  p.lut32 = ((size_t)p.n_clu * p.n_clu * p.lut_cpstride * 8 < ((size_t)1 << 32)) ? 1 : 0;
   {
     const char *ab = getenv("PPK_ABLATE");
     p.ablate = ab ? atoi(ab) : 0;
