@@ -65,6 +65,10 @@ struct DistParams {
   int xcd_map;            // 1: XCD-aware tile order (v2)
   int lut32;              // the whole log-J table is addressable with 32-bit byte offsets
   unsigned r_tiles, q_tiles;   // v2 tile grid
+  unsigned n_strip_pad;        // n_strip rounded up to a multiple of 8 (keeps block % 8 = XCD for the rest)
+  unsigned n_tiles;            // non-empty tiles of the triangle / rectangle part
+  unsigned tiles_per_xcd;      // ceil(n_tiles / 8)
+  int tri_m, tri_c0;           // self job: ref tile r pairs with clamp(tri_m * r + tri_c0, 0, q_tiles) query tiles
   int ablate;             // measurement only (PPK_ABLATE): 1 skip epilogue, 2 skip compare, 4 skip DMA, 8 skip barriers
 
   int kmers[PPK_MAX_NK];
@@ -547,6 +551,23 @@ __device__ __forceinline__ uint64_t spread_even(uint32_t v) {
 
 constexpr int V2_R = 4, V2_TQ = 4, V2_RT = 256, V2_BB = 14;
 
+// Non-empty tiles of ref tiles 0 .. r-1, in ref-tile-major order.  Rectangle: every ref tile pairs
+// with all q_tiles query tiles.  Triangle (self): ref tile i has a pair with r > q only for the
+// first clamp(m*i + c0, 0, q_tiles) query tiles (m = 256 / queries-per-tile).
+__host__ __device__ inline unsigned tiles_before(unsigned r, int self, unsigned q_tiles, int m, int c0) {
+  if (!self) return r * q_tiles;
+  // i_lo: first ref tile with any query tile; i_hi: first with all of them
+  const int i_lo = c0 > 0 ? 0 : (-c0) / m + 1;
+  int i_hi = ((int)q_tiles - c0 + m - 1) / m;
+  if (i_hi < i_lo) i_hi = i_lo;
+  const int rr = (int)r;
+  const int b = rr < i_hi ? rr : i_hi;
+  unsigned t = 0;
+  if (b > i_lo) t = (unsigned)((m * (b * (b - 1) - i_lo * (i_lo - 1))) / 2 + c0 * (b - i_lo));
+  if (rr > i_hi) t += (unsigned)(rr - i_hi) * q_tiles;
+  return t;
+}
+
 // NW = wavefronts per workgroup: 8 (256 x 32 tile, 2 workgroups per CU) or 16 (256 x 64 tile,
 // 1 workgroup per CU: half the ref traffic per pair, one s_barrier over 16 wavefronts)
 template <int NW, int MODE, typename PackT>
@@ -586,8 +607,27 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
     qe = p.n_ref;
     q_tile0 = p.strip_begin / V2_QT;
   } else {
-    const unsigned b = blockIdx.x - p.n_strip;
-    if (p.xcd_map) {
+    if (blockIdx.x < p.n_strip_pad) return;
+    const unsigned b = blockIdx.x - p.n_strip_pad;
+    if (p.xcd_map == 0) {
+      // Default order.  Workgroup b is dispatched to XCD b % 8 (observed; used for speed only) and
+      // every XCD has a private 4 MB L2.  The non-empty tiles, taken ref-tile-major, are cut into
+      // 8 equal contiguous runs, one per XCD: the ~64 workgroups resident on an XCD then work on
+      // one or two ref tiles at a time (their rows are fetched into that L2 once per 64-bin block
+      // and re-used by all of them), and the XCDs are balanced to one tile whatever the shape of
+      // the job (in the triangular self job high ref tiles carry more query tiles than low ones).
+      const unsigned x = b & 7u, j = b >> 3;
+      const unsigned g = x * p.tiles_per_xcd + j;
+      if (j >= p.tiles_per_xcd || g >= p.n_tiles) return;
+      unsigned lo = 0, hi = p.r_tiles - 1;      // largest ref tile with tiles_before(rt) <= g
+      while (lo < hi) {
+        const unsigned mid = (lo + hi + 1) >> 1;
+        if (tiles_before(mid, p.self, p.q_tiles, p.tri_m, p.tri_c0) <= g) lo = mid;
+        else hi = mid - 1;
+      }
+      rt = lo;
+      qt = g - tiles_before(lo, p.self, p.q_tiles, p.tri_m, p.tri_c0);
+    } else if (p.xcd_map == 1) {
       const unsigned xcd = b & 7u, j = b >> 3;
       if (xcd >= p.r_tiles) return;
       const unsigned nloc = (p.r_tiles - xcd + 7u) >> 3;   // ref tiles owned by this XCD
@@ -595,7 +635,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
       rt = xcd + 8u * (j % nloc);
       if (qt >= p.q_tiles) return;
     } else {
-      // Workgroup b is dispatched to XCD b % 8.  With rt = b % r_tiles and r_tiles a multiple of 8
+      // (A/B only, PPK_MAP=2)  With rt = b % r_tiles and r_tiles a multiple of 8
       // every ref tile would stay on one XCD, and in the triangular job high ref tiles carry more
       // query tiles than low ones: XCD 7 would get ~40 % more work than XCD 0.  Skewing each
       // query-tile row by its index rotates the ref tiles over the XCDs.
@@ -995,12 +1035,19 @@ int launch_v2(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const f
   p.q_tiles = (unsigned)(r_tiles ? q_tiles : 0);
   {
     const char *m = getenv("PPK_MAP");
-    p.xcd_map = m ? atoi(m) : 0;  // measured: no gain (L2 hit rate is already 83%, kernel is VALU/LDS bound)
+    p.xcd_map = m ? atoi(m) : 0;  // A/B of tile orders; 0 = XCD-contiguous runs (default)
   }
-  // XCD-aware order: 8 interleaved streams, each as long as the busiest XCD's tile list
+  p.n_strip_pad = (p.n_strip + 7u) & ~7u;
+  p.tri_m = V2_RT / V2_QT;
+  p.tri_c0 = p.tri_m - (int)p.q_tile0;
+  p.n_tiles = r_tiles ? tiles_before(p.r_tiles, p.self, p.q_tiles, p.tri_m, p.tri_c0) : 0;
+  p.tiles_per_xcd = (p.n_tiles + 7u) / 8u;
+  // A/B orders: 1 = XCD-owned interleaved streams (each as long as the busiest XCD's list),
+  // 2 = plain (ref tile fastest, skewed for the self job)
   const size_t per_xcd = ((r_tiles + 7) / 8) * q_tiles;
-  const size_t n_tri = r_tiles ? (p.xcd_map ? per_xcd * 8 : r_tiles * q_tiles) : 0;
-  const size_t n_blocks = n_tri + p.n_strip;
+  const size_t n_tri = !r_tiles ? 0 : p.xcd_map == 0 ? (size_t)p.tiles_per_xcd * 8
+                                  : p.xcd_map == 1 ? per_xcd * 8 : r_tiles * q_tiles;
+  const size_t n_blocks = n_tri + p.n_strip_pad;
   if (n_blocks > 0x7fffffffull) return ppk_fail(PPK_ERR_ARG, "tile grid too large for one launch");
   ppk_set_kernel_name(NW == 8 ? "dist_kernel_v2<256x32,lds-dma>" : "dist_kernel_v2<256x64,lds-dma>");
   ppk_prof_begin(s);
