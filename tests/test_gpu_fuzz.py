@@ -60,6 +60,35 @@ def test_random_bands_and_fused_edges(pool, seed):
     db.close()
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_many_ref_tiles_random_bands(seed):
+    """9-13 ref tiles (256 samples each) with a ragged right edge and random query bands: every
+    workgroup-to-tile decode regime of dist_kernel_v2 (ref tiles below the band, the triangle's
+    linear part, saturated ref tiles, strip tiles) -- whole job against the oracle, bands against
+    the whole job, ref x query against the oracle."""
+    import torch
+    rng = np.random.Generator(np.random.PCG64(4000 + seed))
+    n = int(rng.integers(2100, 3300))
+    sk = synth.make_sketches(n, KMERS, cluster_size=60, seed=500 + seed)[0]
+    db = engine.SketchDB(sk, 16, 14)
+    whole, gf = engine.dist(db, None, KMERS, TBL)
+    want, wf = oracle.query(sk, None, KMERS, 16, 14, TBL, threads=8)
+    assert gf == wf and np.abs(whole.cpu().numpy() - want).max() <= 1e-6
+    cuts = sorted(set([0, n] + [int(x) for x in rng.integers(0, n + 1, size=5)]))
+    pieces = [engine.dist(db, None, KMERS, TBL, q_begin=a, q_end=b)[0] for a, b in zip(cuts[:-1], cuts[1:])]
+    assert torch.equal(torch.cat(pieces), whole)
+    nr = int(rng.integers(1200, n - 300))
+    dbr, dbq = engine.SketchDB(sk[:nr], 16, 14), engine.SketchDB(sk[nr:], 16, 14)
+    got, gf = engine.dist(dbr, dbq, KMERS, TBL)
+    want, wf = oracle.query(sk[:nr], sk[nr:], KMERS, 16, 14, TBL, threads=8)
+    assert gf == wf and np.abs(got.cpu().numpy() - want).max() <= 1e-6
+    a, b = sorted(int(x) for x in rng.integers(0, n - nr + 1, size=2))
+    part = engine.dist(dbr, dbq, KMERS, TBL, q_begin=a, q_end=b)[0]
+    assert torch.equal(part, got[a * nr:b * nr])
+    for d in (db, dbr, dbq):
+        d.close()
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_random_float_patterns_kernel2(seed):
     """Arbitrary float32 bit patterns (denormals, huge, negative, NaN) through assign / edges /
