@@ -240,7 +240,19 @@ int ppk_knn_dev(const float *d_square, size_t n, int knn, long long *d_i, long l
 int ppk_knn_rect_dev(const float *d_block, size_t stride, size_t col, size_t n_rows,
                      size_t n_cols, size_t self_offset, int knn, long long *d_i, long long *d_j,
                      float *d_dist, void *stream);
+/* replaces the per-row Python copy loop of PopPUNK.qc.prune_distance_matrix
+ * (PopPUNK/qc.py:58-83): the long-form (condensed, PopPUNK row order) matrix of the
+ * samples keep[0] < keep[1] < ... out of n; `cols` floats per row (2 for distances) */
+int ppk_prune_long_dev(const float *d_long, size_t n, size_t cols, const long long *d_keep,
+                       size_t n_keep, float *d_out, void *stream);
+/* replaces the boolean row mask of PopPUNK.qc.prune_query_distance_matrix
+ * (PopPUNK/qc.py:121-135): the n_ref-row blocks (row = q*n_ref + r) of the kept queries */
+int ppk_prune_query_rows_dev(const float *d_qr, size_t n_ref, size_t cols,
+                             const long long *d_keep, size_t n_keep, float *d_out,
+                             void *stream);
 /* host-buffer forms */
+int ppk_prune_long(const float *dist, size_t n, size_t cols, const long long *keep,
+                   size_t n_keep, int device_id, float *out);
 int ppk_long_to_square(const float *vec, size_t n, int device_id, float *square);
 int ppk_long_to_square_multi(const float *rr, const float *qr, const float *qq, size_t n_ref,
                              size_t n_qry, int device_id, float *square);

@@ -292,3 +292,14 @@ def knn(sq, k):
         oj[i * k:i * k + len(order)] = order
         od[i * k:i * k + len(order)] = sq[i, order]
     return oi, oj, od
+
+
+def prune_long(dist, n, keep):
+    """PopPUNK/qc.py:58-83 restated with numpy: row (i<j) of the long-form matrix survives when both
+    samples are kept; survivors keep their relative order (which IS the new row order, because
+    iterDistRows enumerates pairs of the kept list in the same nested order)."""
+    dist = np.asarray(dist)
+    kept = np.zeros(n, dtype=bool)
+    kept[np.asarray(keep, dtype=np.int64)] = True
+    i, j = np.triu_indices(n, k=1)          # row-major upper triangle == PopPUNK's condensed order
+    return np.ascontiguousarray(dist[kept[i] & kept[j]])

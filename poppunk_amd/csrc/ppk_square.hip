@@ -5,6 +5,8 @@
 //                                    PopPUNK/utils.py:393-396, models.py:1217,1357, mandrake.py:165)
 //  - ppk_long_to_square_multi_dev  : pp_sketchlib.longToSquareMulti [EXT] (PopPUNK/utils.py:398-405)
 //  - ppk_square_to_long_dev        : pp_sketchlib.squareToLong [EXT] (PopPUNK/network.py:2133-2134)
+//  - ppk_prune_long_dev            : row copy of PopPUNK/qc.py:58-83 (prune_distance_matrix)
+//  - ppk_prune_query_rows_dev      : PopPUNK/qc.py:121-135 (prune_query_distance_matrix)
 //  - ppk_knn_dev                   : poppunk_refine.get_kNN_distances (src/extend.cpp:248-289;
 //                                    callers PopPUNK/models.py:1215-1222, assign.py:680-686, mandrake.py:67)
 //
@@ -122,6 +124,31 @@ knn_pick_kernel(const float *__restrict__ skeys, const int *__restrict__ svals, 
     oj[i * knn + k] = 0;
     od[i * knn + k] = 0.0f;
   }
+}
+
+// prune_distance_matrix (PopPUNK/qc.py:58-83): the long-form matrix of the kept samples.  One block
+// per kept sample a; new row (a, b) copies old row (keep[a], keep[b]) -- keep is ascending, so
+// runs of consecutive kept samples are contiguous on both sides.
+__global__ void __launch_bounds__(256)
+prune_long_kernel(const float *__restrict__ in, size_t n, size_t cols, const long long *__restrict__ keep,
+                  size_t m, float *__restrict__ out) {
+  const size_t a = blockIdx.x;
+  const size_t ia = (size_t)keep[a];
+  const size_t obase = cond_index(a, a + 1, m);
+  for (size_t b = a + 1 + threadIdx.x; b < m; b += 256) {
+    const size_t src = cond_index(ia, (size_t)keep[b], n) * cols, dst = (obase + (b - a - 1)) * cols;
+    for (size_t c = 0; c < cols; ++c) out[dst + c] = in[src + c];
+  }
+}
+
+// prune_query_distance_matrix (PopPUNK/qc.py:121-135): whole n_ref-row blocks of the kept queries
+__global__ void __launch_bounds__(256)
+prune_query_rows_kernel(const float *__restrict__ in, size_t row_elems, const long long *__restrict__ keep,
+                        float *__restrict__ out) {
+  const size_t q = blockIdx.y;
+  const size_t src = (size_t)keep[q] * row_elems, dst = q * row_elems;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < row_elems; e += (size_t)gridDim.x * 256)
+    out[dst + e] = in[src + e];
 }
 
 }  // namespace
@@ -280,6 +307,64 @@ extern "C" int ppk_square_to_long(const float *square, size_t n, int device_id, 
   if (rc == PPK_OK) rc = h2d(a.p, square, n * n * 4);
   if (rc == PPK_OK) rc = ppk_square_to_long_dev(static_cast<float *>(a.p), n, static_cast<float *>(b.p), nullptr);
   if (rc == PPK_OK) rc = d2h(vec, b.p, rows * 4);
+  return rc;
+}
+
+extern "C" int ppk_prune_long_dev(const float *d_long, size_t n, size_t cols, const long long *d_keep,
+                                  size_t n_keep, float *d_out, void *stream) {
+  if (n_keep < 2) return PPK_OK;
+  if (!d_long || !d_keep || !d_out || cols == 0 || n_keep > n)
+    return ppk_fail(PPK_ERR_ARG, "ppk_prune_long_dev: bad arguments");
+  hipLaunchKernelGGL(prune_long_kernel, dim3((unsigned)(n_keep - 1)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), d_long, n, cols, d_keep, n_keep, d_out);
+  PPK_HIP(hipGetLastError());
+  return PPK_OK;
+}
+
+extern "C" int ppk_prune_query_rows_dev(const float *d_qr, size_t n_ref, size_t cols,
+                                        const long long *d_keep, size_t n_keep, float *d_out,
+                                        void *stream) {
+  if (n_keep == 0 || n_ref == 0) return PPK_OK;
+  if (!d_qr || !d_keep || !d_out || cols == 0)
+    return ppk_fail(PPK_ERR_ARG, "ppk_prune_query_rows_dev: bad arguments");
+  if (n_keep > 65535) return ppk_fail(PPK_ERR_ARG, "ppk_prune_query_rows_dev: more than 65535 kept queries per call");
+  const size_t row_elems = n_ref * cols;
+  unsigned gx = (unsigned)((row_elems + 255) / 256);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(prune_query_rows_kernel, dim3(gx, (unsigned)n_keep), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), d_qr, row_elems, d_keep, d_out);
+  PPK_HIP(hipGetLastError());
+  return PPK_OK;
+}
+
+namespace {
+int check_keep(const long long *keep, size_t n_keep, size_t n) {
+  for (size_t i = 0; i < n_keep; ++i)
+    if (keep[i] < 0 || (size_t)keep[i] >= n || (i && keep[i] <= keep[i - 1]))
+      return ppk_fail(PPK_ERR_ARG, "kept indices must be strictly ascending and inside the matrix");
+  return PPK_OK;
+}
+}  // namespace
+
+extern "C" int ppk_prune_long(const float *dist, size_t n, size_t cols, const long long *keep,
+                              size_t n_keep, int device_id, float *out) {
+  if (n_keep < 2) return PPK_OK;
+  if (!dist || !keep || !out || cols == 0) return ppk_fail(PPK_ERR_ARG, "NULL buffer");
+  int rc = check_keep(keep, n_keep, n);
+  if (rc != PPK_OK) return rc;
+  DeviceGuard guard(device_id);
+  if (!guard.ok) return ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(device_id));
+  const size_t rows_in = n * (n - 1) / 2, rows_out = n_keep * (n_keep - 1) / 2;
+  DevBuf a, k, b;
+  rc = a.alloc(rows_in * cols * 4);
+  if (rc == PPK_OK) rc = k.alloc(n_keep * 8);
+  if (rc == PPK_OK) rc = b.alloc(rows_out * cols * 4);
+  if (rc == PPK_OK) rc = h2d(a.p, dist, rows_in * cols * 4);
+  if (rc == PPK_OK) rc = h2d(k.p, keep, n_keep * 8);
+  if (rc == PPK_OK)
+    rc = ppk_prune_long_dev(static_cast<float *>(a.p), n, cols, static_cast<long long *>(k.p), n_keep,
+                            static_cast<float *>(b.p), nullptr);
+  if (rc == PPK_OK) rc = d2h(out, b.p, rows_out * cols * 4);
   return rc;
 }
 

@@ -298,6 +298,47 @@ def long_to_square_dev(dist_t, col, n):
     return out
 
 
+def prune_long_dev(dist_t, n, keep):
+    """Long-form matrix of the kept samples out of the resident long-form matrix of n samples
+    (the row copy of PopPUNK/qc.py:58-83 as one gather).  keep: ascending sample indices."""
+    torch = _torch()
+    keep_t = torch.as_tensor(np.ascontiguousarray(keep, dtype=np.int64), device=dist_t.device)
+    m = int(keep_t.shape[0])
+    if m and (int(keep_t.min()) < 0 or int(keep_t.max()) >= n or
+              (m > 1 and bool((keep_t[1:] <= keep_t[:-1]).any()))):
+        raise RuntimeError("kept indices must be strictly ascending and inside the matrix")
+    cols = 1 if dist_t.dim() == 1 else int(dist_t.shape[1])
+    shape = (m * (m - 1) // 2,) if dist_t.dim() == 1 else (m * (m - 1) // 2, cols)
+    out = torch.empty(shape, dtype=torch.float32, device=dist_t.device)
+    with torch.cuda.device(dist_t.device):
+        rc = _lib.lib().ppk_prune_long_dev(C.c_void_p(dist_t.data_ptr()), n, cols,
+                                           C.c_void_p(keep_t.data_ptr()), m,
+                                           C.c_void_p(out.data_ptr()), _stream_ptr(dist_t.device.index))
+        _lib.check(rc, "ppk_prune_long_dev")
+    return out
+
+
+def prune_query_rows_dev(qr_t, n_ref, keep_q):
+    """Row blocks (row = q*n_ref + r) of the kept queries (PopPUNK/qc.py:121-135)."""
+    torch = _torch()
+    keep_t = torch.as_tensor(np.ascontiguousarray(keep_q, dtype=np.int64), device=qr_t.device)
+    m = int(keep_t.shape[0])
+    cols = 1 if qr_t.dim() == 1 else int(qr_t.shape[1])
+    n_qry = qr_t.shape[0] // max(n_ref, 1)
+    if m and (int(keep_t.min()) < 0 or int(keep_t.max()) >= n_qry):
+        raise RuntimeError("kept query index outside the matrix")
+    shape = (m * n_ref,) if qr_t.dim() == 1 else (m * n_ref, cols)
+    out = torch.empty(shape, dtype=torch.float32, device=qr_t.device)
+    with torch.cuda.device(qr_t.device):
+        for lo in range(0, m, 65535):
+            hi = min(m, lo + 65535)
+            rc = _lib.lib().ppk_prune_query_rows_dev(
+                C.c_void_p(qr_t.data_ptr()), n_ref, cols, C.c_void_p(keep_t[lo:].data_ptr()), hi - lo,
+                C.c_void_p(out[lo * n_ref:].data_ptr()), _stream_ptr(qr_t.device.index))
+            _lib.check(rc, "ppk_prune_query_rows_dev")
+    return out
+
+
 def knn_from_sketches(db, kmers, random_tbl, knn, dist_col=0, random_correct=True,
                       band_items=1 << 29):
     """k nearest neighbours of every sample straight from the resident sketches (what

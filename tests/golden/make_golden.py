@@ -17,6 +17,9 @@ Fixtures written:
   row_order.json       distMat row -> (ref, query) tables from iterDistRows/listDistInts
   json_sketch.npz      the real sketch test/json_sketch.txt (a data file of the
                        reference's test directory) as uint64 arrays
+  prune.json           PopPUNK.qc.prune_distance_matrix / prune_query_distance_matrix
+                       (PopPUNK/qc.py:17-135) run on small seeded matrices, with the real
+                       iterDistRows / storePickle (PopPUNK/utils.py) they call
 boundary_known_answers.json is NOT generated here: src/boundary.cpp needs Eigen,
 absent from this image; its values were captured during the survey (SURVEY.md
 Appendix B) and are transcribed by hand.
@@ -118,7 +121,45 @@ def golden_sketch():
     print("json_sketch.npz:", sk.shape, "kmers", kmers)
 
 
+def golden_prune():
+    import pickle
+    import tempfile
+    ns = {"np": np, "sys": sys, "pickle": pickle}
+    extract_functions(os.path.join(REF, "PopPUNK", "utils.py"), ["iterDistRows", "storePickle"], ns)
+    extract_functions(os.path.join(REF, "PopPUNK", "qc.py"),
+                      ["prune_distance_matrix", "prune_query_distance_matrix"], ns)
+    rng = np.random.Generator(np.random.PCG64(20260929))
+    out = {"source": "PopPUNK/qc.py:17-135 prune_distance_matrix / prune_query_distance_matrix, "
+                     "run by make_golden.py", "self": [], "query": []}
+    with tempfile.TemporaryDirectory() as tmp:
+        for n, n_rm in ((4, 1), (7, 2), (9, 4), (12, 1), (6, 0)):
+            names = ["s%d" % i for i in range(n)]
+            dist = rng.random((n * (n - 1) // 2, 2)).astype(np.float32)
+            remove = [names[i] for i in sorted(rng.choice(n, size=n_rm, replace=False))]
+            if n == 7:
+                remove.append("not_in_db")      # the reference reports it and carries on
+            new_names, new_dist = ns["prune_distance_matrix"](names, remove, dist,
+                                                               os.path.join(tmp, "p%d" % n))
+            out["self"].append({"names": names, "remove": remove, "dist": dist.tolist(),
+                                "new_names": list(new_names), "new_dist": np.asarray(new_dist).tolist()})
+        for nr, nq, n_rm in ((3, 4, 1), (2, 5, 2), (4, 3, 0)):
+            refs = ["r%d" % i for i in range(nr)]
+            qrys = ["q%d" % i for i in range(nq)]
+            qr = rng.random((nr * nq, 2)).astype(np.float32)
+            assign = rng.integers(-1, 2, size=nr * nq).astype(np.int64)
+            remove = set(qrys[i] for i in rng.choice(nq, size=n_rm, replace=False))
+            passing, new_qr, new_assign = ns["prune_query_distance_matrix"](refs, qrys, remove, qr, assign)
+            out["query"].append({"refs": refs, "queries": qrys, "remove": sorted(remove),
+                                 "dist": qr.tolist(), "assign": assign.tolist(),
+                                 "passing": list(passing), "new_dist": np.asarray(new_qr).tolist(),
+                                 "new_assign": np.asarray(new_assign).tolist()})
+    with open(os.path.join(HERE, "prune.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("prune.json:", len(out["self"]), "self cases,", len(out["query"]), "query cases")
+
+
 if __name__ == "__main__":
+    golden_prune()
     golden_fit()
     golden_rows()
     golden_sketch()

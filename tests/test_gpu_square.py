@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle
-from poppunk_amd import poppunk_refine, pp_sketchlib
+from poppunk_amd import engine, poppunk_refine, pp_sketchlib, qc
 
 pytestmark = pytest.mark.gpu
 
@@ -71,3 +71,51 @@ def test_knn_straight_from_sketches():
         # ties between equal distances resolve by column index in both
         assert np.array_equal(gj.cpu().numpy(), wj)
     db.close()
+
+
+def test_prune_distance_matrix_golden_and_random(tmp_path, capsys):
+    """qc.prune_distance_matrix (ppk_prune_long) against the reference's own outputs
+    (tests/golden/prune.json) and, on a larger matrix, against the oracle; the .pkl/.npy pair is
+    written like the reference does."""
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "prune.json")))
+    for k, c in enumerate(g["self"]):
+        dist = np.asarray(c["dist"], dtype=np.float32)
+        names, new = qc.prune_distance_matrix(c["names"], c["remove"], dist, str(tmp_path / ("p%d" % k)))
+        assert list(names) == c["new_names"]
+        assert np.array_equal(np.asarray(new).reshape(-1, 2),
+                              np.asarray(c["new_dist"], dtype=np.float32).reshape(-1, 2))
+        assert os.path.exists(str(tmp_path / ("p%d.pkl" % k)))
+    assert "Couldn't find not_in_db in database" in capsys.readouterr().err
+    rng = np.random.Generator(np.random.PCG64(5))
+    n = 1500
+    dist = rng.random((n * (n - 1) // 2, 2)).astype(np.float32)
+    names = ["g%d" % i for i in range(n)]
+    gone = sorted(rng.choice(n, size=137, replace=False))
+    new_names, new = qc.prune_distance_matrix(names, [names[i] for i in gone], dist, None)
+    keep = [i for i in range(n) if i not in set(gone)]
+    assert new_names == [names[i] for i in keep]
+    assert np.array_equal(new, oracle.prune_long(dist, n, keep))
+    with pytest.raises(TypeError):
+        qc.prune_distance_matrix(names, [names[0]], dist.astype(np.float64), None)
+
+
+def test_prune_on_resident_buffers():
+    import torch
+    rng = np.random.Generator(np.random.PCG64(6))
+    n = 700
+    dist = rng.random((n * (n - 1) // 2, 2)).astype(np.float32)
+    keep = np.sort(rng.choice(n, size=412, replace=False))
+    d = torch.as_tensor(dist, device="cuda")
+    got = engine.prune_long_dev(d, n, keep).cpu().numpy()
+    assert np.array_equal(got, oracle.prune_long(dist, n, keep))
+    one = engine.prune_long_dev(d[:, 1].contiguous(), n, keep).cpu().numpy()    # a single column
+    assert np.array_equal(one, oracle.prune_long(dist[:, 1], n, keep))
+    with pytest.raises(RuntimeError):
+        engine.prune_long_dev(d, n, keep[::-1].copy())
+    n_ref, n_qry = 300, 90
+    qr = rng.random((n_ref * n_qry, 2)).astype(np.float32)
+    kq = np.sort(rng.choice(n_qry, size=55, replace=False))
+    got = engine.prune_query_rows_dev(torch.as_tensor(qr, device="cuda"), n_ref, kq).cpu().numpy()
+    assert np.array_equal(got, qr.reshape(n_qry, n_ref, 2)[kq].reshape(-1, 2))
