@@ -341,3 +341,36 @@ def test_nan_and_inf_rows_follow_the_reference_branches():
     assert a2[0] == -1 and a2[1] == -1 and a2[2] == 1 and a2[3] == -1 and a2[4] == -1 and a2[5] == 0
     e = poppunk_refine.edgeThreshold(d, 2, 0.5, 0.5)
     assert (0, 1) not in e and (0, 2) not in e and (1, 2) in e and (2, 3) in e   # rows 0,1 NaN; 3,5 within/on
+
+
+def test_refine_boundary_model_mirror():
+    """models.RefineBoundary = RefineFit.assign / apply_threshold (PopPUNK/models.py:956-994,
+    :1065-1091) + the generateTuples hand-off (network.py:1180-1184): host path, resident path and
+    the fused sketch -> edge-list path agree with the oracle's statement of the same steps."""
+    import torch
+    from poppunk_amd import engine, models
+    kmers = np.asarray(synth.DEFAULT_KMERS, dtype=np.int32)
+    tbl = synth.random_match_table(kmers)
+    sk = synth.make_sketches(420, kmers, cluster_size=35, seed=11)[0]
+    X, _ = oracle.query(sk, None, kmers, 16, 14, tbl, threads=4)
+    scale = np.amax(X, axis=0)                                 # models.py:253,:861
+    xs = X / scale
+    x_max, y_max = synth.boundary_for_quantile(xs, 0.15)
+    b = models.RefineBoundary(scale=scale, slope=2, optimal_x=x_max, optimal_y=y_max,
+                              core_boundary=0.4 * x_max, accessory_boundary=0.4 * y_max)
+    for slope, (xm, ym) in ((None, (x_max, y_max)), (0, (0.4 * x_max, 0)), (1, (0, 0.4 * y_max))):
+        want = oracle.assign_threshold(xs, 2 if slope is None else slope, xm, ym)
+        assert np.array_equal(b.assign(X, slope), want)
+        got = b.assign_dev(torch.as_tensor(X, device="cuda"), slope).cpu().numpy()
+        assert np.array_equal(got, want)
+        edges_want = oracle.generate_tuples(want.astype(np.int32), -1, True, 0, 0)
+        assert b.edges(X, slope=slope) == [tuple(e) for e in edges_want.tolist()]
+        db = engine.SketchDB(sk, 16, 14)
+        fused, _ = b.edges_from_sketches(db, None, kmers, tbl, slope=slope)
+        assert np.array_equal(fused.cpu().numpy(), edges_want)
+        db.close()
+    t = models.RefineBoundary.from_threshold(float(np.quantile(X[:, 0], 0.1)))
+    assert t.slope == 0 and np.array_equal(t.scale, [1, 1])
+    assert np.array_equal(t.assign(X), oracle.assign_threshold(X, 0, t.core_boundary, 0))
+    with pytest.raises(RuntimeError):
+        models.RefineBoundary().assign(X)
