@@ -13,9 +13,13 @@
 
 namespace {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 constexpr int kBlock = 256;
-constexpr int kWordsPerThread = 8;
-constexpr int kWordsPerBlock = kBlock * kWordsPerThread;  // 2048 mask words = 131072 rows
+// mask words per thread of the compaction passes: 1 keeps the loads coalesced and the serial
+// bit-expansion chain of a thread to one word (8 was 3x slower on scattered edges)
+constexpr int kWordsPerThread = 1;
+constexpr int kWordsPerBlock = kBlock * kWordsPerThread;
 
 __global__ void __launch_bounds__(kBlock)
 assign_kernel(const float2 *__restrict__ dist, size_t n_rows, int slope, float x_max,
@@ -25,6 +29,23 @@ assign_kernel(const float2 *__restrict__ dist, size_t n_rows, int slope, float x
     const float2 d = dist[row];
     const float s = ppk_line_dist(d.x, d.y, x_max, y_max, slope);
     out[row] = (s == 0.0f) ? 0.0f : (s > 0.0f ? 1.0f : -1.0f);
+  }
+}
+
+// Two rows per lane: one 16-byte load, one 8-byte store (the widest accesses the stream allows;
+// taken when both pointers are suitably aligned, which device allocations are).
+__global__ void __launch_bounds__(kBlock)
+assign_kernel_x2(const f32x4 *__restrict__ dist, size_t n_pairs, int slope, float x_max,
+                 float y_max, float2 *__restrict__ out) {
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t p = (size_t)blockIdx.x * kBlock + threadIdx.x; p < n_pairs; p += stride) {
+    const f32x4 d = __builtin_nontemporal_load(dist + p);   // read once: keep it out of the caches' way
+    const float s0 = ppk_line_dist(d.x, d.y, x_max, y_max, slope);
+    const float s1 = ppk_line_dist(d.z, d.w, x_max, y_max, slope);
+    float2 r;
+    r.x = (s0 == 0.0f) ? 0.0f : (s0 > 0.0f ? 1.0f : -1.0f);
+    r.y = (s1 == 0.0f) ? 0.0f : (s1 > 0.0f ? 1.0f : -1.0f);
+    out[p] = r;
   }
 }
 
@@ -65,6 +86,40 @@ mask_from_qc_kernel(const float2 *__restrict__ dist, size_t n_rows, int mode, fl
     }
     const uint64_t m = __ballot(pred);
     if (lane == 0) mask[w] = m;
+  }
+}
+
+// The same with 16-byte loads: a wavefront covers 128 consecutive rows, lane l holding rows 2l and
+// 2l+1.  Mask word A wants row v of the first 64 in bit v, i.e. the predicate of lane v/2, row
+// v%2: one ds_bpermute (the LDS crossbar, no memory traffic) per mask word moves each lane's two
+// predicate bits to the lane whose ballot position they belong to.
+__global__ void __launch_bounds__(kBlock)
+mask_from_dist_kernel_x2(const f32x4 *__restrict__ dist, size_t n_rows, int slope, float x_max,
+                         float y_max, int inclusive, uint64_t *__restrict__ mask, size_t n_words) {
+  const size_t n_w2 = (n_words + 1) / 2;        // pairs of mask words
+  const size_t wstride = (size_t)gridDim.x * (kBlock / 64);
+  const int lane = threadIdx.x & 63;
+  const int src_a = (lane >> 1) * 4, src_b = (32 + (lane >> 1)) * 4;   // byte lane ids for bpermute
+  for (size_t w2 = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); w2 < n_w2; w2 += wstride) {
+    const size_t row = w2 * 128 + 2 * (size_t)lane;
+    int p = 0;
+    if (row + 1 < n_rows) {
+      const f32x4 d = __builtin_nontemporal_load(dist + (row >> 1));
+      const float s0 = ppk_line_dist(d.x, d.y, x_max, y_max, slope);
+      const float s1 = ppk_line_dist(d.z, d.w, x_max, y_max, slope);
+      p = (inclusive ? (s0 <= 0.0f) : (s0 < 0.0f)) ? 1 : 0;
+      p |= (inclusive ? (s1 <= 0.0f) : (s1 < 0.0f)) ? 2 : 0;
+    } else if (row < n_rows) {
+      const float2 d = reinterpret_cast<const float2 *>(dist)[row];
+      const float s0 = ppk_line_dist(d.x, d.y, x_max, y_max, slope);
+      p = (inclusive ? (s0 <= 0.0f) : (s0 < 0.0f)) ? 1 : 0;
+    }
+    const int pa = __builtin_amdgcn_ds_bpermute(src_a, p), pb = __builtin_amdgcn_ds_bpermute(src_b, p);
+    const uint64_t wa = __ballot((pa >> (lane & 1)) & 1), wb = __ballot((pb >> (lane & 1)) & 1);
+    if (lane == 0) {
+      mask[2 * w2] = wa;
+      if (2 * w2 + 1 < n_words) mask[2 * w2 + 1] = wb;
+    }
   }
 }
 
@@ -301,9 +356,21 @@ int ppk_launch_assign(const float *d_dist, size_t n_rows, int slope, float x_max
                       float *d_out, hipStream_t s) {
   if (n_rows == 0) return PPK_OK;
   // memory-bound stream: cap the grid at 256 CUs x 8 blocks and grid-stride
-  const unsigned grid = grid_for(n_rows, kBlock, 2048);
-  hipLaunchKernelGGL(assign_kernel, dim3(grid), dim3(kBlock), 0, s,
-                     reinterpret_cast<const float2 *>(d_dist), n_rows, slope, x_max, y_max, d_out);
+  const bool aligned = (reinterpret_cast<uintptr_t>(d_dist) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_out) & 7) == 0;
+  const size_t n_pairs = aligned ? n_rows / 2 : 0;
+  if (n_pairs) {
+    const unsigned grid = grid_for(n_pairs, kBlock, 2048);
+    hipLaunchKernelGGL(assign_kernel_x2, dim3(grid), dim3(kBlock), 0, s,
+                       reinterpret_cast<const f32x4 *>(d_dist), n_pairs, slope, x_max, y_max,
+                       reinterpret_cast<float2 *>(d_out));
+  }
+  if (2 * n_pairs < n_rows) {    // the odd last row, or everything when the buffers are not aligned
+    const size_t rest = n_rows - 2 * n_pairs;
+    const unsigned grid = grid_for(rest, kBlock, 2048);
+    hipLaunchKernelGGL(assign_kernel, dim3(grid), dim3(kBlock), 0, s,
+                       reinterpret_cast<const float2 *>(d_dist) + 2 * n_pairs, rest, slope, x_max, y_max,
+                       d_out + 2 * n_pairs);
+  }
   PPK_HIP(hipGetLastError());
   return PPK_OK;
 }
@@ -312,10 +379,17 @@ int ppk_launch_mask_from_dist(const float *d_dist, size_t n_rows, int slope, flo
                               float y_max, int inclusive, uint64_t *d_mask, hipStream_t s) {
   const size_t n_words = ppk_mask_words_linear(n_rows);
   if (n_words == 0) return PPK_OK;
-  const unsigned grid = grid_for(n_words, kBlock / 64, 4096);
-  hipLaunchKernelGGL(mask_from_dist_kernel, dim3(grid), dim3(kBlock), 0, s,
-                     reinterpret_cast<const float2 *>(d_dist), n_rows, slope, x_max, y_max,
-                     inclusive, d_mask, n_words);
+  if ((reinterpret_cast<uintptr_t>(d_dist) & 15) == 0) {
+    const unsigned grid = grid_for((n_words + 1) / 2, kBlock / 64, 4096);
+    hipLaunchKernelGGL(mask_from_dist_kernel_x2, dim3(grid), dim3(kBlock), 0, s,
+                       reinterpret_cast<const f32x4 *>(d_dist), n_rows, slope, x_max, y_max,
+                       inclusive, d_mask, n_words);
+  } else {
+    const unsigned grid = grid_for(n_words, kBlock / 64, 4096);
+    hipLaunchKernelGGL(mask_from_dist_kernel, dim3(grid), dim3(kBlock), 0, s,
+                       reinterpret_cast<const float2 *>(d_dist), n_rows, slope, x_max, y_max,
+                       inclusive, d_mask, n_words);
+  }
   PPK_HIP(hipGetLastError());
   return PPK_OK;
 }

@@ -538,17 +538,6 @@ dist_kernel(const uint64_t *__restrict__ refT, const uint32_t *__restrict__ qryT
 #define PPK_LPTR(p) ((__attribute__((address_space(3))) void *)(p))
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-// spread the 32 bits of x to the even bit positions of a 64-bit word (wave-uniform: SALU)
-__device__ __forceinline__ uint64_t spread_even(uint32_t v) {
-  uint64_t x = v;
-  x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
-  x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
-  x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
-  x = (x | (x << 2)) & 0x3333333333333333ull;
-  x = (x | (x << 1)) & 0x5555555555555555ull;
-  return x;
-}
-
 constexpr int V2_R = 4, V2_TQ = 4, V2_RT = 256, V2_BB = 14;
 
 // Non-empty tiles of ref tiles 0 .. r-1, in ref-tile-major order.  Rectangle: every ref tile pairs

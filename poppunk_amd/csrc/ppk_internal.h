@@ -93,6 +93,17 @@ enum { SLOT_LUT = 0, SLOT_MASK = 1, SLOT_WS = 2, SLOT_ITER_A = 3, SLOT_ITER_B = 
        SLOT_COUNT = 6 };
 int ppk_scratch_get(int dev, int slot, size_t bytes, void **out);
 
+// spread the 32 bits of x to the even bit positions of a 64-bit word (wave-uniform: SALU)
+__device__ __forceinline__ uint64_t spread_even(uint32_t v) {
+  uint64_t x = v;
+  x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+  x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+  x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+  x = (x | (x << 2)) & 0x3333333333333333ull;
+  x = (x | (x << 1)) & 0x5555555555555555ull;
+  return x;
+}
+
 // line_dist of src/boundary.cpp:42-58: float32, un-fused, evaluated as
 // ((y0*x_max) + (x0*y_max)) - (x_max*y_max)  (SURVEY.md Appendix B).
 __device__ __forceinline__ float ppk_line_dist(float x0, float y0, float x_max, float y_max,
