@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Randomised differential campaign, GPU path vs the CPU oracle, wider than the test-suite:
+random n / split / bands, nk 2..8, sketchsize64 1..40, bbits in {14 (v2 kernel), 8, 16 (generic
+kernel)}, multi-cluster random tables, mixed related / unrelated data, counts / jaccard / distance /
+fused-edge modes.  Prints one line per case and a summary; exits non-zero on any mismatch.
+
+    gpurun -- python tools/soak.py [n_cases] [seed]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402,F401
+
+from oracle import oracle  # noqa: E402
+from poppunk_amd import engine, pp_sketchlib, synth  # noqa: E402
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.Generator(np.random.PCG64(seed))
+    bad = 0
+    t_start = time.time()
+    for case in range(n_cases):
+        bbits = int(rng.choice([14, 14, 14, 8, 16]))
+        s64 = int(rng.choice([1, 2, 3, 16, 16, 16, 5, 40]))
+        nk = int(rng.integers(2, 9))
+        k0 = int(rng.integers(9, 16))
+        kmers = (k0 + np.arange(nk) * int(rng.integers(1, 5))).astype(np.int32)
+        n = int(rng.integers(2, 1400 if s64 <= 16 else 500))
+        if os.environ.get("SOAK_BIG"):        # many ref tiles: the default-shape kernel at scale
+            bbits, s64 = 14, 16
+            n = int(rng.integers(2000, 7000))
+        related = bool(rng.integers(0, 4))
+        sk, member = synth.make_sketches(n, kmers, sketchsize64=s64, bbits=bbits,
+                                         cluster_size=int(rng.integers(5, 80)), seed=int(rng.integers(1, 1 << 30)),
+                                         related=related)
+        n_clu = int(rng.choice([1, 1, 2, 3]))
+        tbl = (rng.random((nk, n_clu, n_clu)) * 0.05).astype(np.float32)
+        clu = (rng.integers(0, n_clu, size=n)).astype(np.uint16)
+        use_tbl = bool(rng.integers(0, 4))
+        nr = int(rng.integers(1, n)) if n > 2 and rng.integers(0, 2) else n
+        ref, qry = sk[:nr], (sk[nr:] if nr < n else None)
+        rclu, qclu = clu[:nr], (clu[nr:] if nr < n else None)
+        kw = dict(random_table=tbl if use_tbl else None, ref_clusters=rclu if use_tbl else None,
+                  qry_clusters=qclu if (use_tbl and qry is not None) else None, random_correct=use_tbl)
+        okw = dict(random_tbl=tbl if use_tbl else None, ref_clu=rclu if use_tbl else None,
+                   qry_clu=qclu if (use_tbl and qry is not None) else None, random_correct=use_tbl, threads=8)
+        msgs = []
+        try:
+            c, _ = pp_sketchlib.query_arrays(ref, qry, kmers, s64, bbits, counts=True)
+            if not np.array_equal(c, oracle.match_counts(ref, qry, s64, bbits, threads=8)):
+                msgs.append("counts differ")
+            got, gf = pp_sketchlib.query_arrays(ref, qry, kmers, s64, bbits, **kw)
+            want, wf = oracle.query(ref, qry, kmers, s64, bbits, **okw)
+            err = float(np.abs(got - want).max(initial=0))
+            if gf != wf or not err <= 1e-6:
+                msgs.append("dist: failed %d vs %d, max err %.3g" % (gf, wf, err))
+            gj, _ = pp_sketchlib.query_arrays(ref, qry, kmers, s64, bbits, jaccard=True, **kw)
+            wj, _ = oracle.query(ref, qry, kmers, s64, bbits, jaccard=True, **okw)
+            if not np.abs(gj - wj).max(initial=0) <= 1e-6:
+                msgs.append("jaccard differs")
+            # bands + fused edges on the resident path
+            db = engine.SketchDB(ref, s64, bbits, clusters=rclu if use_tbl else None)
+            dbq = engine.SketchDB(qry, s64, bbits, clusters=qclu if use_tbl else None) if qry is not None else None
+            nq = qry.shape[0] if qry is not None else nr
+            cuts = sorted(set([0, nq] + [int(x) for x in rng.integers(0, nq + 1, size=3)]))
+            t_tbl = tbl if use_tbl else None
+            parts = [engine.dist(db, dbq, kmers, t_tbl, random_correct=use_tbl, q_begin=a, q_end=b)[0]
+                     for a, b in zip(cuts[:-1], cuts[1:])]
+            whole = torch.cat(parts).cpu().numpy() if parts else np.zeros((0, 2), np.float32)
+            if not np.abs(whole - want).max(initial=0) <= 1e-6:
+                msgs.append("bands differ")
+            if want.shape[0]:
+                slope = int(rng.integers(0, 3))
+                x_max, y_max = synth.boundary_for_quantile(got, float(rng.uniform(0.05, 0.7)))
+                inclusive = bool(rng.integers(0, 2))
+                scale = (float(rng.uniform(0.5, 2.0)), float(rng.uniform(0.5, 2.0)))
+                scaled = (got / np.asarray(scale, dtype=np.float32)).astype(np.float32)
+                we = oracle.edge_threshold(scaled, slope, x_max, y_max, n_ref=0 if qry is None else nr,
+                                           inclusive=inclusive)
+                fe = [engine.dist_edges(db, dbq, kmers, t_tbl, random_correct=use_tbl, slope=slope, x_max=x_max,
+                                        y_max=y_max, scale=scale, inclusive=inclusive, q_begin=a, q_end=b, cap=16)[0]
+                      for a, b in zip(cuts[:-1], cuts[1:])]
+                fe = torch.cat(fe).cpu().numpy()
+                if not np.array_equal(fe, np.asarray(we).reshape(-1, 2)):
+                    msgs.append("fused edges differ (%d vs %d)" % (len(fe), len(we)))
+            db.close()
+            if dbq is not None:
+                dbq.close()
+        except Exception as e:  # noqa: BLE001
+            msgs.append("EXCEPTION %r" % (e,))
+        status = "ok" if not msgs else "MISMATCH: " + "; ".join(msgs)
+        bad += bool(msgs)
+        print("case %3d bbits=%2d s64=%2d nk=%d n=%4d nr=%4d clu=%d tbl=%d related=%d  %s"
+              % (case, bbits, s64, nk, n, nr, n_clu, use_tbl, related, status), flush=True)
+    print("%d cases, %d mismatches, %.0f s" % (n_cases, bad, time.time() - t_start))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
