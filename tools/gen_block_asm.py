@@ -56,7 +56,7 @@ REF_PLANE_BYTES = 2048      # 256 samples x 8 B
 REF_HALF_BYTES = 1024
 
 
-def gen(QRY_PLANE_BYTES, TQ=4):
+def gen(QRY_PLANE_BYTES, TQ=4, dma_planes=None):
     """TQ = 4: counters %[c0]..%[c15], one per pair (p = 4r + q).
     TQ = 8: counters %[c0]..%[c15], two pairs per counter (pair p = 8r + q -> counter p >> 1,
     16-bit half p & 1; a block adds at most 64 and a k at most 16 * 64 per pair ... callers
@@ -67,6 +67,28 @@ def gen(QRY_PLANE_BYTES, TQ=4):
     NS = TQ // 2                 # ds_read_b128 per query plane
     out = []
     emit = out.append
+
+    def dma(t):
+        """LDS-DMA piece t of the NEXT block, issued from inside the compare stream (a VALU-only
+        stretch: the piece costs the issuing wave far fewer cycles there than next to the block's
+        opening burst of ds_reads).  Operands: %[m00] / %[m03] LDS byte address of piece 0 / 3
+        (pieces 1, 2 are 8 KB apart), %[sb0..3] 64-bit global base of each piece, %[voa] / %[vob]
+        per-lane byte offset of pieces 0-2 / 3, %[xblo],%[xbhi] exec mask of piece 3 (the last query
+        piece has fewer rows).  After the last block the caller lets the pieces re-load that block."""
+        if t == 0:
+            emit("s_mov_b32 m0, %[m00]")
+        elif t < 3:
+            emit("s_add_u32 m0, %%[m00], %d" % (8192 * t))
+        else:
+            emit("s_mov_b32 m0, %[m03]")
+        if t == 3:      # (a 64-bit "s" operand is not reliably kept in SGPRs by the compiler: halves)
+            emit("s_mov_b32 exec_lo, %[xblo]")
+            emit("s_mov_b32 exec_hi, %[xbhi]")
+        else:
+            emit("s_nop 0")     # m0 write -> LDS-DMA needs one wait state
+        emit("global_load_lds_dwordx4 %%[%s], %%[sb%d]" % ("voa" if t < 3 else "vob", t))
+        if t == 3:
+            emit("s_mov_b64 exec, -1")
 
     def load_s(plane):
         base = S0 if (plane & 1) == 0 else S1
@@ -82,6 +104,8 @@ def gen(QRY_PLANE_BYTES, TQ=4):
 
     def ops(plane, rs):
         for r in rs:
+            if dma_planes and r == 3 and plane in dma_planes:
+                dma(dma_planes.index(plane))
             for q in range(TQ):
                 for hi in (0, 1):
                     acc = hi_acc(r, q) if hi else lo_acc(r, q)
@@ -147,6 +171,13 @@ def main():
                 f.write('  "%s\\n" \\\n' % ln)
             f.write("  \"\"\n")
             print("wrote", name, len(lines), "instructions")
+        lines = gen(256, 4, dma_planes=[1, 4, 7, 10])
+        f.write("// the same with the 4 LDS-DMA pieces of the next block issued inside the stream\n")
+        f.write("#define PPK_BLOCK_DMA_ASM_Q32 \\\n")
+        for ln in lines:
+            f.write('  "%s\\n" \\\n' % ln)
+        f.write("  \"\"\n")
+        print("wrote PPK_BLOCK_DMA_ASM_Q32", len(lines), "instructions")
         f.write("#define PPK_BLOCK_ASM PPK_BLOCK_ASM_Q32\n")
         f.write("#define PPK_BLOCK_CLOBBERS %s\n" % clob)
         f.write("// 4x8 register tile (v%d..v%d): 16 counters, two 16-bit pair counts each\n" % (m8.A0, m8.END - 1))

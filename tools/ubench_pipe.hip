@@ -94,7 +94,7 @@ pipe(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ qryT, uint3
   __builtin_amdgcn_s_barrier();
   for (int g = 0; g < total; ++g) {
     const int buf = g & 1;
-    if (g + 1 < total && !(FEAT & 1)) issue_dma(buf ^ 1);
+    if (g + 1 < total && !(FEAT & 1) && !(FEAT & 8)) issue_dma(buf ^ 1);
     if (FEAT & 4) {
       if (g + 2 < total) asm volatile("global_load_dword %0, %1, off" : "=v"(pfsink) : "v"(pf) : "memory");
       pf += (size_t)BB * npad * 8;
@@ -107,7 +107,25 @@ pipe(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ qryT, uint3
       [c5] "+v"(c[5]), [c6] "+v"(c[6]), [c7] "+v"(c[7]), [c8] "+v"(c[8]), [c9] "+v"(c[9]),        \
       [c10] "+v"(c[10]), [c11] "+v"(c[11]), [c12] "+v"(c[12]), [c13] "+v"(c[13]), [c14] "+v"(c[14]), \
       [c15] "+v"(c[15])
-    if constexpr (TQ == 4 && QT == 32)
+    if constexpr (TQ == 4 && QT == 32 && (FEAT & 8) != 0) {
+      // the next block's 4 DMA pieces are issued from inside the compare stream
+      const uint32_t lbase = (uint32_t)(size_t)(__attribute__((address_space(3))) void *)(lds + (buf ^ 1) * CHUNK_U4);
+      const uint32_t m00 = __builtin_amdgcn_readfirstlane(lbase + (uint32_t)doff[0] * 16u);
+      const uint32_t m03 = __builtin_amdgcn_readfirstlane(lbase + (uint32_t)doff[3] * 16u);
+      const uint64_t xb = (wave + NW * 3 == NPIECE - 1) ? __ballot(qlane_ok) : ~0ull;
+      const uint32_t xblo = __builtin_amdgcn_readfirstlane((uint32_t)xb), xbhi = __builtin_amdgcn_readfirstlane((uint32_t)(xb >> 32));
+      const uint32_t vob = dkind[3] == 0 ? voff_ref : voff_qry;
+      asm volatile(PPK_BLOCK_DMA_ASM_Q32
+                   : OPS
+                   : [rp] "v"(rp), [qp] "v"(qp), [m00] "s"(m00), [m03] "s"(m03), [sb0] "s"(dbase[0]),
+                     [sb1] "s"(dbase[1]), [sb2] "s"(dbase[2]), [sb3] "s"(dbase[3]), [voa] "v"(voff_ref),
+                     [vob] "v"(vob), [xblo] "s"(xblo), [xbhi] "s"(xbhi)
+                   : "memory", "scc", PPK_BLOCK_CLOBBERS);
+      if (g + 2 < total) {      // after the last block the pieces harmlessly re-load it
+#pragma unroll
+        for (int t = 0; t < PW; ++t) dbase[t] += dstep[t];
+      }
+    } else if constexpr (TQ == 4 && QT == 32)
       asm volatile(PPK_BLOCK_ASM_Q32 : OPS : [rp] "v"(rp), [qp] "v"(qp) : "memory", PPK_BLOCK_CLOBBERS);
     else if constexpr (TQ == 4 && QT == 64)
       asm volatile(PPK_BLOCK_ASM_Q64 : OPS : [rp] "v"(rp), [qp] "v"(qp) : "memory", PPK_BLOCK_CLOBBERS);
@@ -245,6 +263,7 @@ int main() {
     run<8, 4, 4>(in, in, out, "A: 4x4, 8 waves, 2 WG/CU (product)");
     run<8, 4, 4>(in, in2, out, "A2: same, queries from a second array");
     run<8, 4, 4, 4>(in, in, out, "A+L2 prefetch of block g+2");
+    run<8, 4, 4, 8>(in, in, out, "A with DMA issued inside the compare stream");
     run<8, 4, 4, 1>(in, in, out, "A-nodma");
     run<8, 4, 4, 2>(in, in, out, "A+packed u64 counts");
     run<8, 4, 4, 3>(in, in, out, "A+packed, no dma");
