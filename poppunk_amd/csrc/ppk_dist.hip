@@ -30,12 +30,40 @@
 //  * with MODE_MASK the lane applies the boundary instead (src/boundary.cpp:42-58)
 //    and the wavefront's __ballot is stored as one uint64 of an edge bitmask.
 #include <cstdlib>
+#include <type_traits>
 
 #include "ppk_internal.h"
 #include "ppk_block_asm.inc"
 
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned __int128 u128;
+
+// Per-pair shift register of the per-k match counts.  uint64 / u128: count k at bit k * cnt_bits.
+// Pack96: up to six 16-bit counts in three dwords (the default PopPUNK sketch size, s = 9984, needs
+// 14 bits x 5 or 6 k: 48 VGPRs per lane for the 16 pairs instead of the 64 of u128, which spilled).
+struct Pack96 {
+  uint32_t w0, w1, w2;
+};
+template <typename P> __device__ __forceinline__ void pack_zero(P &pk) { pk = 0; }
+__device__ __forceinline__ void pack_zero(Pack96 &pk) { pk.w0 = pk.w1 = pk.w2 = 0u; }
+template <typename P> __device__ __forceinline__ void pack_put(P &pk, uint32_t c, int k, int bits) {
+  pk |= (P)c << (bits * k);
+}
+__device__ __forceinline__ void pack_put(Pack96 &pk, uint32_t c, int k, int) {
+  const uint32_t x = c << (16 * (k & 1));
+  const int j = k >> 1;             // wave-uniform: selects, not indexed registers
+  pk.w0 |= j == 0 ? x : 0u;
+  pk.w1 |= j == 1 ? x : 0u;
+  pk.w2 |= j == 2 ? x : 0u;
+}
+template <typename P> __device__ __forceinline__ uint32_t pack_get(const P &pk, int k, int bits, uint32_t mask) {
+  return (uint32_t)(pk >> (bits * k)) & mask;
+}
+__device__ __forceinline__ uint32_t pack_get(const Pack96 &pk, int k, int, uint32_t) {
+  const int j = k >> 1;
+  const uint32_t w = j == 0 ? pk.w0 : (j == 1 ? pk.w1 : pk.w2);
+  return (w >> (16 * (k & 1))) & 0xffffu;
+}
 
 enum { MODE_DIST = 0, MODE_JACCARD = 1, MODE_COUNTS = 2, MODE_MASK = 3 };
 
@@ -145,7 +173,7 @@ __device__ __forceinline__ void fit_packed(PackT pk, const double *__restrict__ 
   double sy = 0.0, sxy = 0.0;
   bool all_ok = p.nk >= 2;
   for (int k = 0; k < p.nk; ++k) {
-    const uint32_t c = (uint32_t)(pk >> (p.cnt_bits * k)) & cmask;
+    const uint32_t c = pack_get(pk, k, p.cnt_bits, cmask);
     const double y = lutp[(size_t)k * p.lut_kstride + c];
     all_ok = all_ok && (y <= 0.0);
     sy += y;
@@ -164,7 +192,7 @@ __device__ __forceinline__ void fit_packed(PackT pk, const double *__restrict__ 
     int n = 0;
     bool open = true;
     for (int k = 0; k < p.nk; ++k) {
-      const uint32_t c = (uint32_t)(pk >> (p.cnt_bits * k)) & cmask;
+      const uint32_t c = pack_get(pk, k, p.cnt_bits, cmask);
       const double y = lutp[(size_t)k * p.lut_kstride + c];
       open = open && (y <= 0.0);
       if (open) {
@@ -235,7 +263,7 @@ __device__ __forceinline__ void fit_rows(const PackT (&pk)[NR], const double *co
       const int k = (k0 + i < p.nk) ? k0 + i : p.nk - 1;   // wave-uniform; surplus slots re-read the last k
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
-        const uint32_t c = (uint32_t)(pk[r] >> (p.cnt_bits * k)) & cmask;
+        const uint32_t c = pack_get(pk[r], k, p.cnt_bits, cmask);
         y[r][i] = lutp[r][(size_t)k * p.lut_kstride + c];
       }
     }
@@ -287,7 +315,7 @@ __device__ __forceinline__ bool fit_rows_fixed(const PackT (&pk)[NR], const doub
   for (int k = 0; k < NK; ++k) {
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
-      const uint32_t c = (uint32_t)(pk[r] >> (p.cnt_bits * k)) & cmask;
+      const uint32_t c = pack_get(pk[r], k, p.cnt_bits, cmask);
       const uint32_t boff = (loff[r] + (uint32_t)k * kstride + c) * 8u;
       y[r][k] = *reinterpret_cast<const double *>(base + boff);
     }
@@ -351,7 +379,7 @@ dist_kernel(const uint64_t *__restrict__ refT, const uint32_t *__restrict__ qryT
 #pragma unroll
   for (int j = 0; j < TQ; ++j) {
     cnt[j] = 0;
-    packed[j] = 0;
+    pack_zero(packed[j]);
   }
 
   // ---- chunk staging: global -> VGPR (one chunk ahead) -> LDS ----------------
@@ -460,7 +488,7 @@ dist_kernel(const uint64_t *__restrict__ refT, const uint32_t *__restrict__ qryT
 #pragma unroll
         for (int j = 0; j < TQ; ++j) {
           if constexpr (MODE == MODE_DIST || MODE == MODE_MASK) {
-            packed[j] |= (PackT)cnt[j] << (p.cnt_bits * k);
+            pack_put(packed[j], cnt[j], k, p.cnt_bits);
           } else {
             const size_t q = qw0 + j;
             const bool valid = r < p.n_ref && q >= p.q_begin && q < p.q_end && (!p.self || r > q);
@@ -699,7 +727,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
 #pragma unroll
     for (int q = 0; q < TQ; ++q) {
       cnt[r][q] = 0;
-      packed[r][q] = 0;
+      pack_zero(packed[r][q]);
     }
 
   issue_dma(0);
@@ -740,7 +768,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
 #pragma unroll
           for (int q = 0; q < TQ; ++q) {
             if constexpr (MODE == MODE_DIST || MODE == MODE_MASK) {
-              packed[r][q] |= (PackT)cnt[r][q] << (p.cnt_bits * k);
+              pack_put(packed[r][q], cnt[r][q], k, p.cnt_bits);
             } else {
               const size_t qq = qw0 + q, rf = ref_of(r);
               const bool valid = rf < p.r_limit && qq >= qb && qq < qe && (!p.self || rf > qq);
@@ -1057,7 +1085,7 @@ int launch_tiles(const ppk_db *ref, const ppk_db *qry, const double *d_lut, cons
     return launch_variant<8, 4, 0, MODE, PackT>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask,
                                                 p, s, "dist_kernel<8,4,generic>");
   // v1 tiles are kept for A/B measurements of the plain distance mode only
-  if constexpr (MODE == MODE_DIST && sizeof(PackT) == 8) {
+  if constexpr (MODE == MODE_DIST && std::is_same<PackT, uint64_t>::value) {
     if (g_tile_tq == 16 && g_tile_nw == 4)
       return launch_variant<16, 4, 14, MODE, PackT>(ref, qry, d_lut, d_rtab, d_out, d_n_failed,
                                                     d_mask, p, s, "dist_kernel<16,4,14>");
@@ -1068,7 +1096,7 @@ int launch_tiles(const ppk_db *ref, const ppk_db *qry, const double *d_lut, cons
       return launch_variant<8, 4, 14, MODE, PackT>(ref, qry, d_lut, d_rtab, d_out, d_n_failed,
                                                    d_mask, p, s, "dist_kernel<8,4,14>");
   }
-  if constexpr (MODE == MODE_DIST && sizeof(PackT) == 8) {
+  if constexpr (MODE == MODE_DIST && std::is_same<PackT, uint64_t>::value) {
     if (g_tile_tq == 4 && g_tile_nw == 16)   // experiment: 16-wavefront workgroups
       return launch_v2<16, MODE, PackT>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
   }
@@ -1183,10 +1211,13 @@ int ppk_launch_dist(const ppk_db *ref, const ppk_db *qry_or_null, const int32_t 
     PPK_HIP(hipGetLastError());
   }
   const bool wide = p.nk * p.cnt_bits > 64;
+  const bool mid = wide && p.nk <= 6 && p.cnt_bits <= 16;     // three dwords of 16-bit counts
   if (d_mask) {
+    if (mid) return launch_tiles<MODE_MASK, Pack96>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
     return wide ? launch_tiles<MODE_MASK, u128>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s)
                 : launch_tiles<MODE_MASK, uint64_t>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
   }
+  if (mid) return launch_tiles<MODE_DIST, Pack96>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
   return wide ? launch_tiles<MODE_DIST, u128>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s)
               : launch_tiles<MODE_DIST, uint64_t>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
 }
