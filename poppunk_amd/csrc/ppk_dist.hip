@@ -571,18 +571,22 @@ constexpr int V2_R = 4, V2_TQ = 4, V2_RT = 256, V2_BB = 14;
 // Non-empty tiles of ref tiles 0 .. r-1, in ref-tile-major order.  Rectangle: every ref tile pairs
 // with all q_tiles query tiles.  Triangle (self): ref tile i has a pair with r > q only for the
 // first clamp(m*i + c0, 0, q_tiles) query tiles (m = 256 / queries-per-tile).
-__host__ __device__ inline unsigned tiles_before(unsigned r, int self, unsigned q_tiles, int m, int c0) {
-  if (!self) return r * q_tiles;
+__host__ __device__ inline unsigned long long tiles_before64(unsigned r, int self, unsigned q_tiles, int m, int c0) {
+  if (!self) return (unsigned long long)r * q_tiles;
   // i_lo: first ref tile with any query tile; i_hi: first with all of them
-  const int i_lo = c0 > 0 ? 0 : (-c0) / m + 1;
-  int i_hi = ((int)q_tiles - c0 + m - 1) / m;
+  const long long i_lo = c0 > 0 ? 0 : (-c0) / m + 1;
+  long long i_hi = ((long long)q_tiles - c0 + m - 1) / m;
   if (i_hi < i_lo) i_hi = i_lo;
-  const int rr = (int)r;
-  const int b = rr < i_hi ? rr : i_hi;
-  unsigned t = 0;
-  if (b > i_lo) t = (unsigned)((m * (b * (b - 1) - i_lo * (i_lo - 1))) / 2 + c0 * (b - i_lo));
-  if (rr > i_hi) t += (unsigned)(rr - i_hi) * q_tiles;
+  const long long rr = (long long)r;
+  const long long b = rr < i_hi ? rr : i_hi;
+  unsigned long long t = 0;
+  if (b > i_lo) t = (unsigned long long)((m * (b * (b - 1) - i_lo * (i_lo - 1))) / 2 + c0 * (b - i_lo));
+  if (rr > i_hi) t += (unsigned long long)(rr - i_hi) * q_tiles;
   return t;
+}
+// (the grid is limited to 2^31 blocks, checked by the launcher, so 32 bits hold every count on the device)
+__host__ __device__ inline unsigned tiles_before(unsigned r, int self, unsigned q_tiles, int m, int c0) {
+  return (unsigned)tiles_before64(r, self, q_tiles, m, c0);
 }
 
 // NW = wavefronts per workgroup: 8 (256 x 32 tile, 2 workgroups per CU) or 16 (256 x 64 tile,
@@ -1057,7 +1061,9 @@ int launch_v2(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const f
   p.n_strip_pad = (p.n_strip + 7u) & ~7u;
   p.tri_m = V2_RT / V2_QT;
   p.tri_c0 = p.tri_m - (int)p.q_tile0;
-  p.n_tiles = r_tiles ? tiles_before(p.r_tiles, p.self, p.q_tiles, p.tri_m, p.tri_c0) : 0;
+  const unsigned long long n_tiles64 = r_tiles ? tiles_before64(p.r_tiles, p.self, p.q_tiles, p.tri_m, p.tri_c0) : 0;
+  if (n_tiles64 > 0x7ffffff0ull) return ppk_fail(PPK_ERR_ARG, "tile grid too large for one launch: split the query band");
+  p.n_tiles = (unsigned)n_tiles64;
   p.tiles_per_xcd = (p.n_tiles + 7u) / 8u;
   // A/B orders: 1 = XCD-owned interleaved streams (each as long as the busiest XCD's list),
   // 2 = plain (ref tile fastest, skewed for the self job)
