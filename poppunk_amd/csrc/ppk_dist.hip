@@ -92,6 +92,7 @@ struct DistParams {
   size_t r_limit;         // triangle part: lane samples >= r_limit are left to the strip
   int xcd_map;            // 1: XCD-aware tile order (v2)
   int lut32;              // the whole log-J table is addressable with 32-bit byte offsets
+  int k_split;            // MODE_COUNTS only: gridDim.y = nk, each workgroup counts ONE k (small jobs)
   unsigned r_tiles, q_tiles;   // v2 tile grid
   unsigned n_strip_pad;        // n_strip rounded up to a multiple of 8 (keeps block % 8 = XCD for the rest)
   unsigned n_tiles;            // non-empty tiles of the triangle / rectangle part
@@ -676,7 +677,9 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
   // (recomputed where needed rather than kept live across the compare loop)
   auto ref_of = [&](int r) -> size_t { return r0 + 2 * lane + (r & 1) + (r >> 1) * 128; };
 
-  const int total = p.nk * p.s64;             // one chunk per (k, 64-bin block)
+  // one chunk per (k, 64-bin block); with k_split a workgroup owns the chunks of k = blockIdx.y only
+  const int k_first = p.k_split ? (int)blockIdx.y : 0;
+  const int total = (p.k_split ? 1 : p.nk) * p.s64;
 
   // DMA sources: each wavefront copies PW of the chunk's one-KB pieces (28 ref pieces: row i/2,
   // half i%2; then the query pieces: PPP rows x LPP lanes each).  A piece's address is a
@@ -694,13 +697,13 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
     doff[t] = 0;
     if (i < 2 * BB) {
       dkind[t] = 0;
-      dbase[t] = reinterpret_cast<const char *>(refT + (size_t)(i >> 1) * p.npad_r + r0 + (i & 1) * 128);
+      dbase[t] = reinterpret_cast<const char *>(refT + ((size_t)k_first * p.s64 * BB + (size_t)(i >> 1)) * p.npad_r + r0 + (i & 1) * 128);
       dstep[t] = (size_t)BB * p.npad_r * 8;
       doff[t] = i * 64;
     } else if (i < NPIECE) {
       const int j = i - 2 * BB;
       dkind[t] = 1;
-      dbase[t] = reinterpret_cast<const char *>(qryT + (size_t)(PPP * j) * p.npad_q + q0);
+      dbase[t] = reinterpret_cast<const char *>(qryT + ((size_t)k_first * p.s64 * BB + (size_t)(PPP * j)) * p.npad_q + q0);
       dstep[t] = (size_t)BB * p.npad_q * 8;
       doff[t] = REF_U4 + j * 64;
     } else {
@@ -738,7 +741,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
-  int k = 0, blk = 0;
+  int k = k_first, blk = 0;
   for (int g = 0; g < total; ++g) {
     const int buf = g & 1;
     // the other buffer was last read in iteration g-1, which every wave left through the barrier
@@ -1074,7 +1077,8 @@ int launch_v2(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const f
   if (n_blocks > 0x7fffffffull) return ppk_fail(PPK_ERR_ARG, "tile grid too large for one launch");
   ppk_set_kernel_name(NW == 8 ? "dist_kernel_v2<256x32,lds-dma>" : "dist_kernel_v2<256x64,lds-dma>");
   ppk_prof_begin(s);
-  hipLaunchKernelGGL((dist_kernel_v2<NW, MODE, PackT>), dim3((unsigned)n_blocks),
+  if (MODE != MODE_COUNTS) p.k_split = 0;
+  hipLaunchKernelGGL((dist_kernel_v2<NW, MODE, PackT>), dim3((unsigned)n_blocks, p.k_split ? (unsigned)p.nk : 1u),
                      dim3(NW * 64), 0, s, ref->d_skT, qry->d_skT, d_lut,
                      use_clu ? ref->d_clu : nullptr, use_clu ? qry->d_clu : nullptr, d_rtab, d_out,
                      d_n_failed, d_mask, p);
@@ -1186,8 +1190,21 @@ int ppk_launch_dist(const ppk_db *ref, const ppk_db *qry_or_null, const int32_t 
   if (want_jac)
     return launch_tiles<MODE_JACCARD, uint64_t>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
 
-  if (p.nk > PPK_MAX_NK || p.nk * p.cnt_bits > 128) {
-    // the packed per-pair state does not fit: raw counts to scratch, then a generic regression pass
+  const bool too_wide = p.nk > PPK_MAX_NK || p.nk * p.cnt_bits > 128;
+  // Small jobs (fewer pair tiles than ~2/3 of the 512 workgroup slots, e.g. 1 000 genomes or a handful
+  // of queries): one workgroup per (tile, k) instead of per tile -- nk times the parallelism, a
+  // serial chain of s64 blocks instead of nk * s64 -- writing raw counts, then the regression pass.
+  bool small = false;
+  if (!too_wide && !d_mask && p.bbits == 14 && p.nk >= 2) {
+    const size_t rt = (ref->n + V2_RT - 1) / V2_RT, qt = (q_end - q_begin + 31) / 32;
+    size_t limit = 352;   // measured: 2 000 self (315 tiles) 230 vs 260 us, 2 500 self (480 tiles) 329 vs 264 us
+    if (const char *e = getenv("PPK_KSPLIT")) limit = (size_t)atoi(e);   // A/B: tile-count threshold, 0 = off
+    small = (p.self ? rt * qt / 2 + qt : rt * qt) <= limit;
+  }
+  if (too_wide || small) {
+    // (too_wide: the packed per-pair state does not fit) raw counts to scratch, then a generic
+    // regression pass
+    p.k_split = small ? 1 : 0;
     int dev = ref->device;
     const size_t rows = p.self ? (q_end * ref->n - (q_end * (q_end + 1)) / 2) - p.row_base
                                : (q_end - q_begin) * ref->n;
