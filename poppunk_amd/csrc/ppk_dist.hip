@@ -165,62 +165,6 @@ lut_kernel(double *__restrict__ lut, const float *__restrict__ rtab, int nk, int
 
 // ---- the pair-tile kernel ----------------------------------------------------
 
-template <typename PackT>
-__device__ __forceinline__ void fit_packed(PackT pk, const double *__restrict__ lutp,
-                                           const DistParams &p, float &core, float &acc,
-                                           bool &failed) {
-  // a6: OLS of log J on k over the leading run of usable points, fp64.
-  const uint32_t cmask = (1u << p.cnt_bits) - 1u;
-  double sy = 0.0, sxy = 0.0;
-  bool all_ok = p.nk >= 2;
-  for (int k = 0; k < p.nk; ++k) {
-    const uint32_t c = pack_get(pk, k, p.cnt_bits, cmask);
-    const double y = lutp[(size_t)k * p.lut_kstride + c];
-    all_ok = all_ok && (y <= 0.0);
-    sy += y;
-    sxy += (double)p.kmers[k] * y;
-  }
-  double slope, icpt;
-  if (__all(all_ok)) {
-    // every k usable in every lane of the wavefront (the overwhelmingly common case):
-    // the k-only sums are launch constants
-    slope = ((double)p.nk * sxy - p.sx_all * sy) * p.inv_den_all;
-    icpt = (sy - slope * p.sx_all) * p.inv_n_all;
-  } else {
-    double sx = 0.0, sxx = 0.0;
-    sy = 0.0;
-    sxy = 0.0;
-    int n = 0;
-    bool open = true;
-    for (int k = 0; k < p.nk; ++k) {
-      const uint32_t c = pack_get(pk, k, p.cnt_bits, cmask);
-      const double y = lutp[(size_t)k * p.lut_kstride + c];
-      open = open && (y <= 0.0);
-      if (open) {
-        const double x = (double)p.kmers[k];
-        sx += x;
-        sxx += x * x;
-        sy += y;
-        sxy += x * y;
-        ++n;
-      }
-    }
-    if (n < 2) {
-      core = 0.0f;
-      acc = 0.0f;
-      failed = true;
-      return;
-    }
-    const double dn = (double)n;
-    slope = (dn * sxy - sx * sy) / (dn * sxx - sx * sx);
-    icpt = (sy - slope * sx) / dn;
-  }
-  core = slope < 0.0 ? (float)(1.0 - exp(slope)) : 0.0f;
-  acc = icpt < 0.0 ? (float)(1.0 - exp(icpt)) : 0.0f;
-  failed = false;
-}
-
-
 // e^x for x <= 0 (the fitted slope / intercept), fp64: n = rint(x log2 e), r = x - n ln 2 in two
 // parts, degree-11 Taylor polynomial on |r| <= 0.347 (truncation 6e-15 relative), scaled by 2^n.
 // A third of the instructions of the library exp (no overflow / NaN / +x handling needed here);
@@ -242,6 +186,51 @@ __device__ __forceinline__ double exp_nonpos(double x) {
   q = __builtin_fma(q, r, 1.0);
   q = __builtin_fma(q, r, 1.0);
   return __builtin_ldexp(q, (int)n);
+}
+
+// a6 for one pair: OLS of log J on k over the leading run of usable points, fp64.  Every caller
+// (the tile epilogues' fast paths included) evaluates the SAME expressions in the same order, so a
+// pair's result does not depend on which kernel, tile, band or wavefront computed it: sums in k
+// order with sxy as an fma; when every k is usable the k-only sums are the launch constants.
+template <typename PackT>
+__device__ __forceinline__ void fit_packed(PackT pk, const double *__restrict__ lutp,
+                                           const DistParams &p, float &core, float &acc,
+                                           bool &failed) {
+  const uint32_t cmask = (1u << p.cnt_bits) - 1u;
+  double sx = 0.0, sxx = 0.0, sy = 0.0, sxy = 0.0;
+  int n = 0;
+  bool open = true;
+  for (int k = 0; k < p.nk; ++k) {
+    const uint32_t c = pack_get(pk, k, p.cnt_bits, cmask);
+    const double y = lutp[(size_t)k * p.lut_kstride + c];
+    open = open && (y <= 0.0);
+    if (open) {
+      const double x = (double)p.kmers[k];
+      sx += x;
+      sxx += x * x;
+      sy += y;
+      sxy = __builtin_fma(x, y, sxy);
+      ++n;
+    }
+  }
+  if (n < 2) {
+    core = 0.0f;
+    acc = 0.0f;
+    failed = true;
+    return;
+  }
+  double slope, icpt;
+  if (n == p.nk) {
+    slope = ((double)p.nk * sxy - p.sx_all * sy) * p.inv_den_all;
+    icpt = (sy - slope * p.sx_all) * p.inv_n_all;
+  } else {
+    const double dn = (double)n;
+    slope = (dn * sxy - sx * sy) / (dn * sxx - sx * sx);
+    icpt = (sy - slope * sx) / dn;
+  }
+  core = slope < 0.0 ? (float)(1.0 - exp_nonpos(slope)) : 0.0f;
+  acc = icpt < 0.0 ? (float)(1.0 - exp_nonpos(icpt)) : 0.0f;
+  failed = false;
 }
 
 // a6 for NR of the refs a lane holds against one query (v2 epilogue).  All NR x nk table gathers
@@ -989,6 +978,46 @@ regress_counts_kernel(const uint32_t *__restrict__ counts, size_t n_rows, size_t
   }
 }
 
+// ---- k-split jobs: counts -> distances with the SAME fit as the tile epilogue -------------------
+__global__ void __launch_bounds__(256)
+regress_packed_kernel(const uint32_t *__restrict__ counts, size_t n_rows, const double *__restrict__ lut,
+                      const uint16_t *__restrict__ ref_clu, const uint16_t *__restrict__ qry_clu,
+                      float2 *__restrict__ out, unsigned long long *__restrict__ n_failed,
+                      const DistParams p) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  bool failed = false;
+  if (i < n_rows) {
+    size_t cp = 0;
+    if (p.n_clu > 1 && ref_clu) {
+      const size_t row = p.row_base + i, n_ref = p.n_ref;
+      size_t q, r;
+      if (p.self) {
+        // condensed row -> (q, r): largest q with q*n - q(q+1)/2 <= row
+        const double d = sqrt((double)(4 * n_ref * (n_ref - 1)) - 8.0 * (double)row - 7.0);
+        long long qi = (long long)n_ref - 2 - (long long)floor(d / 2.0 - 0.5);
+        if (qi < 0) qi = 0;
+        while (qi > 0 && (size_t)qi * n_ref - ((size_t)qi * ((size_t)qi + 1)) / 2 > row) --qi;
+        while ((size_t)(qi + 1) * n_ref - ((size_t)(qi + 1) * ((size_t)qi + 2)) / 2 <= row) ++qi;
+        q = (size_t)qi;
+        r = row - (q * n_ref - (q * (q + 1)) / 2) + q + 1;
+      } else {
+        q = row / n_ref;
+        r = row % n_ref;
+      }
+      cp = (size_t)ref_clu[r] * p.n_clu + (qry_clu ? qry_clu[q] : 0);
+    }
+    u128 pk = 0;
+    for (int k = 0; k < p.nk; ++k) pk |= (u128)counts[i * p.nk + k] << (p.cnt_bits * k);
+    float core, acc;
+    fit_packed<u128>(pk, lut + cp * p.lut_cpstride, p, core, acc, failed);
+    out[i] = make_float2(core, acc);
+  }
+  if (n_failed) {
+    const uint64_t fm = __ballot(failed);
+    if (fm && (threadIdx.x & 63) == 0) atomicAdd(n_failed, (unsigned long long)__popcll(fm));
+  }
+}
+
 // ---- host-side launch ------------------------------------------------------
 
 namespace {
@@ -1201,10 +1230,8 @@ int ppk_launch_dist(const ppk_db *ref, const ppk_db *qry_or_null, const int32_t 
     if (const char *e = getenv("PPK_KSPLIT")) limit = (size_t)atoi(e);   // A/B: tile-count threshold, 0 = off
     small = (p.self ? rt * qt / 2 + qt : rt * qt) <= limit;
   }
-  if (too_wide || small) {
-    // (too_wide: the packed per-pair state does not fit) raw counts to scratch, then a generic
-    // regression pass
-    p.k_split = small ? 1 : 0;
+  if (too_wide) {
+    // the packed per-pair state does not fit: raw counts to scratch, then a generic regression pass
     int dev = ref->device;
     const size_t rows = p.self ? (q_end * ref->n - (q_end * (q_end + 1)) / 2) - p.row_base
                                : (q_end - q_begin) * ref->n;
@@ -1232,6 +1259,23 @@ int ppk_launch_dist(const ppk_db *ref, const ppk_db *qry_or_null, const int32_t 
     hipLaunchKernelGGL(lut_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_lut,
                        d_rtab, p.nk, p.n_clu, nbins, ref->s64, ref->bbits, p.random_correct, total);
     PPK_HIP(hipGetLastError());
+  }
+  if (small) {
+    // one workgroup per (tile, k) -> raw counts; then the same per-pair fit as the tile epilogue
+    const size_t rows = p.self ? (q_end * ref->n - (q_end * (q_end + 1)) / 2) - p.row_base
+                               : (q_end - q_begin) * ref->n;
+    void *p_cnt = nullptr;
+    int rc = ppk_scratch_get(ref->device, SLOT_ITER_A, rows * (size_t)p.nk * 4 + 256, &p_cnt);
+    if (rc != PPK_OK) return rc;
+    p.k_split = 1;
+    rc = launch_tiles<MODE_COUNTS, uint64_t>(ref, qry, d_lut, d_rtab, p_cnt, nullptr, nullptr, p, s);
+    if (rc != PPK_OK) return rc;
+    const bool use_clu = p.random_correct && p.n_clu > 1;
+    hipLaunchKernelGGL(regress_packed_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s,
+                       static_cast<const uint32_t *>(p_cnt), rows, d_lut, use_clu ? ref->d_clu : nullptr,
+                       use_clu ? qry->d_clu : nullptr, static_cast<float2 *>(d_out), d_n_failed, p);
+    PPK_HIP(hipGetLastError());
+    return PPK_OK;
   }
   const bool wide = p.nk * p.cnt_bits > 64;
   const bool mid = wide && p.nk <= 6 && p.cnt_bits <= 16;     // three dwords of 16-bit counts

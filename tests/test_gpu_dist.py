@@ -373,3 +373,32 @@ def test_many_kmer_lengths_counts_fallback(s64, kstep):
     with pytest.raises(RuntimeError, match="band"):
         engine.dist_edges(db, None, kmers, tbl, slope=2, x_max=x_max, y_max=y_max, q_begin=0, q_end=n // 2)
     db.close()
+
+
+def test_small_job_k_split_is_bit_identical_to_the_tile_epilogue(monkeypatch):
+    """Below ~350 pair tiles kernel 1 runs one workgroup per (tile, k) and a separate regression
+    pass (DESIGN.md 3.1 'Small jobs'); every pair must come out bit for bit as from the fused tile
+    epilogue (same expressions in the same order: a result never depends on the job's shape)."""
+    import torch
+    from poppunk_amd import engine
+    kmers = np.asarray(synth.DEFAULT_KMERS, dtype=np.int32)
+    tbl3 = (np.random.Generator(np.random.PCG64(9)).random((5, 3, 3)) * 0.04).astype(np.float32)
+    sk, member = synth.make_sketches(900, kmers, cluster_size=40, seed=123, related=False)  # failing fits too
+    clu = (member % 3).astype(np.uint16)
+    for table, clusters in ((synth.random_match_table(kmers), None), (tbl3, clu)):
+        db = engine.SketchDB(sk[:700], 16, 14, clusters=None if clusters is None else clusters[:700])
+        dq = engine.SketchDB(sk[700:], 16, 14, clusters=None if clusters is None else clusters[700:])
+        res = {}
+        for mode in ("0", "100000"):
+            monkeypatch.setenv("PPK_KSPLIT", mode)
+            a, fa = engine.dist(db, None, kmers, table)
+            b, fb = engine.dist(db, dq, kmers, table, q_begin=3, q_end=150)
+            res[mode] = (a.clone(), fa, b.clone(), fb)
+        monkeypatch.delenv("PPK_KSPLIT")
+        assert res["0"][1] == res["100000"][1] and res["0"][3] == res["100000"][3]
+        assert torch.equal(res["0"][0], res["100000"][0]) and torch.equal(res["0"][2], res["100000"][2])
+        want, wf = oracle.query(sk[:700], None, kmers, 16, 14, table,
+                                ref_clu=None if clusters is None else clusters[:700], threads=4)
+        assert res["0"][1] == wf and np.abs(res["0"][0].cpu().numpy() - want).max() <= 1e-6
+        db.close()
+        dq.close()
