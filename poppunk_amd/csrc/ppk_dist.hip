@@ -92,7 +92,7 @@ struct DistParams {
   size_t r_limit;         // triangle part: lane samples >= r_limit are left to the strip
   int xcd_map;            // 1: XCD-aware tile order (v2)
   int lut32;              // the whole log-J table is addressable with 32-bit byte offsets
-  int k_split;            // MODE_COUNTS only: gridDim.y = nk, each workgroup counts ONE k (small jobs)
+  int k_split;            // host side only: launch the KSPLIT instantiation (gridDim.y = nk, one k per workgroup)
   unsigned r_tiles, q_tiles;   // v2 tile grid
   unsigned n_strip_pad;        // n_strip rounded up to a multiple of 8 (keeps block % 8 = XCD for the rest)
   unsigned n_tiles;            // non-empty tiles of the triangle / rectangle part
@@ -283,8 +283,9 @@ __device__ __forceinline__ void fit_rows(const PackT (&pk)[NR], const double *co
     }
     return;
   }
-  // some lane has a k below the 5/nbins floor: the general fit, one pair at a time
-#pragma unroll 1
+  // some lane has a k below the 5/nbins floor: the general fit, one pair at a time (unrolled: a
+  // rolled loop would index the operand arrays dynamically and push them into scratch)
+#pragma unroll
   for (int r = 0; r < NR; ++r) fit_packed<PackT>(pk[r], lutp[r], p, core[r], acc[r], failed[r]);
 }
 
@@ -561,7 +562,7 @@ constexpr int V2_R = 4, V2_TQ = 4, V2_RT = 256, V2_BB = 14;
 // Non-empty tiles of ref tiles 0 .. r-1, in ref-tile-major order.  Rectangle: every ref tile pairs
 // with all q_tiles query tiles.  Triangle (self): ref tile i has a pair with r > q only for the
 // first clamp(m*i + c0, 0, q_tiles) query tiles (m = 256 / queries-per-tile).
-__host__ __device__ inline unsigned long long tiles_before64(unsigned r, int self, unsigned q_tiles, int m, int c0) {
+inline unsigned long long tiles_before64(unsigned r, int self, unsigned q_tiles, int m, int c0) {
   if (!self) return (unsigned long long)r * q_tiles;
   // i_lo: first ref tile with any query tile; i_hi: first with all of them
   const long long i_lo = c0 > 0 ? 0 : (-c0) / m + 1;
@@ -574,14 +575,25 @@ __host__ __device__ inline unsigned long long tiles_before64(unsigned r, int sel
   if (rr > i_hi) t += (unsigned long long)(rr - i_hi) * q_tiles;
   return t;
 }
-// (the grid is limited to 2^31 blocks, checked by the launcher, so 32 bits hold every count on the device)
-__host__ __device__ inline unsigned tiles_before(unsigned r, int self, unsigned q_tiles, int m, int c0) {
-  return (unsigned)tiles_before64(r, self, q_tiles, m, c0);
+// The device copy stays in 32-bit arithmetic: the launcher has checked (with the 64-bit version)
+// that every count fits, and 64-bit scalars in the tile decode cost the tile kernels registers
+// they do not have (VGPR spills 6 -> 14, -3 %).
+__device__ __forceinline__ unsigned tiles_before(unsigned r, int self, unsigned q_tiles, int m, int c0) {
+  if (!self) return r * q_tiles;
+  const int i_lo = c0 > 0 ? 0 : (-c0) / m + 1;
+  int i_hi = ((int)q_tiles - c0 + m - 1) / m;
+  if (i_hi < i_lo) i_hi = i_lo;
+  const int rr = (int)r;
+  const int b = rr < i_hi ? rr : i_hi;
+  unsigned t = 0;
+  if (b > i_lo) t = (unsigned)((m * (b * (b - 1) - i_lo * (i_lo - 1))) / 2 + c0 * (b - i_lo));
+  if (rr > i_hi) t += (unsigned)(rr - i_hi) * q_tiles;
+  return t;
 }
 
 // NW = wavefronts per workgroup: 8 (256 x 32 tile, 2 workgroups per CU) or 16 (256 x 64 tile,
 // 1 workgroup per CU: half the ref traffic per pair, one s_barrier over 16 wavefronts)
-template <int NW, int MODE, typename PackT>
+template <int NW, int MODE, typename PackT, bool KSPLIT = false>
 __global__ void __launch_bounds__(NW * 64, 4)
 dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ qryT,
                const double *__restrict__ lut, const uint16_t *__restrict__ ref_clu,
@@ -667,8 +679,10 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
   auto ref_of = [&](int r) -> size_t { return r0 + 2 * lane + (r & 1) + (r >> 1) * 128; };
 
   // one chunk per (k, 64-bin block); with k_split a workgroup owns the chunks of k = blockIdx.y only
-  const int k_first = p.k_split ? (int)blockIdx.y : 0;
-  const int total = (p.k_split ? 1 : p.nk) * p.s64;
+  // (a template parameter, not a launch parameter: the tile kernels sit at the SGPR limit and one
+  // more live scalar spills into VGPR lanes and from there into scratch inside the loop)
+  const int k_first = KSPLIT ? (int)blockIdx.y : 0;
+  const int total = (KSPLIT ? 1 : p.nk) * p.s64;
 
   // DMA sources: each wavefront copies PW of the chunk's one-KB pieces (28 ref pieces: row i/2,
   // half i%2; then the query pieces: PPP rows x LPP lanes each).  A piece's address is a
@@ -1106,11 +1120,18 @@ int launch_v2(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const f
   if (n_blocks > 0x7fffffffull) return ppk_fail(PPK_ERR_ARG, "tile grid too large for one launch");
   ppk_set_kernel_name(NW == 8 ? "dist_kernel_v2<256x32,lds-dma>" : "dist_kernel_v2<256x64,lds-dma>");
   ppk_prof_begin(s);
-  if (MODE != MODE_COUNTS) p.k_split = 0;
-  hipLaunchKernelGGL((dist_kernel_v2<NW, MODE, PackT>), dim3((unsigned)n_blocks, p.k_split ? (unsigned)p.nk : 1u),
-                     dim3(NW * 64), 0, s, ref->d_skT, qry->d_skT, d_lut,
-                     use_clu ? ref->d_clu : nullptr, use_clu ? qry->d_clu : nullptr, d_rtab, d_out,
-                     d_n_failed, d_mask, p);
+  if (MODE == MODE_COUNTS && NW == 8 && p.k_split) {
+    if constexpr (MODE == MODE_COUNTS && NW == 8)
+      hipLaunchKernelGGL((dist_kernel_v2<NW, MODE, PackT, true>), dim3((unsigned)n_blocks, (unsigned)p.nk),
+                         dim3(NW * 64), 0, s, ref->d_skT, qry->d_skT, d_lut,
+                         use_clu ? ref->d_clu : nullptr, use_clu ? qry->d_clu : nullptr, d_rtab, d_out,
+                         d_n_failed, d_mask, p);
+  } else {
+    hipLaunchKernelGGL((dist_kernel_v2<NW, MODE, PackT>), dim3((unsigned)n_blocks),
+                       dim3(NW * 64), 0, s, ref->d_skT, qry->d_skT, d_lut,
+                       use_clu ? ref->d_clu : nullptr, use_clu ? qry->d_clu : nullptr, d_rtab, d_out,
+                       d_n_failed, d_mask, p);
+  }
   ppk_prof_end(s);
   PPK_HIP(hipGetLastError());
   return PPK_OK;

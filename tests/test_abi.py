@@ -89,3 +89,33 @@ def test_compute_without_a_gpu_is_an_error_not_a_fallback():
         pp_sketchlib.query_arrays(sk, None, [13, 17], 16, 14)
     with pytest.raises(RuntimeError):
         poppunk_refine.assignThreshold(np.zeros((3, 2), dtype=np.float32), 2, 0.5, 0.5)
+
+
+def test_hot_kernels_have_no_scratch():
+    """Register budget guard: the two hot instantiations of dist_kernel_v2 (distances and fused
+    boundary, 64-bit packed counts) must compile without scratch.  They sit at the 128-VGPR /
+    ~102-SGPR limit; an innocent extra live value spills into the compare loop and costs 3 %
+    (it happened twice during round 1), which no functional test notices."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "poppunk_amd", "csrc", "ppk_dist.hip")
+    out = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+                          "--cuda-device-only", "-S", "-o", os.devnull, src,
+                          "-Rpass-analysis=kernel-resource-usage"],
+                         capture_output=True, text=True, cwd=os.path.dirname(src), timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    blocks = re.split(r"remark: Function Name: ", out.stderr)
+    seen = 0
+    for b in blocks[1:]:
+        name = b.split()[0]
+        # dist_kernel_v2<8, MODE_DIST|MODE_MASK, unsigned long, false>
+        if name.startswith("_Z14dist_kernel_v2ILi8ELi0EmLb0E") or name.startswith("_Z14dist_kernel_v2ILi8ELi3EmLb0E"):
+            seen += 1
+            scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
+            vgprs = int(re.search(r" VGPRs: (\d+)", b).group(1))
+            assert scratch == 0 and vgprs <= 128, (name, scratch, vgprs)
+    assert seen == 2
