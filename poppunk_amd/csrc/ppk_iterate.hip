@@ -50,16 +50,23 @@ __global__ void __launch_bounds__(256)
 ti1_classify_kernel(const float2 *__restrict__ dist, size_t n_rows, const Boundaries b,
                     float *__restrict__ d0, unsigned short *__restrict__ first,
                     unsigned *__restrict__ max_ord, unsigned *__restrict__ non_monotone) {
+  // the boundaries live in LDS: indexing the by-value struct with a runtime o is a dependent
+  // scalar load per boundary per row
+  __shared__ float2 sb[kMaxOff];
+  for (int o = threadIdx.x; o < b.n; o += 256) sb[o] = make_float2(b.x_max[o], b.y_max[o]);
+  __syncthreads();
   const size_t stride = (size_t)gridDim.x * 256;
   unsigned local = 0;  // f2ord of -inf-ish: 0 is below every real value's code
   for (size_t row = (size_t)blockIdx.x * 256 + threadIdx.x; row < n_rows; row += stride) {
     const float2 d = dist[row];
-    float dd = ppk_line_dist(d.x, d.y, b.x_max[0], b.y_max[0], b.slope);
+    float dd = ppk_line_dist(d.x, d.y, sb[0].x, sb[0].y, b.slope);
     dd = dd + 0.0f;  // -0.0 -> +0.0 so that the radix order equals operator<
     int f = b.n;
     bool hole = false;   // within some boundary but outside a later one (rounding / shrinking sweep)
+#pragma unroll 4
     for (int o = 0; o < b.n; ++o) {
-      const bool within = ppk_line_dist(d.x, d.y, b.x_max[o], b.y_max[o], b.slope) <= 0.0f;
+      const float2 xy = sb[o];
+      const bool within = ppk_line_dist(d.x, d.y, xy.x, xy.y, b.slope) <= 0.0f;
       if (within && f == b.n) f = o;
       hole = hole || (!within && f < b.n);
     }
@@ -106,12 +113,37 @@ __global__ void __launch_bounds__(256)
 ti1_stops_kernel(const unsigned long long *__restrict__ sorted_rows, size_t n_cand,
                  const unsigned short *__restrict__ first, int n_off,
                  unsigned long long *__restrict__ g) {
-  const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (p >= n_cand) return;
-  const int f = first[sorted_rows[p]];
-  // position p stops the sweep of every offset o < f
-  for (int o = 0; o < f && o < n_off; ++o) {
-    if (g[o] > p) atomicMin(&g[o], (unsigned long long)p);
+  // Position p stops the sweep of every offset o < f(p), so g[o] = min{p : f(p) > o}.  One
+  // conditional atomicMin per position on m[f] = min{p : f(p) = f} (held in g2[1..n_off]); the
+  // suffix minimum g[o] = min(m[o+1..n_off]) is taken by ti1_suffix_min_kernel.
+  // Per workgroup: LDS minima of the 256 positions by f, then one conditional global atomicMin per
+  // f that occurred (a per-position global atomic serialises on the ~40 hot addresses).
+  __shared__ unsigned ms[kMaxOff + 1];
+  for (int o = threadIdx.x; o <= n_off; o += 256) ms[o] = 0xffffffffu;
+  __syncthreads();
+  const size_t base = (size_t)blockIdx.x * 256;
+  const size_t p = base + threadIdx.x;
+  if (p < n_cand) {
+    int f = first[sorted_rows[p]];
+    if (f > n_off) f = n_off;
+    if (f > 0) atomicMin(&ms[f], (unsigned)threadIdx.x);
+  }
+  __syncthreads();
+  for (int o = 1 + threadIdx.x; o <= n_off; o += 256) {
+    const unsigned m = ms[o];
+    if (m != 0xffffffffu && g[n_off + o] > base + m) atomicMin(&g[n_off + o], (unsigned long long)(base + m));
+  }
+}
+
+// g[0..n_off) <- suffix minima of m = g[n_off+1 .. 2 n_off]
+__global__ void __launch_bounds__(64)
+ti1_suffix_min_kernel(unsigned long long *__restrict__ g, int n_off) {
+  if (threadIdx.x != 0) return;
+  unsigned long long run = g[2 * n_off];
+  for (int o = n_off - 1; o >= 0; --o) {
+    const unsigned long long m = g[n_off + o + 1];
+    run = m < run ? m : run;
+    g[o] = run;
   }
 }
 
@@ -262,7 +294,7 @@ extern "C" int ppk_threshold_iterate_1d_dev(const float *d_dist, size_t n_rows,
   // A: d0 (float) | first (u16) | max_ord (u32) | g (u64 x n_off)
   const size_t a_d0 = 0, a_first = a_d0 + ((n_rows * 4 + 255) & ~(size_t)255);
   const size_t a_max = a_first + ((n_rows * 2 + 255) & ~(size_t)255);
-  const size_t a_g = a_max + 256, a_end = a_g + n_off * 8 + 256;   // max_ord, non_monotone share a_max
+  const size_t a_g = a_max + 256, a_end = a_g + (2 * n_off + 1) * 8 + 256;   // max_ord, non_monotone share a_max; g holds g[n_off] + m[n_off+1]
   int rc = ppk_scratch_get(dev, SLOT_ITER_A, a_end, &p_a);
   if (rc == PPK_OK) rc = ppk_scratch_get(dev, SLOT_MASK, n_words * 8 + 8, &p_mask);
   if (rc == PPK_OK) rc = ppk_scratch_get(dev, SLOT_WS, ppk_compact_ws_bytes(n_words), &p_ws);
@@ -327,9 +359,10 @@ extern "C" int ppk_threshold_iterate_1d_dev(const float *d_dist, size_t n_rows,
     PPK_HIP(hipGetLastError());
     return PPK_OK;
   }
-  hipLaunchKernelGGL(fill_u64_kernel, dim3(nblk(n_off)), dim3(256), 0, s, g, n_off, n_cand);
+  hipLaunchKernelGGL(fill_u64_kernel, dim3(nblk(2 * n_off + 1)), dim3(256), 0, s, g, 2 * n_off + 1, n_cand);
   hipLaunchKernelGGL(ti1_stops_kernel, dim3(nblk(n_cand)), dim3(256), 0, s, rows_out, (size_t)n_cand,
                      first, (int)n_off, g);
+  hipLaunchKernelGGL(ti1_suffix_min_kernel, dim3(1), dim3(64), 0, s, g, (int)n_off);
   hipLaunchKernelGGL(ti1_emit_kernel, dim3(nblk(n_cand)), dim3(256), 0, s, rows_out, (size_t)n_cand,
                      (int)n_off, g, n_samples, d_i, d_j, d_off, cap, d_n_out);
   PPK_HIP(hipGetLastError());
