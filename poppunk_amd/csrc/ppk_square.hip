@@ -151,6 +151,74 @@ prune_query_rows_kernel(const float *__restrict__ in, size_t row_elems, const lo
     out[dst + e] = in[src + e];
 }
 
+// ---- k nearest neighbours by selection ----------------------------------------------------------
+// One wavefront per row.  Every element becomes a 64-bit key (order-preserving code of the distance
+// << 32 | column): the smallest key is the nearest neighbour, ties going to the lower column like the
+// reference's stable sort (src/extend.cpp:266-279).  A lane keeps the K smallest keys of its strided
+// share of the row sorted in registers (an element is inserted only if it beats the lane's K-th
+// best, which becomes rare quickly), then the K wave-wide minima are extracted one by one.
+__device__ __forceinline__ unsigned knn_ord(float f) {
+  const unsigned u = __float_as_uint(f + 0.0f);          // -0.0 -> +0.0
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float knn_unord(unsigned o) {
+  return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+
+template <int K>
+__global__ void __launch_bounds__(256)
+knn_select_kernel(const float *__restrict__ src, size_t stride, size_t col, size_t n_rows, size_t n_cols,
+                  size_t self_offset, int knn, long long *__restrict__ oi, long long *__restrict__ oj,
+                  float *__restrict__ od) {
+  const size_t i = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n_rows) return;
+  const int lane = threadIdx.x & 63;
+  const size_t self = self_offset + i;
+  constexpr uint64_t NONE = ~0ull;
+  uint64_t best[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) best[j] = NONE;
+  const float *row = src + (i * n_cols) * stride + col;
+  for (size_t c = lane; c < n_cols; c += 64) {
+    if (c == self) continue;
+    uint64_t x = ((uint64_t)knn_ord(row[c * stride]) << 32) | (uint64_t)c;
+    if (x < best[K - 1]) {
+#pragma unroll
+      for (int j = 0; j < K; ++j) {      // bubble x through the sorted list
+        const uint64_t b = best[j];
+        const bool lt = x < b;
+        best[j] = lt ? x : b;
+        x = lt ? b : x;
+      }
+    }
+  }
+  for (int r = 0; r < knn; ++r) {
+    uint64_t m = best[0];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint64_t v = __shfl_xor(m, o, 64);
+      m = v < m ? v : m;
+    }
+    if (m == NONE) {
+      // fewer than knn other samples: the reference leaves i in i_vec and zeros elsewhere
+      for (int k = r + lane; k < knn; k += 64) {
+        oi[i * knn + k] = (long long)self;
+        oj[i * knn + k] = 0;
+        od[i * knn + k] = 0.0f;
+      }
+      break;
+    }
+    if (best[0] == m) {                   // keys are unique: exactly one lane
+      oi[i * knn + r] = (long long)self;
+      oj[i * knn + r] = (long long)(m & 0xffffffffull);
+      od[i * knn + r] = knn_unord((unsigned)(m >> 32));
+#pragma unroll
+      for (int j = 0; j + 1 < K; ++j) best[j] = best[j + 1];
+      best[K - 1] = NONE;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int ppk_long_to_square_dev(const float *d_long, size_t stride, size_t col, size_t n,
@@ -198,9 +266,21 @@ extern "C" int ppk_knn_rect_dev(const float *d_block, size_t stride, size_t col,
   if (n_rows == 0 || n_cols == 0 || knn <= 0) return PPK_OK;
   if (!d_block || !d_i || !d_j || !d_dist || stride == 0 || col >= stride)
     return ppk_fail(PPK_ERR_ARG, "ppk_knn_rect_dev: bad arguments");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (knn <= 32 && n_cols < 0xffffffffull) {
+    // selection (no sort, no scratch): the common case, lineage models use a handful of neighbours
+    const dim3 grid((unsigned)((n_rows + 3) / 4));
+    if (knn <= 8)
+      hipLaunchKernelGGL(knn_select_kernel<8>, grid, dim3(256), 0, s, d_block, stride, col, n_rows, n_cols,
+                         self_offset, knn, d_i, d_j, d_dist);
+    else
+      hipLaunchKernelGGL(knn_select_kernel<32>, grid, dim3(256), 0, s, d_block, stride, col, n_rows, n_cols,
+                         self_offset, knn, d_i, d_j, d_dist);
+    PPK_HIP(hipGetLastError());
+    return PPK_OK;
+  }
   if (n_rows * n_cols > 0x7fffffffull)
     return ppk_fail(PPK_ERR_ARG, "ppk_knn_rect_dev: block too large for one segmented sort (rows*cols < 2^31)");
-  hipStream_t s = static_cast<hipStream_t>(stream);
   int dev = 0;
   PPK_HIP(hipGetDevice(&dev));
   const size_t nn = n_rows * n_cols;

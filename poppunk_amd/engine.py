@@ -340,20 +340,33 @@ def prune_query_rows_dev(qr_t, n_ref, keep_q):
 
 
 def knn_from_sketches(db, kmers, random_tbl, knn, dist_col=0, random_correct=True,
-                      band_items=1 << 29):
+                      band_items=1 << 31):
     """k nearest neighbours of every sample straight from the resident sketches (what
     get_kNN_distances(longToSquare(queryDatabase(...)[:, dist_col])) gives, PopPUNK/models.py:
-    1215-1222) without materialising the n x n matrix: bands of query rows are computed against
-    all refs (row = q*n + r), their k smallest entries taken on the device, and the band buffer
-    re-used.  Returns CUDA tensors (i, j, dist) of length n*knn."""
+    1215-1222), entirely on the device.  Returns CUDA tensors (i, j, dist) of length n*knn.
+
+    While n*n <= band_items (n <= 46 340 by default: 8 n^2 bytes of HBM) the upper triangle is
+    computed once, expanded to the square matrix and the neighbours selected from its rows.
+    Beyond that, bands of query rows are computed against all refs (row = q*n + r, both triangles:
+    twice the compare work, but only one band of the matrix exists at a time)."""
     torch = _torch()
     lib = _lib.lib()
     n = db.n
     dev = "cuda:%d" % db.device
-    band = max(64, min(n, (band_items // max(n, 1)) // 64 * 64))
     oi = torch.empty(n * knn, dtype=torch.int64, device=dev)
     oj = torch.empty(n * knn, dtype=torch.int64, device=dev)
     od = torch.empty(n * knn, dtype=torch.float32, device=dev)
+    if n * n <= band_items and n > 1:
+        with torch.cuda.device(db.device):
+            tri, _ = dist(db, None, kmers, random_tbl, random_correct=random_correct)
+            sq = long_to_square_dev(tri, dist_col, n)
+            del tri
+            rc = lib.ppk_knn_dev(C.c_void_p(sq.data_ptr()), n, int(knn), C.c_void_p(oi.data_ptr()),
+                                 C.c_void_p(oj.data_ptr()), C.c_void_p(od.data_ptr()),
+                                 _stream_ptr(db.device))
+            _lib.check(rc, "ppk_knn_dev")
+        return oi, oj, od
+    band = max(64, min(n, (band_items // max(n, 1)) // 64 * 64))
     buf = torch.empty((min(band, n) * n, 2), dtype=torch.float32, device=dev)
     with torch.cuda.device(db.device):
         for qb in range(0, n, band):

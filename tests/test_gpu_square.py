@@ -40,7 +40,8 @@ def test_transform_errors():
         pp_sketchlib.squareToLong(np.zeros((2, 3), dtype=np.float32), 1)
 
 
-@pytest.mark.parametrize("n,k", [(5, 2), (64, 3), (300, 10), (300, 1), (4, 7)])
+@pytest.mark.parametrize("n,k", [(5, 2), (64, 3), (300, 10), (300, 1), (4, 7), (1000, 20), (70, 32),
+                                 (70, 33), (200, 40), (130, 8), (130, 9)])
 def test_knn(n, k):
     rng = np.random.Generator(np.random.PCG64(n + k))
     v = (rng.integers(0, 50, size=n * (n - 1) // 2) / 50.0).astype(np.float32)   # many ties
@@ -65,11 +66,12 @@ def test_knn_straight_from_sketches():
     for col, k in ((0, 5), (1, 3)):
         sq = oracle.long_to_square(dist[:, col])
         wi, wj, wd = oracle.knn(sq, k)
-        gi, gj, gd = engine.knn_from_sketches(db, kmers, tbl, k, dist_col=col, band_items=500 * 128)
-        assert np.array_equal(gi.cpu().numpy(), wi)
-        assert np.array_equal(gd.cpu().numpy(), wd)
-        # ties between equal distances resolve by column index in both
-        assert np.array_equal(gj.cpu().numpy(), wj)
+        for band_items in (500 * 128, 1 << 31):      # band by band / triangle -> square -> select
+            gi, gj, gd = engine.knn_from_sketches(db, kmers, tbl, k, dist_col=col, band_items=band_items)
+            assert np.array_equal(gi.cpu().numpy(), wi)
+            assert np.array_equal(gd.cpu().numpy(), wd)
+            # ties between equal distances resolve by column index in both
+            assert np.array_equal(gj.cpu().numpy(), wj)
     db.close()
 
 
