@@ -82,6 +82,6 @@ def test_band_split_and_gather_world2(n_ref, n_qry):
     for p in procs:
         p.start()
     for p in procs:
-        p.join(timeout=240)
+        p.join(timeout=600)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert ret.get(timeout=5) is True

@@ -21,6 +21,6 @@ def test_two_ranks_one_gpu_matches_single_launch():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "tools", "two_ranks_one_gpu.py")]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, cwd=ROOT)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "RESULT equal=True" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
