@@ -153,6 +153,17 @@ def main():
                                         q_begin=b[3], q_end=b[4], cap=len(e) + 16), reps=2, warm=0)
     out["C5_100k_band_4of8_fused_edges"] = {"pairs": rows, "edges": int(len(e)), "ms": t * 1e3,
                                             "pairs_per_s": rows / t, "band": [b[3], b[4]]}
+    # the whole config-5 job on ONE GPU: 5e9 pairs, fused boundary -> edge list; checked against the
+    # per-band edge lists (the multi-GPU decomposition) for identical content
+    whole, _ = engine.dist_edges(db100, None, KMERS, TBL, slope=2, x_max=x_max, y_max=y_max)
+    t = timed(lambda: engine.dist_edges(db100, None, KMERS, TBL, slope=2, x_max=x_max, y_max=y_max,
+                                        cap=len(whole) + 16), reps=2, warm=0)
+    parts = [engine.dist_edges(db100, None, KMERS, TBL, slope=2, x_max=x_max, y_max=y_max,
+                               q_begin=b[r], q_end=b[r + 1])[0] for r in range(8)]
+    same = bool(torch.equal(torch.cat(parts), whole))
+    out["C5_100k_whole_fused_edges_1gpu"] = {"pairs": 100000 * 99999 // 2, "edges": int(len(whole)),
+                                             "ms": t * 1e3, "pairs_per_s": 100000 * 99999 // 2 / t,
+                                             "equals_concatenated_8_band_edge_lists": same}
     txt = json.dumps(out, indent=1)
     print(txt)
     if len(sys.argv) > 1:
