@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--tile", type=str, default="", help="TQ,NW override (experiments)")
+    ap.add_argument("--spinup-ms", type=float, default=200.0,
+                    help="untimed clock spin-up before the warm-up steps (0 disables)")
     ap.add_argument("--chunks", type=int, default=4,
                     help="sub-bands per rank: the gather of chunk c overlaps the compute of c+1")
     return ap.parse_args()
@@ -161,6 +163,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Device spin-up (setup, not part of the W warm-up steps): after an idle period the GPU clock
+    # takes ~50 ms of load to ramp and the first launches run 20-30 % slow; a driver that asks for a
+    # short --warmup would otherwise time the governor instead of the kernel.
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < args.spinup_ms * 1e-3:
+        step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     barrier()
