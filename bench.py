@@ -166,9 +166,14 @@ def main():
     # Device spin-up (setup, not part of the W warm-up steps): after an idle period the GPU clock
     # takes ~50 ms of load to ramp and the first launches run 20-30 % slow; a driver that asks for a
     # short --warmup would otherwise time the governor instead of the kernel.
-    t_spin = time.perf_counter()
-    while time.perf_counter() - t_spin < args.spinup_ms * 1e-3:
-        step()
+    if world == 1:
+        t_spin = time.perf_counter()
+        while time.perf_counter() - t_spin < args.spinup_ms * 1e-3:
+            step()
+            torch.cuda.synchronize()
+    elif args.spinup_ms > 0:
+        for _ in range(30):          # every rank must run the SAME number of gathered steps
+            step()
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
