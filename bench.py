@@ -172,7 +172,8 @@ def main():
             step()
             torch.cuda.synchronize()
     elif args.spinup_ms > 0:
-        for _ in range(30):          # every rank must run the SAME number of gathered steps
+        n_spin = 30 if os.environ.get("PPK_BENCH_BACKEND", "nccl") == "nccl" else 1
+        for _ in range(n_spin):      # every rank must run the SAME number of gathered steps
             step()
         torch.cuda.synchronize()
     for _ in range(args.warmup):
