@@ -82,7 +82,7 @@ struct DistParams {
   int random_correct;
   int slope, inclusive;   // MODE_MASK
   float x_max, y_max, scale_x, scale_y;
-  // v2 MODE_DIST, self job with a ragged right edge: the first n_strip blocks of the grid are
+  // v2 MODE_DIST / MODE_MASK, self job with a ragged right edge: the first n_strip blocks of the grid are
   // "strip" tiles -- the last (n_ref mod 256) refs sit on the query axis against all smaller
   // samples on the lane axis (valid iff lane sample < strip sample); the rest are the triangle.
   unsigned n_strip;       // number of strip blocks (0 = none)
@@ -896,12 +896,19 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
             pred = p.inclusive ? (sd <= 0.0f) : (sd < 0.0f);
           }
           ball[r] = __ballot(pred);
+          // strip tile: the lane sample is the row of the mask, the wave-uniform strip sample its
+          // column -- one bit in 64 different (zero-initialised) words, set atomically (only the
+          // strip tiles touch the words of columns >= r_limit)
+          if (strip && pred)
+            atomicOr(reinterpret_cast<unsigned long long *>(mask_out) +
+                         (ref_of(r) - p.q_begin) * p.n_rtiles + (qq >> 6),
+                     1ull << (qq & 63));
         }
       }
       if constexpr (MODE == MODE_MASK) {
         // ball[0]/ball[1]: even/odd refs of r0..r0+127; ball[2]/ball[3]: of r0+128..r0+255.
         // Interleave them into the [q][ref/64] bitmask words the compaction pass reads.
-        if (lane == 0) {
+        if (lane == 0 && !strip) {
           uint64_t *mrow = mask_out + (qq - qb) * p.n_rtiles + rt * 4;
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
@@ -1082,7 +1089,7 @@ int launch_v2(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const f
   // sit on the query axis against all smaller samples on the lane axis, writing the same
   // condensed rows; the strip tiles lead the same grid.
   const size_t rem = p.n_ref % V2_RT;
-  if constexpr (MODE == MODE_DIST) {
+  if constexpr (MODE == MODE_DIST || MODE == MODE_MASK) {
     bool split = p.self && rem != 0 && rem <= 224 && p.n_ref > V2_RT;
     const char *e = getenv("PPK_STRIP");
     if (e && atoi(e) == 0) split = false;
