@@ -287,6 +287,34 @@ def threshold_iterate_1d_dev(dist_t, offsets, slope, x0, y0, x1, y1, cap=None):
             cap = m
 
 
+def threshold_iterate_2d_dev(dist_t, x_max, y_max, cap=None):
+    """poppunk_refine.thresholdIterate2D on a resident float32 [n,2] CUDA tensor ->
+    (i, j, offset_idx) int64 CUDA tensors (src/boundary.cpp:212-237).  refine's 2-D mode calls it
+    once per y value on the same matrix (PopPUNK/refine.py:587-593): resident, the 400 MB matrix is
+    not re-sent for every y."""
+    torch = _torch()
+    xm = np.ascontiguousarray(x_max, dtype=np.float32).ravel()
+    if xm.size > 1 and np.any(np.diff(xm) < 0):
+        raise RuntimeError("x_max range to thresholdIterate2D must be sorted")
+    n = dist_t.shape[0]
+    if cap is None:
+        cap = min(n, max(1 << 20, n // 8))
+    with torch.cuda.device(dist_t.device):
+        while True:
+            buf = torch.empty((3, max(cap, 1)), dtype=torch.int64, device=dist_t.device)
+            n_out = torch.zeros(1, dtype=torch.int64, device=dist_t.device)
+            rc = _lib.lib().ppk_threshold_iterate_2d_dev(
+                C.c_void_p(dist_t.data_ptr()), n, xm.ctypes.data_as(C.POINTER(C.c_float)), xm.size,
+                float(y_max), C.c_void_p(buf[0].data_ptr()), C.c_void_p(buf[1].data_ptr()),
+                C.c_void_p(buf[2].data_ptr()), cap, C.c_void_p(n_out.data_ptr()),
+                _stream_ptr(dist_t.device.index))
+            _lib.check(rc, "ppk_threshold_iterate_2d_dev")
+            m = int(n_out.item())
+            if m <= cap:
+                return buf[0, :m], buf[1, :m], buf[2, :m]
+            cap = m
+
+
 def long_to_square_dev(dist_t, col, n):
     """pp_sketchlib.longToSquare of one column of the resident [n_pairs,2] matrix -> [n,n] CUDA."""
     torch = _torch()

@@ -374,3 +374,17 @@ def test_refine_boundary_model_mirror():
     assert np.array_equal(t.assign(X), oracle.assign_threshold(X, 0, t.core_boundary, 0))
     with pytest.raises(RuntimeError):
         models.RefineBoundary().assign(X)
+
+
+def test_threshold_iterate_2d_on_resident_matrix():
+    import torch
+    rng = np.random.Generator(np.random.PCG64(42))
+    n = 300
+    d = (rng.random((n * (n - 1) // 2, 2)) * 0.4).astype(np.float32)
+    x_max = np.sort(rng.uniform(0.02, 0.3, size=20)).astype(np.float32)
+    wi, wj, wo = oracle.threshold_iterate_2d(d, x_max, 0.21)
+    gi, gj, go = engine.threshold_iterate_2d_dev(torch.as_tensor(d, device="cuda"), x_max, 0.21, cap=4)
+    assert np.array_equal(gi.cpu().numpy(), wi) and np.array_equal(gj.cpu().numpy(), wj)
+    assert np.array_equal(go.cpu().numpy(), wo)
+    with pytest.raises(RuntimeError):
+        engine.threshold_iterate_2d_dev(torch.as_tensor(d, device="cuda"), x_max[::-1].copy(), 0.21)
