@@ -189,7 +189,11 @@ int ppk_threshold_iterate_2d_dev(const float *d_dist, size_t n_rows, const float
  * klist, random_correct, jaccard, num_threads, use_gpu, device_id) after the
  * HDF5 read (PopPUNK/sketchlib.py:528-537; positional order pinned by
  * test/test-update-gpu.py:85-86).  n_qry == 0 => self.  out: float
- * [n_pairs][2] or [n_pairs][nk] (PPK_FLAG_JACCARD) or uint32 (PPK_FLAG_COUNTS). */
+ * [n_pairs][2] or [n_pairs][nk] (PPK_FLAG_JACCARD) or uint32 (PPK_FLAG_COUNTS).  * The result is produced in sub-bands through two alternating device buffers of
+ * about 256 MB (sub-band c downloads while c+1 computes), so device memory use is
+ * bounded by the sketches plus those buffers for any job size -- the
+ * device-memory chunking of pp-sketchlib's CUDA path [EXT].
+ */
 int ppk_query(const uint64_t *ref_sk, size_t n_ref, const uint64_t *qry_sk,
               size_t n_qry, const int32_t *kmers, size_t nk, size_t sketchsize64,
               size_t bbits, const float *random_tbl, const uint16_t *ref_clu,

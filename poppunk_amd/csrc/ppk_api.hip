@@ -532,18 +532,38 @@ extern "C" int ppk_query(const uint64_t *ref_sk, size_t n_ref, const uint64_t *q
   const bool self = (n_qry == 0);
   const size_t nq = self ? n_ref : n_qry;
   const size_t cols = (flags & (PPK_FLAG_JACCARD | PPK_FLAG_COUNTS)) ? nk : 2;
-  if (ppk_rows_in_band(n_ref, n_qry, 0, nq) == 0) return PPK_OK;  // a single self sample: no pairs
+  const size_t total_rows = ppk_rows_in_band(n_ref, n_qry, 0, nq);
+  if (total_rows == 0) return PPK_OK;  // a single self sample: no pairs
 
-  std::vector<size_t> bounds(n_dev + 1);
-  int rc = ppk_band_split(n_ref, n_qry, n_dev, bounds.data());
+  // Device-memory chunking (what pp-sketchlib's CUDA path does when the result does not fit the
+  // card [EXT]): the query axis is cut into n_dev x C sub-bands of equal pair count; a device
+  // computes its C sub-bands one after the other into two alternating buffers, and sub-band c is
+  // copied to the caller's array while c+1 computes.  Memory per device: the sketches + two
+  // sub-band buffers, whatever the size of the job.
+  size_t target_rows = (size_t)32 << 20;                       // ~256 MB of float2 rows per buffer
+  if (const char *e = getenv("PPK_CHUNK_ROWS")) target_rows = (size_t)atoll(e) > 0 ? (size_t)atoll(e) : target_rows;
+  const size_t per_dev = (total_rows + n_dev - 1) / n_dev;
+  int C = (int)((per_dev + target_rows - 1) / target_rows);
+  if (C < 1) C = 1;
+  if ((size_t)C > nq / 64 + 1) C = (int)(nq / 64 + 1);         // sub-band edges are multiples of 64 queries
+  std::vector<size_t> bounds((size_t)n_dev * C + 1);
+  int rc = ppk_band_split(n_ref, n_qry, n_dev * C, bounds.data());
   if (rc != PPK_OK) return rc;
+  std::vector<size_t> row0((size_t)n_dev * C + 1, 0);           // first output row of every sub-band
+  size_t max_rows = 0;
+  for (int i = 0; i < n_dev * C; ++i) {
+    const size_t r = ppk_rows_in_band(n_ref, n_qry, bounds[i], bounds[i + 1]);
+    row0[i + 1] = row0[i] + r;
+    if (r > max_rows) max_rows = r;
+  }
 
   struct Part {
     ppk_db *ref = nullptr, *qry = nullptr;
-    void *d_out = nullptr;
+    void *buf[2] = {nullptr, nullptr};
     unsigned long long *d_failed = nullptr;
-    hipStream_t s = nullptr;
-    size_t rows = 0, row0 = 0;
+    hipStream_t s = nullptr, sc = nullptr;       // compute / copy
+    bool own_streams = true;                      // false: a device listed twice shares the first entry's
+    hipEvent_t done[2] = {nullptr, nullptr};      // sub-band in buf[i] computed
   };
   std::vector<Part> parts(n_dev);
   auto cleanup = [&]() {
@@ -551,46 +571,77 @@ extern "C" int ppk_query(const uint64_t *ref_sk, size_t n_ref, const uint64_t *q
       Part &p = parts[d];
       DeviceGuard g(devices[d]);
       if (p.s) (void)hipStreamSynchronize(p.s);
-      if (p.d_out) (void)hipFree(p.d_out);
+      if (p.sc) (void)hipStreamSynchronize(p.sc);
+      for (int i = 0; i < 2; ++i) {
+        if (p.buf[i]) (void)hipFree(p.buf[i]);
+        if (p.done[i]) (void)hipEventDestroy(p.done[i]);
+      }
       if (p.d_failed) (void)hipFree(p.d_failed);
       if (p.ref) ppk_db_destroy(p.ref);
       if (p.qry) ppk_db_destroy(p.qry);
-      if (p.s) (void)hipStreamDestroy(p.s);
+      if (p.s && p.own_streams) (void)hipStreamDestroy(p.s);
+      if (p.sc && p.own_streams) (void)hipStreamDestroy(p.sc);
     }
   };
-  size_t row0 = 0;
   for (int d = 0; d < n_dev && rc == PPK_OK; ++d) {
     Part &p = parts[d];
-    p.rows = ppk_rows_in_band(n_ref, n_qry, bounds[d], bounds[d + 1]);
-    p.row0 = row0;
-    row0 += p.rows;
-    if (p.rows == 0) continue;
+    if (row0[(size_t)(d + 1) * C] == row0[(size_t)d * C]) continue;     // nothing for this device
     DeviceGuard g(devices[d]);
     if (!g.ok) {
       rc = ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(devices[d]));
       break;
     }
-    if (hipStreamCreate(&p.s) != hipSuccess) {
-      rc = ppk_fail(PPK_ERR_HIP, "hipStreamCreate failed");
+    // the per-device scratch (log-J table, k-split counts) allows one call in flight per device:
+    // entries naming the same device are ordered on one stream
+    for (int e = 0; e < d; ++e)
+      if (devices[e] == devices[d] && parts[e].s) {
+        p.s = parts[e].s;
+        p.sc = parts[e].sc;
+        p.own_streams = false;
+        break;
+      }
+    if ((p.own_streams && (hipStreamCreate(&p.s) != hipSuccess || hipStreamCreate(&p.sc) != hipSuccess)) ||
+        hipEventCreateWithFlags(&p.done[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&p.done[1], hipEventDisableTiming) != hipSuccess) {
+      rc = ppk_fail(PPK_ERR_HIP, "hipStreamCreate / hipEventCreate failed");
       break;
     }
     rc = ppk_db_create(devices[d], ref_sk, n_ref, nk, sketchsize64, bbits, ref_clu, 0, p.s, &p.ref);
     if (rc == PPK_OK && !self)
       rc = ppk_db_create(devices[d], qry_sk, n_qry, nk, sketchsize64, bbits, qry_clu, 0, p.s, &p.qry);
     if (rc != PPK_OK) break;
-    if (hipMalloc(&p.d_out, p.rows * cols * 4) != hipSuccess ||
+    const size_t buf_bytes = max_rows * cols * 4;
+    if (hipMalloc(&p.buf[0], buf_bytes) != hipSuccess || (C > 1 && hipMalloc(&p.buf[1], buf_bytes) != hipSuccess) ||
         hipMalloc(reinterpret_cast<void **>(&p.d_failed), sizeof(unsigned long long)) != hipSuccess) {
       rc = ppk_fail(PPK_ERR_HIP, "hipMalloc(output) failed");
       break;
     }
     (void)hipMemsetAsync(p.d_failed, 0, sizeof(unsigned long long), p.s);
-    rc = ppk_dist_dev(p.ref, p.qry, kmers, random_tbl, n_clu, flags, bounds[d], bounds[d + 1],
-                      p.d_out, p.d_failed, p.s);
-    if (rc != PPK_OK) break;
-    if (hipMemcpyAsync(static_cast<char *>(out) + p.row0 * cols * 4, p.d_out, p.rows * cols * 4,
-                       hipMemcpyDeviceToHost, p.s) != hipSuccess) {
-      rc = ppk_fail(PPK_ERR_HIP, "hipMemcpy(output) failed");
-      break;
+  }
+  // step c: every device launches sub-band c, then sub-band c-1 of every device is fetched
+  for (int c = 0; c <= C && rc == PPK_OK; ++c) {
+    for (int d = 0; d < n_dev && rc == PPK_OK && c < C; ++d) {
+      Part &p = parts[d];
+      const size_t i = (size_t)d * C + c;
+      if (!p.s || row0[i + 1] == row0[i]) continue;
+      DeviceGuard g(devices[d]);
+      rc = ppk_dist_dev(p.ref, p.qry, kmers, random_tbl, n_clu, flags, bounds[i], bounds[i + 1],
+                        p.buf[c & 1], p.d_failed, p.s);
+      if (rc == PPK_OK && hipEventRecord(p.done[c & 1], p.s) != hipSuccess)
+        rc = ppk_fail(PPK_ERR_HIP, "hipEventRecord failed");
+    }
+    for (int d = 0; d < n_dev && rc == PPK_OK && c > 0; ++d) {
+      Part &p = parts[d];
+      const size_t i = (size_t)d * C + (c - 1);
+      if (!p.s || row0[i + 1] == row0[i]) continue;
+      DeviceGuard g(devices[d]);
+      hipError_t e = hipStreamWaitEvent(p.sc, p.done[(c - 1) & 1], 0);
+      if (e == hipSuccess)
+        e = hipMemcpyAsync(static_cast<char *>(out) + row0[i] * cols * 4, p.buf[(c - 1) & 1],
+                           (row0[i + 1] - row0[i]) * cols * 4, hipMemcpyDeviceToHost, p.sc);
+      if (e == hipSuccess) e = hipStreamSynchronize(p.sc);   // the buffer is free for sub-band c+1
+      if (e != hipSuccess)
+        rc = ppk_fail(PPK_ERR_HIP, std::string("kernel execution / download failed: ") + hipGetErrorString(e));
     }
   }
   if (rc == PPK_OK) {

@@ -402,3 +402,27 @@ def test_small_job_k_split_is_bit_identical_to_the_tile_epilogue(monkeypatch):
         assert res["0"][1] == wf and np.abs(res["0"][0].cpu().numpy() - want).max() <= 1e-6
         db.close()
         dq.close()
+
+
+def test_host_call_chunks_the_result_through_bounded_device_memory(monkeypatch):
+    """ppk_query computes its band in sub-bands through two alternating device buffers (the
+    reference CUDA path's device-memory chunking): many tiny sub-bands, one or several devices in
+    the list, self and ref x query, all output modes -- identical to the one-piece result."""
+    kmers = np.asarray(synth.DEFAULT_KMERS, dtype=np.int32)
+    tbl = synth.random_match_table(kmers)
+    sk = synth.make_sketches(1300, kmers, cluster_size=50, seed=31)[0]
+    ref, qry = sk[:900], sk[900:]
+    base = {}
+    for name, (r, q) in (("self", (sk, None)), ("rq", (ref, qry))):
+        base[name] = (pp_sketchlib.query_arrays(r, q, kmers, 16, 14, tbl),
+                      pp_sketchlib.query_arrays(r, q, kmers, 16, 14, tbl, jaccard=True)[0],
+                      pp_sketchlib.query_arrays(r, q, kmers, 16, 14, counts=True)[0])
+    monkeypatch.setenv("PPK_CHUNK_ROWS", "30000")
+    for devices in ((0,), (0, 0, 0)):
+        for name, (r, q) in (("self", (sk, None)), ("rq", (ref, qry))):
+            d, f = pp_sketchlib.query_arrays(r, q, kmers, 16, 14, tbl, devices=devices)
+            assert f == base[name][0][1] and np.array_equal(d, base[name][0][0])
+            assert np.array_equal(pp_sketchlib.query_arrays(r, q, kmers, 16, 14, tbl, jaccard=True,
+                                                            devices=devices)[0], base[name][1])
+            assert np.array_equal(pp_sketchlib.query_arrays(r, q, kmers, 16, 14, counts=True,
+                                                            devices=devices)[0], base[name][2])
