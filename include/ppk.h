@@ -189,7 +189,8 @@ int ppk_threshold_iterate_2d_dev(const float *d_dist, size_t n_rows, const float
  * klist, random_correct, jaccard, num_threads, use_gpu, device_id) after the
  * HDF5 read (PopPUNK/sketchlib.py:528-537; positional order pinned by
  * test/test-update-gpu.py:85-86).  n_qry == 0 => self.  out: float
- * [n_pairs][2] or [n_pairs][nk] (PPK_FLAG_JACCARD) or uint32 (PPK_FLAG_COUNTS).  * The result is produced in sub-bands through two alternating device buffers of
+ * [n_pairs][2] or [n_pairs][nk] (PPK_FLAG_JACCARD) or uint32 (PPK_FLAG_COUNTS).
+ * The result is produced in sub-bands through two alternating device buffers of
  * about 256 MB (sub-band c downloads while c+1 computes), so device memory use is
  * bounded by the sketches plus those buffers for any job size -- the
  * device-memory chunking of pp-sketchlib's CUDA path [EXT].
