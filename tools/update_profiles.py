@@ -53,6 +53,25 @@ def main():
                       "dist_kernel_v2; separate --pmc passes (profiles/r01/bench_pmc_counters.json)",
                "fetch_size_kb": fetch, "write_size_kb": write}
     json.dump(traffic, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+    # derived per-launch figures of the dominant kernel
+    g = lambda k: counters[k]["avg_per_launch"] if k in counters else float("nan")
+    pairs = bench["config"]["pairs"]
+    cyc = g("GRBM_GUI_ACTIVE") / 8.0          # summed over the 8 XCDs
+    derived = {
+        "valu_instructions_per_pair": g("SQ_INSTS_VALU") * 64 / pairs,
+        "valu_instructions_per_pair_algorithmic": 2400,
+        "lds_instructions_per_pair": g("SQ_INSTS_LDS") * 64 / pairs,
+        "l2_hit_rate": g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum")),
+        "lds_array_busy_fraction": g("SQ_LDS_IDX_ACTIVE") / 256.0 / cyc,
+        "lds_bank_conflict_cycles": g("SQ_LDS_BANK_CONFLICT"),
+        "valu_wave_instructions_per_clk_per_simd": g("SQ_INSTS_VALU") / 1024.0 / cyc,
+        "wave_wait_any_fraction": g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES"),
+        "wave_wait_inst_any_fraction": g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES"),
+        "gpu_cycles_per_launch": cyc,
+        "note": "from bench_pmc_counters.json (separate --pmc passes over python bench.py --steps 5); "
+                "cycles = GRBM_GUI_ACTIVE / 8 XCDs; a pure v_bitop3 stream issues ~0.41 wave-instr/clk/SIMD",
+    }
+    json.dump(derived, open(os.path.join(DST, "derived_metrics.json"), "w"), indent=1)
     for r in csv.DictReader(open(os.path.join(DST, "bench_kernel_stats.csv"))):
         if KERNEL in r["Name"]:
             print("rocprof: %s calls=%s avg=%.4f ms" % (KERNEL, r["Calls"], float(r["AverageNs"]) / 1e6))
