@@ -13,6 +13,7 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o f -- $S > /d
 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_write -o w -- $S > /dev/null 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY --output-format csv -d $OUT/pmc_sq -o s -- $S > /dev/null 2>&1
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM GRBM_GUI_ACTIVE SQ_ACTIVE_INST_LDS --output-format csv -d $OUT/pmc_lds -o l -- $S > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktc -o c -- python tools/measure_configs.py > /dev/null 2>&1
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 ./tools/ubench_valu.out > $OUT/ubench_valu.txt 2>&1
 ./tools/ubench_bank.out > $OUT/ubench_bank.txt 2>&1

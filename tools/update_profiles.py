@@ -26,6 +26,9 @@ def main():
     line = [l for l in open(os.path.join(SRC, "bench.json")) if l.startswith("{")][-1]
     open(os.path.join(DST, "bench_default.json"), "w").write(line)
     shutil.copy(os.path.join(SRC, "configs.json"), os.path.join(DST, "configs_1gpu.json"))
+    ktc = os.path.join(SRC, "ktc", "c_kernel_stats.csv")
+    if os.path.exists(ktc):       # every kernel of tools/measure_configs.py (kernel 2, sweeps, kNN, ...)
+        shutil.copy(ktc, os.path.join(DST, "configs_kernel_stats.csv"))
     for f in glob.glob(os.path.join(SRC, "ubench_*.txt")) + [os.path.join(SRC, "power_clocks.txt")]:
         if os.path.exists(f):
             shutil.copy(f, DST)
