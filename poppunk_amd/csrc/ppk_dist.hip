@@ -169,23 +169,43 @@ lut_kernel(double *__restrict__ lut, const float *__restrict__ rtab, int nk, int
 // parts, degree-11 Taylor polynomial on |r| <= 0.347 (truncation 6e-15 relative), scaled by 2^n.
 // A third of the instructions of the library exp (no overflow / NaN / +x handling needed here);
 // the result is rounded to float32 by the caller, which this error changes for ~2 in 1e7 values.
+constexpr double kExpC[12] = {2.50521083854417187751e-08,   // 1/11!
+                              2.75573192239858906526e-07,   // 1/10!
+                              2.75573192239858906526e-06,   // 1/9!
+                              2.48015873015873015873e-05,   // 1/8!
+                              1.98412698412698412698e-04,   // 1/7!
+                              1.38888888888888888889e-03,   // 1/6!
+                              8.33333333333333333333e-03,   // 1/5!
+                              4.16666666666666666667e-02,   // 1/4!
+                              1.66666666666666666667e-01,   // 1/3!
+                              0.5, 1.0, 1.0};
+
+// N values in lock-step, so that every coefficient is materialised once per N evaluations (64-bit
+// constants cannot be literals of an fp64 instruction; one at a time the compiler re-creates the
+// twelve of them for every call).  Identical arithmetic per element whatever N is.
+template <int N>
+__device__ __forceinline__ void exp_nonpos_n(const double (&x)[N], double (&e)[N]) {
+  double n[N], r[N], q[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    n[i] = __builtin_rint(x[i] * 1.4426950408889634074);
+    r[i] = __builtin_fma(n[i], -6.93147180369123816490e-01, x[i]);
+    r[i] = __builtin_fma(n[i], -1.90821492927058770002e-10, r[i]);
+    q[i] = kExpC[0];
+  }
+#pragma unroll
+  for (int c = 1; c < 12; ++c)
+#pragma unroll
+    for (int i = 0; i < N; ++i) q[i] = __builtin_fma(q[i], r[i], kExpC[c]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) e[i] = __builtin_ldexp(q[i], (int)n[i]);
+}
+
 __device__ __forceinline__ double exp_nonpos(double x) {
-  const double n = __builtin_rint(x * 1.4426950408889634074);
-  double r = __builtin_fma(n, -6.93147180369123816490e-01, x);
-  r = __builtin_fma(n, -1.90821492927058770002e-10, r);
-  double q = 2.50521083854417187751e-08;              // 1/11!
-  q = __builtin_fma(q, r, 2.75573192239858906526e-07);  // 1/10!
-  q = __builtin_fma(q, r, 2.75573192239858906526e-06);  // 1/9!
-  q = __builtin_fma(q, r, 2.48015873015873015873e-05);  // 1/8!
-  q = __builtin_fma(q, r, 1.98412698412698412698e-04);  // 1/7!
-  q = __builtin_fma(q, r, 1.38888888888888888889e-03);  // 1/6!
-  q = __builtin_fma(q, r, 8.33333333333333333333e-03);  // 1/5!
-  q = __builtin_fma(q, r, 4.16666666666666666667e-02);  // 1/4!
-  q = __builtin_fma(q, r, 1.66666666666666666667e-01);  // 1/3!
-  q = __builtin_fma(q, r, 0.5);
-  q = __builtin_fma(q, r, 1.0);
-  q = __builtin_fma(q, r, 1.0);
-  return __builtin_ldexp(q, (int)n);
+  const double xs[1] = {x};
+  double es[1];
+  exp_nonpos_n<1>(xs, es);
+  return es[0];
 }
 
 // a6 for one pair: OLS of log J on k over the leading run of usable points, fp64.  Every caller
@@ -326,12 +346,17 @@ __device__ __forceinline__ bool fit_rows_fixed(const PackT (&pk)[NR], const doub
     }
   }
   if (!__all(all_ok)) return false;
+  double x[2 * NR], e[2 * NR];
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
-    const double slope = ((double)NK * sxy[r] - p.sx_all * sy[r]) * p.inv_den_all;
-    const double icpt = (sy[r] - slope * p.sx_all) * p.inv_n_all;
-    core[r] = slope < 0.0 ? (float)(1.0 - exp_nonpos(slope)) : 0.0f;
-    acc[r] = icpt < 0.0 ? (float)(1.0 - exp_nonpos(icpt)) : 0.0f;
+    x[2 * r] = ((double)NK * sxy[r] - p.sx_all * sy[r]) * p.inv_den_all;      // slope
+    x[2 * r + 1] = (sy[r] - x[2 * r] * p.sx_all) * p.inv_n_all;               // intercept
+  }
+  exp_nonpos_n<2 * NR>(x, e);     // (for x > 0 the value is unused: the distance is clamped to 0)
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    core[r] = x[2 * r] < 0.0 ? (float)(1.0 - e[2 * r]) : 0.0f;
+    acc[r] = x[2 * r + 1] < 0.0 ? (float)(1.0 - e[2 * r + 1]) : 0.0f;
   }
   return true;
 }
@@ -875,12 +900,14 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
                                     : row0 + 1;
           float2 *o = static_cast<float2 *>(out);
           if (valid[2 * h] && valid[2 * h + 1] && !strip) {
-            float4 v;
+            // 16 bytes at 8-byte alignment: one global_store_dwordx4 (a 16-byte memcpy is split in two)
+            typedef float f32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+            f32x4_a8 v;
             v.x = core[2 * h];
             v.y = acc[2 * h];
             v.z = core[2 * h + 1];
             v.w = acc[2 * h + 1];
-            __builtin_memcpy(o + row0, &v, 16);
+            *reinterpret_cast<f32x4_a8 *>(o + row0) = v;
           } else {
             if (valid[2 * h]) o[row0] = make_float2(core[2 * h], acc[2 * h]);
             if (valid[2 * h + 1]) o[row1] = make_float2(core[2 * h + 1], acc[2 * h + 1]);
