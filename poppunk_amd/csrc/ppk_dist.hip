@@ -212,9 +212,9 @@ __device__ __forceinline__ double exp_nonpos(double x) {
 // (the tile epilogues' fast paths included) evaluates the SAME expressions in the same order, so a
 // pair's result does not depend on which kernel, tile, band or wavefront computed it: sums in k
 // order with sxy as an fma; when every k is usable the k-only sums are the launch constants.
-template <typename PackT>
+template <typename PackT, typename ParamsT>
 __device__ __forceinline__ void fit_packed(PackT pk, const double *__restrict__ lutp,
-                                           const DistParams &p, float &core, float &acc,
+                                           const ParamsT &p, float &core, float &acc,
                                            bool &failed) {
   const uint32_t cmask = (1u << p.cnt_bits) - 1u;
   double sx = 0.0, sxx = 0.0, sy = 0.0, sxy = 0.0;
@@ -256,9 +256,9 @@ __device__ __forceinline__ void fit_packed(PackT pk, const double *__restrict__ 
 // a6 for NR of the refs a lane holds against one query (v2 epilogue).  All NR x nk table gathers
 // are issued before the first is consumed: the table look-ups are the only memory latency in the
 // epilogue.
-template <typename PackT, int NR>
+template <typename PackT, int NR, typename ParamsT>
 __device__ __forceinline__ void fit_rows(const PackT (&pk)[NR], const double *const (&lutp)[NR],
-                                         const DistParams &p, float (&core)[NR], float (&acc)[NR],
+                                         const ParamsT &p, float (&core)[NR], float (&acc)[NR],
                                          bool (&failed)[NR]) {
   constexpr int KU = 5;   // k per gather batch (the default k list has 5)
   const uint32_t cmask = (1u << p.cnt_bits) - 1u;
@@ -306,7 +306,7 @@ __device__ __forceinline__ void fit_rows(const PackT (&pk)[NR], const double *co
   // some lane has a k below the 5/nbins floor: the general fit, one pair at a time (unrolled: a
   // rolled loop would index the operand arrays dynamically and push them into scratch)
 #pragma unroll
-  for (int r = 0; r < NR; ++r) fit_packed<PackT>(pk[r], lutp[r], p, core[r], acc[r], failed[r]);
+  for (int r = 0; r < NR; ++r) fit_packed(pk[r], lutp[r], p, core[r], acc[r], failed[r]);
 }
 
 
@@ -314,9 +314,9 @@ __device__ __forceinline__ void fit_rows(const PackT (&pk)[NR], const double *co
 // counts unpacked with uniform shifts, table look-ups as uniform base + 32-bit lane offset
 // (the saddr form of global_load).  Returns false -- nothing written -- when some lane of the
 // wavefront has an unusable k, and the caller takes the general path.
-template <typename PackT, int NR, int NK>
+template <typename PackT, int NR, int NK, typename ParamsT>
 __device__ __forceinline__ bool fit_rows_fixed(const PackT (&pk)[NR], const double *__restrict__ lut,
-                                               const uint32_t (&loff)[NR], const DistParams &p,
+                                               const uint32_t (&loff)[NR], const ParamsT &p,
                                                float (&core)[NR], float (&acc)[NR]) {
   const uint32_t cmask = (1u << p.cnt_bits) - 1u;
   const uint32_t kstride = (uint32_t)p.lut_kstride;
@@ -583,6 +583,8 @@ dist_kernel(const uint64_t *__restrict__ refT, const uint32_t *__restrict__ qryT
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int V2_R = 4, V2_TQ = 4, V2_RT = 256, V2_BB = 14;
+// byte offset of `DistParams p` in dist_kernel_v2's kernarg segment: nine 8-byte pointers precede it
+constexpr int V2_PARAMS_KERNARG_OFFSET = 9 * 8;
 
 // Non-empty tiles of ref tiles 0 .. r-1, in ref-tile-major order.  Rectangle: every ref tile pairs
 // with all q_tiles query tiles.  Triangle (self): ref tile i has a pair with r > q only for the
@@ -843,6 +845,17 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
   // ---- epilogue: regression (+ boundary) per pair ---------------------------
   if constexpr (MODE == MODE_DIST || MODE == MODE_MASK) {
     if (!wave_active || (p.ablate & 1)) return;
+    // The epilogue reads ~40 dwords of launch parameters the compare loop never touches.  Loaded
+    // HERE, through the kernarg segment pointer (DistParams is the 10th argument, after nine
+    // pointers; the offset is checked against the code object's metadata by tests/test_abi.py), they
+    // do not occupy SGPRs across the
+    // loop, where the kernel sits at the register limit.
+    const char __attribute__((address_space(4))) *ka =
+        (const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    typedef const __attribute__((address_space(4))) DistParams LateParams;
+    LateParams &p_late = *reinterpret_cast<LateParams *>(ka + V2_PARAMS_KERNARG_OFFSET);
+    auto epilogue = [&](LateParams &p) {
     int cr[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) cr[r] = (ref_clu && ref_of(r) < p.n_ref) ? ref_clu[ref_of(r)] : 0;
@@ -949,6 +962,8 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
       }
     }
     if (n_failed && n_fail_wave && lane == 0) atomicAdd(n_failed, (unsigned long long)n_fail_wave);
+    };
+    epilogue(p_late);
   }
 }
 

@@ -123,6 +123,18 @@ def test_hot_kernels_have_no_scratch_in_the_compare_loop(tmp_path):
                 assert scratch <= limit and vgprs <= 128, (name, scratch, vgprs)
     assert seen == 2
     text = open(asm).read()
+    # the epilogue reads DistParams through the kernarg segment pointer at a fixed offset
+    # (V2_PARAMS_KERNARG_OFFSET = 72): every dist_kernel_v2 instantiation must really have its
+    # by-value argument there
+    meta = text[text.index("amdhsa.kernels:"):]
+    n_v2 = 0
+    for blk in meta.split("  - .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        if name.startswith("_Z14dist_kernel_v2"):
+            n_v2 += 1
+            byval = re.search(r"- \.offset:\s+(\d+)\n\s+\.size:\s+(\d+)\n\s+\.value_kind:\s+by_value", blk)
+            assert byval and int(byval.group(1)) == 72, (name, byval and byval.group(0))
+    assert n_v2 >= 6
     for prefix in hot:
         m = re.search(r"^(%s\w*):[^\n]*\n(.*?)^\.Lfunc_end" % prefix, text, re.S | re.M)
         assert m, prefix
