@@ -1,0 +1,22 @@
+"""Throughput of the self job (distances resident, HIP-event kernel time) against n."""
+import os, sys, time, ctypes as C
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from poppunk_amd import _lib, engine, synth
+K = np.asarray(synth.DEFAULT_KMERS, dtype=np.int32); T = synth.random_match_table(K)
+lib = _lib.lib()
+sk, _ = synth.make_sketches(100000, K, seed=13)
+for n in (500, 1000, 2000, 5000, 10000, 20000, 50000, 100000):
+    db = engine.SketchDB(sk[:n], 16, 14)
+    rows = n * (n - 1) // 2
+    out = torch.empty((rows, 2), dtype=torch.float32, device="cuda")
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.15:
+        engine.dist(db, None, K, T, out=out); torch.cuda.synchronize()
+    reps = max(2, min(50, int(0.5 / max(rows / 16e9, 1e-5))))
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps): engine.dist(db, None, K, T, out=out)
+    torch.cuda.synchronize(); t = (time.perf_counter() - t0) / reps
+    print("n=%6d  pairs=%11d  %9.3f ms  %6.2f Gpairs/s  (%s)" % (n, rows, t * 1e3, rows / t / 1e9, lib.ppk_last_kernel_name().decode()))
+    del out; db.close(); torch.cuda.empty_cache()
