@@ -93,6 +93,7 @@ struct DistParams {
   int xcd_map;            // 1: XCD-aware tile order (v2)
   int lut32;              // the whole log-J table is addressable with 32-bit byte offsets
   int k_split;            // host side only: launch the KSPLIT instantiation (gridDim.y = nk, one k per workgroup)
+  size_t ks_rows;         // KSPLIT: rows of the band; its counts go to scratch k-major, [k][row]
   unsigned r_tiles, q_tiles;   // v2 tile grid
   unsigned n_strip_pad;        // n_strip rounded up to a multiple of 8 (keeps block % 8 = XCD for the rest)
   unsigned n_tiles;            // non-empty tiles of the triangle / rectangle part
@@ -812,7 +813,10 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
               if (valid) {
                 const size_t row = (p.self ? qq * p.n_ref - (qq * (qq + 1)) / 2 + (rf - qq - 1)
                                            : qq * p.n_ref + rf) - p.row_base;
-                if constexpr (MODE == MODE_COUNTS) {
+                if constexpr (MODE == MODE_COUNTS && KSPLIT) {
+                  // private k-major layout: consecutive lanes write consecutive rows
+                  static_cast<uint32_t *>(out)[(size_t)k * p.ks_rows + row] = cnt[r][q];
+                } else if constexpr (MODE == MODE_COUNTS) {
                   static_cast<uint32_t *>(out)[row * p.nk + k] = cnt[r][q];
                 } else {
                   double jr = 0.0;
@@ -1070,7 +1074,7 @@ regress_packed_kernel(const uint32_t *__restrict__ counts, size_t n_rows, const 
       cp = (size_t)ref_clu[r] * p.n_clu + (qry_clu ? qry_clu[q] : 0);
     }
     u128 pk = 0;
-    for (int k = 0; k < p.nk; ++k) pk |= (u128)counts[i * p.nk + k] << (p.cnt_bits * k);
+    for (int k = 0; k < p.nk; ++k) pk |= (u128)counts[(size_t)k * n_rows + i] << (p.cnt_bits * k);   // [k][row]
     float core, acc;
     fit_packed<u128>(pk, lut + cp * p.lut_cpstride, p, core, acc, failed);
     out[i] = make_float2(core, acc);
@@ -1290,13 +1294,13 @@ int ppk_launch_dist(const ppk_db *ref, const ppk_db *qry_or_null, const int32_t 
     return launch_tiles<MODE_JACCARD, uint64_t>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
 
   const bool too_wide = p.nk > PPK_MAX_NK || p.nk * p.cnt_bits > 128;
-  // Small jobs (fewer pair tiles than ~2/3 of the 512 workgroup slots, e.g. 1 000 genomes or a handful
+  // Small jobs (up to about one round of pair tiles on the 512 workgroup slots, e.g. 1 000 genomes or a handful
   // of queries): one workgroup per (tile, k) instead of per tile -- nk times the parallelism, a
   // serial chain of s64 blocks instead of nk * s64 -- writing raw counts, then the regression pass.
   bool small = false;
   if (!too_wide && !d_mask && p.bbits == 14 && p.nk >= 2) {
     const size_t rt = (ref->n + V2_RT - 1) / V2_RT, qt = (q_end - q_begin + 31) / 32;
-    size_t limit = 352;   // measured: 2 000 self (315 tiles) 230 vs 260 us, 2 500 self (480 tiles) 329 vs 264 us
+    size_t limit = 640;   // measured: 2 000 self (315 tiles) 175 vs 245 us, 2 500 self (480 tiles) 255 vs 252 us, 3 000 (760) 361 vs 368
     if (const char *e = getenv("PPK_KSPLIT")) limit = (size_t)atoi(e);   // A/B: tile-count threshold, 0 = off
     small = (p.self ? rt * qt / 2 + qt : rt * qt) <= limit;
   }
@@ -1338,6 +1342,7 @@ int ppk_launch_dist(const ppk_db *ref, const ppk_db *qry_or_null, const int32_t 
     int rc = ppk_scratch_get(ref->device, SLOT_ITER_A, rows * (size_t)p.nk * 4 + 256, &p_cnt);
     if (rc != PPK_OK) return rc;
     p.k_split = 1;
+    p.ks_rows = rows;
     rc = launch_tiles<MODE_COUNTS, uint64_t>(ref, qry, d_lut, d_rtab, p_cnt, nullptr, nullptr, p, s);
     if (rc != PPK_OK) return rc;
     const bool use_clu = p.random_correct && p.n_clu > 1;

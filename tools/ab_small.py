@@ -14,11 +14,11 @@ def timed(fn, reps=200):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(reps): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps
-o = torch.empty((8000000, 2), dtype=torch.float32, device="cuda")
+o = torch.empty((13000000, 2), dtype=torch.float32, device="cuda")
 print("PPK_KSPLIT=%s" % os.environ.get("PPK_KSPLIT", "default"))
 print("  1000 self           : %.1f us" % (timed(lambda: engine.dist(db1, None, K, T, out=o[:499500])) * 1e6))
 for nq, d in dbq.items():
     print("  %2d queries x 10k refs: %.1f us" % (nq, timed(lambda: engine.dist(db10, d, K, T, out=o[:10000 * nq])) * 1e6))
-for n in (1500, 2000, 2500, 3000, 4000):
+for n in (1500, 2000, 2500, 3000, 3500, 4000, 5000):
     d = engine.SketchDB(sk[:n], 16, 14)
     print("  %d self : %.1f us" % (n, timed(lambda: engine.dist(d, None, K, T, out=o[:n * (n - 1) // 2]), reps=100) * 1e6))
