@@ -103,15 +103,21 @@ ti1_candidate_mask_kernel(const float *__restrict__ d0, size_t n_rows,
 }
 
 __global__ void __launch_bounds__(256)
-ti1_gather_keys_kernel(const unsigned long long *__restrict__ rows, size_t n_cand,
-                       const float *__restrict__ d0, float *__restrict__ keys) {
+ti1_gather_keys_kernel(unsigned long long *__restrict__ rows, size_t n_cand,
+                       const float *__restrict__ d0, const unsigned short *__restrict__ first,
+                       float *__restrict__ keys) {
+  // key = distance to the first boundary; the row's `first` rides in bits 54.. of the sorted value
+  // (rows < 2^54), so the passes after the sort read it in order instead of gathering it
   const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (p < n_cand) keys[p] = d0[rows[p]];
+  if (p < n_cand) {
+    const unsigned long long row = rows[p];
+    keys[p] = d0[row];
+    rows[p] = row | ((unsigned long long)first[row] << 54);
+  }
 }
 
 __global__ void __launch_bounds__(256)
-ti1_stops_kernel(const unsigned long long *__restrict__ sorted_rows, size_t n_cand,
-                 const unsigned short *__restrict__ first, int n_off,
+ti1_stops_kernel(const unsigned long long *__restrict__ sorted_rows, size_t n_cand, int n_off,
                  unsigned long long *__restrict__ g) {
   // Position p stops the sweep of every offset o < f(p), so g[o] = min{p : f(p) > o}.  One
   // conditional atomicMin per position on m[f] = min{p : f(p) = f} (held in g2[1..n_off]); the
@@ -123,11 +129,15 @@ ti1_stops_kernel(const unsigned long long *__restrict__ sorted_rows, size_t n_ca
   __syncthreads();
   const size_t base = (size_t)blockIdx.x * 256;
   const size_t p = base + threadIdx.x;
+  int f = 0;
   if (p < n_cand) {
-    int f = first[sorted_rows[p]];
+    f = (int)(sorted_rows[p] >> 54);
     if (f > n_off) f = n_off;
-    if (f > 0) atomicMin(&ms[f], (unsigned)threadIdx.x);
   }
+  // positions are sorted by the distance `first` grows with, so runs of equal f are long: only the
+  // first lane of a run (within its wavefront) can be the minimum and touches the LDS
+  const int prev = __shfl_up(f, 1, 64);
+  if (f > 0 && ((threadIdx.x & 63) == 0 || prev != f)) atomicMin(&ms[f], (unsigned)threadIdx.x);
   __syncthreads();
   for (int o = 1 + threadIdx.x; o <= n_off; o += 256) {
     const unsigned m = ms[o];
@@ -169,7 +179,7 @@ ti1_emit_kernel(const unsigned long long *__restrict__ sorted_rows, size_t n_can
   if (p >= n_emit || p >= cap) return;
   int o = 0;
   while (o < n_off - 1 && p >= g[o]) ++o;
-  const size_t row = sorted_rows[p];
+  const size_t row = sorted_rows[p] & ((1ull << 54) - 1);
   const size_t i = crow_idx(row, n_samples);
   oi[p] = (long long)i;
   oj[p] = (long long)(row - crow_start(i, n_samples) + i + 1);
@@ -188,7 +198,7 @@ __global__ void ti1_serial_kernel(const unsigned long long *__restrict__ sorted_
   size_t p = 0;
   for (int o = 0; o < b.n && p < n_cand; ++o) {
     while (p < n_cand) {
-      const size_t row = sorted_rows[p];
+      const size_t row = sorted_rows[p] & ((1ull << 54) - 1);
       const float2 d = dist[row];
       if (!(ppk_line_dist(d.x, d.y, b.x_max[o], b.y_max[o], b.slope) <= 0.0f)) break;
       if (p < cap) {
@@ -344,7 +354,7 @@ extern "C" int ppk_threshold_iterate_1d_dev(const float *d_dist, size_t n_rows,
                           reinterpret_cast<long long *>(rows_in), (size_t)n_cand, d_n_out, s);
   if (rc != PPK_OK) return rc;
   hipLaunchKernelGGL(ti1_gather_keys_kernel, dim3(nblk(n_cand)), dim3(256), 0, s, rows_in,
-                     (size_t)n_cand, d0, keys_in);
+                     (size_t)n_cand, d0, first, keys_in);
   size_t tmp_bytes = 0;
   PPK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys_in, keys_out, rows_in, rows_out,
                                              (int)n_cand, 0, 32, s));
@@ -361,7 +371,7 @@ extern "C" int ppk_threshold_iterate_1d_dev(const float *d_dist, size_t n_rows,
   }
   hipLaunchKernelGGL(fill_u64_kernel, dim3(nblk(2 * n_off + 1)), dim3(256), 0, s, g, 2 * n_off + 1, n_cand);
   hipLaunchKernelGGL(ti1_stops_kernel, dim3(nblk(n_cand)), dim3(256), 0, s, rows_out, (size_t)n_cand,
-                     first, (int)n_off, g);
+                     (int)n_off, g);
   hipLaunchKernelGGL(ti1_suffix_min_kernel, dim3(1), dim3(64), 0, s, g, (int)n_off);
   hipLaunchKernelGGL(ti1_emit_kernel, dim3(nblk(n_cand)), dim3(256), 0, s, rows_out, (size_t)n_cand,
                      (int)n_off, g, n_samples, d_i, d_j, d_off, cap, d_n_out);
