@@ -49,6 +49,19 @@ __device__ __forceinline__ void pack_zero(Pack96 &pk) { pk.w0 = pk.w1 = pk.w2 = 
 template <typename P> __device__ __forceinline__ void pack_put(P &pk, uint32_t c, int k, int bits) {
   pk |= (P)c << (bits * k);
 }
+// 64-bit packs are updated as two dwords with the wave-uniform shift: a 64-bit shift of the count
+// needs an even-aligned register pair around it, one register more than the compare loop has
+__device__ __forceinline__ void pack_put(uint64_t &pk, uint32_t c, int k, int bits) {
+  const int sh = bits * k;
+  uint32_t lo = (uint32_t)pk, hi = (uint32_t)(pk >> 32);
+  if (sh < 32) {
+    lo |= c << sh;
+    hi |= (c >> 1) >> (31 - sh);
+  } else {
+    hi |= c << (sh - 32);
+  }
+  pk = ((uint64_t)hi << 32) | lo;
+}
 __device__ __forceinline__ void pack_put(Pack96 &pk, uint32_t c, int k, int) {
   const uint32_t x = c << (16 * (k & 1));
   const int j = k >> 1;             // wave-uniform: selects, not indexed registers
@@ -701,10 +714,14 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
   const size_t qw0 = q0 + (size_t)wave * TQ;
   const bool tri = p.self && !strip;              // upper-triangle tile: pairs need r > q
   if (tri && r0 + (V2_RT - 1) <= q0) return;      // no pair with r > q in this tile
+  // diagonal tile whose queries all lie beyond the first 128 refs: the lanes' refs 0/1 pair with
+  // nothing, so their rows are neither copied nor compared (8-wave shape)
+  const bool half = NW == 8 && tri && q0 >= r0 + 128;
   const bool wave_active = !(tri && r0 + (V2_RT - 1) <= qw0) && qw0 < qe && qw0 + TQ > qb;
   // lane l owns refs r0 + {2l, 2l+1, 128+2l, 128+2l+1}: two conflict-free ds_read_b128 per plane
   // (recomputed where needed rather than kept live across the compare loop)
-  auto ref_of = [&](int r) -> size_t { return r0 + 2 * lane + (r & 1) + (r >> 1) * 128; };
+  int lane_late = lane;   // DIST / MASK: re-derived after the loop, see below
+  auto ref_of = [&](int r) -> size_t { return r0 + 2 * lane_late + (r & 1) + (r >> 1) * 128; };
 
   // one chunk per (k, 64-bin block); with k_split a workgroup owns the chunks of k = blockIdx.y only
   // (a template parameter, not a launch parameter: the tile kernels sit at the SGPR limit and one
@@ -745,12 +762,15 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
   const uint32_t voff_qry = (uint32_t)((lane / LPP) * p.npad_q * 8) + (lane % LPP) * 16;
   // the last query piece may hold fewer than PPP rows (14 is not a multiple of 4)
   const bool qlane_ok = (PPP * (NQP - 1) + lane / LPP) < BB;
-  auto issue_dma = [&](int buf) {
+  // skip_first_half: a half tile does not copy the even ref pieces (samples 0..127 of each row);
+  // with 8 waves piece parity is wave parity
+  auto issue_dma = [&](int buf, bool skip_first_half) {
     u32x4 *base = lds + buf * CHUNK_U4;
 #pragma unroll
     for (int t = 0; t < PW; ++t) {
       if (dkind[t] == 0) {
-        __builtin_amdgcn_global_load_lds(PPK_GPTR(dbase[t] + voff_ref), PPK_LPTR(base + doff[t]), 16, 0, 0);
+        if (!(skip_first_half && (wave & 1) == 0))
+          __builtin_amdgcn_global_load_lds(PPK_GPTR(dbase[t] + voff_ref), PPK_LPTR(base + doff[t]), 16, 0, 0);
       } else if (dkind[t] == 1 && (wave + NW * t != NPIECE - 1 || qlane_ok)) {
         __builtin_amdgcn_global_load_lds(PPK_GPTR(dbase[t] + voff_qry), PPK_LPTR(base + doff[t]), 16, 0, 0);
       }
@@ -768,21 +788,25 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
       pack_zero(packed[r][q]);
     }
 
-  issue_dma(0);
+  issue_dma(0, half);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
+  // the whole loop is instantiated twice (full / half block) rather than branching around the two
+  // instruction streams inside it: a live `half` flag costs the one register the loop does not have
+  auto compare_loop = [&](auto half_tag) {
+  constexpr bool HALF = decltype(half_tag)::value;
   int k = k_first, blk = 0;
   for (int g = 0; g < total; ++g) {
     const int buf = g & 1;
     // the other buffer was last read in iteration g-1, which every wave left through the barrier
-    if (g + 1 < total && !(p.ablate & 4)) issue_dma(buf ^ 1);
+    if (g + 1 < total && !(p.ablate & 4)) issue_dma(buf ^ 1, HALF);
 
     if (wave_active && !(p.ablate & 2)) {
       // One 64-bin block of the 4x4 register tile: 14 x (4 ds_read_b128 + 32 v_bitop3) + 32
       // v_bcnt, as the generated bank-aware instruction stream (tools/gen_block_asm.py).
       const uint32_t rp =
-          (uint32_t)(size_t)(__attribute__((address_space(3))) void *)(lds + buf * CHUNK_U4 + lane);
+          (uint32_t)(size_t)(__attribute__((address_space(3))) void *)(lds + buf * CHUNK_U4) + voff_ref;
       const uint32_t qp = (uint32_t)(size_t)(__attribute__((address_space(3))) void *)(
           lds + buf * CHUNK_U4 + REF_U4 + wave * 2);
 #define PPK_BLOCK_OPERANDS                                                                   \
@@ -791,8 +815,12 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
       [c8] "+v"(cnt[2][0]), [c9] "+v"(cnt[2][1]), [c10] "+v"(cnt[2][2]), [c11] "+v"(cnt[2][3]), \
       [c12] "+v"(cnt[3][0]), [c13] "+v"(cnt[3][1]), [c14] "+v"(cnt[3][2]), [c15] "+v"(cnt[3][3])
       if constexpr (NW == 8) {
-        asm volatile(PPK_BLOCK_ASM_Q32 : PPK_BLOCK_OPERANDS : [rp] "v"(rp), [qp] "v"(qp)
-                     : "memory", PPK_BLOCK_CLOBBERS);
+        if constexpr (HALF)
+          asm volatile(PPK_BLOCK_HALF_ASM_Q32 : PPK_BLOCK_OPERANDS : [rp] "v"(rp), [qp] "v"(qp)
+                       : "memory", PPK_BLOCK_CLOBBERS);
+        else
+          asm volatile(PPK_BLOCK_ASM_Q32 : PPK_BLOCK_OPERANDS : [rp] "v"(rp), [qp] "v"(qp)
+                       : "memory", PPK_BLOCK_CLOBBERS);
       } else {
         asm volatile(PPK_BLOCK_ASM_Q64 : PPK_BLOCK_OPERANDS : [rp] "v"(rp), [qp] "v"(qp)
                      : "memory", PPK_BLOCK_CLOBBERS);
@@ -845,10 +873,22 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
       __builtin_amdgcn_s_barrier();
     }
   }
+  };
+  if (half)
+    compare_loop(std::true_type{});
+  else
+    compare_loop(std::false_type{});
 
   // ---- epilogue: regression (+ boundary) per pair ---------------------------
   if constexpr (MODE == MODE_DIST || MODE == MODE_MASK) {
     if (!wave_active || (p.ablate & 1)) return;
+    {
+      // the loop keeps ONE lane-derived register (voff_ref = 16 * lane); the lane index itself is
+      // recovered from it here, opaquely, so that it is not held live across the loop as well
+      uint32_t t = voff_ref;
+      asm volatile("" : "+v"(t));
+      lane_late = (int)(t >> 4);
+    }
     // The epilogue reads ~40 dwords of launch parameters the compare loop never touches.  Loaded
     // HERE, through the kernarg segment pointer (DistParams is the 10th argument, after nine
     // pointers; the offset is checked against the code object's metadata by tests/test_abi.py), they
@@ -877,6 +917,11 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
       // `valid` only gates what is written.  Two refs (2 x nk gathers in flight) at a time.
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
+        if (half && h == 0) {        // refs 0/1 were not compared: nothing valid, nothing to fit
+          valid[0] = valid[1] = failed[0] = failed[1] = false;
+          core[0] = core[1] = acc[0] = acc[1] = 0.0f;
+          continue;
+        }
         const double *lutp[2];
         uint32_t loff[2];
         PackT pk[2];
@@ -952,7 +997,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
       if constexpr (MODE == MODE_MASK) {
         // ball[0]/ball[1]: even/odd refs of r0..r0+127; ball[2]/ball[3]: of r0+128..r0+255.
         // Interleave them into the [q][ref/64] bitmask words the compaction pass reads.
-        if (lane == 0 && !strip) {
+        if (lane_late == 0 && !strip) {
           uint64_t *mrow = mask_out + (qq - qb) * p.n_rtiles + rt * 4;
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
@@ -965,7 +1010,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
         }
       }
     }
-    if (n_failed && n_fail_wave && lane == 0) atomicAdd(n_failed, (unsigned long long)n_fail_wave);
+    if (n_failed && n_fail_wave && lane_late == 0) atomicAdd(n_failed, (unsigned long long)n_fail_wave);
     };
     epilogue(p_late);
   }

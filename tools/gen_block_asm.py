@@ -56,7 +56,7 @@ REF_PLANE_BYTES = 2048      # 256 samples x 8 B
 REF_HALF_BYTES = 1024
 
 
-def gen(QRY_PLANE_BYTES, TQ=4, dma_planes=None):
+def gen(QRY_PLANE_BYTES, TQ=4, dma_planes=None, half=False):
     """TQ = 4: counters %[c0]..%[c15], one per pair (p = 4r + q).
     TQ = 8: counters %[c0]..%[c15], two pairs per counter (pair p = 8r + q -> counter p >> 1,
     16-bit half p & 1; a block adds at most 64 and a k at most 16 * 64 per pair ... callers
@@ -115,6 +115,27 @@ def gen(QRY_PLANE_BYTES, TQ=4, dma_planes=None):
                     else:
                         emit("v_bitop3_b32 v%d, v%d, v%d, v%d bitop3:0x90" % (acc, acc, a, s))
 
+    if half:
+        # Diagonal tiles whose queries all lie beyond the tile's first 128 refs: refs 0/1 of every
+        # lane pair with nothing, so only refs 2/3 (the a1 operands) are compared: half the stream.
+        load_s(0)
+        load_a1(0)
+        for b in range(BB):
+            last = b == BB - 1
+            if not last:
+                load_s(b + 1)
+                emit("s_waitcnt lgkmcnt(%d)" % NS)     # s(b), a1(b) landed; s(b+1) may be pending
+            else:
+                emit("s_waitcnt lgkmcnt(0)")
+            ops(b, (2, 3))
+            if not last:
+                load_a1(b + 1)
+        for r in (2, 3):
+            for q in range(TQ):
+                p = TQ * r + q
+                emit("v_bcnt_u32_b32 %%[c%d], v%d, %%[c%d]" % (p, lo_acc(r, q), p))
+                emit("v_bcnt_u32_b32 %%[c%d], v%d, %%[c%d]" % (p, hi_acc(r, q), p))
+        return out
     # prologue: s(0), a0(0), a1(0)
     load_s(0)
     load_a0(0)
@@ -178,6 +199,13 @@ def main():
             f.write('  "%s\\n" \\\n' % ln)
         f.write("  \"\"\n")
         print("wrote PPK_BLOCK_DMA_ASM_Q32", len(lines), "instructions")
+        lines = gen(256, 4, half=True)
+        f.write("// refs 2/3 only (diagonal tiles with every query beyond the first 128 refs)\n")
+        f.write("#define PPK_BLOCK_HALF_ASM_Q32 \\\n")
+        for ln in lines:
+            f.write('  "%s\\n" \\\n' % ln)
+        f.write("  \"\"\n")
+        print("wrote PPK_BLOCK_HALF_ASM_Q32", len(lines), "instructions")
         f.write("#define PPK_BLOCK_ASM PPK_BLOCK_ASM_Q32\n")
         f.write("#define PPK_BLOCK_CLOBBERS %s\n" % clob)
         f.write("// 4x8 register tile (v%d..v%d): 16 counters, two 16-bit pair counts each\n" % (m8.A0, m8.END - 1))
