@@ -38,29 +38,27 @@
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned __int128 u128;
 
-// Per-pair shift register of the per-k match counts.  uint64 / u128: count k at bit k * cnt_bits.
-// Pack96: up to six 16-bit counts in three dwords (the default PopPUNK sketch size, s = 9984, needs
-// 14 bits x 5 or 6 k: 48 VGPRs per lane for the 16 pairs instead of the 64 of u128, which spilled).
+// Per-pair record of the per-k match counts.
+//  * integer packs (uint64 / u128; Pack96 = six 16-bit counts in three dwords): count k at bit
+//    k * cnt_bits -- the generic-bbits kernel and the small-job regression pass;
+//  * PackW<W>: W dwords used as ONE shift register by the LDS-DMA tile kernel.  The running count
+//    of the current k lives in the low cnt_bits bits (v_bcnt accumulates straight into dword 0,
+//    and a count never exceeds nbins < 2^cnt_bits, so it cannot carry into its neighbour); at the
+//    start of the next k the whole register moves up by cnt_bits.  Count k therefore ends at bit
+//    (nk - 1 - k) * cnt_bits.  There are no separate counter registers: the 16 pairs of a lane
+//    need 16 * W VGPRs (32 for the default 5 k x 11 bits, 64 at the 128-bit limit), all of which
+//    fit beside the instruction stream's fixed registers -- dwords, not 64-bit values, because
+//    those would each need an even-aligned register pair.
 struct Pack96 {
   uint32_t w0, w1, w2;
+};
+template <int W> struct PackW {
+  uint32_t w[W];
 };
 template <typename P> __device__ __forceinline__ void pack_zero(P &pk) { pk = 0; }
 __device__ __forceinline__ void pack_zero(Pack96 &pk) { pk.w0 = pk.w1 = pk.w2 = 0u; }
 template <typename P> __device__ __forceinline__ void pack_put(P &pk, uint32_t c, int k, int bits) {
   pk |= (P)c << (bits * k);
-}
-// 64-bit packs are updated as two dwords with the wave-uniform shift: a 64-bit shift of the count
-// needs an even-aligned register pair around it, one register more than the compare loop has
-__device__ __forceinline__ void pack_put(uint64_t &pk, uint32_t c, int k, int bits) {
-  const int sh = bits * k;
-  uint32_t lo = (uint32_t)pk, hi = (uint32_t)(pk >> 32);
-  if (sh < 32) {
-    lo |= c << sh;
-    hi |= (c >> 1) >> (31 - sh);
-  } else {
-    hi |= c << (sh - 32);
-  }
-  pk = ((uint64_t)hi << 32) | lo;
 }
 __device__ __forceinline__ void pack_put(Pack96 &pk, uint32_t c, int k, int) {
   const uint32_t x = c << (16 * (k & 1));
@@ -69,13 +67,31 @@ __device__ __forceinline__ void pack_put(Pack96 &pk, uint32_t c, int k, int) {
   pk.w1 |= j == 1 ? x : 0u;
   pk.w2 |= j == 2 ? x : 0u;
 }
-template <typename P> __device__ __forceinline__ uint32_t pack_get(const P &pk, int k, int bits, uint32_t mask) {
+// pack_get(pack, k, cnt_bits, mask, nk)
+template <typename P> __device__ __forceinline__ uint32_t pack_get(const P &pk, int k, int bits, uint32_t mask, int) {
   return (uint32_t)(pk >> (bits * k)) & mask;
 }
-__device__ __forceinline__ uint32_t pack_get(const Pack96 &pk, int k, int, uint32_t) {
+__device__ __forceinline__ uint32_t pack_get(const Pack96 &pk, int k, int, uint32_t, int) {
   const int j = k >> 1;
   const uint32_t w = j == 0 ? pk.w0 : (j == 1 ? pk.w1 : pk.w2);
   return (w >> (16 * (k & 1))) & 0xffffu;
+}
+template <int W> __device__ __forceinline__ uint32_t pack_get(const PackW<W> &pk, int k, int bits, uint32_t mask, int nk) {
+  const int pos = (nk - 1 - k) * bits;      // wave-uniform: the dword choice is a select
+  const int j = pos >> 5;
+  uint32_t lo = pk.w[0], hi = W > 1 ? pk.w[W > 1 ? 1 : 0] : 0u;
+#pragma unroll
+  for (int i = 1; i < W; ++i)
+    if (j == i) {
+      lo = pk.w[i];
+      hi = i + 1 < W ? pk.w[i + 1 < W ? i + 1 : i] : 0u;
+    }
+  return __builtin_amdgcn_alignbit(hi, lo, pos & 31) & mask;
+}
+// two dwords: one 64-bit shift (the epilogue is free to hold the register as an aligned pair)
+__device__ __forceinline__ uint32_t pack_get(const PackW<2> &pk, int k, int bits, uint32_t mask, int nk) {
+  const uint64_t v = ((uint64_t)pk.w[1] << 32) | pk.w[0];
+  return (uint32_t)(v >> ((nk - 1 - k) * bits)) & mask;
 }
 
 enum { MODE_DIST = 0, MODE_JACCARD = 1, MODE_COUNTS = 2, MODE_MASK = 3 };
@@ -235,7 +251,7 @@ __device__ __forceinline__ void fit_packed(PackT pk, const double *__restrict__ 
   int n = 0;
   bool open = true;
   for (int k = 0; k < p.nk; ++k) {
-    const uint32_t c = pack_get(pk, k, p.cnt_bits, cmask);
+    const uint32_t c = pack_get(pk, k, p.cnt_bits, cmask, p.nk);
     const double y = lutp[(size_t)k * p.lut_kstride + c];
     open = open && (y <= 0.0);
     if (open) {
@@ -287,7 +303,7 @@ __device__ __forceinline__ void fit_rows(const PackT (&pk)[NR], const double *co
       const int k = (k0 + i < p.nk) ? k0 + i : p.nk - 1;   // wave-uniform; surplus slots re-read the last k
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
-        const uint32_t c = pack_get(pk[r], k, p.cnt_bits, cmask);
+        const uint32_t c = pack_get(pk[r], k, p.cnt_bits, cmask, p.nk);
         y[r][i] = lutp[r][(size_t)k * p.lut_kstride + c];
       }
     }
@@ -340,7 +356,7 @@ __device__ __forceinline__ bool fit_rows_fixed(const PackT (&pk)[NR], const doub
   for (int k = 0; k < NK; ++k) {
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
-      const uint32_t c = pack_get(pk[r], k, p.cnt_bits, cmask);
+      const uint32_t c = pack_get(pk[r], k, p.cnt_bits, cmask, p.nk);
       const uint32_t boff = (loff[r] + (uint32_t)k * kstride + c) * 8u;
       y[r][k] = *reinterpret_cast<const double *>(base + boff);
     }
@@ -634,7 +650,9 @@ __device__ __forceinline__ unsigned tiles_before(unsigned r, int self, unsigned 
 
 // NW = wavefronts per workgroup: 8 (256 x 32 tile, 2 workgroups per CU) or 16 (256 x 64 tile,
 // 1 workgroup per CU: half the ref traffic per pair, one s_barrier over 16 wavefronts)
-template <int NW, int MODE, typename PackT, bool KSPLIT = false>
+// W = dwords of the per-pair count register (1 in the COUNTS / JACCARD modes, which consume each
+// k's counts at once)
+template <int NW, int MODE, int W, bool KSPLIT = false>
 __global__ void __launch_bounds__(NW * 64, 4)
 dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ qryT,
                const double *__restrict__ lut, const uint16_t *__restrict__ ref_clu,
@@ -778,15 +796,14 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
     }
   };
 
-  uint32_t cnt[R][TQ];
-  PackT packed[R][TQ];
+  using PackT = PackW<W>;
+  uint32_t pw[W][R][TQ];      // the count registers, dword-major; pw[0] counts the current k
 #pragma unroll
-  for (int r = 0; r < R; ++r)
+  for (int i = 0; i < W; ++i)
 #pragma unroll
-    for (int q = 0; q < TQ; ++q) {
-      cnt[r][q] = 0;
-      pack_zero(packed[r][q]);
-    }
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int q = 0; q < TQ; ++q) pw[i][r][q] = 0;
 
   issue_dma(0, half);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -809,11 +826,14 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
           (uint32_t)(size_t)(__attribute__((address_space(3))) void *)(lds + buf * CHUNK_U4) + voff_ref;
       const uint32_t qp = (uint32_t)(size_t)(__attribute__((address_space(3))) void *)(
           lds + buf * CHUNK_U4 + REF_U4 + wave * 2);
+// The counters are pinned to v56..v71 in the order that keeps every v_bcnt's two VGPR sources (the
+// stream's accumulator v96+2j / v97+2j and counter j) in different register banks: left to the
+// allocator, 7 of the 32 v_bcnt of a block collided.
 #define PPK_BLOCK_OPERANDS                                                                   \
-  [c0] "+v"(cnt[0][0]), [c1] "+v"(cnt[0][1]), [c2] "+v"(cnt[0][2]), [c3] "+v"(cnt[0][3]),       \
-      [c4] "+v"(cnt[1][0]), [c5] "+v"(cnt[1][1]), [c6] "+v"(cnt[1][2]), [c7] "+v"(cnt[1][3]),   \
-      [c8] "+v"(cnt[2][0]), [c9] "+v"(cnt[2][1]), [c10] "+v"(cnt[2][2]), [c11] "+v"(cnt[2][3]), \
-      [c12] "+v"(cnt[3][0]), [c13] "+v"(cnt[3][1]), [c14] "+v"(cnt[3][2]), [c15] "+v"(cnt[3][3])
+  [c0] "+{v58}"(pw[0][0][0]), [c1] "+{v56}"(pw[0][0][1]), [c2] "+{v59}"(pw[0][0][2]), [c3] "+{v57}"(pw[0][0][3]), \
+      [c4] "+{v62}"(pw[0][1][0]), [c5] "+{v60}"(pw[0][1][1]), [c6] "+{v63}"(pw[0][1][2]), [c7] "+{v61}"(pw[0][1][3]), \
+      [c8] "+{v66}"(pw[0][2][0]), [c9] "+{v64}"(pw[0][2][1]), [c10] "+{v67}"(pw[0][2][2]), [c11] "+{v65}"(pw[0][2][3]), \
+      [c12] "+{v70}"(pw[0][3][0]), [c13] "+{v68}"(pw[0][3][1]), [c14] "+{v71}"(pw[0][3][2]), [c15] "+{v69}"(pw[0][3][3])
       if constexpr (NW == 8) {
         if constexpr (HALF)
           asm volatile(PPK_BLOCK_HALF_ASM_Q32 : PPK_BLOCK_OPERANDS : [rp] "v"(rp), [qp] "v"(qp)
@@ -828,14 +848,27 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
 #undef PPK_BLOCK_OPERANDS
 
       if (blk == p.s64 - 1) {
-        // ---- end of one k: consume the counts ----------------------------------
+        // ---- end of one k --------------------------------------------------------
+        if constexpr (MODE == MODE_DIST || MODE == MODE_MASK) {
+          // another k follows: the count register moves up by one field
+          if (k + 1 < p.nk) {
+            const int up = 32 - p.cnt_bits;
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+              for (int q = 0; q < TQ; ++q) {
+#pragma unroll
+                for (int i = W - 1; i > 0; --i)
+                  pw[i][r][q] = __builtin_amdgcn_alignbit(pw[i][r][q], pw[i - 1][r][q], up);
+                pw[0][r][q] <<= p.cnt_bits;
+              }
+          }
+        } else {
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
           for (int q = 0; q < TQ; ++q) {
-            if constexpr (MODE == MODE_DIST || MODE == MODE_MASK) {
-              pack_put(packed[r][q], cnt[r][q], k, p.cnt_bits);
-            } else {
+            {
               const size_t qq = qw0 + q, rf = ref_of(r);
               const bool valid = rf < p.r_limit && qq >= qb && qq < qe && (!p.self || rf > qq);
               if (valid) {
@@ -843,9 +876,9 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
                                            : qq * p.n_ref + rf) - p.row_base;
                 if constexpr (MODE == MODE_COUNTS && KSPLIT) {
                   // private k-major layout: consecutive lanes write consecutive rows
-                  static_cast<uint32_t *>(out)[(size_t)k * p.ks_rows + row] = cnt[r][q];
+                  static_cast<uint32_t *>(out)[(size_t)k * p.ks_rows + row] = pw[0][r][q];
                 } else if constexpr (MODE == MODE_COUNTS) {
-                  static_cast<uint32_t *>(out)[row * p.nk + k] = cnt[r][q];
+                  static_cast<uint32_t *>(out)[row * p.nk + k] = pw[0][r][q];
                 } else {
                   double jr = 0.0;
                   if (p.random_correct) {
@@ -854,12 +887,13 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
                     jr = (double)rtab[((size_t)k * p.n_clu + cr) * p.n_clu + cq];
                   }
                   static_cast<float *>(out)[row * p.nk + k] =
-                      (float)observed_excess(jaccard_obs(cnt[r][q], p.s64, BB), jr);
+                      (float)observed_excess(jaccard_obs(pw[0][r][q], p.s64, BB), jr);
                 }
               }
             }
-            cnt[r][q] = 0;
+            pw[0][r][q] = 0;
           }
+        }
       }
     }
     if (++blk == p.s64) {
@@ -882,6 +916,21 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
   // ---- epilogue: regression (+ boundary) per pair ---------------------------
   if constexpr (MODE == MODE_DIST || MODE == MODE_MASK) {
     if (!wave_active || (p.ablate & 1)) return;
+    // Cut every count register's live range here: whatever the register allocator decides for the
+    // epilogue (which has all 128 VGPRs but wants many of them for fp64) must not reach back into
+    // the compare loop -- a register spilled "for its whole life" is read-modified-written in
+    // scratch at every k, behind an s_waitcnt that also waits for the prefetch DMA.
+#pragma unroll
+    for (int i = 0; i < W; ++i)
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int q = 0; q < TQ; ++q) {
+          // a real move: a tied "+v" operand is coalesced back into one live range
+          uint32_t t;
+          asm volatile("v_mov_b32 %0, %1" : "=v"(t) : "v"(pw[i][r][q]));
+          pw[i][r][q] = t;
+        }
     {
       // the loop keeps ONE lane-derived register (voff_ref = 16 * lane); the lane index itself is
       // recovered from it here, opaquely, so that it is not held live across the loop as well
@@ -938,7 +987,8 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
           const size_t cp = (size_t)(strip ? cq * p.n_clu + cr[r] : cr[r] * p.n_clu + cq) * p.lut_cpstride;
           lutp[j] = lut + cp;
           loff[j] = (uint32_t)cp;
-          pk[j] = packed[r][q];
+#pragma unroll
+          for (int i = 0; i < W; ++i) pk[j].w[i] = pw[i][r][q];
         }
         if (!(p.nk == 5 && p.lut32 && fit_rows_fixed<PackT, 2, 5>(pk, lut, loff, p, c2, a2)))
           fit_rows<PackT, 2>(pk, lutp, p, c2, a2, f2);
@@ -1160,7 +1210,7 @@ int launch_variant(const ppk_db *ref, const ppk_db *qry, const double *d_lut, co
   return PPK_OK;
 }
 
-template <int NW, int MODE, typename PackT>
+template <int NW, int MODE, int W>
 int launch_v2(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const float *d_rtab,
               void *d_out, unsigned long long *d_n_failed, uint64_t *d_mask, DistParams &p,
               hipStream_t s) {
@@ -1220,12 +1270,12 @@ int launch_v2(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const f
   ppk_prof_begin(s);
   if (MODE == MODE_COUNTS && NW == 8 && p.k_split) {
     if constexpr (MODE == MODE_COUNTS && NW == 8)
-      hipLaunchKernelGGL((dist_kernel_v2<NW, MODE, PackT, true>), dim3((unsigned)n_blocks, (unsigned)p.nk),
+      hipLaunchKernelGGL((dist_kernel_v2<NW, MODE, W, true>), dim3((unsigned)n_blocks, (unsigned)p.nk),
                          dim3(NW * 64), 0, s, ref->d_skT, qry->d_skT, d_lut,
                          use_clu ? ref->d_clu : nullptr, use_clu ? qry->d_clu : nullptr, d_rtab, d_out,
                          d_n_failed, d_mask, p);
   } else {
-    hipLaunchKernelGGL((dist_kernel_v2<NW, MODE, PackT>), dim3((unsigned)n_blocks),
+    hipLaunchKernelGGL((dist_kernel_v2<NW, MODE, W>), dim3((unsigned)n_blocks),
                        dim3(NW * 64), 0, s, ref->d_skT, qry->d_skT, d_lut,
                        use_clu ? ref->d_clu : nullptr, use_clu ? qry->d_clu : nullptr, d_rtab, d_out,
                        d_n_failed, d_mask, p);
@@ -1235,30 +1285,56 @@ int launch_v2(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const f
   return PPK_OK;
 }
 
-template <int MODE, typename PackT>
-int launch_tiles(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const float *d_rtab,
-                 void *d_out, unsigned long long *d_n_failed, uint64_t *d_mask, DistParams &p,
-                 hipStream_t s) {
+// COUNTS / JACCARD modes: each k's counts are consumed at once, nothing is packed
+template <int MODE>
+int launch_tiles_unpacked(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const float *d_rtab,
+                          void *d_out, unsigned long long *d_n_failed, uint64_t *d_mask, DistParams &p,
+                          hipStream_t s) {
+  static_assert(MODE == MODE_COUNTS || MODE == MODE_JACCARD, "unpacked modes");
   if (p.bbits != 14)
-    return launch_variant<8, 4, 0, MODE, PackT>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask,
-                                                p, s, "dist_kernel<8,4,generic>");
-  // v1 tiles are kept for A/B measurements of the plain distance mode only
-  if constexpr (MODE == MODE_DIST && std::is_same<PackT, uint64_t>::value) {
-    if (g_tile_tq == 16 && g_tile_nw == 4)
-      return launch_variant<16, 4, 14, MODE, PackT>(ref, qry, d_lut, d_rtab, d_out, d_n_failed,
-                                                    d_mask, p, s, "dist_kernel<16,4,14>");
-    if (g_tile_tq == 8 && g_tile_nw == 8)
-      return launch_variant<8, 8, 14, MODE, PackT>(ref, qry, d_lut, d_rtab, d_out, d_n_failed,
-                                                   d_mask, p, s, "dist_kernel<8,8,14>");
-    if (g_tile_tq == 8 && g_tile_nw == 4)
-      return launch_variant<8, 4, 14, MODE, PackT>(ref, qry, d_lut, d_rtab, d_out, d_n_failed,
-                                                   d_mask, p, s, "dist_kernel<8,4,14>");
+    return launch_variant<8, 4, 0, MODE, uint64_t>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask,
+                                                   p, s, "dist_kernel<8,4,generic>");
+  return launch_v2<8, MODE, 1>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
+}
+
+// DIST / MASK modes: the per-pair count register is sized by nk * cnt_bits (<= 128, checked by
+// the caller)
+template <int MODE>
+int launch_tiles_packed(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const float *d_rtab,
+                        void *d_out, unsigned long long *d_n_failed, uint64_t *d_mask, DistParams &p,
+                        hipStream_t s) {
+  static_assert(MODE == MODE_DIST || MODE == MODE_MASK, "packed modes");
+  const int total_bits = p.nk * p.cnt_bits;
+  if (p.bbits != 14) {
+    // the generic-bbits (v1) kernel has registers to spare and packs into plain integers
+    if (total_bits <= 64)
+      return launch_variant<8, 4, 0, MODE, uint64_t>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask,
+                                                     p, s, "dist_kernel<8,4,generic>");
+    if (p.nk <= 6 && p.cnt_bits <= 16)
+      return launch_variant<8, 4, 0, MODE, Pack96>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask,
+                                                   p, s, "dist_kernel<8,4,generic>");
+    return launch_variant<8, 4, 0, MODE, u128>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask,
+                                               p, s, "dist_kernel<8,4,generic>");
   }
-  if constexpr (MODE == MODE_DIST && std::is_same<PackT, uint64_t>::value) {
-    if (g_tile_tq == 4 && g_tile_nw == 16)   // experiment: 16-wavefront workgroups
-      return launch_v2<16, MODE, PackT>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
+  if constexpr (MODE == MODE_DIST) {
+    // v1 tiles and the 16-wavefront shape are kept for A/B measurements of the plain distance mode
+    if (total_bits <= 64) {
+      if (g_tile_tq == 16 && g_tile_nw == 4)
+        return launch_variant<16, 4, 14, MODE, uint64_t>(ref, qry, d_lut, d_rtab, d_out, d_n_failed,
+                                                         d_mask, p, s, "dist_kernel<16,4,14>");
+      if (g_tile_tq == 8 && g_tile_nw == 8)
+        return launch_variant<8, 8, 14, MODE, uint64_t>(ref, qry, d_lut, d_rtab, d_out, d_n_failed,
+                                                        d_mask, p, s, "dist_kernel<8,8,14>");
+      if (g_tile_tq == 8 && g_tile_nw == 4)
+        return launch_variant<8, 4, 14, MODE, uint64_t>(ref, qry, d_lut, d_rtab, d_out, d_n_failed,
+                                                        d_mask, p, s, "dist_kernel<8,4,14>");
+      if (g_tile_tq == 4 && g_tile_nw == 16)
+        return launch_v2<16, MODE, 2>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
+    }
   }
-  return launch_v2<8, MODE, PackT>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
+  if (total_bits <= 64) return launch_v2<8, MODE, 2>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
+  if (total_bits <= 96) return launch_v2<8, MODE, 3>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
+  return launch_v2<8, MODE, 4>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
 }
 
 }  // namespace
@@ -1334,9 +1410,9 @@ int ppk_launch_dist(const ppk_db *ref, const ppk_db *qry_or_null, const int32_t 
   const bool want_counts = flags & PPK_FLAG_COUNTS;
   const bool want_jac = flags & PPK_FLAG_JACCARD;
   if (want_counts)
-    return launch_tiles<MODE_COUNTS, uint64_t>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
+    return launch_tiles_unpacked<MODE_COUNTS>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
   if (want_jac)
-    return launch_tiles<MODE_JACCARD, uint64_t>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
+    return launch_tiles_unpacked<MODE_JACCARD>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
 
   const bool too_wide = p.nk > PPK_MAX_NK || p.nk * p.cnt_bits > 128;
   // Small jobs (up to about one round of pair tiles on the 512 workgroup slots, e.g. 1 000 genomes or a handful
@@ -1361,7 +1437,7 @@ int ppk_launch_dist(const ppk_db *ref, const ppk_db *qry_or_null, const int32_t 
     uint32_t *d_cnt = static_cast<uint32_t *>(p_cnt);
     int *d_kmers = reinterpret_cast<int *>(d_cnt + rows * (size_t)p.nk);
     PPK_HIP(hipMemcpyAsync(d_kmers, kmers, (size_t)p.nk * 4, hipMemcpyHostToDevice, s));
-    rc = launch_tiles<MODE_COUNTS, uint64_t>(ref, qry, d_lut, d_rtab, d_cnt, nullptr, nullptr, p, s);
+    rc = launch_tiles_unpacked<MODE_COUNTS>(ref, qry, d_lut, d_rtab, d_cnt, nullptr, nullptr, p, s);
     if (rc != PPK_OK) return rc;
     const bool use_clu = p.random_correct && p.n_clu > 1;
     hipLaunchKernelGGL(regress_counts_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, d_cnt,
@@ -1388,7 +1464,7 @@ int ppk_launch_dist(const ppk_db *ref, const ppk_db *qry_or_null, const int32_t 
     if (rc != PPK_OK) return rc;
     p.k_split = 1;
     p.ks_rows = rows;
-    rc = launch_tiles<MODE_COUNTS, uint64_t>(ref, qry, d_lut, d_rtab, p_cnt, nullptr, nullptr, p, s);
+    rc = launch_tiles_unpacked<MODE_COUNTS>(ref, qry, d_lut, d_rtab, p_cnt, nullptr, nullptr, p, s);
     if (rc != PPK_OK) return rc;
     const bool use_clu = p.random_correct && p.n_clu > 1;
     hipLaunchKernelGGL(regress_packed_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s,
@@ -1397,14 +1473,6 @@ int ppk_launch_dist(const ppk_db *ref, const ppk_db *qry_or_null, const int32_t 
     PPK_HIP(hipGetLastError());
     return PPK_OK;
   }
-  const bool wide = p.nk * p.cnt_bits > 64;
-  const bool mid = wide && p.nk <= 6 && p.cnt_bits <= 16;     // three dwords of 16-bit counts
-  if (d_mask) {
-    if (mid) return launch_tiles<MODE_MASK, Pack96>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
-    return wide ? launch_tiles<MODE_MASK, u128>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s)
-                : launch_tiles<MODE_MASK, uint64_t>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
-  }
-  if (mid) return launch_tiles<MODE_DIST, Pack96>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
-  return wide ? launch_tiles<MODE_DIST, u128>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s)
-              : launch_tiles<MODE_DIST, uint64_t>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
+  if (d_mask) return launch_tiles_packed<MODE_MASK>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
+  return launch_tiles_packed<MODE_DIST>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
 }

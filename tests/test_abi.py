@@ -92,8 +92,8 @@ def test_compute_without_a_gpu_is_an_error_not_a_fallback():
 
 
 def test_hot_kernels_have_no_scratch_in_the_compare_loop(tmp_path):
-    """Register budget guard: the two hot instantiations of dist_kernel_v2 (distances and fused
-    boundary, 64-bit packed counts) sit at the 128-VGPR / ~102-SGPR limit; an innocent extra live
+    """Register budget guard: the instantiations of dist_kernel_v2 with packed count registers
+    (distances and fused boundary; 2, 3 or 4 dwords per pair) sit at the 128-VGPR / ~102-SGPR limit; an innocent extra live
     value spills into the compare loop and costs 3 % (it happened twice during round 1), which no
     functional test notices.  The distance kernel must use no scratch at all, and neither kernel
     may touch scratch between the DMA issue and the closing barrier of a 64-bin block."""
@@ -110,8 +110,8 @@ def test_hot_kernels_have_no_scratch_in_the_compare_loop(tmp_path):
                           "-Rpass-analysis=kernel-resource-usage"],
                          capture_output=True, text=True, cwd=os.path.dirname(src), timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    hot = {"_Z14dist_kernel_v2ILi8ELi0EmLb0E": 0,      # <8, MODE_DIST, unsigned long, false>: no scratch
-           "_Z14dist_kernel_v2ILi8ELi3EmLb0E": 64}     # <8, MODE_MASK, ...>: epilogue may spill a little
+    hot = {"_Z14dist_kernel_v2ILi8ELi0ELi2ELb0E": 0,      # <8, MODE_DIST, W = 2, false>: no scratch
+           "_Z14dist_kernel_v2ILi8ELi3ELi2ELb0E": 64}     # <8, MODE_MASK, ...>: epilogue may spill a little
     seen = 0
     for b in re.split(r"remark: Function Name: ", out.stderr)[1:]:
         name = b.split()[0]
@@ -135,13 +135,28 @@ def test_hot_kernels_have_no_scratch_in_the_compare_loop(tmp_path):
             byval = re.search(r"- \.offset:\s+(\d+)\n\s+\.size:\s+(\d+)\n\s+\.value_kind:\s+by_value", blk)
             assert byval and int(byval.group(1)) == 72, (name, byval and byval.group(0))
     assert n_v2 >= 6
-    for prefix in hot:
+    # every compare loop (full and half block; each phase loop of the three-word pack) of every
+    # packed instantiation: nothing touches scratch between the loop header and the closing barrier
+    loops = 0
+    packed = ["_Z14dist_kernel_v2ILi8ELi%dELi%dELb0E" % (mode, w) for mode in (0, 3) for w in (2, 3, 4)]
+    for prefix in packed:
         m = re.search(r"^(%s\w*):[^\n]*\n(.*?)^\.Lfunc_end" % prefix, text, re.S | re.M)
         assert m, prefix
         lines = m.group(2).split("\n")
-        blocks = [i for i, ln in enumerate(lines) if "ds_read_b128 v[80:83]" in ln]
-        assert blocks, "compare block not found in " + prefix
-        first = blocks[0]
-        end = next(i for i in range(first, len(lines)) if "s_barrier" in lines[i])
-        loop = lines[max(0, first - 200):end + 1]
-        assert not [ln for ln in loop if "scratch_" in ln], prefix + ": scratch access inside the compare loop"
+        starts = [i for i, ln in enumerate(lines)
+                  if "#ASMSTART" in ln and i + 1 < len(lines) and "ds_read_b128 v[80:83]" in lines[i + 1]]
+        assert len(starts) >= 2, "compare blocks not found in " + prefix
+        for b in starts:
+            hdr = max(i for i in range(b) if "Loop Header" in lines[i])
+            end = next(i for i in range(b, len(lines)) if "s_barrier" in lines[i])
+            assert end - hdr < 1500, (prefix, hdr, end)
+            bad = [ln for ln in lines[hdr:end + 1] if "scratch_" in ln]
+            assert not bad, prefix + ": scratch access inside the compare loop: " + bad[0]
+            loops += 1
+    assert loops >= 12
+    # the counters are pinned so that no v_bcnt reads two VGPRs of the same bank
+    for prefix in packed:
+        m = re.search(r"^(%s\w*):[^\n]*\n(.*?)^\.Lfunc_end" % prefix, text, re.S | re.M)
+        bc = re.findall(r"v_bcnt_u32_b32 v(\d+), v(\d+), v(\d+)", m.group(2))
+        assert len(bc) >= 48
+        assert not [t for t in bc if int(t[1]) % 4 == int(t[2]) % 4], prefix + ": v_bcnt bank conflict"

@@ -426,3 +426,37 @@ def test_host_call_chunks_the_result_through_bounded_device_memory(monkeypatch):
                                                             devices=devices)[0], base[name][1])
             assert np.array_equal(pp_sketchlib.query_arrays(r, q, kmers, 16, 14, counts=True,
                                                             devices=devices)[0], base[name][2])
+
+
+@pytest.mark.parametrize("s64,nk,words", [(16, 5, 2), (16, 6, 3), (16, 8, 3), (16, 9, 4), (16, 11, 4),
+                                          (156, 4, 2), (156, 6, 3), (156, 7, 4), (156, 9, 4)])
+def test_count_register_widths(monkeypatch, s64, nk, words):
+    """The tile kernel keeps each pair's counts in a shift register of 2, 3 or 4 dwords (count k at
+    bit (nk-1-k)*bits; bits = 11 at s = 1024, 14 at s = 9984): every width, fields straddling dword
+    boundaries, the exact 128-bit limit (9 x 14 = 126), distances and the fused boundary; failed and
+    truncated fits (unrelated clusters) read the fields through the general path."""
+    bits = 11 if s64 == 16 else 14
+    assert -(-nk * bits // 32) == words
+    kmers = np.round(np.linspace(13, 31, nk)).astype(np.int32)
+    assert len(set(kmers.tolist())) == nk
+    n = 330 if s64 == 16 else 290        # > 256: diagonal half tiles and a strip / second ref tile
+    for related in (True, False):
+        sk, member = synth.make_sketches(n, kmers, sketchsize64=s64, bbits=14, cluster_size=30, seed=40 + nk,
+                                         related=related)
+        tbl = synth.random_match_table(kmers)
+        counts, _ = pp_sketchlib.query_arrays(sk, None, kmers, s64, 14, counts=True)
+        assert np.array_equal(counts, oracle.match_counts(sk, None, s64, 14, threads=4))
+        want, wf = oracle.query(sk, None, kmers, s64, 14, tbl, threads=4)
+        monkeypatch.setenv("PPK_KSPLIT", "0")       # a job this small would take the k-split path
+        got, gf = pp_sketchlib.query_arrays(sk, None, kmers, s64, 14, tbl)
+        assert gf == wf and np.abs(got - want).max() <= TOL
+        monkeypatch.delenv("PPK_KSPLIT")
+        got2, gf2 = pp_sketchlib.query_arrays(sk, None, kmers, s64, 14, tbl)
+        assert gf2 == wf and np.array_equal(got2, got)      # k-split: same bits
+        if not related:
+            assert wf > 0
+        db = engine.SketchDB(sk, s64, 14)
+        x_max, y_max = synth.boundary_for_quantile(got, 0.2)
+        e, _ = engine.dist_edges(db, None, kmers, tbl, slope=2, x_max=x_max, y_max=y_max)
+        assert np.array_equal(e.cpu().numpy(), oracle.edge_threshold(got, 2, x_max, y_max))
+        db.close()
