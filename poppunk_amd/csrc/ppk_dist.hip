@@ -817,7 +817,11 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
   for (int g = 0; g < total; ++g) {
     const int buf = g & 1;
     // the other buffer was last read in iteration g-1, which every wave left through the barrier
-    if (g + 1 < total && !(p.ablate & 4)) issue_dma(buf ^ 1, HALF);
+    // Two-dword count registers leave room for the variant of the full block that issues the
+    // wave's four DMA pieces from INSIDE its instruction stream (in VALU-only stretches instead of
+    // next to the opening burst of ds_reads); waves with nothing to compare still copy from here.
+    constexpr bool DMA_IN_STREAM = NW == 8 && W == 2 && !HALF;
+    if (g + 1 < total && !(p.ablate & 4) && !(DMA_IN_STREAM && wave_active)) issue_dma(buf ^ 1, HALF);
 
     if (wave_active && !(p.ablate & 2)) {
       // One 64-bin block of the 4x4 register tile: 14 x (4 ds_read_b128 + 32 v_bitop3) + 32
@@ -838,7 +842,30 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
         if constexpr (HALF)
           asm volatile(PPK_BLOCK_HALF_ASM_Q32 : PPK_BLOCK_OPERANDS : [rp] "v"(rp), [qp] "v"(qp)
                        : "memory", PPK_BLOCK_CLOBBERS);
-        else
+        else if constexpr (DMA_IN_STREAM) {
+          static_assert(NW != 8 || PW == 4, "the in-stream variant issues exactly four pieces per wavefront");
+          const uint32_t lbase =
+              (uint32_t)(size_t)(__attribute__((address_space(3))) void *)(lds + (buf ^ 1) * CHUNK_U4);
+          const uint32_t m00 = __builtin_amdgcn_readfirstlane(lbase + (uint32_t)doff[0] * 16u);
+          const uint32_t m03 = __builtin_amdgcn_readfirstlane(lbase + (uint32_t)doff[3] * 16u);
+          // piece 3 is a ref piece for waves 0-3 and a query piece for waves 4-7; the last query
+          // piece holds fewer rows than lanes
+          const uint64_t xb = (wave + NW * 3 == NPIECE - 1) ? __ballot(qlane_ok) : ~0ull;
+          const uint32_t xblo = __builtin_amdgcn_readfirstlane((uint32_t)xb),
+                         xbhi = __builtin_amdgcn_readfirstlane((uint32_t)(xb >> 32));
+          const uint32_t vob = dkind[3] == 0 ? voff_ref : voff_qry;
+          asm volatile(PPK_BLOCK_DMA_ASM_Q32
+                       : PPK_BLOCK_OPERANDS
+                       : [rp] "v"(rp), [qp] "v"(qp), [m00] "s"(m00), [m03] "s"(m03), [sb0] "s"(dbase[0]),
+                         [sb1] "s"(dbase[1]), [sb2] "s"(dbase[2]), [sb3] "s"(dbase[3]), [voa] "v"(voff_ref),
+                         [vob] "v"(vob), [xblo] "s"(xblo), [xbhi] "s"(xbhi)
+                       : "memory", "scc", PPK_BLOCK_CLOBBERS);
+          // (after the last block the pieces harmlessly re-load it into the idle buffer)
+          if (g + 2 < total) {
+#pragma unroll
+            for (int t = 0; t < PW; ++t) dbase[t] += dstep[t];
+          }
+        } else
           asm volatile(PPK_BLOCK_ASM_Q32 : PPK_BLOCK_OPERANDS : [rp] "v"(rp), [qp] "v"(qp)
                        : "memory", PPK_BLOCK_CLOBBERS);
       } else {
