@@ -817,10 +817,10 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
   for (int g = 0; g < total; ++g) {
     const int buf = g & 1;
     // the other buffer was last read in iteration g-1, which every wave left through the barrier
-    // Two-dword count registers leave room for the variant of the full block that issues the
+    // The packed modes run the variant of the full block that issues the
     // wave's four DMA pieces from INSIDE its instruction stream (in VALU-only stretches instead of
     // next to the opening burst of ds_reads); waves with nothing to compare still copy from here.
-    constexpr bool DMA_IN_STREAM = NW == 8 && W == 2 && !HALF;
+    constexpr bool DMA_IN_STREAM = NW == 8 && W >= 2 && !HALF;
     if (g + 1 < total && !(p.ablate & 4) && !(DMA_IN_STREAM && wave_active)) issue_dma(buf ^ 1, HALF);
 
     if (wave_active && !(p.ablate & 2)) {
