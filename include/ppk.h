@@ -193,7 +193,8 @@ int ppk_threshold_iterate_2d_dev(const float *d_dist, size_t n_rows, const float
  * The result is produced in sub-bands through two alternating device buffers of
  * about 256 MB (sub-band c downloads while c+1 computes), so device memory use is
  * bounded by the sketches plus those buffers for any job size -- the
- * device-memory chunking of pp-sketchlib's CUDA path [EXT].
+ * device-memory chunking of pp-sketchlib's CUDA path [EXT].  `out` is written by this call only; a few
+ * helper threads touch its pages ahead of the download (PPK_PREFAULT_THREADS, default 8, 0 = off).
  */
 int ppk_query(const uint64_t *ref_sk, size_t n_ref, const uint64_t *qry_sk,
               size_t n_qry, const int32_t *kmers, size_t nk, size_t sketchsize64,
