@@ -117,6 +117,65 @@ extern "C" const char *ppk_last_kernel_name(void) {
   return copy.c_str();
 }
 
+// ---- pre-touching of host result arrays -------------------------------------------
+// A result lands in the caller's (normally freshly allocated, not yet touched) pageable array:
+// its first-touch page faults -- one per 4 KB, taken serially by the runtime's staging copy --
+// cost more than the PCIe transfer (10k genomes: 29 ms per ppk_query call against 14 with the
+// pages touched).  A few threads therefore write the first byte of every page, front to back in
+// interleaved 2 MB blocks, while the inputs upload and the first chunk computes; a download waits
+// until the blocks under it are done (a toucher never writes behind a download).
+namespace {
+class HostToucher {
+ public:
+  HostToucher(void *out, size_t total_bytes) : out_(out), total_(total_bytes) {
+    int nt = 8;
+    if (const char *e = getenv("PPK_PREFAULT_THREADS")) nt = atoi(e);
+    if (nt > 64) nt = 64;
+    if (!out || total_bytes < ((size_t)8 << 20) || nt < 0) nt = 0;
+    nt_ = nt;
+    n_blocks_ = (total_bytes + kBlock - 1) / kBlock;
+    done_ = std::vector<std::atomic<size_t>>((size_t)(nt > 0 ? nt : 1));
+    for (auto &a : done_) a.store(0);
+    for (int t = 0; t < nt; ++t) threads_.emplace_back([this, t]() { run(t); });
+  }
+  ~HostToucher() { join(); }
+  HostToucher(const HostToucher &) = delete;
+  HostToucher &operator=(const HostToucher &) = delete;
+  // every page of [0, end_byte) has been touched
+  void wait(size_t end_byte) {
+    if (!nt_) return;
+    size_t need = (end_byte + kBlock - 1) / kBlock;
+    if (need > n_blocks_) need = n_blocks_;
+    for (int t = 0; t < nt_; ++t) {
+      const size_t mine = need > (size_t)t ? (need - (size_t)t + (size_t)nt_ - 1) / (size_t)nt_ : 0;
+      while (done_[(size_t)t].load(std::memory_order_acquire) < mine) std::this_thread::yield();
+    }
+  }
+  void join() {
+    for (auto &t : threads_)
+      if (t.joinable()) t.join();
+  }
+
+ private:
+  static constexpr size_t kBlock = (size_t)2 << 20;
+  void run(int t) {
+    volatile char *base = static_cast<volatile char *>(out_);
+    size_t done = 0;
+    for (size_t blk = (size_t)t; blk < n_blocks_; blk += (size_t)nt_) {
+      const size_t b0 = blk * kBlock, b1 = b0 + kBlock < total_ ? b0 + kBlock : total_;
+      base[b0] = 0;
+      for (size_t a = (((size_t)out_ + b0) / 4096 + 1) * 4096 - (size_t)out_; a < b1; a += 4096) base[a] = 0;
+      done_[(size_t)t].store(++done, std::memory_order_release);
+    }
+  }
+  void *out_;
+  size_t total_, n_blocks_ = 0;
+  int nt_ = 0;
+  std::vector<std::atomic<size_t>> done_;
+  std::vector<std::thread> threads_;
+};
+}  // namespace
+
 // ---- geometry helpers -----------------------------------------------------------
 static inline size_t row_start_self(size_t q, size_t n) { return q * n - (q * (q + 1)) / 2; }
 
@@ -620,47 +679,8 @@ extern "C" int ppk_query(const uint64_t *ref_sk, size_t n_ref, const uint64_t *q
     }
     (void)hipMemsetAsync(p.d_failed, 0, sizeof(unsigned long long), p.s);
   }
-  // The result lands in the caller's (normally freshly allocated, not yet touched) pageable array:
-  // its first-touch page faults -- one per 4 KB, taken serially by the runtime's staging copy --
-  // cost more than the PCIe transfer (10k genomes: 29 ms per call against 15 with the pages
-  // touched).  A few threads therefore write the first byte of every page, front to back in
-  // interleaved 2 MB blocks, while the sketches upload and the first sub-band computes; a download
-  // waits until the blocks under it are done (a toucher never writes behind a download).
-  constexpr size_t TOUCH_BLOCK = (size_t)2 << 20;
-  const size_t total_bytes = row0[(size_t)n_dev * C] * cols * 4;
-  const size_t n_tblocks = (total_bytes + TOUCH_BLOCK - 1) / TOUCH_BLOCK;
-  int n_touch = 8;
-  if (const char *e = getenv("PPK_PREFAULT_THREADS")) n_touch = atoi(e);
-  if (n_touch > 64) n_touch = 64;
-  if (rc != PPK_OK || total_bytes < ((size_t)8 << 20) || n_touch < 0) n_touch = 0;
-  std::vector<std::thread> toucher;
-  std::vector<std::atomic<size_t>> touched((size_t)(n_touch > 0 ? n_touch : 1));   // blocks done per thread
-  for (auto &a : touched) a.store(0);
-  for (int t = 0; t < n_touch; ++t)
-    toucher.emplace_back([=, &touched]() {
-      volatile char *base = static_cast<volatile char *>(out);
-      size_t done = 0;
-      for (size_t blk = (size_t)t; blk < n_tblocks; blk += (size_t)n_touch) {
-        const size_t b0 = blk * TOUCH_BLOCK, b1 = b0 + TOUCH_BLOCK < total_bytes ? b0 + TOUCH_BLOCK : total_bytes;
-        base[b0] = 0;
-        for (size_t a = (((size_t)out + b0) / 4096 + 1) * 4096 - (size_t)out; a < b1; a += 4096) base[a] = 0;
-        touched[(size_t)t].store(++done, std::memory_order_release);
-      }
-    });
-  // blocks [0, ceil(end_byte / TOUCH_BLOCK)) have been touched
-  auto wait_touched = [&](size_t end_byte) {
-    if (!n_touch) return;
-    const size_t need = (end_byte + TOUCH_BLOCK - 1) / TOUCH_BLOCK < n_tblocks ? (end_byte + TOUCH_BLOCK - 1) / TOUCH_BLOCK
-                                                                              : n_tblocks;
-    for (int t = 0; t < n_touch; ++t) {
-      const size_t mine = need > (size_t)t ? (need - (size_t)t + (size_t)n_touch - 1) / (size_t)n_touch : 0;
-      while (touched[(size_t)t].load(std::memory_order_acquire) < mine) std::this_thread::yield();
-    }
-  };
-  auto join_touchers = [&]() {
-    for (auto &t : toucher)
-      if (t.joinable()) t.join();
-  };
+  // helper threads touch the result array's pages ahead of the downloads (HostToucher)
+  HostToucher toucher(rc == PPK_OK ? out : nullptr, row0[(size_t)n_dev * C] * cols * 4);
   // step c: every device launches sub-band c, then sub-band c-1 of every device is fetched
   for (int c = 0; c <= C && rc == PPK_OK; ++c) {
     for (int d = 0; d < n_dev && rc == PPK_OK && c < C; ++d) {
@@ -678,7 +698,7 @@ extern "C" int ppk_query(const uint64_t *ref_sk, size_t n_ref, const uint64_t *q
       const size_t i = (size_t)d * C + (c - 1);
       if (!p.s || row0[i + 1] == row0[i]) continue;
       DeviceGuard g(devices[d]);
-      wait_touched(row0[i + 1] * cols * 4);
+      toucher.wait(row0[i + 1] * cols * 4);
       hipError_t e = hipStreamWaitEvent(p.sc, p.done[(c - 1) & 1], 0);
       if (e == hipSuccess)
         e = hipMemcpyAsync(static_cast<char *>(out) + row0[i] * cols * 4, p.buf[(c - 1) & 1],
@@ -703,7 +723,7 @@ extern "C" int ppk_query(const uint64_t *ref_sk, size_t n_ref, const uint64_t *q
         *n_failed += f;
     }
   }
-  join_touchers();
+  toucher.join();
   const std::string keep = g_err;
   cleanup();
   if (rc != PPK_OK) g_err = keep;
@@ -716,20 +736,67 @@ extern "C" int ppk_assign_threshold(const float *dist, size_t n_rows, int slope,
   if (!dist || !out) return ppk_fail(PPK_ERR_ARG, "NULL distance/output buffer");
   DeviceGuard guard(device_id);
   if (!guard.ok) return ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(device_id));
-  float *d_dist = nullptr, *d_out = nullptr;
-  PPK_HIP(hipMalloc(reinterpret_cast<void **>(&d_dist), n_rows * 8));
-  if (hipMalloc(reinterpret_cast<void **>(&d_out), n_rows * 4) != hipSuccess) {
-    (void)hipFree(d_dist);
-    return ppk_fail(PPK_ERR_HIP, "hipMalloc failed");
-  }
+  // 12 bytes per row over PCIe against 0.002 ns of kernel: the rows go through in chunks, the upload
+  // of chunk c+1, the kernel of chunk c and the download of chunk c-1 on three streams, and the
+  // (fresh) result array is pre-touched by helper threads.  Chunk edges are multiples of 64 rows.
+  const size_t chunk = (size_t)8 << 20;                                  // rows: 64 MB in, 32 MB out
+  const size_t n_chunks = (n_rows + chunk - 1) / chunk;
+  const size_t buf_rows = n_rows < chunk ? n_rows : chunk;
+  float *d_in[2] = {nullptr, nullptr}, *d_out[2] = {nullptr, nullptr};
+  hipStream_t s_up = nullptr, s_k = nullptr, s_dn = nullptr;
+  hipEvent_t up[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr}, freed_in[2] = {nullptr, nullptr},
+             freed_out[2] = {nullptr, nullptr};
   int rc = PPK_OK;
-  if (hipMemcpy(d_dist, dist, n_rows * 8, hipMemcpyHostToDevice) != hipSuccess)
-    rc = ppk_fail(PPK_ERR_HIP, "hipMemcpy H2D failed");
-  if (rc == PPK_OK) rc = ppk_assign_threshold_dev(d_dist, n_rows, slope, x_max, y_max, d_out, nullptr);
-  if (rc == PPK_OK && hipMemcpy(out, d_out, n_rows * 4, hipMemcpyDeviceToHost) != hipSuccess)
-    rc = ppk_fail(PPK_ERR_HIP, "hipMemcpy D2H failed");
-  (void)hipFree(d_dist);
-  (void)hipFree(d_out);
+  auto ok = [&](hipError_t e, const char *what) {
+    if (e != hipSuccess && rc == PPK_OK) rc = ppk_fail(PPK_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+    return rc == PPK_OK;
+  };
+  HostToucher toucher(out, n_rows * 4);
+  ok(hipStreamCreate(&s_up), "hipStreamCreate");
+  ok(hipStreamCreate(&s_k), "hipStreamCreate");
+  ok(hipStreamCreate(&s_dn), "hipStreamCreate");
+  const int n_buf = n_chunks > 1 ? 2 : 1;
+  for (int i = 0; i < n_buf && rc == PPK_OK; ++i) {
+    ok(hipMalloc(reinterpret_cast<void **>(&d_in[i]), buf_rows * 8), "hipMalloc");
+    ok(hipMalloc(reinterpret_cast<void **>(&d_out[i]), buf_rows * 4), "hipMalloc");
+    ok(hipEventCreateWithFlags(&up[i], hipEventDisableTiming), "hipEventCreate");
+    ok(hipEventCreateWithFlags(&done[i], hipEventDisableTiming), "hipEventCreate");
+    ok(hipEventCreateWithFlags(&freed_in[i], hipEventDisableTiming), "hipEventCreate");
+    ok(hipEventCreateWithFlags(&freed_out[i], hipEventDisableTiming), "hipEventCreate");
+  }
+  for (size_t c = 0; c < n_chunks && rc == PPK_OK; ++c) {
+    const int b = (int)(c & 1) % n_buf;
+    const size_t r0 = c * chunk, nr = r0 + chunk < n_rows ? chunk : n_rows - r0;
+    if (c >= 2) ok(hipStreamWaitEvent(s_up, freed_in[b], 0), "hipStreamWaitEvent");      // kernel c-2 has read d_in[b]
+    ok(hipMemcpyAsync(d_in[b], dist + r0 * 2, nr * 8, hipMemcpyHostToDevice, s_up), "hipMemcpy H2D");
+    ok(hipEventRecord(up[b], s_up), "hipEventRecord");
+    ok(hipStreamWaitEvent(s_k, up[b], 0), "hipStreamWaitEvent");
+    if (c >= 2) ok(hipStreamWaitEvent(s_k, freed_out[b], 0), "hipStreamWaitEvent");     // download c-2 has read d_out[b]
+    if (rc == PPK_OK) rc = ppk_assign_threshold_dev(d_in[b], nr, slope, x_max, y_max, d_out[b], s_k);
+    ok(hipEventRecord(done[b], s_k), "hipEventRecord");
+    ok(hipEventRecord(freed_in[b], s_k), "hipEventRecord");
+    ok(hipStreamWaitEvent(s_dn, done[b], 0), "hipStreamWaitEvent");
+    toucher.wait((r0 + nr) * 4);
+    ok(hipMemcpyAsync(out + r0, d_out[b], nr * 4, hipMemcpyDeviceToHost, s_dn), "hipMemcpy D2H");
+    ok(hipEventRecord(freed_out[b], s_dn), "hipEventRecord");
+  }
+  if (s_up) (void)hipStreamSynchronize(s_up);
+  if (s_k) ok(hipStreamSynchronize(s_k), "assign kernel");
+  if (s_dn) ok(hipStreamSynchronize(s_dn), "hipMemcpy D2H");
+  toucher.join();
+  const std::string keep = g_err;
+  for (int i = 0; i < 2; ++i) {
+    if (d_in[i]) (void)hipFree(d_in[i]);
+    if (d_out[i]) (void)hipFree(d_out[i]);
+    if (up[i]) (void)hipEventDestroy(up[i]);
+    if (done[i]) (void)hipEventDestroy(done[i]);
+    if (freed_in[i]) (void)hipEventDestroy(freed_in[i]);
+    if (freed_out[i]) (void)hipEventDestroy(freed_out[i]);
+  }
+  if (s_up) (void)hipStreamDestroy(s_up);
+  if (s_k) (void)hipStreamDestroy(s_k);
+  if (s_dn) (void)hipStreamDestroy(s_dn);
+  if (rc != PPK_OK) g_err = keep;
   return rc;
 }
 
