@@ -1,10 +1,8 @@
 // C-ABI entry points of libppk_hip.so (declared in include/ppk.h).
 #include <algorithm>
-#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <mutex>
-#include <thread>
 #include <vector>
 
 #include "ppk_internal.h"
@@ -116,65 +114,6 @@ extern "C" const char *ppk_last_kernel_name(void) {
   copy = g_prof.kernel_name;
   return copy.c_str();
 }
-
-// ---- pre-touching of host result arrays -------------------------------------------
-// A result lands in the caller's (normally freshly allocated, not yet touched) pageable array:
-// its first-touch page faults -- one per 4 KB, taken serially by the runtime's staging copy --
-// cost more than the PCIe transfer (10k genomes: 29 ms per ppk_query call against 14 with the
-// pages touched).  A few threads therefore write the first byte of every page, front to back in
-// interleaved 2 MB blocks, while the inputs upload and the first chunk computes; a download waits
-// until the blocks under it are done (a toucher never writes behind a download).
-namespace {
-class HostToucher {
- public:
-  HostToucher(void *out, size_t total_bytes) : out_(out), total_(total_bytes) {
-    int nt = 8;
-    if (const char *e = getenv("PPK_PREFAULT_THREADS")) nt = atoi(e);
-    if (nt > 64) nt = 64;
-    if (!out || total_bytes < ((size_t)8 << 20) || nt < 0) nt = 0;
-    nt_ = nt;
-    n_blocks_ = (total_bytes + kBlock - 1) / kBlock;
-    done_ = std::vector<std::atomic<size_t>>((size_t)(nt > 0 ? nt : 1));
-    for (auto &a : done_) a.store(0);
-    for (int t = 0; t < nt; ++t) threads_.emplace_back([this, t]() { run(t); });
-  }
-  ~HostToucher() { join(); }
-  HostToucher(const HostToucher &) = delete;
-  HostToucher &operator=(const HostToucher &) = delete;
-  // every page of [0, end_byte) has been touched
-  void wait(size_t end_byte) {
-    if (!nt_) return;
-    size_t need = (end_byte + kBlock - 1) / kBlock;
-    if (need > n_blocks_) need = n_blocks_;
-    for (int t = 0; t < nt_; ++t) {
-      const size_t mine = need > (size_t)t ? (need - (size_t)t + (size_t)nt_ - 1) / (size_t)nt_ : 0;
-      while (done_[(size_t)t].load(std::memory_order_acquire) < mine) std::this_thread::yield();
-    }
-  }
-  void join() {
-    for (auto &t : threads_)
-      if (t.joinable()) t.join();
-  }
-
- private:
-  static constexpr size_t kBlock = (size_t)2 << 20;
-  void run(int t) {
-    volatile char *base = static_cast<volatile char *>(out_);
-    size_t done = 0;
-    for (size_t blk = (size_t)t; blk < n_blocks_; blk += (size_t)nt_) {
-      const size_t b0 = blk * kBlock, b1 = b0 + kBlock < total_ ? b0 + kBlock : total_;
-      base[b0] = 0;
-      for (size_t a = (((size_t)out_ + b0) / 4096 + 1) * 4096 - (size_t)out_; a < b1; a += 4096) base[a] = 0;
-      done_[(size_t)t].store(++done, std::memory_order_release);
-    }
-  }
-  void *out_;
-  size_t total_, n_blocks_ = 0;
-  int nt_ = 0;
-  std::vector<std::atomic<size_t>> done_;
-  std::vector<std::thread> threads_;
-};
-}  // namespace
 
 // ---- geometry helpers -----------------------------------------------------------
 static inline size_t row_start_self(size_t q, size_t n) { return q * n - (q * (q + 1)) / 2; }

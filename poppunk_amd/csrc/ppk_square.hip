@@ -343,11 +343,13 @@ extern "C" int ppk_long_to_square(const float *vec, size_t n, int device_id, flo
   DeviceGuard guard(device_id);
   if (!guard.ok) return ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(device_id));
   const size_t rows = n * (n - 1) / 2;
+  HostToucher toucher(square, n * n * 4);      // the result array's pages, under the upload
   DevBuf a, b;
   int rc = a.alloc(rows * 4);
   if (rc == PPK_OK) rc = b.alloc(n * n * 4);
   if (rc == PPK_OK) rc = h2d(a.p, vec, rows * 4);
   if (rc == PPK_OK) rc = ppk_long_to_square_dev(static_cast<float *>(a.p), 1, 0, n, static_cast<float *>(b.p), nullptr);
+  toucher.join();
   if (rc == PPK_OK) rc = d2h(square, b.p, n * n * 4);
   return rc;
 }
@@ -359,6 +361,7 @@ extern "C" int ppk_long_to_square_multi(const float *rr, const float *qr, const 
   if (!guard.ok) return ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(device_id));
   const size_t n_rr = n_ref * (n_ref - 1) / 2, n_qr = n_ref * n_qry, n_qq = n_qry * (n_qry - 1) / 2;
   const size_t n = n_ref + n_qry;
+  HostToucher toucher(square, n * n * 4);
   DevBuf a, b, c, d;
   int rc = a.alloc(n_rr * 4);
   if (rc == PPK_OK) rc = b.alloc(n_qr * 4);
@@ -371,6 +374,7 @@ extern "C" int ppk_long_to_square_multi(const float *rr, const float *qr, const 
     rc = ppk_long_to_square_multi_dev(static_cast<float *>(a.p), static_cast<float *>(b.p),
                                       static_cast<float *>(c.p), 1, 0, n_ref, n_qry,
                                       static_cast<float *>(d.p), nullptr);
+  toucher.join();
   if (rc == PPK_OK) rc = d2h(square, d.p, n * n * 4);
   return rc;
 }
@@ -381,11 +385,13 @@ extern "C" int ppk_square_to_long(const float *square, size_t n, int device_id, 
   DeviceGuard guard(device_id);
   if (!guard.ok) return ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(device_id));
   const size_t rows = n * (n - 1) / 2;
+  HostToucher toucher(vec, rows * 4);
   DevBuf a, b;
   int rc = a.alloc(n * n * 4);
   if (rc == PPK_OK) rc = b.alloc(rows * 4);
   if (rc == PPK_OK) rc = h2d(a.p, square, n * n * 4);
   if (rc == PPK_OK) rc = ppk_square_to_long_dev(static_cast<float *>(a.p), n, static_cast<float *>(b.p), nullptr);
+  toucher.join();
   if (rc == PPK_OK) rc = d2h(vec, b.p, rows * 4);
   return rc;
 }
@@ -435,6 +441,7 @@ extern "C" int ppk_prune_long(const float *dist, size_t n, size_t cols, const lo
   DeviceGuard guard(device_id);
   if (!guard.ok) return ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(device_id));
   const size_t rows_in = n * (n - 1) / 2, rows_out = n_keep * (n_keep - 1) / 2;
+  HostToucher toucher(out, rows_out * cols * 4);
   DevBuf a, k, b;
   rc = a.alloc(rows_in * cols * 4);
   if (rc == PPK_OK) rc = k.alloc(n_keep * 8);
@@ -444,6 +451,7 @@ extern "C" int ppk_prune_long(const float *dist, size_t n, size_t cols, const lo
   if (rc == PPK_OK)
     rc = ppk_prune_long_dev(static_cast<float *>(a.p), n, cols, static_cast<long long *>(k.p), n_keep,
                             static_cast<float *>(b.p), nullptr);
+  toucher.join();
   if (rc == PPK_OK) rc = d2h(out, b.p, rows_out * cols * 4);
   return rc;
 }
