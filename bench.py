@@ -9,8 +9,9 @@ output [n_pairs, 2] float32 in PopPUNK row order on rank 0.
 
   N = 1 : BASELINE configs[2]'s workload on one GPU -- 10 000 synthetic genomes,
           s = 1024 (sketchsize64 16, bbits 14), k = 13,17,21,25,29 -> 49 995 000 pairs.
-  N > 1 : weak scaling -- round(10 000 * sqrt(N)) genomes, so every GPU still owns
-          ~49 995 000 pairs; the pair space is band-split over the ranks and the
+  N > 1 : weak scaling -- round(10 000 * sqrt(N)) genomes, i.e. N x 49 995 000 pairs per step;
+          the pair space is band-split over the ranks (bands re-cut from measured per-rank rates
+          during the untimed set-up: the root's band needs no transfer; --even-bands) and the
           distance blocks are gathered to rank 0 with grouped RCCL send/recv
           inside the timed region, pipelined under the compute in --chunks
           sub-bands (--strong keeps 10 000 genomes instead).
@@ -52,6 +53,9 @@ def parse():
                     help="untimed clock spin-up before the warm-up steps (0 disables)")
     ap.add_argument("--chunks", type=int, default=4,
                     help="sub-bands per rank: the gather of chunk c overlaps the compute of c+1")
+    ap.add_argument("--even-bands", action="store_true",
+                    help="N > 1: keep equal bands (default: re-cut them from measured rates during "
+                         "the untimed set-up, so that the root, whose band needs no transfer, takes more)")
     return ap.parse_args()
 
 
@@ -171,11 +175,20 @@ def main():
         while time.perf_counter() - t_spin < args.spinup_ms * 1e-3:
             step()
             torch.cuda.synchronize()
-    elif args.spinup_ms > 0:
-        n_spin = 30 if os.environ.get("PPK_BENCH_BACKEND", "nccl") == "nccl" else 1
-        for _ in range(n_spin):      # every rank must run the SAME number of gathered steps
-            step()
-        torch.cuda.synchronize()
+    else:
+        if args.spinup_ms > 0:
+            n_spin = 30 if os.environ.get("PPK_BENCH_BACKEND", "nccl") == "nccl" else 1
+            for _ in range(n_spin):      # every rank must run the SAME number of gathered steps
+                step()
+            torch.cuda.synchronize()
+        # Set-up, like choosing the band edges at all: with equal bands a step lasts as long as the
+        # slowest peer -> root transfer (a GPU produces 8 B per pair faster than its one xGMI link to
+        # the root carries them) while the root's own band needs none.  Three measured steps re-cut
+        # the bands in proportion to each rank's measured rate (engine.ShardedQuery.rebalance).
+        if not args.even_bands:
+            for _ in range(3):
+                shares = job.rebalance(kmers, tbl)
+            rows = job.band_rows
     for _ in range(args.warmup):
         step()
     barrier()
@@ -238,7 +251,7 @@ def main():
                                    "bbits=14), k=13,17,21,25,29, %d pairs, output [n_pairs,2] f32 "
                                    "on rank 0" % (n, total_pairs),
                        "n_genomes": n, "pairs": total_pairs,
-                       "parallelism": "band-split x%d, %d-chunk pipelined p2p gather to rank 0" % (world, args.chunks) if world > 1 else "1 GPU"},
+                       "parallelism": "band-split x%d (%s bands), %d-chunk pipelined p2p gather to rank 0" % (world, "equal" if args.even_bands else "rate-balanced", args.chunks) if world > 1 else "1 GPU"},
             "roofline": roof, "cpu_baseline": cpu,
         }
         if world > 1:
@@ -246,6 +259,9 @@ def main():
             line["multi_gpu"] = {
                 "compute_ms_per_step_max_rank": round(compute_ms, 4),
                 "gathered_bytes_per_step": int(sum(job.band_rows[1:])) * 8,
+                "band_shares": [round(b / max(total_pairs, 1), 4) for b in job.band_rows],
+                "bands": "equal" if args.even_bands else "re-cut from measured per-rank rates during set-up "
+                                                         "(3 untimed steps): the root's band needs no transfer",
                 "note": "value includes the p2p gather of every peer's distance block into the "
                         "PopPUNK-ordered matrix on rank 0 (pipelined under compute in %d chunks); "
                         "the root's inbound xGMI links bound it" % args.chunks}

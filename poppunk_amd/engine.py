@@ -36,6 +36,31 @@ def band_split(n_ref, n_qry, n_parts):
     return [int(b) for b in bounds]
 
 
+def band_split_weighted(n_ref, n_qry, weights):
+    """Query-axis band edges giving band i the share weights[i] / sum(weights) of the pair space
+    (edges on multiples of 64 queries, like ppk_band_split; equal weights reproduce it).  Self:
+    the rows before query q number q*n - q(q+1)/2, inverted in closed form."""
+    w = np.asarray(weights, dtype=np.float64)
+    if w.ndim != 1 or len(w) < 1 or not np.all(np.isfinite(w)) or np.any(w < 0) or w.sum() <= 0:
+        raise ValueError("weights must be non-negative, finite and not all zero")
+    nq = n_qry if n_qry else n_ref
+    total = float(rows_in_band(n_ref, n_qry, 0, nq))
+    cum = np.cumsum(w) / w.sum()
+    bounds = [0]
+    for p in range(len(w) - 1):
+        target = total * float(cum[p])
+        if n_qry == 0:
+            b = 2.0 * n_ref - 1.0
+            disc = max(b * b - 8.0 * target, 0.0)
+            q = int((b - disc ** 0.5) / 2.0)
+        else:
+            q = int(target / float(n_ref))
+        q = (q + 32) // 64 * 64
+        bounds.append(max(min(q, nq), bounds[-1]))
+    bounds.append(nq)
+    return bounds
+
+
 class SketchDB:
     """One sample list's bin-sketches resident in HBM on one GPU (ppk_db).
 
@@ -473,29 +498,38 @@ class ShardedQuery:
     `band_fn(q_begin, q_end, out)` overrides the HIP launch (CPU gloo tests)."""
 
     def __init__(self, ref, qry, rank, world_size, n_chunks=4, cols=2, dtype=None, device=None,
-                 group=None):
+                 group=None, weights=None):
         torch = _torch()
         self.ref, self.qry = ref, qry
         self.rank, self.world = rank, world_size
         self.group = group
         self.n_qry = qry.n if qry is not None else 0
-        self.bounds = shard_bounds(ref.n, self.n_qry, world_size)
-        self.chunks = [sub_bands(self.bounds[r], self.bounds[r + 1], n_chunks)
-                       for r in range(world_size)]
-        self.rows = [[rows_in_band(ref.n, self.n_qry, ch[c], ch[c + 1]) for c in range(n_chunks)]
-                     for ch in self.chunks]
         self.n_chunks = n_chunks
         self.cols = cols
+        self.dtype = dtype or torch.float32
+        self.device = device if device is not None else "cuda:%d" % ref.device
+        self.out = None
+        self.weights = [1.0] * world_size if weights is None else [float(x) for x in weights]
+        self._layout(shard_bounds(ref.n, self.n_qry, world_size) if weights is None
+                     else band_split_weighted(ref.n, self.n_qry, self.weights))
+
+    def _layout(self, bounds):
+        """Bands -> sub-bands -> row counts and offsets; (re)allocates the local result."""
+        torch = _torch()
+        self.bounds = [int(b) for b in bounds]
+        self.chunks = [sub_bands(self.bounds[r], self.bounds[r + 1], self.n_chunks)
+                       for r in range(self.world)]
+        self.rows = [[rows_in_band(self.ref.n, self.n_qry, ch[c], ch[c + 1]) for c in range(self.n_chunks)]
+                     for ch in self.chunks]
         self.band_rows = [sum(r) for r in self.rows]
         self.total_rows = sum(self.band_rows)
-        dtype = dtype or torch.float32
-        if device is None:
-            device = "cuda:%d" % ref.device
         # rank 0 owns the full matrix and computes its own band in place; peers own a band
-        n_local = self.total_rows if rank == 0 else self.band_rows[rank]
-        self.out = torch.empty((n_local, cols), dtype=dtype, device=device)
+        n_local = self.total_rows if self.rank == 0 else self.band_rows[self.rank]
+        if self.out is None or self.out.shape[0] != n_local:
+            self.out = None          # release before allocating the new one
+            self.out = torch.empty((n_local, self.cols), dtype=self.dtype, device=self.device)
         self.band_off = [0]
-        for r in range(world_size):
+        for r in range(self.world):
             self.band_off.append(self.band_off[-1] + self.band_rows[r])
 
     def _chunk_view(self, r, c):
@@ -505,17 +539,29 @@ class ShardedQuery:
 
     def run(self, kmers=None, random_tbl=None, random_correct=True, band_fn=None):
         """One whole-job step.  Returns the full matrix on rank 0 (None elsewhere)."""
+        import time
         import torch.distributed as dist_
+        torch = _torch()
         pending = []
+        timing = getattr(self, "_time_compute", False)
+        on_gpu = str(self.device).startswith("cuda")
+        if timing:
+            self._compute_s = 0.0
+            if on_gpu:
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record(torch.cuda.current_stream(self.device))
         for c in range(self.n_chunks):
             qb, qe = self.chunks[self.rank][c], self.chunks[self.rank][c + 1]
             view = self._chunk_view(self.rank, c)
             if view.shape[0]:
+                t_c = time.perf_counter()
                 if band_fn is not None:
                     band_fn(qb, qe, view)
                 else:
                     dist(self.ref, self.qry, kmers, random_tbl, random_correct=random_correct,
                          q_begin=qb, q_end=qe, out=view)
+                if timing and not on_gpu:
+                    self._compute_s += time.perf_counter() - t_c
             if self.world == 1:
                 continue
             if self.rank == 0:
@@ -525,9 +571,68 @@ class ShardedQuery:
                 ops = [dist_.P2POp(dist_.isend, view, 0, self.group)] if view.shape[0] else []
             if ops:
                 pending.extend(dist_.batch_isend_irecv(ops))
+        if timing and on_gpu:
+            ev1.record(torch.cuda.current_stream(self.device))
         for req in pending:
             req.wait()
+        if timing and on_gpu:
+            ev1.synchronize()
+            self._compute_s = ev0.elapsed_time(ev1) * 1e-3
         return self.out if self.rank == 0 else None
+
+    def rebalance(self, kmers=None, random_tbl=None, random_correct=True, band_fn=None, steps=2):
+        """Re-cut the bands so that every rank's part of a step takes equally long.
+
+        With equal bands a step lasts as long as the slowest peer-to-root transfer: a peer
+        produces 8 B per pair faster than its one link to the root carries them, while the root's
+        own band needs no transfer at all.  One measured step gives each rank's rate -- the root:
+        pairs per second of compute; a peer: pairs per second until its last block has been
+        handed over -- and the new shares are proportional to the rates (the model is linear,
+        so one or two calls converge; where the links keep up with the kernels the rates are
+        equal and so stay the bands).  Collective: every rank must call it the same number of
+        times.  Returns the new shares (fractions of the pair space per rank)."""
+        import time
+        import torch.distributed as dist_
+        torch = _torch()
+        if self.world == 1:
+            return [1.0]
+        on_gpu = str(self.device).startswith("cuda")
+
+        def sync():
+            if on_gpu:
+                torch.cuda.synchronize(self.device)
+
+        mine = 0.0
+        self._time_compute = True
+        try:
+            for _ in range(max(1, steps)):           # the last step's time is the one used
+                dist_.barrier(self.group)
+                sync()
+                t0 = time.perf_counter()
+                self.run(kmers, random_tbl, random_correct, band_fn)
+                sync()
+                # the root's part of a step is its own band's kernels (the rest of its step is
+                # waiting for the peers); a peer's part is everything up to its last hand-over
+                mine = self._compute_s if self.rank == 0 else time.perf_counter() - t0
+        finally:
+            self._time_compute = False
+        nccl = str(dist_.get_backend(self.group)).lower() == "nccl"
+        t = torch.tensor([mine], dtype=torch.float64, device=self.device if (on_gpu and nccl) else "cpu")
+        times = [torch.zeros_like(t) for _ in range(self.world)]
+        dist_.all_gather(times, t, group=self.group)
+        times = [float(x.item()) for x in times]
+        rates = [self.band_rows[r] / times[r] if (times[r] > 0 and self.band_rows[r] > 0) else 0.0
+                 for r in range(self.world)]
+        if not any(x > 0 for x in rates):
+            return [b / max(self.total_rows, 1) for b in self.band_rows]
+        # shares move at most 2x per call (one noisy measurement must not starve a rank: a tiny band's
+        # rate is dominated by fixed costs and would not recover), and no rank drops below 1 %
+        cur = [max(b / max(self.total_rows, 1), 1e-3) for b in self.band_rows]
+        tgt = [x / sum(rates) for x in rates]
+        new = [c * min(max(t / c, 0.5), 2.0) for c, t in zip(cur, tgt)]
+        self.weights = [max(x / sum(new), 0.01) for x in new]
+        self._layout(band_split_weighted(self.ref.n, self.n_qry, self.weights))
+        return [b / max(self.total_rows, 1) for b in self.band_rows]
 
 
 def query_sharded(ref, qry, kmers, random_tbl, rank, world_size, random_correct=True,

@@ -60,16 +60,48 @@ def _worker(rank, world, port, n_ref, n_qry, ret):
                               device="cpu")
     piped = job.run(band_fn=lambda qb, qe, out: out.copy_(band_fn(qb, qe)))
     piped2 = job.run(band_fn=lambda qb, qe, out: out.copy_(band_fn(qb, qe)))   # reusable
+    # re-cut bands from measured rates (collective), then the job must still give the same matrix
+    fn = lambda qb, qe, out: out.copy_(band_fn(qb, qe))
+    shares = job.rebalance(band_fn=fn, steps=1)
+    shares = job.rebalance(band_fn=fn, steps=1)
+    piped3 = job.run(band_fn=fn)
+    # explicit weights: the root takes three quarters of the pair space
+    job_w = engine.ShardedQuery(DB(n_ref), DB(n_qry) if n_qry else None, rank, world, n_chunks=2,
+                                device="cpu", weights=[3.0, 1.0])
+    piped4 = job_w.run(band_fn=fn)
     if rank == 0:
         want, _ = oracle.query(ref_sk, qry_sk, kmers, 16, 14, tbl)
         ok = full is not None and np.array_equal(full.numpy(), want) and sum(rows) == len(want)
         ok = ok and np.array_equal(piped.numpy(), want) and np.array_equal(piped2.numpy(), want)
         ok = ok and job.total_rows == len(want) and sum(job.band_rows) == len(want)
+        ok = ok and np.array_equal(piped3.numpy(), want) and abs(sum(shares) - 1.0) < 1e-9
+        ok = ok and np.array_equal(piped4.numpy(), want) and job_w.bounds[1] % 64 == 0
+        ok = ok and (job_w.band_rows[0] >= job_w.band_rows[1] or job_w.bounds[1] in (0, n_qry or n_ref))
         ret.put(bool(ok))
     else:
-        assert full is None and piped is None
+        assert full is None and piped is None and piped3 is None and piped4 is None
     dist.barrier()
     dist.destroy_process_group()
+
+
+def test_weighted_band_split_properties():
+    sys.path.insert(0, ROOT)
+    from poppunk_amd import engine
+    for n_ref, n_qry in ((10000, 0), (777, 0), (300, 5000), (64, 0)):
+        nq = n_qry or n_ref
+        total = engine.rows_in_band(n_ref, n_qry, 0, nq)
+        for w in ([1, 1], [1, 1, 1, 1, 1, 1, 1, 1], [5, 1, 1, 1], [0.276] + [0.1034] * 7, [1, 0, 1]):
+            b = engine.band_split_weighted(n_ref, n_qry, w)
+            assert b[0] == 0 and b[-1] == nq and len(b) == len(w) + 1
+            assert all(x <= y for x, y in zip(b[:-1], b[1:])) and all(x % 64 == 0 for x in b[1:-1])
+            rows = [engine.rows_in_band(n_ref, n_qry, b[i], b[i + 1]) for i in range(len(w))]
+            assert sum(rows) == total
+            if n_ref >= 5000 or n_qry >= 5000:          # shares follow the weights to within a tile row
+                for i, wi in enumerate(w):
+                    assert abs(rows[i] / total - wi / sum(w)) < 0.02
+        assert engine.band_split_weighted(n_ref, n_qry, [1] * 4) == engine.band_split(n_ref, n_qry, 4)
+    with pytest.raises(ValueError):
+        engine.band_split_weighted(100, 0, [0, 0])
 
 
 @pytest.mark.parametrize("n_ref,n_qry", [(200, 0), (130, 70), (40, 0)])

@@ -18,8 +18,14 @@ job = engine.ShardedQuery(db, None, rank, world, n_chunks=3)
 full = job.run(K, T)
 full = job.run(K, T)          # reusable
 torch.cuda.synchronize()
+first = full.clone() if rank == 0 else None
+shares = job.rebalance(K, T)  # bands re-cut from the measured rates (collective); same matrix after
+shares = job.rebalance(K, T)
+full = job.run(K, T)
+torch.cuda.synchronize()
 if rank == 0:
     whole, _ = engine.dist(db, None, K, T)
-    print("RESULT equal=%s rows=%d bands=%s" % (bool(torch.equal(full, whole)), full.shape[0], job.band_rows))
+    ok = bool(torch.equal(first, whole)) and bool(torch.equal(full, whole))
+    print("RESULT equal=%s rows=%d bands=%s shares=%s" % (ok, full.shape[0], job.band_rows, ["%.3f" % x for x in shares]))
 dist.barrier()
 dist.destroy_process_group()
