@@ -451,6 +451,8 @@ def gather_bands(local, rows_per_rank, cols, dtype, device, rank, world_size, ds
     import torch.distributed as dist_
     if world_size == 1:
         return local
+    if local.is_cuda and str(dist_.get_backend(group)).lower() != "nccl":
+        torch.cuda.current_stream(local.device).synchronize()      # gloo: no stream ordering (see ShardedQuery.run)
     if rank == dst:
         total = int(sum(rows_per_rank))
         full = torch.empty((total, cols), dtype=dtype, device=device)
@@ -532,6 +534,10 @@ class ShardedQuery:
         for r in range(self.world):
             self.band_off.append(self.band_off[-1] + self.band_rows[r])
 
+    def _nccl(self):
+        import torch.distributed as dist_
+        return str(dist_.get_backend(self.group)).lower() == "nccl"
+
     def _chunk_view(self, r, c):
         """Rows of chunk c of rank r's band inside self.out (rank 0: global offsets)."""
         start = sum(self.rows[r][:c]) + (self.band_off[r] if self.rank == 0 else 0)
@@ -564,6 +570,10 @@ class ShardedQuery:
                     self._compute_s += time.perf_counter() - t_c
             if self.world == 1:
                 continue
+            if on_gpu and not self._nccl():
+                # gloo (debugging transport) reads a CUDA tensor's memory from the host with no
+                # stream ordering; RCCL orders the send after the producing kernel by itself
+                torch.cuda.current_stream(self.device).synchronize()
             if self.rank == 0:
                 ops = [dist_.P2POp(dist_.irecv, self._chunk_view(s, c), s, self.group)
                        for s in range(1, self.world) if self.rows[s][c] > 0]
@@ -655,3 +665,40 @@ def query_sharded(ref, qry, kmers, random_tbl, rank, world_size, random_correct=
     full = gather_bands(local, rows, local.shape[1], local.dtype, local.device, rank, world_size,
                         0, group)
     return full, rows
+
+
+def edges_sharded(ref, qry, kmers, random_tbl, rank, world_size, slope=2, x_max=0.0, y_max=0.0,
+                  scale=(1.0, 1.0), inclusive=True, random_correct=True, band_fn=None, group=None,
+                  device=None):
+    """BASELINE config 5 on N GPUs: every rank runs the fused distance -> boundary -> edge-list
+    kernels on its band of query rows; only the edge lists move.  One all-gather of the per-rank
+    edge counts, then the variable-length lists go to rank 0 with the same grouped send/recv as
+    the distance blocks (`gather_bands`).  Bands are contiguous row ranges in rank order, so the
+    concatenation is the edge list of the whole matrix in PopPUNK row order -- equal to
+    `dist_edges` on one GPU.  Bands are equal here: an edge list is ~1e-3 of a distance block, so
+    there is no transfer to balance.  Returns (edges int64 [n_edges, 2] on rank 0 / None
+    elsewhere, per-rank edge counts).  `band_fn(q_begin, q_end) -> int64 [n, 2]` overrides the
+    HIP launch (CPU gloo tests)."""
+    torch = _torch()
+    import torch.distributed as dist_
+    n_qry = qry.n if qry is not None else 0
+    bounds = shard_bounds(ref.n, n_qry, world_size)
+    qb, qe = bounds[rank], bounds[rank + 1]
+    if band_fn is not None:
+        local = band_fn(qb, qe)
+    elif qe > qb:
+        local, _ = dist_edges(ref, qry, kmers, random_tbl, random_correct=random_correct, slope=slope,
+                              x_max=x_max, y_max=y_max, scale=scale, inclusive=inclusive, q_begin=qb,
+                              q_end=qe)
+    else:
+        local = torch.empty((0, 2), dtype=torch.int64, device=device or "cuda:%d" % ref.device)
+    local = local.contiguous()
+    if world_size == 1:
+        return local, [int(local.shape[0])]
+    nccl = str(dist_.get_backend(group)).lower() == "nccl"
+    cnt = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device if nccl else "cpu")
+    counts = [torch.zeros_like(cnt) for _ in range(world_size)]
+    dist_.all_gather(counts, cnt, group=group)
+    counts = [int(c.item()) for c in counts]
+    full = gather_bands(local, counts, 2, torch.int64, local.device, rank, world_size, 0, group)
+    return full, counts

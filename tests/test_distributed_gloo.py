@@ -69,8 +69,27 @@ def _worker(rank, world, port, n_ref, n_qry, ret):
     job_w = engine.ShardedQuery(DB(n_ref), DB(n_qry) if n_qry else None, rank, world, n_chunks=2,
                                 device="cpu", weights=[3.0, 1.0])
     piped4 = job_w.run(band_fn=fn)
+    # config 5 shape: per-band edge lists, variable lengths, gathered in rank order
+    want_all, _ = oracle.query(ref_sk, qry_sk, kmers, 16, 14, tbl)
+    x_max, y_max = synth.boundary_for_quantile(want_all, 0.3)
+    want_edges = np.asarray(oracle.edge_threshold(want_all, 2, x_max, y_max, n_ref=n_ref if n_qry else 0)).reshape(-1, 2)
+
+    # the whole matrix's edge list is in row order, so a band's edges are a contiguous slice of it
+    is_edge = oracle.assign_threshold(want_all, 2, x_max, y_max) <= 0
+    first = np.concatenate([[0], np.cumsum(is_edge)])
+
+    def edge_fn(qb, qe):
+        r0 = engine.rows_in_band(n_ref, n_qry, 0, qb)
+        r1 = engine.rows_in_band(n_ref, n_qry, 0, qe)
+        return torch.from_numpy(want_edges[first[r0]:first[r1]].astype(np.int64).copy())
+
+    e_full, e_counts = engine.edges_sharded(DB(n_ref), DB(n_qry) if n_qry else None, kmers, tbl, rank,
+                                            world, band_fn=edge_fn, device="cpu")
     if rank == 0:
         want, _ = oracle.query(ref_sk, qry_sk, kmers, 16, 14, tbl)
+        ok_e = e_full is not None and np.array_equal(e_full.numpy(), want_edges) and sum(e_counts) == len(want_edges)
+        if not ok_e:
+            ret.put(False)
         ok = full is not None and np.array_equal(full.numpy(), want) and sum(rows) == len(want)
         ok = ok and np.array_equal(piped.numpy(), want) and np.array_equal(piped2.numpy(), want)
         ok = ok and job.total_rows == len(want) and sum(job.band_rows) == len(want)
@@ -79,7 +98,7 @@ def _worker(rank, world, port, n_ref, n_qry, ret):
         ok = ok and (job_w.band_rows[0] >= job_w.band_rows[1] or job_w.bounds[1] in (0, n_qry or n_ref))
         ret.put(bool(ok))
     else:
-        assert full is None and piped is None and piped3 is None and piped4 is None
+        assert full is None and piped is None and piped3 is None and piped4 is None and e_full is None
     dist.barrier()
     dist.destroy_process_group()
 

@@ -24,3 +24,4 @@ def test_two_ranks_one_gpu_matches_single_launch():
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "RESULT equal=True" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "EDGES equal=True" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -27,5 +27,11 @@ if rank == 0:
     whole, _ = engine.dist(db, None, K, T)
     ok = bool(torch.equal(first, whole)) and bool(torch.equal(full, whole))
     print("RESULT equal=%s rows=%d bands=%s shares=%s" % (ok, full.shape[0], job.band_rows, ["%.3f" % x for x in shares]))
+# config 5 shape: fused distance -> boundary -> edges per band, only the edge lists gathered
+xm, ym = 0.02, 0.05
+e_full, e_counts = engine.edges_sharded(db, None, K, T, rank, world, slope=2, x_max=xm, y_max=ym)
+if rank == 0:
+    e_whole, _ = engine.dist_edges(db, None, K, T, slope=2, x_max=xm, y_max=ym)
+    print("EDGES equal=%s n=%d per rank=%s" % (bool(torch.equal(e_full, e_whole)), e_full.shape[0], e_counts))
 dist.barrier()
 dist.destroy_process_group()
