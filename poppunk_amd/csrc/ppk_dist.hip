@@ -21,8 +21,10 @@
 //  * dist_kernel (v1; generic bbits and A/B experiments): 64 refs per wavefront
 //    staged through LDS, query words through the scalar unit (s_load_dwordx16)
 //    as SGPR operands;
-//  * per-k match counts are packed into a 64/128-bit shift register per pair,
-//    and after the last k the lane regresses log J on k in fp64 (log J comes
+//  * per-k match counts live in a 2/3/4-dword shift register per pair whose low
+//    field IS the running counter of the current k (PackW below); the full block
+//    also issues the wave's four DMA pieces of the next block from inside its own
+//    instruction stream; after the last k the lane regresses log J on k in fp64 (log J comes
 //    from a device-built table indexed by (cluster pair, k, count): the count
 //    is an integer in [0, nbins], so the table is exact, not an approximation),
 //    then writes float2 rows -- consecutive lanes are consecutive refs, which

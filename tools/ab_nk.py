@@ -1,4 +1,4 @@
-"""Throughput against the number of k-mer lengths (pack type: u64 for nk<=5, Pack96 for 6, u128 beyond) at s=1024."""
+"""Throughput against the number of k-mer lengths at s=1024 (count register of 2 dwords up to 5 lengths, 3 up to 8, 4 beyond)."""
 import os, sys, time, ctypes as C
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
