@@ -186,9 +186,28 @@ def main():
         # the root carries them) while the root's own band needs none.  Three measured steps re-cut
         # the bands in proportion to each rank's measured rate (engine.ShardedQuery.rebalance).
         if not args.even_bands:
+            def probe(n_steps=3):
+                """ms per gathered step, max over ranks (the same number on every rank)."""
+                barrier()
+                t_p = time.perf_counter()
+                for _ in range(n_steps):
+                    step()
+                barrier()
+                t = torch.tensor([(time.perf_counter() - t_p) / n_steps * 1e3], dtype=torch.float64,
+                                 device=dev if dist.get_backend() == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                return float(t.item())
+            ms_even = probe()
             for _ in range(3):
-                shares = job.rebalance(kmers, tbl)
+                job.rebalance(kmers, tbl)
+            ms_balanced = probe()
+            band_note = "rate-balanced (%.2f ms/step against %.2f with equal bands, set-up probe)" % (ms_balanced, ms_even)
+            if ms_balanced > 1.02 * ms_even:      # never keep a cut that measures worse than the equal one
+                job._layout(engine.shard_bounds(ref.n, 0, world))
+                band_note = "equal (the rate-balanced cut measured %.2f ms/step against %.2f)" % (ms_balanced, ms_even)
             rows = job.band_rows
+        else:
+            band_note = "equal (--even-bands)"
     for _ in range(args.warmup):
         step()
     barrier()
@@ -251,7 +270,7 @@ def main():
                                    "bbits=14), k=13,17,21,25,29, %d pairs, output [n_pairs,2] f32 "
                                    "on rank 0" % (n, total_pairs),
                        "n_genomes": n, "pairs": total_pairs,
-                       "parallelism": "band-split x%d (%s bands), %d-chunk pipelined p2p gather to rank 0" % (world, "equal" if args.even_bands else "rate-balanced", args.chunks) if world > 1 else "1 GPU"},
+                       "parallelism": "band-split x%d (%s bands), %d-chunk pipelined p2p gather to rank 0" % (world, band_note.split(" ")[0], args.chunks) if world > 1 else "1 GPU"},
             "roofline": roof, "cpu_baseline": cpu,
         }
         if world > 1:
@@ -260,8 +279,8 @@ def main():
                 "compute_ms_per_step_max_rank": round(compute_ms, 4),
                 "gathered_bytes_per_step": int(sum(job.band_rows[1:])) * 8,
                 "band_shares": [round(b / max(total_pairs, 1), 4) for b in job.band_rows],
-                "bands": "equal" if args.even_bands else "re-cut from measured per-rank rates during set-up "
-                                                         "(3 untimed steps): the root's band needs no transfer",
+                "bands": band_note + "; the root's band needs no transfer, so equal bands are not the "
+                                     "fastest cut (engine.ShardedQuery.rebalance)",
                 "note": "value includes the p2p gather of every peer's distance block into the "
                         "PopPUNK-ordered matrix on rank 0 (pipelined under compute in %d chunks); "
                         "the root's inbound xGMI links bound it" % args.chunks}
