@@ -460,3 +460,30 @@ def test_count_register_widths(monkeypatch, s64, nk, words):
         e, _ = engine.dist_edges(db, None, kmers, tbl, slope=2, x_max=x_max, y_max=y_max)
         assert np.array_equal(e.cpu().numpy(), oracle.edge_threshold(got, 2, x_max, y_max))
         db.close()
+
+
+def test_host_result_pages_are_touched_ahead_of_the_download(monkeypatch):
+    """ppk_query's helper threads write the first byte of every page of the (fresh) result array
+    before the chunked download reaches it: any thread count, arrays that do not start on a page
+    boundary, several sub-bands and devices in the list -- the result is the one without them."""
+    kmers = np.asarray(synth.DEFAULT_KMERS, dtype=np.int32)
+    tbl = synth.random_match_table(kmers)
+    sk = synth.make_sketches(1700, kmers, cluster_size=40, seed=77)[0]      # 1.44 M pairs: 11.6 MB of float2
+    monkeypatch.setenv("PPK_PREFAULT_THREADS", "0")
+    want, wf = pp_sketchlib.query_arrays(sk, None, kmers, 16, 14, tbl)
+    assert want.nbytes > (8 << 20)
+    for threads, chunk_rows, devices in (("1", None, (0,)), ("3", "200000", (0,)), ("64", "77777", (0, 0)), ("8", None, (0,))):
+        monkeypatch.setenv("PPK_PREFAULT_THREADS", threads)
+        if chunk_rows:
+            monkeypatch.setenv("PPK_CHUNK_ROWS", chunk_rows)
+        else:
+            monkeypatch.delenv("PPK_CHUNK_ROWS", raising=False)
+        got, gf = pp_sketchlib.query_arrays(sk, None, kmers, 16, 14, tbl, devices=devices)
+        assert gf == wf and np.array_equal(got, want)
+    # the square / long helpers pre-touch their results the same way
+    monkeypatch.setenv("PPK_PREFAULT_THREADS", "5")
+    n = 2100                                                                 # 17.6 MB square
+    v = np.random.Generator(np.random.PCG64(3)).random(n * (n - 1) // 2, dtype=np.float32)
+    sq = pp_sketchlib.longToSquare(v.reshape(-1, 1))
+    assert sq.shape == (n, n) and np.array_equal(sq[np.triu_indices(n, 1)], v) and np.array_equal(sq, sq.T)
+    assert np.array_equal(pp_sketchlib.squareToLong(sq).ravel(), v)
