@@ -16,7 +16,9 @@ here is a flat `<prefix>/<basename>.npz` with the same content:
 
 `load()` also reads the reference's .h5 layout when h5py is importable (sketches
 only: the internal layout of pp-sketchlib's /random group is not documented in
-the reference tree, so a .h5 database is loaded without a random-match table).
+the reference tree, so a .h5 database is loaded without a random-match table), and
+`python -m poppunk_amd.sketchdb <prefix>/<basename>` converts a .h5 database to .npz in any
+interpreter that has h5py (no GPU or torch needed).
 """
 import os
 import sys
@@ -102,6 +104,24 @@ def _load_h5(path, names, klist):
                               None, None)
 
 
+def convert_h5_to_npz(db_name, out_name=None):
+    """Rewrite the reference's `<db_name>.h5` (PopPUNK/web.py:14-61 layout) as `<out_name>.npz`
+    (default: next to it) with every sample and every k-mer length it holds.  Needs h5py, not a
+    GPU: `python -m poppunk_amd.sketchdb <prefix>/<basename>` runs it in whatever interpreter has
+    h5py.  The /random group is not carried over (its layout is internal to pp-sketchlib)."""
+    import h5py  # optional
+    with h5py.File(db_name + ".h5", "r") as f:
+        grp = f["sketches"]
+        names = sorted(grp.keys())
+        if not names:
+            raise RuntimeError("no samples in %s.h5" % db_name)
+        kmers = sorted(int(k) for k in grp[names[0]].attrs["kmers"])
+    loaded = _load_h5(db_name + ".h5", names, kmers)
+    save_npz(out_name or db_name, loaded.names, loaded.kmers, loaded.sketches, loaded.sketchsize64,
+             loaded.bbits)
+    return len(names), kmers
+
+
 def load(db_name, names, klist):
     """Load `names` x `klist` from `<db_name>.npz` (preferred) or `<db_name>.h5`."""
     names = [str(n) for n in names]
@@ -114,6 +134,13 @@ def load(db_name, names, klist):
         try:
             return _load_h5(db_name + ".h5", names, klist)
         except ImportError:
-            raise RuntimeError("reading %s.h5 needs h5py, which is not installed; "
-                               "convert the database to .npz" % db_name)
+            raise RuntimeError("reading %s.h5 needs h5py, which is not installed; convert the database with "
+                               "`python -m poppunk_amd.sketchdb %s` in an interpreter that has it" % (db_name, db_name))
     raise RuntimeError("sketch database %s(.npz|.h5) not found" % db_name)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) not in (2, 3):
+        sys.exit("usage: python -m poppunk_amd.sketchdb <prefix>/<basename> [<out prefix>/<basename>]   (.h5 -> .npz)")
+    n_done, k_done = convert_h5_to_npz(sys.argv[1], sys.argv[2] if len(sys.argv) == 3 else None)
+    print("wrote %s.npz: %d samples, k = %s" % (sys.argv[2] if len(sys.argv) == 3 else sys.argv[1], n_done, k_done))

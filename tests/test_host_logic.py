@@ -2,8 +2,12 @@
 behaviour of sketchlib.queryDatabase (PopPUNK/sketchlib.py:475-632), the noconvert rule of
 poppunk_refine (src/python_bindings.cpp:82,:89), the sketch database files and the synthetic
 generator.  No GPU compute is triggered here."""
+import os
+
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from poppunk_amd import poppunk_refine, pp_sketchlib, sketchdb, sketchlib, synth
 
@@ -137,3 +141,71 @@ def test_clusters_from_edges():
     assert n_comp == 3
     assert labels[0] == labels[1] == labels[2] and labels[4] == labels[5] and labels[3] not in (labels[0], labels[4])
     assert distfile.clusters_from_edges(3, np.zeros((0, 2), dtype=np.int64))[0] == 3
+
+
+H5_PYTHON = "/opt/conda/bin/python3.9"      # this image's second interpreter is the one with h5py
+
+
+def _h5_python_ok():
+    import subprocess
+    if not os.path.exists(H5_PYTHON):
+        return False
+    return subprocess.run([H5_PYTHON, "-c", "import h5py, numpy"], capture_output=True).returncode == 0
+
+
+@pytest.mark.skipif(not _h5_python_ok(), reason="no interpreter with h5py in this image")
+def test_reference_h5_layout_reader_and_converter(tmp_path):
+    """The reference keeps sketches in <prefix>/<basename>.h5: group /sketches, one group per sample
+    with attrs sketchsize64 / bbits / kmers / length / ..., one uint64 dataset per k named str(k)
+    (PopPUNK/web.py:14-61).  h5py lives in the image's conda interpreter only, so that interpreter
+    writes such a file, reads it through sketchdb.load (subset and order of names and of k) and
+    converts it; this interpreter then reads the converted .npz and compares everything."""
+    import subprocess
+    from poppunk_amd import sketchdb, synth
+    kmers = np.asarray([13, 17, 21, 25], dtype=np.int32)
+    sk, _ = synth.make_sketches(9, kmers, sketchsize64=3, bbits=14, cluster_size=3, seed=12)
+    names = ["s%02d" % i for i in range(9)]
+    src = tmp_path / "src.npz"
+    np.savez(src, names=np.asarray(names), kmers=kmers, sketches=sk)
+    prefix = str(tmp_path / "db" / "db")
+    script = r'''
+import sys, os, importlib.util
+import numpy as np, h5py
+src, prefix, repo, out = sys.argv[1:5]
+z = np.load(src)
+os.makedirs(os.path.dirname(prefix))
+with h5py.File(prefix + ".h5", "w") as f:
+    g = f.create_group("sketches")
+    g.attrs["sketch_version"] = "test"
+    g.attrs["codon_phased"] = False
+    for i, nm in enumerate(z["names"]):
+        s = g.create_group(str(nm))
+        s.attrs["sketchsize64"] = 3
+        s.attrs["bbits"] = 14
+        s.attrs["length"] = 2000000
+        s.attrs["missing_bases"] = 0
+        s.attrs["base_freq"] = [0.25, 0.25, 0.25, 0.25]
+        s.attrs["kmers"] = [int(k) for k in z["kmers"]]
+        for j, k in enumerate(z["kmers"]):
+            d = s.create_dataset(str(int(k)), data=z["sketches"][i, j], dtype="uint64")
+            d.attrs["kmer-size"] = int(k)
+spec = importlib.util.spec_from_file_location("sketchdb", os.path.join(repo, "poppunk_amd", "sketchdb.py"))
+m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+got = m.load(prefix, ["s07", "s02", "s05"], [21, 13])
+np.savez(out, sketches=got.sketches, kmers=got.kmers, s64=got.sketchsize64, bbits=got.bbits)
+print(m.convert_h5_to_npz(prefix, prefix + "_conv"))
+'''
+    out = tmp_path / "loaded.npz"
+    r = subprocess.run([H5_PYTHON, "-c", script, str(src), prefix, ROOT, str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    z = np.load(out)
+    assert int(z["s64"]) == 3 and int(z["bbits"]) == 14 and list(z["kmers"]) == [21, 13]
+    assert np.array_equal(z["sketches"], sk[[7, 2, 5]][:, [2, 0], :])
+    conv = sketchdb.load(prefix + "_conv", names, kmers)              # .npz written by the converter
+    assert np.array_equal(conv.sketches, sk) and conv.sketchsize64 == 3 and conv.bbits == 14
+    # without h5py (this interpreter) a .h5 database says how to convert it
+    try:
+        import h5py  # noqa: F401
+    except ImportError:
+        with pytest.raises(RuntimeError, match="poppunk_amd.sketchdb"):
+            sketchdb.load(prefix, names, kmers)
