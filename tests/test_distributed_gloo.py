@@ -67,7 +67,7 @@ def _worker(rank, world, port, n_ref, n_qry, ret):
     piped3 = job.run(band_fn=fn)
     # explicit weights: the root takes three quarters of the pair space
     job_w = engine.ShardedQuery(DB(n_ref), DB(n_qry) if n_qry else None, rank, world, n_chunks=2,
-                                device="cpu", weights=[3.0, 1.0])
+                                device="cpu", weights=[3.0] + [1.0] * (world - 1))
     piped4 = job_w.run(band_fn=fn)
     # config 5 shape: per-band edge lists, variable lengths, gathered in rank order
     want_all, _ = oracle.query(ref_sk, qry_sk, kmers, 16, 14, tbl)
@@ -123,13 +123,15 @@ def test_weighted_band_split_properties():
         engine.band_split_weighted(100, 0, [0, 0])
 
 
-@pytest.mark.parametrize("n_ref,n_qry", [(200, 0), (130, 70), (40, 0)])
-def test_band_split_and_gather_world2(n_ref, n_qry):
+@pytest.mark.parametrize("n_ref,n_qry,world", [(200, 0, 2), (130, 70, 2), (40, 0, 2), (700, 0, 8), (90, 600, 4)])
+def test_band_split_and_gather(n_ref, n_qry, world):
+    """world = 8 is the shape of the driver's scaling run: eight bands, eight-way grouped receives on
+    the root, rebalancing and the edge-list gather with eight participants."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_ref, n_qry, ret)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_ref, n_qry, ret)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
