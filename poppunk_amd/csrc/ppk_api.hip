@@ -233,6 +233,30 @@ extern "C" void ppk_db_destroy(ppk_db *db) {
 
 extern "C" size_t ppk_db_size(const ppk_db *db) { return db ? db->n : 0; }
 
+// ---- per-device worker streams of the host-buffer entry points -------------------------
+// hipStreamCreate + hipStreamDestroy cost ~0.4 ms each on this stack: three quarters of a
+// 1 000-genome ppk_query call.  The host-buffer entry points therefore take their (up to three)
+// streams from a per-device cache that lives as long as the process.  Calls from several host
+// threads share them: their work is ordered on the streams, which is correct (each call
+// synchronises its streams before it returns) if not concurrent.
+namespace {
+int worker_streams(int device, hipStream_t *out, int n) {
+  static std::mutex mu;
+  static std::vector<std::vector<hipStream_t>> cache;
+  std::lock_guard<std::mutex> lk(mu);
+  if (device < 0 || n < 1 || n > 3) return ppk_fail(PPK_ERR_ARG, "bad worker stream request");
+  if ((size_t)device >= cache.size()) cache.resize((size_t)device + 1);
+  std::vector<hipStream_t> &v = cache[(size_t)device];
+  while ((int)v.size() < n) {
+    hipStream_t s = nullptr;
+    if (hipStreamCreate(&s) != hipSuccess) return ppk_fail(PPK_ERR_HIP, "hipStreamCreate failed");
+    v.push_back(s);
+  }
+  for (int i = 0; i < n; ++i) out[i] = v[(size_t)i];
+  return PPK_OK;
+}
+}  // namespace
+
 // ---- kernel 1, device entry points -------------------------------------------------
 namespace {
 
@@ -579,8 +603,6 @@ extern "C" int ppk_query(const uint64_t *ref_sk, size_t n_ref, const uint64_t *q
       if (p.d_failed) (void)hipFree(p.d_failed);
       if (p.ref) ppk_db_destroy(p.ref);
       if (p.qry) ppk_db_destroy(p.qry);
-      if (p.s && p.own_streams) (void)hipStreamDestroy(p.s);
-      if (p.sc && p.own_streams) (void)hipStreamDestroy(p.sc);
     }
   };
   for (int d = 0; d < n_dev && rc == PPK_OK; ++d) {
@@ -600,10 +622,16 @@ extern "C" int ppk_query(const uint64_t *ref_sk, size_t n_ref, const uint64_t *q
         p.own_streams = false;
         break;
       }
-    if ((p.own_streams && (hipStreamCreate(&p.s) != hipSuccess || hipStreamCreate(&p.sc) != hipSuccess)) ||
-        hipEventCreateWithFlags(&p.done[0], hipEventDisableTiming) != hipSuccess ||
+    if (p.own_streams) {
+      hipStream_t ws[2] = {nullptr, nullptr};
+      rc = worker_streams(devices[d], ws, 2);
+      if (rc != PPK_OK) break;
+      p.s = ws[0];
+      p.sc = ws[1];
+    }
+    if (hipEventCreateWithFlags(&p.done[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&p.done[1], hipEventDisableTiming) != hipSuccess) {
-      rc = ppk_fail(PPK_ERR_HIP, "hipStreamCreate / hipEventCreate failed");
+      rc = ppk_fail(PPK_ERR_HIP, "hipEventCreate failed");
       break;
     }
     rc = ppk_db_create(devices[d], ref_sk, n_ref, nk, sketchsize64, bbits, ref_clu, 0, p.s, &p.ref);
@@ -691,9 +719,13 @@ extern "C" int ppk_assign_threshold(const float *dist, size_t n_rows, int slope,
     return rc == PPK_OK;
   };
   HostToucher toucher(out, n_rows * 4);
-  ok(hipStreamCreate(&s_up), "hipStreamCreate");
-  ok(hipStreamCreate(&s_k), "hipStreamCreate");
-  ok(hipStreamCreate(&s_dn), "hipStreamCreate");
+  {
+    hipStream_t ws[3] = {nullptr, nullptr, nullptr};
+    if (worker_streams(device_id, ws, 3) != PPK_OK) return PPK_ERR_HIP;
+    s_up = ws[0];
+    s_k = ws[1];
+    s_dn = ws[2];
+  }
   const int n_buf = n_chunks > 1 ? 2 : 1;
   for (int i = 0; i < n_buf && rc == PPK_OK; ++i) {
     ok(hipMalloc(reinterpret_cast<void **>(&d_in[i]), buf_rows * 8), "hipMalloc");
@@ -732,9 +764,6 @@ extern "C" int ppk_assign_threshold(const float *dist, size_t n_rows, int slope,
     if (freed_in[i]) (void)hipEventDestroy(freed_in[i]);
     if (freed_out[i]) (void)hipEventDestroy(freed_out[i]);
   }
-  if (s_up) (void)hipStreamDestroy(s_up);
-  if (s_k) (void)hipStreamDestroy(s_k);
-  if (s_dn) (void)hipStreamDestroy(s_dn);
   if (rc != PPK_OK) g_err = keep;
   return rc;
 }
