@@ -45,15 +45,31 @@ extern "C" {
  * integer half of the path must be bit-identical to the CPU) */
 #define PPK_FLAG_COUNTS 4
 
-/* Threading: like the bindings it replaces, the library expects one call at a time per
- * device (PopPUNK calls it from the main thread, blocking).  Device entry points share
- * grow-only per-device scratch (log-J table, edge bitmask, sort buffers), so two calls
- * may only be in flight on one device if they are ordered on the same stream. */
+/* Threading: entry points may be called from any host thread.  Device entry points share
+ * grow-only per-device scratch (log-J table, edge bitmask, sort buffers): each holds the
+ * device's mutex while it enqueues, and a scratch block last used on another stream is waited
+ * for (an event) before it is re-used, so calls on different streams are ordered where they
+ * share scratch and concurrent elsewhere.  The host-buffer query (ppk_query, ppk_query_db) runs
+ * one call at a time, like the blocking binding it replaces. */
 const char *ppk_last_error(void);
-/* frees the per-device scratch (synchronises each device that holds any) */
+/* frees the per-device scratch, ppk_query's cached resident databases and its result buffers
+ * (synchronises each device that holds any) */
 int ppk_release_scratch(void);
 const char *ppk_version(void); /* replaces pp_sketchlib.version (PopPUNK/sketchlib.py:34) */
 int ppk_device_count(int *n);
+
+/* Run-time options.  Each has a PPK_<NAME> environment variable that is read ONCE, when the
+ * library is first used; afterwards only ppk_set_option changes it.
+ *   measurement / tuning (never change results): "ablate", "map", "strip", "ksplit",
+ *     "chunk_rows", "prefault_threads", "db_cache" 
+ *   [EXT] readings of pp-sketchlib behaviour that this tree cannot verify:
+ *     "ext_collision_adjust" 0 (default): the b-bit collision adjustment of calc_intersize is
+ *                              never in effect (upstream gates it on expected == 0, as recalled);
+ *                            1: applied when expected = nbins >> bbits is > 0
+ *     "ext_fit_skip"         0 (default): the regression uses the k-mer lengths before the first
+ *                              J < 5/nbins; 1: it skips every such k and keeps the rest */
+int ppk_set_option(const char *name, long long value);
+int ppk_get_option(const char *name, long long *value);
 
 /* ------------------------------------------------------------------------
  * Resident sketch database: the flat bin-sketch array of one sample list,
@@ -194,13 +210,25 @@ int ppk_threshold_iterate_2d_dev(const float *d_dist, size_t n_rows, const float
  * about 256 MB (sub-band c downloads while c+1 computes), so device memory use is
  * bounded by the sketches plus those buffers for any job size -- the
  * device-memory chunking of pp-sketchlib's CUDA path [EXT].  `out` is written by this call only; a few
- * helper threads touch its pages ahead of the download (PPK_PREFAULT_THREADS, default 8, 0 = off).
+ * helper threads touch its pages ahead of the download (option "prefault_threads", default 8, 0 = off).
+ * The resident form of the sketches and the two buffers are KEPT between calls (keyed by the host
+ * pointer, the dimensions and a fingerprint of the contents; option "db_cache" 0 turns it off;
+ * ppk_release_scratch frees them): a caller that rewrites sketches in place must do one of the two.
  */
 int ppk_query(const uint64_t *ref_sk, size_t n_ref, const uint64_t *qry_sk,
               size_t n_qry, const int32_t *kmers, size_t nk, size_t sketchsize64,
               size_t bbits, const float *random_tbl, const uint16_t *ref_clu,
               const uint16_t *qry_clu, size_t n_clu, int flags, const int *devices,
               int n_dev, void *out, unsigned long long *n_failed);
+
+/* The same with the sketches already resident (ppk_db_create; both on one device, fully uploaded):
+ * nothing is uploaded or re-laid out, the result goes to the host array `out` through that device's
+ * two persistent sub-band buffers.  What the Python mirror of queryDatabase calls for a database it
+ * has already loaded (poppunk_assign against one reference database; every --plot-fit re-query,
+ * PopPUNK/sketchlib.py:547-564). */
+int ppk_query_db(const ppk_db *ref, const ppk_db *qry, const int32_t *kmers,
+                 const float *random_tbl, size_t n_clu, int flags, void *out,
+                 unsigned long long *n_failed);
 
 int ppk_assign_threshold(const float *dist, size_t n_rows, int slope, float x_max,
                          float y_max, int device_id, float *out);
@@ -285,8 +313,6 @@ int ppk_prof_enable(int on);
 int ppk_prof_read(double *total_ms, long long *n_launches, int reset);
 /* name of the kernel variant the last ppk_dist*_dev call launched */
 const char *ppk_last_kernel_name(void);
-/* Tuning override for experiments: "TQ,NW" of the pair-tile (0,0 = auto). */
-int ppk_set_tile(int tq, int nw);
 
 #ifdef __cplusplus
 }

@@ -71,7 +71,14 @@ def lib():
         _lib.ppk_oracle_boundary_of_offset.argtypes = [c.c_double, c.c_int, c.c_float, c.c_float,
                                                       c.c_float, c.c_float, f32p]
         _lib.ppk_oracle_boundary_of_offset.restype = None
+        _lib.ppk_oracle_set_ext.argtypes = [c.c_int, c.c_int]
+        _lib.ppk_oracle_set_ext.restype = None
     return _lib
+
+
+def set_ext(collision_adjust=0, fit_skip=0):
+    """The two [EXT] switches (oracle/ppk_oracle.c header); defaults (0, 0)."""
+    lib().ppk_oracle_set_ext(int(collision_adjust), int(fit_skip))
 
 
 def _p(a, ct):

@@ -21,13 +21,18 @@
  *    (tests/golden/row_order.json) and the real sketch of
  *    test/json_sketch.txt (tests/golden/json_sketch.npz).  Equality with the
  *    upstream pp-sketchlib binary is UNVERIFIED: "parity unpinned" for the
- *    numerical values of kernel 1.
+ *    numerical values of kernel 1.  The two places where the recalled upstream
+ *    behaviour could be read either way are switches (ppk_oracle_set_ext, the
+ *    same two as libppk_hip.so's ppk_set_option): g_ext_collision_adjust and
+ *    g_ext_fit_skip below -- flipping a default is that one line.
  *  - Kernel 2 (boundary assignment / edge list): restates
- *    /root/reference/src/boundary.cpp:18-123.  That file needs Eigen, which is
+ *    /root/reference/src/boundary.cpp:18-237.  That file needs Eigen, which is
  *    absent from this image, so it cannot be compiled here without a stand-in
- *    header; it is pinned by the known-answer values recorded in SURVEY.md
- *    Appendix B (captured from the unmodified reference source during the
- *    survey) and by the structure of test/test-refine.py:47-82.
+ *    header (no oracle/_ref).  PINNED by the reference's own pure-Python
+ *    statement of the same functions -- withinBoundary / iter_tuples,
+ *    test/test-refine.py:10-38 -- executed by tests/golden/make_golden.py on
+ *    the grid and (seeded) matrices of that test:
+ *    tests/golden/boundary_refine.npz, checked by tests/refine_golden.py.
  *
  * Build: see oracle/Makefile  (gcc -O3 -fopenmp -ffp-contract=off).
  * -ffp-contract=off matters: line_dist must be evaluated as un-fused float32
@@ -44,6 +49,19 @@
 
 #define PPK_FLAG_RANDOM_CORRECT 1
 #define PPK_FLAG_JACCARD 2
+
+/* [EXT] switches (DESIGN.md section 5 lists every assumption and these lines):
+ *  g_ext_collision_adjust  0: calc_intersize's b-bit collision adjustment is never in effect --
+ *                             upstream, as recalled, gates it on expected_samebits == 0, where it
+ *                             is the identity; 1: applied when expected_samebits > 0.
+ *  g_ext_fit_skip          0: the regression stops at the first k with J < 5/nbins (upstream's
+ *                             loop breaks, as recalled); 1: it skips such k and keeps later ones. */
+static int g_ext_collision_adjust = 0;
+static int g_ext_fit_skip = 0;
+void ppk_oracle_set_ext(int collision_adjust, int fit_skip) {
+  g_ext_collision_adjust = collision_adjust != 0;
+  g_ext_fit_skip = fit_skip != 0;
+}
 
 /* ---- a3: bin match ------------------------------------------------------
  * pp-sketchlib calc_intersize [EXT]; SURVEY.md 8a row a3.  Words are
@@ -70,7 +88,7 @@ static inline double jaccard_obs(uint32_t same, size_t sketchsize64,
   const size_t maxnbits = sketchsize64 * 64;
   const size_t expected = maxnbits >> bbits;
   size_t intersize = same;
-  if (expected) {
+  if (g_ext_collision_adjust && expected) {
     size_t ret = same > expected ? same - expected : 0;
     intersize = ret * maxnbits / (maxnbits - expected);
   }
@@ -87,7 +105,8 @@ static inline double observed_excess(double obs, double expd) {
  * Model pr = (1-a)(1-c)^k  (PopPUNK/sketchlib.py:482,:652-654):
  * log J = log(1-a) + k log(1-c).  Points are used up to (not including) the
  * first k whose J < 5/nbins (docs/sketching.rst:161-165; truncation at the
- * first failing k is the pp-sketchlib CPU behaviour [EXT]).  Fewer than two
+ * first failing k is the pp-sketchlib CPU behaviour [EXT]; g_ext_fit_skip = 1
+ * drops only the failing k instead).  Fewer than two
  * usable points -> (0,0) and the pair is counted as a failed fit.
  * core = 1-exp(slope), accessory = 1-exp(intercept), each only if the
  * parameter is < 0, else 0 (clamp as in sketchlib.py:660-670).
@@ -95,26 +114,25 @@ static inline double observed_excess(double obs, double expd) {
 static int fit_pair(const double *jac, const int32_t *kmers, size_t nk,
                     size_t nbins, float *core, float *acc) {
   const double tol = 5.0 / (double)nbins;
-  size_t n = nk;
+  size_t n = 0;
+  double sx = 0, sxx = 0, sy = 0, sxy = 0;
   for (size_t i = 0; i < nk; i++) {
     if (jac[i] < tol) {
-      n = i;
+      if (g_ext_fit_skip) continue;
       break;
     }
-  }
-  if (n < 2) {
-    *core = 0.0f;
-    *acc = 0.0f;
-    return 1;
-  }
-  double sx = 0, sxx = 0, sy = 0, sxy = 0;
-  for (size_t i = 0; i < n; i++) {
     const double x = (double)kmers[i];
     const double y = log(jac[i]);
     sx += x;
     sxx += x * x;
     sy += y;
     sxy += x * y;
+    n++;
+  }
+  if (n < 2) {
+    *core = 0.0f;
+    *acc = 0.0f;
+    return 1;
   }
   const double dn = (double)n;
   const double slope = (dn * sxy - sx * sy) / (dn * sxx - sx * sx);

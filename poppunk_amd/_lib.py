@@ -73,7 +73,9 @@ SIGNATURES = {
     "ppk_prof_enable": (C.c_int, [C.c_int]),
     "ppk_prof_read": (C.c_int, [C.POINTER(C.c_double), _llp, C.c_int]),
     "ppk_last_kernel_name": (C.c_char_p, []),
-    "ppk_set_tile": (C.c_int, [C.c_int, C.c_int]),
+    "ppk_set_option": (C.c_int, [C.c_char_p, C.c_longlong]),
+    "ppk_get_option": (C.c_int, [C.c_char_p, _llp]),
+    "ppk_query_db": (C.c_int, [_vp, _vp, _i32p, _f32p, _sz, C.c_int, _vp, _ullp]),
 }
 
 _lib = None
@@ -118,6 +120,17 @@ def lib():
             fn.argtypes = args
         _lib = handle
     return _lib
+
+
+def set_option(name, value):
+    """ppk_set_option: measurement knobs and the [EXT] switches (include/ppk.h)."""
+    check(lib().ppk_set_option(name.encode(), int(value)), "ppk_set_option(%s)" % name)
+
+
+def get_option(name):
+    v = C.c_longlong(0)
+    check(lib().ppk_get_option(name.encode(), C.byref(v)), "ppk_get_option(%s)" % name)
+    return int(v.value)
 
 
 def last_error():

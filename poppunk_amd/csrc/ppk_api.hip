@@ -24,7 +24,86 @@ int ppk_fail(int code, const std::string &msg) {
   return code;
 }
 extern "C" const char *ppk_last_error(void) { return g_err.c_str(); }
-extern "C" const char *ppk_version(void) { return "poppunk_amd 0.1.0 (gfx950)"; }
+extern "C" const char *ppk_version(void) { return "poppunk_amd 0.2.0 (gfx950)"; }
+
+// ---- run-time options: PPK_* environment read once, then ppk_set_option only ------------------
+namespace {
+struct OptionEntry {
+  const char *name, *env;
+  std::atomic<long long> PpkConfig::*field;
+};
+const OptionEntry kOptions[] = {
+    {"ablate", "PPK_ABLATE", &PpkConfig::ablate},
+    {"map", "PPK_MAP", &PpkConfig::map},
+    {"strip", "PPK_STRIP", &PpkConfig::strip},
+    {"ksplit", "PPK_KSPLIT", &PpkConfig::ksplit},
+    {"chunk_rows", "PPK_CHUNK_ROWS", &PpkConfig::chunk_rows},
+    {"prefault_threads", "PPK_PREFAULT_THREADS", &PpkConfig::prefault_threads},
+    {"db_cache", "PPK_DB_CACHE", &PpkConfig::db_cache},
+    {"ext_collision_adjust", "PPK_EXT_COLLISION_ADJUST", &PpkConfig::ext_collision_adjust},
+    {"ext_fit_skip", "PPK_EXT_FIT_SKIP", &PpkConfig::ext_fit_skip},
+};
+}  // namespace
+
+PpkConfig &ppk_config() {
+  static PpkConfig cfg;
+  static std::once_flag once;
+  std::call_once(once, []() {
+    for (const OptionEntry &o : kOptions)
+      if (const char *e = getenv(o.env))
+        if (*e) (cfg.*(o.field)).store(atoll(e));
+  });
+  return cfg;
+}
+
+extern "C" int ppk_set_option(const char *name, long long value) {
+  if (!name) return ppk_fail(PPK_ERR_ARG, "option name is NULL");
+  for (const OptionEntry &o : kOptions)
+    if (!strcmp(name, o.name)) {
+      (ppk_config().*(o.field)).store(value);
+      return PPK_OK;
+    }
+  return ppk_fail(PPK_ERR_ARG, std::string("unknown option: ") + name);
+}
+
+extern "C" int ppk_get_option(const char *name, long long *value) {
+  if (!name || !value) return ppk_fail(PPK_ERR_ARG, "option name / value is NULL");
+  for (const OptionEntry &o : kOptions)
+    if (!strcmp(name, o.name)) {
+      *value = (ppk_config().*(o.field)).load();
+      return PPK_OK;
+    }
+  return ppk_fail(PPK_ERR_ARG, std::string("unknown option: ") + name);
+}
+
+// ---- the only supported target: gfx950 (MI355X), wave64 ---------------------------------------
+// Every kernel in this library is compiled for gfx950 alone and the tile kernels are fixed-register
+// wave64 instruction streams; on anything else the launches would fail with "no kernel image" (or
+// worse).  Checked once per device, loudly.
+static int check_arch(int device_id) {
+  static std::mutex mu;
+  static int verdict[64] = {0};   // 0 unknown, 1 ok, -1 refused
+  static std::string why[64];
+  if (device_id < 0 || device_id >= 64) return ppk_fail(PPK_ERR_ARG, "device id out of range");
+  std::lock_guard<std::mutex> lk(mu);
+  if (verdict[device_id] == 0) {
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device_id);
+    if (e != hipSuccess) {
+      why[device_id] = std::string("hipGetDeviceProperties: ") + hipGetErrorString(e);
+      verdict[device_id] = -1;
+    } else if (strncmp(prop.gcnArchName, "gfx950", 6) != 0 || prop.warpSize != 64) {
+      why[device_id] = std::string("device ") + std::to_string(device_id) + " is " + prop.gcnArchName +
+                       " (wavefront " + std::to_string(prop.warpSize) +
+                       "): libppk_hip.so is built for gfx950 / wave64 (MI355X) only";
+      verdict[device_id] = -1;
+    } else {
+      verdict[device_id] = 1;
+    }
+  }
+  if (verdict[device_id] < 0) return ppk_fail(PPK_ERR_HIP, why[device_id]);
+  return PPK_OK;
+}
 
 extern "C" int ppk_device_count(int *n) {
   if (!n) return ppk_fail(PPK_ERR_ARG, "n is NULL");
@@ -167,6 +246,7 @@ extern "C" int ppk_db_create(int device_id, const uint64_t *sk, size_t n, size_t
     return ppk_fail(PPK_ERR_ARG, "ppk_db_create: sketch too large");
   DeviceGuard guard(device_id);
   if (!guard.ok) return ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(device_id));
+  if (int rc_arch = check_arch(device_id)) return rc_arch;
   hipStream_t s = static_cast<hipStream_t>(stream);
 
   ppk_db *db = new ppk_db();
@@ -273,21 +353,44 @@ int check_pair(const ppk_db *ref, const ppk_db *qry, const int32_t *kmers, size_
   return PPK_OK;
 }
 
-// Scratch that must live until the enqueued work is done: freed with
-// hipFreeAsync-like semantics by parking it on the stream via a host callback
-// would cost a thread hop; device entry points instead keep one grow-only
-// scratch per device (single-threaded use per device, like the reference's
-// one-call-at-a-time binding).
+// Per-device scratch (log-J table, edge bitmask, sort buffers ...): grow-only blocks shared by all
+// calls on a device.  Two rules make that safe for any caller:
+//  * every entry point that touches scratch holds the device's (recursive) mutex for the length of
+//    the call -- it only enqueues, so that is microseconds -- through a PpkCall scope, which also
+//    names the stream the call enqueues on;
+//  * a slot remembers, as an event recorded when the call that used it returns, the last work
+//    enqueued on it; a later call on a DIFFERENT stream makes its stream wait for that event
+//    before it re-uses (or re-allocates) the block.  Calls on one stream are ordered anyway.
 struct Scratch {
   void *p = nullptr;
   size_t bytes = 0;
+  hipEvent_t ev = nullptr;      // recorded after the last call that used the slot
+  hipStream_t last = nullptr;   // ... on this stream
+  bool recorded = false;
 };
-Scratch g_scratch[64][SLOT_COUNT];  // [device][slot]
+struct DevState {
+  std::recursive_mutex mu;
+  Scratch slot[SLOT_COUNT];
+};
+DevState g_dev[64];
+
+struct CallCtx {
+  int dev = -1;
+  hipStream_t s = nullptr;
+  unsigned touched = 0;
+};
+thread_local CallCtx tl_call;
 
 int scratch_get(int dev, int slot, size_t bytes, void **out) {
   if (dev < 0 || dev >= 64 || slot < 0 || slot >= SLOT_COUNT)
     return ppk_fail(PPK_ERR_ARG, "device id out of range");
-  Scratch &s = g_scratch[dev][slot];
+  if (tl_call.dev != dev) return ppk_fail(PPK_ERR_STATE, "internal: scratch requested outside a PpkCall scope");
+  Scratch &s = g_dev[dev].slot[slot];
+  if (s.recorded && s.last != tl_call.s) {
+    // the previous user ran on another stream: order this call's work after it
+    hipError_t e = hipStreamWaitEvent(tl_call.s, s.ev, 0);
+    if (e != hipSuccess) (void)hipDeviceSynchronize();
+  }
   if (s.bytes < bytes) {
     if (s.p) {
       (void)hipDeviceSynchronize();  // earlier launches may still read the old block
@@ -300,10 +403,10 @@ int scratch_get(int dev, int slot, size_t bytes, void **out) {
     if (e != hipSuccess) return ppk_fail(PPK_ERR_HIP, std::string("hipMalloc(scratch): ") + hipGetErrorString(e));
     s.bytes = want;
   }
+  tl_call.touched |= 1u << slot;
   *out = s.p;
   return PPK_OK;
 }
-
 
 // random table (host) -> device copy placed after the LUT in the LUT scratch
 int stage_tables(const ppk_db *ref, const float *random_tbl, size_t n_clu, int flags, hipStream_t s,
@@ -329,16 +432,48 @@ int stage_tables(const ppk_db *ref, const float *random_tbl, size_t n_clu, int f
 
 int ppk_scratch_get(int dev, int slot, size_t bytes, void **out) { return scratch_get(dev, slot, bytes, out); }
 
+PpkCall::PpkCall(int dev, hipStream_t s) : dev_(dev), prev_dev_(tl_call.dev), prev_s_(tl_call.s), prev_touched_(tl_call.touched) {
+  if (dev_ < 0 || dev_ >= 64) {
+    dev_ = -1;
+    return;
+  }
+  g_dev[dev_].mu.lock();
+  tl_call.dev = dev_;
+  tl_call.s = s;
+  tl_call.touched = 0;
+}
+
+PpkCall::~PpkCall() {
+  if (dev_ < 0) return;
+  for (int k = 0; k < SLOT_COUNT; ++k) {
+    if (!(tl_call.touched & (1u << k))) continue;
+    Scratch &sc = g_dev[dev_].slot[k];
+    if (!sc.ev && hipEventCreateWithFlags(&sc.ev, hipEventDisableTiming) != hipSuccess) sc.ev = nullptr;
+    sc.recorded = sc.ev && hipEventRecord(sc.ev, tl_call.s) == hipSuccess;
+    sc.last = tl_call.s;
+  }
+  // an enclosing scope on the same device (a host wrapper calling a device entry point) has
+  // touched what its callee touched
+  const unsigned mine = tl_call.touched;
+  tl_call.dev = prev_dev_;
+  tl_call.s = prev_s_;
+  tl_call.touched = prev_touched_ | (prev_dev_ == dev_ ? mine : 0u);
+  g_dev[dev_].mu.unlock();
+}
+
 extern "C" int ppk_release_scratch(void) {
+  ppk_query_cache_clear();
   for (int d = 0; d < 64; ++d) {
+    std::lock_guard<std::recursive_mutex> lk(g_dev[d].mu);
     bool any = false;
-    for (int k = 0; k < SLOT_COUNT; ++k) any = any || g_scratch[d][k].p;
+    for (int k = 0; k < SLOT_COUNT; ++k) any = any || g_dev[d].slot[k].p || g_dev[d].slot[k].ev;
     if (!any) continue;
     DeviceGuard guard(d);
     (void)hipDeviceSynchronize();
     for (int k = 0; k < SLOT_COUNT; ++k) {
-      if (g_scratch[d][k].p) (void)hipFree(g_scratch[d][k].p);
-      g_scratch[d][k] = Scratch();
+      if (g_dev[d].slot[k].p) (void)hipFree(g_dev[d].slot[k].p);
+      if (g_dev[d].slot[k].ev) (void)hipEventDestroy(g_dev[d].slot[k].ev);
+      g_dev[d].slot[k] = Scratch();
     }
   }
   return PPK_OK;
@@ -355,6 +490,7 @@ extern "C" int ppk_dist_dev(const ppk_db *ref, const ppk_db *qry, const int32_t 
   if (!d_out) return ppk_fail(PPK_ERR_ARG, "d_out is NULL");
   DeviceGuard guard(ref->device);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  PpkCall call(ref->device, s);
   double *d_lut = nullptr;
   float *d_rtab = nullptr;
   rc = stage_tables(ref, random_tbl, n_clu, flags, s, &d_lut, &d_rtab);
@@ -377,6 +513,7 @@ extern "C" int ppk_dist_edges_dev(const ppk_db *ref, const ppk_db *qry, const in
     return ppk_fail(PPK_ERR_ARG, "edge output excludes the jaccard/counts flags");
   DeviceGuard guard(ref->device);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  PpkCall call(ref->device, s);
   if (q_begin == q_end) {
     PPK_HIP(hipMemsetAsync(d_n_edges, 0, sizeof(unsigned long long), s));
     return PPK_OK;
@@ -461,6 +598,7 @@ extern "C" int ppk_edge_threshold_dev(const float *d_dist, size_t n_rows, size_t
   hipStream_t s = static_cast<hipStream_t>(stream);
   int dev = 0;
   PPK_HIP(hipGetDevice(&dev));
+  PpkCall call(dev, s);
   EdgeGeom g = {};
   g.n_rows = n_rows;
   if (n_ref == 0) {
@@ -490,6 +628,7 @@ extern "C" int ppk_qc_edges_dev(const float *d_dist, size_t n_rows, size_t n_ref
   hipStream_t s = static_cast<hipStream_t>(stream);
   int dev = 0;
   PPK_HIP(hipGetDevice(&dev));
+  PpkCall call(dev, s);
   EdgeGeom g = {};
   g.n_rows = n_rows;
   if (n_ref == 0) {
@@ -518,6 +657,7 @@ extern "C" int ppk_generate_tuples_dev(const int32_t *d_assign, size_t n_rows, i
   hipStream_t s = static_cast<hipStream_t>(stream);
   int dev = 0;
   PPK_HIP(hipGetDevice(&dev));
+  PpkCall call(dev, s);
   EdgeGeom g = {};
   g.n_rows = n_rows;
   g.int_offset = int_offset;
@@ -539,6 +679,263 @@ extern "C" int ppk_generate_tuples_dev(const int32_t *d_assign, size_t n_rows, i
 }
 
 // ---- host-buffer wrappers -------------------------------------------------------------
+// What PopPUNK itself calls.  State kept between calls (per device, grow-only, released by
+// ppk_release_scratch): the two result buffers and the failed-fit counter, so that a call does not
+// pay hipMalloc/hipFree; and, for ppk_query, a small cache of resident databases keyed by the
+// caller's host array, so that repeated queries against the same sketches (poppunk_assign against
+// one reference database; every k-mer fit plot) upload and re-lay them out once.
+namespace {
+std::mutex g_query_mu;           // one host-buffer query at a time (PopPUNK calls blocking, from one thread)
+
+struct QueryBufs {
+  void *buf[2] = {nullptr, nullptr};
+  size_t bytes[2] = {0, 0};
+  unsigned long long *d_failed = nullptr;
+  hipEvent_t done[2] = {nullptr, nullptr};
+};
+constexpr int kMaxDup = 4;       // a device may be listed up to kMaxDup times in one ppk_query call
+QueryBufs g_qbufs[64][kMaxDup];  // [device][occurrence in the device list]
+
+int query_buf(int dev, int dup, int i, size_t bytes, void **out) {
+  QueryBufs &q = g_qbufs[dev][dup];
+  if (q.bytes[i] < bytes) {
+    if (q.buf[i]) {
+      (void)hipDeviceSynchronize();
+      (void)hipFree(q.buf[i]);
+      q.buf[i] = nullptr;
+      q.bytes[i] = 0;
+    }
+    hipError_t e = hipMalloc(&q.buf[i], bytes);
+    if (e != hipSuccess) return ppk_fail(PPK_ERR_HIP, std::string("hipMalloc(output): ") + hipGetErrorString(e));
+    q.bytes[i] = bytes;
+  }
+  *out = q.buf[i];
+  return PPK_OK;
+}
+
+// Resident databases of earlier ppk_query calls.  Key: the host pointer, the dimensions, the device
+// and a fingerprint of the contents (a strided sample of 2^16 words plus both ends, and the whole
+// cluster vector): a different sketch array that happens to sit at a recycled address does not
+// match.  A caller that rewrites sketches IN PLACE between calls must turn the cache off
+// (ppk_set_option("db_cache", 0) / PPK_DB_CACHE=0) or call ppk_release_scratch().
+struct CachedDb {
+  const uint64_t *host = nullptr;
+  size_t n = 0, nk = 0, s64 = 0, bbits = 0;
+  int device = -1;
+  uint64_t fp = 0;
+  ppk_db *db = nullptr;
+  unsigned long long stamp = 0;
+};
+std::vector<CachedDb> g_db_cache;
+unsigned long long g_db_stamp = 0;
+constexpr size_t kDbCachePerDevice = 4;
+
+uint64_t mix64(uint64_t h, uint64_t v) {
+  h ^= v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
+  h *= 0xff51afd7ed558ccdull;
+  return h ^ (h >> 32);
+}
+
+uint64_t fingerprint(const uint64_t *sk, size_t words, const uint16_t *clu, size_t n) {
+  uint64_t h = 0x243f6a8885a308d3ull ^ words;
+  const size_t edge = words < 256 ? words : 256;
+  for (size_t i = 0; i < edge; ++i) h = mix64(h, sk[i]);
+  for (size_t i = words - edge; i < words; ++i) h = mix64(h, sk[i]);
+  const size_t samples = (size_t)1 << 16;
+  if (words > samples) {
+    const size_t step = words / samples;
+    for (size_t i = 0; i < samples; ++i) h = mix64(h, sk[i * step + (i % step)]);
+  } else {
+    for (size_t i = 0; i < words; ++i) h = mix64(h, sk[i]);
+  }
+  if (clu)
+    for (size_t i = 0; i < n; ++i) h = mix64(h, clu[i] + 1u);
+  return h;
+}
+
+// the resident database of (sk, ...) on `device`: from the cache, or created (and cached)
+int db_acquire(int device, const uint64_t *sk, size_t n, size_t nk, size_t s64, size_t bbits,
+               const uint16_t *clu, hipStream_t s, ppk_db **out, bool *owned) {
+  *owned = false;
+  const bool use_cache = ppk_config().db_cache.load() != 0;
+  uint64_t fp = 0;
+  if (use_cache) {
+    fp = fingerprint(sk, n * nk * s64 * bbits, clu, n);
+    for (CachedDb &c : g_db_cache)
+      if (c.host == sk && c.n == n && c.nk == nk && c.s64 == s64 && c.bbits == bbits &&
+          c.device == device && c.fp == fp) {
+        c.stamp = ++g_db_stamp;
+        *out = c.db;
+        return PPK_OK;
+      }
+  }
+  int rc = ppk_db_create(device, sk, n, nk, s64, bbits, clu, 0, s, out);
+  if (rc != PPK_OK) return rc;
+  if (!use_cache) {
+    *owned = true;
+    return PPK_OK;
+  }
+  size_t on_dev = 0, oldest = 0;
+  bool have = false;
+  for (size_t i = 0; i < g_db_cache.size(); ++i)
+    if (g_db_cache[i].device == device) {
+      ++on_dev;
+      if (!have || g_db_cache[i].stamp < g_db_cache[oldest].stamp) {
+        oldest = i;
+        have = true;
+      }
+    }
+  if (on_dev >= kDbCachePerDevice) {
+    ppk_db_destroy(g_db_cache[oldest].db);      // synchronous hipFree: safe after the earlier call returned
+    g_db_cache.erase(g_db_cache.begin() + (long)oldest);
+  }
+  CachedDb c;
+  c.host = sk;
+  c.n = n;
+  c.nk = nk;
+  c.s64 = s64;
+  c.bbits = bbits;
+  c.device = device;
+  c.fp = fp;
+  c.db = *out;
+  c.stamp = ++g_db_stamp;
+  g_db_cache.push_back(c);
+  return PPK_OK;
+}
+
+struct QueryPart {
+  int device = 0;
+  int dup = 0;                                  // occurrence index of `device` in the device list
+  const ppk_db *ref = nullptr, *qry = nullptr;
+  bool own_ref = false, own_qry = false;
+  hipStream_t s = nullptr, sc = nullptr;        // compute / copy
+  void *buf[2] = {nullptr, nullptr};
+  unsigned long long *d_failed = nullptr;
+  hipEvent_t done[2] = {nullptr, nullptr};      // sub-band in buf[i] computed
+  bool active = false;
+};
+
+// The pair space of (n_ref, n_qry) over parts[0..n) devices, result to the host array `out`.
+// Device-memory chunking (what pp-sketchlib's CUDA path does when the result does not fit the card
+// [EXT]): the query axis is cut into n_dev x C sub-bands of equal pair count; a device computes its
+// C sub-bands one after the other into two alternating buffers, and sub-band c is copied to the
+// caller's array while c+1 computes.  Memory per device: the sketches + two sub-band buffers,
+// whatever the size of the job.
+int run_query(std::vector<QueryPart> &parts, size_t n_ref, size_t n_qry, const int32_t *kmers, size_t nk,
+              const float *random_tbl, size_t n_clu, int flags, void *out, unsigned long long *n_failed) {
+  const int n_dev = (int)parts.size();
+  const bool self = (n_qry == 0);
+  const size_t nq = self ? n_ref : n_qry;
+  const size_t cols = (flags & (PPK_FLAG_JACCARD | PPK_FLAG_COUNTS)) ? nk : 2;
+  const size_t total_rows = ppk_rows_in_band(n_ref, n_qry, 0, nq);
+  size_t target_rows = (size_t)32 << 20;                       // ~256 MB of float2 rows per buffer
+  if (const long long cr = ppk_config().chunk_rows.load(); cr > 0) target_rows = (size_t)cr;
+  const size_t per_dev = (total_rows + n_dev - 1) / n_dev;
+  int C = (int)((per_dev + target_rows - 1) / target_rows);
+  if (C < 1) C = 1;
+  if ((size_t)C > nq / 64 + 1) C = (int)(nq / 64 + 1);         // sub-band edges are multiples of 64 queries
+  std::vector<size_t> bounds((size_t)n_dev * C + 1);
+  int rc = ppk_band_split(n_ref, n_qry, n_dev * C, bounds.data());
+  if (rc != PPK_OK) return rc;
+  std::vector<size_t> row0((size_t)n_dev * C + 1, 0);           // first output row of every sub-band
+  size_t max_rows = 0;
+  for (int i = 0; i < n_dev * C; ++i) {
+    const size_t r = ppk_rows_in_band(n_ref, n_qry, bounds[i], bounds[i + 1]);
+    row0[i + 1] = row0[i] + r;
+    if (r > max_rows) max_rows = r;
+  }
+  // helper threads touch the result array's pages ahead of the downloads (HostToucher)
+  HostToucher toucher(out, row0[(size_t)n_dev * C] * cols * 4);
+  for (int d = 0; d < n_dev && rc == PPK_OK; ++d) {
+    QueryPart &p = parts[d];
+    p.active = row0[(size_t)(d + 1) * C] != row0[(size_t)d * C] && p.ref;
+    if (!p.active) continue;
+    DeviceGuard g(p.device);
+    QueryBufs &qb = g_qbufs[p.device][p.dup];
+    const size_t buf_bytes = max_rows * cols * 4;
+    rc = query_buf(p.device, p.dup, 0, buf_bytes, &p.buf[0]);
+    if (rc == PPK_OK && C > 1) rc = query_buf(p.device, p.dup, 1, buf_bytes, &p.buf[1]);
+    if (rc != PPK_OK) break;
+    if (!qb.d_failed && hipMalloc(reinterpret_cast<void **>(&qb.d_failed), sizeof(unsigned long long)) != hipSuccess) {
+      rc = ppk_fail(PPK_ERR_HIP, "hipMalloc(output) failed");
+      break;
+    }
+    for (int i = 0; i < 2; ++i)
+      if (!qb.done[i] && hipEventCreateWithFlags(&qb.done[i], hipEventDisableTiming) != hipSuccess) {
+        rc = ppk_fail(PPK_ERR_HIP, "hipEventCreate failed");
+        break;
+      }
+    if (rc != PPK_OK) break;
+    p.d_failed = qb.d_failed;
+    p.done[0] = qb.done[0];
+    p.done[1] = qb.done[1];
+    (void)hipMemsetAsync(p.d_failed, 0, sizeof(unsigned long long), p.s);
+  }
+  // step c: every device launches sub-band c, then sub-band c-1 of every device is fetched
+  for (int c = 0; c <= C && rc == PPK_OK; ++c) {
+    for (int d = 0; d < n_dev && rc == PPK_OK && c < C; ++d) {
+      QueryPart &p = parts[d];
+      const size_t i = (size_t)d * C + c;
+      if (!p.active || row0[i + 1] == row0[i]) continue;
+      DeviceGuard g(p.device);
+      rc = ppk_dist_dev(p.ref, p.qry, kmers, random_tbl, n_clu, flags, bounds[i], bounds[i + 1],
+                        p.buf[c & 1], p.d_failed, p.s);
+      if (rc == PPK_OK && hipEventRecord(p.done[c & 1], p.s) != hipSuccess)
+        rc = ppk_fail(PPK_ERR_HIP, "hipEventRecord failed");
+    }
+    for (int d = 0; d < n_dev && rc == PPK_OK && c > 0; ++d) {
+      QueryPart &p = parts[d];
+      const size_t i = (size_t)d * C + (c - 1);
+      if (!p.active || row0[i + 1] == row0[i]) continue;
+      DeviceGuard g(p.device);
+      toucher.wait(row0[i + 1] * cols * 4);
+      hipError_t e = hipStreamWaitEvent(p.sc, p.done[(c - 1) & 1], 0);
+      if (e == hipSuccess)
+        e = hipMemcpyAsync(static_cast<char *>(out) + row0[i] * cols * 4, p.buf[(c - 1) & 1],
+                           (row0[i + 1] - row0[i]) * cols * 4, hipMemcpyDeviceToHost, p.sc);
+      if (e == hipSuccess) e = hipStreamSynchronize(p.sc);   // the buffer is free for sub-band c+1
+      if (e != hipSuccess)
+        rc = ppk_fail(PPK_ERR_HIP, std::string("kernel execution / download failed: ") + hipGetErrorString(e));
+    }
+  }
+  const std::string keep = g_err;
+  for (int d = 0; d < n_dev; ++d) {
+    QueryPart &p = parts[d];
+    if (!p.active) continue;
+    DeviceGuard g(p.device);
+    hipError_t e = hipStreamSynchronize(p.s);          // also on failure: nothing may stay in flight
+    (void)hipStreamSynchronize(p.sc);
+    if (e != hipSuccess && rc == PPK_OK)
+      rc = ppk_fail(PPK_ERR_HIP, std::string("kernel execution failed: ") + hipGetErrorString(e));
+    unsigned long long f = 0;
+    if (rc == PPK_OK && hipMemcpy(&f, p.d_failed, sizeof(f), hipMemcpyDeviceToHost) == hipSuccess && n_failed)
+      *n_failed += f;
+  }
+  toucher.join();
+  if (rc != PPK_OK && !keep.empty() && g_err.empty()) g_err = keep;
+  return rc;
+}
+}  // namespace
+
+void ppk_query_cache_clear() {
+  std::lock_guard<std::mutex> lk(g_query_mu);
+  for (CachedDb &c : g_db_cache) ppk_db_destroy(c.db);
+  g_db_cache.clear();
+  for (int d = 0; d < 64; ++d)
+    for (int u = 0; u < kMaxDup; ++u) {
+      QueryBufs &q = g_qbufs[d][u];
+      if (!q.buf[0] && !q.buf[1] && !q.d_failed && !q.done[0] && !q.done[1]) continue;
+      DeviceGuard guard(d);
+      (void)hipDeviceSynchronize();
+      for (int i = 0; i < 2; ++i) {
+        if (q.buf[i]) (void)hipFree(q.buf[i]);
+        if (q.done[i]) (void)hipEventDestroy(q.done[i]);
+      }
+      if (q.d_failed) (void)hipFree(q.d_failed);
+      q = QueryBufs();
+    }
+}
+
 extern "C" int ppk_query(const uint64_t *ref_sk, size_t n_ref, const uint64_t *qry_sk, size_t n_qry,
                          const int32_t *kmers, size_t nk, size_t sketchsize64, size_t bbits,
                          const float *random_tbl, const uint16_t *ref_clu, const uint16_t *qry_clu,
@@ -554,147 +951,78 @@ extern "C" int ppk_query(const uint64_t *ref_sk, size_t n_ref, const uint64_t *q
     n_dev = 1;
   }
   const bool self = (n_qry == 0);
-  const size_t nq = self ? n_ref : n_qry;
-  const size_t cols = (flags & (PPK_FLAG_JACCARD | PPK_FLAG_COUNTS)) ? nk : 2;
-  const size_t total_rows = ppk_rows_in_band(n_ref, n_qry, 0, nq);
-  if (total_rows == 0) return PPK_OK;  // a single self sample: no pairs
-
-  // Device-memory chunking (what pp-sketchlib's CUDA path does when the result does not fit the
-  // card [EXT]): the query axis is cut into n_dev x C sub-bands of equal pair count; a device
-  // computes its C sub-bands one after the other into two alternating buffers, and sub-band c is
-  // copied to the caller's array while c+1 computes.  Memory per device: the sketches + two
-  // sub-band buffers, whatever the size of the job.
-  size_t target_rows = (size_t)32 << 20;                       // ~256 MB of float2 rows per buffer
-  if (const char *e = getenv("PPK_CHUNK_ROWS")) target_rows = (size_t)atoll(e) > 0 ? (size_t)atoll(e) : target_rows;
-  const size_t per_dev = (total_rows + n_dev - 1) / n_dev;
-  int C = (int)((per_dev + target_rows - 1) / target_rows);
-  if (C < 1) C = 1;
-  if ((size_t)C > nq / 64 + 1) C = (int)(nq / 64 + 1);         // sub-band edges are multiples of 64 queries
-  std::vector<size_t> bounds((size_t)n_dev * C + 1);
-  int rc = ppk_band_split(n_ref, n_qry, n_dev * C, bounds.data());
-  if (rc != PPK_OK) return rc;
-  std::vector<size_t> row0((size_t)n_dev * C + 1, 0);           // first output row of every sub-band
-  size_t max_rows = 0;
-  for (int i = 0; i < n_dev * C; ++i) {
-    const size_t r = ppk_rows_in_band(n_ref, n_qry, bounds[i], bounds[i + 1]);
-    row0[i + 1] = row0[i] + r;
-    if (r > max_rows) max_rows = r;
-  }
-
-  struct Part {
-    ppk_db *ref = nullptr, *qry = nullptr;
-    void *buf[2] = {nullptr, nullptr};
-    unsigned long long *d_failed = nullptr;
-    hipStream_t s = nullptr, sc = nullptr;       // compute / copy
-    bool own_streams = true;                      // false: a device listed twice shares the first entry's
-    hipEvent_t done[2] = {nullptr, nullptr};      // sub-band in buf[i] computed
-  };
-  std::vector<Part> parts(n_dev);
-  auto cleanup = [&]() {
-    for (int d = 0; d < n_dev; ++d) {
-      Part &p = parts[d];
-      DeviceGuard g(devices[d]);
-      if (p.s) (void)hipStreamSynchronize(p.s);
-      if (p.sc) (void)hipStreamSynchronize(p.sc);
-      for (int i = 0; i < 2; ++i) {
-        if (p.buf[i]) (void)hipFree(p.buf[i]);
-        if (p.done[i]) (void)hipEventDestroy(p.done[i]);
-      }
-      if (p.d_failed) (void)hipFree(p.d_failed);
-      if (p.ref) ppk_db_destroy(p.ref);
-      if (p.qry) ppk_db_destroy(p.qry);
-    }
-  };
+  if (ppk_rows_in_band(n_ref, n_qry, 0, self ? n_ref : n_qry) == 0) return PPK_OK;  // a single self sample: no pairs
+  std::lock_guard<std::mutex> lk(g_query_mu);
+  std::vector<QueryPart> parts((size_t)n_dev);
+  int rc = PPK_OK;
   for (int d = 0; d < n_dev && rc == PPK_OK; ++d) {
-    Part &p = parts[d];
-    if (row0[(size_t)(d + 1) * C] == row0[(size_t)d * C]) continue;     // nothing for this device
-    DeviceGuard g(devices[d]);
-    if (!g.ok) {
-      rc = ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(devices[d]));
+    QueryPart &p = parts[d];
+    p.device = devices[d];
+    if (p.device < 0 || p.device >= 64) {
+      rc = ppk_fail(PPK_ERR_ARG, "device id out of range");
       break;
     }
-    // the per-device scratch (log-J table, k-split counts) allows one call in flight per device:
-    // entries naming the same device are ordered on one stream
     for (int e = 0; e < d; ++e)
-      if (devices[e] == devices[d] && parts[e].s) {
-        p.s = parts[e].s;
-        p.sc = parts[e].sc;
-        p.own_streams = false;
-        break;
-      }
-    if (p.own_streams) {
-      hipStream_t ws[2] = {nullptr, nullptr};
-      rc = worker_streams(devices[d], ws, 2);
-      if (rc != PPK_OK) break;
-      p.s = ws[0];
-      p.sc = ws[1];
-    }
-    if (hipEventCreateWithFlags(&p.done[0], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&p.done[1], hipEventDisableTiming) != hipSuccess) {
-      rc = ppk_fail(PPK_ERR_HIP, "hipEventCreate failed");
+      if (devices[e] == p.device) ++p.dup;
+    if (p.dup >= kMaxDup) {
+      rc = ppk_fail(PPK_ERR_ARG, "a device may be listed at most 4 times");
       break;
     }
-    rc = ppk_db_create(devices[d], ref_sk, n_ref, nk, sketchsize64, bbits, ref_clu, 0, p.s, &p.ref);
-    if (rc == PPK_OK && !self)
-      rc = ppk_db_create(devices[d], qry_sk, n_qry, nk, sketchsize64, bbits, qry_clu, 0, p.s, &p.qry);
+    DeviceGuard g(p.device);
+    if (!g.ok) {
+      rc = ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(p.device));
+      break;
+    }
+    // entries naming the same device share its streams and resident databases (ordered on one stream)
+    hipStream_t ws[2] = {nullptr, nullptr};
+    rc = worker_streams(p.device, ws, 2);
     if (rc != PPK_OK) break;
-    const size_t buf_bytes = max_rows * cols * 4;
-    if (hipMalloc(&p.buf[0], buf_bytes) != hipSuccess || (C > 1 && hipMalloc(&p.buf[1], buf_bytes) != hipSuccess) ||
-        hipMalloc(reinterpret_cast<void **>(&p.d_failed), sizeof(unsigned long long)) != hipSuccess) {
-      rc = ppk_fail(PPK_ERR_HIP, "hipMalloc(output) failed");
-      break;
-    }
-    (void)hipMemsetAsync(p.d_failed, 0, sizeof(unsigned long long), p.s);
-  }
-  // helper threads touch the result array's pages ahead of the downloads (HostToucher)
-  HostToucher toucher(rc == PPK_OK ? out : nullptr, row0[(size_t)n_dev * C] * cols * 4);
-  // step c: every device launches sub-band c, then sub-band c-1 of every device is fetched
-  for (int c = 0; c <= C && rc == PPK_OK; ++c) {
-    for (int d = 0; d < n_dev && rc == PPK_OK && c < C; ++d) {
-      Part &p = parts[d];
-      const size_t i = (size_t)d * C + c;
-      if (!p.s || row0[i + 1] == row0[i]) continue;
-      DeviceGuard g(devices[d]);
-      rc = ppk_dist_dev(p.ref, p.qry, kmers, random_tbl, n_clu, flags, bounds[i], bounds[i + 1],
-                        p.buf[c & 1], p.d_failed, p.s);
-      if (rc == PPK_OK && hipEventRecord(p.done[c & 1], p.s) != hipSuccess)
-        rc = ppk_fail(PPK_ERR_HIP, "hipEventRecord failed");
-    }
-    for (int d = 0; d < n_dev && rc == PPK_OK && c > 0; ++d) {
-      Part &p = parts[d];
-      const size_t i = (size_t)d * C + (c - 1);
-      if (!p.s || row0[i + 1] == row0[i]) continue;
-      DeviceGuard g(devices[d]);
-      toucher.wait(row0[i + 1] * cols * 4);
-      hipError_t e = hipStreamWaitEvent(p.sc, p.done[(c - 1) & 1], 0);
-      if (e == hipSuccess)
-        e = hipMemcpyAsync(static_cast<char *>(out) + row0[i] * cols * 4, p.buf[(c - 1) & 1],
-                           (row0[i + 1] - row0[i]) * cols * 4, hipMemcpyDeviceToHost, p.sc);
-      if (e == hipSuccess) e = hipStreamSynchronize(p.sc);   // the buffer is free for sub-band c+1
-      if (e != hipSuccess)
-        rc = ppk_fail(PPK_ERR_HIP, std::string("kernel execution / download failed: ") + hipGetErrorString(e));
+    p.s = ws[0];
+    p.sc = ws[1];
+    ppk_db *db = nullptr;
+    rc = db_acquire(p.device, ref_sk, n_ref, nk, sketchsize64, bbits, ref_clu, p.s, &db, &p.own_ref);
+    p.ref = db;
+    if (rc == PPK_OK && !self) {
+      db = nullptr;
+      rc = db_acquire(p.device, qry_sk, n_qry, nk, sketchsize64, bbits, qry_clu, p.s, &db, &p.own_qry);
+      p.qry = db;
     }
   }
-  if (rc == PPK_OK) {
-    for (int d = 0; d < n_dev; ++d) {
-      Part &p = parts[d];
-      if (!p.s) continue;
-      DeviceGuard g(devices[d]);
-      hipError_t e = hipStreamSynchronize(p.s);
-      if (e != hipSuccess) {
-        rc = ppk_fail(PPK_ERR_HIP, std::string("kernel execution failed: ") + hipGetErrorString(e));
-        break;
-      }
-      unsigned long long f = 0;
-      if (hipMemcpy(&f, p.d_failed, sizeof(f), hipMemcpyDeviceToHost) == hipSuccess && n_failed)
-        *n_failed += f;
-    }
-  }
-  toucher.join();
+  if (rc == PPK_OK) rc = run_query(parts, n_ref, n_qry, kmers, nk, random_tbl, n_clu, flags, out, n_failed);
   const std::string keep = g_err;
-  cleanup();
+  for (QueryPart &p : parts) {
+    if (p.own_ref && p.ref) ppk_db_destroy(const_cast<ppk_db *>(p.ref));
+    if (p.own_qry && p.qry) ppk_db_destroy(const_cast<ppk_db *>(p.qry));
+  }
   if (rc != PPK_OK) g_err = keep;
   return rc;
+}
+
+// The same on databases that are already resident (ppk_db_create): nothing is uploaded; the result
+// goes to the host array through the device's two persistent sub-band buffers.
+extern "C" int ppk_query_db(const ppk_db *ref, const ppk_db *qry, const int32_t *kmers,
+                            const float *random_tbl, size_t n_clu, int flags, void *out,
+                            unsigned long long *n_failed) {
+  if (n_failed) *n_failed = 0;
+  int rc = check_pair(ref, qry, kmers, 0, 0);
+  if (rc != PPK_OK) return rc;
+  if (!out) return ppk_fail(PPK_ERR_ARG, "ppk_query_db: out is NULL");
+  const size_t n_qry = qry ? qry->n : 0;
+  if (ppk_rows_in_band(ref->n, n_qry, 0, qry ? qry->n : ref->n) == 0) return PPK_OK;
+  std::lock_guard<std::mutex> lk(g_query_mu);
+  std::vector<QueryPart> parts(1);
+  QueryPart &p = parts[0];
+  p.device = ref->device;
+  DeviceGuard g(p.device);
+  if (!g.ok) return ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(p.device));
+  hipStream_t ws[2] = {nullptr, nullptr};
+  rc = worker_streams(p.device, ws, 2);
+  if (rc != PPK_OK) return rc;
+  p.s = ws[0];
+  p.sc = ws[1];
+  p.ref = ref;
+  p.qry = qry;
+  return run_query(parts, ref->n, n_qry, kmers, ref->nk, random_tbl, n_clu, flags, out, n_failed);
 }
 
 extern "C" int ppk_assign_threshold(const float *dist, size_t n_rows, int slope, float x_max,

@@ -131,6 +131,8 @@ struct DistParams {
   unsigned tiles_per_xcd;      // ceil(n_tiles / 8)
   int tri_m, tri_c0;           // self job: ref tile r pairs with clamp(tri_m * r + tri_c0, 0, q_tiles) query tiles
   int ablate;             // measurement only (PPK_ABLATE): 1 skip epilogue, 2 skip compare, 4 skip DMA, 8 skip barriers
+  int ext_adjust;         // [EXT] a4 gate (PpkConfig::ext_collision_adjust)
+  int ext_skip;           // [EXT] a6: skip instead of truncate at J < 5/s (PpkConfig::ext_fit_skip)
 
   int kmers[PPK_MAX_NK];
   // all-points-usable fast path of the regression: sums of k, 1/(n*sum k^2 - (sum k)^2), 1/n
@@ -139,12 +141,14 @@ struct DistParams {
 
 // ---- small device helpers --------------------------------------------------
 
-// a4: collision adjustment + observed Jaccard (integer part as in the source).
-__device__ __forceinline__ double jaccard_obs(uint32_t same, size_t s64, size_t bbits) {
+// a4: collision adjustment + observed Jaccard (integer part as in the source).  `adjust` is the
+// [EXT] gate (PpkConfig::ext_collision_adjust): 0 = never in effect (upstream as recalled), 1 =
+// applied when expected > 0.
+__device__ __forceinline__ double jaccard_obs(uint32_t same, size_t s64, size_t bbits, int adjust) {
   const size_t maxnbits = s64 * 64;
   const size_t expected = maxnbits >> bbits;
   size_t inter = same;
-  if (expected) {
+  if (adjust && expected) {
     const size_t ret = same > expected ? same - expected : 0;
     inter = ret * maxnbits / (maxnbits - expected);
   }
@@ -181,7 +185,7 @@ transpose_kernel(const uint64_t *__restrict__ in, uint64_t *__restrict__ out, si
 // every later k are dropped from the fit; docs/sketching.rst:161-165).
 __global__ void __launch_bounds__(256)
 lut_kernel(double *__restrict__ lut, const float *__restrict__ rtab, int nk, int n_clu,
-           size_t nbins, size_t s64, size_t bbits, int random_correct, size_t total) {
+           size_t nbins, size_t s64, size_t bbits, int random_correct, int adjust, size_t total) {
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
   const size_t per = nbins + 1;
@@ -190,7 +194,7 @@ lut_kernel(double *__restrict__ lut, const float *__restrict__ rtab, int nk, int
   const size_t cp = idx / (per * nk);
   double jr = 0.0;
   if (random_correct) jr = (double)rtab[(k * n_clu + cp / n_clu) * n_clu + cp % n_clu];
-  const double j = observed_excess(jaccard_obs(c, s64, bbits), jr);
+  const double j = observed_excess(jaccard_obs(c, s64, bbits, adjust), jr);
   const double tol = 5.0 / (double)nbins;
   lut[idx] = (j < tol) ? 1.0 : log(j);
 }
@@ -255,7 +259,7 @@ __device__ __forceinline__ void fit_packed(PackT pk, const double *__restrict__ 
   for (int k = 0; k < p.nk; ++k) {
     const uint32_t c = pack_get(pk, k, p.cnt_bits, cmask, p.nk);
     const double y = lutp[(size_t)k * p.lut_kstride + c];
-    open = open && (y <= 0.0);
+    open = (p.ext_skip || open) && (y <= 0.0);      // [EXT] truncate at (default) / skip the k below the floor
     if (open) {
       const double x = (double)p.kmers[k];
       sx += x;
@@ -393,7 +397,11 @@ __device__ __forceinline__ bool fit_rows_fixed(const PackT (&pk)[NR], const doub
   return true;
 }
 
-template <int TQ, int NW, int BBITS, int MODE, typename PackT>
+// Generic bit-plane count (bbits != 14: sketches made with a non-default --bbits): 64 refs per
+// wavefront staged through LDS one 64-bin block at a time, TQ query samples per wavefront as
+// wave-uniform (SGPR) operands.  Not tuned -- every PopPUNK database in the wild has bbits = 14 and
+// takes dist_kernel_v2.
+template <int TQ, int NW, int MODE, typename PackT>
 __global__ void __launch_bounds__(NW * 64)
 dist_kernel(const uint64_t *__restrict__ refT, const uint32_t *__restrict__ qryT,
             const double *__restrict__ lut, const uint16_t *__restrict__ ref_clu,
@@ -401,11 +409,7 @@ dist_kernel(const uint64_t *__restrict__ refT, const uint32_t *__restrict__ qryT
             void *__restrict__ out, unsigned long long *__restrict__ n_failed,
             uint64_t *__restrict__ mask_out, const DistParams p) {
   constexpr int QT = TQ * NW;                 // queries per workgroup tile
-  constexpr int RPW = 7;                      // staged rows per wavefront per chunk
-  constexpr int CH = (BBITS > 0) ? (RPW * NW) / BBITS : 1;  // 64-bin blocks per chunk
-  constexpr int ROWS = (BBITS > 0) ? CH * BBITS : 64;       // LDS rows per chunk
-  static_assert(BBITS == 0 || CH * BBITS == RPW * NW, "chunk must tile evenly over waves");
-  __shared__ u32x2 lds[ROWS * 64];
+  __shared__ u32x2 lds[64 * 64];              // up to 64 bit-planes x 64 refs
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -417,10 +421,8 @@ dist_kernel(const uint64_t *__restrict__ refT, const uint32_t *__restrict__ qryT
   if (p.self && rt * 64 + 63 <= q0) return;
   const bool wave_active = !(p.self && rt * 64 + 63 <= qw0) && qw0 < p.q_end && qw0 + TQ > p.q_begin;
 
-  const int bbits = (BBITS > 0) ? BBITS : p.bbits;
+  const int bbits = p.bbits;
   const int words = p.s64 * bbits;
-  const int cpk = (p.s64 + CH - 1) / CH;   // chunks per k
-  const int total = p.nk * cpk;
 
   uint32_t cnt[TQ];
   PackT packed[TQ];
@@ -430,40 +432,9 @@ dist_kernel(const uint64_t *__restrict__ refT, const uint32_t *__restrict__ qryT
     pack_zero(packed[j]);
   }
 
-  // ---- chunk staging: global -> VGPR (one chunk ahead) -> LDS ----------------
-  uint64_t pre[RPW];
-  auto load_chunk = [&](int k, int c) {
-    if constexpr (BBITS > 0) {
-      const int nrows = min(CH, p.s64 - c * CH) * BBITS;
-      const size_t grow0 = (size_t)k * words + (size_t)c * CH * BBITS;
-#pragma unroll
-      for (int i = 0; i < RPW; ++i) {
-        const int row = i * NW + wave;
-        pre[i] = (row < nrows) ? refT[(grow0 + row) * p.npad_r + r] : 0ull;
-      }
-    }
-  };
-  auto store_chunk = [&]() {
-    if constexpr (BBITS > 0) {
-#pragma unroll
-      for (int i = 0; i < RPW; ++i) {
-        const int row = i * NW + wave;
-        u32x2 v;
-        v.x = (uint32_t)pre[i];
-        v.y = (uint32_t)(pre[i] >> 32);
-        lds[row * 64 + lane] = v;
-      }
-    }
-  };
-
-  int k = 0, c = 0;
-  load_chunk(0, 0);
-  for (int g = 0; g < total; ++g) {
-    __syncthreads();  // every wave is done reading the previous chunk
-    if constexpr (BBITS > 0) {
-      store_chunk();
-    } else {
-      // generic bbits: one 64-bin block per chunk, staged without prefetch
+  for (int k = 0; k < p.nk; ++k) {
+    for (int c = 0; c < p.s64; ++c) {
+      __syncthreads();  // every wave is done reading the previous block
       const size_t grow0 = (size_t)k * words + (size_t)c * bbits;
       for (int row = wave; row < bbits; row += NW) {
         const uint64_t v = refT[(grow0 + row) * p.npad_r + r];
@@ -472,97 +443,59 @@ dist_kernel(const uint64_t *__restrict__ refT, const uint32_t *__restrict__ qryT
         t.y = (uint32_t)(v >> 32);
         lds[row * 64 + lane] = t;
       }
-    }
-    __syncthreads();
-    int kn = k, cn = c + 1;
-    if (cn == cpk) {
-      cn = 0;
-      kn = k + 1;
-    }
-    if (g + 1 < total) load_chunk(kn, cn);
-
-    if (wave_active) {
-      const int nblk = min(CH, p.s64 - c * CH);
-#pragma unroll
-      for (int blk = 0; blk < CH; ++blk) {
-        if (blk < nblk) {
-          // wave-uniform query words for this 64-bin block: SGPR operands
-          const uint32_t *__restrict__ qp =
-              qryT + 2 * (((size_t)k * words + (size_t)(c * CH + blk) * bbits) * p.npad_q + qw0);
-          const u32x2 *lrow = lds + (blk * bbits) * 64 + lane;
-          uint32_t lo[TQ], hi[TQ];
-          if constexpr (BBITS > 0) {
-#pragma unroll
-            for (int b = 0; b < BBITS; ++b) {
-              const u32x2 a = lrow[b * 64];
-              const uint32_t *qb = qp + (size_t)b * 2 * p.npad_q;
-#pragma unroll
-              for (int j = 0; j < TQ; ++j) {
-                const uint32_t s0 = qb[2 * j], s1 = qb[2 * j + 1];
-                if (b == 0) {
-                  lo[j] = ~(a.x ^ s0);
-                  hi[j] = ~(a.y ^ s1);
-                } else {
-                  lo[j] = __builtin_amdgcn_bitop3_b32(lo[j], a.x, s0, 0x90);
-                  hi[j] = __builtin_amdgcn_bitop3_b32(hi[j], a.y, s1, 0x90);
-                }
-              }
-            }
-          } else {
-#pragma unroll
-            for (int j = 0; j < TQ; ++j) {
-              lo[j] = 0xffffffffu;
-              hi[j] = 0xffffffffu;
-            }
-            for (int b = 0; b < bbits; ++b) {
-              const u32x2 a = lrow[b * 64];
-              const uint32_t *qb = qp + (size_t)b * 2 * p.npad_q;
-#pragma unroll
-              for (int j = 0; j < TQ; ++j) {
-                lo[j] = __builtin_amdgcn_bitop3_b32(lo[j], a.x, qb[2 * j], 0x90);
-                hi[j] = __builtin_amdgcn_bitop3_b32(hi[j], a.y, qb[2 * j + 1], 0x90);
-              }
-            }
-          }
-#pragma unroll
-          for (int j = 0; j < TQ; ++j) cnt[j] += __popc(lo[j]) + __popc(hi[j]);
-        }
-      }
-    }
-
-    if (c == cpk - 1) {
-      // ---- end of one k: consume the counts --------------------------------
+      __syncthreads();
       if (wave_active) {
+        // wave-uniform query words for this 64-bin block: SGPR operands
+        const uint32_t *__restrict__ qp = qryT + 2 * (grow0 * p.npad_q + qw0);
+        const u32x2 *lrow = lds + lane;
+        uint32_t lo[TQ], hi[TQ];
 #pragma unroll
         for (int j = 0; j < TQ; ++j) {
-          if constexpr (MODE == MODE_DIST || MODE == MODE_MASK) {
-            pack_put(packed[j], cnt[j], k, p.cnt_bits);
-          } else {
-            const size_t q = qw0 + j;
-            const bool valid = r < p.n_ref && q >= p.q_begin && q < p.q_end && (!p.self || r > q);
-            if (valid) {
-              const size_t row = (p.self ? q * p.n_ref - (q * (q + 1)) / 2 + (r - q - 1)
-                                         : q * p.n_ref + r) - p.row_base;
-              if constexpr (MODE == MODE_COUNTS) {
-                static_cast<uint32_t *>(out)[row * p.nk + k] = cnt[j];
-              } else {
-                double jr = 0.0;
-                if (p.random_correct) {
-                  const int cr = ref_clu ? ref_clu[r] : 0;
-                  const int cq = qry_clu ? qry_clu[q] : 0;
-                  jr = (double)rtab[((size_t)k * p.n_clu + cr) * p.n_clu + cq];
-                }
-                static_cast<float *>(out)[row * p.nk + k] =
-                    (float)observed_excess(jaccard_obs(cnt[j], p.s64, bbits), jr);
-              }
-            }
-          }
-          cnt[j] = 0;
+          lo[j] = 0xffffffffu;
+          hi[j] = 0xffffffffu;
         }
+        for (int b = 0; b < bbits; ++b) {
+          const u32x2 a = lrow[b * 64];
+          const uint32_t *qb = qp + (size_t)b * 2 * p.npad_q;
+#pragma unroll
+          for (int j = 0; j < TQ; ++j) {
+            lo[j] = __builtin_amdgcn_bitop3_b32(lo[j], a.x, qb[2 * j], 0x90);
+            hi[j] = __builtin_amdgcn_bitop3_b32(hi[j], a.y, qb[2 * j + 1], 0x90);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < TQ; ++j) cnt[j] += __popc(lo[j]) + __popc(hi[j]);
       }
     }
-    k = kn;
-    c = cn;
+    // ---- end of one k: consume the counts --------------------------------
+    if (wave_active) {
+#pragma unroll
+      for (int j = 0; j < TQ; ++j) {
+        if constexpr (MODE == MODE_DIST || MODE == MODE_MASK) {
+          pack_put(packed[j], cnt[j], k, p.cnt_bits);
+        } else {
+          const size_t q = qw0 + j;
+          const bool valid = r < p.n_ref && q >= p.q_begin && q < p.q_end && (!p.self || r > q);
+          if (valid) {
+            const size_t row = (p.self ? q * p.n_ref - (q * (q + 1)) / 2 + (r - q - 1)
+                                       : q * p.n_ref + r) - p.row_base;
+            if constexpr (MODE == MODE_COUNTS) {
+              static_cast<uint32_t *>(out)[row * p.nk + k] = cnt[j];
+            } else {
+              double jr = 0.0;
+              if (p.random_correct) {
+                const int cr = ref_clu ? ref_clu[r] : 0;
+                const int cq = qry_clu ? qry_clu[q] : 0;
+                jr = (double)rtab[((size_t)k * p.n_clu + cr) * p.n_clu + cq];
+              }
+              static_cast<float *>(out)[row * p.nk + k] =
+                  (float)observed_excess(jaccard_obs(cnt[j], p.s64, bbits, p.ext_adjust), jr);
+            }
+          }
+        }
+        cnt[j] = 0;
+      }
+    }
   }
 
   // ---- epilogue: regression (+ boundary) per pair ---------------------------
@@ -650,8 +583,8 @@ __device__ __forceinline__ unsigned tiles_before(unsigned r, int self, unsigned 
   return t;
 }
 
-// NW = wavefronts per workgroup: 8 (256 x 32 tile, 2 workgroups per CU) or 16 (256 x 64 tile,
-// 1 workgroup per CU: half the ref traffic per pair, one s_barrier over 16 wavefronts)
+// NW = wavefronts per workgroup: 8 (256 x 32 tile, 2 workgroups per CU).  The 16-wavefront shape
+// (256 x 64 tile, one workgroup per CU) was measured and rejected (tools/ubench_pipe.hip).
 // W = dwords of the per-pair count register (1 in the COUNTS / JACCARD modes, which consume each
 // k's counts at once)
 template <int NW, int MODE, int W, bool KSPLIT = false>
@@ -661,8 +594,9 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
                const uint16_t *__restrict__ qry_clu, const float *__restrict__ rtab,
                void *__restrict__ out, unsigned long long *__restrict__ n_failed,
                uint64_t *__restrict__ mask_out, const DistParams p) {
+  static_assert(NW == 8, "the product tile is 256 refs x 32 queries (8 wavefronts)");
   constexpr int R = V2_R, TQ = V2_TQ, BB = V2_BB;
-  constexpr int V2_QT = NW * TQ;              // queries per workgroup tile (32 or 64)
+  constexpr int V2_QT = NW * TQ;              // queries per workgroup tile (32)
   constexpr int REF_U4 = BB * 128;            // 14 rows x 256 samples x 8 B = 28 KB
   constexpr int QRY_U4 = BB * (V2_QT / 2);    // 14 rows x QT samples x 8 B = 3.5 / 7 KB
   constexpr int CHUNK_U4 = REF_U4 + QRY_U4;   // one 64-bin block of the tile
@@ -870,9 +804,6 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
         } else
           asm volatile(PPK_BLOCK_ASM_Q32 : PPK_BLOCK_OPERANDS : [rp] "v"(rp), [qp] "v"(qp)
                        : "memory", PPK_BLOCK_CLOBBERS);
-      } else {
-        asm volatile(PPK_BLOCK_ASM_Q64 : PPK_BLOCK_OPERANDS : [rp] "v"(rp), [qp] "v"(qp)
-                     : "memory", PPK_BLOCK_CLOBBERS);
       }
 #undef PPK_BLOCK_OPERANDS
 
@@ -916,7 +847,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
                     jr = (double)rtab[((size_t)k * p.n_clu + cr) * p.n_clu + cq];
                   }
                   static_cast<float *>(out)[row * p.nk + k] =
-                      (float)observed_excess(jaccard_obs(pw[0][r][q], p.s64, BB), jr);
+                      (float)observed_excess(jaccard_obs(pw[0][r][q], p.s64, BB, p.ext_adjust), jr);
                 }
               }
             }
@@ -1104,8 +1035,8 @@ regress_counts_kernel(const uint32_t *__restrict__ counts, size_t n_rows, size_t
                       size_t n_ref, int nk, const int *__restrict__ kmers, size_t s64, size_t bbits,
                       const float *__restrict__ rtab, int n_clu,
                       const uint16_t *__restrict__ ref_clu, const uint16_t *__restrict__ qry_clu,
-                      float scale_x, float scale_y, float2 *__restrict__ out,
-                      unsigned long long *__restrict__ n_failed) {
+                      float scale_x, float scale_y, int ext_adjust, int ext_skip,
+                      float2 *__restrict__ out, unsigned long long *__restrict__ n_failed) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   bool failed = false;
   if (i < n_rows) {
@@ -1137,8 +1068,8 @@ regress_counts_kernel(const uint32_t *__restrict__ counts, size_t n_rows, size_t
         const int cq = (n_clu > 1 && qry_clu) ? qry_clu[q] : 0;
         jr = (double)rtab[((size_t)k * n_clu + cr) * n_clu + cq];
       }
-      const double j = observed_excess(jaccard_obs(counts[i * nk + k], s64, bbits), jr);
-      open = open && !(j < tol);
+      const double j = observed_excess(jaccard_obs(counts[i * nk + k], s64, bbits, ext_adjust), jr);
+      open = (ext_skip || open) && !(j < tol);
       if (open) {
         const double x = (double)kmers[k], y = log(j);
         sx += x;
@@ -1213,9 +1144,7 @@ regress_packed_kernel(const uint32_t *__restrict__ counts, size_t n_rows, const 
 
 namespace {
 
-int g_tile_tq = 0, g_tile_nw = 0;
-
-template <int TQ, int NW, int BBITS, int MODE, typename PackT>
+template <int TQ, int NW, int MODE, typename PackT>
 int launch_variant(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const float *d_rtab,
                    void *d_out, unsigned long long *d_n_failed, uint64_t *d_mask, DistParams &p,
                    hipStream_t s, const char *name) {
@@ -1231,7 +1160,7 @@ int launch_variant(const ppk_db *ref, const ppk_db *qry, const double *d_lut, co
   const uint16_t *qclu = use_clu ? qry->d_clu : nullptr;
   ppk_set_kernel_name(name);
   ppk_prof_begin(s);
-  hipLaunchKernelGGL((dist_kernel<TQ, NW, BBITS, MODE, PackT>), grid, dim3(NW * 64), 0, s,
+  hipLaunchKernelGGL((dist_kernel<TQ, NW, MODE, PackT>), grid, dim3(NW * 64), 0, s,
                      ref->d_skT, reinterpret_cast<const uint32_t *>(qry->d_skT), d_lut, rclu, qclu,
                      d_rtab, d_out, d_n_failed, d_mask, p);
   ppk_prof_end(s);
@@ -1261,8 +1190,7 @@ int launch_v2(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const f
   const size_t rem = p.n_ref % V2_RT;
   if constexpr (MODE == MODE_DIST || MODE == MODE_MASK) {
     bool split = p.self && rem != 0 && rem <= 224 && p.n_ref > V2_RT;
-    const char *e = getenv("PPK_STRIP");
-    if (e && atoi(e) == 0) split = false;
+    if (ppk_config().strip.load() == 0) split = false;
     if (split) {
       p.r_limit = p.n_ref - rem;
       p.strip_begin = p.r_limit;
@@ -1277,10 +1205,7 @@ int launch_v2(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const f
   const bool use_clu = p.random_correct && p.n_clu > 1;
   p.r_tiles = (unsigned)(r_tiles ? r_tiles : 1);
   p.q_tiles = (unsigned)(r_tiles ? q_tiles : 0);
-  {
-    const char *m = getenv("PPK_MAP");
-    p.xcd_map = m ? atoi(m) : 0;  // A/B of tile orders; 0 = XCD-contiguous runs (default)
-  }
+  p.xcd_map = (int)ppk_config().map.load();  // A/B of tile orders; 0 = XCD-contiguous runs (default)
   p.n_strip_pad = (p.n_strip + 7u) & ~7u;
   p.tri_m = V2_RT / V2_QT;
   p.tri_c0 = p.tri_m - (int)p.q_tile0;
@@ -1295,7 +1220,7 @@ int launch_v2(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const f
                                   : p.xcd_map == 1 ? per_xcd * 8 : r_tiles * q_tiles;
   const size_t n_blocks = n_tri + p.n_strip_pad;
   if (n_blocks > 0x7fffffffull) return ppk_fail(PPK_ERR_ARG, "tile grid too large for one launch");
-  ppk_set_kernel_name(NW == 8 ? "dist_kernel_v2<256x32,lds-dma>" : "dist_kernel_v2<256x64,lds-dma>");
+  ppk_set_kernel_name("dist_kernel_v2<256x32,lds-dma>");
   ppk_prof_begin(s);
   if (MODE == MODE_COUNTS && NW == 8 && p.k_split) {
     if constexpr (MODE == MODE_COUNTS && NW == 8)
@@ -1321,8 +1246,8 @@ int launch_tiles_unpacked(const ppk_db *ref, const ppk_db *qry, const double *d_
                           hipStream_t s) {
   static_assert(MODE == MODE_COUNTS || MODE == MODE_JACCARD, "unpacked modes");
   if (p.bbits != 14)
-    return launch_variant<8, 4, 0, MODE, uint64_t>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask,
-                                                   p, s, "dist_kernel<8,4,generic>");
+    return launch_variant<8, 4, MODE, uint64_t>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask,
+                                                p, s, "dist_kernel<8,4,generic>");
   return launch_v2<8, MODE, 1>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
 }
 
@@ -1335,31 +1260,15 @@ int launch_tiles_packed(const ppk_db *ref, const ppk_db *qry, const double *d_lu
   static_assert(MODE == MODE_DIST || MODE == MODE_MASK, "packed modes");
   const int total_bits = p.nk * p.cnt_bits;
   if (p.bbits != 14) {
-    // the generic-bbits (v1) kernel has registers to spare and packs into plain integers
+    // the generic-bbits kernel has registers to spare and packs into plain integers
     if (total_bits <= 64)
-      return launch_variant<8, 4, 0, MODE, uint64_t>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask,
-                                                     p, s, "dist_kernel<8,4,generic>");
+      return launch_variant<8, 4, MODE, uint64_t>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask,
+                                                  p, s, "dist_kernel<8,4,generic>");
     if (p.nk <= 6 && p.cnt_bits <= 16)
-      return launch_variant<8, 4, 0, MODE, Pack96>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask,
-                                                   p, s, "dist_kernel<8,4,generic>");
-    return launch_variant<8, 4, 0, MODE, u128>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask,
-                                               p, s, "dist_kernel<8,4,generic>");
-  }
-  if constexpr (MODE == MODE_DIST) {
-    // v1 tiles and the 16-wavefront shape are kept for A/B measurements of the plain distance mode
-    if (total_bits <= 64) {
-      if (g_tile_tq == 16 && g_tile_nw == 4)
-        return launch_variant<16, 4, 14, MODE, uint64_t>(ref, qry, d_lut, d_rtab, d_out, d_n_failed,
-                                                         d_mask, p, s, "dist_kernel<16,4,14>");
-      if (g_tile_tq == 8 && g_tile_nw == 8)
-        return launch_variant<8, 8, 14, MODE, uint64_t>(ref, qry, d_lut, d_rtab, d_out, d_n_failed,
-                                                        d_mask, p, s, "dist_kernel<8,8,14>");
-      if (g_tile_tq == 8 && g_tile_nw == 4)
-        return launch_variant<8, 4, 14, MODE, uint64_t>(ref, qry, d_lut, d_rtab, d_out, d_n_failed,
-                                                        d_mask, p, s, "dist_kernel<8,4,14>");
-      if (g_tile_tq == 4 && g_tile_nw == 16)
-        return launch_v2<16, MODE, 2>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
-    }
+      return launch_variant<8, 4, MODE, Pack96>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask,
+                                                p, s, "dist_kernel<8,4,generic>");
+    return launch_variant<8, 4, MODE, u128>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask,
+                                            p, s, "dist_kernel<8,4,generic>");
   }
   if (total_bits <= 64) return launch_v2<8, MODE, 2>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
   if (total_bits <= 96) return launch_v2<8, MODE, 3>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
@@ -1367,15 +1276,6 @@ int launch_tiles_packed(const ppk_db *ref, const ppk_db *qry, const double *d_lu
 }
 
 }  // namespace
-
-int ppk_set_tile(int tq, int nw) {
-  if (!((tq == 0 && nw == 0) || (tq == 16 && nw == 4) || (tq == 8 && nw == 8) ||
-        (tq == 8 && nw == 4) || (tq == 4 && nw == 16)))
-    return ppk_fail(PPK_ERR_ARG, "supported v1 tiles: (16,4) (8,8) (8,4); (0,0) = v2 (default)");
-  g_tile_tq = tq;
-  g_tile_nw = nw;
-  return PPK_OK;
-}
 
 int ppk_launch_transpose(const uint64_t *d_in, uint64_t *d_out, size_t n, size_t cols, size_t npad,
                          hipStream_t s) {
@@ -1431,10 +1331,9 @@ int ppk_launch_dist(const ppk_db *ref, const ppk_db *qry_or_null, const int32_t 
     p.inv_n_all = 1.0 / (double)p.nk;
   }
   p.lut32 = ((size_t)p.n_clu * p.n_clu * p.lut_cpstride * 8 < ((size_t)1 << 32)) ? 1 : 0;
-  {
-    const char *ab = getenv("PPK_ABLATE");
-    p.ablate = ab ? atoi(ab) : 0;
-  }
+  p.ablate = (int)ppk_config().ablate.load();
+  p.ext_adjust = ppk_config().ext_collision_adjust.load() ? 1 : 0;
+  p.ext_skip = ppk_config().ext_fit_skip.load() ? 1 : 0;
 
   const bool want_counts = flags & PPK_FLAG_COUNTS;
   const bool want_jac = flags & PPK_FLAG_JACCARD;
@@ -1450,8 +1349,9 @@ int ppk_launch_dist(const ppk_db *ref, const ppk_db *qry_or_null, const int32_t 
   bool small = false;
   if (!too_wide && !d_mask && p.bbits == 14 && p.nk >= 2) {
     const size_t rt = (ref->n + V2_RT - 1) / V2_RT, qt = (q_end - q_begin + 31) / 32;
-    size_t limit = 640;   // measured: 2 000 self (315 tiles) 175 vs 245 us, 2 500 self (480 tiles) 255 vs 252 us, 3 000 (760) 361 vs 368
-    if (const char *e = getenv("PPK_KSPLIT")) limit = (size_t)atoi(e);   // A/B: tile-count threshold, 0 = off
+    // default 640; measured: 2 000 self (315 tiles) 175 vs 245 us, 2 500 self (480 tiles) 255 vs 252 us, 3 000 (760) 361 vs 368
+    const long long ks = ppk_config().ksplit.load();   // A/B: tile-count threshold, 0 = off
+    const size_t limit = ks > 0 ? (size_t)ks : 0;
     small = (p.self ? rt * qt / 2 + qt : rt * qt) <= limit;
   }
   if (too_wide) {
@@ -1472,8 +1372,8 @@ int ppk_launch_dist(const ppk_db *ref, const ppk_db *qry_or_null, const int32_t 
     hipLaunchKernelGGL(regress_counts_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, d_cnt,
                        rows, p.row_base, p.self, p.n_ref, p.nk, d_kmers, ref->s64, ref->bbits,
                        p.random_correct ? d_rtab : nullptr, p.n_clu, use_clu ? ref->d_clu : nullptr,
-                       use_clu ? qry->d_clu : nullptr, scale_x, scale_y, static_cast<float2 *>(d_out),
-                       d_n_failed);
+                       use_clu ? qry->d_clu : nullptr, scale_x, scale_y, p.ext_adjust, p.ext_skip,
+                       static_cast<float2 *>(d_out), d_n_failed);
     PPK_HIP(hipGetLastError());
     return PPK_OK;
   }
@@ -1481,7 +1381,7 @@ int ppk_launch_dist(const ppk_db *ref, const ppk_db *qry_or_null, const int32_t 
   {
     const size_t total = (size_t)p.n_clu * p.n_clu * p.lut_cpstride;
     hipLaunchKernelGGL(lut_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_lut,
-                       d_rtab, p.nk, p.n_clu, nbins, ref->s64, ref->bbits, p.random_correct, total);
+                       d_rtab, p.nk, p.n_clu, nbins, ref->s64, ref->bbits, p.random_correct, p.ext_adjust, total);
     PPK_HIP(hipGetLastError());
   }
   if (small) {

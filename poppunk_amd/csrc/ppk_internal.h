@@ -25,6 +25,27 @@ struct ppk_db {
   uint16_t *d_clu;                         // [npad] or nullptr
 };
 
+// Run-time options ---------------------------------------------------------------
+// Every PPK_* environment knob is read ONCE, when the library is first used (ppk_config()); after
+// that only ppk_set_option() changes a value.  None of the measurement knobs changes results; the
+// two ext_* options select between the readings of pp-sketchlib behaviour that cannot be checked
+// in this tree (DESIGN.md "[EXT] assumptions").
+struct PpkConfig {
+  std::atomic<long long> ablate{0};             // PPK_ABLATE: 1 skip epilogue, 2 compare, 4 DMA, 8 barriers
+  std::atomic<long long> map{0};                // PPK_MAP: tile order of dist_kernel_v2 (0 = XCD-contiguous runs)
+  std::atomic<long long> strip{1};              // PPK_STRIP: strip tiles for the ragged right edge
+  std::atomic<long long> ksplit{640};           // PPK_KSPLIT: tile-count threshold of the small-job path
+  std::atomic<long long> chunk_rows{32ll << 20};    // PPK_CHUNK_ROWS: rows per device buffer of ppk_query
+  std::atomic<long long> prefault_threads{8};   // PPK_PREFAULT_THREADS
+  std::atomic<long long> db_cache{1};           // PPK_DB_CACHE: ppk_query keeps its resident databases / buffers
+  // [EXT] a4: 0 = the b-bit collision adjustment is never in effect (upstream as recalled: it is
+  // gated on expected == 0, where it is the identity); 1 = applied when expected > 0
+  std::atomic<long long> ext_collision_adjust{0};
+  // [EXT] a6: 0 = the fit uses the k-mer lengths before the FIRST J < 5/s; 1 = it skips every such k
+  std::atomic<long long> ext_fit_skip{0};
+};
+PpkConfig &ppk_config();
+
 // Error plumbing -------------------------------------------------------------
 void ppk_set_error(const std::string &msg);
 int ppk_fail(int code, const std::string &msg);
@@ -96,6 +117,22 @@ int ppk_launch_assign(const float *d_dist, size_t n_rows, int slope, float x_max
 enum { SLOT_LUT = 0, SLOT_MASK = 1, SLOT_WS = 2, SLOT_ITER_A = 3, SLOT_ITER_B = 4, SLOT_ITER_C = 5,
        SLOT_COUNT = 6 };
 int ppk_scratch_get(int dev, int slot, size_t bytes, void **out);
+// Scope of one entry point that uses the scratch of `dev`: holds that device's (recursive) mutex and
+// names the stream the call enqueues on, so that a slot last used on another stream is waited for
+// (see ppk_api.hip).  ppk_scratch_get fails outside such a scope.
+class PpkCall {
+ public:
+  PpkCall(int dev, hipStream_t s);
+  ~PpkCall();
+  PpkCall(const PpkCall &) = delete;
+  PpkCall &operator=(const PpkCall &) = delete;
+
+ private:
+  int dev_, prev_dev_;
+  hipStream_t prev_s_;
+  unsigned prev_touched_;
+};
+void ppk_query_cache_clear();
 
 // spread the 32 bits of x to the even bit positions of a 64-bit word (wave-uniform: SALU)
 __device__ __forceinline__ uint64_t spread_even(uint32_t v) {
@@ -138,8 +175,7 @@ __device__ __forceinline__ float ppk_line_dist(float x0, float y0, float x_max, 
 class HostToucher {
  public:
   HostToucher(void *out, size_t total_bytes) : out_(out), total_(total_bytes) {
-    int nt = 8;
-    if (const char *e = getenv("PPK_PREFAULT_THREADS")) nt = atoi(e);
+    int nt = (int)ppk_config().prefault_threads.load();
     if (nt > 64) nt = 64;
     if (!out || total_bytes < ((size_t)8 << 20) || nt < 0) nt = 0;
     nt_ = nt;

@@ -299,6 +299,7 @@ extern "C" int ppk_threshold_iterate_1d_dev(const float *d_dist, size_t n_rows,
 
   int dev = 0;
   PPK_HIP(hipGetDevice(&dev));
+  PpkCall call(dev, s);
   const size_t n_words = ppk_mask_words_linear(n_rows);
   void *p_a = nullptr, *p_mask = nullptr, *p_ws = nullptr;
   // A: d0 (float) | first (u16) | max_ord (u32) | g (u64 x n_off)
@@ -405,6 +406,7 @@ extern "C" int ppk_threshold_iterate_2d_dev(const float *d_dist, size_t n_rows, 
   }
   int dev = 0;
   PPK_HIP(hipGetDevice(&dev));
+  PpkCall call(dev, s);
   const size_t n_words = ppk_mask_words_linear(n_rows);
   const size_t tot_words = n_words * n_off;
   void *p_mask = nullptr, *p_ws = nullptr;

@@ -283,6 +283,7 @@ extern "C" int ppk_knn_rect_dev(const float *d_block, size_t stride, size_t col,
     return ppk_fail(PPK_ERR_ARG, "ppk_knn_rect_dev: block too large for one segmented sort (rows*cols < 2^31)");
   int dev = 0;
   PPK_HIP(hipGetDevice(&dev));
+  PpkCall call(dev, s);
   const size_t nn = n_rows * n_cols;
   void *p_a = nullptr, *p_c = nullptr;
   const size_t o_kin = 0, o_kout = o_kin + nn * 4, o_vin = o_kout + nn * 4, o_vout = o_vin + nn * 4;

@@ -669,7 +669,7 @@ def query_sharded(ref, qry, kmers, random_tbl, rank, world_size, random_correct=
 
 def edges_sharded(ref, qry, kmers, random_tbl, rank, world_size, slope=2, x_max=0.0, y_max=0.0,
                   scale=(1.0, 1.0), inclusive=True, random_correct=True, band_fn=None, group=None,
-                  device=None):
+                  device=None, cap=None):
     """BASELINE config 5 on N GPUs: every rank runs the fused distance -> boundary -> edge-list
     kernels on its band of query rows; only the edge lists move.  One all-gather of the per-rank
     edge counts, then the variable-length lists go to rank 0 with the same grouped send/recv as
@@ -689,7 +689,7 @@ def edges_sharded(ref, qry, kmers, random_tbl, rank, world_size, slope=2, x_max=
     elif qe > qb:
         local, _ = dist_edges(ref, qry, kmers, random_tbl, random_correct=random_correct, slope=slope,
                               x_max=x_max, y_max=y_max, scale=scale, inclusive=inclusive, q_begin=qb,
-                              q_end=qe)
+                              q_end=qe, cap=cap)
     else:
         local = torch.empty((0, 2), dtype=torch.int64, device=device or "cuda:%d" % ref.device)
     local = local.contiguous()

@@ -93,3 +93,46 @@ def boundary_for_quantile(dist, q=0.02):
     x = float(np.quantile(d[:, 0], q))
     y = float(np.quantile(d[:, 1], q))
     return 2.0 * max(x, 1e-4), 2.0 * max(y, 1e-4)
+
+
+def make_sketches_device(n, kmers=DEFAULT_KMERS, sketchsize64=16, bbits=14, cluster_size=50,
+                         seed=DEFAULT_SEED, device="cuda:0", chunk=8192):
+    """The `related=True` population model of make_sketches, drawn and bit-sliced ON the device
+    (torch ops; not the same random stream as the numpy version): int64 CUDA tensor
+    [n, nk, sketchsize64*bbits] ready for engine.SketchDB.  For the 100 000-genome workload of
+    BASELINE config 5, whose sketches take minutes to draw with numpy on the host."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    k = torch.as_tensor(np.asarray(kmers, dtype=np.float64), device=device)
+    nk = int(k.numel())
+    nbins = 64 * sketchsize64
+    n_clusters = max(1, n // cluster_size)
+
+    def uniform(lo, hi, size):
+        return lo + (hi - lo) * torch.rand(size, generator=g, device=device, dtype=torch.float64)
+
+    def redraw_prob(a, c):
+        return (1.0 - torch.sqrt((1.0 - a)[:, None] * (1.0 - c)[:, None] ** k[None, :])).float()
+
+    def bins_of(size):
+        return torch.randint(0, 1 << bbits, size, generator=g, device=device, dtype=torch.int32)
+
+    p = redraw_prob(uniform(0.0, 0.3, (n_clusters,)), uniform(0.0, 0.02, (n_clusters,)))
+    pb = redraw_prob(uniform(0.1, 0.4, (n_clusters,)), uniform(0.005, 0.02, (n_clusters,)))
+    species = bins_of((nk, nbins))
+    roots = bins_of((n_clusters, nk, nbins))
+    keep = torch.rand(roots.shape, generator=g, device=device) >= pb[:, :, None]
+    roots = torch.where(keep, species[None], roots)
+    lanes = torch.arange(64, device=device, dtype=torch.int64)
+    out = torch.empty((n, nk, sketchsize64 * bbits), dtype=torch.int64, device=device)
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        member = torch.arange(s, e, device=device) % n_clusters
+        bins = roots[member]
+        redraw = torch.rand(bins.shape, generator=g, device=device) < p[member][:, :, None]
+        bins = torch.where(redraw, bins_of(bins.shape), bins).view(e - s, nk, sketchsize64, 64).long()
+        for b in range(bbits):
+            # word [blk*bbits + b] = bit b of bins 64*blk .. 64*blk+63 (distinct powers of two: sum == or)
+            out[s:e].view(e - s, nk, sketchsize64, bbits)[..., b] = (((bins >> b) & 1) << lanes).sum(dim=-1)
+    return out

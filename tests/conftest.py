@@ -15,3 +15,23 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+if HERE not in sys.path:
+    sys.path.insert(0, HERE)          # shared checkers (tests/refine_golden.py)
+
+
+@pytest.fixture
+def ppk_option():
+    """Set libppk_hip.so run-time options (ppk_set_option) for one test; restored afterwards."""
+    from poppunk_amd import _lib
+    saved = {}
+
+    def set_(name, value):
+        if name not in saved:
+            saved[name] = _lib.get_option(name)
+        _lib.set_option(name, value)
+
+    yield set_
+    for name, value in saved.items():
+        _lib.set_option(name, value)

@@ -20,9 +20,15 @@ Fixtures written:
   prune.json           PopPUNK.qc.prune_distance_matrix / prune_query_distance_matrix
                        (PopPUNK/qc.py:17-135) run on small seeded matrices, with the real
                        iterDistRows / storePickle (PopPUNK/utils.py) they call
-boundary_known_answers.json is NOT generated here: src/boundary.cpp needs Eigen,
-absent from this image; its values were captured during the survey (SURVEY.md
-Appendix B) and are transcribed by hand.
+  boundary_refine.npz  the reference's own pure-Python statement of kernel 2 --
+                       withinBoundary / iter_tuples of test/test-refine.py:10-38 -- run on
+                       the grid of test-refine.py:47-50 and on seeded stand-ins for its
+                       unseeded random matrices (:64-66), plus the per-offset expected edge
+                       sets of its thresholdIterate1D/2D sections (:84-138) with
+                       withinBoundary in the role poppunk_refine.assignThreshold plays there.
+                       This is the pin of the kernel-2 oracle (oracle/ppk_oracle.c).
+boundary_known_answers.json is NOT generated here and pins nothing: it holds values
+hand-transcribed from SURVEY.md Appendix B and is kept only as a cross-check.
 """
 import ast
 import json
@@ -158,7 +164,98 @@ def golden_prune():
     print("prune.json:", len(out["self"]), "self cases,", len(out["query"]), "query cases")
 
 
+def golden_refine():
+    """test/test-refine.py:10-38.  withinBoundary evaluates the float32 rows with the numpy of
+    this interpreter (numpy >= 2: float32 * python float stays float32, un-fused) and calls a row
+    'on the line' when |in_tri| < float32 eps; src/boundary.cpp tests == 0 exactly.  The test the
+    functions come from asserts equality of the two on the grid (check_res, :59-61) and edge-set
+    containment on the random matrix (:68-82).  Rows whose |in_tri| lies inside that eps band but
+    is not exactly zero are marked `band` (ambiguous between the two statements); everywhere
+    else the fixture is the reference's answer."""
+    ns = {"np": np}
+    extract_functions(os.path.join(REF, "test", "test-refine.py"), ["withinBoundary", "iter_tuples"], ns)
+    within, iter_tuples = ns["withinBoundary"], ns["iter_tuples"]
+    eps = np.finfo(np.float32).eps
+    out = {}
+
+    def in_tri(d, x_max, y_max, slope):
+        # the expression of withinBoundary itself (test-refine.py:14-19), row by row
+        v = np.empty(d.shape[0], dtype=np.float64)
+        for row in range(d.shape[0]):
+            if slope == 2:
+                v[row] = d[row, 1] * x_max + d[row, 0] * y_max - x_max * y_max
+            elif slope == 0:
+                v[row] = d[row, 0] - x_max
+            else:
+                v[row] = d[row, 1] - y_max
+        return v
+
+    # the grid of test-refine.py:47-50
+    x = np.arange(0, 1, 0.1, dtype=np.float32)
+    y = np.arange(0, 1, 0.1, dtype=np.float32)
+    xv, yv = np.meshgrid(x, y)
+    grid = np.hstack((xv.reshape(-1, 1), yv.reshape(-1, 1)))
+    out["grid"] = grid
+    for slope in (0, 1, 2):
+        out["grid_assign%d" % slope] = within(grid, 0.5, 0.5, slope).astype(np.float32)
+        t = in_tri(grid, 0.5, 0.5, slope)
+        out["grid_band%d" % slope] = (np.abs(t) < eps) & (t != 0)
+
+    # seeded stand-ins for the unseeded np.random.rand matrix of :64-66
+    rng = np.random.Generator(np.random.PCG64(20260928))
+    for samples in (100, 363):
+        d = np.array(rng.random((int(0.5 * samples * (samples - 1)), 2)), dtype=np.float32)
+        # a few rows exactly on each boundary and a few inside the eps band, so that the
+        # `== 0` class and the band are both exercised (0.5 and 0.25 are dyadic: exact in float32)
+        d[3] = (0.5, 0.5)          # slope 0, 1: on the line
+        d[7] = (0.25, 0.25)        # slope 2 with x_max = y_max = 0.5: 0.125 + 0.125 - 0.25 = 0
+        d[11] = (0.5, 0.0)         # slope 0 and slope 2: on the line
+        d[13] = (np.nextafter(np.float32(0.5), np.float32(1)), 0.9)   # slope 0: one ulp (6e-8) over, inside the band, not zero
+        d[17] = (0.1, np.nextafter(np.float32(0.5), np.float32(0)))   # slope 1: half an ulp-of-1 under
+        key = "rand%d" % samples
+        out[key] = d
+        for slope in (0, 1, 2):
+            a = within(d, 0.5, 0.5, slope)
+            t = in_tri(d, 0.5, 0.5, slope)
+            out["%s_assign%d" % (key, slope)] = a.astype(np.float32)
+            out["%s_band%d" % (key, slope)] = (np.abs(t) < eps) & (t != 0)
+            out["%s_edges%d" % (key, slope)] = np.asarray(iter_tuples(a, samples),
+                                                           dtype=np.int64).reshape(-1, 2)
+
+    # thresholdIterate1D / 2D sections (:84-138) on the 100-sample matrix: the expected edge set
+    # per offset is {(i, j): assign <= 0}; withinBoundary stands where the test calls
+    # poppunk_refine.assignThreshold
+    from math import sqrt
+    d = out["rand100"]
+    samples = 100
+    offsets = [v * sqrt(2) for v in [-0.1, 0.0, 0.1]]
+    out["it1d_offsets"] = np.asarray(offsets, dtype=np.float64)
+    out["it1d_line"] = np.asarray([0.2, 0.2, 0.3, 0.3], dtype=np.float64)   # x0, y0, x1, y1
+    for oi, off in enumerate(offsets):
+        xmax = 0.4 + (2 * (off / sqrt(2)))
+        a = within(d, xmax, xmax, 2)
+        out["it1d_xmax%d" % oi] = np.float64(xmax)
+        out["it1d_rows%d" % oi] = np.flatnonzero(a <= 0).astype(np.int64)
+        t = in_tri(d, xmax, xmax, 2)
+        out["it1d_band%d" % oi] = np.flatnonzero((np.abs(t) < eps) & (t != 0)).astype(np.int64)
+    xs = [0.1, 0.2, 0.3]
+    out["it2d_xmax"] = np.asarray(xs, dtype=np.float64)
+    out["it2d_ymax"] = np.float64(0.2)
+    for oi, xm in enumerate(xs):
+        a = within(d, xm, 0.2, 2)
+        out["it2d_rows%d" % oi] = np.flatnonzero(a <= 0).astype(np.int64)
+        t = in_tri(d, xm, 0.2, 2)
+        out["it2d_band%d" % oi] = np.flatnonzero((np.abs(t) < eps) & (t != 0)).astype(np.int64)
+    out["numpy_version"] = np.asarray(np.__version__)
+    out["source"] = np.asarray("test/test-refine.py:10-38 withinBoundary / iter_tuples, executed by "
+                               "tests/golden/make_golden.py golden_refine()")
+    np.savez_compressed(os.path.join(HERE, "boundary_refine.npz"), **out)
+    print("boundary_refine.npz:", {k: (int(out[k].sum()) if out[k].dtype == bool else out[k].shape)
+                                   for k in sorted(out) if "band" in k or "edges" in k})
+
+
 if __name__ == "__main__":
+    golden_refine()
     golden_prune()
     golden_fit()
     golden_rows()

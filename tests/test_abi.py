@@ -66,12 +66,36 @@ def test_argument_errors_are_reported_not_raised_across_the_abi():
     lib = _lib.lib()
     assert lib.ppk_band_split(10, 0, 0, None) == _lib.ERR_ARG
     assert b"band split" in lib.ppk_last_error()
-    assert lib.ppk_set_tile(3, 3) == _lib.ERR_ARG
-    assert lib.ppk_set_tile(0, 0) == _lib.OK
+    assert lib.ppk_set_option(b"no_such_option", 1) == _lib.ERR_ARG
+    assert b"unknown option" in lib.ppk_last_error()
     h = C.c_void_p()
     assert lib.ppk_db_create(0, None, 0, 0, 0, 0, None, 0, None, C.byref(h)) == _lib.ERR_ARG
     with pytest.raises(RuntimeError):
         _lib.check(_lib.ERR_ARG, "x")
+
+
+def test_options_are_read_once_and_settable():
+    """PPK_* environment knobs are read when the library is first used; afterwards only
+    ppk_set_option changes them (so a getenv never sits in a launch path)."""
+    _lib.lib()
+    for name, default in (("ablate", 0), ("map", 0), ("strip", 1), ("ksplit", 640),
+                          ("chunk_rows", 32 << 20), ("prefault_threads", 8), ("db_cache", 1),
+                          ("ext_collision_adjust", 0), ("ext_fit_skip", 0)):
+        env = "PPK_" + name.upper()
+        if env not in os.environ:
+            assert _lib.get_option(name) == default, name
+        old = _lib.get_option(name)
+        os.environ[env] = "12345"          # ignored: the environment was read at first use
+        try:
+            assert _lib.get_option(name) == old
+            _lib.set_option(name, 7)
+            assert _lib.get_option(name) == 7
+        finally:
+            _lib.set_option(name, old)
+            del os.environ[env]
+    src = "".join(open(os.path.join(ROOT, "poppunk_amd", "csrc", f)).read()
+                  for f in os.listdir(os.path.join(ROOT, "poppunk_amd", "csrc")) if f.endswith((".hip", ".h")))
+    assert src.count("getenv(") == 1, "only ppk_config() may read the environment"
 
 
 def test_missing_extension_fails_loudly(monkeypatch):

@@ -22,6 +22,21 @@ def grid10():
     return np.ascontiguousarray(np.hstack((xv.reshape(-1, 1), yv.reshape(-1, 1))), dtype=np.float32)
 
 
+class _HipRefine:
+    assign = staticmethod(lambda d, slope, x, y: poppunk_refine.assignThreshold(d, slope, x, y, 2))
+    edges = staticmethod(lambda d, slope, x, y: poppunk_refine.edgeThreshold_array(d, slope, x, y))
+    tuples = staticmethod(lambda a, label: poppunk_refine.generateTuples_array(a, label))
+    iterate_1d = staticmethod(poppunk_refine.thresholdIterate1D_arrays)
+    iterate_2d = staticmethod(poppunk_refine.thresholdIterate2D_arrays)
+
+
+def test_pinned_by_reference_test_refine():
+    """The HIP path against the reference's own pure-Python withinBoundary / iter_tuples
+    (test/test-refine.py:10-38; tests/golden/boundary_refine.npz, see tests/refine_golden.py)."""
+    import refine_golden
+    assert refine_golden.check(_HipRefine) > 70000
+
+
 def test_known_answers_grid(golden_dir):
     ka = json.load(open(os.path.join(golden_dir, "boundary_known_answers.json")))
     d = grid10()

@@ -59,15 +59,12 @@ def test_identical_and_disjoint_sketches():
     assert failed == 2 and np.array_equal(d[1:], np.zeros((2, 2)))
 
 
-@pytest.mark.parametrize("tile", [(16, 4), (8, 8), (8, 4), (4, 16)])
-def test_distances_self(sk300, tbl1, tile):
+@pytest.mark.parametrize("ksplit", [0, 640])
+def test_distances_self(sk300, tbl1, ppk_option, ksplit):
+    """tile epilogue (ksplit 0) and the small-job k-split path (default threshold)"""
     sk = sk300[0]
-    lib = _lib.lib()
-    _lib.check(lib.ppk_set_tile(*tile))
-    try:
-        got, gf = pp_sketchlib.query_arrays(sk, None, KMERS, 16, 14, tbl1)
-    finally:
-        lib.ppk_set_tile(0, 0)
+    ppk_option("ksplit", ksplit)
+    got, gf = pp_sketchlib.query_arrays(sk, None, KMERS, 16, 14, tbl1)
     want, wf = oracle.query(sk, None, KMERS, 16, 14, tbl1, threads=4)
     assert gf == wf
     assert np.abs(got - want).max() <= TOL
@@ -186,6 +183,63 @@ def test_other_sketch_shapes(s64, bbits):
     got, gf = pp_sketchlib.query_arrays(sk, None, kmers, s64, bbits, tbl)
     want, wf = oracle.query(sk, None, kmers, s64, bbits, tbl, threads=4)
     assert gf == wf and np.abs(got - want).max() <= TOL
+
+
+@pytest.mark.parametrize("s64,bbits", [(4, 8), (20, 10), (300, 14)])
+def test_ext_collision_gate_both_ways(ppk_option, s64, bbits):
+    """[EXT] a4: with expected = nbins >> bbits > 0 the two readings of
+    calc_intersize's gate give different numbers; kernel and oracle flip together (one switch each)
+    and agree under both -- tile kernel (bbits 14), generic kernel, k-split and regression pass."""
+    kmers = np.asarray([13, 17, 21, 25], dtype=np.int32)
+    assert (64 * s64) >> bbits > 0
+    sk, _ = synth.make_sketches(90, kmers, sketchsize64=s64, bbits=bbits, cluster_size=9, seed=3)
+    tbl = synth.random_match_table(kmers)
+    res = {}
+    try:
+        for gate in (0, 1):
+            ppk_option("ext_collision_adjust", gate)
+            oracle.set_ext(collision_adjust=gate)
+            want, wf = oracle.query(sk, None, kmers, s64, bbits, tbl, threads=4)
+            wj, _ = oracle.query(sk, None, kmers, s64, bbits, tbl, jaccard=True, threads=4)
+            for ks in (0, 640):
+                ppk_option("ksplit", ks)
+                got, gf = pp_sketchlib.query_arrays(sk, None, kmers, s64, bbits, tbl)
+                assert gf == wf and np.abs(got - want).max() <= TOL
+            jac, _ = pp_sketchlib.query_arrays(sk, None, kmers, s64, bbits, tbl, jaccard=True)
+            assert np.array_equal(jac, wj)
+            res[gate] = got
+    finally:
+        oracle.set_ext(0, 0)
+    assert np.abs(res[0] - res[1]).max() > 1e-5        # the gate matters at these sketch sizes
+
+
+def test_ext_fit_skip_both_ways(ppk_option):
+    """[EXT] a6: truncate at (default) or skip the k-mer lengths whose J < 5/s."""
+    kmers = np.asarray(synth.DEFAULT_KMERS, dtype=np.int32)
+    # distant but related samples: J falls through the 5/1024 floor at the longer k
+    rng = np.random.Generator(np.random.PCG64(8))
+    bins = rng.integers(0, 1 << 14, size=(1, 5, 1024), dtype=np.uint16).repeat(300, axis=0)
+    keep_p = np.asarray([0.25, 0.1, 0.05, 0.1, 0.05])          # J ~ 0.14, 0.05, 0.026, 0.05, 0.026 ...
+    redraw = rng.random(bins.shape) > keep_p[None, :, None]
+    fresh = rng.integers(0, 1 << 14, size=bins.shape, dtype=np.uint16)
+    bins[redraw] = fresh[redraw]
+    sk = synth.bitslice(bins, 14)
+    tbl = synth.random_match_table(kmers)
+    res = {}
+    try:
+        for skip in (0, 1):
+            ppk_option("ext_fit_skip", skip)
+            oracle.set_ext(fit_skip=skip)
+            want, wf = oracle.query(sk, None, kmers, 16, 14, tbl, threads=4)
+            for ks in (0, 640):
+                ppk_option("ksplit", ks)
+                got, gf = pp_sketchlib.query_arrays(sk, None, kmers, 16, 14, tbl)
+                assert gf == wf and np.abs(got - want).max() <= TOL
+            res[skip] = (got, gf)
+    finally:
+        oracle.set_ext(0, 0)
+    assert res[1][1] < res[0][1]                               # skipping rescues fits truncation fails
+    assert np.abs(res[0][0] - res[1][0]).max() > 1e-4
 
 
 def test_two_kmers_minimum():
@@ -375,7 +429,7 @@ def test_many_kmer_lengths_counts_fallback(s64, kstep):
     db.close()
 
 
-def test_small_job_k_split_is_bit_identical_to_the_tile_epilogue(monkeypatch):
+def test_small_job_k_split_is_bit_identical_to_the_tile_epilogue(ppk_option):
     """Below ~350 pair tiles kernel 1 runs one workgroup per (tile, k) and a separate regression
     pass (DESIGN.md 3.1 'Small jobs'); every pair must come out bit for bit as from the fused tile
     epilogue (same expressions in the same order: a result never depends on the job's shape)."""
@@ -390,11 +444,11 @@ def test_small_job_k_split_is_bit_identical_to_the_tile_epilogue(monkeypatch):
         dq = engine.SketchDB(sk[700:], 16, 14, clusters=None if clusters is None else clusters[700:])
         res = {}
         for mode in ("0", "100000"):
-            monkeypatch.setenv("PPK_KSPLIT", mode)
+            ppk_option("ksplit", int(mode))
             a, fa = engine.dist(db, None, kmers, table)
             b, fb = engine.dist(db, dq, kmers, table, q_begin=3, q_end=150)
             res[mode] = (a.clone(), fa, b.clone(), fb)
-        monkeypatch.delenv("PPK_KSPLIT")
+        ppk_option("ksplit", 640)
         assert res["0"][1] == res["100000"][1] and res["0"][3] == res["100000"][3]
         assert torch.equal(res["0"][0], res["100000"][0]) and torch.equal(res["0"][2], res["100000"][2])
         want, wf = oracle.query(sk[:700], None, kmers, 16, 14, table,
@@ -404,7 +458,7 @@ def test_small_job_k_split_is_bit_identical_to_the_tile_epilogue(monkeypatch):
         dq.close()
 
 
-def test_host_call_chunks_the_result_through_bounded_device_memory(monkeypatch):
+def test_host_call_chunks_the_result_through_bounded_device_memory(ppk_option):
     """ppk_query computes its band in sub-bands through two alternating device buffers (the
     reference CUDA path's device-memory chunking): many tiny sub-bands, one or several devices in
     the list, self and ref x query, all output modes -- identical to the one-piece result."""
@@ -417,7 +471,7 @@ def test_host_call_chunks_the_result_through_bounded_device_memory(monkeypatch):
         base[name] = (pp_sketchlib.query_arrays(r, q, kmers, 16, 14, tbl),
                       pp_sketchlib.query_arrays(r, q, kmers, 16, 14, tbl, jaccard=True)[0],
                       pp_sketchlib.query_arrays(r, q, kmers, 16, 14, counts=True)[0])
-    monkeypatch.setenv("PPK_CHUNK_ROWS", "30000")
+    ppk_option("chunk_rows", 30000)
     for devices in ((0,), (0, 0, 0)):
         for name, (r, q) in (("self", (sk, None)), ("rq", (ref, qry))):
             d, f = pp_sketchlib.query_arrays(r, q, kmers, 16, 14, tbl, devices=devices)
@@ -430,7 +484,7 @@ def test_host_call_chunks_the_result_through_bounded_device_memory(monkeypatch):
 
 @pytest.mark.parametrize("s64,nk,words", [(16, 5, 2), (16, 6, 3), (16, 8, 3), (16, 9, 4), (16, 11, 4),
                                           (156, 4, 2), (156, 6, 3), (156, 7, 4), (156, 9, 4)])
-def test_count_register_widths(monkeypatch, s64, nk, words):
+def test_count_register_widths(ppk_option, s64, nk, words):
     """The tile kernel keeps each pair's counts in a shift register of 2, 3 or 4 dwords (count k at
     bit (nk-1-k)*bits; bits = 11 at s = 1024, 14 at s = 9984): every width, fields straddling dword
     boundaries, the exact 128-bit limit (9 x 14 = 126), distances and the fused boundary; failed and
@@ -447,10 +501,10 @@ def test_count_register_widths(monkeypatch, s64, nk, words):
         counts, _ = pp_sketchlib.query_arrays(sk, None, kmers, s64, 14, counts=True)
         assert np.array_equal(counts, oracle.match_counts(sk, None, s64, 14, threads=4))
         want, wf = oracle.query(sk, None, kmers, s64, 14, tbl, threads=4)
-        monkeypatch.setenv("PPK_KSPLIT", "0")       # a job this small would take the k-split path
+        ppk_option("ksplit", 0)       # a job this small would take the k-split path
         got, gf = pp_sketchlib.query_arrays(sk, None, kmers, s64, 14, tbl)
         assert gf == wf and np.abs(got - want).max() <= TOL
-        monkeypatch.delenv("PPK_KSPLIT")
+        ppk_option("ksplit", 640)
         got2, gf2 = pp_sketchlib.query_arrays(sk, None, kmers, s64, 14, tbl)
         assert gf2 == wf and np.array_equal(got2, got)      # k-split: same bits
         if not related:
@@ -462,26 +516,26 @@ def test_count_register_widths(monkeypatch, s64, nk, words):
         db.close()
 
 
-def test_host_result_pages_are_touched_ahead_of_the_download(monkeypatch):
+def test_host_result_pages_are_touched_ahead_of_the_download(ppk_option):
     """ppk_query's helper threads write the first byte of every page of the (fresh) result array
     before the chunked download reaches it: any thread count, arrays that do not start on a page
     boundary, several sub-bands and devices in the list -- the result is the one without them."""
     kmers = np.asarray(synth.DEFAULT_KMERS, dtype=np.int32)
     tbl = synth.random_match_table(kmers)
     sk = synth.make_sketches(1700, kmers, cluster_size=40, seed=77)[0]      # 1.44 M pairs: 11.6 MB of float2
-    monkeypatch.setenv("PPK_PREFAULT_THREADS", "0")
+    ppk_option("prefault_threads", 0)
     want, wf = pp_sketchlib.query_arrays(sk, None, kmers, 16, 14, tbl)
     assert want.nbytes > (8 << 20)
     for threads, chunk_rows, devices in (("1", None, (0,)), ("3", "200000", (0,)), ("64", "77777", (0, 0)), ("8", None, (0,))):
-        monkeypatch.setenv("PPK_PREFAULT_THREADS", threads)
+        ppk_option("prefault_threads", int(threads))
         if chunk_rows:
-            monkeypatch.setenv("PPK_CHUNK_ROWS", chunk_rows)
+            ppk_option("chunk_rows", int(chunk_rows))
         else:
-            monkeypatch.delenv("PPK_CHUNK_ROWS", raising=False)
+            ppk_option("chunk_rows", 32 << 20)
         got, gf = pp_sketchlib.query_arrays(sk, None, kmers, 16, 14, tbl, devices=devices)
         assert gf == wf and np.array_equal(got, want)
     # the square / long helpers pre-touch their results the same way
-    monkeypatch.setenv("PPK_PREFAULT_THREADS", "5")
+    ppk_option("prefault_threads", 5)
     n = 2100                                                                 # 17.6 MB square
     v = np.random.Generator(np.random.PCG64(3)).random(n * (n - 1) // 2, dtype=np.float32)
     sq = pp_sketchlib.longToSquare(v.reshape(-1, 1))

@@ -1,0 +1,138 @@
+"""Kernel 1 against the CPU oracle AT BASELINE.json's sizes (the cache-blocked oracle does 80 M
+pairs/s on 16 threads, so every row of every config can be compared, not sampled):
+
+  config 2   1 000 genomes self                       every row, counts bit-exact
+  config 3  10 000 genomes self                       all 49 995 000 rows + failed-fit count
+  config 4  50 000 queries x 10 000 refs              all 5e8 rows, in query bands
+  config 5 100 000 genomes self, fused edge list      one band of query rows, edge for edge
+
+Bar: match counts bit-identical; distances within 1e-6 (observed: a handful of rows differ by one
+float32 ulp, the rest are identical); failed-fit counts and edge lists identical.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from poppunk_amd import engine, pp_sketchlib, synth
+
+pytestmark = pytest.mark.gpu
+
+KMERS = np.asarray(synth.DEFAULT_KMERS, dtype=np.int32)
+TOL = 1e-6
+THREADS = 16
+
+
+def _device_sketches(n, seed):
+    import torch
+    t = synth.make_sketches_device(n, KMERS, seed=seed, device="cuda:0")
+    sk = t.cpu().numpy().view(np.uint64)
+    del t
+    torch.cuda.empty_cache()
+    return sk
+
+
+def _compare(got, want, what):
+    diff = np.abs(got - want)
+    n_diff = int(np.count_nonzero(diff))
+    worst = float(diff.max()) if diff.size else 0.0
+    print("%s: %d rows, max |d - oracle| = %.3g, %d values differ" % (what, len(got), worst, n_diff))
+    assert worst <= TOL, what
+    # "differ by an ulp in a handful of rows", not "agree to 1e-6 everywhere by luck"
+    assert n_diff <= max(20, len(got) // 100000), (what, n_diff)
+    return worst, n_diff
+
+
+def test_config2_1000_genomes_self_exact():
+    sk, _ = synth.make_sketches(1000, KMERS)
+    tbl = synth.random_match_table(KMERS)
+    counts, _ = pp_sketchlib.query_arrays(sk, None, KMERS, 16, 14, counts=True)
+    assert counts.shape == (499500, 5)
+    assert np.array_equal(counts, oracle.match_counts(sk, None, 16, 14, threads=THREADS))
+    got, gf = pp_sketchlib.query_arrays(sk, None, KMERS, 16, 14, tbl)
+    want, wf = oracle.query(sk, None, KMERS, 16, 14, tbl, threads=THREADS)
+    assert gf == wf == 0
+    _compare(got, want, "config 2 (1 000 self)")
+    jac, _ = pp_sketchlib.query_arrays(sk, None, KMERS, 16, 14, tbl, jaccard=True)
+    wj, _ = oracle.query(sk, None, KMERS, 16, 14, tbl, jaccard=True, threads=THREADS)
+    assert np.array_equal(jac, wj)
+
+
+@pytest.mark.parametrize("related", [True, False])
+def test_config3_10000_genomes_self_every_row(related):
+    """All 49 995 000 rows of the bench workload (related=True: bench.py's own sketches) and of
+    the unrelated-cluster variant (49 750 000 failing fits: the failed-fit path at full size)."""
+    sk, _ = synth.make_sketches(10000, KMERS, related=related)
+    tbl = synth.random_match_table(KMERS)
+    got, gf = pp_sketchlib.query_arrays(sk, None, KMERS, 16, 14, tbl)
+    want, wf = oracle.query(sk, None, KMERS, 16, 14, tbl, threads=THREADS)
+    assert got.shape == (49995000, 2)
+    assert gf == wf
+    if related:
+        assert wf == 0
+        _compare(got, want, "config 3 (10 000 self)")
+    else:
+        assert wf > 49000000
+        assert np.array_equal(got, want)
+
+
+def test_config4_50000_queries_x_10000_refs_in_bands():
+    """ref sketches resident, 50 000 queries, every one of the 5e8 rows (row = q*n_ref + r)."""
+    import torch
+    allsk = _device_sketches(60000, seed=4)
+    ref, qry = allsk[:10000], allsk[10000:]
+    tbl = synth.random_match_table(KMERS)
+    dr = engine.SketchDB(ref, 16, 14)
+    dq = engine.SketchDB(qry, 16, 14)
+    worst, n_diff, failed_gpu, failed_cpu = 0.0, 0, 0, 0
+    band = 6400
+    for qb in range(0, 50000, band):
+        qe = min(50000, qb + band)
+        d, f = engine.dist(dr, dq, KMERS, tbl, q_begin=qb, q_end=qe)
+        got = d.cpu().numpy()
+        failed_gpu += int(f.item())
+        del d
+        want, wf = oracle.query(ref, qry[qb:qe], KMERS, 16, 14, tbl, threads=THREADS)
+        failed_cpu += wf
+        diff = np.abs(got - want)
+        worst = max(worst, float(diff.max()))
+        n_diff += int(np.count_nonzero(diff))
+    dr.close()
+    dq.close()
+    torch.cuda.empty_cache()
+    print("config 4 (50 000 x 10 000): 500000000 rows, max |d - oracle| = %.3g, %d values differ"
+          % (worst, n_diff))
+    assert failed_gpu == failed_cpu
+    assert worst <= TOL and n_diff <= 5000
+
+
+def test_config5_100000_genomes_one_band_fused_edges():
+    """100 000 genomes self: the fused distance -> boundary -> edge-list kernel on one band of
+    query rows (what one of 8 GPUs does, engine.edges_sharded) against oracle.query +
+    assign_threshold on exactly those rows."""
+    import torch
+    n = 100000
+    sk = _device_sketches(n, seed=5)
+    tbl = synth.random_match_table(KMERS)
+    db = engine.SketchDB(sk, 16, 14)
+    # boundary through the 2 % quantiles of a subsample's distances
+    sub, _ = oracle.query(sk[:1500], None, KMERS, 16, 14, tbl, threads=THREADS)
+    x_max, y_max = synth.boundary_for_quantile(sub, 0.02)
+    total_edges = 0
+    for qb, qe in ((0, 256), (49984, 50624), (99712, n)):        # first rows, a mid band, the last rows
+        # the band's rows: query q in [qb, qe) against every ref r > q
+        rect, _ = oracle.query(sk, sk[qb:qe], KMERS, 16, 14, tbl, threads=THREADS)   # row = (q-qb)*n + r
+        a = oracle.assign_threshold(rect, 2, x_max, y_max, threads=THREADS).reshape(qe - qb, n)
+        del rect
+        for inclusive in (True, False):
+            e, nf = engine.dist_edges(db, None, KMERS, tbl, slope=2, x_max=x_max, y_max=y_max,
+                                      inclusive=inclusive, q_begin=qb, q_end=qe, cap=1 << 20)
+            got = e.cpu().numpy()
+            qq, rr = np.nonzero((a <= 0) if inclusive else (a < 0))
+            sel = rr > qq + qb
+            want = np.stack([qq[sel] + qb, rr[sel]], axis=1).astype(np.int64)
+            assert int(nf.item()) == 0
+            assert np.array_equal(got, want), (qb, qe, inclusive, len(got), len(want))
+            total_edges += len(want)
+    assert total_edges > 1000
+    db.close()
+    torch.cuda.empty_cache()

@@ -174,48 +174,43 @@ def gen(QRY_PLANE_BYTES, TQ=4, dma_planes=None, half=False):
     return out
 
 
+def write_macro(f, name, lines):
+    f.write("#define %s \\\n" % name)
+    for ln in lines:
+        f.write('  "%s\\n" \\\n' % ln)
+    f.write("  \"\"\n")
+    print("wrote", name, len(lines), "instructions")
+
+
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
+    # product: what dist_kernel_v2 (256 x 32 tile) runs
     dst = os.path.join(os.path.dirname(here), "poppunk_amd", "csrc", "ppk_block_asm.inc")
+    # experiments (tools/ubench_pipe.hip only): the rejected 256 x 64 tile and 4x8 register tile
+    dst_x = os.path.join(here, "ppk_block_asm_experiments.inc")
     m4, m8 = Map(4), Map(8)
     clob = ", ".join('"v%d"' % i for i in range(m4.A0, m4.END))
     clob8 = ", ".join('"v%d"' % i for i in range(m8.A0, m8.END))
     with open(dst, "w") as f:
         f.write("// GENERATED by tools/gen_block_asm.py -- do not edit.  One 64-bin block (14 planes) of the\n"
                 "// 4x4 register tile with bank-aware fixed VGPRs v%d..v%d; see the generator for the map.\n"
-                "// _Q32 / _Q64: 32 or 64 queries per workgroup tile (query plane stride 256 / 512 bytes).\n"
+                "// _Q32: 32 queries per workgroup tile (query plane stride 256 bytes).\n"
                 % (m4.A0, m4.END - 1))
-        for name, stride in (("PPK_BLOCK_ASM_Q32", 256), ("PPK_BLOCK_ASM_Q64", 512)):
-            lines = gen(stride)
-            f.write("#define %s \\\n" % name)
-            for ln in lines:
-                f.write('  "%s\\n" \\\n' % ln)
-            f.write("  \"\"\n")
-            print("wrote", name, len(lines), "instructions")
-        lines = gen(256, 4, dma_planes=[1, 4, 7, 10])
+        write_macro(f, "PPK_BLOCK_ASM_Q32", gen(256))
         f.write("// the same with the 4 LDS-DMA pieces of the next block issued inside the stream\n")
-        f.write("#define PPK_BLOCK_DMA_ASM_Q32 \\\n")
-        for ln in lines:
-            f.write('  "%s\\n" \\\n' % ln)
-        f.write("  \"\"\n")
-        print("wrote PPK_BLOCK_DMA_ASM_Q32", len(lines), "instructions")
-        lines = gen(256, 4, half=True)
+        write_macro(f, "PPK_BLOCK_DMA_ASM_Q32", gen(256, 4, dma_planes=[1, 4, 7, 10]))
         f.write("// refs 2/3 only (diagonal tiles with every query beyond the first 128 refs)\n")
-        f.write("#define PPK_BLOCK_HALF_ASM_Q32 \\\n")
-        for ln in lines:
-            f.write('  "%s\\n" \\\n' % ln)
-        f.write("  \"\"\n")
-        print("wrote PPK_BLOCK_HALF_ASM_Q32", len(lines), "instructions")
+        write_macro(f, "PPK_BLOCK_HALF_ASM_Q32", gen(256, 4, half=True))
         f.write("#define PPK_BLOCK_ASM PPK_BLOCK_ASM_Q32\n")
         f.write("#define PPK_BLOCK_CLOBBERS %s\n" % clob)
-        f.write("// 4x8 register tile (v%d..v%d): 16 counters, two 16-bit pair counts each\n" % (m8.A0, m8.END - 1))
+    with open(dst_x, "w") as f:
+        f.write("// GENERATED by tools/gen_block_asm.py -- do not edit.  Measured-and-rejected shapes, used by\n"
+                "// tools/ubench_pipe.hip only (not part of libppk_hip.so): _Q64 = 64 queries per workgroup tile\n"
+                "// (16 wavefronts), BLOCK8 = 4x8 register tile (v%d..v%d: 16 counters, two 16-bit counts each).\n"
+                % (m8.A0, m8.END - 1))
+        write_macro(f, "PPK_BLOCK_ASM_Q64", gen(512))
         for name, stride in (("PPK_BLOCK8_ASM_Q32", 256), ("PPK_BLOCK8_ASM_Q64", 512)):
-            lines = gen(stride, 8)
-            f.write("#define %s \\\n" % name)
-            for ln in lines:
-                f.write('  "%s\\n" \\\n' % ln)
-            f.write("  \"\"\n")
-            print("wrote", name, len(lines), "instructions")
+            write_macro(f, name, gen(stride, 8))
         f.write("#define PPK_BLOCK8_CLOBBERS %s\n" % clob8)
 
 

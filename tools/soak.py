@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402,F401
 
 from oracle import oracle  # noqa: E402
-from poppunk_amd import engine, pp_sketchlib, synth  # noqa: E402
+from poppunk_amd import _lib, engine, pp_sketchlib, synth  # noqa: E402
 
 
 def main():
@@ -38,9 +38,9 @@ def main():
         related = bool(rng.integers(0, 4))
         # half of the cases force the tile kernel's own epilogue (small jobs default to the k-split path)
         if rng.integers(0, 2):
-            os.environ["PPK_KSPLIT"] = "0"
+            _lib.set_option("ksplit", 0)
         else:
-            os.environ.pop("PPK_KSPLIT", None)
+            _lib.set_option("ksplit", 640)
         sk, member = synth.make_sketches(n, kmers, sketchsize64=s64, bbits=bbits,
                                          cluster_size=int(rng.integers(5, 80)), seed=int(rng.integers(1, 1 << 30)),
                                          related=related)

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <vector>
 #include "../poppunk_amd/csrc/ppk_block_asm.inc"
+#include "ppk_block_asm_experiments.inc"
 #include "../include/ppk.h"
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
