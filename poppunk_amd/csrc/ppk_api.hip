@@ -413,7 +413,8 @@ int stage_tables(const ppk_db *ref, const float *random_tbl, size_t n_clu, int f
                  double **d_lut, float **d_rtab) {
   const size_t nbins = ref->s64 * 64;
   const size_t C = n_clu ? n_clu : 1;
-  const size_t lut_bytes = C * C * ref->nk * (nbins + 1) * sizeof(double);
+  // log-J table + the (E, F) pairs of the fit's fast path behind it (ppk_dist.hip lut_kernel)
+  const size_t lut_bytes = 3 * C * C * ref->nk * (nbins + 1) * sizeof(double);
   const size_t tab_bytes = C * C * ref->nk * sizeof(float);
   void *base = nullptr;
   int rc = scratch_get(ref->device, SLOT_LUT, lut_bytes + tab_bytes + 256, &base);

@@ -122,7 +122,8 @@ struct DistParams {
   size_t strip_begin;     // first strip sample (= r_limit of the triangle part)
   size_t r_limit;         // triangle part: lane samples >= r_limit are left to the strip
   int xcd_map;            // 1: XCD-aware tile order (v2)
-  int lut32;              // the whole log-J table is addressable with 32-bit byte offsets
+  int lut32;              // the whole fit table is addressable with 32-bit byte offsets
+  size_t lut_total;       // doubles in the log-J table; the (E, F) table of the fast path follows it
   int k_split;            // host side only: launch the KSPLIT instantiation (gridDim.y = nk, one k per workgroup)
   size_t ks_rows;         // KSPLIT: rows of the band; its counts go to scratch k-major, [k][row]
   unsigned r_tiles, q_tiles;   // v2 tile grid
@@ -135,8 +136,15 @@ struct DistParams {
   int ext_skip;           // [EXT] a6: skip instead of truncate at J < 5/s (PpkConfig::ext_fit_skip)
 
   int kmers[PPK_MAX_NK];
-  // all-points-usable fast path of the regression: sums of k, 1/(n*sum k^2 - (sum k)^2), 1/n
-  double sx_all, inv_den_all, inv_n_all;
+};
+
+// With every k usable the least-squares fit is LINEAR in the log J_k with launch-constant weights:
+//   slope = sum_k a_k log J_k,   intercept = sum_k b_k log J_k,
+//   a_k = (nk x_k - sum x) / (nk sum x^2 - (sum x)^2),   b_k = (1 - a_k sum x) / nk,
+// so 1 - e^slope = 1 - prod_k J_k^a_k: the table holds E = J^a_k and F = J^b_k per (k, count) and the
+// fast path of the fit is nk look-ups and 2 (nk - 1) multiplications -- no sums, no exp.
+struct FitCoef {
+  double a[PPK_MAX_NK], b[PPK_MAX_NK];
 };
 
 // ---- small device helpers --------------------------------------------------
@@ -182,10 +190,13 @@ transpose_kernel(const uint64_t *__restrict__ in, uint64_t *__restrict__ out, si
 }
 
 // LUT[(cr*C + cq)][k][count] = log J, or +1.0 when J < 5/nbins (the point and
-// every later k are dropped from the fit; docs/sketching.rst:161-165).
+// every later k are dropped from the fit; docs/sketching.rst:161-165).  Behind it, per entry, the
+// pair (E, F) = (J^a_k, J^b_k) of the all-k-usable fast path (FitCoef), NaN where the log-J entry is
+// the +1.0 marker: a NaN product sends the pair to the general fit.
 __global__ void __launch_bounds__(256)
 lut_kernel(double *__restrict__ lut, const float *__restrict__ rtab, int nk, int n_clu,
-           size_t nbins, size_t s64, size_t bbits, int random_correct, int adjust, size_t total) {
+           size_t nbins, size_t s64, size_t bbits, int random_correct, int adjust, size_t total,
+           const FitCoef coef) {
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
   const size_t per = nbins + 1;
@@ -196,7 +207,12 @@ lut_kernel(double *__restrict__ lut, const float *__restrict__ rtab, int nk, int
   if (random_correct) jr = (double)rtab[(k * n_clu + cp / n_clu) * n_clu + cp % n_clu];
   const double j = observed_excess(jaccard_obs(c, s64, bbits, adjust), jr);
   const double tol = 5.0 / (double)nbins;
-  lut[idx] = (j < tol) ? 1.0 : log(j);
+  const bool usable = !(j < tol);
+  const double y = usable ? log(j) : 1.0;
+  lut[idx] = y;
+  double *ef = lut + total + 2 * idx;
+  ef[0] = usable ? exp(coef.a[k] * y) : __builtin_nan("");
+  ef[1] = usable ? exp(coef.b[k] * y) : __builtin_nan("");
 }
 
 // ---- the pair-tile kernel ----------------------------------------------------
@@ -244,14 +260,17 @@ __device__ __forceinline__ double exp_nonpos(double x) {
   return es[0];
 }
 
-// a6 for one pair: OLS of log J on k over the leading run of usable points, fp64.  Every caller
-// (the tile epilogues' fast paths included) evaluates the SAME expressions in the same order, so a
-// pair's result does not depend on which kernel, tile, band or wavefront computed it: sums in k
-// order with sxy as an fma; when every k is usable the k-only sums are the launch constants.
+// a6 for one pair, fp64.  Every caller evaluates the SAME expressions in the same order, so a
+// pair's result does not depend on which kernel, tile, band or wavefront computed it:
+//  * every k usable (the overwhelmingly common case): core = 1 - prod_k E_k, accessory =
+//    1 - prod_k F_k, products taken in k order from the (E, F) table (FitCoef) -- a NaN entry marks
+//    a k below the 5/nbins floor;
+//  * otherwise OLS of log J on k over the usable points (the leading run, or with ext_skip every
+//    usable k), sums in k order with sxy as an fma, then 1 - e^x with exp_nonpos.
 template <typename PackT, typename ParamsT>
-__device__ __forceinline__ void fit_packed(PackT pk, const double *__restrict__ lutp,
-                                           const ParamsT &p, float &core, float &acc,
-                                           bool &failed) {
+__device__ __forceinline__ void fit_general(const PackT &pk, const double *__restrict__ lutp,
+                                            const ParamsT &p, float &core, float &acc,
+                                            bool &failed) {
   const uint32_t cmask = (1u << p.cnt_bits) - 1u;
   double sx = 0.0, sxx = 0.0, sy = 0.0, sxy = 0.0;
   int n = 0;
@@ -275,132 +294,107 @@ __device__ __forceinline__ void fit_packed(PackT pk, const double *__restrict__ 
     failed = true;
     return;
   }
-  double slope, icpt;
-  if (n == p.nk) {
-    slope = ((double)p.nk * sxy - p.sx_all * sy) * p.inv_den_all;
-    icpt = (sy - slope * p.sx_all) * p.inv_n_all;
-  } else {
-    const double dn = (double)n;
-    slope = (dn * sxy - sx * sy) / (dn * sxx - sx * sx);
-    icpt = (sy - slope * sx) / dn;
-  }
+  const double dn = (double)n;
+  const double slope = (dn * sxy - sx * sy) / (dn * sxx - sx * sx);
+  const double icpt = (sy - slope * sx) / dn;
   core = slope < 0.0 ? (float)(1.0 - exp_nonpos(slope)) : 0.0f;
   acc = icpt < 0.0 ? (float)(1.0 - exp_nonpos(icpt)) : 0.0f;
   failed = false;
 }
 
-// a6 for NR of the refs a lane holds against one query (v2 epilogue).  All NR x nk table gathers
-// are issued before the first is consumed: the table look-ups are the only memory latency in the
-// epilogue.
-template <typename PackT, int NR, typename ParamsT>
-__device__ __forceinline__ void fit_rows(const PackT (&pk)[NR], const double *const (&lutp)[NR],
-                                         const ParamsT &p, float (&core)[NR], float (&acc)[NR],
-                                         bool (&failed)[NR]) {
-  constexpr int KU = 5;   // k per gather batch (the default k list has 5)
+// (1 - prod E, 1 - prod F) clamped at 0: the fast path's last step, shared by every caller
+__device__ __forceinline__ void fit_finish(double pe, double pf, float &core, float &acc) {
+  core = pe < 1.0 ? (float)(1.0 - pe) : 0.0f;
+  acc = pf < 1.0 ? (float)(1.0 - pf) : 0.0f;
+}
+
+// cp_off: offset (in entries) of the pair's cluster-pair block: its log J at lut[cp_off + ...], its
+// (E, F) pairs at lut[lut_total + 2 * (cp_off + ...)]
+template <typename PackT, typename ParamsT>
+__device__ __forceinline__ void fit_packed(const PackT &pk, const double *__restrict__ lut, size_t cp_off,
+                                           const ParamsT &p, float &core, float &acc, bool &failed) {
   const uint32_t cmask = (1u << p.cnt_bits) - 1u;
-  double sy[NR], sxy[NR];
+  const double *ef_base = lut + p.lut_total + 2 * cp_off;
+  double pe = 1.0, pf = 1.0;
+  for (int k = 0; k < p.nk; ++k) {
+    const uint32_t c = pack_get(pk, k, p.cnt_bits, cmask, p.nk);
+    const double *ef = ef_base + 2 * ((size_t)k * p.lut_kstride + c);
+    if (k == 0) {
+      pe = ef[0];
+      pf = ef[1];
+    } else {
+      pe *= ef[0];
+      pf *= ef[1];
+    }
+  }
+  if (pe == pe && p.nk >= 2) {      // not NaN: every k usable
+    fit_finish(pe, pf, core, acc);
+    failed = false;
+    return;
+  }
+  fit_general(pk, lut + cp_off, p, core, acc, failed);
+}
+
+// The fast path for NR of the refs a lane holds against one query (v2 epilogue): all NR x nk
+// 16-byte (E, F) gathers are issued before the first is consumed -- the table look-ups are the only
+// memory latency in the epilogue -- as uniform base + 32-bit lane offset (the saddr form of
+// global_load).  NK > 0: straight-line code for a compile-time number of k (the default k list has
+// 5); NK == 0: any nk.  Returns false -- nothing written -- when some lane of the wavefront has an
+// unusable k (a NaN product), and the caller takes fit_packed pair by pair.
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+template <typename PackT, int NR, int NK, typename ParamsT>
+__device__ __forceinline__ bool fit_rows_fast(const PackT (&pk)[NR], const double *__restrict__ lut,
+                                              const uint32_t (&loff)[NR], const ParamsT &p,
+                                              float (&core)[NR], float (&acc)[NR]) {
+  const uint32_t cmask = (1u << p.cnt_bits) - 1u;
+  const uint32_t kstride = (uint32_t)p.lut_kstride;
+  const char *base = reinterpret_cast<const char *>(lut + p.lut_total);
+  double pe[NR], pf[NR];
+  if constexpr (NK > 0) {
+    f64x2 ef[NR][NK];
 #pragma unroll
-  for (int r = 0; r < NR; ++r) sy[r] = sxy[r] = 0.0;
-  bool all_ok = p.nk >= 2;
-  for (int k0 = 0; k0 < p.nk; k0 += KU) {
-    double y[NR][KU];
-#pragma unroll
-    for (int i = 0; i < KU; ++i) {
-      const int k = (k0 + i < p.nk) ? k0 + i : p.nk - 1;   // wave-uniform; surplus slots re-read the last k
+    for (int k = 0; k < NK; ++k) {
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
         const uint32_t c = pack_get(pk[r], k, p.cnt_bits, cmask, p.nk);
-        y[r][i] = lutp[r][(size_t)k * p.lut_kstride + c];
+        const uint32_t boff = (loff[r] + (uint32_t)k * kstride + c) * 16u;
+        ef[r][k] = *reinterpret_cast<const f64x2 *>(base + boff);
       }
     }
 #pragma unroll
-    for (int i = 0; i < KU; ++i) {
-      const bool live = k0 + i < p.nk;
-      const double x = live ? (double)p.kmers[k0 + i < p.nk ? k0 + i : 0] : 0.0;
+    for (int r = 0; r < NR; ++r) {
+      pe[r] = ef[r][0].x;
+      pf[r] = ef[r][0].y;
+    }
+#pragma unroll
+    for (int k = 1; k < NK; ++k) {
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
-        const double yv = live ? y[r][i] : 0.0;
-        all_ok = all_ok && (yv <= 0.0);
-        sy[r] += yv;
-        sxy[r] = __builtin_fma(x, yv, sxy[r]);
+        pe[r] *= ef[r][k].x;
+        pf[r] *= ef[r][k].y;
+      }
+    }
+  } else {
+    for (int k = 0; k < p.nk; ++k) {
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const uint32_t c = pack_get(pk[r], k, p.cnt_bits, cmask, p.nk);
+        const uint32_t boff = (loff[r] + (uint32_t)k * kstride + c) * 16u;
+        const f64x2 v = *reinterpret_cast<const f64x2 *>(base + boff);
+        pe[r] = k == 0 ? v.x : pe[r] * v.x;
+        pf[r] = k == 0 ? v.y : pf[r] * v.y;
       }
     }
   }
-  if (__all(all_ok)) {
-    // every k usable in every lane of the wavefront (the overwhelmingly common case): the k-only
-    // sums are launch constants
+  bool all_ok = p.nk >= 2;
 #pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      const double slope = ((double)p.nk * sxy[r] - p.sx_all * sy[r]) * p.inv_den_all;
-      const double icpt = (sy[r] - slope * p.sx_all) * p.inv_n_all;
-      core[r] = slope < 0.0 ? (float)(1.0 - exp_nonpos(slope)) : 0.0f;
-      acc[r] = icpt < 0.0 ? (float)(1.0 - exp_nonpos(icpt)) : 0.0f;
-      failed[r] = false;
-    }
-    return;
-  }
-  // some lane has a k below the 5/nbins floor: the general fit, one pair at a time (unrolled: a
-  // rolled loop would index the operand arrays dynamically and push them into scratch)
-#pragma unroll
-  for (int r = 0; r < NR; ++r) fit_packed(pk[r], lutp[r], p, core[r], acc[r], failed[r]);
-}
-
-
-// The same fit for a compile-time number of k (the default k list has 5): straight-line code,
-// counts unpacked with uniform shifts, table look-ups as uniform base + 32-bit lane offset
-// (the saddr form of global_load).  Returns false -- nothing written -- when some lane of the
-// wavefront has an unusable k, and the caller takes the general path.
-template <typename PackT, int NR, int NK, typename ParamsT>
-__device__ __forceinline__ bool fit_rows_fixed(const PackT (&pk)[NR], const double *__restrict__ lut,
-                                               const uint32_t (&loff)[NR], const ParamsT &p,
-                                               float (&core)[NR], float (&acc)[NR]) {
-  const uint32_t cmask = (1u << p.cnt_bits) - 1u;
-  const uint32_t kstride = (uint32_t)p.lut_kstride;
-  const char *base = reinterpret_cast<const char *>(lut);
-  double y[NR][NK];
-#pragma unroll
-  for (int k = 0; k < NK; ++k) {
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      const uint32_t c = pack_get(pk[r], k, p.cnt_bits, cmask, p.nk);
-      const uint32_t boff = (loff[r] + (uint32_t)k * kstride + c) * 8u;
-      y[r][k] = *reinterpret_cast<const double *>(base + boff);
-    }
-  }
-  double sy[NR], sxy[NR];
-  bool all_ok = true;
-#pragma unroll
-  for (int r = 0; r < NR; ++r) sy[r] = sxy[r] = 0.0;
-#pragma unroll
-  for (int k = 0; k < NK; ++k) {
-    const double x = (double)p.kmers[k];
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      all_ok = all_ok && (y[r][k] <= 0.0);
-      sy[r] += y[r][k];
-      sxy[r] = __builtin_fma(x, y[r][k], sxy[r]);
-    }
-  }
+  for (int r = 0; r < NR; ++r) all_ok = all_ok && (pe[r] == pe[r]);
   if (!__all(all_ok)) return false;
-  double x[2 * NR], e[2 * NR];
 #pragma unroll
-  for (int r = 0; r < NR; ++r) {
-    x[2 * r] = ((double)NK * sxy[r] - p.sx_all * sy[r]) * p.inv_den_all;      // slope
-    x[2 * r + 1] = (sy[r] - x[2 * r] * p.sx_all) * p.inv_n_all;               // intercept
-  }
-  exp_nonpos_n<2 * NR>(x, e);     // (for x > 0 the value is unused: the distance is clamped to 0)
-#pragma unroll
-  for (int r = 0; r < NR; ++r) {
-    core[r] = x[2 * r] < 0.0 ? (float)(1.0 - e[2 * r]) : 0.0f;
-    acc[r] = x[2 * r + 1] < 0.0 ? (float)(1.0 - e[2 * r + 1]) : 0.0f;
-  }
+  for (int r = 0; r < NR; ++r) fit_finish(pe[r], pf[r], core[r], acc[r]);
   return true;
 }
 
-// Generic bit-plane count (bbits != 14: sketches made with a non-default --bbits): 64 refs per
-// wavefront staged through LDS one 64-bin block at a time, TQ query samples per wavefront as
-// wave-uniform (SGPR) operands.  Not tuned -- every PopPUNK database in the wild has bbits = 14 and
-// takes dist_kernel_v2.
 template <int TQ, int NW, int MODE, typename PackT>
 __global__ void __launch_bounds__(NW * 64)
 dist_kernel(const uint64_t *__restrict__ refT, const uint32_t *__restrict__ qryT,
@@ -508,10 +502,10 @@ dist_kernel(const uint64_t *__restrict__ refT, const uint32_t *__restrict__ qryT
       if (q < p.q_begin || q >= p.q_end) continue;
       const bool valid = r < p.n_ref && (!p.self || r > q);
       const int cq = qry_clu ? qry_clu[q] : 0;
-      const double *lutp = lut + (size_t)(cr * p.n_clu + cq) * p.lut_cpstride;
+      const size_t cp_off = (size_t)(cr * p.n_clu + cq) * p.lut_cpstride;
       float core = 0.0f, acc = 0.0f;
       bool failed = false;
-      if (valid) fit_packed<PackT>(packed[j], lutp, p, core, acc, failed);
+      if (valid) fit_packed<PackT>(packed[j], lut, cp_off, p, core, acc, failed);
       if (n_failed) {
         const uint64_t fm = __ballot(valid && failed);
         if (fm && lane == 0) atomicAdd(n_failed, (unsigned long long)__popcll(fm));
@@ -931,7 +925,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
           core[0] = core[1] = acc[0] = acc[1] = 0.0f;
           continue;
         }
-        const double *lutp[2];
+        size_t cpo[2];
         uint32_t loff[2];
         PackT pk[2];
         float c2[2], a2[2];
@@ -945,13 +939,19 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
           // table index = (cluster of the ref = larger sample, cluster of the query = smaller sample);
           // in a strip launch the lane holds the smaller sample
           const size_t cp = (size_t)(strip ? cq * p.n_clu + cr[r] : cr[r] * p.n_clu + cq) * p.lut_cpstride;
-          lutp[j] = lut + cp;
+          cpo[j] = cp;
           loff[j] = (uint32_t)cp;
 #pragma unroll
           for (int i = 0; i < W; ++i) pk[j].w[i] = pw[i][r][q];
         }
-        if (!(p.nk == 5 && p.lut32 && fit_rows_fixed<PackT, 2, 5>(pk, lut, loff, p, c2, a2)))
-          fit_rows<PackT, 2>(pk, lutp, p, c2, a2, f2);
+        // the fast path (every k usable in every lane), else pair by pair (unrolled: a rolled loop
+        // would index the operand arrays dynamically and push them into scratch)
+        const bool fast = p.lut32 && (p.nk == 5 ? fit_rows_fast<PackT, 2, 5>(pk, lut, loff, p, c2, a2)
+                                                : fit_rows_fast<PackT, 2, 0>(pk, lut, loff, p, c2, a2));
+        if (!fast) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) fit_packed(pk[j], lut, cpo[j], p, c2[j], a2[j], f2[j]);
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           core[2 * h + j] = c2[j];
@@ -1131,7 +1131,7 @@ regress_packed_kernel(const uint32_t *__restrict__ counts, size_t n_rows, const 
     u128 pk = 0;
     for (int k = 0; k < p.nk; ++k) pk |= (u128)counts[(size_t)k * n_rows + i] << (p.cnt_bits * k);   // [k][row]
     float core, acc;
-    fit_packed<u128>(pk, lut + cp * p.lut_cpstride, p, core, acc, failed);
+    fit_packed<u128>(pk, lut, cp * p.lut_cpstride, p, core, acc, failed);
     out[i] = make_float2(core, acc);
   }
   if (n_failed) {
@@ -1320,17 +1320,21 @@ int ppk_launch_dist(const ppk_db *ref, const ppk_db *qry_or_null, const int32_t 
   while (((size_t)1 << bits) <= nbins) ++bits;
   p.cnt_bits = bits;
   for (int k = 0; k < p.nk && k < PPK_MAX_NK; ++k) p.kmers[k] = kmers[k];
+  FitCoef coef = {};
   {
     double sx = 0.0, sxx = 0.0;
     for (int k = 0; k < p.nk && k < PPK_MAX_NK; ++k) {
       sx += (double)kmers[k];
       sxx += (double)kmers[k] * (double)kmers[k];
     }
-    p.sx_all = sx;
-    p.inv_den_all = 1.0 / ((double)p.nk * sxx - sx * sx);
-    p.inv_n_all = 1.0 / (double)p.nk;
+    const double dn = (double)p.nk, den = dn * sxx - sx * sx;
+    for (int k = 0; k < p.nk && k < PPK_MAX_NK; ++k) {
+      coef.a[k] = den != 0.0 ? (dn * (double)kmers[k] - sx) / den : 0.0;
+      coef.b[k] = (1.0 - coef.a[k] * sx) / dn;
+    }
   }
-  p.lut32 = ((size_t)p.n_clu * p.n_clu * p.lut_cpstride * 8 < ((size_t)1 << 32)) ? 1 : 0;
+  p.lut_total = (size_t)p.n_clu * p.n_clu * p.lut_cpstride;
+  p.lut32 = (p.lut_total * 16 < ((size_t)1 << 32)) ? 1 : 0;
   p.ablate = (int)ppk_config().ablate.load();
   p.ext_adjust = ppk_config().ext_collision_adjust.load() ? 1 : 0;
   p.ext_skip = ppk_config().ext_fit_skip.load() ? 1 : 0;
@@ -1381,7 +1385,8 @@ int ppk_launch_dist(const ppk_db *ref, const ppk_db *qry_or_null, const int32_t 
   {
     const size_t total = (size_t)p.n_clu * p.n_clu * p.lut_cpstride;
     hipLaunchKernelGGL(lut_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_lut,
-                       d_rtab, p.nk, p.n_clu, nbins, ref->s64, ref->bbits, p.random_correct, p.ext_adjust, total);
+                       d_rtab, p.nk, p.n_clu, nbins, ref->s64, ref->bbits, p.random_correct, p.ext_adjust, total,
+                       coef);
     PPK_HIP(hipGetLastError());
   }
   if (small) {

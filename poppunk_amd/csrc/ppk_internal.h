@@ -2,6 +2,8 @@
 // gfx950 / CDNA4 only (wave64); no other target is supported.
 #pragma once
 
+#include <sys/mman.h>
+
 #include <atomic>
 #include <cstdlib>
 #include <thread>
@@ -179,6 +181,14 @@ class HostToucher {
     if (nt > 64) nt = 64;
     if (!out || total_bytes < ((size_t)8 << 20) || nt < 0) nt = 0;
     nt_ = nt;
+    if (nt > 0) {
+      // transparent huge pages for the (whole 2 MB blocks of the) result: a first touch then maps
+      // 2 MB at a time -- measured on the MI355X host: 400 MB touched by 8 threads in 2.5 ms against
+      // 35 ms with 4 KB pages (tools/ubench_host_out.hip).  numpy asks for the same on its own large
+      // allocations; other callers' arrays get it here.  Advice only: failure is harmless.
+      const size_t a0 = ((size_t)out + kBlock - 1) / kBlock * kBlock, a1 = ((size_t)out + total_bytes) / kBlock * kBlock;
+      if (a1 > a0) (void)madvise(reinterpret_cast<void *>(a0), a1 - a0, MADV_HUGEPAGE);
+    }
     n_blocks_ = (total_bytes + kBlock - 1) / kBlock;
     done_ = std::vector<std::atomic<size_t>>((size_t)(nt > 0 ? nt : 1));
     for (auto &a : done_) a.store(0);

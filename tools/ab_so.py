@@ -1,0 +1,61 @@
+"""Same-box A/B of two builds of libppk_hip.so: the kernel-1 time of the 10k self job (and a
+10 240^2 ref x query job), alternating A, B, A, B ... in separate processes so that clock / thermal
+drift and box-to-box differences cancel.
+
+    python tools/ab_so.py tools/prev/libppk_hip_base.so poppunk_amd/csrc/libppk_hip.so [rounds]
+"""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r'''
+import os, sys, time
+import numpy as np
+sys.path.insert(0, %r)
+from poppunk_amd import _lib
+_lib.SO_PATH = os.path.abspath(sys.argv[1])
+import torch
+from poppunk_amd import engine, synth
+K = np.asarray(synth.DEFAULT_KMERS, dtype=np.int32); T = synth.random_match_table(K)
+n = int(os.environ.get("N", "10000"))
+sk, _ = synth.make_sketches(max(n, 10240), K)
+out = {}
+for name, (nr, nq) in (("self%%d" %% n, (n, 0)), ("rq10240", (10240, 10240))):
+    ref = engine.SketchDB(sk[:nr], 16, 14)
+    qry = engine.SketchDB(sk[:nq], 16, 14) if nq else None
+    buf = None
+    for _ in range(40):
+        buf, _f = engine.dist(ref, qry, K, T, out=buf)
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 60
+    ev0.record()
+    for _ in range(reps):
+        engine.dist(ref, qry, K, T, out=buf)
+    ev1.record(); torch.cuda.synchronize()
+    out[name] = ev0.elapsed_time(ev1) / reps
+    del buf
+print(" ".join("%%s %%.4f" %% kv for kv in out.items()))
+''' % ROOT
+
+def main():
+    a, b = sys.argv[1], sys.argv[2]
+    rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    res = {a: [], b: []}
+    for r in range(rounds):
+        for so in (a, b):
+            o = subprocess.run([sys.executable, "-c", CHILD, so], capture_output=True, text=True)
+            if o.returncode:
+                print(o.stderr[-2000:]); sys.exit(1)
+            line = o.stdout.strip().split("\n")[-1]
+            res[so].append(line)
+            print("%-44s %s" % (so, line), flush=True)
+    import re
+    for so in (a, b):
+        vals = {}
+        for line in res[so]:
+            t = line.split()
+            for i in range(0, len(t), 2):
+                vals.setdefault(t[i], []).append(float(t[i + 1]))
+        print(so, {k: round(sum(v) / len(v), 4) for k, v in vals.items()})
+
+main()
