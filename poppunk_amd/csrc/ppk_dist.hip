@@ -342,48 +342,67 @@ __device__ __forceinline__ void fit_packed(const PackT &pk, const double *__rest
 // 5); NK == 0: any nk.  Returns false -- nothing written -- when some lane of the wavefront has an
 // unusable k (a NaN product), and the caller takes fit_packed pair by pair.
 typedef double f64x2 __attribute__((ext_vector_type(2)));
+// issue the NR x NK gathers of one batch
 template <typename PackT, int NR, int NK, typename ParamsT>
-__device__ __forceinline__ bool fit_rows_fast(const PackT (&pk)[NR], const double *__restrict__ lut,
-                                              const uint32_t (&loff)[NR], const ParamsT &p,
-                                              float (&core)[NR], float (&acc)[NR]) {
+__device__ __forceinline__ void ef_gather(const PackT (&pk)[NR], const double *__restrict__ lut,
+                                          const uint32_t (&loff)[NR], const ParamsT &p,
+                                          f64x2 (&ef)[NR][NK]) {
+  const uint32_t cmask = (1u << p.cnt_bits) - 1u;
+  const uint32_t kstride = (uint32_t)p.lut_kstride;
+  const char *base = reinterpret_cast<const char *>(lut + p.lut_total);
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const uint32_t c = pack_get(pk[r], k, p.cnt_bits, cmask, p.nk);
+      const uint32_t boff = (loff[r] + (uint32_t)k * kstride + c) * 16u;
+      ef[r][k] = *reinterpret_cast<const f64x2 *>(base + boff);
+    }
+  }
+}
+// products in k order; false (nothing written) when some lane of the wavefront has a NaN product
+template <int NR, int NK>
+__device__ __forceinline__ bool ef_finish(const f64x2 (&ef)[NR][NK], float (&core)[NR], float (&acc)[NR]) {
+  double pe[NR], pf[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    pe[r] = ef[r][0].x;
+    pf[r] = ef[r][0].y;
+  }
+#pragma unroll
+  for (int k = 1; k < NK; ++k) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      pe[r] *= ef[r][k].x;
+      pf[r] *= ef[r][k].y;
+    }
+  }
+  bool all_ok = true;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) all_ok = all_ok && (pe[r] == pe[r]);
+  if (!__all(all_ok)) return false;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) fit_finish(pe[r], pf[r], core[r], acc[r]);
+  return true;
+}
+
+// any nk: running products (no gather batch to keep in registers)
+template <typename PackT, int NR, typename ParamsT>
+__device__ __forceinline__ bool fit_rows_fast_anyk(const PackT (&pk)[NR], const double *__restrict__ lut,
+                                                   const uint32_t (&loff)[NR], const ParamsT &p,
+                                                   float (&core)[NR], float (&acc)[NR]) {
   const uint32_t cmask = (1u << p.cnt_bits) - 1u;
   const uint32_t kstride = (uint32_t)p.lut_kstride;
   const char *base = reinterpret_cast<const char *>(lut + p.lut_total);
   double pe[NR], pf[NR];
-  if constexpr (NK > 0) {
-    f64x2 ef[NR][NK];
-#pragma unroll
-    for (int k = 0; k < NK; ++k) {
-#pragma unroll
-      for (int r = 0; r < NR; ++r) {
-        const uint32_t c = pack_get(pk[r], k, p.cnt_bits, cmask, p.nk);
-        const uint32_t boff = (loff[r] + (uint32_t)k * kstride + c) * 16u;
-        ef[r][k] = *reinterpret_cast<const f64x2 *>(base + boff);
-      }
-    }
+  for (int k = 0; k < p.nk; ++k) {
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
-      pe[r] = ef[r][0].x;
-      pf[r] = ef[r][0].y;
-    }
-#pragma unroll
-    for (int k = 1; k < NK; ++k) {
-#pragma unroll
-      for (int r = 0; r < NR; ++r) {
-        pe[r] *= ef[r][k].x;
-        pf[r] *= ef[r][k].y;
-      }
-    }
-  } else {
-    for (int k = 0; k < p.nk; ++k) {
-#pragma unroll
-      for (int r = 0; r < NR; ++r) {
-        const uint32_t c = pack_get(pk[r], k, p.cnt_bits, cmask, p.nk);
-        const uint32_t boff = (loff[r] + (uint32_t)k * kstride + c) * 16u;
-        const f64x2 v = *reinterpret_cast<const f64x2 *>(base + boff);
-        pe[r] = k == 0 ? v.x : pe[r] * v.x;
-        pf[r] = k == 0 ? v.y : pf[r] * v.y;
-      }
+      const uint32_t c = pack_get(pk[r], k, p.cnt_bits, cmask, p.nk);
+      const uint32_t boff = (loff[r] + (uint32_t)k * kstride + c) * 16u;
+      const f64x2 v = *reinterpret_cast<const f64x2 *>(base + boff);
+      pe[r] = k == 0 ? v.x : pe[r] * v.x;
+      pf[r] = k == 0 ? v.y : pf[r] * v.y;
     }
   }
   bool all_ok = p.nk >= 2;
@@ -907,58 +926,94 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
 #pragma unroll
     for (int r = 0; r < R; ++r) cr[r] = (ref_clu && ref_of(r) < p.n_ref) ? ref_clu[ref_of(r)] : 0;
     unsigned n_fail_wave = 0;   // failed fits of this wavefront: ONE atomic at the end
+    // A batch = the lane's refs 2h, 2h+1 against query q (2 x nk gathers).  With the default k list
+    // the gathers of batch b+1 are issued BEFORE batch b is consumed (two register sets, alternating):
+    // the table look-ups are the only memory latency in the epilogue, and there are 8 batches of it.
+    constexpr bool PIPE = MODE == MODE_DIST && W == 2;
+    // (the plain distance kernel with the two-dword count register only: the other instantiations have
+    // no registers to spare for the second set, and spill)
+    const bool pipelined = PIPE && p.lut32 && p.nk == 5;      // wave-uniform
+    constexpr int NRB = PIPE ? 1 : 2;      // refs per batch (pipelined: one, 5 gathers = 20 VGPRs per register set)
+    constexpr int NB = R * TQ / NRB;       // batches, query-major: b = q * (R / NRB) + r / NRB
+    f64x2 ef[2][NRB][5];
+    auto batch_operands = [&](int bq, int br0, size_t (&cpo)[NRB], uint32_t (&loff)[NRB], PackT (&pk)[NRB]) {
+      const size_t qq = qw0 + bq;
+      const int cq = (qry_clu && qq >= qb && qq < qe) ? qry_clu[qq] : 0;
 #pragma unroll
-    for (int q = 0; q < TQ; ++q) {
+      for (int j = 0; j < NRB; ++j) {
+        const int r = br0 + j;
+        // table index = (cluster of the ref = larger sample, cluster of the query = smaller sample);
+        // in a strip launch the lane holds the smaller sample
+        const size_t cp = (size_t)(strip ? cq * p.n_clu + cr[r] : cr[r] * p.n_clu + cq) * p.lut_cpstride;
+        cpo[j] = cp;
+        loff[j] = (uint32_t)cp;
+#pragma unroll
+        for (int i = 0; i < W; ++i) pk[j].w[i] = pw[i][r][bq];
+      }
+    };
+    if (pipelined) {
+      size_t cpo[NRB];
+      uint32_t loff[NRB];
+      PackT pk[NRB];
+      batch_operands(0, 0, cpo, loff, pk);
+      ef_gather<PackT, NRB, 5>(pk, lut, loff, p, ef[0]);
+    }
+    uint64_t ball[R];
+    bool valid[R], failed[R];
+    float core[R], acc[R];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int q = b / (R / NRB), r0b = (b % (R / NRB)) * NRB;
       const size_t qq = qw0 + q;   // wave-uniform
-      if (qq < qb || qq >= qe) continue;
-      const int cq = qry_clu ? qry_clu[qq] : 0;
+      const bool in_band = qq >= qb && qq < qe;
       const size_t rowq = (p.self ? qq * p.n_ref - (qq * (qq + 1)) / 2 - qq - 1 : qq * p.n_ref) - p.row_base;
-      uint64_t ball[R];
-      bool valid[R], failed[R];
-      float core[R], acc[R];
+      if (pipelined && b + 1 < NB) {
+        size_t cpo_n[NRB];
+        uint32_t loff_n[NRB];
+        PackT pk_n[NRB];
+        batch_operands((b + 1) / (R / NRB), ((b + 1) % (R / NRB)) * NRB, cpo_n, loff_n, pk_n);
+        ef_gather<PackT, NRB, 5>(pk_n, lut, loff_n, p, ef[(b + 1) & 1]);
+        asm volatile("" ::: "memory");    // the gathers of b+1 stay ahead of everything batch b does
+      }
       // the fit runs for every lane (counts of padding samples index the table like any other);
-      // `valid` only gates what is written.  Two refs (2 x nk gathers in flight) at a time.
+      // `valid` only gates what is written
+      if (!in_band || (half && r0b < 2)) {   // refs 0/1 of a half tile were not compared: nothing to fit
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        if (half && h == 0) {        // refs 0/1 were not compared: nothing valid, nothing to fit
-          valid[0] = valid[1] = failed[0] = failed[1] = false;
-          core[0] = core[1] = acc[0] = acc[1] = 0.0f;
-          continue;
+        for (int j = 0; j < NRB; ++j) {
+          valid[r0b + j] = failed[r0b + j] = false;
+          core[r0b + j] = acc[r0b + j] = 0.0f;
         }
-        size_t cpo[2];
-        uint32_t loff[2];
-        PackT pk[2];
-        float c2[2], a2[2];
-        bool f2[2] = {false, false};
+      } else {
+        size_t cpo[NRB];
+        uint32_t loff[NRB];
+        PackT pk[NRB];
+        float c2[NRB], a2[NRB];
+        bool f2[NRB];
+        batch_operands(q, r0b, cpo, loff, pk);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int r = 2 * h + j;
+        for (int j = 0; j < NRB; ++j) {
+          const int r = r0b + j;
           const size_t rf = ref_of(r);
+          f2[j] = false;
           valid[r] = rf < p.r_limit && (!p.self || rf > qq);
           if (strip) valid[r] = rf < qq && rf >= p.q_begin && rf < p.q_end;   // band filter on the lane sample
-          // table index = (cluster of the ref = larger sample, cluster of the query = smaller sample);
-          // in a strip launch the lane holds the smaller sample
-          const size_t cp = (size_t)(strip ? cq * p.n_clu + cr[r] : cr[r] * p.n_clu + cq) * p.lut_cpstride;
-          cpo[j] = cp;
-          loff[j] = (uint32_t)cp;
-#pragma unroll
-          for (int i = 0; i < W; ++i) pk[j].w[i] = pw[i][r][q];
         }
         // the fast path (every k usable in every lane), else pair by pair (unrolled: a rolled loop
         // would index the operand arrays dynamically and push them into scratch)
-        const bool fast = p.lut32 && (p.nk == 5 ? fit_rows_fast<PackT, 2, 5>(pk, lut, loff, p, c2, a2)
-                                                : fit_rows_fast<PackT, 2, 0>(pk, lut, loff, p, c2, a2));
+        const bool fast = pipelined ? ef_finish<NRB, 5>(ef[b & 1], c2, a2)
+                                    : (p.lut32 && fit_rows_fast_anyk<PackT, NRB>(pk, lut, loff, p, c2, a2));
         if (!fast) {
 #pragma unroll
-          for (int j = 0; j < 2; ++j) fit_packed(pk[j], lut, cpo[j], p, c2[j], a2[j], f2[j]);
+          for (int j = 0; j < NRB; ++j) fit_packed(pk[j], lut, cpo[j], p, c2[j], a2[j], f2[j]);
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          core[2 * h + j] = c2[j];
-          acc[2 * h + j] = a2[j];
-          failed[2 * h + j] = f2[j];
+        for (int j = 0; j < NRB; ++j) {
+          core[r0b + j] = c2[j];
+          acc[r0b + j] = a2[j];
+          failed[r0b + j] = f2[j];
         }
       }
+      if (r0b + NRB < R || !in_band) continue;     // the query's last batch: write its rows
 #pragma unroll
       for (int r = 0; r < R; ++r) n_fail_wave += (unsigned)__popcll(__ballot(valid[r] && failed[r]));
       if constexpr (MODE == MODE_DIST) {

@@ -2,7 +2,7 @@
 10 240^2 ref x query job), alternating A, B, A, B ... in separate processes so that clock / thermal
 drift and box-to-box differences cancel.
 
-    python tools/ab_so.py tools/prev/libppk_hip_base.so poppunk_amd/csrc/libppk_hip.so [rounds]
+    python tools/ab_so.py A.so B.so [C.so ...] [rounds]
 """
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -38,24 +38,23 @@ print(" ".join("%%s %%.4f" %% kv for kv in out.items()))
 ''' % ROOT
 
 def main():
-    a, b = sys.argv[1], sys.argv[2]
-    rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-    res = {a: [], b: []}
+    sos = [x for x in sys.argv[1:] if not x.isdigit()]
+    rounds = int(sys.argv[-1]) if sys.argv[-1].isdigit() else 3
+    res = {so: [] for so in sos}
     for r in range(rounds):
-        for so in (a, b):
+        for so in sos:
             o = subprocess.run([sys.executable, "-c", CHILD, so], capture_output=True, text=True)
             if o.returncode:
                 print(o.stderr[-2000:]); sys.exit(1)
             line = o.stdout.strip().split("\n")[-1]
             res[so].append(line)
             print("%-44s %s" % (so, line), flush=True)
-    import re
-    for so in (a, b):
+    for so in sos:
         vals = {}
         for line in res[so]:
             t = line.split()
             for i in range(0, len(t), 2):
                 vals.setdefault(t[i], []).append(float(t[i + 1]))
-        print(so, {k: round(sum(v) / len(v), 4) for k, v in vals.items()})
+        print("%-44s" % so, {k: round(sum(v) / len(v), 4) for k, v in vals.items()})
 
 main()

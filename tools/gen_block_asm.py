@@ -198,7 +198,9 @@ def main():
                 % (m4.A0, m4.END - 1))
         write_macro(f, "PPK_BLOCK_ASM_Q32", gen(256))
         f.write("// the same with the 4 LDS-DMA pieces of the next block issued inside the stream\n")
-        write_macro(f, "PPK_BLOCK_DMA_ASM_Q32", gen(256, 4, dma_planes=[1, 4, 7, 10]))
+        # (GEN_DMA_PLANES=a,b,c,d: experiments with the placement of the four pieces)
+        planes = [int(x) for x in os.environ.get("GEN_DMA_PLANES", "1,4,7,10").split(",")]
+        write_macro(f, "PPK_BLOCK_DMA_ASM_Q32", gen(256, 4, dma_planes=planes))
         f.write("// refs 2/3 only (diagonal tiles with every query beyond the first 128 refs)\n")
         write_macro(f, "PPK_BLOCK_HALF_ASM_Q32", gen(256, 4, half=True))
         f.write("#define PPK_BLOCK_ASM PPK_BLOCK_ASM_Q32\n")
