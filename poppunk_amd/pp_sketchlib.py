@@ -14,6 +14,18 @@ reference returns.  The computation always runs on the MI355X: `use_gpu` and
 `num_threads` are accepted for signature compatibility only (there is no CPU
 path in this package), `device_id` selects the GPU.  The environment variable
 PPK_DEVICES="0,1,..." band-splits one call over several GPUs of the node.
+
+Random-match correction.  PopPUNK only ever queries databases that carry random match chances
+(it adds them at construction and refuses a database without them, PopPUNK/sketchlib.py:455-466),
+and it always asks for `random_correct=True` distances (:533,:589).  So a `random_correct=True`
+call on a database whose table is missing -- or present in a /random layout this package does not
+recognise -- RAISES: silently uncorrected distances differ from the reference's by a few percent of
+J at k = 13.  Opting out is explicit: `random_correct=False`, or the environment variable
+PPK_ALLOW_NO_RANDOM=1 (distances are then computed without the correction, with a note on stderr).
+
+Loaded databases are kept (a few, keyed by file, modification time, names and k list), so repeated
+queries against one database -- poppunk_assign, every --plot-fit re-query -- neither re-read the file
+nor re-upload the sketches (ppk_query finds the same host array resident).
 """
 import ctypes as C
 import os
@@ -23,7 +35,39 @@ import numpy as np
 
 from . import _lib, sketchdb
 
-version = "2.1.4+poppunk_amd.0.1.0"   # >= the minimum PopPUNK asks for (PopPUNK/__init__.py:9-11)
+# PopPUNK parses this as dotted integers (checkSketchlibVersion, PopPUNK/sketchlib.py:49-50) and wants
+# >= 2.0.1 (PopPUNK/__init__.py:9-11): plain numbers only.  The build of this package is `amd_build`.
+version = "2.1.4"
+amd_build = "poppunk_amd 0.2.0 (gfx950)"
+
+_DB_CACHE = {}          # key -> LoadedSketches (host arrays: stable pointers for ppk_query's cache)
+_DB_CACHE_MAX = 4
+
+
+def _load_cached(db_name, names, klist):
+    path = db_name + (".npz" if os.path.exists(db_name + ".npz") else ".h5")
+    try:
+        st = os.stat(path)
+        stamp = (st.st_mtime_ns, st.st_size)
+    except OSError:
+        stamp = None
+    key = (os.path.abspath(path), stamp, tuple(names), tuple(klist))
+    hit = _DB_CACHE.get(key)
+    if hit is not None:
+        _DB_CACHE[key] = _DB_CACHE.pop(key)          # most recently used last
+        return hit
+    loaded = sketchdb.load(db_name, names, klist)
+    if stamp is not None:
+        _DB_CACHE[key] = loaded
+        while len(_DB_CACHE) > _DB_CACHE_MAX:
+            _DB_CACHE.pop(next(iter(_DB_CACHE)))
+    return loaded
+
+
+def clear_cache():
+    """Forget the loaded databases (and free their resident copies and the result buffers)."""
+    _DB_CACHE.clear()
+    _lib.lib().ppk_release_scratch()
 
 
 def _devices(device_id):
@@ -96,22 +140,39 @@ def queryDatabase(ref_db_name, query_db_name, rList, qList, klist, random_correc
     rList = [str(x) for x in rList]
     qList = [str(x) for x in qList]
     self_query = (ref_db_name == query_db_name) and (rList == qList)
-    ref = sketchdb.load(ref_db_name, rList, klist)
+    ref = _load_cached(ref_db_name, rList, klist)
     if self_query:
+        qry = None
         qry_sk = None
         qry_clu = None
     else:
-        qry = sketchdb.load(query_db_name, qList, klist)
+        qry = _load_cached(query_db_name, qList, klist)
         if qry.sketchsize64 != ref.sketchsize64 or qry.bbits != ref.bbits:
             raise RuntimeError("query and reference sketches have different sketch sizes")
         qry_sk = qry.sketches
         qry_clu = qry.clusters
     table = ref.random_table
     if random_correct and table is None:
-        # the reference refuses a DB without random matches at construction time
-        # (PopPUNK/sketchlib.py:461-466); distances without correction are still defined
-        sys.stderr.write("poppunk_amd: no random-match table in %s; random_correct ignored\n"
-                         % ref_db_name)
+        if ref.random_status == "unrecognised":
+            why = ("the /random group of %s is not in the layout this package knows (datasets: %s)"
+                   % (ref_db_name, ", ".join(sorted(ref.random_raw or {}))))
+        else:
+            why = "%s has no random match chances (run addRandom / poppunk --create-db on it)" % ref_db_name
+        if os.environ.get("PPK_ALLOW_NO_RANDOM", "") not in ("", "0"):
+            sys.stderr.write("poppunk_amd: %s; PPK_ALLOW_NO_RANDOM is set: distances WITHOUT random-match "
+                             "correction\n" % why)
+        else:
+            raise RuntimeError("random_correct=True but " + why + ".  Distances without the correction differ "
+                               "from PopPUNK's; pass random_correct=False or set PPK_ALLOW_NO_RANDOM=1 to "
+                               "compute them anyway")
+    if table is not None and table.shape[1] > 1 and qry is not None:
+        # queries take their cluster from the REFERENCE database's table [EXT closest_cluster]
+        if qry.random_raw is not ref.random_raw and ref.random_raw is not None:
+            mapped = sketchdb.random_from_raw(ref.random_raw, qList, klist, qry.base_freq)
+            if mapped is not None:
+                qry_clu = mapped[1]
+        if qry_clu is None:
+            qry_clu = np.zeros(len(qList), dtype=np.uint16)
     out, n_failed = query_arrays(ref.sketches, qry_sk, klist, ref.sketchsize64, ref.bbits, table,
                                  ref.clusters, qry_clu, random_correct=random_correct,
                                  jaccard=jaccard, devices=_devices(device_id))

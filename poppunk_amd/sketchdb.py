@@ -2,23 +2,31 @@
 
 The reference stores sketches in `<prefix>/<basename>.h5` with one uint64 dataset
 per (sample, k) under /sketches/<name>/<k> and the attributes `sketchsize64`,
-`bbits`, `kmers` ... on the sample group (PopPUNK/web.py:14-61; readers
-PopPUNK/sketchlib.py:109-195).  Sketching itself (pp_sketchlib.constructDatabase)
-is out of scope, and h5py is not part of this image, so the primary on-disk form
-here is a flat `<prefix>/<basename>.npz` with the same content:
+`bbits`, `kmers`, `length`, `missing_bases`, `base_freq` on the sample group,
+`sketch_version`, `codon_phased` on /sketches (PopPUNK/web.py:14-61; readers
+PopPUNK/sketchlib.py:109-214), plus the /random group that pp_sketchlib.addRandom
+leaves there (PopPUNK/sketchlib.py:437-473; its presence is what PopPUNK checks,
+:455-466).  Sketching itself (pp_sketchlib.constructDatabase) is out of scope.
 
-    names         str   [n]
-    kmers         int32 [nk]
-    sketches      uint64 [n, nk, sketchsize64*bbits]
-    sketchsize64, bbits  int
-    random_table  float32 [nk, n_clu, n_clu]   (optional; the /random group)
-    clusters      uint16 [n]                   (optional; per-sample cluster id)
+Two on-disk forms are read and written here:
 
-`load()` also reads the reference's .h5 layout when h5py is importable (sketches
-only: the internal layout of pp-sketchlib's /random group is not documented in
-the reference tree, so a .h5 database is loaded without a random-match table), and
-`python -m poppunk_amd.sketchdb <prefix>/<basename>` converts a .h5 database to .npz in any
-interpreter that has h5py (no GPU or torch needed).
+  `<db>.h5`   the reference's layout, through poppunk_amd.h5lite (libhdf5 via ctypes) or h5py,
+              whichever the interpreter has;
+  `<db>.npz`  the same content flat (fast to load; what the synthetic benchmarks use):
+                names str [n] | kmers int32 [nk] | sketches uint64 [n, nk, sketchsize64*bbits]
+                sketchsize64, bbits int | lengths int64 [n], base_freq float64 [n, 4] (optional)
+                random_table float32 [nk, n_clu, n_clu], clusters uint16 [n] (optional)
+                random/<dataset>, random@<attribute>: the /random group's raw content, verbatim
+
+The /random group [EXT].  Its internal layout belongs to pp-sketchlib and is not stated anywhere
+in the reference tree.  The layout recalled from pp-sketchlib's database code is
+    table_keys (sample names) / table_values (uint16 cluster of each) -- "save_hash" pairs
+    matches_keys (k-mer lengths) / matches_values (per k an n_clu x n_clu matrix)
+    centroids (n_clu x 4 base frequencies), attributes k_min, k_max, use_rc
+`random_from_raw` maps exactly that (and nothing looser) to the engine's `random_table` /
+`clusters`; a group it does not recognise is carried through conversions verbatim and reported,
+never silently dropped: `pp_sketchlib.queryDatabase(random_correct=True)` then raises unless the
+caller opts out (see there).
 """
 import os
 import sys
@@ -26,26 +34,34 @@ import sys
 import numpy as np
 
 
+def _h5_backend():
+    """('h5lite' | 'h5py', open(path, mode)) -- h5py when the interpreter has it, else libhdf5."""
+    try:
+        import h5py
+        return "h5py", (lambda path, mode="r": h5py.File(path, mode))
+    except ImportError:
+        pass
+    from . import h5lite
+    if h5lite.available():
+        return "h5lite", (lambda path, mode="r": h5lite.File(path, mode))
+    raise ImportError("neither h5py nor libhdf5 (set HDF5_LIB) is available")
+
+
+def _ds_read(obj):
+    return obj.read() if hasattr(obj, "read") else obj[()]
+
+
+def _is_group(obj):
+    return hasattr(obj, "keys")
+
+
 def db_file(prefix, ext):
     return prefix + ext
 
 
-def save_npz(db_name, names, kmers, sketches, sketchsize64, bbits, random_table=None,
-             clusters=None):
-    """db_name is the reference's `<prefix>/<basename>` (no extension)."""
-    os.makedirs(os.path.dirname(db_name) or ".", exist_ok=True)
-    payload = dict(names=np.asarray(names, dtype=str), kmers=np.asarray(kmers, dtype=np.int32),
-                   sketches=np.ascontiguousarray(sketches, dtype=np.uint64),
-                   sketchsize64=np.int32(sketchsize64), bbits=np.int32(bbits))
-    if random_table is not None:
-        payload["random_table"] = np.asarray(random_table, dtype=np.float32)
-    if clusters is not None:
-        payload["clusters"] = np.asarray(clusters, dtype=np.uint16)
-    np.savez(db_name + ".npz", **payload)
-
-
 class LoadedSketches:
-    def __init__(self, names, kmers, sketches, sketchsize64, bbits, random_table, clusters):
+    def __init__(self, names, kmers, sketches, sketchsize64, bbits, random_table, clusters,
+                 random_raw=None, lengths=None, base_freq=None, random_status="absent"):
         self.names = names
         self.kmers = kmers
         self.sketches = sketches
@@ -53,6 +69,11 @@ class LoadedSketches:
         self.bbits = bbits
         self.random_table = random_table
         self.clusters = clusters
+        self.random_raw = random_raw          # {"name": array, "@attr": value}: the /random group as found
+        self.lengths = lengths
+        self.base_freq = base_freq
+        # "absent" | "mapped" ([EXT] layout recognised) | "unrecognised" (present, carried raw only)
+        self.random_status = random_status
 
 
 def _select_kmers(db_kmers, klist):
@@ -66,6 +87,107 @@ def _select_kmers(db_kmers, klist):
     return idx
 
 
+# ---- the /random group -----------------------------------------------------------------------
+
+def read_random_raw(grp):
+    """Every dataset and attribute of a /random group, by name, as numpy values (generic walk:
+    nothing is assumed about the layout).  Nested groups are flattened with '/' in the key."""
+    raw = {}
+
+    def visit(g, prefix):
+        for a in list(g.attrs.keys()):
+            raw["@" + prefix + a] = np.asarray(g.attrs[a])
+        for name in list(g.keys()):
+            obj = g[name]
+            if _is_group(obj):
+                visit(obj, prefix + name + "/")
+            else:
+                raw[prefix + name] = np.asarray(_ds_read(obj))
+    visit(grp, "")
+    return raw
+
+
+def random_from_raw(raw, names, klist, base_freq=None):
+    """[EXT] Map the recalled pp-sketchlib /random layout (module docstring) to
+    (random_table float32 [nk, C, C], clusters uint16 [n]); None when `raw` is not exactly that.
+    Samples absent from the cluster table (queries from another database) take the cluster whose
+    centroid is nearest to their base frequencies [EXT closest_cluster], or cluster 0 when the
+    frequencies are unknown.  k outside [k_min, k_max]: random match chance 1 below, 0 above [EXT]."""
+    need = ("table_keys", "table_values", "matches_keys", "matches_values")
+    if raw is None or any(k not in raw for k in need):
+        return None
+    keys = [x.decode() if isinstance(x, bytes) else str(x) for x in np.asarray(raw["table_keys"]).ravel()]
+    vals = np.asarray(raw["table_values"]).ravel()
+    mk = [int(x) for x in np.asarray(raw["matches_keys"]).ravel()]
+    mv = np.asarray(raw["matches_values"], dtype=np.float64)
+    if len(keys) != len(vals) or mv.shape[0] != len(mk) or len(mk) == 0:
+        return None
+    per = int(np.prod(mv.shape[1:])) if mv.ndim > 1 else 0
+    n_clu = int(round(per ** 0.5))
+    if n_clu < 1 or n_clu * n_clu != per or (len(vals) and int(vals.max()) >= n_clu):
+        return None
+    mv = mv.reshape(len(mk), n_clu, n_clu)
+    k_min = int(np.asarray(raw.get("@k_min", min(mk))).ravel()[0])
+    k_max = int(np.asarray(raw.get("@k_max", max(mk))).ravel()[0])
+    tbl = np.empty((len(klist), n_clu, n_clu), dtype=np.float32)
+    for i, k in enumerate(klist):
+        if int(k) in mk:
+            tbl[i] = mv[mk.index(int(k))]
+        elif int(k) < k_min:
+            tbl[i] = 1.0
+        elif int(k) > k_max:
+            tbl[i] = 0.0
+        else:
+            return None
+    of = dict(zip(keys, (int(v) for v in vals)))
+    cent = np.asarray(raw["centroids"], dtype=np.float64) if "centroids" in raw else None
+    if cent is not None and (cent.ndim != 2 or cent.shape[0] != n_clu):
+        cent = None
+    clusters = np.zeros(len(names), dtype=np.uint16)
+    for i, nm in enumerate(names):
+        if nm in of:
+            clusters[i] = of[nm]
+        elif cent is not None and base_freq is not None and cent.shape[1] == np.asarray(base_freq).shape[1]:
+            clusters[i] = int(np.argmin(((cent - np.asarray(base_freq)[i][None, :]) ** 2).sum(axis=1)))
+    return tbl, clusters
+
+
+def random_to_raw(random_table, clusters, names, kmers):
+    """The inverse, for the writer: (random_table, clusters) in the recalled layout [EXT]."""
+    tbl = np.asarray(random_table, dtype=np.float64)
+    n_clu = tbl.shape[1]
+    return {"table_keys": np.asarray([str(n).encode() for n in names]),
+            "table_values": np.asarray(clusters if clusters is not None else np.zeros(len(names)), dtype=np.uint16),
+            "matches_keys": np.asarray(kmers, dtype=np.uint64),
+            "matches_values": tbl.reshape(len(kmers), n_clu * n_clu),
+            "@k_min": np.uint32(min(kmers)), "@k_max": np.uint32(max(kmers)), "@use_rc": np.uint8(1)}
+
+
+# ---- .npz ---------------------------------------------------------------------------------------
+
+def save_npz(db_name, names, kmers, sketches, sketchsize64, bbits, random_table=None,
+             clusters=None, random_raw=None, lengths=None, base_freq=None):
+    """db_name is the reference's `<prefix>/<basename>` (no extension)."""
+    os.makedirs(os.path.dirname(db_name) or ".", exist_ok=True)
+    payload = dict(names=np.asarray(names, dtype=str), kmers=np.asarray(kmers, dtype=np.int32),
+                   sketches=np.ascontiguousarray(sketches, dtype=np.uint64),
+                   sketchsize64=np.int32(sketchsize64), bbits=np.int32(bbits))
+    if random_table is not None:
+        payload["random_table"] = np.asarray(random_table, dtype=np.float32)
+    if clusters is not None:
+        payload["clusters"] = np.asarray(clusters, dtype=np.uint16)
+    if lengths is not None:
+        payload["lengths"] = np.asarray(lengths, dtype=np.int64)
+    if base_freq is not None:
+        payload["base_freq"] = np.asarray(base_freq, dtype=np.float64)
+    for key, val in (random_raw or {}).items():
+        val = np.asarray(val)
+        if val.dtype == object:
+            val = val.astype(str)
+        payload[("random@" + key[1:]) if key.startswith("@") else ("random/" + key)] = val
+    np.savez(db_name + ".npz", **payload)
+
+
 def _load_npz(path, names, klist):
     with np.load(path, allow_pickle=False) as z:
         db_names = [str(x) for x in z["names"]]
@@ -77,49 +199,156 @@ def _load_npz(path, names, klist):
         kidx = _select_kmers(z["kmers"], klist)
         rows = np.asarray([pos[nm] for nm in names], dtype=np.int64)
         sk = z["sketches"][rows][:, kidx, :]
+        raw = {}
+        for key in z.files:
+            if key.startswith("random/"):
+                raw[key[len("random/"):]] = z[key]
+            elif key.startswith("random@"):
+                raw["@" + key[len("random@"):]] = z[key]
+        lengths = z["lengths"][rows] if "lengths" in z.files else None
+        base_freq = z["base_freq"][rows] if "base_freq" in z.files else None
         tbl = z["random_table"][kidx] if "random_table" in z.files else None
         clu = z["clusters"][rows] if "clusters" in z.files else None
+        status = "mapped" if tbl is not None else "absent"
+        if tbl is None and raw:
+            mapped = random_from_raw(raw, names, klist, base_freq)
+            if mapped is not None:
+                tbl, clu = mapped
+                status = "mapped"
+            else:
+                status = "unrecognised"
         return LoadedSketches(list(names), np.asarray(klist, dtype=np.int32),
                               np.ascontiguousarray(sk), int(z["sketchsize64"]), int(z["bbits"]),
-                              tbl, clu)
+                              tbl, clu, raw or None, lengths, base_freq, status)
 
+
+# ---- .h5 ------------------------------------------------------------------------------------------
 
 def _load_h5(path, names, klist):
-    import h5py  # optional
-    with h5py.File(path, "r") as f:
+    _, h5open = _h5_backend()
+    f = h5open(path, "r")
+    try:
         grp = f["sketches"]
+        if names[0] not in grp:
+            raise RuntimeError("sample %s not found in sketch database %s" % (names[0], path))
         first = grp[names[0]]
-        s64 = int(first.attrs["sketchsize64"])
-        bbits = int(first.attrs["bbits"])
+        s64 = int(np.asarray(first.attrs["sketchsize64"]).ravel()[0])
+        bbits = int(np.asarray(first.attrs["bbits"]).ravel()[0])
         sk = np.empty((len(names), len(klist), s64 * bbits), dtype=np.uint64)
+        lengths = np.zeros(len(names), dtype=np.int64)
+        base_freq = np.zeros((len(names), 4), dtype=np.float64)
+        have_freq = True
         for i, nm in enumerate(names):
             if nm not in grp:
                 raise RuntimeError("sample %s not found in sketch database %s" % (nm, path))
+            g = grp[nm]
             for j, k in enumerate(klist):
-                sk[i, j] = grp[nm][str(int(k))][:]
+                if str(int(k)) not in g:
+                    raise RuntimeError("k-mer length %d not found for sample %s in %s" % (int(k), nm, path))
+                words = np.asarray(_ds_read(g[str(int(k))]), dtype=np.uint64).ravel()
+                if words.size != s64 * bbits:
+                    raise RuntimeError("sketch of %s at k=%d has %d words, expected sketchsize64*bbits = %d"
+                                       % (nm, int(k), words.size, s64 * bbits))
+                sk[i, j] = words
+            if "length" in g.attrs:
+                lengths[i] = int(np.asarray(g.attrs["length"]).ravel()[0])
+            bf = np.asarray(g.attrs["base_freq"], dtype=np.float64).ravel() if "base_freq" in g.attrs else None
+            if bf is not None and bf.size == 4:
+                base_freq[i] = bf
+            else:
+                have_freq = False
+        raw, tbl, clu, status = None, None, None, "absent"
         if "random" in f:
-            sys.stderr.write("poppunk_amd: %s has a /random group, but its layout is internal to "
-                             "pp-sketchlib; proceeding without random-match correction\n" % path)
-        return LoadedSketches(list(names), np.asarray(klist, dtype=np.int32), sk, s64, bbits,
-                              None, None)
+            raw = read_random_raw(f["random"])
+            mapped = random_from_raw(raw, names, klist, base_freq if have_freq else None)
+            if mapped is not None:
+                tbl, clu = mapped
+                status = "mapped"
+            else:
+                status = "unrecognised"
+        return LoadedSketches(list(names), np.asarray(klist, dtype=np.int32), sk, s64, bbits, tbl, clu,
+                              raw, lengths, base_freq if have_freq else None, status)
+    finally:
+        f.close()
+
+
+def save_h5(db_name, names, kmers, sketches, sketchsize64, bbits, random_table=None, clusters=None,
+            random_raw=None, lengths=None, base_freq=None, sketch_version="poppunk_amd", codon_phased=False):
+    """Write `<db_name>.h5` in the reference's layout (PopPUNK/web.py:14-61 for /sketches; attribute
+    names as its readers use them, PopPUNK/sketchlib.py:124-133,155-158).  /random: `random_raw`
+    verbatim when given (a round trip of what a conversion carried), else (random_table, clusters)
+    in the recalled pp-sketchlib layout [EXT]."""
+    _, h5open = _h5_backend()
+    os.makedirs(os.path.dirname(db_name) or ".", exist_ok=True)
+    sketches = np.ascontiguousarray(sketches, dtype=np.uint64)
+    kmers = [int(k) for k in kmers]
+    f = h5open(db_name + ".h5", "w")
+    try:
+        top = f.create_group("sketches")
+        top.attrs["sketch_version"] = str(sketch_version)
+        top.attrs["codon_phased"] = bool(codon_phased)
+        for i, nm in enumerate(names):
+            g = top.create_group(str(nm))
+            g.attrs["sketchsize64"] = np.int64(sketchsize64)
+            g.attrs["bbits"] = np.int64(bbits)
+            g.attrs["kmers"] = np.asarray(kmers, dtype=np.int64)
+            g.attrs["length"] = np.int64(lengths[i] if lengths is not None else 0)
+            g.attrs["missing_bases"] = np.int64(0)
+            g.attrs["base_freq"] = np.asarray(base_freq[i] if base_freq is not None else [0.25] * 4, dtype=np.float64)
+            for j, k in enumerate(kmers):
+                d = g.create_dataset(str(k), data=sketches[i, j])
+                d.attrs["kmer-size"] = np.int64(k)
+        if random_raw is None and random_table is not None:
+            random_raw = random_to_raw(random_table, clusters, names, kmers)
+        if random_raw:
+            groups = {"": f.create_group("random")}
+
+            def group_of(path):
+                if path not in groups:
+                    parent, _, leaf = path.rpartition("/")
+                    groups[path] = group_of(parent).create_group(leaf)
+                return groups[path]
+
+            for key, val in random_raw.items():
+                is_attr = key.startswith("@")
+                path, _, leaf = (key[1:] if is_attr else key).rpartition("/")
+                g = group_of(path)
+                val = np.asarray(val)
+                if val.dtype.kind in "UO" or (val.dtype.kind == "S" and is_attr):
+                    val = np.asarray([x if isinstance(x, bytes) else str(x).encode() for x in val.ravel()]).reshape(val.shape)
+                if is_attr:
+                    g.attrs[leaf] = val.item().decode() if val.dtype.kind == "S" and val.ndim == 0 else val
+                else:
+                    # (name lists: fixed-length byte strings, as HighFive / h5py store them)
+                    g.create_dataset(leaf, data=val)
+    finally:
+        f.close()
 
 
 def convert_h5_to_npz(db_name, out_name=None):
-    """Rewrite the reference's `<db_name>.h5` (PopPUNK/web.py:14-61 layout) as `<out_name>.npz`
-    (default: next to it) with every sample and every k-mer length it holds.  Needs h5py, not a
-    GPU: `python -m poppunk_amd.sketchdb <prefix>/<basename>` runs it in whatever interpreter has
-    h5py.  The /random group is not carried over (its layout is internal to pp-sketchlib)."""
-    import h5py  # optional
-    with h5py.File(db_name + ".h5", "r") as f:
+    """Rewrite the reference's `<db_name>.h5` as `<out_name>.npz` (default: next to it) with every
+    sample and every k-mer length it holds, the per-sample `length` / `base_freq`, and the /random
+    group: its raw datasets verbatim (`random/...`, `random@...`) and -- when the [EXT] layout is
+    recognised -- the mapped `random_table` / `clusters`.  Returns (n_samples, kmers, random status)."""
+    _, h5open = _h5_backend()
+    f = h5open(db_name + ".h5", "r")
+    try:
         grp = f["sketches"]
         names = sorted(grp.keys())
         if not names:
             raise RuntimeError("no samples in %s.h5" % db_name)
-        kmers = sorted(int(k) for k in grp[names[0]].attrs["kmers"])
+        kmers = sorted(int(k) for k in np.asarray(grp[names[0]].attrs["kmers"]).ravel())
+    finally:
+        f.close()
     loaded = _load_h5(db_name + ".h5", names, kmers)
     save_npz(out_name or db_name, loaded.names, loaded.kmers, loaded.sketches, loaded.sketchsize64,
-             loaded.bbits)
-    return len(names), kmers
+             loaded.bbits, loaded.random_table, loaded.clusters, loaded.random_raw, loaded.lengths,
+             loaded.base_freq)
+    if loaded.random_status == "unrecognised":
+        sys.stderr.write("poppunk_amd: the /random group of %s.h5 is not in the layout this package knows; its "
+                         "datasets (%s) are carried into the .npz verbatim under random/...\n"
+                         % (db_name, ", ".join(sorted(k for k in loaded.random_raw))))
+    return len(names), kmers, loaded.random_status
 
 
 def load(db_name, names, klist):
@@ -134,13 +363,64 @@ def load(db_name, names, klist):
         try:
             return _load_h5(db_name + ".h5", names, klist)
         except ImportError:
-            raise RuntimeError("reading %s.h5 needs h5py, which is not installed; convert the database with "
-                               "`python -m poppunk_amd.sketchdb %s` in an interpreter that has it" % (db_name, db_name))
+            raise RuntimeError("reading %s.h5 needs h5py or libhdf5 (HDF5_LIB=/path/to/libhdf5.so), neither is "
+                               "available; convert the database with `python -m poppunk_amd.sketchdb %s` in an "
+                               "interpreter that has one" % (db_name, db_name))
     raise RuntimeError("sketch database %s(.npz|.h5) not found" % db_name)
+
+
+# ---- database parameter readers (PopPUNK/sketchlib.py:109-214) ------------------------------------
+
+def getSeqsInDb(dbname):
+    """Sample names in a sketch database file (PopPUNK/sketchlib.py:197-214); `.h5` or `.npz`."""
+    if dbname.endswith(".npz"):
+        with np.load(dbname, allow_pickle=False) as z:
+            return [str(x) for x in z["names"]]
+    _, h5open = _h5_backend()
+    f = h5open(dbname, "r")
+    try:
+        return list(f["sketches"].keys())
+    finally:
+        f.close()
+
+
+def readDBParams(dbPrefix):
+    """(kmers, sketch size in units of 64 bins, codon_phased) of `<dbPrefix>/<basename>.h5|.npz`
+    (PopPUNK/sketchlib.py:170-195, with the consistency checks of :109-168)."""
+    base = dbPrefix + "/" + os.path.basename(dbPrefix)
+    if os.path.exists(base + ".h5"):
+        _, h5open = _h5_backend()
+        f = h5open(base + ".h5", "r")
+        try:
+            top = f["sketches"]
+            codon_phased = bool(np.asarray(top.attrs["codon_phased"]).ravel()[0]) if "codon_phased" in top.attrs else False
+            prev_k, prev_s = None, 0
+            for nm in top.keys():
+                g = top[nm]
+                ks = sorted(int(k) for k in np.asarray(g.attrs["kmers"]).ravel())
+                s = int(np.asarray(g.attrs["sketchsize64"]).ravel()[0])
+                if prev_k is None:
+                    prev_k, prev_s = ks, s
+                elif ks != prev_k:
+                    sys.stderr.write("Problem with database; kmer lengths inconsistent: %s vs %s\n" % (ks, prev_k))
+                    sys.exit(1)
+                elif s != prev_s:
+                    sys.stderr.write("Problem with database; sketch sizes for sample %s is %d, but smaller kmers "
+                                     "have sketch sizes of %d\n" % (nm, prev_s, s))
+                    sys.exit(1)
+        finally:
+            f.close()
+        if not prev_k:
+            sys.stderr.write("Couldn't find sketches in " + dbPrefix + "\n")
+            sys.exit(1)
+        return np.asarray(prev_k), prev_s, codon_phased
+    with np.load(base + ".npz", allow_pickle=False) as z:
+        return np.sort(np.asarray(z["kmers"], dtype=np.int64)), int(z["sketchsize64"]), False
 
 
 if __name__ == "__main__":
     if len(sys.argv) not in (2, 3):
         sys.exit("usage: python -m poppunk_amd.sketchdb <prefix>/<basename> [<out prefix>/<basename>]   (.h5 -> .npz)")
-    n_done, k_done = convert_h5_to_npz(sys.argv[1], sys.argv[2] if len(sys.argv) == 3 else None)
-    print("wrote %s.npz: %d samples, k = %s" % (sys.argv[2] if len(sys.argv) == 3 else sys.argv[1], n_done, k_done))
+    n_done, k_done, r_done = convert_h5_to_npz(sys.argv[1], sys.argv[2] if len(sys.argv) == 3 else None)
+    print("wrote %s.npz: %d samples, k = %s, /random: %s"
+          % (sys.argv[2] if len(sys.argv) == 3 else sys.argv[1], n_done, k_done, r_done))

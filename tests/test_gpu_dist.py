@@ -4,6 +4,8 @@ Integer half (match counts): bit-exact.  Regressed distances: |d| <= 1e-6 (the
 tolerance BASELINE.json's north_star states; fp64 regression on both sides, the
 only difference is the device libm's log/exp vs glibc's).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -541,3 +543,59 @@ def test_host_result_pages_are_touched_ahead_of_the_download(ppk_option):
     sq = pp_sketchlib.longToSquare(v.reshape(-1, 1))
     assert sq.shape == (n, n) and np.array_equal(sq[np.triu_indices(n, 1)], v) and np.array_equal(sq, sq.T)
     assert np.array_equal(pp_sketchlib.squareToLong(sq).ravel(), v)
+
+
+def test_queryDatabase_surface_on_a_reference_layout_h5(tmp_path):
+    """The surface PopPUNK calls (PopPUNK/sketchlib.py:475-632) end to end on `.h5` databases in the
+    reference's own layout, written and read natively (h5lite): self and ref x query, the multi-cluster
+    random table from the ref database's /random group ([EXT] layout) with the queries' clusters taken
+    from the nearest centroid, the --plot-fit leg, the resident-database cache across calls, and the
+    refusal of a database without random match chances."""
+    from poppunk_amd import h5lite, sketchdb, sketchlib
+    if not h5lite.available():
+        pytest.skip("libhdf5 not found")
+    kmers = np.asarray([13, 17, 21, 25, 29], dtype=np.int32)
+    sk, member = synth.make_sketches(260, kmers, cluster_size=20, seed=21)
+    rn = ["ref_%03d" % i for i in range(200)]
+    qn = ["qry_%03d" % i for i in range(60)]
+    tbl = np.ascontiguousarray((np.random.Generator(np.random.PCG64(2)).random((5, 2, 2)) * 0.03 *
+                                np.asarray([1.0, 0.1, 0.01, 0.001, 0.0001])[:, None, None]).astype(np.float32))
+    tbl = (tbl + tbl.transpose(0, 2, 1)) / 2
+    rclu = (member[:200] % 2).astype(np.uint16)
+    cent = np.asarray([[0.3, 0.2, 0.2, 0.3], [0.2, 0.3, 0.3, 0.2]])
+    rfreq = cent[rclu]
+    qclu = np.asarray([i % 2 for i in range(60)], dtype=np.uint16)
+    qfreq = cent[qclu] + 0.01
+    raw = sketchdb.random_to_raw(tbl, rclu, rn, kmers)
+    raw["centroids"] = cent
+    rp, qp = str(tmp_path / "refdb"), str(tmp_path / "qrydb")
+    sketchdb.save_h5(rp + "/refdb", rn, kmers, sk[:200], 16, 14, random_raw=raw, base_freq=rfreq)
+    sketchdb.save_h5(qp + "/qrydb", qn, kmers, sk[200:], 16, 14, base_freq=qfreq)       # queries: no /random
+    pp_sketchlib.clear_cache()
+    # self
+    d = sketchlib.queryDatabase(rn, rn, rp, rp, kmers, self=True, number_plot_fits=2)
+    want, wf = oracle.query(sk[:200], None, kmers, 16, 14, tbl, rclu, rclu, threads=4)
+    assert d.dtype == np.float32 and d.shape == (19900, 2) and np.abs(d - want).max() <= TOL
+    for i in (1, 2):
+        lines = open(rp + "/refdb_fit_example_%d.tsv" % i).read().strip().split("\n")
+        assert lines[2] == "k\traw_jaccard\tcorrected_jaccard" and len(lines) == 3 + 5
+        vals = np.asarray([[float(x) for x in ln.split("\t")] for ln in lines[3:]])
+        assert np.all(vals[:, 1] >= vals[:, 2]) and np.all(np.diff(vals[:, 1]) < 0.2)
+    # ref x query: the queries' clusters come from the ref table's centroids
+    d2 = sketchlib.queryDatabase(rn, qn, rp, qp, kmers, self=False, number_plot_fits=1)
+    want2, _ = oracle.query(sk[:200], sk[200:], kmers, 16, 14, tbl, rclu, qclu, threads=4)
+    assert np.abs(d2 - want2).max() <= TOL
+    assert os.path.exists(str(tmp_path / "qrydb_fit_example_1.tsv"))
+    # a second call finds the database loaded and resident (same answer, no re-read)
+    os.rename(rp + "/refdb.h5", rp + "/refdb.h5.moved")
+    try:
+        with pytest.raises(RuntimeError):
+            sketchlib.queryDatabase(rn[:50], rn[:50], rp, rp, kmers)          # different names: a real read
+    finally:
+        os.rename(rp + "/refdb.h5.moved", rp + "/refdb.h5")
+    assert np.array_equal(sketchlib.queryDatabase(rn, rn, rp, rp, kmers), d)
+    # a self query of the query database: it has no random match chances -> refused, not guessed
+    with pytest.raises(RuntimeError, match="no random match chances"):
+        sketchlib.queryDatabase(qn, qn, qp, qp, kmers)
+    assert pp_sketchlib.queryDatabase(qp + "/qrydb", qp + "/qrydb", qn, qn, kmers, False, False, 1, True, 0).shape == (1770, 2)
+    pp_sketchlib.clear_cache()

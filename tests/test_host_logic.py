@@ -154,24 +154,30 @@ def _h5_python_ok():
 
 
 @pytest.mark.skipif(not _h5_python_ok(), reason="no interpreter with h5py in this image")
-def test_reference_h5_layout_reader_and_converter(tmp_path):
+def test_reference_h5_layout_reader_writer_and_random_group(tmp_path):
     """The reference keeps sketches in <prefix>/<basename>.h5: group /sketches, one group per sample
     with attrs sketchsize64 / bbits / kmers / length / ..., one uint64 dataset per k named str(k)
-    (PopPUNK/web.py:14-61).  h5py lives in the image's conda interpreter only, so that interpreter
-    writes such a file, reads it through sketchdb.load (subset and order of names and of k) and
-    converts it; this interpreter then reads the converted .npz and compares everything."""
+    (PopPUNK/web.py:14-61), and pp-sketchlib's /random group beside it.  h5py (the image's conda
+    interpreter) WRITES such a file -- with a /random group in the layout recalled from pp-sketchlib
+    [EXT] -- and this interpreter reads it natively (h5lite over libhdf5): subset and order of names
+    and of k, the mapped random table, the verbatim conversion to .npz; then this interpreter's
+    writer produces a .h5 that h5py reads back value for value."""
     import subprocess
-    from poppunk_amd import sketchdb, synth
+    from poppunk_amd import h5lite, sketchdb, synth
+    if not h5lite.available():
+        pytest.skip("libhdf5 not found")
     kmers = np.asarray([13, 17, 21, 25], dtype=np.int32)
     sk, _ = synth.make_sketches(9, kmers, sketchsize64=3, bbits=14, cluster_size=3, seed=12)
     names = ["s%02d" % i for i in range(9)]
+    tbl = (np.random.Generator(np.random.PCG64(4)).random((4, 2, 2)) * 0.05)
+    clu = np.asarray([0, 1, 1, 0, 1, 0, 0, 1, 1], dtype=np.uint16)
     src = tmp_path / "src.npz"
-    np.savez(src, names=np.asarray(names), kmers=kmers, sketches=sk)
+    np.savez(src, names=np.asarray(names), kmers=kmers, sketches=sk, tbl=tbl, clu=clu)
     prefix = str(tmp_path / "db" / "db")
     script = r'''
-import sys, os, importlib.util
+import sys, os
 import numpy as np, h5py
-src, prefix, repo, out = sys.argv[1:5]
+src, prefix = sys.argv[1:3]
 z = np.load(src)
 os.makedirs(os.path.dirname(prefix))
 with h5py.File(prefix + ".h5", "w") as f:
@@ -182,30 +188,113 @@ with h5py.File(prefix + ".h5", "w") as f:
         s = g.create_group(str(nm))
         s.attrs["sketchsize64"] = 3
         s.attrs["bbits"] = 14
-        s.attrs["length"] = 2000000
+        s.attrs["length"] = 2000000 + i
         s.attrs["missing_bases"] = 0
-        s.attrs["base_freq"] = [0.25, 0.25, 0.25, 0.25]
+        s.attrs["base_freq"] = [0.25, 0.25, 0.3, 0.2]
         s.attrs["kmers"] = [int(k) for k in z["kmers"]]
         for j, k in enumerate(z["kmers"]):
             d = s.create_dataset(str(int(k)), data=z["sketches"][i, j], dtype="uint64")
             d.attrs["kmer-size"] = int(k)
-spec = importlib.util.spec_from_file_location("sketchdb", os.path.join(repo, "poppunk_amd", "sketchdb.py"))
-m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
-got = m.load(prefix, ["s07", "s02", "s05"], [21, 13])
-np.savez(out, sketches=got.sketches, kmers=got.kmers, s64=got.sketchsize64, bbits=got.bbits)
-print(m.convert_h5_to_npz(prefix, prefix + "_conv"))
+    r = f.create_group("random")
+    r.attrs["k_min"] = np.uint32(13); r.attrs["k_max"] = np.uint32(25); r.attrs["use_rc"] = True
+    r.create_dataset("table_keys", data=np.asarray([str(n).encode() for n in z["names"]]))
+    r.create_dataset("table_values", data=z["clu"].astype("uint16"))
+    r.create_dataset("matches_keys", data=z["kmers"].astype("uint64"))
+    r.create_dataset("matches_values", data=z["tbl"].reshape(4, 4))
+    r.create_dataset("centroids", data=np.asarray([[0.25, 0.25, 0.25, 0.25], [0.2, 0.3, 0.3, 0.2]]))
 '''
-    out = tmp_path / "loaded.npz"
-    r = subprocess.run([H5_PYTHON, "-c", script, str(src), prefix, ROOT, str(out)], capture_output=True, text=True)
+    r = subprocess.run([H5_PYTHON, "-c", script, str(src), prefix], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
-    z = np.load(out)
-    assert int(z["s64"]) == 3 and int(z["bbits"]) == 14 and list(z["kmers"]) == [21, 13]
-    assert np.array_equal(z["sketches"], sk[[7, 2, 5]][:, [2, 0], :])
-    conv = sketchdb.load(prefix + "_conv", names, kmers)              # .npz written by the converter
+    # native read: subset / order of names and k, attributes, the [EXT]-mapped random table
+    got = sketchdb.load(prefix, ["s07", "s02", "s05"], [21, 13])
+    assert got.sketchsize64 == 3 and got.bbits == 14 and list(got.kmers) == [21, 13]
+    assert np.array_equal(got.sketches, sk[[7, 2, 5]][:, [2, 0], :])
+    assert got.random_status == "mapped" and list(got.clusters) == [1, 1, 0]
+    assert np.array_equal(got.random_table, tbl[[2, 0]].astype(np.float32))
+    assert list(got.lengths) == [2000007, 2000002, 2000005] and np.allclose(got.base_freq[0], [0.25, 0.25, 0.3, 0.2])
+    assert sketchdb.getSeqsInDb(prefix + ".h5") == names
+    ks, s64, phased = sketchdb.readDBParams(os.path.dirname(prefix))
+    assert list(ks) == [13, 17, 21, 25] and s64 == 3 and phased is False
+    # conversion carries everything, the /random group verbatim
+    assert sketchdb.convert_h5_to_npz(prefix, prefix + "_conv") == (9, [13, 17, 21, 25], "mapped")
+    conv = sketchdb.load(prefix + "_conv", names, kmers)
     assert np.array_equal(conv.sketches, sk) and conv.sketchsize64 == 3 and conv.bbits == 14
-    # without h5py (this interpreter) a .h5 database says how to convert it
-    try:
-        import h5py  # noqa: F401
-    except ImportError:
-        with pytest.raises(RuntimeError, match="poppunk_amd.sketchdb"):
-            sketchdb.load(prefix, names, kmers)
+    assert np.array_equal(conv.random_table, tbl.astype(np.float32)) and np.array_equal(conv.clusters, clu)
+    assert sorted(conv.random_raw) == ["@k_max", "@k_min", "@use_rc", "centroids", "matches_keys",
+                                       "matches_values", "table_keys", "table_values"]
+    assert np.array_equal(conv.random_raw["matches_values"], tbl.reshape(4, 4))
+    # a /random group in some other layout is carried, reported, and NOT guessed at
+    script2 = r'''
+import sys, h5py, numpy as np
+with h5py.File(sys.argv[1], "r+") as f:
+    del f["random"]
+    r = f.create_group("random"); r.create_dataset("something_else", data=np.arange(5)); r.attrs["v"] = 3
+'''
+    assert subprocess.run([H5_PYTHON, "-c", script2, prefix + ".h5"], capture_output=True).returncode == 0
+    odd = sketchdb.load(prefix, names, kmers)
+    assert odd.random_status == "unrecognised" and odd.random_table is None
+    assert np.array_equal(odd.random_raw["something_else"], np.arange(5)) and int(odd.random_raw["@v"]) == 3
+    # writer -> h5py reads it back (layout of web.py:14-61 + the raw /random group)
+    out = str(tmp_path / "w" / "w")
+    sketchdb.save_h5(out, names, kmers, sk, 3, 14, random_raw=conv.random_raw, lengths=conv.lengths,
+                     base_freq=conv.base_freq, sketch_version="test")
+    script3 = r'''
+import sys, h5py, numpy as np
+z = np.load(sys.argv[2])
+with h5py.File(sys.argv[1], "r") as f:
+    g = f["sketches"]
+    assert g.attrs["sketch_version"] == "test" and not g.attrs["codon_phased"]
+    assert sorted(g.keys()) == sorted(str(n) for n in z["names"])
+    for i, nm in enumerate(z["names"]):
+        s = g[str(nm)]
+        assert int(s.attrs["sketchsize64"]) == 3 and int(s.attrs["bbits"]) == 14 and int(s.attrs["length"]) == 2000000 + i
+        assert list(s.attrs["kmers"]) == [int(k) for k in z["kmers"]]
+        for j, k in enumerate(z["kmers"]):
+            assert s[str(int(k))].dtype == np.uint64 and np.array_equal(s[str(int(k))][:], z["sketches"][i, j])
+            assert int(s[str(int(k))].attrs["kmer-size"]) == int(k)
+    r = f["random"]
+    assert int(r.attrs["k_min"]) == 13 and int(r.attrs["k_max"]) == 25
+    assert [x.decode() for x in r["table_keys"][:]] == [str(n) for n in z["names"]]
+    assert np.array_equal(r["matches_values"][:], z["tbl"].reshape(4, 4)) and np.array_equal(r["table_values"][:], z["clu"])
+print("ok")
+'''
+    r = subprocess.run([H5_PYTHON, "-c", script3, out + ".h5", str(src)], capture_output=True, text=True)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+    back = sketchdb.load(out, names, kmers)
+    assert np.array_equal(back.sketches, sk) and np.array_equal(back.random_table, tbl.astype(np.float32))
+
+
+def test_random_correct_on_a_database_without_a_table_raises(tmp_path, monkeypatch):
+    """PopPUNK never queries a database without random match chances (PopPUNK/sketchlib.py:455-466);
+    random_correct=True on one must not silently return uncorrected distances."""
+    prefix, names, _ = make_db(tmp_path, "norand", 6, with_random=False)
+    db = prefix + "/norand"
+    monkeypatch.delenv("PPK_ALLOW_NO_RANDOM", raising=False)
+    pp_sketchlib._DB_CACHE.clear()
+    with pytest.raises(RuntimeError, match="no random match chances"):
+        pp_sketchlib.queryDatabase(db, db, names, names, [13, 17, 21], True, False, 1, False, 0)
+    with pytest.raises(RuntimeError, match="no random match chances"):
+        sketchlib.queryDatabase(names, names, prefix, prefix, [13, 17, 21])
+
+
+def test_version_is_parsed_by_the_reference_check():
+    """checkSketchlibVersion does [int(v) for v in version.split('.')] (PopPUNK/sketchlib.py:49-50)
+    and wants >= 2.0.1 (PopPUNK/__init__.py:9-11)."""
+    v = [int(x) for x in pp_sketchlib.version.split(".")]
+    assert len(v) == 3 and tuple(v) >= (2, 0, 1)
+
+
+def test_fitKmerCurve_mirror_against_the_reference_goldens(golden_dir):
+    """tests/golden/fit_kmer_curve.json (the reference's fitKmerCurve run by make_golden.py): the
+    mirror solves the same bounded least-squares problem exactly, INCLUDING the cases where a
+    bound is active (which the regression of the distance kernel clamps instead)."""
+    import json
+    g = json.load(open(os.path.join(golden_dir, "fit_kmer_curve.json")))
+    n_active = 0
+    for c in g["cases"]:
+        got = sketchlib.fitKmerCurve(np.asarray(c["jaccard"]), np.asarray(c["klist"]))
+        tol = 5e-6 if c["interior"] else 1e-4          # the reference's trust-region solver stops early on a bound
+        assert abs(got[0] - c["core"]) <= tol and abs(got[1] - c["accessory"]) <= tol, c
+        n_active += not c["interior"]
+    assert n_active >= 5
+    assert list(sketchlib.fitKmerCurve(np.asarray([0.5, 0.0]), np.asarray([13, 17]))) == [0, 0]
