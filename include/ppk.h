@@ -274,6 +274,19 @@ int ppk_knn_dev(const float *d_square, size_t n, int knn, long long *d_i, long l
 int ppk_knn_rect_dev(const float *d_block, size_t stride, size_t col, size_t n_rows,
                      size_t n_cols, size_t self_offset, int knn, long long *d_i, long long *d_j,
                      float *d_dist, void *stream);
+/* k nearest neighbours of every sample of a database straight from kernel 1's tiles: what
+ * get_kNN_distances(longToSquare(queryDatabase(...)[:, dist_col]), kNN) gives (callers
+ * PopPUNK/models.py:1215-1222, PopPUNK/assign.py:680-686), with the upper triangle compared once
+ * and neither the square nor the long-form distance matrix ever materialised.  Each tile emits a
+ * pair's distance as a neighbour candidate of both its samples while it beats a per-sample bound that
+ * tightens as tiles finish; a sort by sample and a per-sample selection (ties by column index, as
+ * the reference's stable sort, src/extend.cpp:266-279) finish.  knn <= 32; bbits = 14.  Outputs
+ * [n*knn] (i, j, dist) on the device; *n_candidates (host, nullable) receives the number of
+ * candidates the tiles emitted.  Synchronises the stream (the candidate count sizes the sort). */
+int ppk_knn_sketches_dev(const ppk_db *db, const int32_t *kmers, const float *random_tbl,
+                         size_t n_clu, int flags, int knn, int dist_col, long long *d_i,
+                         long long *d_j, float *d_dist, unsigned long long *n_candidates,
+                         void *stream);
 /* replaces the per-row Python copy loop of PopPUNK.qc.prune_distance_matrix
  * (PopPUNK/qc.py:58-83): the long-form (condensed, PopPUNK row order) matrix of the
  * samples keep[0] < keep[1] < ... out of n; `cols` floats per row (2 for distances) */

@@ -14,7 +14,7 @@ int ppk_launch_dist(const ppk_db *ref, const ppk_db *qry_or_null, const int32_t 
                     const float *d_rtab, size_t n_clu, int flags, size_t q_begin, size_t q_end,
                     void *d_out, unsigned long long *d_n_failed, uint64_t *d_mask, int slope,
                     float x_max, float y_max, float scale_x, float scale_y, int inclusive,
-                    double *d_lut, hipStream_t s);
+                    double *d_lut, hipStream_t s, const int *knn_args = nullptr);
 
 // ---- errors ---------------------------------------------------------------
 static thread_local std::string g_err;
@@ -564,6 +564,74 @@ extern "C" int ppk_dist_edges_dev(const ppk_db *ref, const ppk_db *qry, const in
   g.int_offset = 0;
   return ppk_launch_compact(static_cast<const uint64_t *>(d_mask), n_words, g, d_ws, d_edges, cap,
                             d_n_edges, s);
+}
+
+// k nearest neighbours of every sample straight from the resident sketches: kernel 1's tiles emit
+// neighbour candidates under per-sample bounds (ppk_dist.hip MODE_KNN), a sort by sample and a per-sample
+// selection finish (ppk_square.hip).  The upper triangle is compared ONCE and neither the n x n matrix
+// nor the [n_pairs, 2] matrix ever exists: memory is the sketches + a few dozen candidates per sample.
+extern "C" int ppk_knn_sketches_dev(const ppk_db *db, const int32_t *kmers, const float *random_tbl,
+                                    size_t n_clu, int flags, int knn, int dist_col, long long *d_i,
+                                    long long *d_j, float *d_dist, unsigned long long *n_candidates,
+                                    void *stream) {
+  if (n_candidates) *n_candidates = 0;
+  int rc = check_pair(db, nullptr, kmers, 0, db ? db->n : 0);
+  if (rc != PPK_OK) return rc;
+  if (knn < 1 || knn > 32) return ppk_fail(PPK_ERR_ARG, "knn must be in [1, 32]");
+  if (dist_col != 0 && dist_col != 1) return ppk_fail(PPK_ERR_ARG, "dist_col must be 0 (core) or 1 (accessory)");
+  if (!d_i || !d_j || !d_dist) return ppk_fail(PPK_ERR_ARG, "NULL output buffer");
+  if (flags & (PPK_FLAG_JACCARD | PPK_FLAG_COUNTS)) return ppk_fail(PPK_ERR_ARG, "neighbours are taken from distances");
+  if (db->n >= ((size_t)1 << 32)) return ppk_fail(PPK_ERR_ARG, "too many samples");
+  DeviceGuard guard(db->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  PpkCall call(db->device, s);
+  const size_t n = db->n;
+  double *d_lut = nullptr;
+  float *d_rtab = nullptr;
+  rc = stage_tables(db, random_tbl, n_clu, flags, s, &d_lut, &d_rtab);
+  if (rc != PPK_OK) return rc;
+  void *d_state = nullptr;
+  rc = scratch_get(db->device, SLOT_ITER_A, 3 * sizeof(unsigned long long) + n * 4 + 256, &d_state);
+  if (rc != PPK_OK) return rc;
+  const size_t all = n * (n - 1);                                  // two candidates per pair at most
+  // Measured (k = 5): ~200 / 530 / 1 000 candidates per sample at 10k / 50k / 100k samples.  A bound is the
+  // k-th smallest of ONE tile's candidates (bounds are not merged across tiles: that would need a
+  // lock per sample), so it settles near the (k / 256) / (tiles per row) quantile rather than at the
+  // true k-th distance; 12 bytes per candidate make that a non-issue (1.8 GB of scratch at 100k).  An
+  // overflow costs a second run of the kernel, which then starts from the settled bounds.
+  // (Tried: three launches of growing size so that the bulk runs under settled bounds -- emitted more,
+  // not less, in the first two.)
+  size_t cap = n * (size_t)(256 + 256 * knn);
+  if (cap < ((size_t)1 << 20)) cap = (size_t)1 << 20;
+  if (cap > all) cap = all;
+  if (cap == 0) cap = 1;
+  const int knn_args[2] = {knn, dist_col};
+  unsigned long long count = 0;
+  void *d_cand = nullptr;
+  size_t vals_off = 0;
+  for (int attempt = 0;; ++attempt) {
+    vals_off = (cap * 4 + 255) & ~(size_t)255;
+    rc = scratch_get(db->device, SLOT_ITER_B, vals_off + cap * 8 + 256, &d_cand);
+    if (rc != PPK_OK) return rc;
+    // the bounds of an earlier attempt stay valid (they only ever tighten): the re-run emits less
+    rc = ppk_launch_knn_state_init(d_state, n, cap, vals_off, attempt == 0, s);
+    if (rc != PPK_OK) return rc;
+    if (n > 1) {
+      rc = ppk_launch_dist(db, nullptr, kmers, d_rtab, d_rtab ? n_clu : 1, flags, 0, n, d_cand, nullptr,
+                           static_cast<uint64_t *>(d_state), 2, 0.f, 0.f, 1.f, 1.f, 1, d_lut, s, knn_args);
+      if (rc != PPK_OK) return rc;
+    }
+    PPK_HIP(hipMemcpyAsync(&count, d_state, sizeof(count), hipMemcpyDeviceToHost, s));
+    PPK_HIP(hipStreamSynchronize(s));
+    if (count <= cap) break;
+    if (attempt >= 4) return ppk_fail(PPK_ERR_CAPACITY, "neighbour candidates keep overflowing their buffer");
+    cap = (size_t)count + (size_t)count / 4 + 1024;
+    if (cap > all) cap = all;
+  }
+  if (n_candidates) *n_candidates = count;
+  return ppk_knn_from_candidates(db->device, static_cast<const uint32_t *>(d_cand),
+                                 reinterpret_cast<const uint64_t *>(static_cast<char *>(d_cand) + vals_off),
+                                 (size_t)count, n, knn, d_i, d_j, d_dist, s);
 }
 
 // ---- kernel 2, device entry points -------------------------------------------------

@@ -96,7 +96,31 @@ __device__ __forceinline__ uint32_t pack_get(const PackW<2> &pk, int k, int bits
   return (uint32_t)(v >> ((nk - 1 - k) * bits)) & mask;
 }
 
-enum { MODE_DIST = 0, MODE_JACCARD = 1, MODE_COUNTS = 2, MODE_MASK = 3 };
+enum { MODE_DIST = 0, MODE_JACCARD = 1, MODE_COUNTS = 2, MODE_MASK = 3, MODE_KNN = 4 };
+
+// MODE_KNN (k nearest neighbours of every sample of a self job, straight from the tiles): a pair's
+// distance is a CANDIDATE for both of its samples' neighbour lists.  Two filters keep the candidate
+// stream small without ever dropping a true neighbour (keys are (distance bits, other sample):
+// distances are >= 0, so their bits order like the values, and the sample index breaks ties exactly
+// like the reference's stable sort by distance):
+//  * local top-k: a tile holds 256 candidates for each of its 32 queries and 32 for each of its 256
+//    refs; a candidate that is not among the k smallest keys of (a subset of) its sample's candidates
+//    here cannot be among the k smallest overall;
+//  * bounds: `thr[s]` is an upper bound of sample s's final k-th smallest distance -- the k-th
+//    smallest of any k or more of its candidates is one -- lowered (atomicMin) by every tile that
+//    holds enough of them; a candidate is emitted only if d <= thr[s] (<=: ties stay in play).
+//    Bounds only ever tighten and a stale read is merely conservative, so tiles need no ordering.
+// Out comes a superset of every true neighbour list: ~k (2 + ln(n/256) + ln(n/16)) candidates per
+// sample instead of n.  Queries are handled by the wavefront that owns them (k rounds of wave-wide
+// minimum extraction over its 4 x 64 registers); refs need all 32 queries of the tile, so the
+// distances go through LDS (idle after the compare loop) and each thread ranks 16 of one ref's 32.
+// One global atomic per workgroup reserves the tile's slice of the candidate arrays.
+struct KnnState {
+  unsigned long long count;   // candidates emitted (may exceed cap: the host then re-runs with more room)
+  unsigned long long cap;     // capacity of the candidate arrays
+  unsigned long long vals_off;   // byte offset of the uint64 value array behind the uint32 key array
+  // uint32 thr[n] follows
+};
 
 struct DistParams {
   size_t npad_r, npad_q;  // padded sample counts of the two resident arrays
@@ -131,6 +155,7 @@ struct DistParams {
   unsigned n_tiles;            // non-empty tiles of the triangle / rectangle part
   unsigned tiles_per_xcd;      // ceil(n_tiles / 8)
   int tri_m, tri_c0;           // self job: ref tile r pairs with clamp(tri_m * r + tri_c0, 0, q_tiles) query tiles
+  int knn, knn_col;       // MODE_KNN: neighbours per sample, distance column (0 core, 1 accessory)
   int ablate;             // measurement only (PPK_ABLATE): 1 skip epilogue, 2 skip compare, 4 skip DMA, 8 skip barriers
   int ext_adjust;         // [EXT] a4 gate (PpkConfig::ext_collision_adjust)
   int ext_skip;           // [EXT] a6: skip instead of truncate at J < 5/s (PpkConfig::ext_fit_skip)
@@ -822,7 +847,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
 
       if (blk == p.s64 - 1) {
         // ---- end of one k --------------------------------------------------------
-        if constexpr (MODE == MODE_DIST || MODE == MODE_MASK) {
+        if constexpr (MODE == MODE_DIST || MODE == MODE_MASK || MODE == MODE_KNN) {
           // another k follows: the count register moves up by one field
           if (k + 1 < p.nk) {
             const int up = 32 - p.cnt_bits;
@@ -887,8 +912,9 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
     compare_loop(std::false_type{});
 
   // ---- epilogue: regression (+ boundary) per pair ---------------------------
-  if constexpr (MODE == MODE_DIST || MODE == MODE_MASK) {
-    if (!wave_active || (p.ablate & 1)) return;
+  if constexpr (MODE == MODE_DIST || MODE == MODE_MASK || MODE == MODE_KNN) {
+    if (p.ablate & 1) return;
+    if (MODE != MODE_KNN && !wave_active) return;      // (KNN: every wave takes part in the LDS exchange)
     // Cut every count register's live range here: whatever the register allocator decides for the
     // epilogue (which has all 128 VGPRs but wants many of them for fp64) must not reach back into
     // the compare loop -- a register spilled "for its whole life" is read-modified-written in
@@ -961,8 +987,16 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
     uint64_t ball[R];
     bool valid[R], failed[R];
     float core[R], acc[R];
+    uint32_t knn_bits[MODE == MODE_KNN ? TQ : 1][R];   // MODE_KNN: distance bits of the 16 pairs, ~0 = no pair
+    if constexpr (MODE == MODE_KNN) {
+#pragma unroll
+      for (int q = 0; q < TQ; ++q)
+#pragma unroll
+        for (int r = 0; r < R; ++r) knn_bits[q][r] = 0xffffffffu;
+    }
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
+      if (MODE == MODE_KNN && !wave_active) break;     // nothing was compared: every pair stays "no pair"
       const int q = b / (R / NRB), r0b = (b % (R / NRB)) * NRB;
       const size_t qq = qw0 + q;   // wave-uniform
       const bool in_band = qq >= qb && qq < qe;
@@ -1040,7 +1074,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
             if (valid[2 * h + 1]) o[row1] = make_float2(core[2 * h + 1], acc[2 * h + 1]);
           }
         }
-      } else {
+      } else if constexpr (MODE == MODE_MASK) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           bool pred = false;
@@ -1059,6 +1093,11 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
                      1ull << (qq & 63));
         }
       }
+      if constexpr (MODE == MODE_KNN) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          if (valid[r]) knn_bits[q][r] = __float_as_uint((p.knn_col ? acc[r] : core[r]) + 0.0f);
+      }
       if constexpr (MODE == MODE_MASK) {
         // ball[0]/ball[1]: even/odd refs of r0..r0+127; ball[2]/ball[3]: of r0+128..r0+255.
         // Interleave them into the [q][ref/64] bitmask words the compaction pass reads.
@@ -1076,6 +1115,136 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
       }
     }
     if (n_failed && n_fail_wave && lane_late == 0) atomicAdd(n_failed, (unsigned long long)n_fail_wave);
+    if constexpr (MODE == MODE_KNN) {
+      KnnState *ks = reinterpret_cast<KnnState *>(mask_out);
+      uint32_t *thr = reinterpret_cast<uint32_t *>(ks + 1);
+      uint32_t *ckeys = static_cast<uint32_t *>(out);
+      uint64_t *cvals = reinterpret_cast<uint64_t *>(static_cast<char *>(out) + ks->vals_off);
+      const unsigned long long cap = ks->cap;
+      uint32_t *ld = reinterpret_cast<uint32_t *>(lds);          // [32 queries][256 refs] distance bits
+      uint32_t *lctl = ld + V2_QT * V2_RT;                        // [0] workgroup total, [1..2] its base
+      constexpr uint64_t NONE = ~0ull;
+      const int knn = p.knn;
+      // ---- 1. distances to LDS; the wave's own queries: local top-k by rounds of wave-wide minima ----
+      if (wave == 0 && lane_late == 0) lctl[0] = 0;
+      uint32_t won[TQ];       // per lane and query: byte r = the round ref r's candidate was extracted in (0xff: none)
+      int cq[TQ];             // candidates of query q that pass (wave-uniform): the first cq[q] rounds
+      int c1 = 0;
+#pragma unroll
+      for (int q = 0; q < TQ; ++q) {
+        uint32_t *row = ld + (wave * TQ + q) * V2_RT;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          u32x2 v2;
+          v2.x = knn_bits[q][2 * h];
+          v2.y = knn_bits[q][2 * h + 1];
+          *reinterpret_cast<u32x2 *>(row + 2 * lane_late + 128 * h) = v2;
+        }
+        const size_t qq = qw0 + q;
+        won[q] = 0xffffffffu;
+        cq[q] = 0;
+        if (!wave_active || qq < qb || qq >= qe) continue;      // wave-uniform
+        const uint32_t thr_q = __hip_atomic_load(thr + qq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint64_t key[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          key[r] = knn_bits[q][r] != 0xffffffffu ? (((uint64_t)knn_bits[q][r] << 32) | (uint32_t)ref_of(r)) : NONE;
+        uint64_t kth = NONE;
+        int round = 0;
+        for (; round < knn; ++round) {
+          uint64_t m = key[0];
+#pragma unroll
+          for (int r = 1; r < R; ++r) m = key[r] < m ? key[r] : m;
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) {
+            const uint64_t v = __shfl_xor(m, o, 64);
+            m = v < m ? v : m;
+          }
+          if (m == NONE) break;                        // fewer than knn pairs here: no bound from this tile
+          kth = m;
+          const bool pass = (uint32_t)(m >> 32) <= thr_q;    // minima ascend: the passing rounds are a prefix
+#pragma unroll
+          for (int r = 0; r < R; ++r)
+            if (key[r] == m) {                         // keys are unique: one lane, one r
+              key[r] = NONE;
+              if (pass) won[q] = (won[q] & ~(0xffu << (8 * r))) | ((uint32_t)round << (8 * r));
+            }
+          cq[q] += pass ? 1 : 0;
+        }
+        // (only when it improves on what was read: once the bounds have settled no atomic is issued)
+        if (round == knn && (uint32_t)(kth >> 32) < thr_q && lane_late == 0) atomicMin(thr + qq, (uint32_t)(kth >> 32));
+        c1 += cq[q];
+      }
+      __syncthreads();
+      // ---- 2. the refs: thread t ranks 16 of the 32 queries' distances to ref (t mod 256) ----------
+      const int t = wave * 64 + lane_late;
+      const int ref_local = t & (V2_RT - 1), qhalf = t >> 8;
+      const size_t rf2 = r0 + ref_local;
+      uint32_t bits2[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) bits2[j] = ld[(qhalf * 16 + j) * V2_RT + ref_local];
+      const uint32_t thr_r = rf2 < p.n_ref ? __hip_atomic_load(thr + rf2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      uint32_t pass2 = 0;       // bit j: candidate j is among the k smallest of the 16 and passes the bound
+      int n_valid = 0;
+      uint32_t kth2 = 0xffffffffu;
+#pragma unroll
+      for (int a = 0; a < 16; ++a) {
+        // rank of a = candidates with a smaller key; within one ref the query index orders ties, and
+        // the queries here ascend with j, so (bits, j) is the key
+        int rank = 0;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) rank += (bits2[c] < bits2[a] || (bits2[c] == bits2[a] && c < a)) ? 1 : 0;
+        const bool is = bits2[a] != 0xffffffffu;
+        n_valid += is ? 1 : 0;
+        if (is && rank < knn && bits2[a] <= thr_r) pass2 |= 1u << a;
+        if (is && rank == knn - 1) kth2 = bits2[a];
+      }
+      if (kth2 < thr_r) atomicMin(thr + rf2, kth2);
+      const int c2 = __popc(pass2);
+      int incl = c2;            // inclusive prefix of c2 over the wave
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane_late >= o) incl += v;
+      }
+      const int c2_wave = __shfl(incl, 63, 64);
+      // ---- 3. one reservation per workgroup -----------------------------------------------------------
+      uint32_t off_w = 0;
+      if (lane_late == 0) off_w = atomicAdd(lctl, (uint32_t)(c1 + c2_wave));
+      off_w = __shfl(off_w, 0, 64);
+      __syncthreads();
+      if (t == 0) {
+        const unsigned long long base = lctl[0] ? atomicAdd(&ks->count, (unsigned long long)lctl[0]) : 0ull;
+        lctl[1] = (uint32_t)base;
+        lctl[2] = (uint32_t)(base >> 32);
+      }
+      __syncthreads();
+      const unsigned long long base = (((unsigned long long)lctl[2]) << 32) | lctl[1];
+      // ---- 4. write: (sample, distance bits << 32 | the other sample) ------------------------------------
+      unsigned long long pos = base + off_w;
+#pragma unroll
+      for (int q = 0; q < TQ; ++q) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const uint32_t rnd = (won[q] >> (8 * r)) & 0xffu;
+          if (rnd != 0xffu && pos + rnd < cap) {
+            ckeys[pos + rnd] = (uint32_t)(qw0 + q);
+            cvals[pos + rnd] = ((uint64_t)knn_bits[q][r] << 32) | (uint32_t)ref_of(r);
+          }
+        }
+        pos += (unsigned long long)cq[q];
+      }
+      pos = base + off_w + (unsigned long long)c1 + (unsigned long long)(incl - c2);
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (pass2 & (1u << j)) {
+          if (pos < cap) {
+            ckeys[pos] = (uint32_t)rf2;
+            cvals[pos] = ((uint64_t)bits2[j] << 32) | (uint32_t)(q0 + qhalf * 16 + j);
+          }
+          ++pos;
+        }
+    }
     };
     epilogue(p_late);
   }
@@ -1312,9 +1481,11 @@ template <int MODE>
 int launch_tiles_packed(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const float *d_rtab,
                         void *d_out, unsigned long long *d_n_failed, uint64_t *d_mask, DistParams &p,
                         hipStream_t s) {
-  static_assert(MODE == MODE_DIST || MODE == MODE_MASK, "packed modes");
+  static_assert(MODE == MODE_DIST || MODE == MODE_MASK || MODE == MODE_KNN, "packed modes");
   const int total_bits = p.nk * p.cnt_bits;
-  if (p.bbits != 14) {
+  if constexpr (MODE == MODE_KNN) {
+    if (p.bbits != 14) return ppk_fail(PPK_ERR_ARG, "neighbours from tiles need bbits = 14 (use the square-matrix path)");
+  } else if (p.bbits != 14) {
     // the generic-bbits kernel has registers to spare and packs into plain integers
     if (total_bits <= 64)
       return launch_variant<8, 4, MODE, uint64_t>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask,
@@ -1346,7 +1517,7 @@ int ppk_launch_dist(const ppk_db *ref, const ppk_db *qry_or_null, const int32_t 
                     const float *d_rtab, size_t n_clu, int flags, size_t q_begin, size_t q_end,
                     void *d_out, unsigned long long *d_n_failed, uint64_t *d_mask, int slope,
                     float x_max, float y_max, float scale_x, float scale_y, int inclusive,
-                    double *d_lut, hipStream_t s) {
+                    double *d_lut, hipStream_t s, const int *knn_args) {
   const ppk_db *qry = qry_or_null ? qry_or_null : ref;
   DistParams p = {};
   p.self = qry_or_null ? 0 : 1;
@@ -1390,6 +1561,8 @@ int ppk_launch_dist(const ppk_db *ref, const ppk_db *qry_or_null, const int32_t 
   }
   p.lut_total = (size_t)p.n_clu * p.n_clu * p.lut_cpstride;
   p.lut32 = (p.lut_total * 16 < ((size_t)1 << 32)) ? 1 : 0;
+  p.knn = knn_args ? knn_args[0] : 0;
+  p.knn_col = knn_args ? knn_args[1] : 0;
   p.ablate = (int)ppk_config().ablate.load();
   p.ext_adjust = ppk_config().ext_collision_adjust.load() ? 1 : 0;
   p.ext_skip = ppk_config().ext_fit_skip.load() ? 1 : 0;
@@ -1406,13 +1579,14 @@ int ppk_launch_dist(const ppk_db *ref, const ppk_db *qry_or_null, const int32_t 
   // of queries): one workgroup per (tile, k) instead of per tile -- nk times the parallelism, a
   // serial chain of s64 blocks instead of nk * s64 -- writing raw counts, then the regression pass.
   bool small = false;
-  if (!too_wide && !d_mask && p.bbits == 14 && p.nk >= 2) {
+  if (!too_wide && !d_mask && !knn_args && p.bbits == 14 && p.nk >= 2) {
     const size_t rt = (ref->n + V2_RT - 1) / V2_RT, qt = (q_end - q_begin + 31) / 32;
     // default 640; measured: 2 000 self (315 tiles) 175 vs 245 us, 2 500 self (480 tiles) 255 vs 252 us, 3 000 (760) 361 vs 368
     const long long ks = ppk_config().ksplit.load();   // A/B: tile-count threshold, 0 = off
     const size_t limit = ks > 0 ? (size_t)ks : 0;
     small = (p.self ? rt * qt / 2 + qt : rt * qt) <= limit;
   }
+  if (too_wide && knn_args) return ppk_fail(PPK_ERR_ARG, "neighbours from tiles need nk * count bits <= 128");
   if (too_wide) {
     // the packed per-pair state does not fit: raw counts to scratch, then a generic regression pass
     int dev = ref->device;
@@ -1461,6 +1635,11 @@ int ppk_launch_dist(const ppk_db *ref, const ppk_db *qry_or_null, const int32_t 
                        use_clu ? qry->d_clu : nullptr, static_cast<float2 *>(d_out), d_n_failed, p);
     PPK_HIP(hipGetLastError());
     return PPK_OK;
+  }
+  if (knn_args) {
+    // d_out: candidate arrays, d_mask: KnnState + bounds (MODE_KNN); self jobs only
+    if (!p.self) return ppk_fail(PPK_ERR_ARG, "neighbours from tiles are defined for a self comparison");
+    return launch_tiles_packed<MODE_KNN>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
   }
   if (d_mask) return launch_tiles_packed<MODE_MASK>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
   return launch_tiles_packed<MODE_DIST>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);

@@ -136,6 +136,12 @@ class PpkCall {
 };
 void ppk_query_cache_clear();
 
+// neighbours from kernel 1's tiles (ppk_square.hip): state = {count, cap, vals_off} + uint32 bounds[n]
+int ppk_launch_knn_state_init(void *d_state, size_t n, unsigned long long cap, unsigned long long vals_off,
+                              int reset_bounds, hipStream_t s);
+int ppk_knn_from_candidates(int dev, const uint32_t *d_keys, const uint64_t *d_vals, size_t count, size_t n,
+                            int knn, long long *d_i, long long *d_j, float *d_dist, hipStream_t s);
+
 // spread the 32 bits of x to the even bit positions of a 64-bit word (wave-uniform: SALU)
 __device__ __forceinline__ uint64_t spread_even(uint32_t v) {
   uint64_t x = v;

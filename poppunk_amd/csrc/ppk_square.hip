@@ -309,6 +309,134 @@ extern "C" int ppk_knn_rect_dev(const float *d_block, size_t stride, size_t col,
   return PPK_OK;
 }
 
+// ---- neighbours from kernel 1's tiles: candidate lists -> k nearest ---------------------------------
+// The tile kernel (ppk_dist.hip MODE_KNN) leaves an unordered list of candidates (sample, distance
+// bits << 32 | other sample): a superset of every sample's true neighbour list, a few dozen entries
+// per sample.  They are sorted by sample (stable radix sort on the sample id alone) and one wavefront
+// per sample then selects its k smallest (distance, column) keys -- the reference's stable sort by
+// distance, ties by column index (src/extend.cpp:266-279).
+namespace {
+__global__ void __launch_bounds__(256)
+knn_state_init_kernel(unsigned long long *state, uint32_t *thr, size_t n, unsigned long long cap,
+                      unsigned long long vals_off, int reset_bounds) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) {
+    state[0] = 0;
+    state[1] = cap;
+    state[2] = vals_off;
+  }
+  if (reset_bounds && i < n) thr[i] = 0x7f800000u;      // +inf: every distance passes until a tile tightens it
+}
+
+template <int K>
+__global__ void __launch_bounds__(256)
+knn_select_sorted_kernel(const uint32_t *__restrict__ skeys, const uint64_t *__restrict__ svals,
+                         size_t count, size_t n, int knn, long long *__restrict__ oi,
+                         long long *__restrict__ oj, float *__restrict__ od) {
+  const size_t i = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const int lane = threadIdx.x & 63;
+  // [lo, hi): the candidates of sample i in the sorted list (wave-uniform binary searches)
+  size_t lo = 0, hi = count;
+  {
+    size_t a = 0, b = count;
+    while (a < b) {
+      const size_t mid = (a + b) >> 1;
+      if (skeys[mid] < (uint32_t)i) a = mid + 1;
+      else b = mid;
+    }
+    lo = a;
+    b = count;
+    while (a < b) {
+      const size_t mid = (a + b) >> 1;
+      if (skeys[mid] <= (uint32_t)i) a = mid + 1;
+      else b = mid;
+    }
+    hi = a;
+  }
+  constexpr uint64_t NONE = ~0ull;
+  uint64_t best[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) best[j] = NONE;
+  for (size_t c = lo + lane; c < hi; c += 64) {
+    uint64_t x = svals[c];
+    if (x < best[K - 1]) {
+#pragma unroll
+      for (int j = 0; j < K; ++j) {      // bubble x through the sorted list
+        const uint64_t b = best[j];
+        const bool lt = x < b;
+        best[j] = lt ? x : b;
+        x = lt ? b : x;
+      }
+    }
+  }
+  for (int r = 0; r < knn; ++r) {
+    uint64_t m = best[0];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint64_t v = __shfl_xor(m, o, 64);
+      m = v < m ? v : m;
+    }
+    if (m == NONE) {
+      // fewer than knn other samples: the reference leaves i in i_vec and zeros elsewhere
+      for (int k = r + lane; k < knn; k += 64) {
+        oi[i * knn + k] = (long long)i;
+        oj[i * knn + k] = 0;
+        od[i * knn + k] = 0.0f;
+      }
+      break;
+    }
+    if (best[0] == m) {                   // keys are unique (one candidate per pair and role): one lane
+      oi[i * knn + r] = (long long)i;
+      oj[i * knn + r] = (long long)(m & 0xffffffffull);
+      od[i * knn + r] = __uint_as_float((unsigned)(m >> 32));
+#pragma unroll
+      for (int j = 0; j + 1 < K; ++j) best[j] = best[j + 1];
+      best[K - 1] = NONE;
+    }
+  }
+}
+}  // namespace
+
+int ppk_launch_knn_state_init(void *d_state, size_t n, unsigned long long cap, unsigned long long vals_off,
+                              int reset_bounds, hipStream_t s) {
+  unsigned long long *st = static_cast<unsigned long long *>(d_state);
+  hipLaunchKernelGGL(knn_state_init_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, s, st,
+                     reinterpret_cast<uint32_t *>(st + 3), n, cap, vals_off, reset_bounds);
+  PPK_HIP(hipGetLastError());
+  return PPK_OK;
+}
+
+// keys/vals: `count` candidates; sorted copies and the sort's workspace come from SLOT_ITER_C
+int ppk_knn_from_candidates(int dev, const uint32_t *d_keys, const uint64_t *d_vals, size_t count, size_t n,
+                            int knn, long long *d_i, long long *d_j, float *d_dist, hipStream_t s) {
+  if (knn > 32) return ppk_fail(PPK_ERR_ARG, "neighbours from tiles: at most 32 neighbours per sample");
+  if (count >= (size_t)0x7fffffff) return ppk_fail(PPK_ERR_ARG, "too many neighbour candidates for one sort");
+  const size_t o_keys = 0, o_vals = (count * 4 + 255) & ~(size_t)255, o_tmp = o_vals + ((count * 8 + 255) & ~(size_t)255);
+  int end_bit = 1;
+  while (((size_t)1 << end_bit) < n && end_bit < 32) ++end_bit;
+  size_t tmp = 0;
+  uint32_t *nk = nullptr;
+  uint64_t *nv = nullptr;
+  PPK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, d_keys, nk, d_vals, nv, (int)count, 0, end_bit, s));
+  void *p_c = nullptr;
+  int rc = ppk_scratch_get(dev, SLOT_ITER_C, o_tmp + tmp + 256, &p_c);
+  if (rc != PPK_OK) return rc;
+  char *C = static_cast<char *>(p_c);
+  uint32_t *skeys = reinterpret_cast<uint32_t *>(C + o_keys);
+  uint64_t *svals = reinterpret_cast<uint64_t *>(C + o_vals);
+  if (count)
+    PPK_HIP(hipcub::DeviceRadixSort::SortPairs(C + o_tmp, tmp, d_keys, skeys, d_vals, svals, (int)count, 0,
+                                               end_bit, s));
+  const dim3 grid((unsigned)((n + 3) / 4));
+  if (knn <= 8)
+    hipLaunchKernelGGL(knn_select_sorted_kernel<8>, grid, dim3(256), 0, s, skeys, svals, count, n, knn, d_i, d_j, d_dist);
+  else
+    hipLaunchKernelGGL(knn_select_sorted_kernel<32>, grid, dim3(256), 0, s, skeys, svals, count, n, knn, d_i, d_j, d_dist);
+  PPK_HIP(hipGetLastError());
+  return PPK_OK;
+}
+
 extern "C" int ppk_knn_dev(const float *d_square, size_t n, int knn, long long *d_i, long long *d_j,
                            float *d_dist, void *stream) {
   return ppk_knn_rect_dev(d_square, 1, 0, n, n, 0, knn, d_i, d_j, d_dist, stream);

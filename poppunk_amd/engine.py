@@ -393,15 +393,19 @@ def prune_query_rows_dev(qr_t, n_ref, keep_q):
 
 
 def knn_from_sketches(db, kmers, random_tbl, knn, dist_col=0, random_correct=True,
-                      band_items=1 << 31):
+                      band_items=1 << 31, method="auto", info=None):
     """k nearest neighbours of every sample straight from the resident sketches (what
     get_kNN_distances(longToSquare(queryDatabase(...)[:, dist_col])) gives, PopPUNK/models.py:
     1215-1222), entirely on the device.  Returns CUDA tensors (i, j, dist) of length n*knn.
 
-    While n*n <= band_items (n <= 46 340 by default: 8 n^2 bytes of HBM) the upper triangle is
-    computed once, expanded to the square matrix and the neighbours selected from its rows.
-    Beyond that, bands of query rows are computed against all refs (row = q*n + r, both triangles:
-    twice the compare work, but only one band of the matrix exists at a time)."""
+    method "tiles" (the default where it applies: bbits 14, knn <= 32, packed counts <= 128 bits):
+        kernel 1's tiles emit neighbour candidates under per-sample bounds and a sort + selection
+        pass finishes (ppk_knn_sketches_dev): the upper triangle is compared once and no distance
+        matrix -- long or square -- is ever built.  `info` (a dict) receives the candidate count.
+    method "square": upper triangle -> n x n square -> per-row selection (8 n^2 bytes of HBM).
+    method "bands":  bands of query rows against all refs (row = q*n + r; both triangles: twice the
+        compare work, one band of the matrix at a time).
+    "auto" falls back to "square" while n*n <= band_items, else "bands", where "tiles" does not apply."""
     torch = _torch()
     lib = _lib.lib()
     n = db.n
@@ -409,7 +413,25 @@ def knn_from_sketches(db, kmers, random_tbl, knn, dist_col=0, random_correct=Tru
     oi = torch.empty(n * knn, dtype=torch.int64, device=dev)
     oj = torch.empty(n * knn, dtype=torch.int64, device=dev)
     od = torch.empty(n * knn, dtype=torch.float32, device=dev)
-    if n * n <= band_items and n > 1:
+    if method == "auto":
+        bits = 1
+        while (1 << bits) <= 64 * db.sketchsize64:
+            bits += 1
+        tiles_ok = db.bbits == 14 and 1 <= knn <= 32 and db.nk * bits <= 128 and db.nk <= 32 and n > 1
+        method = "tiles" if tiles_ok else ("square" if n * n <= band_items else "bands")
+    if method == "tiles":
+        kmers_a, random_tbl, tbl_ptr, n_clu = _prep_tables(kmers, random_tbl, db.nk)
+        n_cand = C.c_ulonglong(0)
+        with torch.cuda.device(db.device):
+            rc = lib.ppk_knn_sketches_dev(db._h, kmers_a.ctypes.data_as(C.POINTER(C.c_int32)), tbl_ptr, n_clu,
+                                          FLAG_RANDOM_CORRECT if random_correct else 0, int(knn), int(dist_col),
+                                          C.c_void_p(oi.data_ptr()), C.c_void_p(oj.data_ptr()),
+                                          C.c_void_p(od.data_ptr()), C.byref(n_cand), _stream_ptr(db.device))
+            _lib.check(rc, "ppk_knn_sketches_dev")
+        if info is not None:
+            info["candidates"] = int(n_cand.value)
+        return oi, oj, od
+    if method == "square" and n > 1:
         with torch.cuda.device(db.device):
             tri, _ = dist(db, None, kmers, random_tbl, random_correct=random_correct)
             sq = long_to_square_dev(tri, dist_col, n)

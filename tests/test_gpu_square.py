@@ -66,13 +66,64 @@ def test_knn_straight_from_sketches():
     for col, k in ((0, 5), (1, 3)):
         sq = oracle.long_to_square(dist[:, col])
         wi, wj, wd = oracle.knn(sq, k)
-        for band_items in (500 * 128, 1 << 31):      # band by band / triangle -> square -> select
-            gi, gj, gd = engine.knn_from_sketches(db, kmers, tbl, k, dist_col=col, band_items=band_items)
-            assert np.array_equal(gi.cpu().numpy(), wi)
-            assert np.array_equal(gd.cpu().numpy(), wd)
+        for method, band_items in (("bands", 500 * 128), ("square", 1 << 31), ("tiles", 0)):
+            gi, gj, gd = engine.knn_from_sketches(db, kmers, tbl, k, dist_col=col, band_items=band_items,
+                                                  method=method)
+            assert np.array_equal(gi.cpu().numpy(), wi), method
+            assert np.array_equal(gd.cpu().numpy(), wd), method
             # ties between equal distances resolve by column index in both
-            assert np.array_equal(gj.cpu().numpy(), wj)
+            assert np.array_equal(gj.cpu().numpy(), wj), method
     db.close()
+
+
+@pytest.mark.parametrize("n,related", [(3000, True), (2300, False), (257, True), (40, True)])
+def test_knn_from_tiles_equals_oracle(n, related):
+    """Neighbours straight from kernel 1's tiles (MODE_KNN: candidates under tightening per-sample
+    bounds, then sort + select) == get_kNN_distances(longToSquare(.)) of the oracle's distances, at a
+    size with a dozen ref tiles, diagonal half tiles and a ragged edge; unrelated clusters give
+    masses of failed fits (distance 0.0: ties everywhere, resolved by column index); tiny n leaves
+    slots unfilled like the reference."""
+    from poppunk_amd import engine, synth
+    kmers = np.asarray(synth.DEFAULT_KMERS, dtype=np.int32)
+    sk, _ = synth.make_sketches(n, kmers, cluster_size=37, seed=n, related=related)
+    tbl = synth.random_match_table(kmers)
+    want, _ = oracle.query(sk, None, kmers, 16, 14, tbl, threads=16)
+    db = engine.SketchDB(sk, 16, 14)
+    for col, k in ((0, 5), (1, 1), (0, 32)):
+        sq = oracle.long_to_square(want[:, col])
+        wi, wj, wd = oracle.knn(sq, k)
+        info = {}
+        gi, gj, gd = engine.knn_from_sketches(db, kmers, tbl, k, dist_col=col, method="tiles", info=info)
+        assert np.array_equal(gi.cpu().numpy(), wi)
+        gd, gj = gd.cpu().numpy(), gj.cpu().numpy()
+        # distances within the regression tolerance; where they are bit-equal (all but a handful of
+        # rows) the neighbour order -- ties by column index -- is the reference's
+        assert np.abs(gd - wd).max() <= 1e-6
+        same = gd == wd
+        assert same.mean() > 0.999 and np.array_equal(gj[same], wj[same])
+        assert 0 < info["candidates"] <= n * (n - 1)
+    db.close()
+
+
+def test_knn_from_tiles_at_50000_without_any_matrix():
+    """n = 50 000 (beyond the 46 340 where the square stops fitting the default budget): the tile path
+    equals the band-by-band path -- which computes both triangles -- neighbour for neighbour, from a
+    few dozen candidates per sample instead of n."""
+    import torch
+    from poppunk_amd import engine, synth
+    kmers = np.asarray(synth.DEFAULT_KMERS, dtype=np.int32)
+    t = synth.make_sketches_device(50000, kmers, seed=50, device="cuda:0")
+    db = engine.SketchDB(t, 16, 14)
+    del t
+    tbl = synth.random_match_table(kmers)
+    info = {}
+    ti, tj, td = engine.knn_from_sketches(db, kmers, tbl, 5, method="tiles", info=info)
+    bi, bj, bd = engine.knn_from_sketches(db, kmers, tbl, 5, method="bands")
+    assert torch.equal(ti, bi) and torch.equal(td, bd) and torch.equal(tj, bj)
+    assert info["candidates"] < 50000 * 1000         # vs 2.5e9 pair-roles
+    print("50 000 samples, k = 5: %d candidates (%.1f per sample)" % (info["candidates"], info["candidates"] / 50000))
+    db.close()
+    torch.cuda.empty_cache()
 
 
 def test_prune_distance_matrix_golden_and_random(tmp_path, capsys):
