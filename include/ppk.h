@@ -179,7 +179,8 @@ int ppk_qc_edges_dev(const float *d_dist, size_t n_rows, size_t n_ref, int mode,
  * three int64 arrays (i, j, offset index), element for element the vectors
  * the reference returns; *d_n_out receives the total (only the first cap
  * entries are stored).  These two entry points synchronise the stream once
- * (the intermediate candidate count sizes a sort).
+ * (the intermediate candidate count sizes a sort).  At most 1023 offsets per call (the
+ * reference's callers pass 40 and 20; its loops have no limit).
  */
 /* replaces poppunk_refine.thresholdIterate1D (src/python_bindings.cpp:49-60;
  * src/boundary.cpp:154-210; caller PopPUNK/refine.py:190-200).  `offsets`
@@ -234,7 +235,10 @@ int ppk_assign_threshold(const float *dist, size_t n_rows, int slope, float x_ma
                          float y_max, int device_id, float *out);
 
 /* Edge lists have a data-dependent size: *n_edges always receives the total;
- * PPK_ERR_CAPACITY is returned when it exceeds cap (nothing is written). */
+ * PPK_ERR_CAPACITY is returned when it exceeds cap (nothing is written).  The call that reports
+ * PPK_ERR_CAPACITY has already computed the whole list: it stays parked on the device, and the next
+ * call with the same arguments and enough room only copies it out -- "ask the size, then fetch" costs
+ * one upload and one device pass (also for the two sweeps below). */
 int ppk_edge_threshold(const float *dist, size_t n_rows, size_t n_ref, int slope,
                        float x_max, float y_max, int inclusive, int device_id,
                        long long *ij_out, size_t cap, size_t *n_edges);

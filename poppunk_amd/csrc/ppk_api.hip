@@ -2,6 +2,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <vector>
 
@@ -464,6 +465,7 @@ PpkCall::~PpkCall() {
 
 extern "C" int ppk_release_scratch(void) {
   ppk_query_cache_clear();
+  ppk_parked_clear();
   for (int d = 0; d < 64; ++d) {
     std::lock_guard<std::recursive_mutex> lk(g_dev[d].mu);
     bool any = false;
@@ -1165,39 +1167,88 @@ extern "C" int ppk_assign_threshold(const float *dist, size_t n_rows, int slope,
   return rc;
 }
 
-namespace {
-// Shared tail of the host edge wrappers: run `enqueue` twice at most -- the
-// edge count is data dependent, so first with cap 0 (count only), then, if the
-// caller's buffer is big enough, again into a device buffer of exactly that size.
-template <typename F>
-int host_edges(int device_id, long long *ij_out, size_t cap, size_t *n_edges, F enqueue) {
-  if (!n_edges) return ppk_fail(PPK_ERR_ARG, "n_edges is NULL");
-  unsigned long long *d_n = nullptr;
-  PPK_HIP(hipMalloc(reinterpret_cast<void **>(&d_n), sizeof(unsigned long long)));
-  int rc = enqueue(nullptr, 0, d_n);
-  unsigned long long n = 0;
-  if (rc == PPK_OK && hipMemcpy(&n, d_n, sizeof(n), hipMemcpyDeviceToHost) != hipSuccess)
-    rc = ppk_fail(PPK_ERR_HIP, "hipMemcpy D2H failed");
-  if (rc == PPK_OK) {
-    *n_edges = (size_t)n;
-    if (n > cap) {
-      rc = ppk_fail(PPK_ERR_CAPACITY, "edge buffer too small: need " + std::to_string(n));
-    } else if (n > 0) {
-      if (!ij_out) rc = ppk_fail(PPK_ERR_ARG, "ij_out is NULL");
-      long long *d_e = nullptr;
-      if (rc == PPK_OK && hipMalloc(reinterpret_cast<void **>(&d_e), n * 16) != hipSuccess)
-        rc = ppk_fail(PPK_ERR_HIP, "hipMalloc(edges) failed");
-      if (rc == PPK_OK) rc = enqueue(d_e, (size_t)n, d_n);
-      if (rc == PPK_OK && hipMemcpy(ij_out, d_e, n * 16, hipMemcpyDeviceToHost) != hipSuccess)
-        rc = ppk_fail(PPK_ERR_HIP, "hipMemcpy D2H failed");
-      if (d_e) (void)hipFree(d_e);
-    }
+// ---- host edge lists: data-dependent size, ONE pass ---------------------------------------------
+// The Python / pybind side cannot know the size of an edge list in advance and calls twice: once to
+// learn it, once with a buffer of that size.  The first call already computes the whole list into a
+// device buffer (capacity guessed; a second device pass only if the guess was too small); when the
+// caller's buffer is too small the result stays parked on the device under a token of the call's
+// inputs, and the second call -- same inputs, enough room -- only copies it out: one upload, one pass.
+struct ParkedResult {
+  uint64_t token = 0;
+  int device = -1;
+  void *d = nullptr;
+  size_t n = 0, cap_used = 0;     // entries wanted / capacity the buffer was computed with
+};
+static std::mutex g_parked_mu;
+static ParkedResult g_parked[2];          // [0] edge lists (this file), [1] sweeps (ppk_iterate.hip)
+
+uint64_t ppk_token(const void *bytes, size_t len, uint64_t seed) {
+  const unsigned char *b = static_cast<const unsigned char *>(bytes);
+  uint64_t h = 1469598103934665603ull ^ seed;
+  for (size_t i = 0; i < len; ++i) h = (h ^ b[i]) * 1099511628211ull;
+  return h ? h : 1;
+}
+
+void ppk_parked_drop_locked(int slot) {
+  ParkedResult &p = g_parked[slot];
+  if (p.d) {
+    DeviceGuard g(p.device);
+    (void)hipFree(p.d);
   }
-  (void)hipFree(d_n);
-  (void)device_id;
+  p = ParkedResult();
+}
+
+// compute(cap_entries, &d_result, &n): runs the whole job into a fresh device buffer of cap entries
+// (allocated by compute), n = total entries it wanted to write.  copy_out(d_result, n, cap_used):
+// device -> the caller's arrays.
+int ppk_host_result(int slot, uint64_t token, int device, size_t guess, size_t cap, size_t *n_out,
+                    const std::function<int(size_t, void **, unsigned long long *)> &compute,
+                    const std::function<int(const void *, size_t, size_t)> &copy_out) {
+  std::lock_guard<std::mutex> lk(g_parked_mu);
+  ParkedResult &pk = g_parked[slot];
+  void *d = nullptr;
+  size_t n = 0, cap_used = 0;
+  if (pk.d && pk.token == token && pk.device == device) {
+    d = pk.d;
+    n = pk.n;
+    cap_used = pk.cap_used;
+    pk = ParkedResult();
+  } else {
+    ppk_parked_drop_locked(slot);
+    unsigned long long want = 0;
+    cap_used = guess ? guess : 1;
+    int rc = compute(cap_used, &d, &want);
+    if (rc == PPK_OK && want > cap_used) {          // the guess was too small: once more with the exact size
+      if (d) (void)hipFree(d);
+      d = nullptr;
+      cap_used = (size_t)want;
+      rc = compute(cap_used, &d, &want);
+    }
+    if (rc != PPK_OK) {
+      if (d) (void)hipFree(d);
+      return rc;
+    }
+    n = (size_t)want;
+  }
+  *n_out = n;
+  if (n > cap) {
+    pk.token = token;
+    pk.device = device;
+    pk.d = d;
+    pk.n = n;
+    pk.cap_used = cap_used;
+    return ppk_fail(PPK_ERR_CAPACITY, "output too small: need " + std::to_string(n));
+  }
+  int rc = n > 0 ? copy_out(d, n, cap_used) : PPK_OK;
+  if (d) (void)hipFree(d);
   return rc;
 }
-}  // namespace
+
+void ppk_parked_clear() {
+  std::lock_guard<std::mutex> lk(g_parked_mu);
+  ppk_parked_drop_locked(0);
+  ppk_parked_drop_locked(1);
+}
 
 extern "C" int ppk_edge_threshold(const float *dist, size_t n_rows, size_t n_ref, int slope,
                                   float x_max, float y_max, int inclusive, int device_id,
@@ -1205,21 +1256,38 @@ extern "C" int ppk_edge_threshold(const float *dist, size_t n_rows, size_t n_ref
   if (n_edges) *n_edges = 0;
   if (n_rows == 0) return PPK_OK;
   if (!dist) return ppk_fail(PPK_ERR_ARG, "dist is NULL");
+  if (!n_edges) return ppk_fail(PPK_ERR_ARG, "n_edges is NULL");
   DeviceGuard guard(device_id);
   if (!guard.ok) return ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(device_id));
-  float *d_dist = nullptr;
-  PPK_HIP(hipMalloc(reinterpret_cast<void **>(&d_dist), n_rows * 8));
-  int rc = PPK_OK;
-  if (hipMemcpy(d_dist, dist, n_rows * 8, hipMemcpyHostToDevice) != hipSuccess)
-    rc = ppk_fail(PPK_ERR_HIP, "hipMemcpy H2D failed");
-  if (rc == PPK_OK)
-    rc = host_edges(device_id, ij_out, cap, n_edges,
-                    [&](long long *d_e, size_t c, unsigned long long *d_n) {
-                      return ppk_edge_threshold_dev(d_dist, n_rows, n_ref, slope, x_max, y_max,
-                                                    inclusive, d_e, c, d_n, nullptr);
-                    });
-  (void)hipFree(d_dist);
-  return rc;
+  struct { const void *p; size_t rows, n_ref; int slope, incl; float x, y; } key = {dist, n_rows, n_ref, slope, inclusive, x_max, y_max};
+  size_t guess = n_rows / 8 > ((size_t)1 << 20) ? n_rows / 8 : ((size_t)1 << 20);
+  if (guess > n_rows) guess = n_rows;
+  auto copy_out = [&](const void *d, size_t n, size_t) {
+    if (!ij_out) return ppk_fail(PPK_ERR_ARG, "ij_out is NULL");
+    if (hipMemcpy(ij_out, d, n * 16, hipMemcpyDeviceToHost) != hipSuccess) return ppk_fail(PPK_ERR_HIP, "hipMemcpy D2H failed");
+    return (int)PPK_OK;
+  };
+  return ppk_host_result(0, ppk_token(&key, sizeof(key), 1), device_id, guess, cap, n_edges,
+                         [&](size_t c, void **d_res, unsigned long long *want) {
+                           float *d_dist = nullptr;
+                           unsigned long long *d_n = nullptr;
+                           int rc = PPK_OK;
+                           if (hipMalloc(reinterpret_cast<void **>(&d_dist), n_rows * 8) != hipSuccess ||
+                               hipMalloc(reinterpret_cast<void **>(&d_n), 8) != hipSuccess ||
+                               hipMalloc(d_res, (c ? c : 1) * 16) != hipSuccess)
+                             rc = ppk_fail(PPK_ERR_HIP, "hipMalloc failed");
+                           if (rc == PPK_OK && hipMemcpy(d_dist, dist, n_rows * 8, hipMemcpyHostToDevice) != hipSuccess)
+                             rc = ppk_fail(PPK_ERR_HIP, "hipMemcpy H2D failed");
+                           if (rc == PPK_OK)
+                             rc = ppk_edge_threshold_dev(d_dist, n_rows, n_ref, slope, x_max, y_max, inclusive,
+                                                         static_cast<long long *>(*d_res), c, d_n, nullptr);
+                           if (rc == PPK_OK && hipMemcpy(want, d_n, 8, hipMemcpyDeviceToHost) != hipSuccess)
+                             rc = ppk_fail(PPK_ERR_HIP, "hipMemcpy D2H failed");
+                           if (d_dist) (void)hipFree(d_dist);
+                           if (d_n) (void)hipFree(d_n);
+                           return rc;
+                         },
+                         copy_out);
 }
 
 extern "C" int ppk_generate_tuples(const int32_t *assignments, size_t n_rows, int within_label,
@@ -1228,19 +1296,36 @@ extern "C" int ppk_generate_tuples(const int32_t *assignments, size_t n_rows, in
   if (n_edges) *n_edges = 0;
   if (n_rows == 0) return PPK_OK;
   if (!assignments) return ppk_fail(PPK_ERR_ARG, "assignments is NULL");
+  if (!n_edges) return ppk_fail(PPK_ERR_ARG, "n_edges is NULL");
   DeviceGuard guard(device_id);
   if (!guard.ok) return ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(device_id));
-  int32_t *d_a = nullptr;
-  PPK_HIP(hipMalloc(reinterpret_cast<void **>(&d_a), n_rows * 4));
-  int rc = PPK_OK;
-  if (hipMemcpy(d_a, assignments, n_rows * 4, hipMemcpyHostToDevice) != hipSuccess)
-    rc = ppk_fail(PPK_ERR_HIP, "hipMemcpy H2D failed");
-  if (rc == PPK_OK)
-    rc = host_edges(device_id, ij_out, cap, n_edges,
-                    [&](long long *d_e, size_t c, unsigned long long *d_n) {
-                      return ppk_generate_tuples_dev(d_a, n_rows, within_label, self, num_ref,
-                                                     int_offset, d_e, c, d_n, nullptr);
-                    });
-  (void)hipFree(d_a);
-  return rc;
+  struct { const void *p; size_t rows, num_ref; int label, self; long long off; } key = {assignments, n_rows, num_ref, within_label, self, int_offset};
+  size_t guess = n_rows / 8 > ((size_t)1 << 20) ? n_rows / 8 : ((size_t)1 << 20);
+  if (guess > n_rows) guess = n_rows;
+  auto copy_out = [&](const void *d, size_t n, size_t) {
+    if (!ij_out) return ppk_fail(PPK_ERR_ARG, "ij_out is NULL");
+    if (hipMemcpy(ij_out, d, n * 16, hipMemcpyDeviceToHost) != hipSuccess) return ppk_fail(PPK_ERR_HIP, "hipMemcpy D2H failed");
+    return (int)PPK_OK;
+  };
+  return ppk_host_result(0, ppk_token(&key, sizeof(key), 2), device_id, guess, cap, n_edges,
+                         [&](size_t c, void **d_res, unsigned long long *want) {
+                           int32_t *d_a = nullptr;
+                           unsigned long long *d_n = nullptr;
+                           int rc = PPK_OK;
+                           if (hipMalloc(reinterpret_cast<void **>(&d_a), n_rows * 4) != hipSuccess ||
+                               hipMalloc(reinterpret_cast<void **>(&d_n), 8) != hipSuccess ||
+                               hipMalloc(d_res, (c ? c : 1) * 16) != hipSuccess)
+                             rc = ppk_fail(PPK_ERR_HIP, "hipMalloc failed");
+                           if (rc == PPK_OK && hipMemcpy(d_a, assignments, n_rows * 4, hipMemcpyHostToDevice) != hipSuccess)
+                             rc = ppk_fail(PPK_ERR_HIP, "hipMemcpy H2D failed");
+                           if (rc == PPK_OK)
+                             rc = ppk_generate_tuples_dev(d_a, n_rows, within_label, self, num_ref, int_offset,
+                                                          static_cast<long long *>(*d_res), c, d_n, nullptr);
+                           if (rc == PPK_OK && hipMemcpy(want, d_n, 8, hipMemcpyDeviceToHost) != hipSuccess)
+                             rc = ppk_fail(PPK_ERR_HIP, "hipMemcpy D2H failed");
+                           if (d_a) (void)hipFree(d_a);
+                           if (d_n) (void)hipFree(d_n);
+                           return rc;
+                         },
+                         copy_out);
 }

@@ -5,6 +5,7 @@
 #include <sys/mman.h>
 
 #include <atomic>
+#include <functional>
 #include <cstdlib>
 #include <thread>
 #include <vector>
@@ -135,6 +136,13 @@ class PpkCall {
   unsigned prev_touched_;
 };
 void ppk_query_cache_clear();
+// host entry points with a data-dependent result size (ppk_api.hip): one pass, result parked on the
+// device between the caller's size query and its fetch
+uint64_t ppk_token(const void *bytes, size_t len, uint64_t seed);
+int ppk_host_result(int slot, uint64_t token, int device, size_t guess, size_t cap, size_t *n_out,
+                    const std::function<int(size_t, void **, unsigned long long *)> &compute,
+                    const std::function<int(const void *, size_t, size_t)> &copy_out);
+void ppk_parked_clear();
 
 // neighbours from kernel 1's tiles (ppk_square.hip): state = {count, cap, vals_off} + uint32 bounds[n]
 int ppk_launch_knn_state_init(void *d_state, size_t n, unsigned long long cap, unsigned long long vals_off,

@@ -28,13 +28,13 @@
 
 namespace {
 
-constexpr int kMaxOff = 256;
+// offsets per call: the sweep's sort carries a row's first offset in 10 bits of its 64-bit value
+constexpr int kMaxOff = 1023;
 
 struct Boundaries {
   int n;
   int slope;
-  float x_max[kMaxOff];
-  float y_max[kMaxOff];
+  const float2 *xy;      // device: (x_max, y_max) of every offset's boundary
 };
 
 // order-preserving float <-> uint32 (for atomicMax on floats)
@@ -53,7 +53,7 @@ ti1_classify_kernel(const float2 *__restrict__ dist, size_t n_rows, const Bounda
   // the boundaries live in LDS: indexing the by-value struct with a runtime o is a dependent
   // scalar load per boundary per row
   __shared__ float2 sb[kMaxOff];
-  for (int o = threadIdx.x; o < b.n; o += 256) sb[o] = make_float2(b.x_max[o], b.y_max[o]);
+  for (int o = threadIdx.x; o < b.n; o += 256) sb[o] = b.xy[o];
   __syncthreads();
   const size_t stride = (size_t)gridDim.x * 256;
   unsigned local = 0;  // f2ord of -inf-ish: 0 is below every real value's code
@@ -200,7 +200,7 @@ __global__ void ti1_serial_kernel(const unsigned long long *__restrict__ sorted_
     while (p < n_cand) {
       const size_t row = sorted_rows[p] & ((1ull << 54) - 1);
       const float2 d = dist[row];
-      if (!(ppk_line_dist(d.x, d.y, b.x_max[o], b.y_max[o], b.slope) <= 0.0f)) break;
+      if (!(ppk_line_dist(d.x, d.y, b.xy[o].x, b.xy[o].y, b.slope) <= 0.0f)) break;
       if (p < cap) {
         const size_t i = crow_idx(row, n_samples);
         oi[p] = (long long)i;
@@ -231,11 +231,11 @@ ti2_mask_kernel(const float2 *__restrict__ dist, size_t n_rows, const Boundaries
     const bool in = row < n_rows;
     if (in) d = dist[row];
     for (int o = 0; o < b.n; ++o) {
-      const float s = ppk_line_dist(d.x, d.y, b.x_max[o], b.y_max[0], 2);
+      const float s = ppk_line_dist(d.x, d.y, b.xy[o].x, b.xy[0].y, 2);
       const bool within = s <= 0.0f;
       // boundary.cpp:221-226: within boundary o, and (o == 0 or line_dist(o-1) > 0)
       bool prev_out = true;
-      if (o > 0) prev_out = ppk_line_dist(d.x, d.y, b.x_max[o - 1], b.y_max[0], 2) > 0.0f;
+      if (o > 0) prev_out = ppk_line_dist(d.x, d.y, b.xy[o - 1].x, b.xy[0].y, 2) > 0.0f;
       const uint64_t bits = __ballot(in && within && prev_out);
       if (lane == 0) mask[(size_t)o * n_words + w] = bits;
     }
@@ -261,7 +261,7 @@ extern "C" int ppk_threshold_iterate_1d_dev(const float *d_dist, size_t n_rows,
                                             void *stream) {
   if (!d_n_out) return ppk_fail(PPK_ERR_ARG, "d_n_out is NULL");
   if (slope < 0 || slope > 2) return ppk_fail(PPK_ERR_ARG, "slope must be 0, 1 or 2");
-  if (n_off > (size_t)kMaxOff) return ppk_fail(PPK_ERR_ARG, "too many offsets (max 256)");
+  if (n_off > (size_t)kMaxOff) return ppk_fail(PPK_ERR_ARG, "too many offsets (max 1023 per call)");
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (n_rows == 0 || n_off == 0) {
     PPK_HIP(hipMemsetAsync(d_n_out, 0, sizeof(unsigned long long), s));
@@ -276,6 +276,7 @@ extern "C" int ppk_threshold_iterate_1d_dev(const float *d_dist, size_t n_rows,
   if (n_rows >= (size_t)0x7fffffff * 64) return ppk_fail(PPK_ERR_ARG, "too many rows");
 
   // boundaries, with the arithmetic of boundary.cpp:161-186 (float/double mix kept as is)
+  std::vector<float2> bxy(n_off);
   Boundaries b = {};
   b.n = (int)n_off;
   b.slope = slope;
@@ -286,20 +287,27 @@ extern "C" int ppk_threshold_iterate_1d_dev(const float *d_dist, size_t n_rows,
     const float x_int = (float)((double)x0 + offsets[o] * (double)(dx / ds));
     const float y_int = (float)((double)y0 + offsets[o] * (double)(dy / ds));
     if (slope == 2) {
-      b.x_max[o] = x_int + y_int * gradient;
-      b.y_max[o] = y_int + x_int / gradient;
+      bxy[o].x = x_int + y_int * gradient;
+      bxy[o].y = y_int + x_int / gradient;
     } else if (slope == 0) {
-      b.x_max[o] = x_int;
-      b.y_max[o] = 0;
+      bxy[o].x = x_int;
+      bxy[o].y = 0;
     } else {
-      b.x_max[o] = 0;
-      b.y_max[o] = y_int;
+      bxy[o].x = 0;
+      bxy[o].y = y_int;
     }
   }
 
   int dev = 0;
   PPK_HIP(hipGetDevice(&dev));
   PpkCall call(dev, s);
+  {
+    void *p_b = nullptr;     // the boundaries live in the (otherwise unused here) table slot
+    int rcb = ppk_scratch_get(dev, SLOT_LUT, n_off * sizeof(float2) + 256, &p_b);
+    if (rcb != PPK_OK) return rcb;
+    PPK_HIP(hipMemcpyAsync(p_b, bxy.data(), n_off * sizeof(float2), hipMemcpyHostToDevice, s));
+    b.xy = static_cast<const float2 *>(p_b);
+  }
   const size_t n_words = ppk_mask_words_linear(n_rows);
   void *p_a = nullptr, *p_mask = nullptr, *p_ws = nullptr;
   // A: d0 (float) | first (u16) | max_ord (u32) | g (u64 x n_off)
@@ -385,7 +393,7 @@ extern "C" int ppk_threshold_iterate_2d_dev(const float *d_dist, size_t n_rows, 
                                             long long *d_j, long long *d_off, size_t cap,
                                             unsigned long long *d_n_out, void *stream) {
   if (!d_n_out) return ppk_fail(PPK_ERR_ARG, "d_n_out is NULL");
-  if (n_off > (size_t)kMaxOff) return ppk_fail(PPK_ERR_ARG, "too many offsets (max 256)");
+  if (n_off > (size_t)kMaxOff) return ppk_fail(PPK_ERR_ARG, "too many offsets (max 1023 per call)");
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (n_rows == 0 || n_off == 0) {
     PPK_HIP(hipMemsetAsync(d_n_out, 0, sizeof(unsigned long long), s));
@@ -397,16 +405,21 @@ extern "C" int ppk_threshold_iterate_2d_dev(const float *d_dist, size_t n_rows, 
   const size_t n_samples = samples_of(n_rows);
   if (n_samples * (n_samples - 1) / 2 != n_rows)
     return ppk_fail(PPK_ERR_ARG, "row count is not n(n-1)/2 for any n (self/condensed matrix expected)");
+  std::vector<float2> bxy(n_off);
   Boundaries b = {};
   b.n = (int)n_off;
   b.slope = 2;
-  for (size_t o = 0; o < n_off; ++o) {
-    b.x_max[o] = x_max[o];
-    b.y_max[o] = y_max;
-  }
+  for (size_t o = 0; o < n_off; ++o) bxy[o] = make_float2(x_max[o], y_max);
   int dev = 0;
   PPK_HIP(hipGetDevice(&dev));
   PpkCall call(dev, s);
+  {
+    void *p_b = nullptr;
+    int rcb = ppk_scratch_get(dev, SLOT_LUT, n_off * sizeof(float2) + 256, &p_b);
+    if (rcb != PPK_OK) return rcb;
+    PPK_HIP(hipMemcpyAsync(p_b, bxy.data(), n_off * sizeof(float2), hipMemcpyHostToDevice, s));
+    b.xy = static_cast<const float2 *>(p_b);
+  }
   const size_t n_words = ppk_mask_words_linear(n_rows);
   const size_t tot_words = n_words * n_off;
   void *p_mask = nullptr, *p_ws = nullptr;
@@ -429,47 +442,47 @@ extern "C" int ppk_threshold_iterate_2d_dev(const float *d_dist, size_t n_rows, 
 
 // ---- host-buffer wrappers (what the pybind functions of python_bindings.cpp:49-73 bind) ----
 namespace {
+// One upload, one device pass (ppk_host_result, ppk_api.hip): the result is computed into a device
+// buffer of guessed capacity and, when the caller's arrays are too small, parked there until the
+// caller comes back with room.  Layout on the device: [3][cap_used] (i, j, offset index).
 template <typename F>
-int host_coo(const float *dist, size_t n_rows, int device_id, long long *i_out, long long *j_out,
-             long long *off_out, size_t cap, size_t *n_out, F enqueue) {
+int host_coo(uint64_t token, const float *dist, size_t n_rows, size_t n_off, int device_id, long long *i_out,
+             long long *j_out, long long *off_out, size_t cap, size_t *n_out, F enqueue) {
   if (!n_out) return ppk_fail(PPK_ERR_ARG, "n_out is NULL");
   *n_out = 0;
   if (n_rows == 0) return PPK_OK;
   if (!dist) return ppk_fail(PPK_ERR_ARG, "dist is NULL");
   DeviceGuard guard(device_id);
   if (!guard.ok) return ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(device_id));
-  float *d_dist = nullptr;
-  unsigned long long *d_n = nullptr;
-  long long *d_buf = nullptr;
-  int rc = PPK_OK;
-  if (hipMalloc(reinterpret_cast<void **>(&d_dist), n_rows * 8) != hipSuccess ||
-      hipMalloc(reinterpret_cast<void **>(&d_n), 8) != hipSuccess)
-    rc = ppk_fail(PPK_ERR_HIP, "hipMalloc failed");
-  if (rc == PPK_OK && hipMemcpy(d_dist, dist, n_rows * 8, hipMemcpyHostToDevice) != hipSuccess)
-    rc = ppk_fail(PPK_ERR_HIP, "hipMemcpy H2D failed");
-  // first pass with capacity 0 gives the count, second fills a buffer of exactly that size
-  unsigned long long n = 0;
-  if (rc == PPK_OK) rc = enqueue(d_dist, nullptr, nullptr, nullptr, 0, d_n);
-  if (rc == PPK_OK && hipMemcpy(&n, d_n, 8, hipMemcpyDeviceToHost) != hipSuccess)
-    rc = ppk_fail(PPK_ERR_HIP, "hipMemcpy D2H failed");
-  if (rc == PPK_OK) {
-    *n_out = (size_t)n;
-    if (n > cap) {
-      rc = ppk_fail(PPK_ERR_CAPACITY, "output too small: need " + std::to_string(n));
-    } else if (n > 0) {
-      if (hipMalloc(reinterpret_cast<void **>(&d_buf), n * 24) != hipSuccess)
-        rc = ppk_fail(PPK_ERR_HIP, "hipMalloc failed");
-      if (rc == PPK_OK) rc = enqueue(d_dist, d_buf, d_buf + n, d_buf + 2 * n, (size_t)n, d_n);
-      if (rc == PPK_OK && (hipMemcpy(i_out, d_buf, n * 8, hipMemcpyDeviceToHost) != hipSuccess ||
-                           hipMemcpy(j_out, d_buf + n, n * 8, hipMemcpyDeviceToHost) != hipSuccess ||
-                           hipMemcpy(off_out, d_buf + 2 * n, n * 8, hipMemcpyDeviceToHost) != hipSuccess))
-        rc = ppk_fail(PPK_ERR_HIP, "hipMemcpy D2H failed");
-    }
-  }
-  if (d_buf) (void)hipFree(d_buf);
-  if (d_n) (void)hipFree(d_n);
-  if (d_dist) (void)hipFree(d_dist);
-  return rc;
+  size_t guess = n_rows / 4 > ((size_t)1 << 20) ? n_rows / 4 : ((size_t)1 << 20);
+  if (guess > n_rows * (n_off ? n_off : 1)) guess = n_rows * (n_off ? n_off : 1);
+  auto compute = [&](size_t c, void **d_res, unsigned long long *want) {
+    float *d_dist = nullptr;
+    unsigned long long *d_n = nullptr;
+    int rc = PPK_OK;
+    if (hipMalloc(reinterpret_cast<void **>(&d_dist), n_rows * 8) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&d_n), 8) != hipSuccess || hipMalloc(d_res, c * 24) != hipSuccess)
+      rc = ppk_fail(PPK_ERR_HIP, "hipMalloc failed");
+    if (rc == PPK_OK && hipMemcpy(d_dist, dist, n_rows * 8, hipMemcpyHostToDevice) != hipSuccess)
+      rc = ppk_fail(PPK_ERR_HIP, "hipMemcpy H2D failed");
+    long long *buf = static_cast<long long *>(*d_res);
+    if (rc == PPK_OK) rc = enqueue(d_dist, buf, buf + c, buf + 2 * c, c, d_n);
+    if (rc == PPK_OK && hipMemcpy(want, d_n, 8, hipMemcpyDeviceToHost) != hipSuccess)
+      rc = ppk_fail(PPK_ERR_HIP, "hipMemcpy D2H failed");
+    if (d_dist) (void)hipFree(d_dist);
+    if (d_n) (void)hipFree(d_n);
+    return rc;
+  };
+  auto copy_out = [&](const void *d, size_t n, size_t cap_used) {
+    const long long *buf = static_cast<const long long *>(d);
+    if (!i_out || !j_out || !off_out) return ppk_fail(PPK_ERR_ARG, "output arrays are NULL");
+    if (hipMemcpy(i_out, buf, n * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(j_out, buf + cap_used, n * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(off_out, buf + 2 * cap_used, n * 8, hipMemcpyDeviceToHost) != hipSuccess)
+      return ppk_fail(PPK_ERR_HIP, "hipMemcpy D2H failed");
+    return (int)PPK_OK;
+  };
+  return ppk_host_result(1, token, device_id, guess, cap, n_out, compute, copy_out);
 }
 }  // namespace
 
@@ -478,7 +491,11 @@ extern "C" int ppk_threshold_iterate_1d(const float *dist, size_t n_rows, const 
                                         float y1, int device_id, long long *i_out,
                                         long long *j_out, long long *off_out, size_t cap,
                                         size_t *n_out) {
-  return host_coo(dist, n_rows, device_id, i_out, j_out, off_out, cap, n_out,
+  uint64_t token = ppk_token(offsets, n_off * sizeof(double), 11);
+  const float fk[4] = {x0, y0, x1, y1};
+  const uint64_t key[3] = {(uint64_t)(size_t)dist, (uint64_t)n_rows, (uint64_t)(unsigned)slope};
+  token = ppk_token(fk, sizeof(fk), ppk_token(key, sizeof(key), token));
+  return host_coo(token, dist, n_rows, n_off, device_id, i_out, j_out, off_out, cap, n_out,
                   [&](const float *d, long long *a, long long *b, long long *c, size_t cp,
                       unsigned long long *dn) {
                     return ppk_threshold_iterate_1d_dev(d, n_rows, offsets, n_off, slope, x0, y0, x1,
@@ -490,7 +507,10 @@ extern "C" int ppk_threshold_iterate_2d(const float *dist, size_t n_rows, const 
                                         size_t n_off, float y_max, int device_id,
                                         long long *i_out, long long *j_out, long long *off_out,
                                         size_t cap, size_t *n_out) {
-  return host_coo(dist, n_rows, device_id, i_out, j_out, off_out, cap, n_out,
+  uint64_t token = ppk_token(x_max, n_off * sizeof(float), 12);
+  const uint64_t key[3] = {(uint64_t)(size_t)dist, (uint64_t)n_rows, (uint64_t)__builtin_bit_cast(unsigned, y_max)};
+  token = ppk_token(key, sizeof(key), token);
+  return host_coo(token, dist, n_rows, n_off, device_id, i_out, j_out, off_out, cap, n_out,
                   [&](const float *d, long long *a, long long *b, long long *c, size_t cp,
                       unsigned long long *dn) {
                     return ppk_threshold_iterate_2d_dev(d, n_rows, x_max, n_off, y_max, a, b, c, cp,

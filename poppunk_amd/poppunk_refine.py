@@ -47,17 +47,23 @@ def assignThreshold(distMat, slope, x_max, y_max, num_threads=1):
     return out
 
 
-def _edges(call):
+def _edges(call, rows_hint=0):
+    """Edge lists have a data-dependent size.  The first call offers a guessed capacity; if it is too
+    small the library keeps the finished list on the device and the second call, with room, only
+    fetches it (include/ppk.h: one upload, one pass either way)."""
     n_edges = C.c_size_t(0)
-    rc = call(None, 0, C.byref(n_edges))
+    guess = min(int(rows_hint), max(65536, int(rows_hint) // 16))
+    ij = np.empty((guess, 2), dtype=np.int64)
+    rc = call(ij.ctypes.data_as(C.POINTER(C.c_longlong)) if guess else None, guess, C.byref(n_edges))
     if rc not in (_lib.OK, _lib.ERR_CAPACITY):
         _lib.check(rc, "edge list")
     n = int(n_edges.value)
-    ij = np.empty((n, 2), dtype=np.int64)
-    if n:
+    if rc == _lib.ERR_CAPACITY:
+        ij = np.empty((n, 2), dtype=np.int64)
         rc = call(ij.ctypes.data_as(C.POINTER(C.c_longlong)), n, C.byref(n_edges))
         _lib.check(rc, "edge list")
-    return ij
+        return ij
+    return ij[:n].copy() if n < guess else ij
 
 
 def edgeThreshold_array(distMat, slope, x_max, y_max, n_ref=0, inclusive=True):
@@ -65,7 +71,7 @@ def edgeThreshold_array(distMat, slope, x_max, y_max, n_ref=0, inclusive=True):
     lib = _lib.lib()
     return _edges(lambda p, cap, ne: lib.ppk_edge_threshold(
         d.ctypes.data_as(C.POINTER(C.c_float)), d.shape[0], int(n_ref), int(slope), float(x_max),
-        float(y_max), 1 if inclusive else 0, _DEVICE, p, cap, ne))
+        float(y_max), 1 if inclusive else 0, _DEVICE, p, cap, ne), d.shape[0])
 
 
 def edgeThreshold(distMat, slope, x_max, y_max):
@@ -82,7 +88,7 @@ def generateTuples_array(assignments, within_label, self=True, num_ref=0, int_of
     lib = _lib.lib()
     return _edges(lambda p, cap, ne: lib.ppk_generate_tuples(
         a.ctypes.data_as(C.POINTER(C.c_int32)), a.shape[0], int(within_label), 1 if self else 0,
-        int(num_ref), int(int_offset), _DEVICE, p, cap, ne))
+        int(num_ref), int(int_offset), _DEVICE, p, cap, ne), a.shape[0])
 
 
 def generateTuples(assignments, within_label, self=True, num_ref=0, int_offset=0):
@@ -91,19 +97,28 @@ def generateTuples(assignments, within_label, self=True, num_ref=0, int_offset=0
             generateTuples_array(assignments, within_label, self, num_ref, int_offset).tolist()]
 
 
-def _coo(call):
+def _coo(call, rows_hint=0):
+    """As _edges, for the (i, j, offset index) triplets of the sweeps."""
     n_out = C.c_size_t(0)
-    rc = call(None, None, None, 0, C.byref(n_out))
+    ll = C.POINTER(C.c_longlong)
+    guess = min(int(rows_hint), max(65536, int(rows_hint) // 8))
+    i = np.empty(guess, dtype=np.int64)
+    j = np.empty(guess, dtype=np.int64)
+    o = np.empty(guess, dtype=np.int64)
+    rc = call(i.ctypes.data_as(ll), j.ctypes.data_as(ll), o.ctypes.data_as(ll), guess, C.byref(n_out)) \
+        if guess else call(None, None, None, 0, C.byref(n_out))
     if rc not in (_lib.OK, _lib.ERR_CAPACITY):
         _lib.check(rc, "threshold iterate")
     n = int(n_out.value)
-    i = np.empty(n, dtype=np.int64)
-    j = np.empty(n, dtype=np.int64)
-    o = np.empty(n, dtype=np.int64)
-    if n:
-        ll = C.POINTER(C.c_longlong)
+    if rc == _lib.ERR_CAPACITY:
+        i = np.empty(n, dtype=np.int64)
+        j = np.empty(n, dtype=np.int64)
+        o = np.empty(n, dtype=np.int64)
         rc = call(i.ctypes.data_as(ll), j.ctypes.data_as(ll), o.ctypes.data_as(ll), n, C.byref(n_out))
         _lib.check(rc, "threshold iterate")
+        return i, j, o
+    if n < guess:
+        return i[:n].copy(), j[:n].copy(), o[:n].copy()
     return i, j, o
 
 
@@ -116,7 +131,8 @@ def thresholdIterate1D_arrays(distMat, offsets, slope, x0, y0, x1, y1):
     lib = _lib.lib()
     return _coo(lambda pi, pj, po, cap, n: lib.ppk_threshold_iterate_1d(
         d.ctypes.data_as(C.POINTER(C.c_float)), d.shape[0], off.ctypes.data_as(C.POINTER(C.c_double)),
-        off.size, int(slope), float(x0), float(y0), float(x1), float(y1), _DEVICE, pi, pj, po, cap, n))
+        off.size, int(slope), float(x0), float(y0), float(x1), float(y1), _DEVICE, pi, pj, po, cap, n),
+        d.shape[0])
 
 
 def thresholdIterate1D(distMat, offsets, slope, x0, y0, x1, y1, num_threads=1):
@@ -135,7 +151,7 @@ def thresholdIterate2D_arrays(distMat, x_max, y_max):
     lib = _lib.lib()
     return _coo(lambda pi, pj, po, cap, n: lib.ppk_threshold_iterate_2d(
         d.ctypes.data_as(C.POINTER(C.c_float)), d.shape[0], xm.ctypes.data_as(C.POINTER(C.c_float)),
-        xm.size, float(y_max), _DEVICE, pi, pj, po, cap, n))
+        xm.size, float(y_max), _DEVICE, pi, pj, po, cap, n), d.shape[0] * max(int(xm.size), 1))
 
 
 def thresholdIterate2D(distMat, x_max, y_max):

@@ -403,3 +403,39 @@ def test_threshold_iterate_2d_on_resident_matrix():
     assert np.array_equal(go.cpu().numpy(), wo)
     with pytest.raises(RuntimeError):
         engine.threshold_iterate_2d_dev(torch.as_tensor(d, device="cuda"), x_max[::-1].copy(), 0.21)
+
+
+def test_threshold_iterate_many_offsets_and_one_pass_host_calls():
+    """More offsets than fit a kernel argument (the boundaries live in device memory: up to 1023 per
+    call; the reference has no limit, its callers pass 40 and 20), and the host entry points'
+    protocol: a first call with too little room leaves the finished result parked on the device and
+    reports its size, the second call only fetches it."""
+    import ctypes as C
+    from poppunk_amd import _lib
+    rng = np.random.Generator(np.random.PCG64(77))
+    samples = 260
+    d = rng.random((samples * (samples - 1) // 2, 2)).astype(np.float32)
+    offsets = np.linspace(-0.25, 0.3, 300) * np.sqrt(2)
+    gi, gj, go = poppunk_refine.thresholdIterate1D_arrays(d, offsets, 2, 0.2, 0.2, 0.3, 0.3)
+    wi, wj, wo = oracle.threshold_iterate_1d(d, offsets, 2, 0.2, 0.2, 0.3, 0.3)
+    assert np.array_equal(gi, wi) and np.array_equal(gj, wj) and np.array_equal(go, wo) and len(wi) > 1000
+    xs = np.linspace(0.01, 0.6, 300).astype(np.float32)
+    gi, gj, go = poppunk_refine.thresholdIterate2D_arrays(d, xs, 0.2)
+    wi, wj, wo = oracle.threshold_iterate_2d(d, xs, 0.2)
+    assert np.array_equal(gi, wi) and np.array_equal(gj, wj) and np.array_equal(go, wo) and len(wi) > 1000
+    with pytest.raises(RuntimeError, match="too many offsets"):
+        poppunk_refine.thresholdIterate2D_arrays(d, np.linspace(0.01, 0.6, 1024).astype(np.float32), 0.2)
+    # the two-call protocol through the raw C ABI
+    lib = _lib.lib()
+    n = C.c_size_t(0)
+    fp = d.ctypes.data_as(C.POINTER(C.c_float))
+    assert lib.ppk_edge_threshold(fp, d.shape[0], 0, 2, 0.5, 0.5, 1, 0, None, 0, C.byref(n)) == _lib.ERR_CAPACITY
+    want = oracle.edge_threshold(d, 2, 0.5, 0.5)
+    assert n.value == len(want) > 0
+    ij = np.empty((n.value, 2), dtype=np.int64)
+    assert lib.ppk_edge_threshold(fp, d.shape[0], 0, 2, 0.5, 0.5, 1, 0, ij.ctypes.data_as(C.POINTER(C.c_longlong)),
+                                  n.value, C.byref(n)) == _lib.OK
+    assert np.array_equal(ij, want)
+    # different arguments after a parked result: a fresh computation, not the parked list
+    e2 = poppunk_refine.edgeThreshold_array(d, 2, 0.4, 0.5)
+    assert np.array_equal(e2, oracle.edge_threshold(d, 2, 0.4, 0.5))
