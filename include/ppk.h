@@ -36,6 +36,7 @@ extern "C" {
 #define PPK_ERR_HIP 2      /* a HIP runtime call failed / no usable device   */
 #define PPK_ERR_CAPACITY 3 /* caller-provided output too small               */
 #define PPK_ERR_STATE 4    /* call sequence error                            */
+#define PPK_ERR_INTERRUPTED 5 /* the interrupt check asked to stop (Ctrl-C)   */
 
 /* flags of ppk_query / ppk_dist_dev: the random_correct and jaccard booleans of
  * pp_sketchlib.queryDatabase (PopPUNK/sketchlib.py:528-537,:547-566) */
@@ -70,6 +71,19 @@ int ppk_device_count(int *n);
  *                              J < 5/nbins; 1: it skips every such k and keeps the rest */
 int ppk_set_option(const char *name, long long value);
 int ppk_get_option(const char *name, long long *value);
+
+/* Interrupts and progress of the long host calls (ppk_query, ppk_query_db), the contract of the
+ * bindings they replace: the reference's C++ loops poll PyErr_CheckSignals and stop on Ctrl-C
+ * (src/extend.cpp:263,:284-286; pp-sketchlib the same [EXT]) and print a progress meter to stderr,
+ * which PopPUNK silences with an fd-level redirect around re-queries (PopPUNK/utils.py:61-83,
+ * PopPUNK/sketchlib.py:546).
+ *  - `check` (NULL = none) is called from the calling thread between sub-bands (every ~256 MB of
+ *    results, a few ms); a non-zero return abandons the call: nothing more is launched, the device is
+ *    drained, PPK_ERR_INTERRUPTED is returned.  The Python mirror passes a check that lets Python's
+ *    signal handlers run.
+ *  - option "progress" (default 1): jobs of more than a few sub-bands write "\rProgress (GPU): nn.n%"
+ *    to file descriptor 2 with write(2): fd-level redirection silences it. */
+int ppk_set_interrupt_check(int (*check)(void));
 
 /* ------------------------------------------------------------------------
  * Resident sketch database: the flat bin-sketch array of one sample list,

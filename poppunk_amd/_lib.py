@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "csrc", "libppk_hip.so")
 
-OK, ERR_ARG, ERR_HIP, ERR_CAPACITY, ERR_STATE = 0, 1, 2, 3, 4
+OK, ERR_ARG, ERR_HIP, ERR_CAPACITY, ERR_STATE, ERR_INTERRUPTED = 0, 1, 2, 3, 4, 5
 FLAG_RANDOM_CORRECT, FLAG_JACCARD, FLAG_COUNTS = 1, 2, 4
 
 # every symbol include/ppk.h declares: name -> (restype, argtypes)
@@ -77,6 +77,7 @@ SIGNATURES = {
     "ppk_last_kernel_name": (C.c_char_p, []),
     "ppk_set_option": (C.c_int, [C.c_char_p, C.c_longlong]),
     "ppk_get_option": (C.c_int, [C.c_char_p, _llp]),
+    "ppk_set_interrupt_check": (C.c_int, [_vp]),
     "ppk_query_db": (C.c_int, [_vp, _vp, _i32p, _f32p, _sz, C.c_int, _vp, _ullp]),
 }
 
@@ -133,6 +134,47 @@ def get_option(name):
     v = C.c_longlong(0)
     check(lib().ppk_get_option(name.encode(), C.byref(v)), "ppk_get_option(%s)" % name)
     return int(v.value)
+
+
+class interruptible:
+    """`with interruptible(): rc = lib.ppk_query(...)` -- Ctrl-C during a long host call.
+
+    ctypes releases the GIL for the call and Python runs signal handlers only between bytecodes of
+    the main thread, so a SIGINT would otherwise wait for the call to return.  The library polls a
+    check between sub-bands (include/ppk.h: ppk_set_interrupt_check); the check is a ctypes callback
+    -- executing it gives Python's pending handlers their chance to run -- that reports a flag which
+    a temporary SIGINT handler sets.  On exit the previous handler is restored and, if the flag is
+    set, KeyboardInterrupt is raised (the reference's loops raise through PyErr_CheckSignals,
+    src/extend.cpp:263,:284-286).  Outside the main thread it does nothing."""
+    _CB = C.CFUNCTYPE(C.c_int)
+
+    def __enter__(self):
+        import signal
+        import threading
+        self.flag = False
+        self.installed = False
+        if threading.current_thread() is not threading.main_thread():
+            return self
+        try:
+            self.prev = signal.signal(signal.SIGINT, self._on_sigint)
+        except ValueError:
+            return self
+        self.cb = self._CB(lambda: 1 if self.flag else 0)
+        lib().ppk_set_interrupt_check(C.cast(self.cb, C.c_void_p))
+        self.installed = True
+        return self
+
+    def _on_sigint(self, signum, frame):
+        self.flag = True
+
+    def __exit__(self, *exc):
+        if self.installed:
+            import signal
+            lib().ppk_set_interrupt_check(None)
+            signal.signal(signal.SIGINT, self.prev)
+            if self.flag:
+                raise KeyboardInterrupt
+        return False
 
 
 def last_error():

@@ -2,6 +2,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <unistd.h>
 #include <functional>
 #include <mutex>
 #include <vector>
@@ -41,6 +42,7 @@ const OptionEntry kOptions[] = {
     {"chunk_rows", "PPK_CHUNK_ROWS", &PpkConfig::chunk_rows},
     {"prefault_threads", "PPK_PREFAULT_THREADS", &PpkConfig::prefault_threads},
     {"db_cache", "PPK_DB_CACHE", &PpkConfig::db_cache},
+    {"progress", "PPK_PROGRESS", &PpkConfig::progress},
     {"ext_collision_adjust", "PPK_EXT_COLLISION_ADJUST", &PpkConfig::ext_collision_adjust},
     {"ext_fit_skip", "PPK_EXT_FIT_SKIP", &PpkConfig::ext_fit_skip},
 };
@@ -75,6 +77,22 @@ extern "C" int ppk_get_option(const char *name, long long *value) {
       return PPK_OK;
     }
   return ppk_fail(PPK_ERR_ARG, std::string("unknown option: ") + name);
+}
+
+// ---- interrupt check / progress meter of the long host calls ------------------------------------
+static std::atomic<int (*)(void)> g_interrupt_check{nullptr};
+extern "C" int ppk_set_interrupt_check(int (*check)(void)) {
+  g_interrupt_check.store(check);
+  return PPK_OK;
+}
+static bool interrupted() {
+  int (*f)(void) = g_interrupt_check.load();
+  return f && f() != 0;
+}
+static void progress_line(double frac, bool last) {
+  char buf[64];
+  const int n = snprintf(buf, sizeof(buf), "\rProgress (GPU): %.1f%%%s", 100.0 * frac, last ? "\n" : "");
+  if (n > 0) (void)!write(2, buf, (size_t)n);
 }
 
 // ---- the only supported target: gfx950 (MI355X), wave64 ---------------------------------------
@@ -943,7 +961,13 @@ int run_query(std::vector<QueryPart> &parts, size_t n_ref, size_t n_qry, const i
     (void)hipMemsetAsync(p.d_failed, 0, sizeof(unsigned long long), p.s);
   }
   // step c: every device launches sub-band c, then sub-band c-1 of every device is fetched
+  const bool meter = ppk_config().progress.load() != 0 && C >= 4;
   for (int c = 0; c <= C && rc == PPK_OK; ++c) {
+    if (interrupted()) {
+      rc = ppk_fail(PPK_ERR_INTERRUPTED, "interrupted");
+      break;
+    }
+    if (meter) progress_line((double)c / (double)(C + 1), false);
     for (int d = 0; d < n_dev && rc == PPK_OK && c < C; ++d) {
       QueryPart &p = parts[d];
       const size_t i = (size_t)d * C + c;
@@ -983,6 +1007,7 @@ int run_query(std::vector<QueryPart> &parts, size_t n_ref, size_t n_qry, const i
       *n_failed += f;
   }
   toucher.join();
+  if (meter && rc == PPK_OK) progress_line(1.0, true);
   if (rc != PPK_OK && !keep.empty() && g_err.empty()) g_err = keep;
   return rc;
 }

@@ -41,6 +41,7 @@ struct PpkConfig {
   std::atomic<long long> chunk_rows{32ll << 20};    // PPK_CHUNK_ROWS: rows per device buffer of ppk_query
   std::atomic<long long> prefault_threads{8};   // PPK_PREFAULT_THREADS
   std::atomic<long long> db_cache{1};           // PPK_DB_CACHE: ppk_query keeps its resident databases / buffers
+  std::atomic<long long> progress{1};           // PPK_PROGRESS: progress meter of long host calls on fd 2
   // [EXT] a4: 0 = the b-bit collision adjustment is never in effect (upstream as recalled: it is
   // gated on expected == 0, where it is the identity); 1 = applied when expected > 0
   std::atomic<long long> ext_collision_adjust{0};

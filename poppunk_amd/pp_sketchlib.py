@@ -123,10 +123,11 @@ def query_arrays(ref_sk, qry_sk, klist, sketchsize64, bbits, random_table=None, 
     n_failed = C.c_ulonglong(0)
     if n_pairs == 0:
         return out, 0
-    rc = lib.ppk_query(ref_sk.ctypes.data_as(C.POINTER(C.c_uint64)), n_ref, qptr, n_qry,
-                       kmers.ctypes.data_as(C.POINTER(C.c_int32)), nk, sketchsize64, bbits, tptr,
-                       rcp, qcp, n_clu, flags, devs, len(devices),
-                       C.c_void_p(out.ctypes.data), C.byref(n_failed))
+    with _lib.interruptible():        # Ctrl-C is honoured between sub-bands (KeyboardInterrupt on exit)
+        rc = lib.ppk_query(ref_sk.ctypes.data_as(C.POINTER(C.c_uint64)), n_ref, qptr, n_qry,
+                           kmers.ctypes.data_as(C.POINTER(C.c_int32)), nk, sketchsize64, bbits, tptr,
+                           rcp, qcp, n_clu, flags, devs, len(devices),
+                           C.c_void_p(out.ctypes.data), C.byref(n_failed))
     _lib.check(rc, "ppk_query")
     return out, int(n_failed.value)
 

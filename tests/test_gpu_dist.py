@@ -599,3 +599,57 @@ def test_queryDatabase_surface_on_a_reference_layout_h5(tmp_path):
         sketchlib.queryDatabase(qn, qn, qp, qp, kmers)
     assert pp_sketchlib.queryDatabase(qp + "/qrydb", qp + "/qrydb", qn, qn, kmers, False, False, 1, True, 0).shape == (1770, 2)
     pp_sketchlib.clear_cache()
+
+
+def test_host_call_honours_ctrl_c_and_reports_progress_on_fd2(ppk_option, tmp_path):
+    """the bindings being replaced poll for signals in their long loops and raise, and
+    print progress to stderr, which PopPUNK silences with an fd-level redirect.  Here: SIGINT during
+    a many-sub-band host call -> KeyboardInterrupt well before the job would have finished, library
+    intact afterwards; the meter goes to file descriptor 2 (seen through a dup2 redirect, as
+    PopPUNK.utils.stderr_redirected does it), only for jobs of several sub-bands, off with progress=0."""
+    import signal
+    import threading
+    import time
+    kmers = np.asarray(synth.DEFAULT_KMERS, dtype=np.int32)
+    tbl = synth.random_match_table(kmers)
+    sk = synth.make_sketches(6000, kmers, cluster_size=50, seed=6)[0]
+    want, _ = pp_sketchlib.query_arrays(sk[:1500], None, kmers, 16, 14, tbl)
+    ppk_option("chunk_rows", 20000)            # 6000 genomes: ~900 sub-bands
+
+    def fd2_of(fn):
+        path = str(tmp_path / "fd2.txt")
+        saved = os.dup(2)
+        with open(path, "wb") as f:
+            os.dup2(f.fileno(), 2)
+            try:
+                fn()
+            finally:
+                os.dup2(saved, 2)
+                os.close(saved)
+        return open(path, "rb").read()
+
+    text = fd2_of(lambda: pp_sketchlib.query_arrays(sk, None, kmers, 16, 14, tbl))
+    assert b"Progress (GPU): " in text and text.rstrip().endswith(b"100.0%")
+    ppk_option("progress", 0)
+    assert b"Progress" not in fd2_of(lambda: pp_sketchlib.query_arrays(sk, None, kmers, 16, 14, tbl))
+    ppk_option("progress", 1)
+    ppk_option("chunk_rows", 32 << 20)
+    assert b"Progress" not in fd2_of(lambda: pp_sketchlib.query_arrays(sk[:1500], None, kmers, 16, 14, tbl))
+    # Ctrl-C
+    ppk_option("chunk_rows", 20000)
+    ppk_option("progress", 0)
+    t0 = time.perf_counter()
+    pp_sketchlib.query_arrays(sk, None, kmers, 16, 14, tbl)
+    full = time.perf_counter() - t0
+    timer = threading.Timer(full * 0.2, lambda: os.kill(os.getpid(), signal.SIGINT))
+    timer.start()
+    t0 = time.perf_counter()
+    with pytest.raises(KeyboardInterrupt):
+        pp_sketchlib.query_arrays(sk, None, kmers, 16, 14, tbl)
+    took = time.perf_counter() - t0
+    timer.join()
+    assert took < 0.8 * full, (took, full)
+    assert signal.getsignal(signal.SIGINT) is signal.default_int_handler      # the handler was restored
+    ppk_option("chunk_rows", 32 << 20)
+    again, _ = pp_sketchlib.query_arrays(sk[:1500], None, kmers, 16, 14, tbl)
+    assert np.array_equal(again, want)
