@@ -77,7 +77,7 @@ int ppk_get_option(const char *name, long long *value);
  * (src/extend.cpp:263,:284-286; pp-sketchlib the same [EXT]) and print a progress meter to stderr,
  * which PopPUNK silences with an fd-level redirect around re-queries (PopPUNK/utils.py:61-83,
  * PopPUNK/sketchlib.py:546).
- *  - `check` (NULL = none) is called from the calling thread between sub-bands (every ~256 MB of
+ *  - `check` (NULL = none) is called from the calling thread between sub-bands (every ~64 MB of
  *    results, a few ms); a non-zero return abandons the call: nothing more is launched, the device is
  *    drained, PPK_ERR_INTERRUPTED is returned.  The Python mirror passes a check that lets Python's
  *    signal handlers run.
@@ -222,7 +222,7 @@ int ppk_threshold_iterate_2d_dev(const float *d_dist, size_t n_rows, const float
  * test/test-update-gpu.py:85-86).  n_qry == 0 => self.  out: float
  * [n_pairs][2] or [n_pairs][nk] (PPK_FLAG_JACCARD) or uint32 (PPK_FLAG_COUNTS).
  * The result is produced in sub-bands through two alternating device buffers of
- * about 256 MB (sub-band c downloads while c+1 computes), so device memory use is
+ * about 64 MB (sub-band c downloads while c+1 computes), so device memory use is
  * bounded by the sketches plus those buffers for any job size -- the
  * device-memory chunking of pp-sketchlib's CUDA path [EXT].  `out` is written by this call only; a few
  * helper threads touch its pages ahead of the download (option "prefault_threads", default 8, 0 = off).

@@ -917,7 +917,9 @@ int run_query(std::vector<QueryPart> &parts, size_t n_ref, size_t n_qry, const i
   const size_t nq = self ? n_ref : n_qry;
   const size_t cols = (flags & (PPK_FLAG_JACCARD | PPK_FLAG_COUNTS)) ? nk : 2;
   const size_t total_rows = ppk_rows_in_band(n_ref, n_qry, 0, nq);
-  size_t target_rows = (size_t)32 << 20;                       // ~256 MB of float2 rows per buffer
+  // ~64 MB of float2 rows per buffer: the first download starts after 1/6 of a 10k job instead of 1/2
+  // (PCIe is the bound of the host call: 11.2 -> 10.2 ms there; tools/ab_host.py)
+  size_t target_rows = (size_t)8 << 20;
   if (const long long cr = ppk_config().chunk_rows.load(); cr > 0) target_rows = (size_t)cr;
   const size_t per_dev = (total_rows + n_dev - 1) / n_dev;
   int C = (int)((per_dev + target_rows - 1) / target_rows);
@@ -961,7 +963,8 @@ int run_query(std::vector<QueryPart> &parts, size_t n_ref, size_t n_qry, const i
     (void)hipMemsetAsync(p.d_failed, 0, sizeof(unsigned long long), p.s);
   }
   // step c: every device launches sub-band c, then sub-band c-1 of every device is fetched
-  const bool meter = ppk_config().progress.load() != 0 && C >= 4;
+  const long long prog = ppk_config().progress.load();          // 1: jobs of >= ~0.1 s of work; 2: any multi-band job
+  const bool meter = prog != 0 && C >= 4 && (prog >= 2 || total_rows >= ((size_t)1 << 29));
   for (int c = 0; c <= C && rc == PPK_OK; ++c) {
     if (interrupted()) {
       rc = ppk_fail(PPK_ERR_INTERRUPTED, "interrupted");

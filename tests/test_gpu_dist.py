@@ -533,7 +533,7 @@ def test_host_result_pages_are_touched_ahead_of_the_download(ppk_option):
         if chunk_rows:
             ppk_option("chunk_rows", int(chunk_rows))
         else:
-            ppk_option("chunk_rows", 32 << 20)
+            ppk_option("chunk_rows", 8 << 20)
         got, gf = pp_sketchlib.query_arrays(sk, None, kmers, 16, 14, tbl, devices=devices)
         assert gf == wf and np.array_equal(got, want)
     # the square / long helpers pre-touch their results the same way
@@ -615,6 +615,7 @@ def test_host_call_honours_ctrl_c_and_reports_progress_on_fd2(ppk_option, tmp_pa
     sk = synth.make_sketches(6000, kmers, cluster_size=50, seed=6)[0]
     want, _ = pp_sketchlib.query_arrays(sk[:1500], None, kmers, 16, 14, tbl)
     ppk_option("chunk_rows", 20000)            # 6000 genomes: ~900 sub-bands
+    ppk_option("progress", 2)                  # 2: also for jobs below the 2^29-row (~0.1 s) threshold
 
     def fd2_of(fn):
         path = str(tmp_path / "fd2.txt")
@@ -633,7 +634,8 @@ def test_host_call_honours_ctrl_c_and_reports_progress_on_fd2(ppk_option, tmp_pa
     ppk_option("progress", 0)
     assert b"Progress" not in fd2_of(lambda: pp_sketchlib.query_arrays(sk, None, kmers, 16, 14, tbl))
     ppk_option("progress", 1)
-    ppk_option("chunk_rows", 32 << 20)
+    assert b"Progress" not in fd2_of(lambda: pp_sketchlib.query_arrays(sk, None, kmers, 16, 14, tbl))     # small job: silent
+    ppk_option("chunk_rows", 8 << 20)
     assert b"Progress" not in fd2_of(lambda: pp_sketchlib.query_arrays(sk[:1500], None, kmers, 16, 14, tbl))
     # Ctrl-C
     ppk_option("chunk_rows", 20000)
@@ -650,6 +652,6 @@ def test_host_call_honours_ctrl_c_and_reports_progress_on_fd2(ppk_option, tmp_pa
     timer.join()
     assert took < 0.8 * full, (took, full)
     assert signal.getsignal(signal.SIGINT) is signal.default_int_handler      # the handler was restored
-    ppk_option("chunk_rows", 32 << 20)
+    ppk_option("chunk_rows", 8 << 20)
     again, _ = pp_sketchlib.query_arrays(sk[:1500], None, kmers, 16, 14, tbl)
     assert np.array_equal(again, want)

@@ -1,12 +1,13 @@
 #!/bin/bash
-# Regenerates every measured artefact under gpurun_out/r01 (run through gpurun from the repo root):
-#   tools/collect_profiles.sh     then copy into profiles/ with tools/pmc_summary.py / the snippet in DESIGN.md
+# Regenerates every measured artefact under gpurun_out/$ROUND (run through gpurun from the repo root):
+#   ROUND=r02 tools/collect_profiles.sh     then `ROUND=r02 python tools/update_profiles.py` copies into profiles/
 set -u
-OUT=gpurun_out/r01
+ROUND=${ROUND:-r02}
+OUT=gpurun_out/$ROUND
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:-/root/repo}"
-B="python bench.py --steps 100 --warmup 20 --no-cpu"
-S="python bench.py --steps 5 --warmup 2 --no-cpu"
+B="python bench.py --steps 100 --warmup 20 --no-cpu --no-config5 --no-host-call"
+S="python bench.py --steps 5 --warmup 2 --no-cpu --no-config5 --no-host-call"
 timeout 1500 python tools/measure_configs.py $OUT/configs.json > $OUT/configs.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- $B > $OUT/bench_under_rocprof.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o f -- $S > /dev/null 2>&1
@@ -20,4 +21,8 @@ python bench.py > $OUT/bench.json 2> $OUT/bench.err
 ./tools/ubench_lds_tile.out > $OUT/ubench_lds_tile.txt 2>&1
 ./tools/ubench_pipe.out > $OUT/ubench_pipe.txt 2>&1
 ./tools/watch_clocks.sh > $OUT/power_clocks.txt 2>&1
+./tools/ubench_host_out.out > $OUT/ubench_host_out.txt 2>&1
+python tools/ab_host.py > $OUT/ab_host.txt 2>&1
+python tools/ab_knn.py > $OUT/knn_from_tiles.txt 2>&1
+PPK_BENCH_ONE_GPU=1 PPK_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 2 --steps 5 --warmup 2 --config5-genomes 20000 --no-cpu > $OUT/two_ranks_one_gpu.json 2> $OUT/two_ranks_one_gpu.err
 tail -1 $OUT/bench.json | cut -c1-300

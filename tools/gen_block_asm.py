@@ -136,12 +136,20 @@ def gen(QRY_PLANE_BYTES, TQ=4, dma_planes=None, half=False):
                 emit("v_bcnt_u32_b32 %%[c%d], v%d, %%[c%d]" % (p, lo_acc(r, q), p))
                 emit("v_bcnt_u32_b32 %%[c%d], v%d, %%[c%d]" % (p, hi_acc(r, q), p))
         return out
+    # experiments (environment): GEN_ALIGN=<log2> aligns the block's first instruction; GEN_PRIO=a,b,c,d
+    # sets the wave's issue priority at planes 0 / 4 / 8 / 12 (a wave early in its block -- the one the
+    # workgroup's barrier will be waiting for -- can be given precedence over one that is nearly done)
+    if os.environ.get("GEN_ALIGN") and dma_planes:
+        emit(".p2align %d" % int(os.environ["GEN_ALIGN"]))
+    prio = [int(x) for x in os.environ["GEN_PRIO"].split(",")] if (os.environ.get("GEN_PRIO") and dma_planes) else None
     # prologue: s(0), a0(0), a1(0)
     load_s(0)
     load_a0(0)
     load_a1(0)
     for b in range(BB):
         last = b == BB - 1
+        if prio and b % 4 == 0:
+            emit("s_setprio %d" % prio[b // 4])
         if not last:
             load_s(b + 1)
             emit("s_waitcnt lgkmcnt(%d)" % (NS + 1))   # s(b) and a0(b) have landed; a1(b), s(b+1) may be pending

@@ -1,7 +1,7 @@
 // Pipeline microbenchmark: the compare loop of dist_kernel_v2 WITH its LDS-DMA double buffering
 // and s_barrier per 64-bin block, but no epilogue, for different register tiles / workgroup
 // shapes.  10240 x 10240 samples, 5 k x 16 blocks, [k][word][sample] layout as in the product.
-//   hipcc --offload-arch=gfx950 -O3 -o tools/ubench_pipe.out tools/ubench_pipe.hip
+//   hipcc --offload-arch=gfx950 -O3 -o tools/ubench_pipe.out tools/ubench_pipe.hip -Lpoppunk_amd/csrc -lppk_hip -Wl,-rpath,'$ORIGIN/../poppunk_amd/csrc'
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
@@ -181,7 +181,7 @@ void run(const uint64_t *in, const uint64_t *in2, uint32_t *out, const char *wha
 // the product kernel through the C ABI, same shape (10240 x 10240 ref x query), HIP-event timed
 static void run_product(const ppk_db *a, const ppk_db *b, void *d_out, const char *ablate, const char *what) {
   const int32_t kmers[5] = {13, 17, 21, 25, 29};
-  setenv("PPK_ABLATE", ablate, 1);
+  ppk_set_option("ablate", atoll(ablate));      // (environment knobs are read once at load)
   const size_t n = ppk_db_size(a);
   const double pairs = b ? (double)n * n : (double)n * (n - 1) / 2;
   hipEvent_t e0, e1;
@@ -253,6 +253,11 @@ int main() {
       run_product(dba, dbb, d_out, "0", "P: product kernel");
       run_product(dba, dbb, d_out, "1", "P: product, no epilogue");
       run_product(dba, dbb, d_out, "5", "P: product, no epilogue, no DMA");
+      run_product(dba, dbb, d_out, "9", "P: product, no epilogue, no barriers");
+      run_product(dba, dbb, d_out, "13", "P: product, no epilogue, no DMA, no barriers");
+      run_product(dba, dbb, d_out, "4", "P: product, no DMA");
+      run_product(dba, dbb, d_out, "8", "P: product, no barriers");
+      run_product(dba, dbb, d_out, "3", "P: product, no epilogue, no compare");
       run_product(dba, dba, d_out, "1", "P: product, no epilogue, same db");
       run_product(dbs, nullptr, d_out, "0", "P: product 10000 self");
       run_product(dbs, nullptr, d_out, "1", "P: product 10000 self, no epilogue");

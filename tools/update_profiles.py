@@ -15,8 +15,9 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "r01")
-DST = os.path.join(ROOT, "profiles", "r01")
+ROUND = os.environ.get("ROUND", "r02")
+SRC = os.path.join(ROOT, "gpurun_out", ROUND)
+DST = os.path.join(ROOT, "profiles", ROUND)
 KERNEL = "dist_kernel_v2"
 
 
@@ -29,7 +30,8 @@ def main():
     ktc = os.path.join(SRC, "ktc", "c_kernel_stats.csv")
     if os.path.exists(ktc):       # every kernel of tools/measure_configs.py (kernel 2, sweeps, kNN, ...)
         shutil.copy(ktc, os.path.join(DST, "configs_kernel_stats.csv"))
-    for f in glob.glob(os.path.join(SRC, "ubench_*.txt")) + [os.path.join(SRC, "power_clocks.txt")]:
+    for f in glob.glob(os.path.join(SRC, "ubench_*.txt")) + [os.path.join(SRC, x) for x in (
+            "power_clocks.txt", "ab_host.txt", "knn_from_tiles.txt", "two_ranks_one_gpu.json")]:
         if os.path.exists(f):
             shutil.copy(f, DST)
     counters = {}
@@ -50,10 +52,13 @@ def main():
            "counters": dict(sorted(counters.items()))}
     json.dump(doc, open(os.path.join(DST, "bench_pmc_counters.json"), "w"), indent=1)
     fetch, write = counters["FETCH_SIZE"]["avg_per_launch"], counters["WRITE_SIZE"]["avg_per_launch"]
+    import datetime
     traffic = {"n%d" % bench["config"]["n_genomes"]: (2.0 * fetch + write) * 1024.0,
+               "source": "profiles/%s/bench_pmc_counters.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over "
+                         "bench.py, %s)" % (ROUND, datetime.date.today().isoformat()),
                "how": "2 x FETCH_SIZE (gfx950 rocprofv3 reports half the bytes of a 16 B/lane stream: "
                       "MI355X_MICROARCH.md HBM section) + WRITE_SIZE, KB -> bytes, averaged per launch of "
-                      "dist_kernel_v2; separate --pmc passes (profiles/r01/bench_pmc_counters.json)",
+                      "dist_kernel_v2; separate --pmc passes",
                "fetch_size_kb": fetch, "write_size_kb": write}
     json.dump(traffic, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
     # derived per-launch figures of the dominant kernel
