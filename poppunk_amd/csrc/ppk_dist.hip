@@ -915,6 +915,10 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
   if constexpr (MODE == MODE_DIST || MODE == MODE_MASK || MODE == MODE_KNN) {
     if (p.ablate & 1) return;
     if (MODE != MODE_KNN && !wave_active) return;      // (KNN: every wave takes part in the LDS exchange)
+    // the compare stream leaves the wave at priority 0 (it falls through each block, see
+    // tools/gen_block_asm.py); the epilogue is the last thing between this workgroup's slot and the next
+    // tile, so it runs at the top priority (measured: another -0.5..-1 %)
+    __builtin_amdgcn_s_setprio(3);
     // Cut every count register's live range here: whatever the register allocator decides for the
     // epilogue (which has all 128 VGPRs but wants many of them for fp64) must not reach back into
     // the compare loop -- a register spilled "for its whole life" is read-modified-written in

@@ -115,6 +115,18 @@ def gen(QRY_PLANE_BYTES, TQ=4, dma_planes=None, half=False):
                     else:
                         emit("v_bitop3_b32 v%d, v%d, v%d, v%d bitop3:0x90" % (acc, acc, a, s))
 
+    # Wave priority falls through the block: 3 at plane 0, 2 at plane 4, 1 at plane 8, 0 at plane 12.  Every
+    # block ends in the workgroup's barrier, which waits for the SLOWEST of its 8 wavefronts; of two
+    # wavefronts on a SIMD the one that is earlier in its block is the one a barrier is waiting for, so it
+    # gets the issue slots first.  Measured on MI355X (tools/ab_so.py, same box): -1.8..-2.5 % kernel time;
+    # the reverse schedule (0,1,2,3) +4.7 %; two levels or a later fall less.  (GEN_PRIO=a,b,c,d or one value
+    # per plane overrides; GEN_ALIGN=<log2> aligns the block's first instruction: no effect measured.)
+    if os.environ.get("GEN_ALIGN") and dma_planes:
+        emit(".p2align %d" % int(os.environ["GEN_ALIGN"]))
+    prio = None
+    if dma_planes:       # (the full block of the packed modes; on the half block it measured 1 % worse)
+        v = [int(x) for x in os.environ.get("GEN_PRIO", "3,2,1,0").split(",")]
+        prio = v if len(v) == BB else [v[b // 4] for b in range(BB)]
     if half:
         # Diagonal tiles whose queries all lie beyond the tile's first 128 refs: refs 0/1 of every
         # lane pair with nothing, so only refs 2/3 (the a1 operands) are compared: half the stream.
@@ -122,6 +134,8 @@ def gen(QRY_PLANE_BYTES, TQ=4, dma_planes=None, half=False):
         load_a1(0)
         for b in range(BB):
             last = b == BB - 1
+            if prio and (b == 0 or prio[b] != prio[b - 1]):
+                emit("s_setprio %d" % prio[b])
             if not last:
                 load_s(b + 1)
                 emit("s_waitcnt lgkmcnt(%d)" % NS)     # s(b), a1(b) landed; s(b+1) may be pending
@@ -136,20 +150,14 @@ def gen(QRY_PLANE_BYTES, TQ=4, dma_planes=None, half=False):
                 emit("v_bcnt_u32_b32 %%[c%d], v%d, %%[c%d]" % (p, lo_acc(r, q), p))
                 emit("v_bcnt_u32_b32 %%[c%d], v%d, %%[c%d]" % (p, hi_acc(r, q), p))
         return out
-    # experiments (environment): GEN_ALIGN=<log2> aligns the block's first instruction; GEN_PRIO=a,b,c,d
-    # sets the wave's issue priority at planes 0 / 4 / 8 / 12 (a wave early in its block -- the one the
-    # workgroup's barrier will be waiting for -- can be given precedence over one that is nearly done)
-    if os.environ.get("GEN_ALIGN") and dma_planes:
-        emit(".p2align %d" % int(os.environ["GEN_ALIGN"]))
-    prio = [int(x) for x in os.environ["GEN_PRIO"].split(",")] if (os.environ.get("GEN_PRIO") and dma_planes) else None
     # prologue: s(0), a0(0), a1(0)
     load_s(0)
     load_a0(0)
     load_a1(0)
     for b in range(BB):
         last = b == BB - 1
-        if prio and b % 4 == 0:
-            emit("s_setprio %d" % prio[b // 4])
+        if prio and (b == 0 or prio[b] != prio[b - 1]):
+            emit("s_setprio %d" % prio[b])
         if not last:
             load_s(b + 1)
             emit("s_waitcnt lgkmcnt(%d)" % (NS + 1))   # s(b) and a0(b) have landed; a1(b), s(b+1) may be pending
