@@ -16,7 +16,7 @@ int ppk_launch_dist(const ppk_db *ref, const ppk_db *qry_or_null, const int32_t 
                     const float *d_rtab, size_t n_clu, int flags, size_t q_begin, size_t q_end,
                     void *d_out, unsigned long long *d_n_failed, uint64_t *d_mask, int slope,
                     float x_max, float y_max, float scale_x, float scale_y, int inclusive,
-                    double *d_lut, hipStream_t s, const int *knn_args = nullptr);
+                    double *d_lut, hipStream_t s, const int *knn_args = nullptr, bool lut_ready = false);
 
 // ---- errors ---------------------------------------------------------------
 static thread_local std::string g_err;
@@ -390,6 +390,10 @@ struct Scratch {
 struct DevState {
   std::recursive_mutex mu;
   Scratch slot[SLOT_COUNT];
+  // the fit tables sitting in SLOT_LUT: key of what they were built from (0 = nothing valid) and the
+  // block they sit in -- a call with the same k list, random table and options skips the rebuild
+  uint64_t lut_key = 0;
+  const void *lut_ptr = nullptr;
 };
 DevState g_dev[64];
 
@@ -399,6 +403,8 @@ struct CallCtx {
   unsigned touched = 0;
 };
 thread_local CallCtx tl_call;
+thread_local uint64_t tl_lut_pending_key = 0;
+thread_local const void *tl_lut_pending_ptr = nullptr;
 
 int scratch_get(int dev, int slot, size_t bytes, void **out) {
   if (dev < 0 || dev >= 64 || slot < 0 || slot >= SLOT_COUNT)
@@ -427,23 +433,36 @@ int scratch_get(int dev, int slot, size_t bytes, void **out) {
   return PPK_OK;
 }
 
-// random table (host) -> device copy placed after the LUT in the LUT scratch
-int stage_tables(const ppk_db *ref, const float *random_tbl, size_t n_clu, int flags, hipStream_t s,
-                 double **d_lut, float **d_rtab) {
+// random table (host) -> device copy placed after the LUT in the LUT scratch.  *lut_ready: the
+// tables of an identical earlier call (same k list, random table, sketch size, options) are still
+// there -- the launcher then skips lut_kernel (one launch and one H2D copy less per call: what a
+// 1 000-genome query or a plot-fit re-query mostly consists of).
+int stage_tables(const ppk_db *ref, const int32_t *kmers, const float *random_tbl, size_t n_clu, int flags,
+                 hipStream_t s, double **d_lut, float **d_rtab, bool *lut_ready) {
   const size_t nbins = ref->s64 * 64;
   const size_t C = n_clu ? n_clu : 1;
   // log-J table + the (E, F) pairs of the fit's fast path behind it (ppk_dist.hip lut_kernel)
   const size_t lut_bytes = 3 * C * C * ref->nk * (nbins + 1) * sizeof(double);
   const size_t tab_bytes = C * C * ref->nk * sizeof(float);
+  const bool use_tbl = (flags & PPK_FLAG_RANDOM_CORRECT) && random_tbl;
   void *base = nullptr;
   int rc = scratch_get(ref->device, SLOT_LUT, lut_bytes + tab_bytes + 256, &base);
   if (rc != PPK_OK) return rc;
   *d_lut = static_cast<double *>(base);
-  *d_rtab = nullptr;
-  if ((flags & PPK_FLAG_RANDOM_CORRECT) && random_tbl) {
-    float *t = reinterpret_cast<float *>(static_cast<char *>(base) + ((lut_bytes + 255) / 256) * 256);
-    PPK_HIP(hipMemcpyAsync(t, random_tbl, tab_bytes, hipMemcpyHostToDevice, s));
-    *d_rtab = t;
+  float *t = reinterpret_cast<float *>(static_cast<char *>(base) + ((lut_bytes + 255) / 256) * 256);
+  *d_rtab = use_tbl ? t : nullptr;
+  const long long dims[8] = {(long long)ref->nk, (long long)ref->s64, (long long)ref->bbits, (long long)C,
+                             use_tbl ? 1 : 0, ppk_config().ext_collision_adjust.load(), 0, 0};
+  uint64_t key = ppk_token(dims, sizeof(dims), 21);
+  key = ppk_token(kmers, ref->nk * sizeof(int32_t), key);
+  if (use_tbl) key = ppk_token(random_tbl, tab_bytes, key);
+  DevState &ds = g_dev[ref->device];
+  *lut_ready = ds.lut_key == key && ds.lut_ptr == base;
+  if (!*lut_ready) {
+    ds.lut_key = 0;        // nothing valid until the launcher has really built the tables (ppk_lut_commit)
+    tl_lut_pending_key = key;
+    tl_lut_pending_ptr = base;
+    if (use_tbl) PPK_HIP(hipMemcpyAsync(t, random_tbl, tab_bytes, hipMemcpyHostToDevice, s));
   }
   return PPK_OK;
 }
@@ -451,6 +470,13 @@ int stage_tables(const ppk_db *ref, const float *random_tbl, size_t n_clu, int f
 }  // namespace
 
 int ppk_scratch_get(int dev, int slot, size_t bytes, void **out) { return scratch_get(dev, slot, bytes, out); }
+
+// lut_kernel has been enqueued for the tables stage_tables announced: they may be re-used
+void ppk_lut_commit(int dev, const void *d_lut) {
+  if (dev < 0 || dev >= 64 || tl_lut_pending_ptr != d_lut) return;
+  g_dev[dev].lut_key = tl_lut_pending_key;
+  g_dev[dev].lut_ptr = d_lut;
+}
 
 PpkCall::PpkCall(int dev, hipStream_t s) : dev_(dev), prev_dev_(tl_call.dev), prev_s_(tl_call.s), prev_touched_(tl_call.touched) {
   if (dev_ < 0 || dev_ >= 64) {
@@ -514,10 +540,11 @@ extern "C" int ppk_dist_dev(const ppk_db *ref, const ppk_db *qry, const int32_t 
   PpkCall call(ref->device, s);
   double *d_lut = nullptr;
   float *d_rtab = nullptr;
-  rc = stage_tables(ref, random_tbl, n_clu, flags, s, &d_lut, &d_rtab);
+  bool lut_ready = false;
+  rc = stage_tables(ref, kmers, random_tbl, n_clu, flags, s, &d_lut, &d_rtab, &lut_ready);
   if (rc != PPK_OK) return rc;
   return ppk_launch_dist(ref, qry, kmers, d_rtab, d_rtab ? n_clu : 1, flags, q_begin, q_end, d_out,
-                         d_n_failed, nullptr, 2, 0.f, 0.f, 1.f, 1.f, 1, d_lut, s);
+                         d_n_failed, nullptr, 2, 0.f, 0.f, 1.f, 1.f, 1, d_lut, s, nullptr, lut_ready);
 }
 
 extern "C" int ppk_dist_edges_dev(const ppk_db *ref, const ppk_db *qry, const int32_t *kmers,
@@ -541,7 +568,8 @@ extern "C" int ppk_dist_edges_dev(const ppk_db *ref, const ppk_db *qry, const in
   }
   double *d_lut = nullptr;
   float *d_rtab = nullptr;
-  rc = stage_tables(ref, random_tbl, n_clu, flags, s, &d_lut, &d_rtab);
+  bool lut_ready = false;
+  rc = stage_tables(ref, kmers, random_tbl, n_clu, flags, s, &d_lut, &d_rtab, &lut_ready);
   if (rc != PPK_OK) return rc;
   {
     // nk * count-bits > 128: no fused path; distances (pre-divided by scale) go to scratch and the
@@ -574,7 +602,7 @@ extern "C" int ppk_dist_edges_dev(const ppk_db *ref, const ppk_db *qry, const in
   PPK_HIP(hipMemsetAsync(d_mask, 0, n_words * sizeof(uint64_t), s));
   rc = ppk_launch_dist(ref, qry, kmers, d_rtab, d_rtab ? n_clu : 1, flags, q_begin, q_end, nullptr,
                        d_n_failed, static_cast<uint64_t *>(d_mask), slope, x_max, y_max, scale_x,
-                       scale_y, inclusive, d_lut, s);
+                       scale_y, inclusive, d_lut, s, nullptr, lut_ready);
   if (rc != PPK_OK) return rc;
   EdgeGeom g = {};
   g.layout = qry ? EDGE_TILED_NONSELF : EDGE_TILED_SELF;
@@ -608,7 +636,8 @@ extern "C" int ppk_knn_sketches_dev(const ppk_db *db, const int32_t *kmers, cons
   const size_t n = db->n;
   double *d_lut = nullptr;
   float *d_rtab = nullptr;
-  rc = stage_tables(db, random_tbl, n_clu, flags, s, &d_lut, &d_rtab);
+  bool lut_ready = false;
+  rc = stage_tables(db, kmers, random_tbl, n_clu, flags, s, &d_lut, &d_rtab, &lut_ready);
   if (rc != PPK_OK) return rc;
   void *d_state = nullptr;
   rc = scratch_get(db->device, SLOT_ITER_A, 3 * sizeof(unsigned long long) + n * 4 + 256, &d_state);
@@ -638,7 +667,8 @@ extern "C" int ppk_knn_sketches_dev(const ppk_db *db, const int32_t *kmers, cons
     if (rc != PPK_OK) return rc;
     if (n > 1) {
       rc = ppk_launch_dist(db, nullptr, kmers, d_rtab, d_rtab ? n_clu : 1, flags, 0, n, d_cand, nullptr,
-                           static_cast<uint64_t *>(d_state), 2, 0.f, 0.f, 1.f, 1.f, 1, d_lut, s, knn_args);
+                           static_cast<uint64_t *>(d_state), 2, 0.f, 0.f, 1.f, 1.f, 1, d_lut, s, knn_args,
+                           lut_ready || attempt > 0);
       if (rc != PPK_OK) return rc;
     }
     PPK_HIP(hipMemcpyAsync(&count, d_state, sizeof(count), hipMemcpyDeviceToHost, s));

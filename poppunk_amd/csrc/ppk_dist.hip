@@ -1521,7 +1521,7 @@ int ppk_launch_dist(const ppk_db *ref, const ppk_db *qry_or_null, const int32_t 
                     const float *d_rtab, size_t n_clu, int flags, size_t q_begin, size_t q_end,
                     void *d_out, unsigned long long *d_n_failed, uint64_t *d_mask, int slope,
                     float x_max, float y_max, float scale_x, float scale_y, int inclusive,
-                    double *d_lut, hipStream_t s, const int *knn_args) {
+                    double *d_lut, hipStream_t s, const int *knn_args, bool lut_ready) {
   const ppk_db *qry = qry_or_null ? qry_or_null : ref;
   DistParams p = {};
   p.self = qry_or_null ? 0 : 1;
@@ -1614,13 +1614,15 @@ int ppk_launch_dist(const ppk_db *ref, const ppk_db *qry_or_null, const int32_t 
     PPK_HIP(hipGetLastError());
     return PPK_OK;
   }
-  // log-J table, built on the device for this (random table, k list)
-  {
+  // log-J table, built on the device for this (random table, k list) -- unless an identical earlier call
+  // left it there (stage_tables)
+  if (!lut_ready) {
     const size_t total = (size_t)p.n_clu * p.n_clu * p.lut_cpstride;
     hipLaunchKernelGGL(lut_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_lut,
                        d_rtab, p.nk, p.n_clu, nbins, ref->s64, ref->bbits, p.random_correct, p.ext_adjust, total,
                        coef);
     PPK_HIP(hipGetLastError());
+    ppk_lut_commit(ref->device, d_lut);
   }
   if (small) {
     // one workgroup per (tile, k) -> raw counts; then the same per-pair fit as the tile epilogue

@@ -119,8 +119,9 @@ int ppk_launch_assign(const float *d_dist, size_t n_rows, int slope, float x_max
 
 // grow-only per-device scratch (ppk_api.hip)
 enum { SLOT_LUT = 0, SLOT_MASK = 1, SLOT_WS = 2, SLOT_ITER_A = 3, SLOT_ITER_B = 4, SLOT_ITER_C = 5,
-       SLOT_COUNT = 6 };
+       SLOT_BOUNDS = 6, SLOT_COUNT = 7 };
 int ppk_scratch_get(int dev, int slot, size_t bytes, void **out);
+void ppk_lut_commit(int dev, const void *d_lut);
 // Scope of one entry point that uses the scratch of `dev`: holds that device's (recursive) mutex and
 // names the stream the call enqueues on, so that a slot last used on another stream is waited for
 // (see ppk_api.hip).  ppk_scratch_get fails outside such a scope.

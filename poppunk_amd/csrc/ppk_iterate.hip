@@ -302,8 +302,8 @@ extern "C" int ppk_threshold_iterate_1d_dev(const float *d_dist, size_t n_rows,
   PPK_HIP(hipGetDevice(&dev));
   PpkCall call(dev, s);
   {
-    void *p_b = nullptr;     // the boundaries live in the (otherwise unused here) table slot
-    int rcb = ppk_scratch_get(dev, SLOT_LUT, n_off * sizeof(float2) + 256, &p_b);
+    void *p_b = nullptr;     // the boundaries' own slot
+    int rcb = ppk_scratch_get(dev, SLOT_BOUNDS, n_off * sizeof(float2) + 256, &p_b);
     if (rcb != PPK_OK) return rcb;
     PPK_HIP(hipMemcpyAsync(p_b, bxy.data(), n_off * sizeof(float2), hipMemcpyHostToDevice, s));
     b.xy = static_cast<const float2 *>(p_b);
@@ -415,7 +415,7 @@ extern "C" int ppk_threshold_iterate_2d_dev(const float *d_dist, size_t n_rows, 
   PpkCall call(dev, s);
   {
     void *p_b = nullptr;
-    int rcb = ppk_scratch_get(dev, SLOT_LUT, n_off * sizeof(float2) + 256, &p_b);
+    int rcb = ppk_scratch_get(dev, SLOT_BOUNDS, n_off * sizeof(float2) + 256, &p_b);
     if (rcb != PPK_OK) return rcb;
     PPK_HIP(hipMemcpyAsync(p_b, bxy.data(), n_off * sizeof(float2), hipMemcpyHostToDevice, s));
     b.xy = static_cast<const float2 *>(p_b);

@@ -655,3 +655,36 @@ def test_host_call_honours_ctrl_c_and_reports_progress_on_fd2(ppk_option, tmp_pa
     ppk_option("chunk_rows", 8 << 20)
     again, _ = pp_sketchlib.query_arrays(sk[:1500], None, kmers, 16, 14, tbl)
     assert np.array_equal(again, want)
+
+
+def test_fit_tables_are_reused_only_for_identical_inputs(sk300):
+    """The device keeps the log-J / (E, F) tables of the last call and skips the rebuild when the k
+    list, random table, sketch size and [EXT] options are the same: alternate between inputs (and
+    through the modes that do not build them) and check every answer."""
+    sk = sk300[0]
+    kmers = np.asarray(synth.DEFAULT_KMERS, dtype=np.int32)
+    db = engine.SketchDB(sk, 16, 14)
+    t1 = synth.random_match_table(kmers)
+    t2 = synth.random_match_table(kmers, genome_length=5_000_000)
+    assert not np.array_equal(t1, t2)
+    want = {}
+    for name, tbl, rc in (("t1", t1, True), ("t2", t2, True), ("none", None, False)):
+        want[name] = oracle.query(sk, None, kmers, 16, 14, tbl, random_correct=rc, threads=4)[0]
+    order = ["t1", "t1", "t2", "none", "t1", "counts", "t1", "t2", "t2", "jaccard", "t2", "none", "none"]
+    tables = {"t1": (t1, True), "t2": (t2, True), "none": (None, False)}
+    for step in order:
+        if step == "counts":
+            c, _ = engine.dist(db, None, kmers, counts=True)
+            assert np.array_equal(c.cpu().numpy(), oracle.match_counts(sk, None, 16, 14, threads=4))
+        elif step == "jaccard":
+            j, _ = engine.dist(db, None, kmers, t1, jaccard=True)
+            assert np.array_equal(j.cpu().numpy(), oracle.query(sk, None, kmers, 16, 14, t1, jaccard=True, threads=4)[0])
+        else:
+            tbl, rc = tables[step]
+            d, _ = engine.dist(db, None, kmers, tbl, random_correct=rc)
+            assert np.abs(d.cpu().numpy() - want[step]).max() <= TOL, step
+    # a different k list with the same number of k
+    k2 = kmers + 1
+    d, _ = engine.dist(db, None, k2, synth.random_match_table(k2))
+    assert np.abs(d.cpu().numpy() - oracle.query(sk, None, k2, 16, 14, synth.random_match_table(k2), threads=4)[0]).max() <= TOL
+    db.close()
