@@ -263,6 +263,7 @@ extern "C" int ppk_db_create(int device_id, const uint64_t *sk, size_t n, size_t
     return ppk_fail(PPK_ERR_ARG, "ppk_db_create: empty or invalid sketch dimensions");
   if (sketchsize64 * 64 >= ((size_t)1 << 31))
     return ppk_fail(PPK_ERR_ARG, "ppk_db_create: sketch too large");
+  if (n >= ((size_t)1 << 31)) return ppk_fail(PPK_ERR_ARG, "ppk_db_create: too many samples (sample indices are 32-bit)");
   DeviceGuard guard(device_id);
   if (!guard.ok) return ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(device_id));
   if (int rc_arch = check_arch(device_id)) return rc_arch;

@@ -381,7 +381,11 @@ __device__ __forceinline__ void ef_gather(const PackT (&pk)[NR], const double *_
     for (int r = 0; r < NR; ++r) {
       const uint32_t c = pack_get(pk[r], k, p.cnt_bits, cmask, p.nk);
       const uint32_t boff = (loff[r] + (uint32_t)k * kstride + c) * 16u;
+#ifdef PPK_EXP_NO_GATHER      // experiment: the epilogue's VALU work without its table gathers
+      ef[r][k] = f64x2{1.0 + (double)boff * 1e-12, 1.0};
+#else
       ef[r][k] = *reinterpret_cast<const f64x2 *>(base + boff);
+#endif
     }
   }
 }
@@ -1031,10 +1035,10 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
 #pragma unroll
         for (int j = 0; j < NRB; ++j) {
           const int r = r0b + j;
-          const size_t rf = ref_of(r);
+          const uint32_t rf = (uint32_t)ref_of(r), q32 = (uint32_t)qq;      // sample indices fit 32 bits
           f2[j] = false;
-          valid[r] = rf < p.r_limit && (!p.self || rf > qq);
-          if (strip) valid[r] = rf < qq && rf >= p.q_begin && rf < p.q_end;   // band filter on the lane sample
+          valid[r] = rf < (uint32_t)p.r_limit && (!p.self || rf > q32);
+          if (strip) valid[r] = rf < q32 && rf >= (uint32_t)p.q_begin && rf < (uint32_t)p.q_end;   // band filter on the lane sample
         }
         // the fast path (every k usable in every lane), else pair by pair (unrolled: a rolled loop
         // would index the operand arrays dynamically and push them into scratch)
@@ -1056,26 +1060,35 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
       for (int r = 0; r < R; ++r) n_fail_wave += (unsigned)__popcll(__ballot(valid[r] && failed[r]));
       if constexpr (MODE == MODE_DIST) {
         // refs 2l and 2l+1 are adjacent rows: one 16-byte store when both are written
+        float2 *o = static_cast<float2 *>(out);
+        if (!strip) {      // workgroup-uniform
+          // the query's row block starts at a wave-uniform address; the lane adds a 32-bit offset
+          // (row = rowq + ref: per-lane 64-bit index arithmetic was a fifth of the epilogue's VALU work)
+          float2 *orow = o + (rowq + r0);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const size_t rf = ref_of(2 * h);
-          // strip launch: the lane sample is the smaller index, i.e. the row's "query"
-          const size_t row0 = strip ? rf * p.n_ref - (rf * (rf + 1)) / 2 + (qq - rf - 1) - p.row_base : rowq + rf;
-          const size_t row1 = strip ? (rf + 1) * p.n_ref - ((rf + 1) * (rf + 2)) / 2 + (qq - rf - 2) - p.row_base
-                                    : row0 + 1;
-          float2 *o = static_cast<float2 *>(out);
-          if (valid[2 * h] && valid[2 * h + 1] && !strip) {
-            // 16 bytes at 8-byte alignment: one global_store_dwordx4 (a 16-byte memcpy is split in two)
-            typedef float f32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
-            f32x4_a8 v;
-            v.x = core[2 * h];
-            v.y = acc[2 * h];
-            v.z = core[2 * h + 1];
-            v.w = acc[2 * h + 1];
-            *reinterpret_cast<f32x4_a8 *>(o + row0) = v;
-          } else {
-            if (valid[2 * h]) o[row0] = make_float2(core[2 * h], acc[2 * h]);
-            if (valid[2 * h + 1]) o[row1] = make_float2(core[2 * h + 1], acc[2 * h + 1]);
+          for (int h = 0; h < 2; ++h) {
+            const uint32_t loc = 2u * (uint32_t)lane_late + 128u * h;
+            if (valid[2 * h] && valid[2 * h + 1]) {
+              // 16 bytes at 8-byte alignment: one global_store_dwordx4 (a 16-byte memcpy is split in two)
+              typedef float f32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+              f32x4_a8 v;
+              v.x = core[2 * h];
+              v.y = acc[2 * h];
+              v.z = core[2 * h + 1];
+              v.w = acc[2 * h + 1];
+              *reinterpret_cast<f32x4_a8 *>(orow + loc) = v;
+            } else {
+              if (valid[2 * h]) orow[loc] = make_float2(core[2 * h], acc[2 * h]);
+              if (valid[2 * h + 1]) orow[loc + 1] = make_float2(core[2 * h + 1], acc[2 * h + 1]);
+            }
+          }
+        } else {
+          // strip tile: the lane sample is the smaller index, i.e. the row's "query"
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const size_t rf = ref_of(r);
+            if (valid[r])
+              o[rf * p.n_ref - (rf * (rf + 1)) / 2 + (qq - rf - 1) - p.row_base] = make_float2(core[r], acc[r]);
           }
         }
       } else if constexpr (MODE == MODE_MASK) {
