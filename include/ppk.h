@@ -305,6 +305,19 @@ int ppk_knn_sketches_dev(const ppk_db *db, const int32_t *kmers, const float *ra
                          size_t n_clu, int flags, int knn, int dist_col, long long *d_i,
                          long long *d_j, float *d_dist, unsigned long long *n_candidates,
                          void *stream);
+/* The same in two pieces, for N GPUs (engine.knn_sharded): every rank emits the neighbour candidates of
+ * its band of query rows [q_begin, q_end) -- (sample, distance bits << 32 | other sample) for BOTH
+ * samples of each pair in the band -- into d_keys / d_vals (capacity `cap`; *n_candidates (host) gets
+ * the total, PPK_ERR_CAPACITY if it exceeds cap); the lists are concatenated in any order and one rank
+ * selects every sample's knn smallest (distance, column) keys from them.  ppk_knn_candidates_dev
+ * synchronises the stream. */
+int ppk_knn_candidates_dev(const ppk_db *db, const int32_t *kmers, const float *random_tbl,
+                           size_t n_clu, int flags, int knn, int dist_col, size_t q_begin,
+                           size_t q_end, unsigned *d_keys, unsigned long long *d_vals, size_t cap,
+                           unsigned long long *n_candidates, void *stream);
+int ppk_knn_select_dev(const unsigned *d_keys, const unsigned long long *d_vals, size_t count,
+                       size_t n, int knn, long long *d_i, long long *d_j, float *d_dist,
+                       void *stream);
 /* replaces the per-row Python copy loop of PopPUNK.qc.prune_distance_matrix
  * (PopPUNK/qc.py:58-83): the long-form (condensed, PopPUNK row order) matrix of the
  * samples keep[0] < keep[1] < ... out of n; `cols` floats per row (2 for distances) */

@@ -64,6 +64,9 @@ SIGNATURES = {
     "ppk_knn_rect_dev": (C.c_int, [_vp, _sz, _sz, _sz, _sz, _sz, C.c_int, _vp, _vp, _vp, _vp]),
     "ppk_knn_sketches_dev": (C.c_int, [_vp, _i32p, _f32p, _sz, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp,
                                        _ullp, _vp]),
+    "ppk_knn_candidates_dev": (C.c_int, [_vp, _i32p, _f32p, _sz, C.c_int, C.c_int, C.c_int, _sz, _sz, _vp, _vp,
+                                         _sz, _ullp, _vp]),
+    "ppk_knn_select_dev": (C.c_int, [_vp, _vp, _sz, _sz, C.c_int, _vp, _vp, _vp, _vp]),
     "ppk_prune_long_dev": (C.c_int, [_vp, _sz, _sz, _vp, _sz, _vp, _vp]),
     "ppk_prune_query_rows_dev": (C.c_int, [_vp, _sz, _sz, _vp, _sz, _vp, _vp]),
     "ppk_prune_long": (C.c_int, [_f32p, _sz, _sz, _llp, _sz, C.c_int, _f32p]),

@@ -685,6 +685,64 @@ extern "C" int ppk_knn_sketches_dev(const ppk_db *db, const int32_t *kmers, cons
                                  (size_t)count, n, knn, d_i, d_j, d_dist, s);
 }
 
+// The two halves of the above for N GPUs: each rank emits the candidates of ITS band of query rows
+// (a pair is emitted by the rank whose band holds its smaller sample, for both of its samples), the
+// candidate lists are gathered, and one rank selects.  Bounds are per call: a band knows nothing of
+// the others' -- the union is still a superset of every true neighbour list.
+extern "C" int ppk_knn_candidates_dev(const ppk_db *db, const int32_t *kmers, const float *random_tbl,
+                                      size_t n_clu, int flags, int knn, int dist_col, size_t q_begin,
+                                      size_t q_end, unsigned *d_keys, unsigned long long *d_vals, size_t cap,
+                                      unsigned long long *n_candidates, void *stream) {
+  if (!n_candidates) return ppk_fail(PPK_ERR_ARG, "n_candidates is NULL");
+  *n_candidates = 0;
+  int rc = check_pair(db, nullptr, kmers, q_begin, q_end);
+  if (rc != PPK_OK) return rc;
+  if (knn < 1 || knn > 32) return ppk_fail(PPK_ERR_ARG, "knn must be in [1, 32]");
+  if (dist_col != 0 && dist_col != 1) return ppk_fail(PPK_ERR_ARG, "dist_col must be 0 (core) or 1 (accessory)");
+  if (cap && (!d_keys || !d_vals)) return ppk_fail(PPK_ERR_ARG, "NULL candidate buffer");
+  if (flags & (PPK_FLAG_JACCARD | PPK_FLAG_COUNTS)) return ppk_fail(PPK_ERR_ARG, "neighbours are taken from distances");
+  DeviceGuard guard(db->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  PpkCall call(db->device, s);
+  const size_t n = db->n;
+  if (ppk_rows_in_band(n, 0, q_begin, q_end) == 0) return PPK_OK;
+  double *d_lut = nullptr;
+  float *d_rtab = nullptr;
+  bool lut_ready = false;
+  rc = stage_tables(db, kmers, random_tbl, n_clu, flags, s, &d_lut, &d_rtab, &lut_ready);
+  if (rc != PPK_OK) return rc;
+  void *d_state = nullptr;
+  rc = scratch_get(db->device, SLOT_ITER_A, 3 * sizeof(unsigned long long) + n * 4 + 256, &d_state);
+  if (rc != PPK_OK) return rc;
+  // the kernel addresses the value array relative to the key array (modulo 2^64)
+  const unsigned long long vals_off = (unsigned long long)(reinterpret_cast<char *>(d_vals) - reinterpret_cast<char *>(d_keys));
+  rc = ppk_launch_knn_state_init(d_state, n, cap, vals_off, 1, s);
+  if (rc != PPK_OK) return rc;
+  const int knn_args[2] = {knn, dist_col};
+  rc = ppk_launch_dist(db, nullptr, kmers, d_rtab, d_rtab ? n_clu : 1, flags, q_begin, q_end, d_keys, nullptr,
+                       static_cast<uint64_t *>(d_state), 2, 0.f, 0.f, 1.f, 1.f, 1, d_lut, s, knn_args, lut_ready);
+  if (rc != PPK_OK) return rc;
+  unsigned long long count = 0;
+  PPK_HIP(hipMemcpyAsync(&count, d_state, sizeof(count), hipMemcpyDeviceToHost, s));
+  PPK_HIP(hipStreamSynchronize(s));
+  *n_candidates = count;
+  if (count > cap) return ppk_fail(PPK_ERR_CAPACITY, "candidate buffers too small: need " + std::to_string(count));
+  return PPK_OK;
+}
+
+extern "C" int ppk_knn_select_dev(const unsigned *d_keys, const unsigned long long *d_vals, size_t count,
+                                  size_t n, int knn, long long *d_i, long long *d_j, float *d_dist,
+                                  void *stream) {
+  if (knn < 1 || knn > 32) return ppk_fail(PPK_ERR_ARG, "knn must be in [1, 32]");
+  if (!d_i || !d_j || !d_dist || (count && (!d_keys || !d_vals))) return ppk_fail(PPK_ERR_ARG, "NULL buffer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int dev = 0;
+  PPK_HIP(hipGetDevice(&dev));
+  PpkCall call(dev, s);
+  return ppk_knn_from_candidates(dev, d_keys, reinterpret_cast<const uint64_t *>(d_vals), count, n, knn, d_i,
+                                 d_j, d_dist, s);
+}
+
 // ---- kernel 2, device entry points -------------------------------------------------
 extern "C" int ppk_assign_threshold_dev(const float *d_dist, size_t n_rows, int slope, float x_max,
                                         float y_max, float *d_out, void *stream) {

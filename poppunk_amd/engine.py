@@ -457,6 +457,86 @@ def knn_from_sketches(db, kmers, random_tbl, knn, dist_col=0, random_correct=Tru
     return oi, oj, od
 
 
+def knn_candidates(db, kmers, random_tbl, knn, dist_col=0, random_correct=True, q_begin=0, q_end=None,
+                   cap=None):
+    """Neighbour candidates of one band of query rows (ppk_knn_candidates_dev): CUDA tensors
+    (keys int32 [m] = sample, vals int64 [m] = distance bits << 32 | other sample)."""
+    torch = _torch()
+    lib = _lib.lib()
+    q_end = db.n if q_end is None else int(q_end)
+    kmers_a, random_tbl, tbl_ptr, n_clu = _prep_tables(kmers, random_tbl, db.nk)
+    dev = "cuda:%d" % db.device
+    rows = rows_in_band(db.n, 0, q_begin, q_end)
+    if cap is None:
+        cap = min(2 * rows, max(1 << 20, (256 + 256 * knn) * max(q_end - q_begin, 1) * 2))
+    with torch.cuda.device(db.device):
+        while True:
+            keys = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
+            vals = torch.empty(max(cap, 1), dtype=torch.int64, device=dev)
+            n_cand = C.c_ulonglong(0)
+            rc = lib.ppk_knn_candidates_dev(db._h, kmers_a.ctypes.data_as(C.POINTER(C.c_int32)), tbl_ptr, n_clu,
+                                            FLAG_RANDOM_CORRECT if random_correct else 0, int(knn), int(dist_col),
+                                            int(q_begin), q_end, C.c_void_p(keys.data_ptr()),
+                                            C.c_void_p(vals.data_ptr()), cap, C.byref(n_cand),
+                                            _stream_ptr(db.device))
+            m = int(n_cand.value)
+            if rc == _lib.ERR_CAPACITY:
+                cap = m + m // 4 + 1024
+                continue
+            _lib.check(rc, "ppk_knn_candidates_dev")
+            return keys[:m], vals[:m]
+
+
+def knn_select(keys, vals, n, knn):
+    """Every sample's knn smallest (distance, column) keys out of a candidate list
+    (ppk_knn_select_dev) -> (i, j, dist) CUDA tensors of length n*knn."""
+    torch = _torch()
+    dev = keys.device
+    oi = torch.empty(n * knn, dtype=torch.int64, device=dev)
+    oj = torch.empty(n * knn, dtype=torch.int64, device=dev)
+    od = torch.empty(n * knn, dtype=torch.float32, device=dev)
+    keys = keys.contiguous()
+    vals = vals.contiguous()
+    with torch.cuda.device(dev):
+        rc = _lib.lib().ppk_knn_select_dev(C.c_void_p(keys.data_ptr()), C.c_void_p(vals.data_ptr()), int(keys.shape[0]),
+                                           int(n), int(knn), C.c_void_p(oi.data_ptr()), C.c_void_p(oj.data_ptr()),
+                                           C.c_void_p(od.data_ptr()), _stream_ptr(dev.index))
+        _lib.check(rc, "ppk_knn_select_dev")
+    return oi, oj, od
+
+
+def knn_sharded(db, kmers, random_tbl, knn, rank, world_size, dist_col=0, random_correct=True, group=None,
+                band_fn=None):
+    """k nearest neighbours of every sample on N GPUs: every rank holds the full resident sketches and
+    emits the neighbour candidates of its band of the triangle (the band split of the distance job:
+    equal pair counts); the candidate lists -- tens to hundreds per sample, not the n^2 / N distances --
+    are gathered to rank 0 with the same grouped send/recv as the distance blocks, and rank 0 selects.
+    Returns (i, j, dist) on rank 0, None elsewhere.  `band_fn(q_begin, q_end) -> (keys, vals)` overrides
+    the HIP launch (CPU gloo tests of the exchange)."""
+    torch = _torch()
+    import torch.distributed as dist_
+    bounds = shard_bounds(db.n, 0, world_size)
+    qb, qe = bounds[rank], bounds[rank + 1]
+    if band_fn is not None:
+        keys, vals = band_fn(qb, qe)
+    else:
+        keys, vals = knn_candidates(db, kmers, random_tbl, knn, dist_col, random_correct, qb, qe)
+    if world_size > 1:
+        nccl = str(dist_.get_backend(group)).lower() == "nccl"
+        cnt = torch.tensor([keys.shape[0]], dtype=torch.int64, device=keys.device if nccl else "cpu")
+        counts = [torch.zeros_like(cnt) for _ in range(world_size)]
+        dist_.all_gather(counts, cnt, group=group)
+        counts = [int(c.item()) for c in counts]
+        both = torch.stack([keys.to(torch.int64), vals], dim=1).contiguous()      # one exchange: [m, 2] int64
+        full = gather_bands(both, counts, 2, torch.int64, both.device, rank, world_size, 0, group)
+        if rank != 0:
+            return None
+        keys, vals = full[:, 0].to(torch.int32).contiguous(), full[:, 1].contiguous()
+    if band_fn is not None and not keys.is_cuda:
+        return keys, vals                  # CPU test of the exchange: the caller selects
+    return knn_select(keys, vals, db.n, knn)
+
+
 # ---- multi-GPU: one process per GPU, band-sharded pair space, gather to rank 0 -------------
 
 def shard_bounds(n_ref, n_qry, world_size):

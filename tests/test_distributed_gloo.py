@@ -85,8 +85,37 @@ def _worker(rank, world, port, n_ref, n_qry, ret):
 
     e_full, e_counts = engine.edges_sharded(DB(n_ref), DB(n_qry) if n_qry else None, kmers, tbl, rank,
                                             world, band_fn=edge_fn, device="cpu")
+    # neighbour candidates (engine.knn_sharded): variable-length (sample, key) lists per band, gathered to
+    # rank 0 in one exchange.  Stand-in candidates: EVERY pair of the band, for both its samples --
+    # the selection of the gathered lists must then be the k nearest neighbours of the whole matrix.
+    knn_ok = True
+    if not n_qry:
+        import struct
+
+        def cand_fn(qb, qe):
+            keys, vals = [], []
+            for q in range(qb, qe):
+                for r in range(q + 1, n_ref):
+                    row = q * n_ref - q * (q + 1) // 2 + (r - q - 1)
+                    bits = struct.unpack("<I", struct.pack("<f", float(want_all[row, 0])))[0]
+                    keys += [q, r]
+                    vals += [(bits << 32) | r, (bits << 32) | q]
+            return torch.tensor(keys, dtype=torch.int32), torch.tensor(vals, dtype=torch.int64)
+
+        got = engine.knn_sharded(DB(n_ref), kmers, tbl, 3, rank, world, band_fn=cand_fn)
+        if rank == 0:
+            keys, vals = got[0].numpy(), got[1].numpy()
+            wi, wj, wd = oracle.knn(oracle.long_to_square(want_all[:, 0]), 3)
+            for smp in range(n_ref):
+                mine = np.sort(vals[keys == smp].astype(np.uint64))[:3]
+                knn_ok = knn_ok and [int(v & 0xffffffff) for v in mine] == wj[3 * smp:3 * smp + len(mine)].tolist()
+            knn_ok = knn_ok and len(keys) == n_ref * (n_ref - 1)
+        else:
+            knn_ok = got is None
     if rank == 0:
         want, _ = oracle.query(ref_sk, qry_sk, kmers, 16, 14, tbl)
+        if not knn_ok:
+            ret.put(False)
         ok_e = e_full is not None and np.array_equal(e_full.numpy(), want_edges) and sum(e_counts) == len(want_edges)
         if not ok_e:
             ret.put(False)

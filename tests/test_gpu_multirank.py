@@ -25,3 +25,4 @@ def test_two_ranks_one_gpu_matches_single_launch():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "RESULT equal=True" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     assert "EDGES equal=True" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "KNN equal=True" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -105,6 +105,26 @@ def test_knn_from_tiles_equals_oracle(n, related):
     db.close()
 
 
+def test_knn_candidates_of_bands_select_to_the_whole_answer():
+    """The N-GPU decomposition on one GPU: the candidates of four bands of query rows (any order),
+    concatenated and selected, are the neighbours of the whole job."""
+    import torch
+    from poppunk_amd import engine, synth
+    kmers = np.asarray(synth.DEFAULT_KMERS, dtype=np.int32)
+    sk, _ = synth.make_sketches(2600, kmers, cluster_size=40, seed=26)
+    tbl = synth.random_match_table(kmers)
+    db = engine.SketchDB(sk, 16, 14)
+    wi, wj, wd = engine.knn_from_sketches(db, kmers, tbl, 7, dist_col=1, method="tiles")
+    bounds = engine.shard_bounds(db.n, 0, 4)
+    parts = [engine.knn_candidates(db, kmers, tbl, 7, dist_col=1, q_begin=bounds[i], q_end=bounds[i + 1], cap=1000)
+             for i in (2, 0, 3, 1)]                     # cap 1000: the capacity retry is exercised
+    keys = torch.cat([p[0] for p in parts])
+    vals = torch.cat([p[1] for p in parts])
+    gi, gj, gd = engine.knn_select(keys, vals, db.n, 7)
+    assert torch.equal(gi, wi) and torch.equal(gj, wj) and torch.equal(gd, wd)
+    db.close()
+
+
 def test_knn_from_tiles_at_50000_without_any_matrix():
     """n = 50 000 (beyond the 46 340 where the square stops fitting the default budget): the tile path
     equals the band-by-band path -- which computes both triangles -- neighbour for neighbour, from a

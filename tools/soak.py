@@ -2,7 +2,8 @@
 """Randomised differential campaign, GPU path vs the CPU oracle, wider than the test-suite:
 random n / split / bands, nk 2..11, sketchsize64 1..40, bbits in {14 (v2 kernel), 8, 16 (generic
 kernel)}, multi-cluster random tables, mixed related / unrelated data, counts / jaccard / distance /
-fused-edge modes.  Prints one line per case and a summary; exits non-zero on any mismatch.
+fused-edge modes, neighbours from the tiles, both settings of the two [EXT] switches (kernel and
+oracle flipped together).  Prints one line per case and a summary; exits non-zero on any mismatch.
 
     gpurun -- python tools/soak.py [n_cases] [seed]
 """
@@ -41,6 +42,10 @@ def main():
             _lib.set_option("ksplit", 0)
         else:
             _lib.set_option("ksplit", 640)
+        ext = (int(rng.integers(0, 2)), int(rng.integers(0, 2))) if rng.integers(0, 3) == 0 else (0, 0)
+        _lib.set_option("ext_collision_adjust", ext[0])
+        _lib.set_option("ext_fit_skip", ext[1])
+        oracle.set_ext(ext[0], ext[1])
         sk, member = synth.make_sketches(n, kmers, sketchsize64=s64, bbits=bbits,
                                          cluster_size=int(rng.integers(5, 80)), seed=int(rng.integers(1, 1 << 30)),
                                          related=related)
@@ -98,6 +103,17 @@ def main():
                 fe = torch.cat(fe).cpu().numpy()
                 if not np.array_equal(fe, np.asarray(we).reshape(-1, 2)):
                     msgs.append("fused edges differ (%d vs %d)" % (len(fe), len(we)))
+            # neighbours straight from the tiles == get_kNN_distances(longToSquare(.)) of the same distances
+            cnt_bits_k = int(64 * s64).bit_length()
+            if qry is None and bbits == 14 and nk * cnt_bits_k <= 128 and nr > 1:
+                knn = int(rng.integers(1, 33))
+                col = int(rng.integers(0, 2))
+                gi, gj, gd = engine.knn_from_sketches(db, kmers, t_tbl, knn, dist_col=col, random_correct=use_tbl,
+                                                      method="tiles")
+                wi, wj, wd = oracle.knn(oracle.long_to_square(got[:, col]), knn)
+                if not (np.array_equal(gi.cpu().numpy(), wi) and np.array_equal(gj.cpu().numpy(), wj)
+                        and np.array_equal(gd.cpu().numpy(), wd)):
+                    msgs.append("kNN from tiles differs (k=%d col=%d)" % (knn, col))
             db.close()
             if dbq is not None:
                 dbq.close()
@@ -105,8 +121,11 @@ def main():
             msgs.append("EXCEPTION %r" % (e,))
         status = "ok" if not msgs else "MISMATCH: " + "; ".join(msgs)
         bad += bool(msgs)
-        print("case %3d bbits=%2d s64=%2d nk=%d n=%4d nr=%4d clu=%d tbl=%d related=%d  %s"
-              % (case, bbits, s64, nk, n, nr, n_clu, use_tbl, related, status), flush=True)
+        print("case %3d bbits=%2d s64=%2d nk=%d n=%4d nr=%4d clu=%d tbl=%d related=%d ext=%d%d  %s"
+              % (case, bbits, s64, nk, n, nr, n_clu, use_tbl, related, ext[0], ext[1], status), flush=True)
+    _lib.set_option("ext_collision_adjust", 0)
+    _lib.set_option("ext_fit_skip", 0)
+    oracle.set_ext(0, 0)
     print("%d cases, %d mismatches, %.0f s" % (n_cases, bad, time.time() - t_start))
     sys.exit(1 if bad else 0)
 
