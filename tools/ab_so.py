@@ -3,6 +3,8 @@
 drift and box-to-box differences cancel.
 
     python tools/ab_so.py A.so B.so [C.so ...] [rounds]
+
+`A.so@PPK_ABLATE=32` runs that build with the variable set (the library reads PPK_* once at load).
 """
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -43,7 +45,11 @@ def main():
     res = {so: [] for so in sos}
     for r in range(rounds):
         for so in sos:
-            o = subprocess.run([sys.executable, "-c", CHILD, so], capture_output=True, text=True)
+            path, _, assign = so.partition("@")
+            env = dict(os.environ)
+            if assign:
+                env.update([assign.split("=", 1)])
+            o = subprocess.run([sys.executable, "-c", CHILD, path], capture_output=True, text=True, env=env)
             if o.returncode:
                 print(o.stderr[-2000:]); sys.exit(1)
             line = o.stdout.strip().split("\n")[-1]

@@ -261,6 +261,9 @@ int main() {
       run_product(dba, dba, d_out, "1", "P: product, no epilogue, same db");
       run_product(dbs, nullptr, d_out, "0", "P: product 10000 self");
       run_product(dbs, nullptr, d_out, "1", "P: product 10000 self, no epilogue");
+      run_product(dbs, nullptr, d_out, "16", "P: product 10000 self, no first-copy wait");
+      run_product(dbs, nullptr, d_out, "17", "P: 10000 self, no epilogue, no first wait");
+      run_product(dba, dbb, d_out, "16", "P: product, no first-copy wait");
     }
     if (rep == 2) {
       hipLaunchKernelGGL(fill_random, dim3((words * n + 255) / 256), dim3(256), 0, 0, in, words * n);
