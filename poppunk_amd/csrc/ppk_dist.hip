@@ -647,7 +647,12 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
   constexpr int NQP = (BB + PPP - 1) / PPP;   // query pieces per chunk
   constexpr int NPIECE = 2 * BB + NQP;        // 28 ref pieces + query pieces
   constexpr int PW = (NPIECE + NW - 1) / NW;  // DMA pieces per wavefront per chunk
-  __shared__ u32x4 lds[2 * CHUNK_U4];         // double buffer: 63 KB (2 WG/CU) or 70 KB (1 WG/CU)
+  // double buffer: 63 KB.  The modes with a per-pair fit take 80 KB -- two workgroups then own all
+  // 160 KB of a CU -- so that the epilogue of an interior tile can hold the whole (E, F) table
+  // (5 k x 1024 counts x 16 B) in LDS, see below.
+  constexpr bool LDS_TABLE = NW == 8 && W == 2 && !KSPLIT && (MODE == MODE_DIST || MODE == MODE_MASK || MODE == MODE_KNN);
+  constexpr int TAB_U4 = 5 * 1024;
+  __shared__ u32x4 lds[LDS_TABLE && TAB_U4 > 2 * CHUNK_U4 ? TAB_U4 : 2 * CHUNK_U4];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -784,8 +789,10 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
       for (int q = 0; q < TQ; ++q) pw[i][r][q] = 0;
 
   issue_dma(0, half);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
+  if (!(p.ablate & 16)) {   // (bit 16, measurement only: what hiding the tile's first copy could win)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
 
   // the whole loop is instantiated twice (full / half block) rather than branching around the two
   // instruction streams inside it: a live `half` flag costs the one register the loop does not have
@@ -960,6 +967,138 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
 #pragma unroll
     for (int r = 0; r < R; ++r) cr[r] = (ref_clu && ref_of(r) < p.n_ref) ? ref_clu[ref_of(r)] : 0;
     unsigned n_fail_wave = 0;   // failed fits of this wavefront: ONE atomic at the end
+    uint32_t knn_bits[MODE == MODE_KNN ? TQ : 1][R];   // MODE_KNN: distance bits of the 16 pairs, ~0 = no pair
+    if constexpr (MODE == MODE_KNN) {
+#pragma unroll
+      for (int q = 0; q < TQ; ++q)
+#pragma unroll
+        for (int r = 0; r < R; ++r) knn_bits[q][r] = 0xffffffffu;
+    }
+    // ---- interior tiles of the default sketch shape -------------------------------------------
+    // Almost every tile of a large job lies off the diagonal and inside the band, holds 5 k of 11-bit
+    // counts and has one cluster pair.  Such a tile needs no per-pair validity, cluster or band
+    // arithmetic, and its 80 (E, F) look-ups per lane do not go to memory at all: 640 divergent
+    // 16-byte gathers per tile occupy the CU's (in-order) vector memory path for ~40 000 cycles, during
+    // which the OTHER resident workgroup's block copies queue behind them and its eight wavefronts sit at
+    // their barrier (measured: the same gathers with lane-uniform addresses make the kernel 2.7 %
+    // faster; halving the epilogue's VALU work changes nothing; more gathers in flight make it slower).
+    // Instead the workgroup copies the table's rows for counts 0..1023 -- 5 x 16 KB = exactly the 80 KB
+    // it owns, its compare buffers being dead -- into LDS with 80 one-KB DMA pieces and every look-up is
+    // a ds_read_b128.  Count 1024 (every bin equal) wraps to row 0, whose entry is always the NaN
+    // sentinel (J = 0 is below the floor), so such a pair takes the general path like any failed fit.
+    // Same expressions, same order as fit_packed: same bits.
+    bool interior = false;
+    if constexpr (LDS_TABLE) {
+      interior = p.lut32 && p.nk == 5 && p.cnt_bits == 11 && p.lut_kstride == 1025 && !ref_clu && !qry_clu &&
+                 !strip && !half && !(p.ablate & 32) && r0 + V2_RT <= p.r_limit && q0 >= qb &&
+                 q0 + V2_QT <= qe && (!p.self || r0 >= q0 + V2_QT);      // workgroup-uniform
+    }
+    const bool table_in_lds = interior;      // (a wavefront may still leave the interior path: `interior` is cleared)
+    if constexpr (LDS_TABLE) {
+    if (interior) {
+      {
+        const char *tab = reinterpret_cast<const char *>(lut + p.lut_total) + 16 * lane_late;
+        constexpr int PIECES = TAB_U4 / 64 / NW;      // 10 one-KB pieces per wavefront
+#pragma unroll
+        for (int t = 0; t < PIECES; ++t) {
+          const int piece = wave * PIECES + t;        // k = piece / 16, rows 64 * (piece % 16) ..
+          __builtin_amdgcn_global_load_lds(PPK_GPTR(tab + (size_t)(piece >> 4) * (1025 * 16) + (piece & 15) * 1024),
+                                           PPK_LPTR(lds + piece * 64), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+      // two register sets of 5 look-ups: pair b+1's are in flight while pair b is finished (three sets
+      // measure the same, four spill)
+      constexpr int SETS = 2;
+      f64x2 ef[SETS][5];
+      const char __attribute__((address_space(3))) *ltab =
+          (const char __attribute__((address_space(3))) *)(__attribute__((address_space(3))) void *)lds;
+      auto gather = [&](int b, f64x2 (&e)[5]) {
+        const uint32_t lo = pw[0][b & 3][b >> 2], hi = pw[1][b & 3][b >> 2];
+        // k at bit 11 * (4 - k) of the 55-bit register; byte offset = (count mod 1024) * 16
+        const uint32_t o0 = (hi >> 8) & 0x3ff0u;
+        const uint32_t o1 = (hi << 3) & 0x3ff0u;
+        const uint32_t o2 = (__builtin_amdgcn_alignbit(hi, lo, 22) << 4) & 0x3ff0u;
+        const uint32_t o3 = (lo >> 7) & 0x3ff0u;
+        const uint32_t o4 = (lo << 4) & 0x3ff0u;
+        typedef const f64x2 __attribute__((address_space(3))) *LP;
+        e[0] = *reinterpret_cast<LP>(ltab + o0);
+        e[1] = *reinterpret_cast<LP>(ltab + 16384 + o1);
+        e[2] = *reinterpret_cast<LP>(ltab + 32768 + o2);
+        e[3] = *reinterpret_cast<LP>(ltab + 49152 + o3);
+        e[4] = *reinterpret_cast<LP>(ltab + 65536 + o4);
+      };
+#pragma unroll
+      for (int b = 0; b < SETS - 1; ++b) gather(b, ef[b]);
+      float core[R], acc[R];
+#pragma unroll
+      for (int b = 0; b < R * TQ; ++b) {
+        const int q = b >> 2, r = b & 3;
+        if (b + SETS - 1 < R * TQ) {
+          gather(b + SETS - 1, ef[(b + SETS - 1) % SETS]);
+          asm volatile("" ::: "memory");    // the gathers of later pairs stay ahead of everything pair b does
+        }
+        {
+          const f64x2(&e)[5] = ef[b % SETS];
+          const double pe = e[0].x * e[1].x * e[2].x * e[3].x * e[4].x;
+          const double pf = e[0].y * e[1].y * e[2].y * e[3].y * e[4].y;
+          // some lane has a k below the floor: the whole wavefront goes through the general statement below
+          if (!__all(pe == pe)) {
+            interior = false;
+            break;
+          }
+          fit_finish(pe, pf, core[r], acc[r]);
+          // finished HERE (not sunk to the stores, which would keep four pairs' gathers live)
+          asm volatile("" : "+v"(core[r]), "+v"(acc[r]));
+        }
+        if (r != R - 1) continue;
+        // the query's four pairs are done: write its rows
+        const size_t qq = qw0 + q;   // wave-uniform
+        if constexpr (MODE == MODE_DIST) {
+          // refs 2l and 2l+1 are adjacent rows: 16 bytes at 8-byte alignment, one global_store_dwordx4
+          // (the look-ups wait on lgkmcnt, the stores count in vmcnt: neither waits for the other)
+          const size_t rowq = (p.self ? qq * p.n_ref - (qq * (qq + 1)) / 2 - qq - 1 : qq * p.n_ref) - p.row_base;
+          float2 *orow = static_cast<float2 *>(out) + (rowq + r0);
+          typedef float f32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            f32x4_a8 v;
+            v.x = core[2 * h];
+            v.y = acc[2 * h];
+            v.z = core[2 * h + 1];
+            v.w = acc[2 * h + 1];
+            if (!(p.ablate & 128))      // (measurement only)
+              *reinterpret_cast<f32x4_a8 *>(orow + (2u * (uint32_t)lane_late + 128u * h)) = v;
+          }
+        } else if constexpr (MODE == MODE_MASK) {
+          uint64_t ball[R];
+#pragma unroll
+          for (int rr = 0; rr < R; ++rr) {
+            const float xs = __fdiv_rn(core[rr], p.scale_x), ys = __fdiv_rn(acc[rr], p.scale_y);
+            const float sd = ppk_line_dist(xs, ys, p.x_max, p.y_max, p.slope);
+            ball[rr] = __ballot(p.inclusive ? (sd <= 0.0f) : (sd < 0.0f));
+          }
+          if (lane_late == 0) {
+            uint64_t *mrow = mask_out + (qq - qb) * p.n_rtiles + rt * 4;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const uint64_t e = ball[2 * h], o = ball[2 * h + 1];
+              const uint64_t w0 = spread_even((uint32_t)e) | (spread_even((uint32_t)o) << 1);
+              const uint64_t w1 = spread_even((uint32_t)(e >> 32)) | (spread_even((uint32_t)(o >> 32)) << 1);
+              if (rt * 4 + 2 * h < p.n_rtiles) mrow[2 * h] = w0;
+              if (rt * 4 + 2 * h + 1 < p.n_rtiles) mrow[2 * h + 1] = w1;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int rr = 0; rr < R; ++rr)
+            knn_bits[q][rr] = __float_as_uint((p.knn_col ? acc[rr] : core[rr]) + 0.0f);
+        }
+      }
+    }
+    }
+    if (!interior) {
     // A batch = the lane's refs 2h, 2h+1 against query q (2 x nk gathers).  With the default k list
     // the gathers of batch b+1 are issued BEFORE batch b is consumed (two register sets, alternating):
     // the table look-ups are the only memory latency in the epilogue, and there are 8 batches of it.
@@ -995,13 +1134,6 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
     uint64_t ball[R];
     bool valid[R], failed[R];
     float core[R], acc[R];
-    uint32_t knn_bits[MODE == MODE_KNN ? TQ : 1][R];   // MODE_KNN: distance bits of the 16 pairs, ~0 = no pair
-    if constexpr (MODE == MODE_KNN) {
-#pragma unroll
-      for (int q = 0; q < TQ; ++q)
-#pragma unroll
-        for (int r = 0; r < R; ++r) knn_bits[q][r] = 0xffffffffu;
-    }
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       if (MODE == MODE_KNN && !wave_active) break;     // nothing was compared: every pair stays "no pair"
@@ -1131,6 +1263,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
         }
       }
     }
+    }   // !interior
     if (n_failed && n_fail_wave && lane_late == 0) atomicAdd(n_failed, (unsigned long long)n_fail_wave);
     if constexpr (MODE == MODE_KNN) {
       KnnState *ks = reinterpret_cast<KnnState *>(mask_out);
@@ -1143,6 +1276,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
       constexpr uint64_t NONE = ~0ull;
       const int knn = p.knn;
       // ---- 1. distances to LDS; the wave's own queries: local top-k by rounds of wave-wide minima ----
+      if (table_in_lds) __syncthreads();      // every wavefront is done with the (E, F) table that lives there
       if (wave == 0 && lane_late == 0) lctl[0] = 0;
       uint32_t won[TQ];       // per lane and query: byte r = the round ref r's candidate was extracted in (0xff: none)
       int cq[TQ];             // candidates of query q that pass (wave-uniform): the first cq[q] rounds

@@ -688,3 +688,37 @@ def test_fit_tables_are_reused_only_for_identical_inputs(sk300):
     d, _ = engine.dist(db, None, k2, synth.random_match_table(k2))
     assert np.abs(d.cpu().numpy() - oracle.query(sk, None, k2, 16, 14, synth.random_match_table(k2), threads=4)[0]).max() <= TOL
     db.close()
+
+
+def test_interior_tiles_with_identical_and_unrelated_pairs(tbl1, ppk_option):
+    """The epilogue of an interior tile (off the diagonal, default sketch shape, one cluster pair) reads
+    the (E, F) table from LDS, where only counts 0..1023 have a row: a count of 1024 -- every bin of
+    a k equal -- wraps to row 0, the NaN sentinel, and the wavefront takes the general path.  Samples
+    copied far away in the index space (exact duplicates, duplicates at some k only) and unrelated
+    samples (every fit fails) sit in interior tiles here, next to ordinary pairs; ref x query too."""
+    ppk_option("ksplit", 0)          # the tile kernel's own epilogue, not the small-job path
+    n = 1500
+    sk, _ = synth.make_sketches(n, KMERS, cluster_size=40, seed=99)
+    rng = np.random.Generator(np.random.PCG64(5))
+    sk = sk.copy()
+    sk[700] = sk[10]                                   # all five k identical
+    sk[1301, :2] = sk[45, :2]                          # identical at the two smallest k only
+    sk[900, 4] = sk[3, 4]                              # identical at the largest k only
+    for s in (600, 1100, 1499):                        # unrelated to everything: all fits fail
+        sk[s] = rng.integers(0, np.iinfo(np.int64).max, size=sk[s].shape, dtype=np.int64).astype(np.uint64)
+    got, gf = pp_sketchlib.query_arrays(sk, None, KMERS, 16, 14, tbl1)
+    want, wf = oracle.query(sk, None, KMERS, 16, 14, random_tbl=tbl1, threads=8)
+    assert gf == wf and wf > 0
+    assert np.abs(got - want).max() <= TOL
+    row = 10 * n - 10 * 11 // 2 + (700 - 10 - 1)
+    assert np.array_equal(got[row], [0.0, 0.0])
+    ref, qry = sk[:1024], sk[1024:]
+    got, gf = pp_sketchlib.query_arrays(ref, qry, KMERS, 16, 14, tbl1)
+    want, wf = oracle.query(ref, qry, KMERS, 16, 14, random_tbl=tbl1, threads=8)
+    assert gf == wf
+    assert np.abs(got - want).max() <= TOL
+    # the interior path off (ablate bit 32): bit-identical results either way
+    a, _ = pp_sketchlib.query_arrays(sk, None, KMERS, 16, 14, tbl1)
+    ppk_option("ablate", 32)
+    b, _ = pp_sketchlib.query_arrays(sk, None, KMERS, 16, 14, tbl1)
+    assert np.array_equal(a, b)
