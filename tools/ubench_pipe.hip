@@ -264,6 +264,10 @@ int main() {
       run_product(dbs, nullptr, d_out, "16", "P: product 10000 self, no first-copy wait");
       run_product(dbs, nullptr, d_out, "17", "P: 10000 self, no epilogue, no first wait");
       run_product(dba, dbb, d_out, "16", "P: product, no first-copy wait");
+      run_product(dba, dbb, d_out, "32", "P: product, table look-ups from memory");
+      run_product(dba, dbb, d_out, "128", "P: product, nothing stored");
+      run_product(dba, dbb, d_out, "0", "P: product kernel (again)");
+      run_product(dbs, nullptr, d_out, "32", "P: 10000 self, table look-ups from memory");
     }
     if (rep == 2) {
       hipLaunchKernelGGL(fill_random, dim3((words * n + 255) / 256), dim3(256), 0, 0, in, words * n);
