@@ -1336,7 +1336,6 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
       for (int j = 0; j < 16; ++j) bits2[j] = ld[(qhalf * 16 + j) * V2_RT + ref_local];
       const uint32_t thr_r = rf2 < p.n_ref ? __hip_atomic_load(thr + rf2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
       uint32_t pass2 = 0;       // bit j: candidate j is among the k smallest of the 16 and passes the bound
-      int n_valid = 0;
       uint32_t kth2 = 0xffffffffu;
 #pragma unroll
       for (int a = 0; a < 16; ++a) {
@@ -1346,7 +1345,6 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
 #pragma unroll
         for (int c = 0; c < 16; ++c) rank += (bits2[c] < bits2[a] || (bits2[c] == bits2[a] && c < a)) ? 1 : 0;
         const bool is = bits2[a] != 0xffffffffu;
-        n_valid += is ? 1 : 0;
         if (is && rank < knn && bits2[a] <= thr_r) pass2 |= 1u << a;
         if (is && rank == knn - 1) kth2 = bits2[a];
       }
