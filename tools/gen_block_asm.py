@@ -32,6 +32,7 @@ class Map:
     def __init__(self, tq):
         self.TQ = tq
         self.A0, self.A1 = 72, 76
+        self.B0, self.B1 = 48, 52      # second ref-operand buffer (GEN_A2: odd planes)
         self.S0 = 80
         self.S1 = self.S0 + 2 * tq
         self.ACC = self.S1 + 2 * tq
@@ -43,8 +44,11 @@ class Map:
     def hi_acc(self, r, q):
         return self.ACC + 2 * (self.TQ * r + q)
 
-    def a_reg(self, r, hi):      # r in 0..3 -> register of ref r's lo/hi dword
-        base = self.A0 if r < 2 else self.A1
+    def a_reg(self, r, hi, plane=0, a2=False):      # r in 0..3 -> register of ref r's lo/hi dword
+        if a2 and (plane & 1):
+            base = self.B0 if r < 2 else self.B1
+        else:
+            base = self.A0 if r < 2 else self.A1
         return base + 2 * (r & 1) + (1 if hi else 0)
 
     def s_reg(self, plane, q, hi):
@@ -56,7 +60,7 @@ REF_PLANE_BYTES = 2048      # 256 samples x 8 B
 REF_HALF_BYTES = 1024
 
 
-def gen(QRY_PLANE_BYTES, TQ=4, dma_planes=None, half=False):
+def gen(QRY_PLANE_BYTES, TQ=4, dma_planes=None, half=False, a2=False):
     """TQ = 4: counters %[c0]..%[c15], one per pair (p = 4r + q).
     TQ = 8: counters %[c0]..%[c15], two pairs per counter (pair p = 8r + q -> counter p >> 1,
     16-bit half p & 1; a block adds at most 64 and a k at most 16 * 64 per pair ... callers
@@ -97,10 +101,12 @@ def gen(QRY_PLANE_BYTES, TQ=4, dma_planes=None, half=False):
                  % (base + 4 * i, base + 4 * i + 3, plane * QRY_PLANE_BYTES + 16 * i))
 
     def load_a0(plane):
-        emit("ds_read_b128 v[%d:%d], %%[rp] offset:%d" % (A0, A0 + 3, plane * REF_PLANE_BYTES))
+        base = m.B0 if (a2 and (plane & 1)) else A0
+        emit("ds_read_b128 v[%d:%d], %%[rp] offset:%d" % (base, base + 3, plane * REF_PLANE_BYTES))
 
     def load_a1(plane):
-        emit("ds_read_b128 v[%d:%d], %%[rp] offset:%d" % (A1, A1 + 3, plane * REF_PLANE_BYTES + REF_HALF_BYTES))
+        base = m.B1 if (a2 and (plane & 1)) else A1
+        emit("ds_read_b128 v[%d:%d], %%[rp] offset:%d" % (base, base + 3, plane * REF_PLANE_BYTES + REF_HALF_BYTES))
 
     def ops(plane, rs):
         for r in rs:
@@ -109,7 +115,7 @@ def gen(QRY_PLANE_BYTES, TQ=4, dma_planes=None, half=False):
             for q in range(TQ):
                 for hi in (0, 1):
                     acc = hi_acc(r, q) if hi else lo_acc(r, q)
-                    a, s = a_reg(r, hi), s_reg(plane, q, hi)
+                    a, s = a_reg(r, hi, plane, a2), s_reg(plane, q, hi)
                     if plane == 0:
                         emit("v_xnor_b32 v%d, v%d, v%d" % (acc, a, s))
                     else:
@@ -145,6 +151,34 @@ def gen(QRY_PLANE_BYTES, TQ=4, dma_planes=None, half=False):
             if not last:
                 load_a1(b + 1)
         for r in (2, 3):
+            for q in range(TQ):
+                p = TQ * r + q
+                emit("v_bcnt_u32_b32 %%[c%d], v%d, %%[c%d]" % (p, lo_acc(r, q), p))
+                emit("v_bcnt_u32_b32 %%[c%d], v%d, %%[c%d]" % (p, hi_acc(r, q), p))
+        return out
+    if a2:
+        # Ref operands double-buffered like the query operands: ALL four reads of plane b+1 are issued
+        # before the 32 compares of plane b, so every operand has a full plane of the wave's own issue
+        # time to arrive (single-buffered: half a plane), and one s_waitcnt per plane instead of two.
+        # A wavefront then stalls less when fewer of its SIMD's other wavefronts are there to cover for
+        # it -- while the other workgroup is at a barrier or in its epilogue.  (GEN_A2=1; measured
+        # 1 % SLOWER than the single-buffered schedule, same box: not used.)
+        load_s(0)
+        load_a0(0)
+        load_a1(0)
+        for b in range(BB):
+            last = b == BB - 1
+            if prio and (b == 0 or prio[b] != prio[b - 1]):
+                emit("s_setprio %d" % prio[b])
+            if not last:
+                load_s(b + 1)
+                load_a0(b + 1)
+                load_a1(b + 1)
+                emit("s_waitcnt lgkmcnt(%d)" % (NS + 2))   # plane b's operands have landed
+            else:
+                emit("s_waitcnt lgkmcnt(0)")
+            ops(b, (0, 1, 2, 3))
+        for r in range(4):
             for q in range(TQ):
                 p = TQ * r + q
                 emit("v_bcnt_u32_b32 %%[c%d], v%d, %%[c%d]" % (p, lo_acc(r, q), p))
@@ -205,18 +239,19 @@ def main():
     # experiments (tools/ubench_pipe.hip only): the rejected 256 x 64 tile and 4x8 register tile
     dst_x = os.path.join(here, "ppk_block_asm_experiments.inc")
     m4, m8 = Map(4), Map(8)
-    clob = ", ".join('"v%d"' % i for i in range(m4.A0, m4.END))
+    a2 = os.environ.get("GEN_A2", "0") == "1"
+    clob = ", ".join('"v%d"' % i for i in (list(range(m4.B0, m4.B0 + 8)) if a2 else []) + list(range(m4.A0, m4.END)))
     clob8 = ", ".join('"v%d"' % i for i in range(m8.A0, m8.END))
     with open(dst, "w") as f:
         f.write("// GENERATED by tools/gen_block_asm.py -- do not edit.  One 64-bin block (14 planes) of the\n"
                 "// 4x4 register tile with bank-aware fixed VGPRs v%d..v%d; see the generator for the map.\n"
                 "// _Q32: 32 queries per workgroup tile (query plane stride 256 bytes).\n"
                 % (m4.A0, m4.END - 1))
-        write_macro(f, "PPK_BLOCK_ASM_Q32", gen(256))
+        write_macro(f, "PPK_BLOCK_ASM_Q32", gen(256, a2=a2))
         f.write("// the same with the 4 LDS-DMA pieces of the next block issued inside the stream\n")
         # (GEN_DMA_PLANES=a,b,c,d: experiments with the placement of the four pieces)
         planes = [int(x) for x in os.environ.get("GEN_DMA_PLANES", "1,4,7,10").split(",")]
-        write_macro(f, "PPK_BLOCK_DMA_ASM_Q32", gen(256, 4, dma_planes=planes))
+        write_macro(f, "PPK_BLOCK_DMA_ASM_Q32", gen(256, 4, dma_planes=planes, a2=a2))
         f.write("// refs 2/3 only (diagonal tiles with every query beyond the first 128 refs)\n")
         write_macro(f, "PPK_BLOCK_HALF_ASM_Q32", gen(256, 4, half=True))
         f.write("#define PPK_BLOCK_ASM PPK_BLOCK_ASM_Q32\n")
