@@ -976,8 +976,8 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
     }
     // ---- interior tiles of the default sketch shape -------------------------------------------
     // Almost every tile of a large job lies off the diagonal and inside the band, holds 5 k of 11-bit
-    // counts and has one cluster pair.  Such a tile needs no per-pair validity, cluster or band
-    // arithmetic, and its 80 (E, F) look-ups per lane do not go to memory at all: 640 divergent
+    // counts and has one cluster pair (checked below).  Such a tile needs no per-pair validity, cluster
+    // or band arithmetic, and its 80 (E, F) look-ups per lane do not go to memory at all: 640 divergent
     // 16-byte gathers per tile occupy the CU's (in-order) vector memory path for ~40 000 cycles, during
     // which the OTHER resident workgroup's block copies queue behind them and its eight wavefronts sit at
     // their barrier (measured: the same gathers with lane-uniform addresses make the kernel 2.7 %
@@ -988,16 +988,35 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
     // sentinel (J = 0 is below the floor), so such a pair takes the general path like any failed fit.
     // Same expressions, same order as fit_packed: same bits.
     bool interior = false;
+    size_t cp_tile = 0;      // the tile's one cluster pair: its block of the table (entries)
     if constexpr (LDS_TABLE) {
-      interior = p.lut32 && p.nk == 5 && p.cnt_bits == 11 && p.lut_kstride == 1025 && !ref_clu && !qry_clu &&
+      interior = p.lut32 && p.nk == 5 && p.cnt_bits == 11 && p.lut_kstride == 1025 &&
                  !strip && !half && !(p.ablate & 32) && r0 + V2_RT <= p.r_limit && q0 >= qb &&
                  q0 + V2_QT <= qe && (!p.self || r0 >= q0 + V2_QT);      // workgroup-uniform
+      if (interior && (ref_clu || qry_clu)) {
+        // Several random-match clusters (a real database has ~3, by base composition): the samples of
+        // one tile -- one species, neighbours in the database -- almost always share one, and then the
+        // tile needs ONE cluster pair's block of the table.  Every wavefront holds the same 256 refs
+        // and reads all 32 queries' cluster ids, so all eight reach the same verdict without talking.
+        const int c_ref = ref_clu ? ref_clu[r0] : 0;
+        const int c_qry = qry_clu ? qry_clu[q0] : 0;
+        bool same = true;
+        if (ref_clu) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) same = same && cr[r] == c_ref;
+        }
+        if (qry_clu) {
+          for (int j = 1; j < V2_QT; ++j) same = same && qry_clu[q0 + j] == c_qry;      // scalar loads
+        }
+        interior = __all(same);
+        cp_tile = (size_t)(c_ref * p.n_clu + c_qry) * p.lut_cpstride;
+      }
     }
     const bool table_in_lds = interior;      // (a wavefront may still leave the interior path: `interior` is cleared)
     if constexpr (LDS_TABLE) {
     if (interior) {
       {
-        const char *tab = reinterpret_cast<const char *>(lut + p.lut_total) + 16 * lane_late;
+        const char *tab = reinterpret_cast<const char *>(lut + p.lut_total + 2 * cp_tile) + 16 * lane_late;
         constexpr int PIECES = TAB_U4 / 64 / NW;      // 10 one-KB pieces per wavefront
 #pragma unroll
         for (int t = 0; t < PIECES; ++t) {

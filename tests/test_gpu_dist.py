@@ -717,8 +717,25 @@ def test_interior_tiles_with_identical_and_unrelated_pairs(tbl1, ppk_option):
     want, wf = oracle.query(ref, qry, KMERS, 16, 14, random_tbl=tbl1, threads=8)
     assert gf == wf
     assert np.abs(got - want).max() <= TOL
+    # three random-match clusters in contiguous runs (a tile with ONE cluster pair takes the LDS path with
+    # that pair's block of the table; tiles across a run boundary do not)
+    tbl3 = (rng.random((5, 3, 3)) * 0.04).astype(np.float32)
+    clu = np.zeros(n, dtype=np.uint16)
+    clu[500:1100] = 2
+    clu[1100:] = 1
+    clu[37] = 1                                        # one stray sample inside a run
+    got3, gf = pp_sketchlib.query_arrays(sk, None, KMERS, 16, 14, tbl3, ref_clusters=clu)
+    want3, wf = oracle.query(sk, None, KMERS, 16, 14, random_tbl=tbl3, ref_clu=clu, threads=8)
+    assert gf == wf
+    assert np.abs(got3 - want3).max() <= TOL
+    got, gf = pp_sketchlib.query_arrays(ref, qry, KMERS, 16, 14, tbl3, ref_clusters=clu[:1024], qry_clusters=clu[1024:])
+    want, wf = oracle.query(ref, qry, KMERS, 16, 14, random_tbl=tbl3, ref_clu=clu[:1024], qry_clu=clu[1024:], threads=8)
+    assert gf == wf
+    assert np.abs(got - want).max() <= TOL
     # the interior path off (ablate bit 32): bit-identical results either way
     a, _ = pp_sketchlib.query_arrays(sk, None, KMERS, 16, 14, tbl1)
     ppk_option("ablate", 32)
     b, _ = pp_sketchlib.query_arrays(sk, None, KMERS, 16, 14, tbl1)
     assert np.array_equal(a, b)
+    b3, _ = pp_sketchlib.query_arrays(sk, None, KMERS, 16, 14, tbl3, ref_clusters=clu)
+    assert np.array_equal(got3, b3)
