@@ -439,3 +439,35 @@ def test_threshold_iterate_many_offsets_and_one_pass_host_calls():
     # different arguments after a parked result: a fresh computation, not the parked list
     e2 = poppunk_refine.edgeThreshold_array(d, 2, 0.4, 0.5)
     assert np.array_equal(e2, oracle.edge_threshold(d, 2, 0.4, 0.5))
+
+
+def test_forked_workers_can_use_the_library_when_the_parent_has_not_touched_the_gpu():
+    """SURVEY 8(b), threading: refine's 2-D mode calls thresholdIterate2D from forked
+    multiprocessing.Pool workers (refine.py:147-163).  Loading libppk_hip.so must not create a HIP
+    context (options and devices are set up at first use), so children forked from a parent that has
+    only IMPORTED the module each bring up their own."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, %r)
+from poppunk_amd import _lib, poppunk_refine
+_lib.lib()                                   # loaded in the parent, GPU untouched
+rng = np.random.Generator(np.random.PCG64(3))
+d = rng.random((4950, 2), dtype=np.float32)          # 100 samples, condensed
+xs = np.linspace(0.2, 0.8, 5).astype(np.float32)
+pids = []
+for w in range(2):
+    pid = os.fork()
+    if pid == 0:
+        i, j, o = poppunk_refine.thresholdIterate2D_arrays(d, xs, 0.5)
+        a0 = poppunk_refine.assignThreshold(d, 2, float(xs[0]), 0.5)
+        ok = len(i) == len(j) == len(o) and (o == 0).sum() == (a0 <= 0).sum()
+        os._exit(0 if ok else 3)
+    pids.append(pid)
+bad = [os.waitpid(p, 0)[1] for p in pids]
+sys.exit(1 if any(bad) else 0)
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
