@@ -132,6 +132,7 @@ def gen(QRY_PLANE_BYTES, TQ=4, dma_planes=None, half=False, a2=False):
     prio = None
     if dma_planes:       # (the full block of the packed modes; on the half block it measured 1 % worse)
         v = [int(x) for x in os.environ.get("GEN_PRIO", "3,2,1,0").split(",")]
+        prio_cnt = v.pop() if len(v) == BB + 1 else None      # (a 15th value: the popcount tail)
         prio = v if len(v) == BB else [v[b // 4] for b in range(BB)]
     if half:
         # Diagonal tiles whose queries all lie beyond the tile's first 128 refs: refs 0/1 of every
@@ -207,6 +208,8 @@ def gen(QRY_PLANE_BYTES, TQ=4, dma_planes=None, half=False, a2=False):
         if not last:
             load_a1(b + 1)
     # popcount-accumulate into the compiler-visible counters %[c0] .. %[c15]
+    if dma_planes and prio_cnt is not None and prio_cnt != prio[-1]:
+        emit("s_setprio %d" % prio_cnt)
     for r in range(4):
         for q in range(TQ):
             p = TQ * r + q
