@@ -30,7 +30,10 @@ pipe(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ qryT, uint3
   constexpr int NQP = (BB + PPP - 1) / PPP;
   constexpr int NPIECE = 2 * BB + NQP;
   constexpr int PW = (NPIECE + NW - 1) / NW;
-  __shared__ u32x4 lds[2 * CHUNK_U4];
+  // FEAT 16: three buffers, DMA two blocks ahead, per-slot LDS counters instead of s_barrier (a wave may
+  // run up to a block ahead of the slowest); FEAT 32: the control -- the two-buffer barrier loop with
+  // the same LDS footprint (one workgroup per CU either way)
+  __shared__ u32x4 lds[((FEAT & 48) ? 3 : 2) * CHUNK_U4 + 4];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned b = blockIdx.x;
@@ -90,6 +93,54 @@ pipe(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ qryT, uint3
 #pragma unroll
   for (int i = 0; i < 16; ++i) packed[i] = 0;
   int k = 0;
+  if constexpr ((FEAT & 16) != 0) {
+    uint32_t *flags = reinterpret_cast<uint32_t *>(lds + 3 * CHUNK_U4);      // landed[0..2] | done[0..2] (one u32x4 each... first 6 dwords)
+    if (threadIdx.x < 8) flags[threadIdx.x] = threadIdx.x < 2 ? 8u : 0u;     // blocks 0 and 1 land below, before the barrier
+    issue_dma(0);
+    issue_dma(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    auto wait_ge = [&](uint32_t *p, uint32_t v) {
+      while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < v)
+        __builtin_amdgcn_s_sleep(1);
+    };
+    auto signal = [&](uint32_t *p) {
+      if (lane == 0) __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    for (int g = 0; g < total; ++g) {
+      const int slot = g % 3, slot2 = (g + 2) % 3;
+      if (g >= 1 && g + 1 < total) {       // the pieces issued in iteration g-1 (block g+1) have had a block to land
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        signal(flags + (g + 1) % 3);
+      }
+      wait_ge(flags + slot, 8u * (uint32_t)(g / 3 + 1));
+      if (g + 2 < total) {
+        wait_ge(flags + 3 + slot2, 8u * (uint32_t)((g + 2) / 3));
+        issue_dma(slot2);
+      }
+      const uint32_t rp = (uint32_t)(size_t)(__attribute__((address_space(3))) void *)(lds + slot * CHUNK_U4 + lane);
+      const uint32_t qp = (uint32_t)(size_t)(__attribute__((address_space(3))) void *)(
+          lds + slot * CHUNK_U4 + REF_U4 + wave * (TQ / 2));
+#define OPS16                                                                                      \
+  [c0] "+v"(c[0]), [c1] "+v"(c[1]), [c2] "+v"(c[2]), [c3] "+v"(c[3]), [c4] "+v"(c[4]),            \
+      [c5] "+v"(c[5]), [c6] "+v"(c[6]), [c7] "+v"(c[7]), [c8] "+v"(c[8]), [c9] "+v"(c[9]),        \
+      [c10] "+v"(c[10]), [c11] "+v"(c[11]), [c12] "+v"(c[12]), [c13] "+v"(c[13]), [c14] "+v"(c[14]), \
+      [c15] "+v"(c[15])
+      asm volatile(PPK_BLOCK_ASM_Q32 : OPS16 : [rp] "v"(rp), [qp] "v"(qp) : "memory", PPK_BLOCK_CLOBBERS);
+      signal(flags + 3 + slot);
+      if ((g & 15) == 15) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          sum += c[i] * (i + 1);
+          c[i] = 0;
+        }
+        ++k;
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    out[(size_t)blockIdx.x * NW * 64 + threadIdx.x] = sum;
+    return;
+  }
   issue_dma(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -174,8 +225,13 @@ void run(const uint64_t *in, const uint64_t *in2, uint32_t *out, const char *wha
   float ms; (void)hipEventElapsedTime(&ms, e0, e1);
   ms /= 5;
   hipError_t err = hipGetLastError();
-  printf("%-44s NW=%d TQ=%d tile=256x%d : %.3f ms  %.2f Gpairs/s  (%s)\n", what, NW, TQ, NW * TQ, ms,
-         (double)n * n / (ms * 1e-3) / 1e9, hipGetErrorString(err));
+  // checksum of the per-thread sums (variants of one tile shape must agree)
+  std::vector<uint32_t> h((size_t)r_tiles * q_tiles * NW * 64);
+  (void)hipMemcpy(h.data(), out, h.size() * 4, hipMemcpyDeviceToHost);
+  uint64_t cs = 0;
+  for (uint32_t v : h) cs = cs * 1099511628211ull + v;
+  printf("%-44s NW=%d TQ=%d tile=256x%d : %.3f ms  %.2f Gpairs/s  (%s, checksum %016llx)\n", what, NW, TQ, NW * TQ, ms,
+         (double)n * n / (ms * 1e-3) / 1e9, hipGetErrorString(err), (unsigned long long)cs);
 }
 
 // the product kernel through the C ABI, same shape (10240 x 10240 ref x query), HIP-event timed
@@ -280,6 +336,8 @@ int main() {
     run<8, 4, 4, 1>(in, in, out, "A-nodma");
     run<8, 4, 4, 2>(in, in, out, "A+packed u64 counts");
     run<8, 4, 4, 3>(in, in, out, "A+packed, no dma");
+    run<8, 4, 2, 32>(in, in, out, "E: A at one workgroup per CU (94.5 KB LDS held)");
+    run<8, 4, 2, 16>(in, in, out, "F: E with 3 buffers + LDS counters, no barrier");
     if (rep == 0) {
     run<4, 8, 2>(in, in, out, "B: 4x8, 4 waves, 2 WG/CU");
     run<8, 8, 2>(in, in, out, "C: 4x8, 8 waves, 1 WG/CU");
