@@ -990,7 +990,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
     bool interior = false;
     size_t cp_tile = 0;      // the tile's one cluster pair: its block of the table (entries)
     if constexpr (LDS_TABLE) {
-      interior = p.lut32 && p.nk == 5 && p.cnt_bits == 11 && p.lut_kstride == 1025 &&
+      interior = p.lut32 && p.nk >= 3 && p.nk <= 5 && p.cnt_bits == 11 && p.lut_kstride == 1025 &&
                  !strip && !half && !(p.ablate & 32) && r0 + V2_RT <= p.r_limit && q0 >= qb &&
                  q0 + V2_QT <= qe && (!p.self || r0 >= q0 + V2_QT);      // workgroup-uniform
       if (interior && (ref_clu || qry_clu)) {
@@ -1021,10 +1021,16 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
 #pragma unroll
         for (int t = 0; t < PIECES; ++t) {
           const int piece = wave * PIECES + t;        // k = piece / 16, rows 64 * (piece % 16) ..
-          __builtin_amdgcn_global_load_lds(PPK_GPTR(tab + (size_t)(piece >> 4) * (1025 * 16) + (piece & 15) * 1024),
-                                           PPK_LPTR(lds + piece * 64), 16, 0, 0);
+          if ((piece >> 4) < p.nk) {
+            __builtin_amdgcn_global_load_lds(PPK_GPTR(tab + (size_t)(piece >> 4) * (1025 * 16) + (piece & 15) * 1024),
+                                             PPK_LPTR(lds + piece * 64), 16, 0, 0);
+          } else if ((piece & 15) == 0 && lane_late == 0) {
+            // 3 or 4 k: the count registers are shifted up to the 5-k layout below, the missing k read
+            // count 0 of their own block, and that row holds (1, 1): a factor that changes no bit
+            *reinterpret_cast<f64x2 *>(lds + piece * 64) = f64x2{1.0, 1.0};
+          }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
       }
       // two register sets of 5 look-ups: pair b+1's are in flight while pair b is finished (three sets
@@ -1033,8 +1039,10 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
       f64x2 ef[SETS][5];
       const char __attribute__((address_space(3))) *ltab =
           (const char __attribute__((address_space(3))) *)(__attribute__((address_space(3))) void *)lds;
+      const int up = 11 * (5 - p.nk);      // 0 with the default 5 k
       auto gather = [&](int b, f64x2 (&e)[5]) {
-        const uint32_t lo = pw[0][b & 3][b >> 2], hi = pw[1][b & 3][b >> 2];
+        const uint64_t v = (((uint64_t)pw[1][b & 3][b >> 2] << 32) | pw[0][b & 3][b >> 2]) << up;
+        const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
         // k at bit 11 * (4 - k) of the 55-bit register; byte offset = (count mod 1024) * 16
         const uint32_t o0 = (hi >> 8) & 0x3ff0u;
         const uint32_t o1 = (hi << 3) & 0x3ff0u;

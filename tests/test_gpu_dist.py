@@ -739,3 +739,33 @@ def test_interior_tiles_with_identical_and_unrelated_pairs(tbl1, ppk_option):
     assert np.array_equal(a, b)
     b3, _ = pp_sketchlib.query_arrays(sk, None, KMERS, 16, 14, tbl3, ref_clusters=clu)
     assert np.array_equal(got3, b3)
+
+
+@pytest.mark.parametrize("nk", [3, 4])
+def test_interior_tiles_with_three_and_four_kmer_lengths(ppk_option, nk):
+    """11-bit counts of 3 or 4 k also fill two dwords: the LDS-table epilogue shifts the register up
+    to the 5-k layout and the missing k read a (1, 1) row.  Same bits as the general path, oracle
+    within tolerance, fused boundary and neighbours included."""
+    ppk_option("ksplit", 0)
+    kmers = np.asarray([13, 17, 21, 25][:nk], dtype=np.int32)
+    n = 1300
+    sk, _ = synth.make_sketches(n, kmers, cluster_size=40, seed=70 + nk)
+    sk = sk.copy()
+    sk[900] = sk[20]                                   # an exact duplicate far away
+    tbl = synth.random_match_table(kmers)
+    got, gf = pp_sketchlib.query_arrays(sk, None, kmers, 16, 14, tbl)
+    want, wf = oracle.query(sk, None, kmers, 16, 14, random_tbl=tbl, threads=8)
+    assert gf == wf
+    assert np.abs(got - want).max() <= TOL
+    db = engine.SketchDB(sk, 16, 14)
+    x_max, y_max = synth.boundary_for_quantile(got, 0.1)
+    e, _ = engine.dist_edges(db, None, kmers, tbl, slope=2, x_max=x_max, y_max=y_max)
+    assert np.array_equal(e.cpu().numpy(), oracle.edge_threshold(got, 2, x_max, y_max))
+    gi, gj, gd = engine.knn_from_sketches(db, kmers, tbl, 4, method="tiles")
+    wi, wj, wd = oracle.knn(oracle.long_to_square(got[:, 0]), 4)
+    assert np.array_equal(gi.cpu().numpy(), wi) and np.array_equal(gj.cpu().numpy(), wj)
+    assert np.array_equal(gd.cpu().numpy(), wd)
+    db.close()
+    ppk_option("ablate", 32)
+    b, _ = pp_sketchlib.query_arrays(sk, None, kmers, 16, 14, tbl)
+    assert np.array_equal(got, b)
