@@ -61,8 +61,12 @@ int ppk_device_count(int *n);
 
 /* Run-time options.  Each has a PPK_<NAME> environment variable that is read ONCE, when the
  * library is first used; afterwards only ppk_set_option changes it.
- *   measurement / tuning (never change results): "ablate", "map", "strip", "ksplit",
- *     "chunk_rows", "prefault_threads", "db_cache" 
+ *   tuning (never change results): "map", "strip", "ksplit", "chunk_rows", "prefault_threads",
+ *     "db_cache", "progress" 
+ *   measurement only: "ablate", a bit mask that SKIPS parts of the distance kernel to time the rest
+ *     (1 epilogue, 2 compare, 4 DMA, 8 barriers, 16 first-copy wait, 128 stores: results are
+ *     garbage) or switches a path off (32: the LDS-table epilogue; results unchanged); 0 in any
+ *     real use
  *   [EXT] readings of pp-sketchlib behaviour that this tree cannot verify:
  *     "ext_collision_adjust" 0 (default): the b-bit collision adjustment of calc_intersize is
  *                              never in effect (upstream gates it on expected == 0, as recalled);

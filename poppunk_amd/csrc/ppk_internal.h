@@ -30,11 +30,12 @@ struct ppk_db {
 
 // Run-time options ---------------------------------------------------------------
 // Every PPK_* environment knob is read ONCE, when the library is first used (ppk_config()); after
-// that only ppk_set_option() changes a value.  None of the measurement knobs changes results; the
+// that only ppk_set_option() changes a value.  None of the tuning knobs changes results (`ablate`
+// skips work to time the rest: measurement only, 0 in any real use); the
 // two ext_* options select between the readings of pp-sketchlib behaviour that cannot be checked
 // in this tree (DESIGN.md "[EXT] assumptions").
 struct PpkConfig {
-  std::atomic<long long> ablate{0};             // PPK_ABLATE: 1 skip epilogue, 2 compare, 4 DMA, 8 barriers
+  std::atomic<long long> ablate{0};             // PPK_ABLATE: skip 1 epilogue, 2 compare, 4 DMA, 8 barriers, 16 first-copy wait, 128 stores; 32 LDS-table path off
   std::atomic<long long> map{0};                // PPK_MAP: tile order of dist_kernel_v2 (0 = XCD-contiguous runs)
   std::atomic<long long> strip{1};              // PPK_STRIP: strip tiles for the ragged right edge
   std::atomic<long long> ksplit{640};           // PPK_KSPLIT: tile-count threshold of the small-job path
