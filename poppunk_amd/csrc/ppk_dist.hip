@@ -148,7 +148,7 @@ struct DistParams {
   int xcd_map;            // 1: XCD-aware tile order (v2)
   int lut32;              // the whole fit table is addressable with 32-bit byte offsets
   size_t lut_total;       // doubles in the log-J table; the (E, F) table of the fast path follows it
-  int k_split;            // host side only: launch the KSPLIT instantiation (gridDim.y = nk, one k per workgroup)
+  int k_split;            // > 0: the KSPLIT instantiation (gridDim.y = nk * k_split: one k, or a half / quarter of one, per workgroup)
   size_t ks_rows;         // KSPLIT: rows of the band; its counts go to scratch k-major, [k][row]
   unsigned r_tiles, q_tiles;   // v2 tile grid
   unsigned n_strip_pad;        // n_strip rounded up to a multiple of 8 (keeps block % 8 = XCD for the rest)
@@ -1529,7 +1529,12 @@ regress_packed_kernel(const uint32_t *__restrict__ counts, size_t n_rows, const 
       cp = (size_t)ref_clu[r] * p.n_clu + (qry_clu ? qry_clu[q] : 0);
     }
     u128 pk = 0;
-    for (int k = 0; k < p.nk; ++k) pk |= (u128)counts[(size_t)k * n_rows + i] << (p.cnt_bits * k);   // [k][row]
+    const int slices = p.k_split;      // a k's blocks were counted in `slices` pieces: [k * slices + piece][row]
+    for (int k = 0; k < p.nk; ++k) {
+      uint32_t c = 0;
+      for (int h = 0; h < slices; ++h) c += counts[((size_t)k * slices + h) * n_rows + i];
+      pk |= (u128)c << (p.cnt_bits * k);
+    }
     float core, acc;
     fit_packed<u128>(pk, lut, cp * p.lut_cpstride, p, core, acc, failed);
     out[i] = make_float2(core, acc);
@@ -1800,12 +1805,27 @@ int ppk_launch_dist(const ppk_db *ref, const ppk_db *qry_or_null, const int32_t 
     // one workgroup per (tile, k) -> raw counts; then the same per-pair fit as the tile epilogue
     const size_t rows = p.self ? (q_end * ref->n - (q_end * (q_end + 1)) / 2) - p.row_base
                                : (q_end - q_begin) * ref->n;
+    // Very small jobs still leave workgroup slots empty with one workgroup per (tile, k): each k is cut
+    // into 2 or 4 pieces of consecutive blocks as long as that stays within one round of the 512
+    // slots.  The kernel needs no change: the resident layout is [k][block][plane][sample], so "nk * S
+    // k-mer lengths of s64 / S blocks" addresses the same words; the regression pass adds the pieces.
+    int slices = 1;
+    {
+      const size_t rt = (ref->n + V2_RT - 1) / V2_RT, qt = (q_end - q_begin + 31) / 32;
+      const size_t wgs = (p.self ? rt * qt / 2 + qt : rt * qt) * (size_t)p.nk;
+      while (slices < 4 && wgs * (size_t)slices * 2 <= 512 && p.s64 % (slices * 2) == 0) slices *= 2;
+    }
     void *p_cnt = nullptr;
-    int rc = ppk_scratch_get(ref->device, SLOT_ITER_A, rows * (size_t)p.nk * 4 + 256, &p_cnt);
+    int rc = ppk_scratch_get(ref->device, SLOT_ITER_A, rows * (size_t)p.nk * slices * 4 + 256, &p_cnt);
     if (rc != PPK_OK) return rc;
-    p.k_split = 1;
+    p.k_split = slices;
     p.ks_rows = rows;
-    rc = launch_tiles_unpacked<MODE_COUNTS>(ref, qry, d_lut, d_rtab, p_cnt, nullptr, nullptr, p, s);
+    {
+      DistParams pc = p;
+      pc.nk = p.nk * slices;
+      pc.s64 = p.s64 / slices;
+      rc = launch_tiles_unpacked<MODE_COUNTS>(ref, qry, d_lut, d_rtab, p_cnt, nullptr, nullptr, pc, s);
+    }
     if (rc != PPK_OK) return rc;
     const bool use_clu = p.random_correct && p.n_clu > 1;
     hipLaunchKernelGGL(regress_packed_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s,

@@ -52,6 +52,8 @@ def main():
         n_clu = int(rng.choice([1, 1, 2, 3]))
         tbl = (rng.random((nk, n_clu, n_clu)) * 0.05).astype(np.float32)
         clu = (rng.integers(0, n_clu, size=n)).astype(np.uint16)
+        if rng.integers(0, 2):
+            clu = np.sort(clu)          # contiguous runs: whole tiles with one cluster pair (the LDS-table epilogue)
         use_tbl = bool(rng.integers(0, 4))
         nr = int(rng.integers(1, n)) if n > 2 and rng.integers(0, 2) else n
         ref, qry = sk[:nr], (sk[nr:] if nr < n else None)

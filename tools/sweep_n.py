@@ -6,8 +6,9 @@ import torch
 from poppunk_amd import _lib, engine, synth
 K = np.asarray(synth.DEFAULT_KMERS, dtype=np.int32); T = synth.random_match_table(K)
 lib = _lib.lib()
-sk = synth.make_sketches_device(100000, K, seed=13)      # drawn on the device: numpy needs minutes for 100k
-for n in (500, 1000, 2000, 3000, 5000, 10000, 14000, 20000, 30000, 50000, 100000):
+sk = synth.make_sketches_device(max(int(x) for x in os.environ.get("SIZES", "100000").split(",")), K, seed=13)      # drawn on the device: numpy needs minutes for 100k
+SIZES = [int(x) for x in os.environ.get("SIZES", "500,1000,2000,3000,5000,10000,14000,20000,30000,50000,100000").split(",")]
+for n in SIZES:
     db = engine.SketchDB(sk[:n], 16, 14)
     rows = n * (n - 1) // 2
     out = torch.empty((rows, 2), dtype=torch.float32, device="cuda")
