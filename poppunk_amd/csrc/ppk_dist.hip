@@ -977,11 +977,12 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
     // ---- interior tiles of the default sketch shape -------------------------------------------
     // Almost every tile of a large job lies off the diagonal and inside the band, holds 5 k of 11-bit
     // counts and has one cluster pair (checked below).  Such a tile needs no per-pair validity, cluster
-    // or band arithmetic, and its 80 (E, F) look-ups per lane do not go to memory at all: 640 divergent
-    // 16-byte gathers per tile occupy the CU's (in-order) vector memory path for ~40 000 cycles, during
-    // which the OTHER resident workgroup's block copies queue behind them and its eight wavefronts sit at
-    // their barrier (measured: the same gathers with lane-uniform addresses make the kernel 2.7 %
-    // faster; halving the epilogue's VALU work changes nothing; more gathers in flight make it slower).
+    // or band arithmetic, and its 80 (E, F) look-ups per lane do not go to memory at all.  What the
+    // epilogue costs is its DURATION (while a workgroup is in it the CU runs on the other workgroup's
+    // wavefronts alone), and with the table in memory that was 16 dependent round trips of divergent
+    // 16-byte gathers, 640 instructions of 64 different lines per tile (measured: the same gathers with
+    // lane-uniform addresses make the kernel 2.7 % faster; halving the epilogue's VALU work changes
+    // nothing; more gathers in flight make it slower).
     // Instead the workgroup copies the table's rows for counts 0..1023 -- 5 x 16 KB = exactly the 80 KB
     // it owns, its compare buffers being dead -- into LDS with 80 one-KB DMA pieces and every look-up is
     // a ds_read_b128.  Count 1024 (every bin equal) wraps to row 0, whose entry is always the NaN
