@@ -471,3 +471,15 @@ sys.exit(1 if any(bad) else 0)
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_quickstart_example_runs_end_to_end(tmp_path):
+    """examples/quickstart.py: .h5 database -> queryDatabase -> dists.pkl/.npy -> boundary -> edges ->
+    clusters, and the fused edge list equal to the unfused one."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "quickstart.py"), "400", str(tmp_path)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "identical" in r.stdout
