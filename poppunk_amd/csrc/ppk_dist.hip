@@ -1763,9 +1763,12 @@ int ppk_launch_dist(const ppk_db *ref, const ppk_db *qry_or_null, const int32_t 
   bool small = false;
   if (!too_wide && !d_mask && !knn_args && p.bbits == 14 && p.nk >= 2) {
     const size_t rt = (ref->n + V2_RT - 1) / V2_RT, qt = (q_end - q_begin + 31) / 32;
-    // default 640; measured: 2 000 self (315 tiles) 175 vs 245 us, 2 500 self (480 tiles) 255 vs 252 us, 3 000 (760) 361 vs 368
-    const long long ks = ppk_config().ksplit.load();   // A/B: tile-count threshold, 0 = off
-    const size_t limit = ks > 0 ? (size_t)ks : 0;
+    // default 215 tiles at 5 k (scaled by 5 / nk: the comparison is between nk * tiles short workgroups
+    // and `tiles` long ones).  Measured with the round-2 kernels, 5 k, s = 1024 (k-split vs tile
+    // kernel, us): 1 000 genomes / 80 tiles 81 vs 163; 1 500 / 200: 142 vs 158; 1 600 / 225: 168 vs 164;
+    // 1 800 / 285: 190 vs 149; 2 400 / 450: 276 vs 215; 2 600 / 533: 326 vs 214; 2 800 / 572: 332 vs 353
+    const long long ks = ppk_config().ksplit.load();   // tile-count threshold at 5 k, 0 = off
+    const size_t limit = ks > 0 ? (size_t)ks * 5 / (size_t)p.nk : 0;
     small = (p.self ? rt * qt / 2 + qt : rt * qt) <= limit;
   }
   if (too_wide && knn_args) return ppk_fail(PPK_ERR_ARG, "neighbours from tiles need nk * count bits <= 128");

@@ -38,7 +38,7 @@ struct PpkConfig {
   std::atomic<long long> ablate{0};             // PPK_ABLATE: skip 1 epilogue, 2 compare, 4 DMA, 8 barriers, 16 first-copy wait, 128 stores; 32 LDS-table path off
   std::atomic<long long> map{0};                // PPK_MAP: tile order of dist_kernel_v2 (0 = XCD-contiguous runs)
   std::atomic<long long> strip{1};              // PPK_STRIP: strip tiles for the ragged right edge
-  std::atomic<long long> ksplit{640};           // PPK_KSPLIT: tile-count threshold of the small-job path
+  std::atomic<long long> ksplit{215};           // PPK_KSPLIT: tile-count threshold (at 5 k) of the small-job path
   std::atomic<long long> chunk_rows{8ll << 20};     // PPK_CHUNK_ROWS: rows per device buffer of ppk_query
   std::atomic<long long> prefault_threads{8};   // PPK_PREFAULT_THREADS
   std::atomic<long long> db_cache{1};           // PPK_DB_CACHE: ppk_query keeps its resident databases / buffers
