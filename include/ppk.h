@@ -50,8 +50,9 @@ extern "C" {
  * grow-only per-device scratch (log-J table, edge bitmask, sort buffers): each holds the
  * device's mutex while it enqueues, and a scratch block last used on another stream is waited
  * for (an event) before it is re-used, so calls on different streams are ordered where they
- * share scratch and concurrent elsewhere.  The host-buffer query (ppk_query, ppk_query_db) runs
- * one call at a time, like the blocking binding it replaces. */
+ * share scratch and concurrent elsewhere.  The host-buffer query (ppk_query, ppk_query_dbs) runs
+ * one call at a time, like the blocking binding it replaces; inside a call every listed device has
+ * its own worker thread. */
 const char *ppk_last_error(void);
 /* frees the per-device scratch, ppk_query's cached resident databases and its result buffers
  * (synchronises each device that holds any) */
@@ -230,9 +231,19 @@ int ppk_threshold_iterate_2d_dev(const float *d_dist, size_t n_rows, const float
  * bounded by the sketches plus those buffers for any job size -- the
  * device-memory chunking of pp-sketchlib's CUDA path [EXT].  `out` is written by this call only; a few
  * helper threads touch its pages ahead of the download (option "prefault_threads", default 8, 0 = off).
- * The resident form of the sketches and the two buffers are KEPT between calls (keyed by the host
- * pointer, the dimensions and a fingerprint of the contents; option "db_cache" 0 turns it off;
- * ppk_release_scratch frees them): a caller that rewrites sketches in place must do one of the two.
+ * The resident form of the sketches and the two buffers are KEPT between calls, keyed by the host
+ * pointer, the dimensions and a 64-bit hash of EVERY word of the array (computed on the helper threads,
+ * ~1-2 ms per 90 MB): an array rewritten in place, or another one at a recycled address, is uploaded
+ * again -- there is no stale-answer mode.  Option "db_cache" 0 turns the cache off; ppk_release_scratch
+ * frees it; at most 4 databases per device are kept, and they are dropped first when device memory
+ * runs out.  A caller that knows its data's identity avoids the hash altogether by holding ppk_db
+ * handles and calling ppk_query_dbs (what the Python mirror does).
+ * Several devices: ONE HOST WORKER THREAD PER LISTED DEVICE uploads (or finds resident) the sketches,
+ * computes its share of the pair space and downloads it into its disjoint row range of `out`, all
+ * devices side by side -- each GPU's PCIe link carries its own share (a copy into pageable memory
+ * blocks the issuing thread, hence threads, not just streams).  This is the multi-GPU route of a
+ * single-process caller (PopPUNK passes one device_id; the mirror reads PPK_DEVICES=0,1,...).  The
+ * interrupt check and the progress meter run on the calling thread.
  */
 int ppk_query(const uint64_t *ref_sk, size_t n_ref, const uint64_t *qry_sk,
               size_t n_qry, const int32_t *kmers, size_t nk, size_t sketchsize64,
@@ -240,29 +251,49 @@ int ppk_query(const uint64_t *ref_sk, size_t n_ref, const uint64_t *qry_sk,
               const uint16_t *qry_clu, size_t n_clu, int flags, const int *devices,
               int n_dev, void *out, unsigned long long *n_failed);
 
-/* The same with the sketches already resident (ppk_db_create; both on one device, fully uploaded):
- * nothing is uploaded or re-laid out, the result goes to the host array `out` through that device's
- * two persistent sub-band buffers.  What the Python mirror of queryDatabase calls for a database it
- * has already loaded (poppunk_assign against one reference database; every --plot-fit re-query,
- * PopPUNK/sketchlib.py:547-564). */
+/* The same with the sketches already resident: refs[d] (and qrys[d]; qrys == NULL => self) is the
+ * database as created by ppk_db_create on the d-th device, one per device, all of the same samples.
+ * Nothing is uploaded, hashed or looked up; device d computes its share and sends it to its rows of
+ * the host array `out` through its two persistent sub-band buffers, the devices side by side on one
+ * worker thread each.  What the Python mirror of queryDatabase calls for a database it has loaded
+ * (it keys the handles by file, modification time, names and k list: poppunk_assign against one
+ * reference database; every --plot-fit re-query, PopPUNK/sketchlib.py:547-564). */
+int ppk_query_dbs(const ppk_db *const *refs, const ppk_db *const *qrys, int n_dev,
+                  const int32_t *kmers, const float *random_tbl, size_t n_clu, int flags,
+                  void *out, unsigned long long *n_failed);
+/* one device: ppk_query_dbs(&ref, qry ? &qry : NULL, 1, ...) */
 int ppk_query_db(const ppk_db *ref, const ppk_db *qry, const int32_t *kmers,
                  const float *random_tbl, size_t n_clu, int flags, void *out,
                  unsigned long long *n_failed);
+/* What the last ppk_query / ppk_query_dbs of the process ran side by side (measurement, tests):
+ * vals[0] device entries, [1] worker threads (0 = ran on the calling thread), [2] most result
+ * downloads in flight at one time, [3] most sketch uploads in flight at one time, [4] wall ms of the
+ * device phase, [5] longest upload ms, [6] longest per-device ms. */
+int ppk_query_last_stats(double *vals, int n);
 
 int ppk_assign_threshold(const float *dist, size_t n_rows, int slope, float x_max,
                          float y_max, int device_id, float *out);
 
 /* Edge lists have a data-dependent size: *n_edges always receives the total;
  * PPK_ERR_CAPACITY is returned when it exceeds cap (nothing is written).  The call that reports
- * PPK_ERR_CAPACITY has already computed the whole list: it stays parked on the device, and the next
- * call with the same arguments and enough room only copies it out -- "ask the size, then fetch" costs
- * one upload and one device pass (also for the two sweeps below). */
+ * PPK_ERR_CAPACITY has already computed the whole list: it stays parked on the device for the calling
+ * thread, which fetches it with ppk_parked_fetch into a buffer of that size -- "ask the size, then
+ * fetch" costs one upload and one device pass (also for the two sweeps below).  The hand-over is
+ * explicit: no call is ever answered from a parked result, so a rewritten or recycled input array
+ * cannot meet a stale list; calling the same entry point again with more room simply recomputes.  A
+ * parked result is dropped by the next call of this family (any thread) and by ppk_release_scratch. */
 int ppk_edge_threshold(const float *dist, size_t n_rows, size_t n_ref, int slope,
                        float x_max, float y_max, int inclusive, int device_id,
                        long long *ij_out, size_t cap, size_t *n_edges);
 int ppk_generate_tuples(const int32_t *assignments, size_t n_rows, int within_label,
                         int self, size_t num_ref, long long int_offset, int device_id,
                         long long *ij_out, size_t cap, size_t *n_edges);
+/* The result the calling thread's last ppk_edge_threshold / ppk_generate_tuples (out0 = int64 [n][2];
+ * out1, out2 ignored) or ppk_threshold_iterate_1d / _2d (out0, out1, out2 = i, j, offset index, int64
+ * [n] each) call parked when it returned PPK_ERR_CAPACITY.  cap = room in entries; *n_out (nullable)
+ * receives the entry count.  PPK_ERR_STATE when this thread has nothing parked; the result is freed by
+ * a successful fetch. */
+int ppk_parked_fetch(long long *out0, long long *out1, long long *out2, size_t cap, size_t *n_out);
 
 /* ------------------------------------------------------------------------
  * Long <-> square distance transforms and k nearest neighbours (SURVEY.md 8f

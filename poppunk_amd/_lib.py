@@ -82,6 +82,9 @@ SIGNATURES = {
     "ppk_get_option": (C.c_int, [C.c_char_p, _llp]),
     "ppk_set_interrupt_check": (C.c_int, [_vp]),
     "ppk_query_db": (C.c_int, [_vp, _vp, _i32p, _f32p, _sz, C.c_int, _vp, _ullp]),
+    "ppk_query_dbs": (C.c_int, [C.POINTER(_vp), C.POINTER(_vp), C.c_int, _i32p, _f32p, _sz, C.c_int, _vp, _ullp]),
+    "ppk_query_last_stats": (C.c_int, [C.POINTER(C.c_double), C.c_int]),
+    "ppk_parked_fetch": (C.c_int, [_llp, _llp, _llp, _sz, _szp]),
 }
 
 _lib = None

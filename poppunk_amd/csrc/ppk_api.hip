@@ -1,5 +1,6 @@
 // C-ABI entry points of libppk_hip.so (declared in include/ppk.h).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <unistd.h>
@@ -418,6 +419,10 @@ int scratch_get(int dev, int slot, size_t bytes, void **out) {
     if (e != hipSuccess) (void)hipDeviceSynchronize();
   }
   if (s.bytes < bytes) {
+    if (slot == SLOT_LUT) {          // the tables a later call might re-use go with the block
+      g_dev[dev].lut_key = 0;
+      g_dev[dev].lut_ptr = nullptr;
+    }
     if (s.p) {
       (void)hipDeviceSynchronize();  // earlier launches may still read the old block
       (void)hipFree(s.p);
@@ -523,6 +528,10 @@ extern "C" int ppk_release_scratch(void) {
       if (g_dev[d].slot[k].ev) (void)hipEventDestroy(g_dev[d].slot[k].ev);
       g_dev[d].slot[k] = Scratch();
     }
+    // a re-allocated block commonly comes back at the same address: without this the next call with the
+    // same k list and table would take the freed tables for valid (stage_tables) and skip lut_kernel
+    g_dev[d].lut_key = 0;
+    g_dev[d].lut_ptr = nullptr;
   }
   return PPK_OK;
 }
@@ -858,10 +867,10 @@ extern "C" int ppk_generate_tuples_dev(const int32_t *d_assign, size_t n_rows, i
 
 // ---- host-buffer wrappers -------------------------------------------------------------
 // What PopPUNK itself calls.  State kept between calls (per device, grow-only, released by
-// ppk_release_scratch): the two result buffers and the failed-fit counter, so that a call does not
-// pay hipMalloc/hipFree; and, for ppk_query, a small cache of resident databases keyed by the
-// caller's host array, so that repeated queries against the same sketches (poppunk_assign against
-// one reference database; every k-mer fit plot) upload and re-lay them out once.
+// ppk_release_scratch): the two result buffers and the failed-fit counter of every (device,
+// occurrence) pair, so that a call does not pay hipMalloc/hipFree; and, for ppk_query, a small cache
+// of resident databases keyed by the caller's host array AND A HASH OF ITS WHOLE CONTENT, so that
+// repeated queries against the same sketches upload and re-lay them out once.
 namespace {
 std::mutex g_query_mu;           // one host-buffer query at a time (PopPUNK calls blocking, from one thread)
 
@@ -872,7 +881,7 @@ struct QueryBufs {
   hipEvent_t done[2] = {nullptr, nullptr};
 };
 constexpr int kMaxDup = 4;       // a device may be listed up to kMaxDup times in one ppk_query call
-QueryBufs g_qbufs[64][kMaxDup];  // [device][occurrence in the device list]
+QueryBufs g_qbufs[64][kMaxDup];  // [device][occurrence in the device list]; one worker owns each
 
 int query_buf(int dev, int dup, int i, size_t bytes, void **out) {
   QueryBufs &q = g_qbufs[dev][dup];
@@ -891,11 +900,30 @@ int query_buf(int dev, int dup, int i, size_t bytes, void **out) {
   return PPK_OK;
 }
 
-// Resident databases of earlier ppk_query calls.  Key: the host pointer, the dimensions, the device
-// and a fingerprint of the contents (a strided sample of 2^16 words plus both ends, and the whole
-// cluster vector): a different sketch array that happens to sit at a recycled address does not
-// match.  A caller that rewrites sketches IN PLACE between calls must turn the cache off
-// (ppk_set_option("db_cache", 0) / PPK_DB_CACHE=0) or call ppk_release_scratch().
+// worker streams per (device, occurrence): two entries naming one device run on their own streams
+int part_streams(int device, int dup, hipStream_t *out) {
+  static std::mutex mu;
+  static hipStream_t cache[64][kMaxDup][2];
+  std::lock_guard<std::mutex> lk(mu);
+  if (device < 0 || device >= 64 || dup < 0 || dup >= kMaxDup) return ppk_fail(PPK_ERR_ARG, "bad worker stream request");
+  for (int i = 0; i < 2; ++i) {
+    if (!cache[device][dup][i] && hipStreamCreate(&cache[device][dup][i]) != hipSuccess) {
+      cache[device][dup][i] = nullptr;
+      return ppk_fail(PPK_ERR_HIP, "hipStreamCreate failed");
+    }
+    out[i] = cache[device][dup][i];
+  }
+  return PPK_OK;
+}
+
+// ---- resident databases of earlier ppk_query calls ------------------------------------------------
+// Key: the host pointer, the dimensions, the device and a 64-bit hash of EVERY word of the sketch array
+// and of the cluster vector.  A sketch array rewritten in place, or a different one at a recycled
+// address, therefore never matches (round 2 sampled 2^16 words: above ~65 000 genomes a one-sample
+// change could be missed -- a silent stale answer).  The hash runs on the helper threads that
+// pre-touch the result array (option "prefault_threads"): 90 MB in ~1-2 ms, against the ~13 ms of the
+// upload + re-layout it saves.  Callers that know their data's identity skip it altogether by holding
+// ppk_db handles (ppk_db_create + ppk_query_dbs: what the Python mirror does).
 struct CachedDb {
   const uint64_t *host = nullptr;
   size_t n = 0, nk = 0, s64 = 0, bbits = 0;
@@ -904,41 +932,83 @@ struct CachedDb {
   ppk_db *db = nullptr;
   unsigned long long stamp = 0;
 };
+std::mutex g_cache_mu;
 std::vector<CachedDb> g_db_cache;
 unsigned long long g_db_stamp = 0;
 constexpr size_t kDbCachePerDevice = 4;
 
-uint64_t mix64(uint64_t h, uint64_t v) {
+inline uint64_t mix64(uint64_t h, uint64_t v) {
   h ^= v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
   h *= 0xff51afd7ed558ccdull;
   return h ^ (h >> 32);
 }
 
-uint64_t fingerprint(const uint64_t *sk, size_t words, const uint16_t *clu, size_t n) {
-  uint64_t h = 0x243f6a8885a308d3ull ^ words;
-  const size_t edge = words < 256 ? words : 256;
-  for (size_t i = 0; i < edge; ++i) h = mix64(h, sk[i]);
-  for (size_t i = words - edge; i < words; ++i) h = mix64(h, sk[i]);
-  const size_t samples = (size_t)1 << 16;
-  if (words > samples) {
-    const size_t step = words / samples;
-    for (size_t i = 0; i < samples; ++i) h = mix64(h, sk[i * step + (i % step)]);
-  } else {
-    for (size_t i = 0; i < words; ++i) h = mix64(h, sk[i]);
+// every word of [p, p + words): four independent multiply-rotate lanes (each step is a bijection of
+// the lane state, so a change of any single word changes the result)
+uint64_t hash_words(const uint64_t *p, size_t words) {
+  uint64_t h0 = 0x243f6a8885a308d3ull, h1 = 0x13198a2e03707344ull, h2 = 0xa4093822299f31d0ull,
+           h3 = 0x082efa98ec4e6c89ull;
+  const uint64_t K = 0x9e3779b97f4a7c15ull;
+  size_t i = 0;
+  for (; i + 4 <= words; i += 4) {
+    h0 = (((h0 << 23) | (h0 >> 41)) ^ p[i]) * K;
+    h1 = (((h1 << 23) | (h1 >> 41)) ^ p[i + 1]) * K;
+    h2 = (((h2 << 23) | (h2 >> 41)) ^ p[i + 2]) * K;
+    h3 = (((h3 << 23) | (h3 >> 41)) ^ p[i + 3]) * K;
   }
+  for (; i < words; ++i) h0 = (((h0 << 23) | (h0 >> 41)) ^ p[i]) * K;
+  return mix64(mix64(mix64(mix64(words, h0), h1), h2), h3);
+}
+
+uint64_t fingerprint(const uint64_t *sk, size_t words, const uint16_t *clu, size_t n) {
+  int nt = (int)ppk_config().prefault_threads.load();
+  if (nt > 64) nt = 64;
+  if (nt < 1 || words < ((size_t)1 << 19)) nt = 1;       // < 4 MB: one thread
+  std::vector<uint64_t> part((size_t)nt, 0);
+  const size_t per = (words + (size_t)nt - 1) / (size_t)nt;
+  auto run = [&](int t) {
+    const size_t a = (size_t)t * per, b = a + per < words ? a + per : words;
+    part[(size_t)t] = a < b ? hash_words(sk + a, b - a) : 0;
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < nt; ++t) th.emplace_back(run, t);
+  run(0);
+  for (auto &t : th) t.join();
+  uint64_t h = 0x452821e638d01377ull ^ words;
+  for (int t = 0; t < nt; ++t) h = mix64(h, part[(size_t)t]);
   if (clu)
     for (size_t i = 0; i < n; ++i) h = mix64(h, clu[i] + 1u);
   return h;
 }
 
-// the resident database of (sk, ...) on `device`: from the cache, or created (and cached)
+// frees every cached database on `device` except the two a running call holds; returns how many
+size_t db_cache_evict_locked(int device, const ppk_db *keep0, const ppk_db *keep1, bool only_oldest) {
+  size_t freed = 0;
+  for (;;) {
+    size_t victim = g_db_cache.size();
+    for (size_t i = 0; i < g_db_cache.size(); ++i) {
+      const CachedDb &c = g_db_cache[i];
+      if (c.device != device || c.db == keep0 || c.db == keep1) continue;
+      if (victim == g_db_cache.size() || c.stamp < g_db_cache[victim].stamp) victim = i;
+    }
+    if (victim == g_db_cache.size()) break;
+    ppk_db_destroy(g_db_cache[victim].db);      // synchronous hipFree; nothing of an earlier call is in flight
+    g_db_cache.erase(g_db_cache.begin() + (long)victim);
+    ++freed;
+    if (only_oldest) break;
+  }
+  return freed;
+}
+
+// the resident database of (sk, ...) on `device`: from the cache (fp = the content hash, computed once
+// per call by the caller), or created and cached.  `pinned`: a database this call already uses on the
+// device (never evicted).  Called from the device's worker thread; uploads of different devices overlap.
 int db_acquire(int device, const uint64_t *sk, size_t n, size_t nk, size_t s64, size_t bbits,
-               const uint16_t *clu, hipStream_t s, ppk_db **out, bool *owned) {
+               const uint16_t *clu, uint64_t fp, bool use_cache, const ppk_db *pinned, hipStream_t s,
+               ppk_db **out, bool *owned) {
   *owned = false;
-  const bool use_cache = ppk_config().db_cache.load() != 0;
-  uint64_t fp = 0;
   if (use_cache) {
-    fp = fingerprint(sk, n * nk * s64 * bbits, clu, n);
+    std::lock_guard<std::mutex> lk(g_cache_mu);
     for (CachedDb &c : g_db_cache)
       if (c.host == sk && c.n == n && c.nk == nk && c.s64 == s64 && c.bbits == bbits &&
           c.device == device && c.fp == fp) {
@@ -946,26 +1016,25 @@ int db_acquire(int device, const uint64_t *sk, size_t n, size_t nk, size_t s64, 
         *out = c.db;
         return PPK_OK;
       }
+    // room first: the cache never holds more than kDbCachePerDevice databases per device, new one included
+    size_t on_dev = 0;
+    for (const CachedDb &c : g_db_cache) on_dev += c.device == device;
+    while (on_dev >= kDbCachePerDevice && db_cache_evict_locked(device, pinned, nullptr, true)) --on_dev;
   }
   int rc = ppk_db_create(device, sk, n, nk, s64, bbits, clu, 0, s, out);
+  if (rc == PPK_ERR_HIP) {
+    // out of device memory?  drop every cached database of this device that the call does not use, once
+    size_t freed;
+    {
+      std::lock_guard<std::mutex> lk(g_cache_mu);
+      freed = db_cache_evict_locked(device, pinned, nullptr, false);
+    }
+    if (freed) rc = ppk_db_create(device, sk, n, nk, s64, bbits, clu, 0, s, out);
+  }
   if (rc != PPK_OK) return rc;
   if (!use_cache) {
     *owned = true;
     return PPK_OK;
-  }
-  size_t on_dev = 0, oldest = 0;
-  bool have = false;
-  for (size_t i = 0; i < g_db_cache.size(); ++i)
-    if (g_db_cache[i].device == device) {
-      ++on_dev;
-      if (!have || g_db_cache[i].stamp < g_db_cache[oldest].stamp) {
-        oldest = i;
-        have = true;
-      }
-    }
-  if (on_dev >= kDbCachePerDevice) {
-    ppk_db_destroy(g_db_cache[oldest].db);      // synchronous hipFree: safe after the earlier call returned
-    g_db_cache.erase(g_db_cache.begin() + (long)oldest);
   }
   CachedDb c;
   c.host = sk;
@@ -976,36 +1045,209 @@ int db_acquire(int device, const uint64_t *sk, size_t n, size_t nk, size_t s64, 
   c.device = device;
   c.fp = fp;
   c.db = *out;
+  std::lock_guard<std::mutex> lk(g_cache_mu);
   c.stamp = ++g_db_stamp;
   g_db_cache.push_back(c);
   return PPK_OK;
 }
 
+// ---- one host query = one job, one part per listed device ---------------------------------------
 struct QueryPart {
   int device = 0;
   int dup = 0;                                  // occurrence index of `device` in the device list
+  int leader = -1;                              // dup > 0: index of the part that acquires this device's databases
   const ppk_db *ref = nullptr, *qry = nullptr;
   bool own_ref = false, own_qry = false;
   hipStream_t s = nullptr, sc = nullptr;        // compute / copy
   void *buf[2] = {nullptr, nullptr};
   unsigned long long *d_failed = nullptr;
   hipEvent_t done[2] = {nullptr, nullptr};      // sub-band in buf[i] computed
-  bool active = false;
+  std::atomic<int> db_ready{0};                 // 0 pending, 1 databases resident, -1 failed
+  int rc = PPK_OK;
+  std::string err;
+  unsigned long long failed = 0;
+  double upload_ms = 0.0, total_ms = 0.0;
 };
+
+struct QueryJob {
+  size_t n_ref = 0, n_qry = 0, nk = 0, s64 = 0, bbits = 0, n_clu = 0;
+  const int32_t *kmers = nullptr;
+  const float *random_tbl = nullptr;
+  int flags = 0;
+  // host sketches (ppk_query) -- null when the parts come with resident databases (ppk_query_dbs)
+  const uint64_t *ref_sk = nullptr, *qry_sk = nullptr;
+  const uint16_t *ref_clu = nullptr, *qry_clu = nullptr;
+  uint64_t ref_fp = 0, qry_fp = 0;
+  bool use_cache = false;
+  char *out = nullptr;
+  size_t cols = 2;
+  int C = 1;                                    // sub-bands per part
+  std::vector<size_t> bounds, row0;
+  size_t max_rows = 0;
+  HostToucher *toucher = nullptr;
+  std::atomic<int> stop{0};                     // interrupt or another part's failure: launch nothing more
+  std::atomic<long long> done_chunks{0};
+  std::atomic<int> parts_done{0};
+};
+
+// counters of the last host query (ppk_query_last_stats): what ran side by side
+struct QueryStats {
+  std::atomic<int> dl_now{0}, dl_max{0}, up_now{0}, up_max{0};
+  int parts = 0, threads = 0;
+  double wall_ms = 0.0, upload_ms_max = 0.0, part_ms_max = 0.0;
+} g_qstats;
+
+void stat_enter(std::atomic<int> &now, std::atomic<int> &mx) {
+  const int v = now.fetch_add(1) + 1;
+  int m = mx.load();
+  while (v > m && !mx.compare_exchange_weak(m, v)) {
+  }
+}
+
+double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// Everything one device does for a host query, on its own host thread: make the databases resident
+// (upload + re-layout, or a cache hit), then its C sub-bands -- sub-band c+1 computes while sub-band c
+// goes to its rows of the caller's array.  The copy into PAGEABLE host memory blocks the thread that
+// issues it, so side-by-side downloads over several PCIe links need one thread per device, not
+// just one stream per device.  `poll`: this is the calling thread (single-device job): it runs the
+// interrupt check and the progress meter itself.
+void run_part(QueryJob &job, std::vector<QueryPart> &parts, int d, bool poll, bool meter) {
+  QueryPart &p = parts[(size_t)d];
+  const double t_begin = now_ms();
+  auto fail = [&](int code) {
+    p.rc = code;
+    p.err = g_err;
+    job.stop.store(1);
+  };
+  DeviceGuard g(p.device);
+  if (!g.ok) {
+    ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(p.device));
+    p.db_ready.store(-1);
+    return fail(PPK_ERR_HIP);
+  }
+  int rc = PPK_OK;
+  // 1. resident databases
+  if (job.ref_sk) {
+    if (p.leader >= 0) {
+      QueryPart &l = parts[(size_t)p.leader];
+      int st;
+      while ((st = l.db_ready.load(std::memory_order_acquire)) == 0) std::this_thread::yield();
+      if (st < 0) {
+        p.db_ready.store(-1);
+        return;                                  // the leader has reported the failure
+      }
+      p.ref = l.ref;
+      p.qry = l.qry;
+    } else {
+      stat_enter(g_qstats.up_now, g_qstats.up_max);
+      const double t_up = now_ms();
+      ppk_db *db = nullptr;
+      rc = db_acquire(p.device, job.ref_sk, job.n_ref, job.nk, job.s64, job.bbits, job.ref_clu, job.ref_fp,
+                      job.use_cache, nullptr, p.s, &db, &p.own_ref);
+      p.ref = db;
+      if (rc == PPK_OK && job.n_qry) {
+        db = nullptr;
+        rc = db_acquire(p.device, job.qry_sk, job.n_qry, job.nk, job.s64, job.bbits, job.qry_clu, job.qry_fp,
+                        job.use_cache, p.ref, p.s, &db, &p.own_qry);
+        p.qry = db;
+      }
+      p.upload_ms = now_ms() - t_up;
+      g_qstats.up_now.fetch_sub(1);
+      if (rc != PPK_OK) {
+        p.db_ready.store(-1, std::memory_order_release);
+        return fail(rc);
+      }
+    }
+  }
+  p.db_ready.store(1, std::memory_order_release);
+  const int C = job.C;
+  const size_t first = (size_t)d * (size_t)C;
+  if (job.row0[first + (size_t)C] == job.row0[first]) return;     // an empty share (more devices than tiles)
+  // 2. buffers
+  QueryBufs &qb = g_qbufs[p.device][p.dup];
+  const size_t buf_bytes = job.max_rows * job.cols * 4;
+  rc = query_buf(p.device, p.dup, 0, buf_bytes, &p.buf[0]);
+  if (rc == PPK_OK && C > 1) rc = query_buf(p.device, p.dup, 1, buf_bytes, &p.buf[1]);
+  if (rc == PPK_OK && !qb.d_failed &&
+      hipMalloc(reinterpret_cast<void **>(&qb.d_failed), sizeof(unsigned long long)) != hipSuccess)
+    rc = ppk_fail(PPK_ERR_HIP, "hipMalloc(output) failed");
+  for (int i = 0; i < 2 && rc == PPK_OK; ++i)
+    if (!qb.done[i] && hipEventCreateWithFlags(&qb.done[i], hipEventDisableTiming) != hipSuccess)
+      rc = ppk_fail(PPK_ERR_HIP, "hipEventCreate failed");
+  if (rc != PPK_OK) return fail(rc);
+  p.d_failed = qb.d_failed;
+  p.done[0] = qb.done[0];
+  p.done[1] = qb.done[1];
+  (void)hipMemsetAsync(p.d_failed, 0, sizeof(unsigned long long), p.s);
+  // 3. step c: launch sub-band c, then fetch sub-band c-1
+  for (int c = 0; c <= C && rc == PPK_OK; ++c) {
+    if (poll) {
+      if (interrupted()) {
+        rc = ppk_fail(PPK_ERR_INTERRUPTED, "interrupted");
+        break;
+      }
+      if (meter) progress_line((double)c / (double)(C + 1), false);
+    } else if (job.stop.load()) {
+      break;
+    }
+    if (c < C) {
+      const size_t i = first + (size_t)c;
+      if (job.row0[i + 1] != job.row0[i]) {
+        rc = ppk_dist_dev(p.ref, p.qry, job.kmers, job.random_tbl, job.n_clu, job.flags, job.bounds[i],
+                          job.bounds[i + 1], p.buf[c & 1], p.d_failed, p.s);
+        if (rc == PPK_OK && hipEventRecord(p.done[c & 1], p.s) != hipSuccess)
+          rc = ppk_fail(PPK_ERR_HIP, "hipEventRecord failed");
+      }
+    }
+    if (c > 0 && rc == PPK_OK) {
+      const size_t i = first + (size_t)(c - 1);
+      if (job.row0[i + 1] != job.row0[i]) {
+        job.toucher->wait(job.row0[i + 1] * job.cols * 4);
+        // the sub-band is computed (waited for here, so that the counter below brackets the copy alone)
+        hipError_t e = hipEventSynchronize(p.done[(c - 1) & 1]);
+        stat_enter(g_qstats.dl_now, g_qstats.dl_max);
+        if (e == hipSuccess)
+          e = hipMemcpyAsync(job.out + job.row0[i] * job.cols * 4, p.buf[(c - 1) & 1],
+                             (job.row0[i + 1] - job.row0[i]) * job.cols * 4, hipMemcpyDeviceToHost, p.sc);
+        if (e == hipSuccess) e = hipStreamSynchronize(p.sc);   // the buffer is free for sub-band c+1
+        g_qstats.dl_now.fetch_sub(1);
+        if (e != hipSuccess)
+          rc = ppk_fail(PPK_ERR_HIP, std::string("kernel execution / download failed: ") + hipGetErrorString(e));
+      }
+      job.done_chunks.fetch_add(1);
+    }
+  }
+  // 4. drain (also on failure: nothing may stay in flight), failed-fit count
+  const std::string keep = g_err;
+  hipError_t e = hipStreamSynchronize(p.s);
+  (void)hipStreamSynchronize(p.sc);
+  if (e != hipSuccess && rc == PPK_OK)
+    rc = ppk_fail(PPK_ERR_HIP, std::string("kernel execution failed: ") + hipGetErrorString(e));
+  else if (rc != PPK_OK)
+    g_err = keep;
+  unsigned long long f = 0;
+  if (rc == PPK_OK && hipMemcpy(&f, p.d_failed, sizeof(f), hipMemcpyDeviceToHost) == hipSuccess) p.failed = f;
+  p.total_ms = now_ms() - t_begin;
+  if (rc != PPK_OK) fail(rc);
+}
 
 // The pair space of (n_ref, n_qry) over parts[0..n) devices, result to the host array `out`.
 // Device-memory chunking (what pp-sketchlib's CUDA path does when the result does not fit the card
 // [EXT]): the query axis is cut into n_dev x C sub-bands of equal pair count; a device computes its
 // C sub-bands one after the other into two alternating buffers, and sub-band c is copied to the
 // caller's array while c+1 computes.  Memory per device: the sketches + two sub-band buffers,
-// whatever the size of the job.
-int run_query(std::vector<QueryPart> &parts, size_t n_ref, size_t n_qry, const int32_t *kmers, size_t nk,
-              const float *random_tbl, size_t n_clu, int flags, void *out, unsigned long long *n_failed) {
+// whatever the size of the job.  One device: everything on the calling thread.  Several: one worker
+// thread per device (run_part); the calling thread runs the interrupt check and the progress meter.
+int run_query(QueryJob &job, std::vector<QueryPart> &parts, unsigned long long *n_failed) {
+  const double t_begin = now_ms();
   const int n_dev = (int)parts.size();
-  const bool self = (n_qry == 0);
-  const size_t nq = self ? n_ref : n_qry;
-  const size_t cols = (flags & (PPK_FLAG_JACCARD | PPK_FLAG_COUNTS)) ? nk : 2;
-  const size_t total_rows = ppk_rows_in_band(n_ref, n_qry, 0, nq);
+  const bool self = (job.n_qry == 0);
+  const size_t nq = self ? job.n_ref : job.n_qry;
+  job.cols = (job.flags & (PPK_FLAG_JACCARD | PPK_FLAG_COUNTS)) ? job.nk : 2;
+  const size_t total_rows = ppk_rows_in_band(job.n_ref, job.n_qry, 0, nq);
   // ~64 MB of float2 rows per buffer: the first download starts after 1/6 of a 10k job instead of 1/2
   // (PCIe is the bound of the host call: 11.2 -> 10.2 ms there; tools/ab_host.py)
   size_t target_rows = (size_t)8 << 20;
@@ -1014,101 +1256,98 @@ int run_query(std::vector<QueryPart> &parts, size_t n_ref, size_t n_qry, const i
   int C = (int)((per_dev + target_rows - 1) / target_rows);
   if (C < 1) C = 1;
   if ((size_t)C > nq / 64 + 1) C = (int)(nq / 64 + 1);         // sub-band edges are multiples of 64 queries
-  std::vector<size_t> bounds((size_t)n_dev * C + 1);
-  int rc = ppk_band_split(n_ref, n_qry, n_dev * C, bounds.data());
+  job.C = C;
+  job.bounds.assign((size_t)n_dev * C + 1, 0);
+  int rc = ppk_band_split(job.n_ref, job.n_qry, n_dev * C, job.bounds.data());
   if (rc != PPK_OK) return rc;
-  std::vector<size_t> row0((size_t)n_dev * C + 1, 0);           // first output row of every sub-band
-  size_t max_rows = 0;
+  job.row0.assign((size_t)n_dev * C + 1, 0);                    // first output row of every sub-band
+  job.max_rows = 0;
   for (int i = 0; i < n_dev * C; ++i) {
-    const size_t r = ppk_rows_in_band(n_ref, n_qry, bounds[i], bounds[i + 1]);
-    row0[i + 1] = row0[i] + r;
-    if (r > max_rows) max_rows = r;
+    const size_t r = ppk_rows_in_band(job.n_ref, job.n_qry, job.bounds[i], job.bounds[i + 1]);
+    job.row0[i + 1] = job.row0[i] + r;
+    if (r > job.max_rows) job.max_rows = r;
   }
   // helper threads touch the result array's pages ahead of the downloads (HostToucher)
-  HostToucher toucher(out, row0[(size_t)n_dev * C] * cols * 4);
-  for (int d = 0; d < n_dev && rc == PPK_OK; ++d) {
-    QueryPart &p = parts[d];
-    p.active = row0[(size_t)(d + 1) * C] != row0[(size_t)d * C] && p.ref;
-    if (!p.active) continue;
-    DeviceGuard g(p.device);
-    QueryBufs &qb = g_qbufs[p.device][p.dup];
-    const size_t buf_bytes = max_rows * cols * 4;
-    rc = query_buf(p.device, p.dup, 0, buf_bytes, &p.buf[0]);
-    if (rc == PPK_OK && C > 1) rc = query_buf(p.device, p.dup, 1, buf_bytes, &p.buf[1]);
-    if (rc != PPK_OK) break;
-    if (!qb.d_failed && hipMalloc(reinterpret_cast<void **>(&qb.d_failed), sizeof(unsigned long long)) != hipSuccess) {
-      rc = ppk_fail(PPK_ERR_HIP, "hipMalloc(output) failed");
-      break;
-    }
-    for (int i = 0; i < 2; ++i)
-      if (!qb.done[i] && hipEventCreateWithFlags(&qb.done[i], hipEventDisableTiming) != hipSuccess) {
-        rc = ppk_fail(PPK_ERR_HIP, "hipEventCreate failed");
-        break;
-      }
-    if (rc != PPK_OK) break;
-    p.d_failed = qb.d_failed;
-    p.done[0] = qb.done[0];
-    p.done[1] = qb.done[1];
-    (void)hipMemsetAsync(p.d_failed, 0, sizeof(unsigned long long), p.s);
-  }
-  // step c: every device launches sub-band c, then sub-band c-1 of every device is fetched
+  HostToucher toucher(job.out, job.row0[(size_t)n_dev * C] * job.cols * 4);
+  job.toucher = &toucher;
   const long long prog = ppk_config().progress.load();          // 1: jobs of >= ~0.1 s of work; 2: any multi-band job
   const bool meter = prog != 0 && C >= 4 && (prog >= 2 || total_rows >= ((size_t)1 << 29));
-  for (int c = 0; c <= C && rc == PPK_OK; ++c) {
-    if (interrupted()) {
-      rc = ppk_fail(PPK_ERR_INTERRUPTED, "interrupted");
-      break;
+  g_qstats.dl_now = 0;
+  g_qstats.dl_max = 0;
+  g_qstats.up_now = 0;
+  g_qstats.up_max = 0;
+  g_qstats.parts = n_dev;
+  g_qstats.upload_ms_max = 0.0;
+  g_qstats.part_ms_max = 0.0;
+  if (n_dev == 1) {
+    g_qstats.threads = 0;
+    run_part(job, parts, 0, true, meter);
+  } else {
+    g_qstats.threads = n_dev;
+    std::vector<std::thread> th;
+    for (int d = 0; d < n_dev; ++d)
+      th.emplace_back([&job, &parts, d]() {
+        run_part(job, parts, d, false, false);
+        job.parts_done.fetch_add(1);
+      });
+    // the calling thread: Ctrl-C and the meter (a Python signal handler only ever runs on this thread)
+    const long long all_chunks = (long long)n_dev * C;
+    bool was_interrupted = false;
+    while (job.parts_done.load() < n_dev) {
+      if (!was_interrupted && interrupted()) {
+        was_interrupted = true;
+        job.stop.store(1);
+      }
+      if (meter) progress_line((double)job.done_chunks.load() / (double)(all_chunks + 1), false);
+      std::this_thread::sleep_for(std::chrono::microseconds(200));
     }
-    if (meter) progress_line((double)c / (double)(C + 1), false);
-    for (int d = 0; d < n_dev && rc == PPK_OK && c < C; ++d) {
-      QueryPart &p = parts[d];
-      const size_t i = (size_t)d * C + c;
-      if (!p.active || row0[i + 1] == row0[i]) continue;
-      DeviceGuard g(p.device);
-      rc = ppk_dist_dev(p.ref, p.qry, kmers, random_tbl, n_clu, flags, bounds[i], bounds[i + 1],
-                        p.buf[c & 1], p.d_failed, p.s);
-      if (rc == PPK_OK && hipEventRecord(p.done[c & 1], p.s) != hipSuccess)
-        rc = ppk_fail(PPK_ERR_HIP, "hipEventRecord failed");
-    }
-    for (int d = 0; d < n_dev && rc == PPK_OK && c > 0; ++d) {
-      QueryPart &p = parts[d];
-      const size_t i = (size_t)d * C + (c - 1);
-      if (!p.active || row0[i + 1] == row0[i]) continue;
-      DeviceGuard g(p.device);
-      toucher.wait(row0[i + 1] * cols * 4);
-      hipError_t e = hipStreamWaitEvent(p.sc, p.done[(c - 1) & 1], 0);
-      if (e == hipSuccess)
-        e = hipMemcpyAsync(static_cast<char *>(out) + row0[i] * cols * 4, p.buf[(c - 1) & 1],
-                           (row0[i + 1] - row0[i]) * cols * 4, hipMemcpyDeviceToHost, p.sc);
-      if (e == hipSuccess) e = hipStreamSynchronize(p.sc);   // the buffer is free for sub-band c+1
-      if (e != hipSuccess)
-        rc = ppk_fail(PPK_ERR_HIP, std::string("kernel execution / download failed: ") + hipGetErrorString(e));
-    }
-  }
-  const std::string keep = g_err;
-  for (int d = 0; d < n_dev; ++d) {
-    QueryPart &p = parts[d];
-    if (!p.active) continue;
-    DeviceGuard g(p.device);
-    hipError_t e = hipStreamSynchronize(p.s);          // also on failure: nothing may stay in flight
-    (void)hipStreamSynchronize(p.sc);
-    if (e != hipSuccess && rc == PPK_OK)
-      rc = ppk_fail(PPK_ERR_HIP, std::string("kernel execution failed: ") + hipGetErrorString(e));
-    unsigned long long f = 0;
-    if (rc == PPK_OK && hipMemcpy(&f, p.d_failed, sizeof(f), hipMemcpyDeviceToHost) == hipSuccess && n_failed)
-      *n_failed += f;
+    for (auto &t : th) t.join();
+    if (was_interrupted) rc = ppk_fail(PPK_ERR_INTERRUPTED, "interrupted");
   }
   toucher.join();
+  job.toucher = nullptr;
+  for (QueryPart &p : parts) {
+    if (p.rc != PPK_OK && rc == PPK_OK) rc = ppk_fail(p.rc, p.err);
+    if (n_failed) *n_failed += p.failed;
+    if (p.upload_ms > g_qstats.upload_ms_max) g_qstats.upload_ms_max = p.upload_ms;
+    if (p.total_ms > g_qstats.part_ms_max) g_qstats.part_ms_max = p.total_ms;
+  }
+  if (rc != PPK_OK && n_failed) *n_failed = 0;
   if (meter && rc == PPK_OK) progress_line(1.0, true);
-  if (rc != PPK_OK && !keep.empty() && g_err.empty()) g_err = keep;
+  g_qstats.wall_ms = now_ms() - t_begin;
   return rc;
+}
+
+int prepare_parts(std::vector<QueryPart> &parts, const int *devices) {
+  for (size_t d = 0; d < parts.size(); ++d) {
+    QueryPart &p = parts[d];
+    p.device = devices[d];
+    if (p.device < 0 || p.device >= 64) return ppk_fail(PPK_ERR_ARG, "device id out of range");
+    for (size_t e = 0; e < d; ++e)
+      if (devices[e] == p.device) {
+        ++p.dup;
+        if (p.leader < 0) p.leader = (int)e;
+      }
+    if (p.dup >= kMaxDup) return ppk_fail(PPK_ERR_ARG, "a device may be listed at most 4 times");
+    DeviceGuard g(p.device);
+    if (!g.ok) return ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(p.device));
+    if (int rc = check_arch(p.device)) return rc;
+    hipStream_t ws[2] = {nullptr, nullptr};
+    if (int rc = part_streams(p.device, p.dup, ws)) return rc;
+    p.s = ws[0];
+    p.sc = ws[1];
+  }
+  return PPK_OK;
 }
 }  // namespace
 
 void ppk_query_cache_clear() {
   std::lock_guard<std::mutex> lk(g_query_mu);
-  for (CachedDb &c : g_db_cache) ppk_db_destroy(c.db);
-  g_db_cache.clear();
+  {
+    std::lock_guard<std::mutex> lc(g_cache_mu);
+    for (CachedDb &c : g_db_cache) ppk_db_destroy(c.db);
+    g_db_cache.clear();
+  }
   for (int d = 0; d < 64; ++d)
     for (int u = 0; u < kMaxDup; ++u) {
       QueryBufs &q = g_qbufs[d][u];
@@ -1142,41 +1381,29 @@ extern "C" int ppk_query(const uint64_t *ref_sk, size_t n_ref, const uint64_t *q
   if (ppk_rows_in_band(n_ref, n_qry, 0, self ? n_ref : n_qry) == 0) return PPK_OK;  // a single self sample: no pairs
   std::lock_guard<std::mutex> lk(g_query_mu);
   std::vector<QueryPart> parts((size_t)n_dev);
-  int rc = PPK_OK;
-  for (int d = 0; d < n_dev && rc == PPK_OK; ++d) {
-    QueryPart &p = parts[d];
-    p.device = devices[d];
-    if (p.device < 0 || p.device >= 64) {
-      rc = ppk_fail(PPK_ERR_ARG, "device id out of range");
-      break;
-    }
-    for (int e = 0; e < d; ++e)
-      if (devices[e] == p.device) ++p.dup;
-    if (p.dup >= kMaxDup) {
-      rc = ppk_fail(PPK_ERR_ARG, "a device may be listed at most 4 times");
-      break;
-    }
-    DeviceGuard g(p.device);
-    if (!g.ok) {
-      rc = ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(p.device));
-      break;
-    }
-    // entries naming the same device share its streams and resident databases (ordered on one stream)
-    hipStream_t ws[2] = {nullptr, nullptr};
-    rc = worker_streams(p.device, ws, 2);
-    if (rc != PPK_OK) break;
-    p.s = ws[0];
-    p.sc = ws[1];
-    ppk_db *db = nullptr;
-    rc = db_acquire(p.device, ref_sk, n_ref, nk, sketchsize64, bbits, ref_clu, p.s, &db, &p.own_ref);
-    p.ref = db;
-    if (rc == PPK_OK && !self) {
-      db = nullptr;
-      rc = db_acquire(p.device, qry_sk, n_qry, nk, sketchsize64, bbits, qry_clu, p.s, &db, &p.own_qry);
-      p.qry = db;
-    }
+  int rc = prepare_parts(parts, devices);
+  if (rc != PPK_OK) return rc;
+  QueryJob job;
+  job.n_ref = n_ref;
+  job.n_qry = n_qry;
+  job.nk = nk;
+  job.s64 = sketchsize64;
+  job.bbits = bbits;
+  job.n_clu = n_clu;
+  job.kmers = kmers;
+  job.random_tbl = random_tbl;
+  job.flags = flags;
+  job.ref_sk = ref_sk;
+  job.qry_sk = self ? nullptr : qry_sk;
+  job.ref_clu = ref_clu;
+  job.qry_clu = qry_clu;
+  job.out = static_cast<char *>(out);
+  job.use_cache = ppk_config().db_cache.load() != 0;
+  if (job.use_cache) {
+    job.ref_fp = fingerprint(ref_sk, n_ref * nk * sketchsize64 * bbits, ref_clu, n_ref);
+    if (!self) job.qry_fp = fingerprint(qry_sk, n_qry * nk * sketchsize64 * bbits, qry_clu, n_qry);
   }
-  if (rc == PPK_OK) rc = run_query(parts, n_ref, n_qry, kmers, nk, random_tbl, n_clu, flags, out, n_failed);
+  rc = run_query(job, parts, n_failed);
   const std::string keep = g_err;
   for (QueryPart &p : parts) {
     if (p.own_ref && p.ref) ppk_db_destroy(const_cast<ppk_db *>(p.ref));
@@ -1186,31 +1413,70 @@ extern "C" int ppk_query(const uint64_t *ref_sk, size_t n_ref, const uint64_t *q
   return rc;
 }
 
-// The same on databases that are already resident (ppk_db_create): nothing is uploaded; the result
-// goes to the host array through the device's two persistent sub-band buffers.
+// The same on databases that are already resident (ppk_db_create), one per device: nothing is
+// uploaded, hashed or looked up; device d computes its share of the pair space from refs[d] (and
+// qrys[d]) and sends it to its rows of `out`, the devices side by side (run_part).
+extern "C" int ppk_query_dbs(const ppk_db *const *refs, const ppk_db *const *qrys, int n_dev,
+                             const int32_t *kmers, const float *random_tbl, size_t n_clu, int flags,
+                             void *out, unsigned long long *n_failed) {
+  if (n_failed) *n_failed = 0;
+  if (!refs || n_dev < 1 || n_dev > 64) return ppk_fail(PPK_ERR_ARG, "ppk_query_dbs: no databases");
+  if (!out) return ppk_fail(PPK_ERR_ARG, "ppk_query_dbs: out is NULL");
+  std::vector<int> devices((size_t)n_dev);
+  for (int d = 0; d < n_dev; ++d) {
+    const ppk_db *q = qrys ? qrys[d] : nullptr;
+    if (!refs[d] || (qrys && !q)) return ppk_fail(PPK_ERR_ARG, "ppk_query_dbs: a database is missing for some device");
+    int rc = check_pair(refs[d], q, kmers, 0, 0);
+    if (rc != PPK_OK) return rc;
+    if (refs[d]->n != refs[0]->n || refs[d]->nk != refs[0]->nk || refs[d]->s64 != refs[0]->s64 ||
+        refs[d]->bbits != refs[0]->bbits || (q ? q->n : 0) != (qrys && qrys[0] ? qrys[0]->n : 0))
+      return ppk_fail(PPK_ERR_ARG, "ppk_query_dbs: the per-device databases differ in shape");
+    devices[(size_t)d] = refs[d]->device;
+  }
+  const ppk_db *q0 = qrys ? qrys[0] : nullptr;
+  const size_t n_qry = q0 ? q0->n : 0;
+  if (ppk_rows_in_band(refs[0]->n, n_qry, 0, q0 ? q0->n : refs[0]->n) == 0) return PPK_OK;
+  std::lock_guard<std::mutex> lk(g_query_mu);
+  std::vector<QueryPart> parts((size_t)n_dev);
+  int rc = prepare_parts(parts, devices.data());
+  if (rc != PPK_OK) return rc;
+  for (int d = 0; d < n_dev; ++d) {
+    parts[(size_t)d].ref = refs[d];
+    parts[(size_t)d].qry = qrys ? qrys[d] : nullptr;
+    parts[(size_t)d].leader = -1;
+  }
+  QueryJob job;
+  job.n_ref = refs[0]->n;
+  job.n_qry = n_qry;
+  job.nk = refs[0]->nk;
+  job.s64 = refs[0]->s64;
+  job.bbits = refs[0]->bbits;
+  job.n_clu = n_clu;
+  job.kmers = kmers;
+  job.random_tbl = random_tbl;
+  job.flags = flags;
+  job.out = static_cast<char *>(out);
+  return run_query(job, parts, n_failed);
+}
+
 extern "C" int ppk_query_db(const ppk_db *ref, const ppk_db *qry, const int32_t *kmers,
                             const float *random_tbl, size_t n_clu, int flags, void *out,
                             unsigned long long *n_failed) {
-  if (n_failed) *n_failed = 0;
-  int rc = check_pair(ref, qry, kmers, 0, 0);
-  if (rc != PPK_OK) return rc;
-  if (!out) return ppk_fail(PPK_ERR_ARG, "ppk_query_db: out is NULL");
-  const size_t n_qry = qry ? qry->n : 0;
-  if (ppk_rows_in_band(ref->n, n_qry, 0, qry ? qry->n : ref->n) == 0) return PPK_OK;
+  return ppk_query_dbs(&ref, qry ? &qry : nullptr, 1, kmers, random_tbl, n_clu, flags, out, n_failed);
+}
+
+// what the last ppk_query / ppk_query_dbs of this process did side by side (measurement and tests):
+//   [0] parts (device entries)        [1] worker threads spawned (0: ran on the calling thread)
+//   [2] most downloads in flight at once   [3] most uploads (database creations) in flight at once
+//   [4] wall ms of the call's device phase [5] longest upload ms   [6] longest part ms
+extern "C" int ppk_query_last_stats(double *vals, int n) {
+  if (!vals || n < 1) return ppk_fail(PPK_ERR_ARG, "vals is NULL");
   std::lock_guard<std::mutex> lk(g_query_mu);
-  std::vector<QueryPart> parts(1);
-  QueryPart &p = parts[0];
-  p.device = ref->device;
-  DeviceGuard g(p.device);
-  if (!g.ok) return ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(p.device));
-  hipStream_t ws[2] = {nullptr, nullptr};
-  rc = worker_streams(p.device, ws, 2);
-  if (rc != PPK_OK) return rc;
-  p.s = ws[0];
-  p.sc = ws[1];
-  p.ref = ref;
-  p.qry = qry;
-  return run_query(parts, ref->n, n_qry, kmers, ref->nk, random_tbl, n_clu, flags, out, n_failed);
+  const double v[7] = {(double)g_qstats.parts, (double)g_qstats.threads, (double)g_qstats.dl_max.load(),
+                       (double)g_qstats.up_max.load(), g_qstats.wall_ms, g_qstats.upload_ms_max,
+                       g_qstats.part_ms_max};
+  for (int i = 0; i < n; ++i) vals[i] = i < 7 ? v[i] : 0.0;
+  return PPK_OK;
 }
 
 extern "C" int ppk_assign_threshold(const float *dist, size_t n_rows, int slope, float x_max,
@@ -1284,20 +1550,23 @@ extern "C" int ppk_assign_threshold(const float *dist, size_t n_rows, int slope,
   return rc;
 }
 
-// ---- host edge lists: data-dependent size, ONE pass ---------------------------------------------
-// The Python / pybind side cannot know the size of an edge list in advance and calls twice: once to
-// learn it, once with a buffer of that size.  The first call already computes the whole list into a
-// device buffer (capacity guessed; a second device pass only if the guess was too small); when the
-// caller's buffer is too small the result stays parked on the device under a token of the call's
-// inputs, and the second call -- same inputs, enough room -- only copies it out: one upload, one pass.
+// ---- host results of data-dependent size: ONE pass, explicit fetch ---------------------------------
+// The Python / pybind side cannot know the size of an edge list in advance.  A call whose buffer is
+// too small has nevertheless computed the whole list: it returns PPK_ERR_CAPACITY with the size and
+// leaves the list PARKED on the device for the calling thread, which fetches it with
+// ppk_parked_fetch() into a buffer of that size -- one upload, one device pass.  The hand-over is
+// explicit: no later call is ever answered from a parked result (round 2 matched a token of the
+// pointer and the scalar arguments, which a rewritten or recycled array would have matched too).  Any
+// other host-result call, on any thread, drops what is parked.
 struct ParkedResult {
-  uint64_t token = 0;
+  std::thread::id owner;
   int device = -1;
+  int arrays = 0;                 // 1: int64 [n][2] contiguous; 3: int64 [3][cap_used] (i, j, offset index)
   void *d = nullptr;
   size_t n = 0, cap_used = 0;     // entries wanted / capacity the buffer was computed with
 };
 static std::mutex g_parked_mu;
-static ParkedResult g_parked[2];          // [0] edge lists (this file), [1] sweeps (ppk_iterate.hip)
+static ParkedResult g_parked;
 
 uint64_t ppk_token(const void *bytes, size_t len, uint64_t seed) {
   const unsigned char *b = static_cast<const unsigned char *>(bytes);
@@ -1306,65 +1575,80 @@ uint64_t ppk_token(const void *bytes, size_t len, uint64_t seed) {
   return h ? h : 1;
 }
 
-void ppk_parked_drop_locked(int slot) {
-  ParkedResult &p = g_parked[slot];
-  if (p.d) {
-    DeviceGuard g(p.device);
-    (void)hipFree(p.d);
+static void parked_drop_locked() {
+  if (g_parked.d) {
+    DeviceGuard g(g_parked.device);
+    (void)hipFree(g_parked.d);
   }
-  p = ParkedResult();
+  g_parked = ParkedResult();
 }
 
 // compute(cap_entries, &d_result, &n): runs the whole job into a fresh device buffer of cap entries
 // (allocated by compute), n = total entries it wanted to write.  copy_out(d_result, n, cap_used):
-// device -> the caller's arrays.
-int ppk_host_result(int slot, uint64_t token, int device, size_t guess, size_t cap, size_t *n_out,
+// device -> the caller's arrays.  `arrays`: the device layout (ParkedResult).
+int ppk_host_result(int arrays, int device, size_t guess, size_t cap, size_t *n_out,
                     const std::function<int(size_t, void **, unsigned long long *)> &compute,
                     const std::function<int(const void *, size_t, size_t)> &copy_out) {
   std::lock_guard<std::mutex> lk(g_parked_mu);
-  ParkedResult &pk = g_parked[slot];
+  parked_drop_locked();
   void *d = nullptr;
-  size_t n = 0, cap_used = 0;
-  if (pk.d && pk.token == token && pk.device == device) {
-    d = pk.d;
-    n = pk.n;
-    cap_used = pk.cap_used;
-    pk = ParkedResult();
-  } else {
-    ppk_parked_drop_locked(slot);
-    unsigned long long want = 0;
-    cap_used = guess ? guess : 1;
-    int rc = compute(cap_used, &d, &want);
-    if (rc == PPK_OK && want > cap_used) {          // the guess was too small: once more with the exact size
-      if (d) (void)hipFree(d);
-      d = nullptr;
-      cap_used = (size_t)want;
-      rc = compute(cap_used, &d, &want);
-    }
-    if (rc != PPK_OK) {
-      if (d) (void)hipFree(d);
-      return rc;
-    }
-    n = (size_t)want;
+  unsigned long long want = 0;
+  size_t cap_used = guess ? guess : 1;
+  int rc = compute(cap_used, &d, &want);
+  if (rc == PPK_OK && want > cap_used) {            // the guess was too small: once more with the exact size
+    if (d) (void)hipFree(d);
+    d = nullptr;
+    cap_used = (size_t)want;
+    rc = compute(cap_used, &d, &want);
   }
+  if (rc != PPK_OK) {
+    if (d) (void)hipFree(d);
+    return rc;
+  }
+  const size_t n = (size_t)want;
   *n_out = n;
   if (n > cap) {
-    pk.token = token;
-    pk.device = device;
-    pk.d = d;
-    pk.n = n;
-    pk.cap_used = cap_used;
-    return ppk_fail(PPK_ERR_CAPACITY, "output too small: need " + std::to_string(n));
+    g_parked.owner = std::this_thread::get_id();
+    g_parked.device = device;
+    g_parked.arrays = arrays;
+    g_parked.d = d;
+    g_parked.n = n;
+    g_parked.cap_used = cap_used;
+    return ppk_fail(PPK_ERR_CAPACITY, "output too small: need " + std::to_string(n) +
+                                          " entries (parked: ppk_parked_fetch)");
   }
-  int rc = n > 0 ? copy_out(d, n, cap_used) : PPK_OK;
+  rc = n > 0 ? copy_out(d, n, cap_used) : PPK_OK;
   if (d) (void)hipFree(d);
   return rc;
 }
 
 void ppk_parked_clear() {
   std::lock_guard<std::mutex> lk(g_parked_mu);
-  ppk_parked_drop_locked(0);
-  ppk_parked_drop_locked(1);
+  parked_drop_locked();
+}
+
+extern "C" int ppk_parked_fetch(long long *out0, long long *out1, long long *out2, size_t cap, size_t *n_out) {
+  std::lock_guard<std::mutex> lk(g_parked_mu);
+  if (n_out) *n_out = 0;
+  if (!g_parked.d || g_parked.owner != std::this_thread::get_id())
+    return ppk_fail(PPK_ERR_STATE, "ppk_parked_fetch: this thread's last call parked no result");
+  if (n_out) *n_out = g_parked.n;
+  if (cap < g_parked.n) return ppk_fail(PPK_ERR_CAPACITY, "output too small: need " + std::to_string(g_parked.n));
+  if (!out0 || (g_parked.arrays == 3 && (!out1 || !out2))) return ppk_fail(PPK_ERR_ARG, "ppk_parked_fetch: NULL output");
+  DeviceGuard g(g_parked.device);
+  const long long *buf = static_cast<const long long *>(g_parked.d);
+  const size_t n = g_parked.n, cu = g_parked.cap_used;
+  hipError_t e;
+  if (g_parked.arrays == 1) {
+    e = hipMemcpy(out0, buf, n * 16, hipMemcpyDeviceToHost);
+  } else {
+    e = hipMemcpy(out0, buf, n * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out1, buf + cu, n * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out2, buf + 2 * cu, n * 8, hipMemcpyDeviceToHost);
+  }
+  parked_drop_locked();
+  if (e != hipSuccess) return ppk_fail(PPK_ERR_HIP, std::string("hipMemcpy D2H failed: ") + hipGetErrorString(e));
+  return PPK_OK;
 }
 
 extern "C" int ppk_edge_threshold(const float *dist, size_t n_rows, size_t n_ref, int slope,
@@ -1376,7 +1660,6 @@ extern "C" int ppk_edge_threshold(const float *dist, size_t n_rows, size_t n_ref
   if (!n_edges) return ppk_fail(PPK_ERR_ARG, "n_edges is NULL");
   DeviceGuard guard(device_id);
   if (!guard.ok) return ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(device_id));
-  struct { const void *p; size_t rows, n_ref; int slope, incl; float x, y; } key = {dist, n_rows, n_ref, slope, inclusive, x_max, y_max};
   size_t guess = n_rows / 8 > ((size_t)1 << 20) ? n_rows / 8 : ((size_t)1 << 20);
   if (guess > n_rows) guess = n_rows;
   auto copy_out = [&](const void *d, size_t n, size_t) {
@@ -1384,7 +1667,7 @@ extern "C" int ppk_edge_threshold(const float *dist, size_t n_rows, size_t n_ref
     if (hipMemcpy(ij_out, d, n * 16, hipMemcpyDeviceToHost) != hipSuccess) return ppk_fail(PPK_ERR_HIP, "hipMemcpy D2H failed");
     return (int)PPK_OK;
   };
-  return ppk_host_result(0, ppk_token(&key, sizeof(key), 1), device_id, guess, cap, n_edges,
+  return ppk_host_result(1, device_id, guess, cap, n_edges,
                          [&](size_t c, void **d_res, unsigned long long *want) {
                            float *d_dist = nullptr;
                            unsigned long long *d_n = nullptr;
@@ -1416,7 +1699,6 @@ extern "C" int ppk_generate_tuples(const int32_t *assignments, size_t n_rows, in
   if (!n_edges) return ppk_fail(PPK_ERR_ARG, "n_edges is NULL");
   DeviceGuard guard(device_id);
   if (!guard.ok) return ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(device_id));
-  struct { const void *p; size_t rows, num_ref; int label, self; long long off; } key = {assignments, n_rows, num_ref, within_label, self, int_offset};
   size_t guess = n_rows / 8 > ((size_t)1 << 20) ? n_rows / 8 : ((size_t)1 << 20);
   if (guess > n_rows) guess = n_rows;
   auto copy_out = [&](const void *d, size_t n, size_t) {
@@ -1424,7 +1706,7 @@ extern "C" int ppk_generate_tuples(const int32_t *assignments, size_t n_rows, in
     if (hipMemcpy(ij_out, d, n * 16, hipMemcpyDeviceToHost) != hipSuccess) return ppk_fail(PPK_ERR_HIP, "hipMemcpy D2H failed");
     return (int)PPK_OK;
   };
-  return ppk_host_result(0, ppk_token(&key, sizeof(key), 2), device_id, guess, cap, n_edges,
+  return ppk_host_result(1, device_id, guess, cap, n_edges,
                          [&](size_t c, void **d_res, unsigned long long *want) {
                            int32_t *d_a = nullptr;
                            unsigned long long *d_n = nullptr;

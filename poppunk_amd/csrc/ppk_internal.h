@@ -139,10 +139,10 @@ class PpkCall {
   unsigned prev_touched_;
 };
 void ppk_query_cache_clear();
-// host entry points with a data-dependent result size (ppk_api.hip): one pass, result parked on the
-// device between the caller's size query and its fetch
+// host entry points with a data-dependent result size (ppk_api.hip): one pass; a result that did not
+// fit the caller's buffer stays parked on the device for the calling thread's ppk_parked_fetch
 uint64_t ppk_token(const void *bytes, size_t len, uint64_t seed);
-int ppk_host_result(int slot, uint64_t token, int device, size_t guess, size_t cap, size_t *n_out,
+int ppk_host_result(int arrays, int device, size_t guess, size_t cap, size_t *n_out,
                     const std::function<int(size_t, void **, unsigned long long *)> &compute,
                     const std::function<int(const void *, size_t, size_t)> &copy_out);
 void ppk_parked_clear();

@@ -446,7 +446,7 @@ namespace {
 // buffer of guessed capacity and, when the caller's arrays are too small, parked there until the
 // caller comes back with room.  Layout on the device: [3][cap_used] (i, j, offset index).
 template <typename F>
-int host_coo(uint64_t token, const float *dist, size_t n_rows, size_t n_off, int device_id, long long *i_out,
+int host_coo(const float *dist, size_t n_rows, size_t n_off, int device_id, long long *i_out,
              long long *j_out, long long *off_out, size_t cap, size_t *n_out, F enqueue) {
   if (!n_out) return ppk_fail(PPK_ERR_ARG, "n_out is NULL");
   *n_out = 0;
@@ -482,7 +482,7 @@ int host_coo(uint64_t token, const float *dist, size_t n_rows, size_t n_off, int
       return ppk_fail(PPK_ERR_HIP, "hipMemcpy D2H failed");
     return (int)PPK_OK;
   };
-  return ppk_host_result(1, token, device_id, guess, cap, n_out, compute, copy_out);
+  return ppk_host_result(3, device_id, guess, cap, n_out, compute, copy_out);
 }
 }  // namespace
 
@@ -491,11 +491,7 @@ extern "C" int ppk_threshold_iterate_1d(const float *dist, size_t n_rows, const 
                                         float y1, int device_id, long long *i_out,
                                         long long *j_out, long long *off_out, size_t cap,
                                         size_t *n_out) {
-  uint64_t token = ppk_token(offsets, n_off * sizeof(double), 11);
-  const float fk[4] = {x0, y0, x1, y1};
-  const uint64_t key[3] = {(uint64_t)(size_t)dist, (uint64_t)n_rows, (uint64_t)(unsigned)slope};
-  token = ppk_token(fk, sizeof(fk), ppk_token(key, sizeof(key), token));
-  return host_coo(token, dist, n_rows, n_off, device_id, i_out, j_out, off_out, cap, n_out,
+  return host_coo(dist, n_rows, n_off, device_id, i_out, j_out, off_out, cap, n_out,
                   [&](const float *d, long long *a, long long *b, long long *c, size_t cp,
                       unsigned long long *dn) {
                     return ppk_threshold_iterate_1d_dev(d, n_rows, offsets, n_off, slope, x0, y0, x1,
@@ -507,10 +503,7 @@ extern "C" int ppk_threshold_iterate_2d(const float *dist, size_t n_rows, const 
                                         size_t n_off, float y_max, int device_id,
                                         long long *i_out, long long *j_out, long long *off_out,
                                         size_t cap, size_t *n_out) {
-  uint64_t token = ppk_token(x_max, n_off * sizeof(float), 12);
-  const uint64_t key[3] = {(uint64_t)(size_t)dist, (uint64_t)n_rows, (uint64_t)__builtin_bit_cast(unsigned, y_max)};
-  token = ppk_token(key, sizeof(key), token);
-  return host_coo(token, dist, n_rows, n_off, device_id, i_out, j_out, off_out, cap, n_out,
+  return host_coo(dist, n_rows, n_off, device_id, i_out, j_out, off_out, cap, n_out,
                   [&](const float *d, long long *a, long long *b, long long *c, size_t cp,
                       unsigned long long *dn) {
                     return ppk_threshold_iterate_2d_dev(d, n_rows, x_max, n_off, y_max, a, b, c, cp,

@@ -48,9 +48,10 @@ def assignThreshold(distMat, slope, x_max, y_max, num_threads=1):
 
 
 def _edges(call, rows_hint=0):
-    """Edge lists have a data-dependent size.  The first call offers a guessed capacity; if it is too
-    small the library keeps the finished list on the device and the second call, with room, only
-    fetches it (include/ppk.h: one upload, one pass either way)."""
+    """Edge lists have a data-dependent size.  The call offers a guessed capacity; if it is too small
+    the library has nevertheless finished the list and keeps it on the device for this thread, and
+    `ppk_parked_fetch` copies it into an array of the reported size (include/ppk.h: one upload, one
+    pass either way; the hand-over is explicit, a parked list is never matched to a later call)."""
     n_edges = C.c_size_t(0)
     guess = min(int(rows_hint), max(65536, int(rows_hint) // 16))
     ij = np.empty((guess, 2), dtype=np.int64)
@@ -60,8 +61,8 @@ def _edges(call, rows_hint=0):
     n = int(n_edges.value)
     if rc == _lib.ERR_CAPACITY:
         ij = np.empty((n, 2), dtype=np.int64)
-        rc = call(ij.ctypes.data_as(C.POINTER(C.c_longlong)), n, C.byref(n_edges))
-        _lib.check(rc, "edge list")
+        rc = _lib.lib().ppk_parked_fetch(ij.ctypes.data_as(C.POINTER(C.c_longlong)), None, None, n, None)
+        _lib.check(rc, "edge list (fetch)")
         return ij
     return ij[:n].copy() if n < guess else ij
 
@@ -114,8 +115,8 @@ def _coo(call, rows_hint=0):
         i = np.empty(n, dtype=np.int64)
         j = np.empty(n, dtype=np.int64)
         o = np.empty(n, dtype=np.int64)
-        rc = call(i.ctypes.data_as(ll), j.ctypes.data_as(ll), o.ctypes.data_as(ll), n, C.byref(n_out))
-        _lib.check(rc, "threshold iterate")
+        rc = _lib.lib().ppk_parked_fetch(i.ctypes.data_as(ll), j.ctypes.data_as(ll), o.ctypes.data_as(ll), n, None)
+        _lib.check(rc, "threshold iterate (fetch)")
         return i, j, o
     if n < guess:
         return i[:n].copy(), j[:n].copy(), o[:n].copy()
@@ -151,7 +152,7 @@ def thresholdIterate2D_arrays(distMat, x_max, y_max):
     lib = _lib.lib()
     return _coo(lambda pi, pj, po, cap, n: lib.ppk_threshold_iterate_2d(
         d.ctypes.data_as(C.POINTER(C.c_float)), d.shape[0], xm.ctypes.data_as(C.POINTER(C.c_float)),
-        xm.size, float(y_max), _DEVICE, pi, pj, po, cap, n), d.shape[0] * max(int(xm.size), 1))
+        xm.size, float(y_max), _DEVICE, pi, pj, po, cap, n), d.shape[0])   # a row enters at most one band
 
 
 def thresholdIterate2D(distMat, x_max, y_max):

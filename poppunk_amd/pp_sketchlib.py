@@ -23,13 +23,18 @@ recognise -- RAISES: silently uncorrected distances differ from the reference's 
 J at k = 13.  Opting out is explicit: `random_correct=False`, or the environment variable
 PPK_ALLOW_NO_RANDOM=1 (distances are then computed without the correction, with a note on stderr).
 
-Loaded databases are kept (a few, keyed by file, modification time, names and k list), so repeated
-queries against one database -- poppunk_assign, every --plot-fit re-query -- neither re-read the file
-nor re-upload the sketches (ppk_query finds the same host array resident).
+Loaded databases are kept (a few, keyed by file, modification time, names and k list) TOGETHER WITH
+their resident form on every GPU they have been queried on (`ppk_db` handles), and queries run through
+`ppk_query_dbs`: repeated queries against one database -- poppunk_assign, every --plot-fit re-query --
+neither re-read the file nor re-upload the sketches, and nothing has to guess whether a host array
+still holds what was uploaded (the key is exact).  A re-query of a few samples of a database that is
+already loaded (the --plot-fit example pairs) is sliced from it and never enters -- or evicts from --
+the cache.
 """
 import ctypes as C
 import os
 import sys
+import threading
 
 import numpy as np
 
@@ -38,10 +43,81 @@ from . import _lib, sketchdb
 # PopPUNK parses this as dotted integers (checkSketchlibVersion, PopPUNK/sketchlib.py:49-50) and wants
 # >= 2.0.1 (PopPUNK/__init__.py:9-11): plain numbers only.  The build of this package is `amd_build`.
 version = "2.1.4"
-amd_build = "poppunk_amd 0.2.0 (gfx950)"
+amd_build = "poppunk_amd 0.3.0 (gfx950)"
 
-_DB_CACHE = {}          # key -> LoadedSketches (host arrays: stable pointers for ppk_query's cache)
+
+class _Entry:
+    """One loaded sample list: the host arrays (sketchdb.LoadedSketches) and their resident copies,
+    one ppk_db per (device, cluster-id vector)."""
+
+    def __init__(self, loaded, transient=False):
+        self.loaded = loaded
+        self.transient = transient          # a slice of a cached entry: closed after the call
+        self._handles = {}                  # (device, cluster key) -> c_void_p
+        self._pos = None
+
+    def position(self):
+        if self._pos is None:
+            self._pos = {nm: i for i, nm in enumerate(self.loaded.names)}
+        return self._pos
+
+    def resident(self, devices, clusters):
+        """ppk_db handles on `devices` (created side by side where missing), in that order."""
+        lib = _lib.lib()
+        ld = self.loaded
+        clu = None if clusters is None else np.ascontiguousarray(clusters, dtype=np.uint16)
+        ckey = None if clu is None else clu.tobytes()
+        missing = [d for d in dict.fromkeys(devices) if (d, ckey) not in self._handles]
+        errors = []
+
+        def create(dev):
+            h = C.c_void_p()
+            n, nk, _ = ld.sketches.shape
+            rc = lib.ppk_db_create(int(dev), C.c_void_p(ld.sketches.ctypes.data), n, nk, ld.sketchsize64,
+                                   ld.bbits, None if clu is None else C.c_void_p(clu.ctypes.data), 0, None,
+                                   C.byref(h))
+            if rc != _lib.OK:
+                errors.append("ppk_db_create on device %d failed (%d): %s" % (dev, rc, _lib.last_error()))
+            else:
+                self._handles[(dev, ckey)] = h
+
+        if len(missing) == 1:
+            create(missing[0])
+        elif missing:                        # ctypes releases the GIL: the uploads overlap
+            threads = [threading.Thread(target=create, args=(d,)) for d in missing]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+        if errors:
+            raise RuntimeError("; ".join(errors))
+        return [self._handles[(d, ckey)] for d in devices]
+
+    def close(self):
+        if self._handles:
+            lib = _lib.lib()
+            for h in self._handles.values():
+                lib.ppk_db_destroy(h)
+            self._handles = {}
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_DB_CACHE = {}          # key -> _Entry
 _DB_CACHE_MAX = 4
+
+
+def _slice(loaded, rows):
+    rows = np.asarray(rows, dtype=np.int64)
+    pick = (lambda a: None if a is None else np.ascontiguousarray(np.asarray(a)[rows]))
+    return sketchdb.LoadedSketches([loaded.names[i] for i in rows], loaded.kmers, pick(loaded.sketches),
+                                   loaded.sketchsize64, loaded.bbits, loaded.random_table, pick(loaded.clusters),
+                                   loaded.random_raw, pick(loaded.lengths), pick(loaded.base_freq),
+                                   loaded.random_status)
 
 
 def _load_cached(db_name, names, klist):
@@ -56,16 +132,28 @@ def _load_cached(db_name, names, klist):
     if hit is not None:
         _DB_CACHE[key] = _DB_CACHE.pop(key)          # most recently used last
         return hit
-    loaded = sketchdb.load(db_name, names, klist)
     if stamp is not None:
-        _DB_CACHE[key] = loaded
+        # some samples of a database that is already loaded: slice, do not read the file again and
+        # do not push the full database out of the cache
+        for k2 in reversed(list(_DB_CACHE)):
+            if k2[0] == key[0] and k2[1] == stamp and k2[3] == key[3] and len(names) < len(k2[2]):
+                pos = _DB_CACHE[k2].position()
+                if all(nm in pos for nm in names):
+                    return _Entry(_slice(_DB_CACHE[k2].loaded, [pos[nm] for nm in names]), transient=True)
+    entry = _Entry(sketchdb.load(db_name, names, klist))
+    if stamp is not None:
+        _DB_CACHE[key] = entry
         while len(_DB_CACHE) > _DB_CACHE_MAX:
-            _DB_CACHE.pop(next(iter(_DB_CACHE)))
-    return loaded
+            _DB_CACHE.pop(next(iter(_DB_CACHE))).close()
+    else:
+        entry.transient = True
+    return entry
 
 
 def clear_cache():
     """Forget the loaded databases (and free their resident copies and the result buffers)."""
+    for e in _DB_CACHE.values():
+        e.close()
     _DB_CACHE.clear()
     _lib.lib().ppk_release_scratch()
 
@@ -75,6 +163,69 @@ def _devices(device_id):
     if env:
         return [int(x) for x in env.split(",") if x.strip() != ""]
     return [int(device_id)]
+
+
+def _flags(random_correct, jaccard, counts=False):
+    return (_lib.FLAG_RANDOM_CORRECT if random_correct else 0) | \
+        (_lib.FLAG_JACCARD if jaccard else 0) | (_lib.FLAG_COUNTS if counts else 0)
+
+
+def _table_args(random_table, random_correct, ref_clusters, qry_clusters, have_qry):
+    """(table pointer, n_clu, ref clusters, query clusters, keep-alive) with the checks of the C ABI's caller."""
+    if random_table is None or not random_correct:
+        return None, 0, None, None, None
+    random_table = np.ascontiguousarray(random_table, dtype=np.float32)
+    n_clu = random_table.shape[1]
+    if n_clu > 1:
+        if ref_clusters is None or (have_qry and qry_clusters is None):
+            raise RuntimeError("a multi-cluster random table needs per-sample cluster ids")
+        ref_clusters = np.ascontiguousarray(ref_clusters, dtype=np.uint16)
+        if ref_clusters.max(initial=0) >= n_clu:
+            raise RuntimeError("cluster id out of range of the random table")
+        if have_qry:
+            qry_clusters = np.ascontiguousarray(qry_clusters, dtype=np.uint16)
+            if qry_clusters.max(initial=0) >= n_clu:
+                raise RuntimeError("cluster id out of range of the random table")
+        else:
+            qry_clusters = None
+    else:
+        ref_clusters = qry_clusters = None
+    return random_table.ctypes.data_as(C.POINTER(C.c_float)), n_clu, ref_clusters, qry_clusters, random_table
+
+
+def query_entries(ref, qry, klist, random_table=None, ref_clusters=None, qry_clusters=None,
+                  random_correct=True, jaccard=False, counts=False, devices=(0,)):
+    """ppk_query_dbs on loaded databases (`_Entry`; qry=None => self): their resident copies are made
+    on first use and kept with the entry."""
+    lib = _lib.lib()
+    rl = ref.loaded
+    n_ref, nk, _ = rl.sketches.shape
+    kmers = np.ascontiguousarray(klist, dtype=np.int32).ravel()
+    if kmers.size != nk:
+        raise RuntimeError("klist does not match the sketches")
+    n_qry = 0 if qry is None else qry.loaded.sketches.shape[0]
+    if qry is not None and qry.loaded.sketches.shape[1:] != rl.sketches.shape[1:]:
+        raise RuntimeError("query and reference sketches have different shapes")
+    n_pairs = n_ref * (n_ref - 1) // 2 if qry is None else n_ref * n_qry
+    cols = nk if (jaccard or counts) else 2
+    out = np.zeros((n_pairs, cols), dtype=np.uint32 if counts else np.float32)
+    if n_pairs == 0:
+        return out, 0
+    tptr, n_clu, rclu, qclu, keep = _table_args(random_table, random_correct, ref_clusters, qry_clusters,
+                                                qry is not None)
+    devices = [int(d) for d in devices]
+    rh = ref.resident(devices, rclu)
+    qh = qry.resident(devices, qclu) if qry is not None else None
+    refs = (C.c_void_p * len(devices))(*[h.value for h in rh])
+    qrys = (C.c_void_p * len(devices))(*[h.value for h in qh]) if qh is not None else None
+    n_failed = C.c_ulonglong(0)
+    with _lib.interruptible():        # Ctrl-C is honoured between sub-bands (KeyboardInterrupt on exit)
+        rc = lib.ppk_query_dbs(refs, qrys, len(devices), kmers.ctypes.data_as(C.POINTER(C.c_int32)), tptr, n_clu,
+                               _flags(random_correct, jaccard, counts), C.c_void_p(out.ctypes.data),
+                               C.byref(n_failed))
+    del keep
+    _lib.check(rc, "ppk_query_dbs")
+    return out, int(n_failed.value)
 
 
 def query_arrays(ref_sk, qry_sk, klist, sketchsize64, bbits, random_table=None, ref_clusters=None,
@@ -97,28 +248,13 @@ def query_arrays(ref_sk, qry_sk, klist, sketchsize64, bbits, random_table=None, 
         n_qry = qry_sk.shape[0]
         qptr = qry_sk.ctypes.data_as(C.POINTER(C.c_uint64))
     n_pairs = n_ref * (n_ref - 1) // 2 if qry_sk is None else n_ref * n_qry
-    flags = (_lib.FLAG_RANDOM_CORRECT if random_correct else 0) | \
-        (_lib.FLAG_JACCARD if jaccard else 0) | (_lib.FLAG_COUNTS if counts else 0)
     cols = nk if (jaccard or counts) else 2
     out = np.zeros((n_pairs, cols), dtype=np.uint32 if counts else np.float32)
-    tptr = rcp = qcp = None
-    n_clu = 0
-    if random_table is not None and random_correct:
-        random_table = np.ascontiguousarray(random_table, dtype=np.float32)
-        n_clu = random_table.shape[1]
-        tptr = random_table.ctypes.data_as(C.POINTER(C.c_float))
-        if n_clu > 1:
-            if ref_clusters is None or (qry_sk is not None and qry_clusters is None):
-                raise RuntimeError("a multi-cluster random table needs per-sample cluster ids")
-            ref_clusters = np.ascontiguousarray(ref_clusters, dtype=np.uint16)
-            if ref_clusters.max(initial=0) >= n_clu:
-                raise RuntimeError("cluster id out of range of the random table")
-            rcp = ref_clusters.ctypes.data_as(C.POINTER(C.c_uint16))
-            if qry_sk is not None:
-                qry_clusters = np.ascontiguousarray(qry_clusters, dtype=np.uint16)
-                if qry_clusters.max(initial=0) >= n_clu:
-                    raise RuntimeError("cluster id out of range of the random table")
-                qcp = qry_clusters.ctypes.data_as(C.POINTER(C.c_uint16))
+    tptr, n_clu, rclu, qclu, keep = _table_args(random_table, random_correct, ref_clusters, qry_clusters,
+                                                qry_sk is not None)
+    u16 = C.POINTER(C.c_uint16)
+    rcp = None if rclu is None else rclu.ctypes.data_as(u16)
+    qcp = None if qclu is None else qclu.ctypes.data_as(u16)
     devs = (C.c_int * len(devices))(*[int(d) for d in devices])
     n_failed = C.c_ulonglong(0)
     if n_pairs == 0:
@@ -126,8 +262,9 @@ def query_arrays(ref_sk, qry_sk, klist, sketchsize64, bbits, random_table=None, 
     with _lib.interruptible():        # Ctrl-C is honoured between sub-bands (KeyboardInterrupt on exit)
         rc = lib.ppk_query(ref_sk.ctypes.data_as(C.POINTER(C.c_uint64)), n_ref, qptr, n_qry,
                            kmers.ctypes.data_as(C.POINTER(C.c_int32)), nk, sketchsize64, bbits, tptr,
-                           rcp, qcp, n_clu, flags, devs, len(devices),
+                           rcp, qcp, n_clu, _flags(random_correct, jaccard, counts), devs, len(devices),
                            C.c_void_p(out.ctypes.data), C.byref(n_failed))
+    del keep
     _lib.check(rc, "ppk_query")
     return out, int(n_failed.value)
 
@@ -141,42 +278,48 @@ def queryDatabase(ref_db_name, query_db_name, rList, qList, klist, random_correc
     rList = [str(x) for x in rList]
     qList = [str(x) for x in qList]
     self_query = (ref_db_name == query_db_name) and (rList == qList)
-    ref = _load_cached(ref_db_name, rList, klist)
-    if self_query:
-        qry = None
-        qry_sk = None
-        qry_clu = None
-    else:
-        qry = _load_cached(query_db_name, qList, klist)
-        if qry.sketchsize64 != ref.sketchsize64 or qry.bbits != ref.bbits:
-            raise RuntimeError("query and reference sketches have different sketch sizes")
-        qry_sk = qry.sketches
-        qry_clu = qry.clusters
-    table = ref.random_table
-    if random_correct and table is None:
-        if ref.random_status == "unrecognised":
-            why = ("the /random group of %s is not in the layout this package knows (datasets: %s)"
-                   % (ref_db_name, ", ".join(sorted(ref.random_raw or {}))))
+    ref_e = _load_cached(ref_db_name, rList, klist)
+    ref = ref_e.loaded
+    qry_e = None
+    try:
+        if self_query:
+            qry = None
+            qry_clu = None
         else:
-            why = "%s has no random match chances (run addRandom / poppunk --create-db on it)" % ref_db_name
-        if os.environ.get("PPK_ALLOW_NO_RANDOM", "") not in ("", "0"):
-            sys.stderr.write("poppunk_amd: %s; PPK_ALLOW_NO_RANDOM is set: distances WITHOUT random-match "
-                             "correction\n" % why)
-        else:
-            raise RuntimeError("random_correct=True but " + why + ".  Distances without the correction differ "
-                               "from PopPUNK's; pass random_correct=False or set PPK_ALLOW_NO_RANDOM=1 to "
-                               "compute them anyway")
-    if table is not None and table.shape[1] > 1 and qry is not None:
-        # queries take their cluster from the REFERENCE database's table [EXT closest_cluster]
-        if qry.random_raw is not ref.random_raw and ref.random_raw is not None:
-            mapped = sketchdb.random_from_raw(ref.random_raw, qList, klist, qry.base_freq)
-            if mapped is not None:
-                qry_clu = mapped[1]
-        if qry_clu is None:
-            qry_clu = np.zeros(len(qList), dtype=np.uint16)
-    out, n_failed = query_arrays(ref.sketches, qry_sk, klist, ref.sketchsize64, ref.bbits, table,
-                                 ref.clusters, qry_clu, random_correct=random_correct,
-                                 jaccard=jaccard, devices=_devices(device_id))
+            qry_e = _load_cached(query_db_name, qList, klist)
+            qry = qry_e.loaded
+            if qry.sketchsize64 != ref.sketchsize64 or qry.bbits != ref.bbits:
+                raise RuntimeError("query and reference sketches have different sketch sizes")
+            qry_clu = qry.clusters
+        table = ref.random_table
+        if random_correct and table is None:
+            if ref.random_status == "unrecognised":
+                why = ("the /random group of %s is not in the layout this package knows (datasets: %s)"
+                       % (ref_db_name, ", ".join(sorted(ref.random_raw or {}))))
+            else:
+                why = "%s has no random match chances (run addRandom / poppunk --create-db on it)" % ref_db_name
+            if os.environ.get("PPK_ALLOW_NO_RANDOM", "") not in ("", "0"):
+                sys.stderr.write("poppunk_amd: %s; PPK_ALLOW_NO_RANDOM is set: distances WITHOUT random-match "
+                                 "correction\n" % why)
+            else:
+                raise RuntimeError("random_correct=True but " + why + ".  Distances without the correction "
+                                   "differ from PopPUNK's; pass random_correct=False or set "
+                                   "PPK_ALLOW_NO_RANDOM=1 to compute them anyway")
+        if table is not None and table.shape[1] > 1 and qry is not None:
+            # queries take their cluster from the REFERENCE database's table [EXT closest_cluster]
+            if qry.random_raw is not ref.random_raw and ref.random_raw is not None:
+                mapped = sketchdb.random_from_raw(ref.random_raw, qList, klist, qry.base_freq)
+                if mapped is not None:
+                    qry_clu = mapped[1]
+            if qry_clu is None:
+                qry_clu = np.zeros(len(qList), dtype=np.uint16)
+        out, n_failed = query_entries(ref_e, qry_e, klist, table, ref.clusters, qry_clu,
+                                      random_correct=random_correct, jaccard=jaccard,
+                                      devices=_devices(device_id))
+    finally:
+        for e in (ref_e, qry_e):
+            if e is not None and e.transient:
+                e.close()
     if n_failed:
         sys.stderr.write("poppunk_amd: fitting k-mer gradient failed for %d pair(s) "
                          "(fewer than two k-mer lengths above the 5/s Jaccard floor); "

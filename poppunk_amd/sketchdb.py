@@ -225,6 +225,8 @@ def _load_npz(path, names, klist):
 # ---- .h5 ------------------------------------------------------------------------------------------
 
 def _load_h5(path, names, klist):
+    if len(names) == 0:
+        raise RuntimeError("no sample names given")
     _, h5open = _h5_backend()
     f = h5open(path, "r")
     try:

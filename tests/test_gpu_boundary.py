@@ -408,8 +408,8 @@ def test_threshold_iterate_2d_on_resident_matrix():
 def test_threshold_iterate_many_offsets_and_one_pass_host_calls():
     """More offsets than fit a kernel argument (the boundaries live in device memory: up to 1023 per
     call; the reference has no limit, its callers pass 40 and 20), and the host entry points'
-    protocol: a first call with too little room leaves the finished result parked on the device and
-    reports its size, the second call only fetches it."""
+    protocol: a call with too little room leaves the finished result parked on the device and
+    reports its size, ppk_parked_fetch copies it out (tests/test_gpu_hostcalls.py has the rest)."""
     import ctypes as C
     from poppunk_amd import _lib
     rng = np.random.Generator(np.random.PCG64(77))
@@ -425,7 +425,7 @@ def test_threshold_iterate_many_offsets_and_one_pass_host_calls():
     assert np.array_equal(gi, wi) and np.array_equal(gj, wj) and np.array_equal(go, wo) and len(wi) > 1000
     with pytest.raises(RuntimeError, match="too many offsets"):
         poppunk_refine.thresholdIterate2D_arrays(d, np.linspace(0.01, 0.6, 1024).astype(np.float32), 0.2)
-    # the two-call protocol through the raw C ABI
+    # size query + explicit fetch through the raw C ABI
     lib = _lib.lib()
     n = C.c_size_t(0)
     fp = d.ctypes.data_as(C.POINTER(C.c_float))
@@ -433,8 +433,7 @@ def test_threshold_iterate_many_offsets_and_one_pass_host_calls():
     want = oracle.edge_threshold(d, 2, 0.5, 0.5)
     assert n.value == len(want) > 0
     ij = np.empty((n.value, 2), dtype=np.int64)
-    assert lib.ppk_edge_threshold(fp, d.shape[0], 0, 2, 0.5, 0.5, 1, 0, ij.ctypes.data_as(C.POINTER(C.c_longlong)),
-                                  n.value, C.byref(n)) == _lib.OK
+    assert lib.ppk_parked_fetch(ij.ctypes.data_as(C.POINTER(C.c_longlong)), None, None, n.value, None) == _lib.OK
     assert np.array_equal(ij, want)
     # different arguments after a parked result: a fresh computation, not the parked list
     e2 = poppunk_refine.edgeThreshold_array(d, 2, 0.4, 0.5)

@@ -1,0 +1,212 @@
+"""The host-buffer layer of libppk_hip.so on a real MI355X: what stays on the device between
+calls (fit tables, resident databases, parked results) must never answer for inputs it was not
+computed from, and a device list runs its entries side by side (one worker thread each).
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from poppunk_amd import _lib, engine, poppunk_refine, pp_sketchlib, synth
+
+pytestmark = pytest.mark.gpu
+
+KMERS = np.asarray(synth.DEFAULT_KMERS, dtype=np.int32)
+TOL = 1e-6
+
+
+def _stats():
+    v = (C.c_double * 7)()
+    _lib.check(_lib.lib().ppk_query_last_stats(v, 7), "ppk_query_last_stats")
+    return dict(zip(("parts", "threads", "dl_max", "up_max", "wall_ms", "upload_ms_max", "part_ms_max"), list(v)))
+
+
+def test_fit_tables_are_rebuilt_after_release_scratch():
+    """ppk_release_scratch frees the block that holds the log-J / (E, F) tables; the next call with
+    the same k list and table gets, as a rule, the same address back from hipMalloc -- the tables
+    must be rebuilt, not taken for valid (round-2 advisor finding)."""
+    sk, _ = synth.make_sketches(300, KMERS, cluster_size=30)
+    tbl = synth.random_match_table(KMERS)
+    want, wf = oracle.query(sk, None, KMERS, 16, 14, tbl, threads=4)
+    lib = _lib.lib()
+    for _ in range(3):
+        got, gf = pp_sketchlib.query_arrays(sk, None, KMERS, 16, 14, tbl)
+        assert gf == wf and np.abs(got - want).max() <= TOL
+        lib.ppk_release_scratch()
+        # something else takes (and scribbles over) the freed block before the tables come back
+        junk = np.full((50000, 2), 0.5, dtype=np.float32)
+        poppunk_refine.assignThreshold(junk, 2, 0.3, 0.3)
+    db = engine.SketchDB(sk, 16, 14)
+    for _ in range(2):
+        d, _ = engine.dist(db, None, KMERS, tbl)
+        assert np.abs(d.cpu().numpy() - want).max() <= TOL
+        pp_sketchlib.clear_cache()
+    db.close()
+
+
+def test_in_place_rewrite_of_one_sample_at_70k_genomes_is_seen():
+    """ppk_query keeps resident databases keyed by the host pointer, the dimensions and a hash of
+    EVERY word.  Round 2 sampled 2^16 words: above ~65 000 genomes a one-sample change could go
+    unnoticed and the call answered with the OLD sketches.  70 000 refs x 64 queries, default
+    options: rewrite one ref in place (same pointer, same shape) -> the new counts."""
+    rng = np.random.Generator(np.random.PCG64(11))
+    n_ref, n_qry = 70000, 64
+    ref = rng.integers(0, 1 << 63, size=(n_ref, 5, 224), dtype=np.int64).astype(np.uint64)
+    qry = rng.integers(0, 1 << 63, size=(n_qry, 5, 224), dtype=np.int64).astype(np.uint64)
+    assert _lib.get_option("db_cache") == 1
+    first, _ = pp_sketchlib.query_arrays(ref, qry, KMERS, 16, 14, counts=True)
+    assert first.max() < 64                               # unrelated words: a handful of chance matches
+    again, _ = pp_sketchlib.query_arrays(ref, qry, KMERS, 16, 14, counts=True)
+    assert np.array_equal(first, again)
+    for victim in (41234, 69999, 0):
+        ref[victim] = qry[7]                              # in place: every bin of every k now matches query 7
+        got, _ = pp_sketchlib.query_arrays(ref, qry, KMERS, 16, 14, counts=True)
+        assert np.array_equal(got[7 * n_ref + victim], np.full(5, 1024)), victim
+    rows = np.concatenate([np.arange(7 * n_ref, 8 * n_ref), np.arange(0, n_ref)])
+    want = oracle.match_counts(ref, qry[[7, 0]], 16, 14, threads=8)
+    assert np.array_equal(got[rows], np.concatenate([want[:n_ref], want[n_ref:]]))
+    # one WORD changed (the smallest possible edit)
+    ref[12345, 3, 100] ^= np.uint64(1)
+    got2, _ = pp_sketchlib.query_arrays(ref, qry, KMERS, 16, 14, counts=True)
+    want2 = oracle.match_counts(ref[12345:12346], qry, 16, 14, threads=1)
+    assert np.array_equal(got2[12345::n_ref], want2)
+    pp_sketchlib.clear_cache()
+
+
+def test_resident_database_cache_stays_bounded_and_correct():
+    """Six different host arrays in turn (more than the four kept per device), each queried twice:
+    every answer is its own."""
+    tbl = synth.random_match_table(KMERS)
+    arrays = [synth.make_sketches(150 + 10 * i, KMERS, cluster_size=25, seed=100 + i)[0] for i in range(6)]
+    want = [oracle.query(a, None, KMERS, 16, 14, tbl, threads=4)[0] for a in arrays]
+    for rnd in range(2):
+        for a, w in zip(arrays, want):
+            got, _ = pp_sketchlib.query_arrays(a, None, KMERS, 16, 14, tbl)
+            assert np.abs(got - w).max() <= TOL
+    pp_sketchlib.clear_cache()
+
+
+def test_parked_result_is_fetched_explicitly_and_never_matched_to_a_later_call():
+    """A host call whose buffer is too small parks the finished list for ppk_parked_fetch; the same
+    entry point called again -- same pointer, same arguments, rewritten contents -- recomputes."""
+    lib = _lib.lib()
+    rng = np.random.Generator(np.random.PCG64(5))
+    samples = 300
+    d = rng.random((samples * (samples - 1) // 2, 2)).astype(np.float32)
+    fp = d.ctypes.data_as(C.POINTER(C.c_float))
+    ll = C.POINTER(C.c_longlong)
+    n = C.c_size_t(0)
+    want = oracle.edge_threshold(d, 2, 0.5, 0.5)
+    assert lib.ppk_edge_threshold(fp, d.shape[0], 0, 2, 0.5, 0.5, 1, 0, None, 0, C.byref(n)) == _lib.ERR_CAPACITY
+    assert n.value == len(want) > 0
+    # another thread has nothing parked
+    seen = []
+    t = threading.Thread(target=lambda: seen.append(lib.ppk_parked_fetch(None, None, None, 0, None)))
+    t.start()
+    t.join()
+    assert seen == [_lib.ERR_STATE]
+    ij = np.empty((n.value, 2), dtype=np.int64)
+    m = C.c_size_t(0)
+    assert lib.ppk_parked_fetch(ij.ctypes.data_as(ll), None, None, 3, C.byref(m)) == _lib.ERR_CAPACITY and m.value == n.value
+    assert lib.ppk_parked_fetch(ij.ctypes.data_as(ll), None, None, n.value, C.byref(m)) == _lib.OK
+    assert np.array_equal(ij, want)
+    assert lib.ppk_parked_fetch(ij.ctypes.data_as(ll), None, None, n.value, None) == _lib.ERR_STATE   # fetched once
+    # the size query that is never followed by a fetch (an exception between the two calls), then the same
+    # array rewritten in place
+    assert lib.ppk_edge_threshold(fp, d.shape[0], 0, 2, 0.5, 0.5, 1, 0, None, 0, C.byref(n)) == _lib.ERR_CAPACITY
+    d[:] = rng.random(d.shape).astype(np.float32)
+    want2 = oracle.edge_threshold(d, 2, 0.5, 0.5)
+    assert not np.array_equal(want2, want)
+    ij2 = np.empty((len(want2) + 5, 2), dtype=np.int64)
+    assert lib.ppk_edge_threshold(fp, d.shape[0], 0, 2, 0.5, 0.5, 1, 0, ij2.ctypes.data_as(ll), len(ij2),
+                                  C.byref(n)) == _lib.OK
+    assert n.value == len(want2) and np.array_equal(ij2[:n.value], want2)
+    assert lib.ppk_parked_fetch(ij.ctypes.data_as(ll), None, None, len(ij), None) == _lib.ERR_STATE   # dropped
+    # the sweeps' three arrays
+    offsets = np.linspace(-0.2, 0.3, 40) * np.sqrt(2)
+    wi, wj, wo = oracle.threshold_iterate_1d(d, offsets, 2, 0.2, 0.2, 0.3, 0.3)
+    od = offsets.ctypes.data_as(C.POINTER(C.c_double))
+    assert lib.ppk_threshold_iterate_1d(fp, d.shape[0], od, len(offsets), 2, 0.2, 0.2, 0.3, 0.3, 0, None, None,
+                                        None, 0, C.byref(n)) == _lib.ERR_CAPACITY
+    assert n.value == len(wi) > 0
+    gi, gj, go = (np.empty(n.value, dtype=np.int64) for _ in range(3))
+    assert lib.ppk_parked_fetch(gi.ctypes.data_as(ll), gj.ctypes.data_as(ll), go.ctypes.data_as(ll), n.value,
+                                None) == _lib.OK
+    assert np.array_equal(gi, wi) and np.array_equal(gj, wj) and np.array_equal(go, wo)
+    # and the Python mirrors (guess too small -> fetch) on the rewritten matrix
+    assert np.array_equal(poppunk_refine.edgeThreshold_array(d, 2, 0.9, 0.9), oracle.edge_threshold(d, 2, 0.9, 0.9))
+    lib.ppk_release_scratch()
+
+
+def test_device_list_entries_run_side_by_side(ppk_option):
+    """ppk_query with a device list: one worker thread per entry uploads / computes / downloads its
+    share.  On a 1-GPU box the same device is listed twice (separate streams and buffers): the result
+    equals the one-device result bit for bit, two threads ran, and at some moment both had a
+    download in flight (library counters)."""
+    tbl = synth.random_match_table(KMERS)
+    sk = synth.make_sketches(5000, KMERS, cluster_size=50, seed=9)[0]          # 12.5 M pairs, 100 MB of result
+    one, f1 = pp_sketchlib.query_arrays(sk, None, KMERS, 16, 14, tbl, devices=(0,))
+    st = _stats()
+    assert st["parts"] == 1 and st["threads"] == 0 and st["dl_max"] == 1
+    ppk_option("chunk_rows", 400000)                                           # ~16 sub-bands per entry
+    overlapped = 0
+    for _ in range(5):
+        two, f2 = pp_sketchlib.query_arrays(sk, None, KMERS, 16, 14, tbl, devices=(0, 0))
+        assert f2 == f1 and np.array_equal(one, two)
+        st = _stats()
+        assert st["parts"] == 2 and st["threads"] == 2
+        overlapped = max(overlapped, st["dl_max"])
+    assert overlapped == 2
+    # cold start with the cache off: the leader entry uploads, the other waits for it
+    ppk_option("db_cache", 0)
+    three, f3 = pp_sketchlib.query_arrays(sk[:3000], sk[3000:], KMERS, 16, 14, tbl, devices=(0, 0, 0))
+    base, fb = pp_sketchlib.query_arrays(sk[:3000], sk[3000:], KMERS, 16, 14, tbl, devices=(0,))
+    assert f3 == fb and np.array_equal(three, base)
+    want, _ = oracle.query(sk[:3000], sk[3000:3200], KMERS, 16, 14, tbl, threads=8)
+    assert np.abs(base[:3000 * 200] - want).max() <= TOL
+    pp_sketchlib.clear_cache()
+
+
+def test_queryDatabase_holds_handles_and_splits_over_PPK_DEVICES(tmp_path, monkeypatch):
+    """The Python mirror keeps ppk_db handles with its loaded databases and calls ppk_query_dbs:
+    self, ref x query and sub-sample re-queries, one device and a list; a rewritten FILE is read
+    again (the key holds its modification time)."""
+    from poppunk_amd import sketchdb
+    sk, _ = synth.make_sketches(700, KMERS, cluster_size=35, seed=21)
+    tbl = synth.random_match_table(KMERS)
+    names = ["s%04d" % i for i in range(700)]
+    db = str(tmp_path / "db")
+    sketchdb.save_npz(db, names, KMERS, sk, 16, 14, random_table=tbl)
+    pp_sketchlib.clear_cache()
+    klist = KMERS.tolist()
+    want, _ = oracle.query(sk, None, KMERS, 16, 14, tbl, threads=4)
+    got = pp_sketchlib.queryDatabase(db, db, names, names, klist, True, False, 1, True, 0)
+    assert np.abs(got - want).max() <= TOL
+    assert len(pp_sketchlib._DB_CACHE) == 1
+    entry = next(iter(pp_sketchlib._DB_CACHE.values()))
+    assert len(entry._handles) == 1
+    # --plot-fit style re-queries of single samples: sliced from the loaded database, never cached
+    for a, b in ((3, 4), (10, 699)):
+        j = pp_sketchlib.queryDatabase(db, db, [names[a]], [names[b]], klist, True, True, 1, True, 0)
+        wj = oracle.query(sk[a:a + 1], sk[b:b + 1], KMERS, 16, 14, tbl, jaccard=True, threads=1)[0]
+        assert np.array_equal(j, wj)
+    assert len(pp_sketchlib._DB_CACHE) == 1 and len(entry._handles) == 1
+    # ref x query out of one file, over a device list
+    monkeypatch.setenv("PPK_DEVICES", "0,0")
+    rq = pp_sketchlib.queryDatabase(db, db, names[:500], names[500:], klist, True, False, 1, True, 0)
+    assert np.abs(rq - oracle.query(sk[:500], sk[500:], KMERS, 16, 14, tbl, threads=4)[0]).max() <= TOL
+    assert _stats()["threads"] == 2
+    again = pp_sketchlib.queryDatabase(db, db, names, names, klist, True, False, 1, True, 0)
+    assert np.array_equal(again, got)
+    monkeypatch.delenv("PPK_DEVICES")
+    # the file is rewritten with other sketches under the same names
+    sk2, _ = synth.make_sketches(700, KMERS, cluster_size=35, seed=22)
+    sketchdb.save_npz(db, names, KMERS, sk2, 16, 14, random_table=tbl)
+    os.utime(db + ".npz", ns=(1, 1))                      # whatever the clock granularity
+    got2 = pp_sketchlib.queryDatabase(db, db, names, names, klist, True, False, 1, True, 0)
+    assert np.abs(got2 - oracle.query(sk2, None, KMERS, 16, 14, tbl, threads=4)[0]).max() <= TOL
+    pp_sketchlib.clear_cache()
+    assert not pp_sketchlib._DB_CACHE
