@@ -23,16 +23,19 @@ Rank 0 prints ONE JSON line (see the driver contract) carrying
   `roofline`     the dominant kernel, HIP-event timed inside libppk_hip.so on its own stream,
                  against the integer-VALU roof that binds it (and, for reference, the HBM figures);
   `cpu_baseline` the oracle, timed on this host on a bounded sample (N = 1 only);
-  `host_call`    the PCIe-inclusive ppk_query call PopPUNK itself makes (N = 1 only; never `value`);
+  `host_call`    the PCIe-inclusive call PopPUNK itself makes (never `value`); N > 1: as
+                 `multi_gpu.host_call`, ONE process driving all N GPUs (a worker thread per device);
   `config5`      BASELINE config 5's shape -- 100 000 genomes self, fused distance -> boundary ->
                  edge list, only the edge lists gathered (engine.edges_sharded) -- timed separately
                  after the headline steps; `multi_gpu` (N > 1) compute vs gather time.
 """
 import argparse
+import ctypes as C
 import json
 import os
 import socket
 import sys
+import threading
 import time
 
 import numpy as np
@@ -68,6 +71,11 @@ def parse():
                     help="untimed clock spin-up before the warm-up steps (0 disables)")
     ap.add_argument("--chunks", type=int, default=4,
                     help="sub-bands per rank: the gather of chunk c overlaps the compute of c+1")
+    ap.add_argument("--watchdog-s", type=float, default=240.0,
+                    help="a phase (init, spin-up, rebalance, timed steps, ...) that lasts longer prints the "
+                         "JSON line with what has been measured and ends the process (0 = off)")
+    ap.add_argument("--collective-timeout", type=float, default=120.0,
+                    help="process-group timeout in seconds (a stuck collective raises instead of hanging)")
     ap.add_argument("--even-bands", action="store_true",
                     help="N > 1: keep equal bands (default: re-cut them from measured rates during "
                          "the untimed set-up, so that the root, whose band needs no transfer, takes more)")
@@ -144,26 +152,47 @@ def cpu_baseline(sk, kmers, tbl, seconds):
                       % (n_s, sk.shape[0], pairs, reps, total, threads, os.cpu_count() or 0)}
 
 
-def host_call(sk, kmers, tbl, device, reps=5):
-    """The call PopPUNK itself makes (pp_sketchlib.queryDatabase after the file read -> ppk_query):
-    host sketches in, a FRESH host result array out, PCIe both ways.  The first call uploads and
-    re-lays out the sketches; later calls find them resident (ppk_query's database cache)."""
-    from poppunk_amd import _lib, pp_sketchlib
-    _lib.lib().ppk_release_scratch()                 # start cold: no cached database, no buffers
+def host_call(sk, kmers, tbl, devices, reps=5):
+    """The call PopPUNK itself makes, after the file read (pp_sketchlib.queryDatabase: the loaded
+    database's resident handles -> ppk_query_dbs): host sketches in, a FRESH pageable host result array
+    out, PCIe both ways, `devices` driven by ONE process (a worker thread per device).  The first call
+    uploads and re-lays out the sketches on every device (side by side); later calls find them resident.
+    `arrays_ms`: the raw-array entry point ppk_query on the same job (it must hash every word of the
+    sketch array per call to know that its resident copy is still good)."""
+    from poppunk_amd import _lib, pp_sketchlib, sketchdb
+    lib = _lib.lib()
+    lib.ppk_release_scratch()                 # start cold: no cached database, no buffers
+    n = sk.shape[0]
+    entry = pp_sketchlib._Entry(sketchdb.LoadedSketches(["g%d" % i for i in range(n)], kmers, sk, 16, 14, tbl,
+                                                        None, random_status="mapped"))
     times = []
     for _ in range(reps):
         t0 = time.perf_counter()
-        out, _ = pp_sketchlib.query_arrays(sk, None, kmers, 16, 14, tbl, devices=(device,))
+        out, _ = pp_sketchlib.query_entries(entry, None, kmers, tbl, devices=devices)
         times.append((time.perf_counter() - t0) * 1e3)
         del out
-    pairs = sk.shape[0] * (sk.shape[0] - 1) // 2
+    st = (C.c_double * 7)()
+    lib.ppk_query_last_stats(st, 7)
+    entry.close()
+    arr = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        out, _ = pp_sketchlib.query_arrays(sk, None, kmers, 16, 14, tbl, devices=tuple(devices))
+        arr.append((time.perf_counter() - t0) * 1e3)
+        del out
+    lib.ppk_release_scratch()
+    pairs = n * (n - 1) // 2
     warm = sorted(times[1:])
     med = warm[len(warm) // 2]
-    return {"first_call_ms": round(times[0], 3), "ms": round(med, 3), "min_ms": round(warm[0], 3),
-            "pairs_per_s": pairs / (med * 1e-3), "result_bytes": pairs * 8,
-            "note": "ppk_query, host buffers in / fresh host array out (np.zeros pages untouched), "
-                    "median of %d calls after the first; the first call also uploads + re-lays out "
-                    "the %d MB of sketches" % (reps - 1, sk.nbytes >> 20)}
+    return {"devices": list(devices), "first_call_ms": round(times[0], 3), "ms": round(med, 3),
+            "min_ms": round(warm[0], 3), "pairs_per_s": pairs / (med * 1e-3), "result_bytes": pairs * 8,
+            "worker_threads": int(st[1]), "max_downloads_in_flight": int(st[2]),
+            "arrays_ms": round(sorted(arr[1:])[0], 3),
+            "note": "pp_sketchlib.queryDatabase after the file read: ppk_query_dbs on resident handles, host "
+                    "buffers in / fresh host array out (np.zeros pages untouched), median of %d calls after "
+                    "the first; the first call also uploads + re-lays out the %d MB of sketches per device.  "
+                    "arrays_ms: ppk_query on the raw array (adds a hash of every sketch word per call)"
+                    % (reps - 1, sk.nbytes >> 20)}
 
 
 def config5(args, rank, world, local_rank, dev, barrier):
@@ -213,132 +242,107 @@ def config5(args, rank, world, local_rank, dev, barrier):
             "gathered_bytes_per_step": int(sum(counts[1:])) * 16}
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
-        relaunch_under_torchrun(args)        # does not return
-    import torch
-    import torch.distributed as dist
-    from poppunk_amd import _lib, engine, synth
+class Report:
+    """The ONE JSON line, whatever happens: phases record what they measured into `fields`; `emit`
+    prints once (rank 0).  A per-phase watchdog (threading.Timer) prints the line with what is there
+    and ends the process if a phase hangs (a stuck collective never returns to Python)."""
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if os.environ.get("PPK_BENCH_ONE_GPU"):      # debugging aid: every rank on GPU 0
-        local_rank = 0
-    if world != args.gpus:
-        sys.exit("bench.py --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs a GPU (there is no CPU path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("PPK_BENCH_BACKEND", "nccl")   # "gloo": debugging aid with PPK_BENCH_ONE_GPU
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+    def __init__(self, rank, world, args):
+        self.rank, self.world, self.args = rank, world, args
+        self.fields = {}
+        self.errors = []
+        self.phase = "start"
+        self._lock = threading.Lock()
+        self._done = False
+        self._timer = None
+        self.per_rank_dir = None
 
-    lib = _lib.lib()
-    n = int(round(args.n * world ** 0.5)) if (args.weak and world > 1) else args.n
-    kmers = np.asarray(synth.DEFAULT_KMERS, dtype=np.int32)
-    sk, _ = synth.make_sketches(n, kmers, sketchsize64=16, bbits=14)
-    tbl = synth.random_match_table(kmers)
-    ref = engine.SketchDB(sk, 16, 14, device=local_rank)
+    def enter(self, phase):
+        self.phase = phase
+        if self._timer is not None:
+            self._timer.cancel()
+        limit = self.args.watchdog_s
+        if limit > 0:
+            self._timer = threading.Timer(limit, self._hung)
+            self._timer.daemon = True
+            self._timer.start()
 
-    job = engine.ShardedQuery(ref, None, rank, world, n_chunks=args.chunks if world > 1 else 1)
-    rows = job.band_rows
-    total_pairs = int(job.total_rows)
+    def _hung(self):
+        self.errors.append("watchdog: phase '%s' exceeded %.0f s" % (self.phase, self.args.watchdog_s))
+        try:
+            self.emit()
+        finally:
+            sys.stdout.flush()
+            os._exit(3)
 
-    def step():
-        job.run(kmers, tbl)
+    def error(self, where, exc):
+        self.errors.append("%s: %s: %s" % (where, type(exc).__name__, str(exc).splitlines()[0][:300] if str(exc) else ""))
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def finish(self):
+        if self._timer is not None:
+            self._timer.cancel()
 
-    # Device spin-up (setup, not part of the W warm-up steps): after an idle period the GPU clock
-    # takes ~50 ms of load to ramp and the first launches run 20-30 % slow; a driver that asks for a
-    # short --warmup would otherwise time the governor instead of the kernel.
-    band_note = "1 GPU"
-    if world == 1:
-        t_spin = time.perf_counter()
-        while time.perf_counter() - t_spin < args.spinup_ms * 1e-3:
-            step()
-            torch.cuda.synchronize()
-    else:
-        if args.spinup_ms > 0:
-            n_spin = 30 if os.environ.get("PPK_BENCH_BACKEND", "nccl") == "nccl" else 1
-            for _ in range(n_spin):      # every rank must run the SAME number of gathered steps
-                step()
-            torch.cuda.synchronize()
-        # Set-up, like choosing the band edges at all: with equal bands a step lasts as long as the
-        # slowest peer -> root transfer (a GPU produces 8 B per pair faster than its one xGMI link to
-        # the root carries them) while the root's own band needs none.  Three measured steps re-cut
-        # the bands in proportion to each rank's measured rate (engine.ShardedQuery.rebalance).
-        if not args.even_bands:
-            def probe(n_steps=3):
-                """ms per gathered step, max over ranks (the same number on every rank)."""
-                barrier()
-                t_p = time.perf_counter()
-                for _ in range(n_steps):
-                    step()
-                barrier()
-                t = torch.tensor([(time.perf_counter() - t_p) / n_steps * 1e3], dtype=torch.float64,
-                                 device=dev if dist.get_backend() == "nccl" else "cpu")
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                return float(t.item())
-            ms_even = probe()
-            for _ in range(3):
-                job.rebalance(kmers, tbl)
-            ms_balanced = probe()
-            band_note = "rate-balanced (%.2f ms/step against %.2f with equal bands, set-up probe)" % (ms_balanced, ms_even)
-            if ms_balanced > 1.02 * ms_even:      # never keep a cut that measures worse than the equal one
-                job._layout(engine.shard_bounds(ref.n, 0, world))
-                band_note = "equal (the rate-balanced cut measured %.2f ms/step against %.2f)" % (ms_balanced, ms_even)
-            rows = job.band_rows
-        else:
-            band_note = "equal (--even-bands)"
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    lib.ppk_prof_enable(1)
-    lib.ppk_prof_read(None, None, 1)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    lib.ppk_prof_enable(0)
-    import ctypes as C
-    kms, kn = C.c_double(0), C.c_longlong(0)
-    lib.ppk_prof_read(C.byref(kms), C.byref(kn), 1)
-    kernel_ms = kms.value / max(kn.value, 1)
-    kname = lib.ppk_last_kernel_name().decode()
+    # per-rank numbers travel through files: they must reach rank 0 even when the process group is broken
+    def publish_rank(self, d):
+        if self.per_rank_dir is None:
+            return
+        tmp = os.path.join(self.per_rank_dir, "rank%d.json.tmp" % self.rank)
+        with open(tmp, "w") as f:
+            json.dump(d, f)
+        os.replace(tmp, os.path.join(self.per_rank_dir, "rank%d.json" % self.rank))
 
-    compute_ms = kms.value / args.steps          # kernel time per step on this rank (HIP events)
-    if world > 1:
-        t = torch.tensor([elapsed, compute_ms], dtype=torch.float64,
-                         device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, compute_ms = float(t[0].item()), float(t[1].item())
+    def collect_ranks(self, wait_s=10.0):
+        out = [None] * self.world
+        if self.per_rank_dir is None:
+            return out
+        t_end = time.time() + wait_s
+        while True:
+            for r in range(self.world):
+                if out[r] is None:
+                    try:
+                        out[r] = json.load(open(os.path.join(self.per_rank_dir, "rank%d.json" % r)))
+                    except Exception:
+                        pass
+            if all(x is not None for x in out) or time.time() > t_end:
+                return out
+            time.sleep(0.05)
 
-    c5 = None
-    if not args.no_config5:
-        ref.close()
-        job.out = None
-        torch.cuda.empty_cache()
-        c5 = config5(args, rank, world, local_rank, dev, barrier)
+    def emit(self):
+        with self._lock:
+            if self._done or self.rank != 0:
+                self._done = True
+                return
+            self._done = True
+            line = build_line(self)
+            print(json.dumps(line))
+            sys.stdout.flush()
 
-    if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = total_pairs * args.steps / elapsed
-        per_launch = rows[0] / job.n_chunks          # pairs one launch of the dominant kernel covers
-        k_s = kernel_ms * 1e-3
-        lane_ops = VALU_OPS_PER_PAIR * per_launch / k_s if k_s > 0 else 0.0
-        algo_gbs = ALGO_BYTES_PER_PAIR * per_launch / k_s / 1e9 if k_s > 0 else 0.0
+
+def build_line(rep):
+    """Everything rank 0 knows at this point -> the driver's JSON line."""
+    args, world, f = rep.args, rep.world, rep.fields
+    n = f.get("n", args.n)
+    total_pairs = f.get("total_pairs", n * (n - 1) // 2)
+    ranks = rep.collect_ranks(10.0 if (world > 1 and ("elapsed" not in f or rep.errors)) else 0.5) if world > 1 else []
+    per_rank_compute = [None if r is None else r.get("compute_ms_per_step") for r in ranks]
+    per_rank_pairs = [None if r is None else r.get("band_pairs") for r in ranks]
+    value = ms_per_step = None
+    value_note = None
+    if "elapsed" in f:
+        ms_per_step = f["elapsed"] / args.steps * 1e3
+        value = total_pairs * args.steps / f["elapsed"]
+    elif world > 1 and per_rank_compute and all(x is not None and x > 0 for x in per_rank_compute):
+        # the gathered steps did not complete: what the ranks computed side by side, WITHOUT the gather
+        ms_per_step = max(per_rank_compute)
+        value = sum(per_rank_pairs) / (ms_per_step * 1e-3)
+        value_note = ("the gathered steps did not complete (multi_gpu.error): value is the aggregate of the "
+                      "ranks' compute-only steps (HIP events, no collective) and EXCLUDES the gather to rank 0")
+    roof = None
+    kernel_ms = f.get("kernel_ms")
+    if kernel_ms and f.get("per_launch"):
+        per_launch, k_s = f["per_launch"], kernel_ms * 1e-3
+        lane_ops = VALU_OPS_PER_PAIR * per_launch / k_s
+        algo_gbs = ALGO_BYTES_PER_PAIR * per_launch / k_s / 1e9
         traffic, traffic_source = None, None
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile) and world == 1:
@@ -352,10 +356,10 @@ def main():
                 "unit": "T lane-op/s", "frac": round(lane_ops / VALU_PEAK_LANE_OPS, 4),
                 "frac_of_measured_bitop3_stream": round(lane_ops / VALU_MEASURED_LANE_OPS, 4),
                 "traffic": traffic, "traffic_source": traffic_source,
-                "hbm_frac_counter": round(traffic / k_s / 1e9 / HBM_PEAK_GBS, 4) if (traffic and k_s > 0) else None,
+                "hbm_frac_counter": round(traffic / k_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                 "hbm_naive_x": round(algo_gbs / HBM_PEAK_GBS, 2),
                 "hbm_naive_GBs": round(algo_gbs, 1),
-                "kernel": kname, "kernel_ms": round(kernel_ms, 4),
+                "kernel": f.get("kernel_name"), "kernel_ms": round(kernel_ms, 4),
                 "pairs_per_launch": per_launch,
                 "note": "Integer set-intersection (no MFMA): the binding roof is VALU issue.  achieved = "
                         "2400 VALU lane-ops/pair (5 k x 16 blocks x (28 v_bitop3 + 2 v_bcnt)) x pairs per launch "
@@ -367,44 +371,335 @@ def main():
                         "fraction); hbm_frac_counter = PMC-measured fabric bytes per launch (traffic, from "
                         "traffic_source -- a recorded rocprofv3 run, not measured in this process) / kernel "
                         "time / 8 TB/s"}
-        cpu = None
-        if not args.no_cpu and world == 1:
-            cpu = cpu_baseline(sk, kmers, tbl, args.cpu_seconds)
-        hc = None
-        if not args.no_host_call and world == 1:
-            hc = host_call(sk, kmers, tbl, local_rank)
-        line = {
-            "metric": "genome-pair distances/sec (10k self, s=1024, k=13-29)",
-            "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak" if (args.weak and world > 1) else "strong", "vs_baseline": None, "dtype": "u64",
-            "data": "synthetic",
-            "config": {"workload": "%d synthetic genomes self-vs-self, s=1024 (sketchsize64=16, "
-                                   "bbits=14), k=13,17,21,25,29, %d pairs, output [n_pairs,2] f32 "
-                                   "on rank 0" % (n, total_pairs),
-                       "n_genomes": n, "pairs": total_pairs,
-                       "parallelism": "band-split x%d (%s bands), %d-chunk pipelined p2p gather to rank 0"
-                                      % (world, band_note.split(" ")[0], args.chunks) if world > 1 else "1 GPU"},
-            "roofline": roof, "cpu_baseline": cpu, "host_call": hc, "config5": c5,
-        }
-        if world > 1:
-            # where an N-GPU step goes: the slowest rank's kernel time, and what the root receives
-            line["multi_gpu"] = {
-                "compute_ms_per_step_max_rank": round(compute_ms, 4),
-                "gather_exposed_ms_per_step": round(max(ms_per_step - compute_ms, 0.0), 4),
-                "gathered_bytes_per_step": int(sum(job.band_rows[1:])) * 8,
-                "band_shares": [round(b / max(total_pairs, 1), 4) for b in job.band_rows],
-                "bands": band_note + "; the root's band needs no transfer, so equal bands are not the "
-                                     "fastest cut (engine.ShardedQuery.rebalance)",
-                "note": "value includes the p2p gather of every peer's distance block into the "
-                        "PopPUNK-ordered matrix on rank 0 (pipelined under compute in %d chunks); "
-                        "the root's inbound xGMI links bound it.  config5 is the shape that scales: "
-                        "only edge lists move" % args.chunks}
-        if cpu:
-            line["speedup_vs_cpu"] = value / cpu["value"]
-        print(json.dumps(line))
+    band_note = f.get("band_note", "1 GPU")
+    line = {
+        "metric": "genome-pair distances/sec (10k self, s=1024, k=13-29)",
+        "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "weak" if (args.weak and world > 1) else "strong", "vs_baseline": None, "dtype": "u64",
+        "data": f.get("data", "synthetic"),
+        "config": {"workload": "%d synthetic genomes self-vs-self, s=1024 (sketchsize64=16, "
+                               "bbits=14), k=13,17,21,25,29, %d pairs, output [n_pairs,2] f32 "
+                               "on rank 0" % (n, total_pairs),
+                   "n_genomes": n, "pairs": total_pairs,
+                   "parallelism": "band-split x%d (%s bands), %d-chunk pipelined p2p gather to rank 0"
+                                  % (world, band_note.split(" ")[0], args.chunks) if world > 1 else "1 GPU"},
+        "roofline": roof, "cpu_baseline": f.get("cpu"), "host_call": f.get("host_call"), "config5": f.get("config5"),
+    }
+    if value_note:
+        line["value_note"] = value_note
     if world > 1:
-        dist.destroy_process_group()
+        compute_ms = f.get("compute_ms_max")
+        mg = {
+            "compute_ms_per_step_max_rank": round(compute_ms, 4) if compute_ms else None,
+            "gather_exposed_ms_per_step": round(max(ms_per_step - compute_ms, 0.0), 4)
+            if (compute_ms and ms_per_step and "elapsed" in f) else None,
+            "per_rank_compute_only_ms_per_step": per_rank_compute,
+            "per_rank_band_pairs": per_rank_pairs,
+            "gathered_bytes_per_step": f.get("gathered_bytes"),
+            "band_shares": f.get("band_shares"),
+            "bands": band_note + "; the root's band needs no transfer, so equal bands are not the "
+                                 "fastest cut (engine.ShardedQuery.rebalance)",
+            "host_call": f.get("multi_host_call"),
+            "note": "value includes the p2p gather of every peer's distance block into the "
+                    "PopPUNK-ordered matrix on rank 0 (pipelined under compute in %d chunks); "
+                    "the root's inbound xGMI links bound it.  per_rank_compute_only_ms_per_step: each "
+                    "rank's band without any collective (HIP events), measured before the gathered steps.  "
+                    "host_call: ONE process driving all N GPUs through ppk_query_dbs (a worker thread per "
+                    "device, each GPU's share over its own PCIe link into one pageable host array) -- the "
+                    "multi-GPU route of a single-process PopPUNK.  config5 is the shape that scales: "
+                    "only edge lists move" % args.chunks}
+        if rep.errors:
+            mg["error"] = "; ".join(rep.errors)
+        line["multi_gpu"] = mg
+    elif rep.errors:
+        line["error"] = "; ".join(rep.errors)
+    if f.get("cpu") and value:
+        line["speedup_vs_cpu"] = value / f["cpu"]["value"]
+    return line
+
+
+class _FakeDB:
+    """bench self-test (PPK_BENCH_FAKE=1, no GPU): stands in for engine.SketchDB in ShardedQuery."""
+    def __init__(self, n):
+        self.n, self.nk, self.device = n, 5, 0
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+        relaunch_under_torchrun(args)        # does not return
+    fake = bool(os.environ.get("PPK_BENCH_FAKE"))      # self-test of this script's control flow on CPU (tests/)
+    # a stuck or failed collective must surface as a Python exception, not take the process down
+    # (2 = CleanUpOnly: communicators are aborted, the process lives); the per-phase watchdog is the backstop
+    os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "2")
+    import datetime
+    import torch
+    import torch.distributed as dist
+    from poppunk_amd import engine, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("PPK_BENCH_ONE_GPU"):      # debugging aid: every rank on GPU 0
+        local_rank = 0
+    if world != args.gpus:
+        sys.exit("bench.py --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not fake and not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (there is no CPU path)")
+    rep = Report(rank, world, args)
+    if world > 1:
+        rep.per_rank_dir = os.path.join("/tmp", "ppk_bench_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid()))
+        os.makedirs(rep.per_rank_dir, exist_ok=True)
+    try:
+        run(args, rep, rank, local_rank, world, fake, torch, dist, engine, synth, datetime)
+    except BaseException as e:                   # whatever it was: the line still goes out
+        if isinstance(e, SystemExit):
+            raise
+        rep.error(rep.phase, e)
+    rep.finish()
+    rep.emit()
+    if world > 1:
+        try:
+            if dist.is_initialized():
+                dist.destroy_process_group()
+        except Exception:
+            pass
+        if rep.errors:
+            sys.stdout.flush()
+            os._exit(0 if rank == 0 else 1)      # do not hang in atexit handlers of a broken process group
+
+
+def run(args, rep, rank, local_rank, world, fake, torch, dist, engine, synth, datetime):
+    f = rep.fields
+    dev = torch.device("cpu") if fake else torch.device("cuda", local_rank)
+    if not fake:
+        torch.cuda.set_device(local_rank)
+    backend = "gloo" if fake else os.environ.get("PPK_BENCH_BACKEND", "nccl")   # "gloo": debugging aid with PPK_BENCH_ONE_GPU
+    pg_ok = world == 1
+    rep.enter("init_process_group")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        try:
+            timeout = datetime.timedelta(seconds=args.collective_timeout)
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=timeout)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world, timeout=timeout)
+            pg_ok = True
+        except Exception as e:
+            rep.error("init_process_group", e)
+    inject = os.environ.get("PPK_BENCH_INJECT", "")          # self-test: make a collective fail
+    if inject.startswith("isend"):
+        after = int(inject.split(":")[1]) if ":" in inject else 0
+        real, calls = dist.batch_isend_irecv, [0]
+
+        def failing(ops):
+            calls[0] += 1
+            if calls[0] > after:
+                raise RuntimeError("injected failure of batch_isend_irecv (PPK_BENCH_INJECT)")
+            return real(ops)
+        dist.batch_isend_irecv = failing
+    elif inject.startswith("hang") and rank == world - 1:      # self-test: the last rank stops answering
+        after = int(inject.split(":")[1]) if ":" in inject else 0
+        real, calls = dist.batch_isend_irecv, [0]
+
+        def hanging(ops):
+            calls[0] += 1
+            if calls[0] > after:
+                time.sleep(3600)
+            return real(ops)
+        dist.batch_isend_irecv = hanging
+
+    rep.enter("setup")
+    n = int(round(args.n * world ** 0.5)) if (args.weak and world > 1) else args.n
+    kmers = np.asarray(synth.DEFAULT_KMERS, dtype=np.int32)
+    tbl = synth.random_match_table(kmers)
+    f["n"] = n
+    if fake:
+        f["data"] = "FAKE (bench.py self-test on CPU: no kernels ran, the numbers mean nothing)"
+        lib, sk = None, None
+        ref = _FakeDB(n)
+
+        def band_fn(qb, qe, view):
+            time.sleep(0.002)
+            view.fill_(float(rank))
+    else:
+        from poppunk_amd import _lib
+        lib = _lib.lib()
+        sk, _ = synth.make_sketches(n, kmers, sketchsize64=16, bbits=14)
+        ref = engine.SketchDB(sk, 16, 14, device=local_rank)
+        band_fn = None
+
+    job = engine.ShardedQuery(ref, None, rank, world, n_chunks=args.chunks if world > 1 else 1,
+                              device="cpu" if fake else None)
+    f["total_pairs"] = int(job.total_rows)
+
+    def step():
+        job.run(kmers, tbl, band_fn=band_fn)
+
+    def sync():
+        if not fake:
+            torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        sync()
+
+    def reduce_max(vals):
+        if world == 1:
+            return vals
+        t = torch.tensor(vals, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(x) for x in t.tolist()]
+
+    def prof_on():
+        if lib is not None:
+            lib.ppk_prof_enable(1)
+            lib.ppk_prof_read(None, None, 1)
+
+    def prof_off():
+        if lib is None:
+            return 0.0, 0
+        lib.ppk_prof_enable(0)
+        kms, kn = C.c_double(0), C.c_longlong(0)
+        lib.ppk_prof_read(C.byref(kms), C.byref(kn), 1)
+        return kms.value, kn.value
+
+    # ---- compute only: this rank's band, no collective anywhere (HIP events inside the library) --------------
+    # N > 1: measured first and handed to rank 0 through a file, so that it is on the line whatever the
+    # process group does afterwards.
+    rep.enter("compute_only")
+    if world > 1:
+        qb, qe = job.bounds[rank], job.bounds[rank + 1]
+        band_pairs = int(job.band_rows[rank])
+        if fake:
+            local = torch.empty((max(band_pairs, 1), 2), dtype=torch.float32)
+            t0 = time.perf_counter()
+            for _ in range(max(args.steps, 1)):
+                band_fn(qb, qe, local)
+            c_ms = (time.perf_counter() - t0) / max(args.steps, 1) * 1e3
+        else:
+            local = torch.empty((max(band_pairs, 1), 2), dtype=torch.float32, device=dev)
+            t_spin = time.perf_counter()
+            while time.perf_counter() - t_spin < args.spinup_ms * 1e-3:
+                engine.dist(ref, None, kmers, tbl, q_begin=qb, q_end=qe, out=local[:band_pairs])
+                sync()
+            prof_on()
+            for _ in range(max(args.steps, 1)):
+                engine.dist(ref, None, kmers, tbl, q_begin=qb, q_end=qe, out=local[:band_pairs])
+            sync()
+            kms, kn = prof_off()
+            c_ms = kms / max(args.steps, 1)
+        del local
+        rep.publish_rank({"rank": rank, "compute_ms_per_step": round(c_ms, 4), "band_pairs": band_pairs,
+                          "device": local_rank})
+
+    # Device spin-up (setup, not part of the W warm-up steps): after an idle period the GPU clock
+    # takes ~50 ms of load to ramp and the first launches run 20-30 % slow; a driver that asks for a
+    # short --warmup would otherwise time the governor instead of the kernel.
+    band_note = "1 GPU"
+    if world == 1:
+        rep.enter("spinup")
+        t_spin = time.perf_counter()
+        while time.perf_counter() - t_spin < args.spinup_ms * 1e-3:
+            step()
+            sync()
+    elif not pg_ok:
+        raise RuntimeError("no process group: the gathered steps cannot run")
+    else:
+        rep.enter("spinup")
+        if args.spinup_ms > 0:
+            n_spin = 30 if backend == "nccl" else 1
+            for _ in range(n_spin):      # every rank must run the SAME number of gathered steps
+                step()
+            sync()
+        # Set-up, like choosing the band edges at all: with equal bands a step lasts as long as the
+        # slowest peer -> root transfer (a GPU produces 8 B per pair faster than its one xGMI link to
+        # the root carries them) while the root's own band needs none.  Three measured steps re-cut
+        # the bands in proportion to each rank's measured rate (engine.ShardedQuery.rebalance).
+        band_note = "equal (--even-bands)"
+        if not args.even_bands:
+            rep.enter("rebalance")
+            try:
+                def probe(n_steps=3):
+                    """ms per gathered step, max over ranks (the same number on every rank)."""
+                    barrier()
+                    t_p = time.perf_counter()
+                    for _ in range(n_steps):
+                        step()
+                    barrier()
+                    return reduce_max([(time.perf_counter() - t_p) / n_steps * 1e3])[0]
+                ms_even = probe()
+                for _ in range(3):
+                    job.rebalance(kmers, tbl, band_fn=band_fn)
+                ms_balanced = probe()
+                band_note = "rate-balanced (%.2f ms/step against %.2f with equal bands, set-up probe)" % (ms_balanced, ms_even)
+                if ms_balanced > 1.02 * ms_even:      # never keep a cut that measures worse than the equal one
+                    job._layout(engine.shard_bounds(ref.n, 0, world))
+                    band_note = "equal (the rate-balanced cut measured %.2f ms/step against %.2f)" % (ms_balanced, ms_even)
+            except Exception as e:
+                # a failure here is deterministic across ranks only when it is ours (not a lost peer): try the
+                # equal cut; if the group itself is broken the timed loop fails next and says so
+                rep.error("rebalance", e)
+                job._layout(engine.shard_bounds(ref.n, 0, world))
+                band_note = "equal (rebalance failed)"
+    f["band_note"] = band_note
+    rep.enter("warmup")
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    rep.enter("timed_steps")
+    prof_on()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kms, kn = prof_off()
+    f["kernel_ms"] = kms / max(kn, 1)
+    f["kernel_name"] = lib.ppk_last_kernel_name().decode() if lib is not None else "none (fake)"
+    f["per_launch"] = job.band_rows[0] / job.n_chunks          # pairs one launch of the dominant kernel covers
+    compute_ms = kms / args.steps          # kernel time per step on this rank (HIP events)
+    elapsed, compute_ms = reduce_max([elapsed, compute_ms])
+    f["elapsed"], f["compute_ms_max"] = elapsed, compute_ms
+    f["band_shares"] = [round(b / max(job.total_rows, 1), 4) for b in job.band_rows]
+    f["gathered_bytes"] = int(sum(job.band_rows[1:])) * 8
+
+    if fake:
+        return
+    # ---- the call PopPUNK makes, PCIe both ways.  N = 1: one device.  N > 1: rank 0 alone drives all N GPUs
+    # in-process (ppk_query_dbs, a worker thread per device) while the other ranks wait at the barrier.
+    if not args.no_host_call:
+        rep.enter("host_call")
+        try:
+            if world == 1:
+                f["host_call"] = host_call(sk, kmers, tbl, [local_rank])
+            else:
+                if rank == 0:
+                    if torch.cuda.device_count() >= world:
+                        f["multi_host_call"] = host_call(sk, kmers, tbl, list(range(world)))
+                        f["multi_host_call"]["one_device"] = host_call(sk, kmers, tbl, [local_rank], reps=3)
+                    else:
+                        f["multi_host_call"] = {"skipped": "rank 0 sees %d of %d GPUs" % (torch.cuda.device_count(), world)}
+                barrier()
+        except Exception as e:
+            rep.error("host_call", e)
+
+    if not args.no_config5:
+        rep.enter("config5")
+        try:
+            ref.close()
+            job.out = None
+            torch.cuda.empty_cache()
+            f["config5"] = config5(args, rank, world, local_rank, dev, barrier)
+        except Exception as e:
+            rep.error("config5", e)
+    if rank == 0 and not args.no_cpu and world == 1:
+        rep.enter("cpu_baseline")
+        rep._timer and rep._timer.cancel()       # bounded by --cpu-seconds itself
+        f["cpu"] = cpu_baseline(sk, kmers, tbl, args.cpu_seconds)
 
 
 if __name__ == "__main__":

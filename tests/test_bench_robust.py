@@ -1,0 +1,78 @@
+"""bench.py --gpus N must print exactly ONE parsable JSON line whatever the process group does
+(the 8-GPU scaling run is the driver's, never the builder's: a traceback there wastes it).
+
+The script's control flow runs here on CPU (PPK_BENCH_FAKE=1: gloo, a stand-in for the kernels, the
+line says so in `data`), two ranks under torch.distributed.run, with a collective made to fail
+(PPK_BENCH_INJECT=isend:<after n calls>) or a rank made to stop answering (hang:<n>).
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(inject, extra=()):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, PPK_BENCH_FAKE="1", MASTER_ADDR="127.0.0.1")
+    env.pop("PPK_BENCH_INJECT", None)
+    if inject:
+        env["PPK_BENCH_INJECT"] = inject
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "3", "--warmup", "1", "--genomes", "1500", "--no-cpu",
+           "--collective-timeout", "8", "--watchdog-s", "25"] + list(extra)
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=180, cwd=ROOT)
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, (p.stdout.decode()[-2000:], p.stderr.decode()[-2000:])
+    return json.loads(lines[0])
+
+
+def _check_common(d):
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["unit"] == "pairs/s"
+    assert "FAKE" in d["data"]
+    mg = d["multi_gpu"]
+    per = mg["per_rank_compute_only_ms_per_step"]
+    assert len(per) == 2 and all(x is not None and x > 0 for x in per)
+    assert sum(mg["per_rank_band_pairs"]) == d["config"]["pairs"] == 1500 * 1499 // 2
+    return mg
+
+
+def test_clean_run_prints_the_gathered_value():
+    d = _run(None)
+    mg = _check_common(d)
+    assert "error" not in mg and "value_note" not in d
+    assert d["value"] > 0 and d["ms_per_step"] > 0
+    assert abs(sum(mg["band_shares"]) - 1.0) < 1e-3
+
+
+@pytest.mark.parametrize("inject", ["isend:0", "isend:7", "isend:30"])
+def test_failing_send_recv_still_yields_one_line_with_per_rank_compute(inject):
+    """The first gathered step, the rebalance probe or the timed loop loses batch_isend_irecv: the line
+    carries multi_gpu.error, every rank's compute-only ms per step (measured before any collective,
+    handed over through files) and a value that says it excludes the gather."""
+    d = _run(inject)
+    mg = _check_common(d)
+    assert "injected failure" in mg["error"]
+    assert d["value"] > 0 and "EXCLUDES the gather" in d["value_note"]
+    assert d["ms_per_step"] == max(mg["per_rank_compute_only_ms_per_step"])
+
+
+def test_a_rank_that_stops_answering_ends_in_a_line_not_a_hang():
+    d = _run("hang:5")
+    mg = _check_common(d)
+    assert mg["error"]
+    assert d["value"] > 0
+
+
+def test_even_bands_flag_skips_the_rebalance():
+    d = _run(None, ["--even-bands"])
+    mg = _check_common(d)
+    assert mg["bands"].startswith("equal (--even-bands)") and "error" not in mg

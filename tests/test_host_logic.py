@@ -298,3 +298,33 @@ def test_fitKmerCurve_mirror_against_the_reference_goldens(golden_dir):
         n_active += not c["interior"]
     assert n_active >= 5
     assert list(sketchlib.fitKmerCurve(np.asarray([0.5, 0.0]), np.asarray([13, 17]))) == [0, 0]
+
+
+def test_sub_sample_requery_is_sliced_from_the_loaded_database(tmp_path, monkeypatch):
+    """The --plot-fit leg re-queries single samples of the database it has just queried
+    (PopPUNK/sketchlib.py:547-564).  Those requests are sliced from the loaded full database: the file
+    is not read again and the full database (with its resident copies) is not pushed out of the
+    four-entry cache (round-2 advisor finding)."""
+    prefix, names, sk = make_db(tmp_path, "full", 12)
+    db = prefix + "/full"
+    pp_sketchlib._DB_CACHE.clear()
+    loads = []
+    real = sketchdb.load
+    monkeypatch.setattr(sketchdb, "load", lambda *a, **k: (loads.append(a[1]), real(*a, **k))[1])
+    full = pp_sketchlib._load_cached(db, names, [13, 17, 21])
+    assert len(loads) == 1 and not full.transient and len(pp_sketchlib._DB_CACHE) == 1
+    for pick in ([names[3]], [names[7]], [names[11], names[0]], [names[5]], [names[6]], [names[2]]):
+        e = pp_sketchlib._load_cached(db, pick, [13, 17, 21])
+        assert e.transient and e.loaded.names == pick
+        rows = [names.index(p) for p in pick]
+        assert np.array_equal(e.loaded.sketches, sk[rows]) and e.loaded.sketches.flags["C_CONTIGUOUS"]
+        assert e.loaded.random_table is full.loaded.random_table
+        assert np.array_equal(e.loaded.clusters, full.loaded.clusters[rows])
+    assert len(loads) == 1 and list(pp_sketchlib._DB_CACHE.values()) == [full]
+    assert pp_sketchlib._load_cached(db, names, [13, 17, 21]) is full
+    # another k list is another load; a name the database lacks still fails in the loader
+    other = pp_sketchlib._load_cached(db, names, [13, 21])
+    assert len(loads) == 2 and other is not full and other.loaded.sketches.shape[1] == 2
+    with pytest.raises(RuntimeError, match="not found"):
+        pp_sketchlib._load_cached(db, ["nobody"], [13, 17, 21])
+    pp_sketchlib._DB_CACHE.clear()
