@@ -381,11 +381,7 @@ __device__ __forceinline__ void ef_gather(const PackT (&pk)[NR], const double *_
     for (int r = 0; r < NR; ++r) {
       const uint32_t c = pack_get(pk[r], k, p.cnt_bits, cmask, p.nk);
       const uint32_t boff = (loff[r] + (uint32_t)k * kstride + c) * 16u;
-#ifdef PPK_EXP_NO_GATHER      // experiment: the epilogue's VALU work without its table gathers
-      ef[r][k] = f64x2{1.0 + (double)boff * 1e-12, 1.0};
-#else
       ef[r][k] = *reinterpret_cast<const f64x2 *>(base + boff);
-#endif
     }
   }
 }

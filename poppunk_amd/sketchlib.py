@@ -18,6 +18,7 @@ from random import sample
 import numpy as np
 
 from . import pp_sketchlib
+from .utils import iterDistRows, stderr_redirected  # noqa: F401  (PopPUNK/utils.py:61-83,:199-226)
 from .sketchdb import getSeqsInDb, readDBParams  # noqa: F401  (PopPUNK/sketchlib.py:170-214)
 
 
@@ -123,13 +124,14 @@ def queryDatabase(rNames, qNames, dbPrefix, queryPrefix, klist, self=True, numbe
             query_examples = sample(list(qNames), k=number_plot_fits)
         for plot_idx in range(number_plot_fits):
             jac = []
-            for correct in (False, True):
-                jac.append(pp_sketchlib.queryDatabase(ref_db_name=ref_db, query_db_name=q_db,
-                                                      rList=[ref_examples[plot_idx]],
-                                                      qList=[query_examples[plot_idx]], klist=klist,
-                                                      random_correct=correct, jaccard=True,
-                                                      num_threads=threads, use_gpu=use_gpu,
-                                                      device_id=deviceid)[0])
+            with stderr_redirected():      # hide the re-queries' progress output (PopPUNK/sketchlib.py:546)
+                for correct in (False, True):
+                    jac.append(pp_sketchlib.queryDatabase(ref_db_name=ref_db, query_db_name=q_db,
+                                                          rList=[ref_examples[plot_idx]],
+                                                          qList=[query_examples[plot_idx]], klist=klist,
+                                                          random_correct=correct, jaccard=True,
+                                                          num_threads=threads, use_gpu=use_gpu,
+                                                          device_id=deviceid)[0])
             raw, corrected = jac
             out_prefix = (ref_db if self else os.path.join(os.path.dirname(queryPrefix), os.path.basename(queryPrefix))) \
                 + "_fit_example_" + str(plot_idx + 1)
@@ -137,17 +139,3 @@ def queryDatabase(rNames, qNames, dbPrefix, queryPrefix, klist, self=True, numbe
                                out_prefix, "Example fit " + str(plot_idx + 1) + " - " + ref_examples[plot_idx] +
                                " vs. " + query_examples[plot_idx])
     return distMat
-
-
-def iterDistRows(refSeqs, querySeqs, self=True):
-    """Row -> (ref, query) names of the distance matrix (PopPUNK/utils.py:199-226)."""
-    if self:
-        if refSeqs != querySeqs:
-            raise RuntimeError('refSeqs must equal querySeqs for db building (self = true)')
-        for i, ref in enumerate(refSeqs):
-            for j in range(i + 1, len(refSeqs)):
-                yield (refSeqs[j], ref)
-    else:
-        for query in querySeqs:
-            for ref in refSeqs:
-                yield (ref, query)

@@ -3,6 +3,7 @@ behaviour of sketchlib.queryDatabase (PopPUNK/sketchlib.py:475-632), the noconve
 poppunk_refine (src/python_bindings.cpp:82,:89), the sketch database files and the synthetic
 generator.  No GPU compute is triggered here."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -328,3 +329,25 @@ def test_sub_sample_requery_is_sliced_from_the_loaded_database(tmp_path, monkeyp
     with pytest.raises(RuntimeError, match="not found"):
         pp_sketchlib._load_cached(db, ["nobody"], [13, 17, 21])
     pp_sketchlib._DB_CACHE.clear()
+
+
+def test_stderr_redirected_is_fd_level(tmp_path, capfd):
+    """PopPUNK wraps the --plot-fit re-queries in an fd-level redirect (PopPUNK/utils.py:61-83,
+    PopPUNK/sketchlib.py:546): native write(2, ...) output is silenced too, and fd 2 works again after."""
+    from poppunk_amd.utils import stderr_redirected
+    log = str(tmp_path / "err.txt")
+    os.write(2, b"before\n")
+    with stderr_redirected(to=log):
+        os.write(2, b"native meter\n")
+        sys.stderr.write("python side\n")
+        sys.stderr.flush()
+    os.write(2, b"after\n")
+    err = capfd.readouterr().err
+    assert "before" in err and "after" in err and "native" not in err and "python side" not in err
+    got = open(log).read()
+    assert "native meter" in got and "python side" in got
+    with pytest.raises(ValueError):
+        with stderr_redirected():
+            raise ValueError("restored on exceptions too")
+    os.write(2, b"still there\n")
+    assert "still there" in capfd.readouterr().err

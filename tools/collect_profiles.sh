@@ -1,8 +1,8 @@
 #!/bin/bash
 # Regenerates every measured artefact under gpurun_out/$ROUND (run through gpurun from the repo root):
-#   ROUND=r02 tools/collect_profiles.sh     then `ROUND=r02 python tools/update_profiles.py` copies into profiles/
+#   ROUND=r03 tools/collect_profiles.sh     then `ROUND=r03 python tools/update_profiles.py` copies into profiles/
 set -u
-ROUND=${ROUND:-r02}
+ROUND=${ROUND:-r03}
 OUT=gpurun_out/$ROUND
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:-/root/repo}"

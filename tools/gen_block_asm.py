@@ -259,6 +259,9 @@ def main():
         write_macro(f, "PPK_BLOCK_HALF_ASM_Q32", gen(256, 4, half=True))
         f.write("#define PPK_BLOCK_ASM PPK_BLOCK_ASM_Q32\n")
         f.write("#define PPK_BLOCK_CLOBBERS %s\n" % clob)
+    if "--experiments" not in sys.argv[1:]:
+        return
+    # measured-and-rejected shapes: generated on demand, not tracked (tools/ubench_pipe.hip needs them)
     with open(dst_x, "w") as f:
         f.write("// GENERATED by tools/gen_block_asm.py -- do not edit.  Measured-and-rejected shapes, used by\n"
                 "// tools/ubench_pipe.hip only (not part of libppk_hip.so): _Q64 = 64 queries per workgroup tile\n"

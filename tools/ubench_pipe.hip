@@ -1,6 +1,7 @@
 // Pipeline microbenchmark: the compare loop of dist_kernel_v2 WITH its LDS-DMA double buffering
 // and s_barrier per 64-bin block, but no epilogue, for different register tiles / workgroup
 // shapes.  10240 x 10240 samples, 5 k x 16 blocks, [k][word][sample] layout as in the product.
+//   python tools/gen_block_asm.py --experiments   (writes tools/ppk_block_asm_experiments.inc: the rejected shapes, not tracked)
 //   hipcc --offload-arch=gfx950 -O3 -o tools/ubench_pipe.out tools/ubench_pipe.hip -Lpoppunk_amd/csrc -lppk_hip -Wl,-rpath,'$ORIGIN/../poppunk_amd/csrc'
 #include <hip/hip_runtime.h>
 #include <cstdint>
