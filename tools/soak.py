@@ -13,11 +13,12 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402,F401
 
-from oracle import oracle  # noqa: E402
-from poppunk_amd import _lib, engine, pp_sketchlib, synth  # noqa: E402
+from soak_case import reset_options, soak_case  # noqa: E402  (tests/soak_case.py: the case itself)
 
 
 def main():
@@ -27,107 +28,11 @@ def main():
     bad = 0
     t_start = time.time()
     for case in range(n_cases):
-        bbits = int(rng.choice([14, 14, 14, 8, 16]))
-        s64 = int(rng.choice([1, 2, 3, 16, 16, 16, 5, 40]))
-        nk = int(rng.integers(2, 12))      # count registers of 2, 3 and 4 dwords
-        k0 = int(rng.integers(9, 16))
-        kmers = (k0 + np.arange(nk) * int(rng.integers(1, 5))).astype(np.int32)
-        n = int(rng.integers(2, 1400 if s64 <= 16 else 500))
-        if os.environ.get("SOAK_BIG"):        # many ref tiles: the default-shape kernel at scale
-            bbits, s64 = 14, 16
-            n = int(rng.integers(2000, 7000))
-        related = bool(rng.integers(0, 4))
-        # half of the cases force the tile kernel's own epilogue (small jobs default to the k-split path)
-        if rng.integers(0, 2):
-            _lib.set_option("ksplit", 0)
-        else:
-            _lib.set_option("ksplit", 640)
-        ext = (int(rng.integers(0, 2)), int(rng.integers(0, 2))) if rng.integers(0, 3) == 0 else (0, 0)
-        _lib.set_option("ext_collision_adjust", ext[0])
-        _lib.set_option("ext_fit_skip", ext[1])
-        oracle.set_ext(ext[0], ext[1])
-        sk, member = synth.make_sketches(n, kmers, sketchsize64=s64, bbits=bbits,
-                                         cluster_size=int(rng.integers(5, 80)), seed=int(rng.integers(1, 1 << 30)),
-                                         related=related)
-        n_clu = int(rng.choice([1, 1, 2, 3]))
-        tbl = (rng.random((nk, n_clu, n_clu)) * 0.05).astype(np.float32)
-        clu = (rng.integers(0, n_clu, size=n)).astype(np.uint16)
-        if rng.integers(0, 2):
-            clu = np.sort(clu)          # contiguous runs: whole tiles with one cluster pair (the LDS-table epilogue)
-        use_tbl = bool(rng.integers(0, 4))
-        nr = int(rng.integers(1, n)) if n > 2 and rng.integers(0, 2) else n
-        ref, qry = sk[:nr], (sk[nr:] if nr < n else None)
-        rclu, qclu = clu[:nr], (clu[nr:] if nr < n else None)
-        kw = dict(random_table=tbl if use_tbl else None, ref_clusters=rclu if use_tbl else None,
-                  qry_clusters=qclu if (use_tbl and qry is not None) else None, random_correct=use_tbl)
-        okw = dict(random_tbl=tbl if use_tbl else None, ref_clu=rclu if use_tbl else None,
-                   qry_clu=qclu if (use_tbl and qry is not None) else None, random_correct=use_tbl, threads=8)
-        msgs = []
-        try:
-            c, _ = pp_sketchlib.query_arrays(ref, qry, kmers, s64, bbits, counts=True)
-            if not np.array_equal(c, oracle.match_counts(ref, qry, s64, bbits, threads=8)):
-                msgs.append("counts differ")
-            got, gf = pp_sketchlib.query_arrays(ref, qry, kmers, s64, bbits, **kw)
-            want, wf = oracle.query(ref, qry, kmers, s64, bbits, **okw)
-            err = float(np.abs(got - want).max(initial=0))
-            if gf != wf or not err <= 1e-6:
-                msgs.append("dist: failed %d vs %d, max err %.3g" % (gf, wf, err))
-            gj, _ = pp_sketchlib.query_arrays(ref, qry, kmers, s64, bbits, jaccard=True, **kw)
-            wj, _ = oracle.query(ref, qry, kmers, s64, bbits, jaccard=True, **okw)
-            if not np.abs(gj - wj).max(initial=0) <= 1e-6:
-                msgs.append("jaccard differs")
-            # bands + fused edges on the resident path
-            db = engine.SketchDB(ref, s64, bbits, clusters=rclu if use_tbl else None)
-            dbq = engine.SketchDB(qry, s64, bbits, clusters=qclu if use_tbl else None) if qry is not None else None
-            nq = qry.shape[0] if qry is not None else nr
-            cuts = sorted(set([0, nq] + [int(x) for x in rng.integers(0, nq + 1, size=3)]))
-            t_tbl = tbl if use_tbl else None
-            parts = [engine.dist(db, dbq, kmers, t_tbl, random_correct=use_tbl, q_begin=a, q_end=b)[0]
-                     for a, b in zip(cuts[:-1], cuts[1:])]
-            whole = torch.cat(parts).cpu().numpy() if parts else np.zeros((0, 2), np.float32)
-            if not np.abs(whole - want).max(initial=0) <= 1e-6:
-                msgs.append("bands differ")
-            if want.shape[0]:
-                slope = int(rng.integers(0, 3))
-                x_max, y_max = synth.boundary_for_quantile(got, float(rng.uniform(0.05, 0.7)))
-                inclusive = bool(rng.integers(0, 2))
-                scale = (float(rng.uniform(0.5, 2.0)), float(rng.uniform(0.5, 2.0)))
-                scaled = (got / np.asarray(scale, dtype=np.float32)).astype(np.float32)
-                we = oracle.edge_threshold(scaled, slope, x_max, y_max, n_ref=0 if qry is None else nr,
-                                           inclusive=inclusive)
-                # counts wider than 128 bits per pair: only the whole matrix has an edge list (documented
-                # limit of the fused path: a band is refused)
-                cnt_bits = int(64 * s64).bit_length()
-                ecuts = cuts if nk * cnt_bits <= 128 else [0, nq]
-                fe = [engine.dist_edges(db, dbq, kmers, t_tbl, random_correct=use_tbl, slope=slope, x_max=x_max,
-                                        y_max=y_max, scale=scale, inclusive=inclusive, q_begin=a, q_end=b, cap=16)[0]
-                      for a, b in zip(ecuts[:-1], ecuts[1:])]
-                fe = torch.cat(fe).cpu().numpy()
-                if not np.array_equal(fe, np.asarray(we).reshape(-1, 2)):
-                    msgs.append("fused edges differ (%d vs %d)" % (len(fe), len(we)))
-            # neighbours straight from the tiles == get_kNN_distances(longToSquare(.)) of the same distances
-            cnt_bits_k = int(64 * s64).bit_length()
-            if qry is None and bbits == 14 and nk * cnt_bits_k <= 128 and nr > 1:
-                knn = int(rng.integers(1, 33))
-                col = int(rng.integers(0, 2))
-                gi, gj, gd = engine.knn_from_sketches(db, kmers, t_tbl, knn, dist_col=col, random_correct=use_tbl,
-                                                      method="tiles")
-                wi, wj, wd = oracle.knn(oracle.long_to_square(got[:, col]), knn)
-                if not (np.array_equal(gi.cpu().numpy(), wi) and np.array_equal(gj.cpu().numpy(), wj)
-                        and np.array_equal(gd.cpu().numpy(), wd)):
-                    msgs.append("kNN from tiles differs (k=%d col=%d)" % (knn, col))
-            db.close()
-            if dbq is not None:
-                dbq.close()
-        except Exception as e:  # noqa: BLE001
-            msgs.append("EXCEPTION %r" % (e,))
+        desc, msgs = soak_case(rng, big=bool(os.environ.get("SOAK_BIG")))
         status = "ok" if not msgs else "MISMATCH: " + "; ".join(msgs)
         bad += bool(msgs)
-        print("case %3d bbits=%2d s64=%2d nk=%d n=%4d nr=%4d clu=%d tbl=%d related=%d ext=%d%d  %s"
-              % (case, bbits, s64, nk, n, nr, n_clu, use_tbl, related, ext[0], ext[1], status), flush=True)
-    _lib.set_option("ext_collision_adjust", 0)
-    _lib.set_option("ext_fit_skip", 0)
-    oracle.set_ext(0, 0)
+        print("case %3d %s  %s" % (case, desc, status), flush=True)
+    reset_options()
     print("%d cases, %d mismatches, %.0f s" % (n_cases, bad, time.time() - t_start))
     sys.exit(1 if bad else 0)
 
