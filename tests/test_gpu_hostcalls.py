@@ -210,3 +210,24 @@ def test_queryDatabase_holds_handles_and_splits_over_PPK_DEVICES(tmp_path, monke
     assert np.abs(got2 - oracle.query(sk2, None, KMERS, 16, 14, tbl, threads=4)[0]).max() <= TOL
     pp_sketchlib.clear_cache()
     assert not pp_sketchlib._DB_CACHE
+
+
+def test_pin_kit_runs_its_own_half_without_upstream(tmp_path):
+    """tools/pin_upstream.py settles DESIGN.md section 5's [EXT] rows wherever upstream pp-sketchlib is
+    installed.  Here it is not: the script must say so, still write its databases and run this
+    package's half of every comparison, and exit 2 ("nothing pinned")."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        import pp_sketchlib as upstream  # noqa: F401
+        pytest.skip("upstream pp-sketchlib is importable here: run tools/pin_upstream.py itself")
+    except ImportError:
+        pass
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "pin_upstream.py"), "--ours-only", "--out",
+                        str(tmp_path), "--keep"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 2, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "NOTHING PINNED" in r.stdout and "our half ran" in r.stdout
+    for tag in ("s1024", "s19200", "s1024q", "gap"):
+        assert os.path.exists(str(tmp_path / (tag + ".h5")))
+    assert "our two readings differ on 6 of 66 rows" in r.stdout      # the gap pairs tell truncate from skip
