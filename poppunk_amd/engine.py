@@ -151,12 +151,14 @@ def _check_pair(ref, qry):
 
 
 def dist(ref, qry=None, kmers=None, random_tbl=None, random_correct=True, jaccard=False,
-         counts=False, q_begin=0, q_end=None, out=None):
+         counts=False, q_begin=0, q_end=None, out=None, n_failed=None):
     """Enqueue kernel 1 for query rows [q_begin, q_end) on the current stream.
 
     Returns (out, n_failed): out is a CUDA tensor float32 [rows,2] (core, accessory),
     float32 [rows,nk] (jaccard) or int32 [rows,nk] (counts); n_failed a 1-element
-    int64 CUDA tensor (pairs with < 2 usable k-mer lengths).
+    int64 CUDA tensor (pairs with < 2 usable k-mer lengths).  A caller-provided `n_failed`
+    is ADDED to (a job that launches band after band keeps one counter instead of paying a
+    fill kernel per launch).
     """
     torch = _torch()
     lib = _lib.lib()
@@ -175,7 +177,8 @@ def dist(ref, qry=None, kmers=None, random_tbl=None, random_correct=True, jaccar
                               device=dev)
         elif out.numel() != rows * cols or not out.is_contiguous() or out.element_size() != 4:
             raise ValueError("out has the wrong size")
-        n_failed = torch.zeros(1, dtype=torch.int64, device=dev)
+        if n_failed is None:
+            n_failed = torch.zeros(1, dtype=torch.int64, device=dev)
         rc = lib.ppk_dist_dev(ref._h, qry._h if qry is not None else None,
                               kmers.ctypes.data_as(C.POINTER(C.c_int32)), tbl_ptr, n_clu, flags,
                               q_begin, q_end, C.c_void_p(out.data_ptr()),
@@ -613,6 +616,7 @@ class ShardedQuery:
         self.dtype = dtype or torch.float32
         self.device = device if device is not None else "cuda:%d" % ref.device
         self.out = None
+        self.n_failed = None
         self.weights = [1.0] * world_size if weights is None else [float(x) for x in weights]
         self._layout(shard_bounds(ref.n, self.n_qry, world_size) if weights is None
                      else band_split_weighted(ref.n, self.n_qry, self.weights))
@@ -666,8 +670,10 @@ class ShardedQuery:
                 if band_fn is not None:
                     band_fn(qb, qe, view)
                 else:
+                    if self.n_failed is None:      # failed fits of every step so far, this rank's bands
+                        self.n_failed = torch.zeros(1, dtype=torch.int64, device=self.device)
                     dist(self.ref, self.qry, kmers, random_tbl, random_correct=random_correct,
-                         q_begin=qb, q_end=qe, out=view)
+                         q_begin=qb, q_end=qe, out=view, n_failed=self.n_failed)
                 if timing and not on_gpu:
                     self._compute_s += time.perf_counter() - t_c
             if self.world == 1:

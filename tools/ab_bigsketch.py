@@ -15,7 +15,7 @@ def kms(fn, reps=5):
     torch.cuda.synchronize(); lib.ppk_prof_enable(0)
     ms, n = C.c_double(0), C.c_longlong(0); lib.ppk_prof_read(C.byref(ms), C.byref(n), 1)
     return ms.value / max(n.value, 1)
-for kmers in ([13, 17, 21, 25, 29], [13, 16, 19, 22, 25, 28], [13, 17, 21, 25]):
+for kmers in ([13, 17, 21, 25, 29], [13, 16, 19, 22, 25, 28], [13, 17, 21, 25])[:1 if os.environ.get('ONLY5') else 3]:
     K = np.asarray(kmers, dtype=np.int32); T = synth.random_match_table(K)
     n = int(os.environ.get('N', '4000'))
     sk, _ = synth.make_sketches(n, K, sketchsize64=156, bbits=14, cluster_size=50)
