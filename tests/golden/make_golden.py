@@ -59,6 +59,19 @@ def golden_fit():
     ns = {"np": np, "optimize": optimize, "sys": sys}
     extract_functions(os.path.join(REF, "PopPUNK", "sketchlib.py"), ["fitKmerCurve"], ns)
     fit = ns["fitKmerCurve"]
+
+    # The same reference function once more with ONLY the solver's stopping tolerances tightened: its
+    # default ftol = 1e-8 leaves ~5e-6 of solver error in the parameters, more than the 1e-6 this path
+    # is held to.  Model, Jacobian, start point and bounds stay the reference's own (the function body
+    # runs unchanged; `optimize` in its namespace forwards to scipy with xtol = ftol = gtol = 1e-15).
+    class TightOptimize:
+        @staticmethod
+        def least_squares(*a, **k):
+            k.update(xtol=1e-15, ftol=1e-15, gtol=1e-15, max_nfev=100000)
+            return optimize.least_squares(*a, **k)
+    ns_t = {"np": np, "optimize": TightOptimize, "sys": sys}
+    extract_functions(os.path.join(REF, "PopPUNK", "sketchlib.py"), ["fitKmerCurve"], ns_t)
+    fit_tight = ns_t["fitKmerCurve"]
     rng = np.random.Generator(np.random.PCG64(20260928))
     cases = []
     klists = [np.arange(13, 30, 4), np.arange(13, 29, 3), np.arange(15, 32, 2), np.array([13, 29])]
@@ -74,21 +87,26 @@ def golden_fit():
             y = y * np.exp(rng.normal(0.0, noise, size=y.shape))
             y = np.minimum(y, 1.0)
             core, acc = fit(y, klist, jac_mat)
+            core_t, acc_t = fit_tight(y, klist, jac_mat)
             # unconstrained OLS, to record whether a bound was active in the reference fit
             A = np.vstack([np.ones_like(klist, dtype=np.float64), klist.astype(np.float64)]).T
             icpt, slope = np.linalg.lstsq(A, np.log(y), rcond=None)[0]
             cases.append({"klist": klist.tolist(), "jaccard": y.tolist(),
                           "core": float(core), "accessory": float(acc),
+                          "core_tight": float(core_t), "accessory_tight": float(acc_t),
                           "interior": bool(icpt < 0 and slope < 0)})
     # exact model points: fitKmerCurve((1-0.1)*(1-0.02)**k) -> [0.02, 0.1]
     klist = np.arange(13, 30, 4)
     jac_mat = -np.hstack((np.ones((klist.shape[0], 1)), klist.reshape(-1, 1)))
     y = (1 - 0.1) * (1 - 0.02) ** klist.astype(np.float64)
     core, acc = fit(y, klist, jac_mat)
+    core_t, acc_t = fit_tight(y, klist, jac_mat)
     cases.append({"klist": klist.tolist(), "jaccard": y.tolist(), "core": float(core),
-                  "accessory": float(acc), "interior": True})
+                  "accessory": float(acc), "core_tight": float(core_t), "accessory_tight": float(acc_t),
+                  "interior": True})
     with open(os.path.join(HERE, "fit_kmer_curve.json"), "w") as f:
-        json.dump({"source": "PopPUNK/sketchlib.py:635-670 fitKmerCurve, run by make_golden.py",
+        json.dump({"source": "PopPUNK/sketchlib.py:635-670 fitKmerCurve, run by make_golden.py; *_tight: the same "
+                             "function with only scipy's stopping tolerances set to 1e-15",
                    "cases": cases}, f, indent=1)
     print("fit_kmer_curve.json:", len(cases), "cases,",
           sum(c["interior"] for c in cases), "interior")

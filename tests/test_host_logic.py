@@ -296,6 +296,9 @@ def test_fitKmerCurve_mirror_against_the_reference_goldens(golden_dir):
         got = sketchlib.fitKmerCurve(np.asarray(c["jaccard"]), np.asarray(c["klist"]))
         tol = 5e-6 if c["interior"] else 1e-4          # the reference's trust-region solver stops early on a bound
         assert abs(got[0] - c["core"]) <= tol and abs(got[1] - c["accessory"]) <= tol, c
+        # *_tight: the same reference function with only scipy's stopping tolerances at 1e-15 (make_golden.py):
+        # the exact bounded minimiser, bound-active cases included
+        assert abs(got[0] - c["core_tight"]) <= 1e-8 and abs(got[1] - c["accessory_tight"]) <= 1e-8, c
         n_active += not c["interior"]
     assert n_active >= 5
     assert list(sketchlib.fitKmerCurve(np.asarray([0.5, 0.0]), np.asarray([13, 17]))) == [0, 0]
