@@ -67,7 +67,7 @@ int ppk_device_count(int *n);
  *     default 2: the device is entered twice, each entry with its own streams and buffers, so that one
  *     download is in flight while the next is being set up)
  *   measurement only: "ablate", a bit mask that SKIPS parts of the distance kernel to time the rest
- *     (1 epilogue, 2 compare, 4 DMA, 8 barriers, 16 first-copy wait, 128 stores: results are
+ *     (1 epilogue, 2 compare, 4 DMA, 8 barriers, 16 first-copy wait, 64 the interior tiles' table copy, 128 stores: results are
  *     garbage) or switches a path off (32: the LDS-table epilogue; results unchanged); 0 in any
  *     real use
  *   [EXT] readings of pp-sketchlib behaviour that this tree cannot verify:

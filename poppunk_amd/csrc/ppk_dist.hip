@@ -156,7 +156,7 @@ struct DistParams {
   unsigned tiles_per_xcd;      // ceil(n_tiles / 8)
   int tri_m, tri_c0;           // self job: ref tile r pairs with clamp(tri_m * r + tri_c0, 0, q_tiles) query tiles
   int knn, knn_col;       // MODE_KNN: neighbours per sample, distance column (0 core, 1 accessory)
-  int ablate;             // measurement only (PPK_ABLATE): 1 skip epilogue, 2 skip compare, 4 skip DMA, 8 skip barriers
+  int ablate;             // measurement only (PPK_ABLATE): 1 skip epilogue, 2 skip compare, 4 skip DMA, 8 skip barriers, 64 skip the (E, F) table copy
   int ext_adjust;         // [EXT] a4 gate (PpkConfig::ext_collision_adjust)
   int ext_skip;           // [EXT] a6: skip instead of truncate at J < 5/s (PpkConfig::ext_fit_skip)
 
@@ -1018,7 +1018,10 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
 #pragma unroll
         for (int t = 0; t < PIECES; ++t) {
           const int piece = wave * PIECES + t;        // k = piece / 16, rows 64 * (piece % 16) ..
-          if ((piece >> 4) < p.nk) {
+          if (p.ablate & 64) {
+            // (bit 64, measurement only: what the table copy costs -- an upper bound on what issuing part of
+            // it under the last compare block could win; the look-ups then read whatever the buffers hold)
+          } else if ((piece >> 4) < p.nk) {
             __builtin_amdgcn_global_load_lds(PPK_GPTR(tab + (size_t)(piece >> 4) * (1025 * 16) + (piece & 15) * 1024),
                                              PPK_LPTR(lds + piece * 64), 16, 0, 0);
           } else if ((piece & 15) == 0 && lane_late == 0) {
@@ -1068,7 +1071,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
           const double pe = e[0].x * e[1].x * e[2].x * e[3].x * e[4].x;
           const double pf = e[0].y * e[1].y * e[2].y * e[3].y * e[4].y;
           // some lane has a k below the floor: the whole wavefront goes through the general statement below
-          if (!__all(pe == pe)) {
+          if (!__all(pe == pe) && !(p.ablate & 64)) {
             interior = false;
             break;
           }

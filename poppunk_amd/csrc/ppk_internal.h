@@ -35,7 +35,7 @@ struct ppk_db {
 // two ext_* options select between the readings of pp-sketchlib behaviour that cannot be checked
 // in this tree (DESIGN.md "[EXT] assumptions").
 struct PpkConfig {
-  std::atomic<long long> ablate{0};             // PPK_ABLATE: skip 1 epilogue, 2 compare, 4 DMA, 8 barriers, 16 first-copy wait, 128 stores; 32 LDS-table path off
+  std::atomic<long long> ablate{0};             // PPK_ABLATE: skip 1 epilogue, 2 compare, 4 DMA, 8 barriers, 16 first-copy wait, 64 the interior tiles' table copy, 128 stores; 32 LDS-table path off
   std::atomic<long long> map{0};                // PPK_MAP: tile order of dist_kernel_v2 (0 = XCD-contiguous runs)
   std::atomic<long long> strip{1};              // PPK_STRIP: strip tiles for the ragged right edge
   std::atomic<long long> ksplit{215};           // PPK_KSPLIT: tile-count threshold (at 5 k) of the small-job path
