@@ -23,6 +23,8 @@ python bench.py > $OUT/bench.json 2> $OUT/bench.err
 ./tools/watch_clocks.sh > $OUT/power_clocks.txt 2>&1
 ./tools/ubench_host_out.out > $OUT/ubench_host_out.txt 2>&1
 python tools/ab_host.py > $OUT/ab_host.txt 2>&1
+python tools/ab_host_parts.py > $OUT/ab_host_parts.txt 2>&1
+./tools/ubench_hwid.out > $OUT/ubench_hwid.txt 2>&1
 python tools/ab_knn.py > $OUT/knn_from_tiles.txt 2>&1
 PPK_BENCH_ONE_GPU=1 PPK_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 2 --steps 5 --warmup 2 --config5-genomes 20000 --no-cpu > $OUT/two_ranks_one_gpu.json 2> $OUT/two_ranks_one_gpu.err
 tail -1 $OUT/bench.json | cut -c1-300

@@ -15,7 +15,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = os.environ.get("ROUND", "r02")
+ROUND = os.environ.get("ROUND", "r03")
 SRC = os.path.join(ROOT, "gpurun_out", ROUND)
 DST = os.path.join(ROOT, "profiles", ROUND)
 KERNEL = "dist_kernel_v2"
@@ -31,7 +31,7 @@ def main():
     if os.path.exists(ktc):       # every kernel of tools/measure_configs.py (kernel 2, sweeps, kNN, ...)
         shutil.copy(ktc, os.path.join(DST, "configs_kernel_stats.csv"))
     for f in glob.glob(os.path.join(SRC, "ubench_*.txt")) + [os.path.join(SRC, x) for x in (
-            "power_clocks.txt", "ab_host.txt", "knn_from_tiles.txt", "two_ranks_one_gpu.json")]:
+            "power_clocks.txt", "ab_host.txt", "ab_host_parts.txt", "knn_from_tiles.txt", "two_ranks_one_gpu.json")]:
         if os.path.exists(f):
             shutil.copy(f, DST)
     counters = {}
