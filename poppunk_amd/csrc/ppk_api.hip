@@ -27,7 +27,7 @@ int ppk_fail(int code, const std::string &msg) {
   return code;
 }
 extern "C" const char *ppk_last_error(void) { return g_err.c_str(); }
-extern "C" const char *ppk_version(void) { return "poppunk_amd 0.2.0 (gfx950)"; }
+extern "C" const char *ppk_version(void) { return "poppunk_amd 0.3.0 (gfx950)"; }
 
 // ---- run-time options: PPK_* environment read once, then ppk_set_option only ------------------
 namespace {
