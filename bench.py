@@ -678,11 +678,15 @@ def run(args, rep, rank, local_rank, world, fake, torch, dist, engine, synth, da
                 f["host_call"] = host_call(sk, kmers, tbl, [local_rank])
             else:
                 if rank == 0:
-                    if torch.cuda.device_count() >= world:
-                        f["multi_host_call"] = host_call(sk, kmers, tbl, list(range(world)))
-                        f["multi_host_call"]["one_device"] = host_call(sk, kmers, tbl, [local_rank], reps=3)
-                    else:
-                        f["multi_host_call"] = {"skipped": "rank 0 sees %d of %d GPUs" % (torch.cuda.device_count(), world)}
+                    try:      # whatever happens here, rank 0 reaches the barrier the other ranks wait at
+                        if torch.cuda.device_count() >= world:
+                            f["multi_host_call"] = host_call(sk, kmers, tbl, list(range(world)))
+                            f["multi_host_call"]["one_device"] = host_call(sk, kmers, tbl, [local_rank], reps=3)
+                        else:
+                            f["multi_host_call"] = {"skipped": "rank 0 sees %d of %d GPUs"
+                                                               % (torch.cuda.device_count(), world)}
+                    except Exception as e:
+                        rep.error("host_call", e)
                 barrier()
         except Exception as e:
             rep.error("host_call", e)

@@ -13,6 +13,7 @@ pp_sketchlib.query_arrays(sk[:500], None, K, 16, 14, T)
 lib = _lib.lib()
 for chunk in (8 << 20, 4 << 20, 2 << 20):
     _lib.set_option("chunk_rows", chunk)
+    _lib.set_option("host_parts", 1)      # the entries are listed explicitly here
     for devs in ((0,), (0, 0), (0, 0, 0), (0, 0, 0, 0)):
         ts = []
         dp = []
