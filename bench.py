@@ -447,6 +447,9 @@ def main():
         sys.exit("bench.py --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not fake and not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (there is no CPU path)")
+    if not fake and torch.cuda.device_count() <= local_rank:
+        # a launcher that gives every rank its own visible device (HIP_VISIBLE_DEVICES per rank)
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     rep = Report(rank, world, args)
     if world > 1:
         rep.per_rank_dir = os.path.join("/tmp", "ppk_bench_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid()))
