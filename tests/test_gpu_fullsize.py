@@ -22,9 +22,10 @@ TOL = 1e-6
 THREADS = 16
 
 
-def _device_sketches(n, seed):
+def _device_sketches(n, seed, kmers=KMERS, sketchsize64=16):
     import torch
-    t = synth.make_sketches_device(n, KMERS, seed=seed, device="cuda:0")
+    t = synth.make_sketches_device(n, kmers, sketchsize64=sketchsize64, seed=seed, device="cuda:0",
+                                    chunk=8192 if sketchsize64 <= 16 else 1024)
     sk = t.cpu().numpy().view(np.uint64)
     del t
     torch.cuda.empty_cache()
@@ -136,3 +137,36 @@ def test_config5_100000_genomes_one_band_fused_edges():
     assert total_edges > 1000
     db.close()
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("nk", [5, 6])
+def test_default_sketch_size_many_ref_tiles(nk):
+    """PopPUNK's DEFAULT sketch size (s = 9 984: sketchsize64 156, 14-bit counts -> the three-dword count
+    register) on a job with 11 ref tiles and a ragged right edge: 3.5 M pairs of 780 / 936 blocks each.
+    Counts bit-identical, distances within 1e-6 on every row, query bands equal to the whole job, the
+    fused edge list equal to the oracle's, ref x query as well."""
+    import torch
+    n = 2650
+    kmers = np.asarray([13, 17, 21, 25, 29] if nk == 5 else [13, 16, 19, 22, 25, 28], dtype=np.int32)
+    tbl = synth.random_match_table(kmers)
+    sk = _device_sketches(n, 600 + nk, kmers, 156)          # (drawn on the GPU: 20 s with numpy on the host)
+    counts, _ = pp_sketchlib.query_arrays(sk, None, kmers, 156, 14, counts=True)
+    assert np.array_equal(counts, oracle.match_counts(sk, None, 156, 14, threads=THREADS))
+    del counts
+    want, wf = oracle.query(sk, None, kmers, 156, 14, tbl, threads=THREADS)
+    db = engine.SketchDB(sk, 156, 14)
+    whole, gf = engine.dist(db, None, kmers, tbl)
+    assert int(gf.item()) == wf
+    _compare(whole.cpu().numpy(), want, "s=9984 nk=%d, %d genomes self" % (nk, n))
+    cuts = [0, 37, 1024, 1111, 2600, n]
+    pieces = [engine.dist(db, None, kmers, tbl, q_begin=a, q_end=b)[0] for a, b in zip(cuts[:-1], cuts[1:])]
+    assert torch.equal(torch.cat(pieces), whole)
+    x_max, y_max = synth.boundary_for_quantile(want, 0.05)
+    e, _ = engine.dist_edges(db, None, kmers, tbl, slope=2, x_max=x_max, y_max=y_max)
+    assert np.array_equal(e.cpu().numpy(), oracle.edge_threshold(want, 2, x_max, y_max))
+    db.close()
+    nr = 1500
+    got, gf2 = pp_sketchlib.query_arrays(sk[:nr], sk[nr:], kmers, 156, 14, tbl)
+    want2, wf2 = oracle.query(sk[:nr], sk[nr:], kmers, 156, 14, tbl, threads=THREADS)
+    assert gf2 == wf2
+    _compare(got, want2, "s=9984 nk=%d, %d x %d" % (nk, nr, n - nr))
