@@ -416,6 +416,12 @@ def build_line(rep):
         line["error"] = "; ".join(rep.errors)
     if f.get("cpu") and value:
         line["speedup_vs_cpu"] = value / f["cpu"]["value"]
+        # the container may use `cores` of the host's `host_hw_threads` hardware threads, so the ratio above is
+        # against a fraction of the host; per core it reads: one GPU = this many CPU cores of the oracle's loop
+        if f["cpu"].get("single_thread_value"):
+            line["cpu_cores_equivalent"] = round(value / f["cpu"]["single_thread_value"])
+            if f.get("host_call"):
+                line["host_call_vs_cpu"] = f["host_call"]["pairs_per_s"] / f["cpu"]["value"]
     return line
 
 
