@@ -79,13 +79,14 @@ int ppk_device_count(int *n);
 int ppk_set_option(const char *name, long long value);
 int ppk_get_option(const char *name, long long *value);
 
-/* Interrupts and progress of the long host calls (ppk_query, ppk_query_db), the contract of the
+/* Interrupts and progress of the long host calls (ppk_query, ppk_query_dbs), the contract of the
  * bindings they replace: the reference's C++ loops poll PyErr_CheckSignals and stop on Ctrl-C
  * (src/extend.cpp:263,:284-286; pp-sketchlib the same [EXT]) and print a progress meter to stderr,
  * which PopPUNK silences with an fd-level redirect around re-queries (PopPUNK/utils.py:61-83,
  * PopPUNK/sketchlib.py:546).
- *  - `check` (NULL = none) is called from the calling thread between sub-bands (every ~64 MB of
- *    results, a few ms); a non-zero return abandons the call: nothing more is launched, the device is
+ *  - `check` (NULL = none) is called from the calling thread -- between sub-bands (every ~64 MB of
+ *    results, a few ms) when it does the work itself, every ~0.2 ms while worker threads do (several
+ *    device entries); a non-zero return abandons the call: nothing more is launched, the devices are
  *    drained, PPK_ERR_INTERRUPTED is returned.  The Python mirror passes a check that lets Python's
  *    signal handlers run.
  *  - option "progress" (default 1): jobs of more than a few sub-bands write "\rProgress (GPU): nn.n%"
