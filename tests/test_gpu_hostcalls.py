@@ -151,9 +151,11 @@ def test_device_list_entries_run_side_by_side(ppk_option):
     one, f1 = pp_sketchlib.query_arrays(sk, None, KMERS, 16, 14, tbl, devices=(0,))
     st = _stats()
     assert st["parts"] == 1 and st["threads"] == 0 and st["dl_max"] == 1
-    ppk_option("chunk_rows", 400000)                                           # ~16 sub-bands per entry
+    ppk_option("chunk_rows", 800000)                                           # ~8 sub-bands of 6.4 MB per entry
     overlapped = 0
-    for _ in range(5):
+    for _ in range(12):
+        if overlapped == 2:
+            break
         two, f2 = pp_sketchlib.query_arrays(sk, None, KMERS, 16, 14, tbl, devices=(0, 0))
         assert f2 == f1 and np.array_equal(one, two)
         st = _stats()
