@@ -1064,6 +1064,8 @@ struct QueryPart {
   unsigned long long *d_failed = nullptr;
   hipEvent_t done[2] = {nullptr, nullptr};      // sub-band in buf[i] computed
   std::atomic<int> db_ready{0};                 // 0 pending, 1 databases resident, -1 failed
+  std::atomic<int> first_launched{0};           // 1: done[0] has been recorded (or never will be)
+  int prev_same_dev = -1;                       // the entry of the same device before this one, if any
   int rc = PPK_OK;
   std::string err;
   unsigned long long failed = 0;
@@ -1083,7 +1085,7 @@ struct QueryJob {
   char *out = nullptr;
   size_t cols = 2;
   int C = 1;                                    // sub-bands per part
-  std::vector<size_t> bounds, row0;
+  std::vector<size_t> bounds, row0, seg_of;     // seg_of: the toucher's segment of sub-band i
   size_t max_rows = 0;
   HostToucher *toucher = nullptr;
   std::atomic<int> stop{0};                     // interrupt or another part's failure: launch nothing more
@@ -1109,6 +1111,20 @@ double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// PPK_HOST_TRACE=1 (measurement): one line per event of a host query on fd 2, ms since the call began
+struct HostTrace {
+  bool on = getenv("PPK_HOST_TRACE") != nullptr;
+  double t0 = 0.0;
+  std::mutex mu;
+  void mark(int part, const char *what, long long arg = -1) {
+    if (!on) return;
+    char buf[128];
+    const int n = snprintf(buf, sizeof(buf), "trace part %d %-14s %lld  %.3f ms\n", part, what, arg, now_ms() - t0);
+    std::lock_guard<std::mutex> lk(mu);
+    if (n > 0) (void)!write(2, buf, (size_t)n);
+  }
+} g_trace;
+
 // Everything one device does for a host query, on its own host thread: make the databases resident
 // (upload + re-layout, or a cache hit), then its C sub-bands -- sub-band c+1 computes while sub-band c
 // goes to its rows of the caller's array.  The copy into PAGEABLE host memory blocks the thread that
@@ -1118,10 +1134,12 @@ double now_ms() {
 void run_part(QueryJob &job, std::vector<QueryPart> &parts, int d, bool poll, bool meter) {
   QueryPart &p = parts[(size_t)d];
   const double t_begin = now_ms();
+  g_trace.mark(d, "thread_start");
   auto fail = [&](int code) {
     p.rc = code;
     p.err = g_err;
     job.stop.store(1);
+    if (p.first_launched.load() == 0) p.first_launched.store(2);
   };
   DeviceGuard g(p.device);
   if (!g.ok) {
@@ -1130,6 +1148,7 @@ void run_part(QueryJob &job, std::vector<QueryPart> &parts, int d, bool poll, bo
     return fail(PPK_ERR_HIP);
   }
   int rc = PPK_OK;
+  g_trace.mark(d, "device_set");
   // 1. resident databases
   if (job.ref_sk) {
     if (p.leader >= 0) {
@@ -1138,6 +1157,7 @@ void run_part(QueryJob &job, std::vector<QueryPart> &parts, int d, bool poll, bo
       while ((st = l.db_ready.load(std::memory_order_acquire)) == 0) std::this_thread::yield();
       if (st < 0) {
         p.db_ready.store(-1);
+        p.first_launched.store(2);
         return;                                  // the leader has reported the failure
       }
       p.ref = l.ref;
@@ -1164,9 +1184,13 @@ void run_part(QueryJob &job, std::vector<QueryPart> &parts, int d, bool poll, bo
     }
   }
   p.db_ready.store(1, std::memory_order_release);
+  g_trace.mark(d, "db_ready");
   const int C = job.C;
   const size_t first = (size_t)d * (size_t)C;
-  if (job.row0[first + (size_t)C] == job.row0[first]) return;     // an empty share (more devices than tiles)
+  if (job.row0[first + (size_t)C] == job.row0[first]) {             // an empty share (more devices than tiles)
+    p.first_launched.store(2);
+    return;
+  }
   // 2. buffers
   QueryBufs &qb = g_qbufs[p.device][p.dup];
   const size_t buf_bytes = job.max_rows * job.cols * 4;
@@ -1196,25 +1220,38 @@ void run_part(QueryJob &job, std::vector<QueryPart> &parts, int d, bool poll, bo
     }
     if (c < C) {
       const size_t i = first + (size_t)c;
+      if (c == 0 && p.prev_same_dev >= 0) {
+        // Entries of ONE device: this entry's first sub-band starts when the previous entry's first one is
+        // done -- run side by side they would both finish late, and the link can only carry one result at full
+        // rate anyway: the first download starts after one sub-band's compute time, not two.
+        QueryPart &pv = parts[(size_t)p.prev_same_dev];
+        while (pv.first_launched.load(std::memory_order_acquire) == 0 && !job.stop.load()) std::this_thread::yield();
+        if (pv.first_launched.load() == 1 && pv.done[0]) (void)hipStreamWaitEvent(p.s, pv.done[0], 0);
+      }
       if (job.row0[i + 1] != job.row0[i]) {
         rc = ppk_dist_dev(p.ref, p.qry, job.kmers, job.random_tbl, job.n_clu, job.flags, job.bounds[i],
                           job.bounds[i + 1], p.buf[c & 1], p.d_failed, p.s);
         if (rc == PPK_OK && hipEventRecord(p.done[c & 1], p.s) != hipSuccess)
           rc = ppk_fail(PPK_ERR_HIP, "hipEventRecord failed");
+        g_trace.mark(d, "launched", c);
       }
+      if (c == 0) p.first_launched.store(rc == PPK_OK && job.row0[i + 1] != job.row0[i] ? 1 : 2, std::memory_order_release);
     }
     if (c > 0 && rc == PPK_OK) {
       const size_t i = first + (size_t)(c - 1);
       if (job.row0[i + 1] != job.row0[i]) {
-        job.toucher->wait(job.row0[i + 1] * job.cols * 4);
+        job.toucher->wait_segment(job.seg_of[i]);
+        g_trace.mark(d, "touched", c - 1);
         // the sub-band is computed (waited for here, so that the counter below brackets the copy alone)
         hipError_t e = hipEventSynchronize(p.done[(c - 1) & 1]);
+        g_trace.mark(d, "computed", c - 1);
         stat_enter(g_qstats.dl_now, g_qstats.dl_max);
         if (e == hipSuccess)
           e = hipMemcpyAsync(job.out + job.row0[i] * job.cols * 4, p.buf[(c - 1) & 1],
                              (job.row0[i + 1] - job.row0[i]) * job.cols * 4, hipMemcpyDeviceToHost, p.sc);
         if (e == hipSuccess) e = hipStreamSynchronize(p.sc);   // the buffer is free for sub-band c+1
         g_qstats.dl_now.fetch_sub(1);
+        g_trace.mark(d, "downloaded", c - 1);
         if (e != hipSuccess)
           rc = ppk_fail(PPK_ERR_HIP, std::string("kernel execution / download failed: ") + hipGetErrorString(e));
       }
@@ -1244,6 +1281,7 @@ void run_part(QueryJob &job, std::vector<QueryPart> &parts, int d, bool poll, bo
 // thread per device (run_part); the calling thread runs the interrupt check and the progress meter.
 int run_query(QueryJob &job, std::vector<QueryPart> &parts, unsigned long long *n_failed) {
   const double t_begin = now_ms();
+  g_trace.t0 = t_begin;
   const int n_dev = (int)parts.size();
   const bool self = (job.n_qry == 0);
   const size_t nq = self ? job.n_ref : job.n_qry;
@@ -1257,10 +1295,41 @@ int run_query(QueryJob &job, std::vector<QueryPart> &parts, unsigned long long *
   int C = (int)((per_dev + target_rows - 1) / target_rows);
   if (C < 1) C = 1;
   if ((size_t)C > nq / 64 + 1) C = (int)(nq / 64 + 1);         // sub-band edges are multiples of 64 queries
-  job.C = C;
-  job.bounds.assign((size_t)n_dev * C + 1, 0);
-  int rc = ppk_band_split(job.n_ref, job.n_qry, n_dev * C, job.bounds.data());
+  std::vector<size_t> eq((size_t)n_dev * C + 1, 0);
+  int rc = ppk_band_split(job.n_ref, job.n_qry, n_dev * C, eq.data());
   if (rc != PPK_OK) return rc;
+  // A large job starts with a SHORT sub-band per entry (a quarter of the others): the first download begins
+  // after a quarter of a sub-band's compute time, and the link -- the bound of the whole call -- has two
+  // downloads to carry that much sooner (10k self: device phase 8.5 -> 8.1 ms).
+  const bool short_first = total_rows >= ((size_t)16 << 20);
+  if (short_first) {
+    std::vector<size_t> b;
+    b.reserve((size_t)n_dev * (C + 1) + 1);
+    for (int d = 0; d < n_dev; ++d) {
+      const size_t lo = eq[(size_t)d * C], hi = eq[(size_t)d * C + 1];
+      const size_t want = ppk_rows_in_band(job.n_ref, job.n_qry, lo, hi) / 4;
+      // smallest multiple of 64 queries beyond lo whose rows reach `want` (rows grow with q)
+      size_t a = lo / 64 + 1, z = hi / 64;
+      size_t cut = hi;
+      if (a * 64 < hi) {
+        while (a < z) {
+          const size_t m = (a + z) / 2;
+          if (ppk_rows_in_band(job.n_ref, job.n_qry, lo, m * 64) >= want) z = m;
+          else a = m + 1;
+        }
+        cut = a * 64 < hi ? a * 64 : hi;
+      }
+      b.push_back(lo);
+      b.push_back(cut);
+      for (int c = 1; c < C; ++c) b.push_back(eq[(size_t)d * C + c]);
+    }
+    b.push_back(eq[(size_t)n_dev * C]);
+    ++C;
+    job.bounds = std::move(b);
+  } else {
+    job.bounds = std::move(eq);
+  }
+  job.C = C;
   job.row0.assign((size_t)n_dev * C + 1, 0);                    // first output row of every sub-band
   job.max_rows = 0;
   for (int i = 0; i < n_dev * C; ++i) {
@@ -1269,8 +1338,19 @@ int run_query(QueryJob &job, std::vector<QueryPart> &parts, unsigned long long *
     if (r > job.max_rows) job.max_rows = r;
   }
   // helper threads touch the result array's pages ahead of the downloads (HostToucher)
-  HostToucher toucher(job.out, job.row0[(size_t)n_dev * C] * job.cols * 4);
+  g_trace.mark(-1, "plan_done");
+  // the pages are touched in the order the downloads will want them: sub-band c of every entry before c+1 of any
+  std::vector<std::pair<size_t, size_t>> segs;
+  job.seg_of.assign((size_t)n_dev * C, 0);
+  for (int c = 0; c < C; ++c)
+    for (int d = 0; d < n_dev; ++d) {
+      const size_t i = (size_t)d * C + c;
+      job.seg_of[i] = segs.size();
+      segs.emplace_back(job.row0[i] * job.cols * 4, job.row0[i + 1] * job.cols * 4);
+    }
+  HostToucher toucher(job.out, job.row0[(size_t)n_dev * C] * job.cols * 4, std::move(segs));
   job.toucher = &toucher;
+  g_trace.mark(-1, "toucher_up");
   const long long prog = ppk_config().progress.load();          // 1: jobs of >= ~0.1 s of work; 2: any multi-band job
   const bool meter = prog != 0 && C >= 4 && (prog >= 2 || total_rows >= ((size_t)1 << 29));
   g_qstats.dl_now = 0;
@@ -1305,7 +1385,9 @@ int run_query(QueryJob &job, std::vector<QueryPart> &parts, unsigned long long *
     for (auto &t : th) t.join();
     if (was_interrupted) rc = ppk_fail(PPK_ERR_INTERRUPTED, "interrupted");
   }
+  g_trace.mark(-1, "parts_done");
   toucher.join();
+  g_trace.mark(-1, "toucher_joined");
   job.toucher = nullptr;
   for (QueryPart &p : parts) {
     if (p.rc != PPK_OK && rc == PPK_OK) rc = ppk_fail(p.rc, p.err);
@@ -1340,6 +1422,7 @@ int prepare_parts(std::vector<QueryPart> &parts, const int *devices) {
       if (devices[e] == p.device) {
         ++p.dup;
         if (p.leader < 0) p.leader = (int)e;
+        p.prev_same_dev = (int)e;
       }
     if (p.dup >= kMaxDup) return ppk_fail(PPK_ERR_ARG, "a device may be listed at most 4 times");
     DeviceGuard g(p.device);

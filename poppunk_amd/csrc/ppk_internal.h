@@ -194,36 +194,52 @@ __device__ __forceinline__ float ppk_line_dist(float x0, float y0, float x_max, 
 // until the blocks under it are done (a toucher never writes behind a download).
 class HostToucher {
  public:
-  HostToucher(void *out, size_t total_bytes) : out_(out), total_(total_bytes) {
+  // `segments` (optional): byte ranges [first, second) of the array in the order they will be needed (the
+  // sub-bands of several worker entries interleave); without them the array is touched front to back.
+  HostToucher(void *out, size_t total_bytes, std::vector<std::pair<size_t, size_t>> segments = {})
+      : out_(out), total_(total_bytes) {
     int nt = (int)ppk_config().prefault_threads.load();
     if (nt > 64) nt = 64;
     if (!out || total_bytes < ((size_t)8 << 20) || nt < 0) nt = 0;
     nt_ = nt;
-    if (nt > 0) {
-      // transparent huge pages for the (whole 2 MB blocks of the) result: a first touch then maps
-      // 2 MB at a time -- measured on the MI355X host: 400 MB touched by 8 threads in 2.5 ms against
-      // 35 ms with 4 KB pages (tools/ubench_host_out.hip).  numpy asks for the same on its own large
-      // allocations; other callers' arrays get it here.  Advice only: failure is harmless.
-      const size_t a0 = ((size_t)out + kBlock - 1) / kBlock * kBlock, a1 = ((size_t)out + total_bytes) / kBlock * kBlock;
-      if (a1 > a0) (void)madvise(reinterpret_cast<void *>(a0), a1 - a0, MADV_HUGEPAGE);
-    }
     n_blocks_ = (total_bytes + kBlock - 1) / kBlock;
+    if (nt > 0 && !segments.empty()) {
+      // the 2 MB blocks in the order of the segments that (first) overlap them
+      order_.reserve(n_blocks_);
+      std::vector<char> taken(n_blocks_, 0);
+      for (const auto &sg : segments) {
+        const size_t e = sg.second < total_bytes ? sg.second : total_bytes;
+        if (e > sg.first)
+          for (size_t blk = sg.first / kBlock; blk <= (e - 1) / kBlock && blk < n_blocks_; ++blk)
+            if (!taken[blk]) {
+              taken[blk] = 1;
+              order_.push_back(blk);
+            }
+        seg_end_.push_back(order_.size());
+      }
+      for (size_t blk = 0; blk < n_blocks_; ++blk)
+        if (!taken[blk]) order_.push_back(blk);
+    }
     done_ = std::vector<std::atomic<size_t>>((size_t)(nt > 0 ? nt : 1));
     for (auto &a : done_) a.store(0);
-    for (int t = 0; t < nt; ++t) threads_.emplace_back([this, t]() { run(t); });
+    // the first helper advises the kernel and starts the others: the constructor itself returns at once (the
+    // advice on 400 MB plus eight thread starts were 0.2 ms in front of the first kernel launch)
+    if (nt > 0) threads_.emplace_back([this]() { lead(); });
   }
   ~HostToucher() { join(); }
   HostToucher(const HostToucher &) = delete;
   HostToucher &operator=(const HostToucher &) = delete;
-  // every page of [0, end_byte) has been touched
+  // every page of [0, end_byte) has been touched (front-to-back order only)
   void wait(size_t end_byte) {
     if (!nt_) return;
     size_t need = (end_byte + kBlock - 1) / kBlock;
-    if (need > n_blocks_) need = n_blocks_;
-    for (int t = 0; t < nt_; ++t) {
-      const size_t mine = need > (size_t)t ? (need - (size_t)t + (size_t)nt_ - 1) / (size_t)nt_ : 0;
-      while (done_[(size_t)t].load(std::memory_order_acquire) < mine) std::this_thread::yield();
-    }
+    if (!order_.empty()) need = n_blocks_;      // (a caller mixing the two forms waits for everything)
+    wait_blocks(need);
+  }
+  // every page of segment i (and of all segments before it in the order) has been touched
+  void wait_segment(size_t i) {
+    if (!nt_) return;
+    wait_blocks(i < seg_end_.size() ? seg_end_[i] : n_blocks_);
   }
   void join() {
     for (auto &t : threads_)
@@ -232,10 +248,30 @@ class HostToucher {
 
  private:
   static constexpr size_t kBlock = (size_t)2 << 20;
+  void wait_blocks(size_t need) {
+    if (need > n_blocks_) need = n_blocks_;
+    for (int t = 0; t < nt_; ++t) {
+      const size_t mine = need > (size_t)t ? (need - (size_t)t + (size_t)nt_ - 1) / (size_t)nt_ : 0;
+      while (done_[(size_t)t].load(std::memory_order_acquire) < mine) std::this_thread::yield();
+    }
+  }
+  void lead() {
+    // transparent huge pages for the (whole 2 MB blocks of the) result: a first touch then maps
+    // 2 MB at a time -- measured on the MI355X host: 400 MB touched by 8 threads in 2.5 ms against
+    // 35 ms with 4 KB pages (tools/ubench_host_out.hip).  numpy asks for the same on its own large
+    // allocations; other callers' arrays get it here.  Advice only: failure is harmless.
+    const size_t a0 = ((size_t)out_ + kBlock - 1) / kBlock * kBlock, a1 = ((size_t)out_ + total_) / kBlock * kBlock;
+    if (a1 > a0) (void)madvise(reinterpret_cast<void *>(a0), a1 - a0, MADV_HUGEPAGE);
+    std::vector<std::thread> helpers;
+    for (int t = 1; t < nt_; ++t) helpers.emplace_back([this, t]() { run(t); });
+    run(0);
+    for (auto &h : helpers) h.join();
+  }
   void run(int t) {
     volatile char *base = static_cast<volatile char *>(out_);
     size_t done = 0;
-    for (size_t blk = (size_t)t; blk < n_blocks_; blk += (size_t)nt_) {
+    for (size_t pos = (size_t)t; pos < n_blocks_; pos += (size_t)nt_) {
+      const size_t blk = order_.empty() ? pos : order_[pos];
       const size_t b0 = blk * kBlock, b1 = b0 + kBlock < total_ ? b0 + kBlock : total_;
       base[b0] = 0;
       for (size_t a = (((size_t)out_ + b0) / 4096 + 1) * 4096 - (size_t)out_; a < b1; a += 4096) base[a] = 0;
@@ -245,6 +281,7 @@ class HostToucher {
   void *out_;
   size_t total_, n_blocks_ = 0;
   int nt_ = 0;
+  std::vector<size_t> order_, seg_end_;
   std::vector<std::atomic<size_t>> done_;
   std::vector<std::thread> threads_;
 };
