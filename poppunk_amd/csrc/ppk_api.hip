@@ -2,9 +2,13 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
+#include <pthread.h>
 #include <unistd.h>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <vector>
 
@@ -28,6 +32,71 @@ int ppk_fail(int code, const std::string &msg) {
 }
 extern "C" const char *ppk_last_error(void) { return g_err.c_str(); }
 extern "C" const char *ppk_version(void) { return "poppunk_amd 0.3.0 (gfx950)"; }
+
+// ---- pool of parked helper threads (ppk_internal.h) ------------------------------------------------
+namespace {
+struct WorkerPool {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<std::pair<std::function<void()>, PpkTicket>> q;
+  int idle = 0, total = 0;
+  void loop() {
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+      while (q.empty()) {
+        ++idle;
+        cv.wait(lk);
+        --idle;
+      }
+      auto task = std::move(q.front());
+      q.pop_front();
+      lk.unlock();
+      task.first();
+      task.second->store(1, std::memory_order_release);
+      lk.lock();
+    }
+  }
+};
+std::atomic<WorkerPool *> g_pool{nullptr};
+std::once_flag g_pool_fork_once;
+WorkerPool *pool() {
+  WorkerPool *p = g_pool.load(std::memory_order_acquire);
+  if (p) return p;
+  static std::mutex mk;
+  std::lock_guard<std::mutex> lk(mk);
+  p = g_pool.load();
+  if (!p) {
+    p = new WorkerPool();            // never destroyed: its threads park until the process ends
+    g_pool.store(p, std::memory_order_release);
+    // a forked child has none of the parent's threads: it starts over with an empty pool
+    std::call_once(g_pool_fork_once, []() { pthread_atfork(nullptr, nullptr, []() { g_pool.store(nullptr); }); });
+  }
+  return p;
+}
+}  // namespace
+
+PpkTicket ppk_pool_run(std::function<void()> fn) {
+  WorkerPool *p = pool();
+  PpkTicket t = std::make_shared<std::atomic<int>>(0);
+  bool spawn = false;
+  {
+    std::lock_guard<std::mutex> lk(p->mu);
+    p->q.emplace_back(std::move(fn), t);
+    // one parked thread per queued task, or a new one (tasks may wait for each other: never queue behind a busy thread)
+    if ((int)p->q.size() > p->idle && p->total < 256) {
+      spawn = true;
+      ++p->total;
+    }
+  }
+  if (spawn) std::thread([p]() { p->loop(); }).detach();
+  p->cv.notify_one();
+  return t;
+}
+
+void ppk_pool_wait(const PpkTicket &t) {
+  if (!t) return;
+  while (t->load(std::memory_order_acquire) == 0) std::this_thread::yield();
+}
 
 // ---- run-time options: PPK_* environment read once, then ppk_set_option only ------------------
 namespace {
@@ -971,10 +1040,10 @@ uint64_t fingerprint(const uint64_t *sk, size_t words, const uint16_t *clu, size
     const size_t a = (size_t)t * per, b = a + per < words ? a + per : words;
     part[(size_t)t] = a < b ? hash_words(sk + a, b - a) : 0;
   };
-  std::vector<std::thread> th;
-  for (int t = 1; t < nt; ++t) th.emplace_back(run, t);
+  std::vector<PpkTicket> th;
+  for (int t = 1; t < nt; ++t) th.push_back(ppk_pool_run([&run, t]() { run(t); }));
   run(0);
-  for (auto &t : th) t.join();
+  for (auto &t : th) ppk_pool_wait(t);
   uint64_t h = 0x452821e638d01377ull ^ words;
   for (int t = 0; t < nt; ++t) h = mix64(h, part[(size_t)t]);
   if (clu)
@@ -1064,8 +1133,8 @@ struct QueryPart {
   unsigned long long *d_failed = nullptr;
   hipEvent_t done[2] = {nullptr, nullptr};      // sub-band in buf[i] computed
   std::atomic<int> db_ready{0};                 // 0 pending, 1 databases resident, -1 failed
-  std::atomic<int> first_launched{0};           // 1: done[0] has been recorded (or never will be)
   int prev_same_dev = -1;                       // the entry of the same device before this one, if any
+  int work = 0;                                 // index of this entry's device in QueryJob::work
   int rc = PPK_OK;
   std::string err;
   unsigned long long failed = 0;
@@ -1084,8 +1153,23 @@ struct QueryJob {
   bool use_cache = false;
   char *out = nullptr;
   size_t cols = 2;
-  int C = 1;                                    // sub-bands per part
+  // The sub-bands of the whole job, device after device (a device's sub-bands are consecutive): sub-band i is
+  // query rows [bounds[i], bounds[i+1]) and lands at output row row0[i].  The entries of ONE device take that
+  // device's sub-bands from a common counter, whichever is free first (DevWork::next).
   std::vector<size_t> bounds, row0, seg_of;     // seg_of: the toucher's segment of sub-band i
+  struct DevWork {
+    int device = 0;
+    size_t c_begin = 0, c_end = 0;              // this device's sub-bands
+    std::unique_ptr<std::atomic<size_t>> next;  // the next one to take
+  };
+  std::vector<DevWork> work;
+  // A device's sub-bands run in their order, whichever entry launches them: the launch of sub-band i waits for
+  // the event behind i-1 (each kernel fills the GPU by itself; side by side both would finish late, and the
+  // first download -- the start of the link's busy time -- with them).  state: 0 not launched yet, 1 launched
+  // (chunk_ev valid), 2 will not be launched.
+  std::unique_ptr<std::atomic<int>[]> chunk_state;
+  std::vector<hipEvent_t> chunk_ev;
+  size_t n_chunks = 0;
   size_t max_rows = 0;
   HostToucher *toucher = nullptr;
   std::atomic<int> stop{0};                     // interrupt or another part's failure: launch nothing more
@@ -1139,7 +1223,6 @@ void run_part(QueryJob &job, std::vector<QueryPart> &parts, int d, bool poll, bo
     p.rc = code;
     p.err = g_err;
     job.stop.store(1);
-    if (p.first_launched.load() == 0) p.first_launched.store(2);
   };
   DeviceGuard g(p.device);
   if (!g.ok) {
@@ -1157,7 +1240,6 @@ void run_part(QueryJob &job, std::vector<QueryPart> &parts, int d, bool poll, bo
       while ((st = l.db_ready.load(std::memory_order_acquire)) == 0) std::this_thread::yield();
       if (st < 0) {
         p.db_ready.store(-1);
-        p.first_launched.store(2);
         return;                                  // the leader has reported the failure
       }
       p.ref = l.ref;
@@ -1185,17 +1267,13 @@ void run_part(QueryJob &job, std::vector<QueryPart> &parts, int d, bool poll, bo
   }
   p.db_ready.store(1, std::memory_order_release);
   g_trace.mark(d, "db_ready");
-  const int C = job.C;
-  const size_t first = (size_t)d * (size_t)C;
-  if (job.row0[first + (size_t)C] == job.row0[first]) {             // an empty share (more devices than tiles)
-    p.first_launched.store(2);
-    return;
-  }
+  QueryJob::DevWork &w = job.work[(size_t)p.work];
+  if (w.c_end == w.c_begin) return;                                 // no work for this device
   // 2. buffers
   QueryBufs &qb = g_qbufs[p.device][p.dup];
   const size_t buf_bytes = job.max_rows * job.cols * 4;
   rc = query_buf(p.device, p.dup, 0, buf_bytes, &p.buf[0]);
-  if (rc == PPK_OK && C > 1) rc = query_buf(p.device, p.dup, 1, buf_bytes, &p.buf[1]);
+  if (rc == PPK_OK && w.c_end - w.c_begin > 1) rc = query_buf(p.device, p.dup, 1, buf_bytes, &p.buf[1]);
   if (rc == PPK_OK && !qb.d_failed &&
       hipMalloc(reinterpret_cast<void **>(&qb.d_failed), sizeof(unsigned long long)) != hipSuccess)
     rc = ppk_fail(PPK_ERR_HIP, "hipMalloc(output) failed");
@@ -1207,56 +1285,81 @@ void run_part(QueryJob &job, std::vector<QueryPart> &parts, int d, bool poll, bo
   p.done[0] = qb.done[0];
   p.done[1] = qb.done[1];
   (void)hipMemsetAsync(p.d_failed, 0, sizeof(unsigned long long), p.s);
-  // 3. step c: launch sub-band c, then fetch sub-band c-1
-  for (int c = 0; c <= C && rc == PPK_OK; ++c) {
+  // 3. take the device's next sub-band and launch it, then fetch the one launched before
+  constexpr size_t kNone = ~(size_t)0;
+  size_t pending = kNone;        // sub-band computing (or computed) in buf[pending_slot], not yet downloaded
+  int pending_slot = 0, slot = 0;
+  bool first = true, took_own = false;
+  long long step = 0;
+  for (;;) {
     if (poll) {
       if (interrupted()) {
         rc = ppk_fail(PPK_ERR_INTERRUPTED, "interrupted");
         break;
       }
-      if (meter) progress_line((double)c / (double)(C + 1), false);
+      if (meter) progress_line((double)step / (double)(w.c_end - w.c_begin + 1), false);
     } else if (job.stop.load()) {
       break;
     }
-    if (c < C) {
-      const size_t i = first + (size_t)c;
-      if (c == 0 && p.prev_same_dev >= 0) {
-        // Entries of ONE device: this entry's first sub-band starts when the previous entry's first one is
-        // done -- run side by side they would both finish late, and the link can only carry one result at full
-        // rate anyway: the first download starts after one sub-band's compute time, not two.
-        QueryPart &pv = parts[(size_t)p.prev_same_dev];
-        while (pv.first_launched.load(std::memory_order_acquire) == 0 && !job.stop.load()) std::this_thread::yield();
-        if (pv.first_launched.load() == 1 && pv.done[0]) (void)hipStreamWaitEvent(p.s, pv.done[0], 0);
+    ++step;
+    size_t i = kNone;
+    for (;;) {                                                       // (a sub-band without rows is skipped)
+      // an entry's first sub-band is its own (the k-th entry of a device takes the device's k-th: the short
+      // ones, one each); after that whichever the common counter hands out
+      const size_t t = w.c_begin + (first && !took_own ? (size_t)p.dup : w.next->fetch_add(1));
+      took_own = true;
+      if (t >= w.c_end) break;
+      if (job.row0[t + 1] != job.row0[t]) {
+        i = t;
+        break;
       }
-      if (job.row0[i + 1] != job.row0[i]) {
-        rc = ppk_dist_dev(p.ref, p.qry, job.kmers, job.random_tbl, job.n_clu, job.flags, job.bounds[i],
-                          job.bounds[i + 1], p.buf[c & 1], p.d_failed, p.s);
-        if (rc == PPK_OK && hipEventRecord(p.done[c & 1], p.s) != hipSuccess)
-          rc = ppk_fail(PPK_ERR_HIP, "hipEventRecord failed");
-        g_trace.mark(d, "launched", c);
-      }
-      if (c == 0) p.first_launched.store(rc == PPK_OK && job.row0[i + 1] != job.row0[i] ? 1 : 2, std::memory_order_release);
-    }
-    if (c > 0 && rc == PPK_OK) {
-      const size_t i = first + (size_t)(c - 1);
-      if (job.row0[i + 1] != job.row0[i]) {
-        job.toucher->wait_segment(job.seg_of[i]);
-        g_trace.mark(d, "touched", c - 1);
-        // the sub-band is computed (waited for here, so that the counter below brackets the copy alone)
-        hipError_t e = hipEventSynchronize(p.done[(c - 1) & 1]);
-        g_trace.mark(d, "computed", c - 1);
-        stat_enter(g_qstats.dl_now, g_qstats.dl_max);
-        if (e == hipSuccess)
-          e = hipMemcpyAsync(job.out + job.row0[i] * job.cols * 4, p.buf[(c - 1) & 1],
-                             (job.row0[i + 1] - job.row0[i]) * job.cols * 4, hipMemcpyDeviceToHost, p.sc);
-        if (e == hipSuccess) e = hipStreamSynchronize(p.sc);   // the buffer is free for sub-band c+1
-        g_qstats.dl_now.fetch_sub(1);
-        g_trace.mark(d, "downloaded", c - 1);
-        if (e != hipSuccess)
-          rc = ppk_fail(PPK_ERR_HIP, std::string("kernel execution / download failed: ") + hipGetErrorString(e));
-      }
+      job.chunk_state[t].store(2, std::memory_order_release);
       job.done_chunks.fetch_add(1);
     }
+    int my_slot = 0;
+    if (i != kNone) {
+      if (i > w.c_begin) {
+        std::atomic<int> &st = job.chunk_state[i - 1];
+        while (st.load(std::memory_order_acquire) == 0 && !job.stop.load()) std::this_thread::yield();
+        if (st.load() == 1 && job.chunk_ev[i - 1] != p.done[0] && job.chunk_ev[i - 1] != p.done[1])
+          (void)hipStreamWaitEvent(p.s, job.chunk_ev[i - 1], 0);      // (my own stream is ordered as it is)
+      }
+      my_slot = slot;
+      slot ^= 1;
+      rc = ppk_dist_dev(p.ref, p.qry, job.kmers, job.random_tbl, job.n_clu, job.flags, job.bounds[i],
+                        job.bounds[i + 1], p.buf[my_slot], p.d_failed, p.s);
+      if (rc == PPK_OK && hipEventRecord(p.done[my_slot], p.s) != hipSuccess)
+        rc = ppk_fail(PPK_ERR_HIP, "hipEventRecord failed");
+      g_trace.mark(d, "launched", (long long)i);
+      job.chunk_ev[i] = p.done[my_slot];
+      job.chunk_state[i].store(rc == PPK_OK ? 1 : 2, std::memory_order_release);
+      first = false;
+      if (rc != PPK_OK) break;
+    }
+    first = false;
+    if (pending != kNone) {
+      job.toucher->wait_segment(job.seg_of[pending]);
+      g_trace.mark(d, "touched", (long long)pending);
+      // the sub-band is computed (waited for here, so that the counter below brackets the copy alone)
+      hipError_t e = hipEventSynchronize(p.done[pending_slot]);
+      g_trace.mark(d, "computed", (long long)pending);
+      stat_enter(g_qstats.dl_now, g_qstats.dl_max);
+      if (e == hipSuccess)
+        e = hipMemcpyAsync(job.out + job.row0[pending] * job.cols * 4, p.buf[pending_slot],
+                           (job.row0[pending + 1] - job.row0[pending]) * job.cols * 4, hipMemcpyDeviceToHost, p.sc);
+      if (e == hipSuccess) e = hipStreamSynchronize(p.sc);   // the buffer is free for the sub-band after next
+      g_qstats.dl_now.fetch_sub(1);
+      g_trace.mark(d, "downloaded", (long long)pending);
+      job.done_chunks.fetch_add(1);
+      pending = kNone;
+      if (e != hipSuccess) {
+        rc = ppk_fail(PPK_ERR_HIP, std::string("kernel execution / download failed: ") + hipGetErrorString(e));
+        break;
+      }
+    }
+    if (i == kNone) break;                                            // nothing launched, nothing pending: done
+    pending = i;
+    pending_slot = my_slot;
   }
   // 4. drain (also on failure: nothing may stay in flight), failed-fit count
   const std::string keep = g_err;
@@ -1291,66 +1394,92 @@ int run_query(QueryJob &job, std::vector<QueryPart> &parts, unsigned long long *
   // (PCIe is the bound of the host call: 11.2 -> 10.2 ms there; tools/ab_host.py)
   size_t target_rows = (size_t)8 << 20;
   if (const long long cr = ppk_config().chunk_rows.load(); cr > 0) target_rows = (size_t)cr;
-  const size_t per_dev = (total_rows + n_dev - 1) / n_dev;
-  int C = (int)((per_dev + target_rows - 1) / target_rows);
-  if (C < 1) C = 1;
-  if ((size_t)C > nq / 64 + 1) C = (int)(nq / 64 + 1);         // sub-band edges are multiples of 64 queries
-  std::vector<size_t> eq((size_t)n_dev * C + 1, 0);
-  int rc = ppk_band_split(job.n_ref, job.n_qry, n_dev * C, eq.data());
-  if (rc != PPK_OK) return rc;
-  // A large job starts with a SHORT sub-band per entry (a quarter of the others): the first download begins
-  // after a quarter of a sub-band's compute time, and the link -- the bound of the whole call -- has two
-  // downloads to carry that much sooner (10k self: device phase 8.5 -> 8.1 ms).
-  const bool short_first = total_rows >= ((size_t)16 << 20);
-  if (short_first) {
-    std::vector<size_t> b;
-    b.reserve((size_t)n_dev * (C + 1) + 1);
-    for (int d = 0; d < n_dev; ++d) {
-      const size_t lo = eq[(size_t)d * C], hi = eq[(size_t)d * C + 1];
-      const size_t want = ppk_rows_in_band(job.n_ref, job.n_qry, lo, hi) / 4;
-      // smallest multiple of 64 queries beyond lo whose rows reach `want` (rows grow with q)
-      size_t a = lo / 64 + 1, z = hi / 64;
-      size_t cut = hi;
-      if (a * 64 < hi) {
-        while (a < z) {
-          const size_t m = (a + z) / 2;
-          if (ppk_rows_in_band(job.n_ref, job.n_qry, lo, m * 64) >= want) z = m;
-          else a = m + 1;
-        }
-        cut = a * 64 < hi ? a * 64 : hi;
-      }
-      b.push_back(lo);
-      b.push_back(cut);
-      for (int c = 1; c < C; ++c) b.push_back(eq[(size_t)d * C + c]);
+  // devices in the order of their first entry, and how many entries each has
+  job.work.clear();
+  std::vector<int> entries;
+  for (int d = 0; d < n_dev; ++d) {
+    size_t u = 0;
+    while (u < job.work.size() && job.work[u].device != parts[(size_t)d].device) ++u;
+    if (u == job.work.size()) {
+      job.work.emplace_back();
+      job.work[u].device = parts[(size_t)d].device;
+      job.work[u].next.reset(new std::atomic<size_t>(0));      // set below: starts behind the entries' own sub-bands
+      entries.push_back(0);
     }
-    b.push_back(eq[(size_t)n_dev * C]);
-    ++C;
-    job.bounds = std::move(b);
-  } else {
-    job.bounds = std::move(eq);
+    parts[(size_t)d].work = (int)u;
+    ++entries[u];
   }
-  job.C = C;
-  job.row0.assign((size_t)n_dev * C + 1, 0);                    // first output row of every sub-band
+  const int n_u = (int)job.work.size();
+  std::vector<size_t> dev_q((size_t)n_u + 1, 0);
+  int rc = ppk_band_split(job.n_ref, job.n_qry, n_u, dev_q.data());
+  if (rc != PPK_OK) return rc;
+  // smallest multiple of 64 queries in (lo, hi] whose rows from lo reach `want` (rows grow with q); hi if none
+  auto cut_at = [&](size_t lo, size_t hi, size_t want) {
+    size_t a = lo / 64 + 1, z = hi / 64;
+    if (a * 64 >= hi) return hi;
+    while (a < z) {
+      const size_t m = (a + z) / 2;
+      if (ppk_rows_in_band(job.n_ref, job.n_qry, lo, m * 64) >= want) z = m;
+      else a = m + 1;
+    }
+    return a * 64 < hi ? a * 64 : hi;
+  };
+  // A large job opens with SHORT sub-bands, one per entry of a device (a quarter of the others): the first
+  // download begins after a quarter of a sub-band's compute time, and the link -- the bound of the whole
+  // call -- is busy that much sooner.  The rest of a device's share is cut into equal sub-bands of about
+  // `target_rows`; its entries take them in turn, whichever is free first, so they finish together.
+  const bool short_first = total_rows >= ((size_t)16 << 20);
+  job.bounds.assign(1, 0);
+  for (int u = 0; u < n_u; ++u) {
+    const size_t lo = dev_q[(size_t)u], hi = dev_q[(size_t)u + 1];
+    job.work[(size_t)u].c_begin = job.bounds.size() - 1;
+    size_t q = lo;
+    if (short_first)
+      for (int e = 0; e < entries[(size_t)u] && q < hi; ++e) {
+        q = cut_at(q, hi, target_rows / 4);
+        job.bounds.push_back(q);
+      }
+    const size_t rest = ppk_rows_in_band(job.n_ref, job.n_qry, q, hi);
+    size_t pieces = (rest + target_rows - 1) / target_rows;
+    for (size_t k = 1; k < pieces && q < hi; ++k) {
+      q = cut_at(q, hi, ppk_rows_in_band(job.n_ref, job.n_qry, q, hi) / (pieces - k + 1));
+      job.bounds.push_back(q);
+    }
+    if (q < hi || job.bounds.size() - 1 == job.work[(size_t)u].c_begin) job.bounds.push_back(hi);
+    job.work[(size_t)u].c_end = job.bounds.size() - 1;
+  }
+  for (int u = 0; u < n_u; ++u) job.work[(size_t)u].next->store((size_t)entries[(size_t)u]);
+  job.n_chunks = job.bounds.size() - 1;
+  job.chunk_state.reset(new std::atomic<int>[job.n_chunks]);
+  for (size_t i = 0; i < job.n_chunks; ++i) job.chunk_state[i].store(0);
+  job.chunk_ev.assign(job.n_chunks, nullptr);
+  job.row0.assign(job.n_chunks + 1, 0);                         // first output row of every sub-band
   job.max_rows = 0;
-  for (int i = 0; i < n_dev * C; ++i) {
+  for (size_t i = 0; i < job.n_chunks; ++i) {
     const size_t r = ppk_rows_in_band(job.n_ref, job.n_qry, job.bounds[i], job.bounds[i + 1]);
     job.row0[i + 1] = job.row0[i] + r;
     if (r > job.max_rows) job.max_rows = r;
   }
-  // helper threads touch the result array's pages ahead of the downloads (HostToucher)
+  // helper threads touch the result array's pages ahead of the downloads (HostToucher), in the order the
+  // downloads will want them: the k-th sub-band of every device before the (k+1)-th of any
   g_trace.mark(-1, "plan_done");
-  // the pages are touched in the order the downloads will want them: sub-band c of every entry before c+1 of any
   std::vector<std::pair<size_t, size_t>> segs;
-  job.seg_of.assign((size_t)n_dev * C, 0);
-  for (int c = 0; c < C; ++c)
-    for (int d = 0; d < n_dev; ++d) {
-      const size_t i = (size_t)d * C + c;
+  job.seg_of.assign(job.n_chunks, 0);
+  for (size_t k = 0;; ++k) {
+    bool any = false;
+    for (int u = 0; u < n_u; ++u) {
+      const size_t i = job.work[(size_t)u].c_begin + k;
+      if (i >= job.work[(size_t)u].c_end) continue;
+      any = true;
       job.seg_of[i] = segs.size();
       segs.emplace_back(job.row0[i] * job.cols * 4, job.row0[i + 1] * job.cols * 4);
     }
-  HostToucher toucher(job.out, job.row0[(size_t)n_dev * C] * job.cols * 4, std::move(segs));
+    if (!any) break;
+  }
+  HostToucher toucher(job.out, job.row0[job.n_chunks] * job.cols * 4, std::move(segs));
   job.toucher = &toucher;
   g_trace.mark(-1, "toucher_up");
+  const int C = (int)job.n_chunks;
   const long long prog = ppk_config().progress.load();          // 1: jobs of >= ~0.1 s of work; 2: any multi-band job
   const bool meter = prog != 0 && C >= 4 && (prog >= 2 || total_rows >= ((size_t)1 << 29));
   g_qstats.dl_now = 0;
@@ -1365,14 +1494,14 @@ int run_query(QueryJob &job, std::vector<QueryPart> &parts, unsigned long long *
     run_part(job, parts, 0, true, meter);
   } else {
     g_qstats.threads = n_dev;
-    std::vector<std::thread> th;
+    std::vector<PpkTicket> th;
     for (int d = 0; d < n_dev; ++d)
-      th.emplace_back([&job, &parts, d]() {
+      th.push_back(ppk_pool_run([&job, &parts, d]() {
         run_part(job, parts, d, false, false);
         job.parts_done.fetch_add(1);
-      });
+      }));
     // the calling thread: Ctrl-C and the meter (a Python signal handler only ever runs on this thread)
-    const long long all_chunks = (long long)n_dev * C;
+    const long long all_chunks = (long long)job.n_chunks;
     bool was_interrupted = false;
     while (job.parts_done.load() < n_dev) {
       if (!was_interrupted && interrupted()) {
@@ -1382,7 +1511,7 @@ int run_query(QueryJob &job, std::vector<QueryPart> &parts, unsigned long long *
       if (meter) progress_line((double)job.done_chunks.load() / (double)(all_chunks + 1), false);
       std::this_thread::sleep_for(std::chrono::microseconds(200));
     }
-    for (auto &t : th) t.join();
+    for (auto &t : th) ppk_pool_wait(t);
     if (was_interrupted) rc = ppk_fail(PPK_ERR_INTERRUPTED, "interrupted");
   }
   g_trace.mark(-1, "parts_done");

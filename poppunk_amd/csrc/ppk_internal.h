@@ -7,6 +7,7 @@
 #include <atomic>
 #include <functional>
 #include <cstdlib>
+#include <memory>
 #include <thread>
 #include <vector>
 #include <hip/hip_runtime.h>
@@ -185,6 +186,16 @@ __device__ __forceinline__ float ppk_line_dist(float x0, float y0, float x_max, 
   return side;
 }
 
+// ---- helper threads ----------------------------------------------------------------
+// A host call uses a dozen short-lived helpers (page touchers, per-device workers, hash lanes); starting
+// a thread costs 30-100 us and jitters to several hundred, which is the scale of the call's whole start-up.
+// They are therefore taken from a grow-only pool of parked threads (ppk_api.hip).  A task's completion is
+// the ticket's flag; ppk_pool_wait spins with yield (tasks here last from 0.1 to 10 ms).  A forked child
+// starts with an empty pool of its own.
+typedef std::shared_ptr<std::atomic<int>> PpkTicket;
+PpkTicket ppk_pool_run(std::function<void()> fn);
+void ppk_pool_wait(const PpkTicket &t);
+
 // ---- pre-touching of host result arrays -------------------------------------------
 // A result lands in the caller's (normally freshly allocated, not yet touched) pageable array:
 // its first-touch page faults -- one per 4 KB, taken serially by the runtime's staging copy --
@@ -224,7 +235,7 @@ class HostToucher {
     for (auto &a : done_) a.store(0);
     // the first helper advises the kernel and starts the others: the constructor itself returns at once (the
     // advice on 400 MB plus eight thread starts were 0.2 ms in front of the first kernel launch)
-    if (nt > 0) threads_.emplace_back([this]() { lead(); });
+    if (nt > 0) lead_ = ppk_pool_run([this]() { lead(); });
   }
   ~HostToucher() { join(); }
   HostToucher(const HostToucher &) = delete;
@@ -242,8 +253,8 @@ class HostToucher {
     wait_blocks(i < seg_end_.size() ? seg_end_[i] : n_blocks_);
   }
   void join() {
-    for (auto &t : threads_)
-      if (t.joinable()) t.join();
+    if (lead_) ppk_pool_wait(lead_);
+    lead_.reset();
   }
 
  private:
@@ -262,10 +273,10 @@ class HostToucher {
     // allocations; other callers' arrays get it here.  Advice only: failure is harmless.
     const size_t a0 = ((size_t)out_ + kBlock - 1) / kBlock * kBlock, a1 = ((size_t)out_ + total_) / kBlock * kBlock;
     if (a1 > a0) (void)madvise(reinterpret_cast<void *>(a0), a1 - a0, MADV_HUGEPAGE);
-    std::vector<std::thread> helpers;
-    for (int t = 1; t < nt_; ++t) helpers.emplace_back([this, t]() { run(t); });
+    std::vector<PpkTicket> helpers;
+    for (int t = 1; t < nt_; ++t) helpers.push_back(ppk_pool_run([this, t]() { run(t); }));
     run(0);
-    for (auto &h : helpers) h.join();
+    for (auto &h : helpers) ppk_pool_wait(h);
   }
   void run(int t) {
     volatile char *base = static_cast<volatile char *>(out_);
@@ -283,6 +294,6 @@ class HostToucher {
   int nt_ = 0;
   std::vector<size_t> order_, seg_end_;
   std::vector<std::atomic<size_t>> done_;
-  std::vector<std::thread> threads_;
+  PpkTicket lead_;
 };
 
