@@ -114,6 +114,7 @@ const OptionEntry kOptions[] = {
     {"db_cache", "PPK_DB_CACHE", &PpkConfig::db_cache},
     {"progress", "PPK_PROGRESS", &PpkConfig::progress},
     {"host_parts", "PPK_HOST_PARTS", &PpkConfig::host_parts},
+    {"host_trace", "PPK_HOST_TRACE", &PpkConfig::host_trace},
     {"ext_collision_adjust", "PPK_EXT_COLLISION_ADJUST", &PpkConfig::ext_collision_adjust},
     {"ext_fit_skip", "PPK_EXT_FIT_SKIP", &PpkConfig::ext_fit_skip},
 };
@@ -1195,13 +1196,13 @@ double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-// PPK_HOST_TRACE=1 (measurement): one line per event of a host query on fd 2, ms since the call began
+// option "host_trace" / PPK_HOST_TRACE=1 (measurement): one line per event of a host query on fd 2, ms since
+// the call began
 struct HostTrace {
-  bool on = getenv("PPK_HOST_TRACE") != nullptr;
   double t0 = 0.0;
   std::mutex mu;
   void mark(int part, const char *what, long long arg = -1) {
-    if (!on) return;
+    if (ppk_config().host_trace.load() == 0) return;
     char buf[128];
     const int n = snprintf(buf, sizeof(buf), "trace part %d %-14s %lld  %.3f ms\n", part, what, arg, now_ms() - t0);
     std::lock_guard<std::mutex> lk(mu);

@@ -44,6 +44,7 @@ struct PpkConfig {
   std::atomic<long long> prefault_threads{8};   // PPK_PREFAULT_THREADS
   std::atomic<long long> db_cache{1};           // PPK_DB_CACHE: ppk_query keeps its resident databases / buffers
   std::atomic<long long> progress{1};           // PPK_PROGRESS: progress meter of long host calls on fd 2
+  std::atomic<long long> host_trace{0};         // PPK_HOST_TRACE: timeline of a host query on fd 2 (measurement)
   std::atomic<long long> host_parts{2};         // PPK_HOST_PARTS: worker threads of a one-device host query (>= 16 Mi rows)
   // [EXT] a4: 0 = the b-bit collision adjustment is never in effect (upstream as recalled: it is
   // gated on expected == 0, where it is the identity); 1 = applied when expected > 0
