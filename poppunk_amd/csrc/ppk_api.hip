@@ -98,6 +98,60 @@ void ppk_pool_wait(const PpkTicket &t) {
   while (t->load(std::memory_order_acquire) == 0) std::this_thread::yield();
 }
 
+// ---- staged uploads (ppk_internal.h) ----------------------------------------------------------------
+namespace {
+struct UploadRing {
+  std::mutex mu;                       // one upload at a time per device
+  void *slot[2] = {nullptr, nullptr};
+  hipEvent_t freed[2] = {nullptr, nullptr};
+  bool used[2] = {false, false};
+};
+UploadRing g_ring[64];
+constexpr size_t kUploadPiece = (size_t)32 << 20;
+}  // namespace
+
+int ppk_upload(int device, void *d_dst, const void *h_src, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return PPK_OK;
+  if (device < 0 || device >= 64) return ppk_fail(PPK_ERR_ARG, "device id out of range");
+  int nt = (int)ppk_config().prefault_threads.load();
+  if (bytes < ((size_t)4 << 20) || nt < 1) {      // small: the runtime's own path
+    PPK_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, s));
+    return PPK_OK;
+  }
+  if (nt > 16) nt = 16;
+  UploadRing &r = g_ring[device];
+  std::lock_guard<std::mutex> lk(r.mu);
+  for (int i = 0; i < 2; ++i) {
+    if (!r.slot[i] && hipHostMalloc(&r.slot[i], kUploadPiece, hipHostMallocDefault) != hipSuccess) {
+      r.slot[i] = nullptr;
+      PPK_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, s));      // no pinned memory: the plain path
+      return PPK_OK;
+    }
+    if (!r.freed[i]) PPK_HIP(hipEventCreateWithFlags(&r.freed[i], hipEventDisableTiming));
+  }
+  const char *src = static_cast<const char *>(h_src);
+  char *dst = static_cast<char *>(d_dst);
+  int i = 0;
+  for (size_t off = 0; off < bytes; off += kUploadPiece, i ^= 1) {
+    const size_t len = bytes - off < kUploadPiece ? bytes - off : kUploadPiece;
+    if (r.used[i]) PPK_HIP(hipEventSynchronize(r.freed[i]));      // the DMA that last read this slot is done
+    char *stage = static_cast<char *>(r.slot[i]);
+    const size_t per = (len + (size_t)nt - 1) / (size_t)nt;
+    std::vector<PpkTicket> th;
+    auto copy = [&](int t) {
+      const size_t a = (size_t)t * per, b = a + per < len ? a + per : len;
+      if (a < b) memcpy(stage + a, src + off + a, b - a);
+    };
+    for (int t = 1; t < nt; ++t) th.push_back(ppk_pool_run([&copy, t]() { copy(t); }));
+    copy(0);
+    for (auto &t : th) ppk_pool_wait(t);
+    PPK_HIP(hipMemcpyAsync(dst + off, stage, len, hipMemcpyHostToDevice, s));
+    PPK_HIP(hipEventRecord(r.freed[i], s));
+    r.used[i] = true;
+  }
+  return PPK_OK;
+}
+
 // ---- run-time options: PPK_* environment read once, then ppk_set_option only ------------------
 namespace {
 struct OptionEntry {
@@ -369,10 +423,10 @@ extern "C" int ppk_db_create(int device_id, const uint64_t *sk, size_t n, size_t
   if (!src_on_device) {
     e = hipMalloc(reinterpret_cast<void **>(&d_stage), in_bytes);
     if (e != hipSuccess) return bail(PPK_ERR_HIP, std::string("hipMalloc(stage): ") + hipGetErrorString(e));
-    e = hipMemcpyAsync(d_stage, sk, in_bytes, hipMemcpyHostToDevice, s);
-    if (e != hipSuccess) {
+    if (ppk_upload(device_id, d_stage, sk, in_bytes, s) != PPK_OK) {
+      const std::string why = g_err;
       (void)hipFree(d_stage);
-      return bail(PPK_ERR_HIP, std::string("hipMemcpy(sketches): ") + hipGetErrorString(e));
+      return bail(PPK_ERR_HIP, "upload of the sketches: " + why);
     }
     d_in = d_stage;
   }
@@ -584,9 +638,23 @@ PpkCall::~PpkCall() {
   g_dev[dev_].mu.unlock();
 }
 
+void ppk_assign_bufs_release_all();
 extern "C" int ppk_release_scratch(void) {
   ppk_query_cache_clear();
   ppk_parked_clear();
+  ppk_assign_bufs_release_all();
+  for (int d = 0; d < 64; ++d) {                 // the pinned upload rings
+    UploadRing &r = g_ring[d];
+    std::lock_guard<std::mutex> lk(r.mu);
+    for (int i = 0; i < 2; ++i) {
+      if (r.used[i] && r.freed[i]) (void)hipEventSynchronize(r.freed[i]);
+      if (r.slot[i]) (void)hipHostFree(r.slot[i]);
+      if (r.freed[i]) (void)hipEventDestroy(r.freed[i]);
+      r.slot[i] = nullptr;
+      r.freed[i] = nullptr;
+      r.used[i] = false;
+    }
+  }
   for (int d = 0; d < 64; ++d) {
     std::lock_guard<std::recursive_mutex> lk(g_dev[d].mu);
     bool any = false;
@@ -1716,28 +1784,63 @@ extern "C" int ppk_query_last_stats(double *vals, int n) {
   return PPK_OK;
 }
 
+// persistent per-device buffers of the host-array assign path (hipMalloc + hipFree of its four buffers cost
+// more than its transfers: 10 of the call's 24 ms at 5e7 rows); freed by ppk_release_scratch
+namespace {
+struct AssignBufs {
+  std::mutex mu;                 // one host assign at a time per device
+  float *d_in[2] = {nullptr, nullptr}, *d_out[2] = {nullptr, nullptr};
+  size_t rows = 0;
+  hipEvent_t up[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr}, freed_in[2] = {nullptr, nullptr};
+};
+AssignBufs g_assign[64];
+void assign_bufs_release(int d) {
+  AssignBufs &a = g_assign[d];
+  std::lock_guard<std::mutex> lk(a.mu);
+  if (!a.d_in[0] && !a.up[0]) return;
+  DeviceGuard guard(d);
+  (void)hipDeviceSynchronize();
+  for (int i = 0; i < 2; ++i) {
+    if (a.d_in[i]) (void)hipFree(a.d_in[i]);
+    if (a.d_out[i]) (void)hipFree(a.d_out[i]);
+    if (a.up[i]) (void)hipEventDestroy(a.up[i]);
+    if (a.done[i]) (void)hipEventDestroy(a.done[i]);
+    if (a.freed_in[i]) (void)hipEventDestroy(a.freed_in[i]);
+    a.d_in[i] = a.d_out[i] = nullptr;
+    a.up[i] = a.done[i] = a.freed_in[i] = nullptr;
+  }
+  a.rows = 0;
+}
+}  // namespace
+void ppk_assign_bufs_release_all() {
+  for (int d = 0; d < 64; ++d) assign_bufs_release(d);
+}
+
 extern "C" int ppk_assign_threshold(const float *dist, size_t n_rows, int slope, float x_max,
                                     float y_max, int device_id, float *out) {
   if (n_rows == 0) return PPK_OK;
   if (!dist || !out) return ppk_fail(PPK_ERR_ARG, "NULL distance/output buffer");
+  if (device_id < 0 || device_id >= 64) return ppk_fail(PPK_ERR_ARG, "device id out of range");
   DeviceGuard guard(device_id);
   if (!guard.ok) return ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(device_id));
-  // 12 bytes per row over PCIe against 0.002 ns of kernel: the rows go through in chunks, the upload
-  // of chunk c+1, the kernel of chunk c and the download of chunk c-1 on three streams, and the
-  // (fresh) result array is pre-touched by helper threads.  Chunk edges are multiples of 64 rows.
-  const size_t chunk = (size_t)8 << 20;                                  // rows: 64 MB in, 32 MB out
+  // 12 bytes per row over PCIe against 0.002 ns of kernel: the rows go through in chunks of 64 MB in / 32 MB out.
+  // Step c stages and uploads chunk c (ppk_upload: helper threads copy it into a pinned ring, the DMA runs on
+  // behind), launches its kernel, and only then fetches chunk c-1 -- that copy into pageable memory blocks the
+  // calling thread, and chunk c's DMA is on the link meanwhile (PCIe is full duplex).  The (fresh) result array
+  // is pre-touched by helper threads.  Chunk edges are multiples of 64 rows.
+  const size_t chunk = (size_t)8 << 20;
   const size_t n_chunks = (n_rows + chunk - 1) / chunk;
   const size_t buf_rows = n_rows < chunk ? n_rows : chunk;
-  float *d_in[2] = {nullptr, nullptr}, *d_out[2] = {nullptr, nullptr};
-  hipStream_t s_up = nullptr, s_k = nullptr, s_dn = nullptr;
-  hipEvent_t up[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr}, freed_in[2] = {nullptr, nullptr},
-             freed_out[2] = {nullptr, nullptr};
+  AssignBufs &ab = g_assign[device_id];
+  std::lock_guard<std::mutex> lk(ab.mu);
   int rc = PPK_OK;
   auto ok = [&](hipError_t e, const char *what) {
     if (e != hipSuccess && rc == PPK_OK) rc = ppk_fail(PPK_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
     return rc == PPK_OK;
   };
+  g_trace.t0 = now_ms();
   HostToucher toucher(out, n_rows * 4);
+  hipStream_t s_up = nullptr, s_k = nullptr, s_dn = nullptr;
   {
     hipStream_t ws[3] = {nullptr, nullptr, nullptr};
     if (worker_streams(device_id, ws, 3) != PPK_OK) return PPK_ERR_HIP;
@@ -1745,45 +1848,60 @@ extern "C" int ppk_assign_threshold(const float *dist, size_t n_rows, int slope,
     s_k = ws[1];
     s_dn = ws[2];
   }
-  const int n_buf = n_chunks > 1 ? 2 : 1;
-  for (int i = 0; i < n_buf && rc == PPK_OK; ++i) {
-    ok(hipMalloc(reinterpret_cast<void **>(&d_in[i]), buf_rows * 8), "hipMalloc");
-    ok(hipMalloc(reinterpret_cast<void **>(&d_out[i]), buf_rows * 4), "hipMalloc");
-    ok(hipEventCreateWithFlags(&up[i], hipEventDisableTiming), "hipEventCreate");
-    ok(hipEventCreateWithFlags(&done[i], hipEventDisableTiming), "hipEventCreate");
-    ok(hipEventCreateWithFlags(&freed_in[i], hipEventDisableTiming), "hipEventCreate");
-    ok(hipEventCreateWithFlags(&freed_out[i], hipEventDisableTiming), "hipEventCreate");
+  if (ab.rows < buf_rows) {
+    (void)hipDeviceSynchronize();
+    for (int i = 0; i < 2; ++i) {
+      if (ab.d_in[i]) (void)hipFree(ab.d_in[i]);
+      if (ab.d_out[i]) (void)hipFree(ab.d_out[i]);
+      ab.d_in[i] = ab.d_out[i] = nullptr;
+    }
+    ab.rows = 0;
+    for (int i = 0; i < 2 && rc == PPK_OK; ++i) {
+      ok(hipMalloc(reinterpret_cast<void **>(&ab.d_in[i]), buf_rows * 8), "hipMalloc");
+      ok(hipMalloc(reinterpret_cast<void **>(&ab.d_out[i]), buf_rows * 4), "hipMalloc");
+    }
+    if (rc == PPK_OK) ab.rows = buf_rows;
   }
-  for (size_t c = 0; c < n_chunks && rc == PPK_OK; ++c) {
-    const int b = (int)(c & 1) % n_buf;
-    const size_t r0 = c * chunk, nr = r0 + chunk < n_rows ? chunk : n_rows - r0;
-    if (c >= 2) ok(hipStreamWaitEvent(s_up, freed_in[b], 0), "hipStreamWaitEvent");      // kernel c-2 has read d_in[b]
-    ok(hipMemcpyAsync(d_in[b], dist + r0 * 2, nr * 8, hipMemcpyHostToDevice, s_up), "hipMemcpy H2D");
-    ok(hipEventRecord(up[b], s_up), "hipEventRecord");
-    ok(hipStreamWaitEvent(s_k, up[b], 0), "hipStreamWaitEvent");
-    if (c >= 2) ok(hipStreamWaitEvent(s_k, freed_out[b], 0), "hipStreamWaitEvent");     // download c-2 has read d_out[b]
-    if (rc == PPK_OK) rc = ppk_assign_threshold_dev(d_in[b], nr, slope, x_max, y_max, d_out[b], s_k);
-    ok(hipEventRecord(done[b], s_k), "hipEventRecord");
-    ok(hipEventRecord(freed_in[b], s_k), "hipEventRecord");
-    ok(hipStreamWaitEvent(s_dn, done[b], 0), "hipStreamWaitEvent");
-    toucher.wait((r0 + nr) * 4);
-    ok(hipMemcpyAsync(out + r0, d_out[b], nr * 4, hipMemcpyDeviceToHost, s_dn), "hipMemcpy D2H");
-    ok(hipEventRecord(freed_out[b], s_dn), "hipEventRecord");
+  for (int i = 0; i < 2 && rc == PPK_OK; ++i) {
+    if (!ab.up[i]) ok(hipEventCreateWithFlags(&ab.up[i], hipEventDisableTiming), "hipEventCreate");
+    if (!ab.done[i]) ok(hipEventCreateWithFlags(&ab.done[i], hipEventDisableTiming), "hipEventCreate");
+    if (!ab.freed_in[i]) ok(hipEventCreateWithFlags(&ab.freed_in[i], hipEventDisableTiming), "hipEventCreate");
   }
+  for (size_t c = 0; c <= n_chunks && rc == PPK_OK; ++c) {
+    if (c < n_chunks) {
+      const int b = (int)(c & 1);
+      const size_t r0 = c * chunk, nr = r0 + chunk < n_rows ? chunk : n_rows - r0;
+      if (c >= 2) ok(hipStreamWaitEvent(s_up, ab.freed_in[b], 0), "hipStreamWaitEvent");      // kernel c-2 has read d_in[b]
+      g_trace.mark(0, "a_up_begin", (long long)c);
+      if (rc == PPK_OK) rc = ppk_upload(device_id, ab.d_in[b], dist + r0 * 2, nr * 8, s_up);
+      g_trace.mark(0, "a_up_end", (long long)c);
+      ok(hipEventRecord(ab.up[b], s_up), "hipEventRecord");
+      ok(hipStreamWaitEvent(s_k, ab.up[b], 0), "hipStreamWaitEvent");
+      // (d_out[b] is free: chunk c-2 was fetched, synchronously, in step c-1)
+      if (rc == PPK_OK) rc = ppk_assign_threshold_dev(ab.d_in[b], nr, slope, x_max, y_max, ab.d_out[b], s_k);
+      ok(hipEventRecord(ab.done[b], s_k), "hipEventRecord");
+      ok(hipEventRecord(ab.freed_in[b], s_k), "hipEventRecord");
+    }
+    if (c > 0 && rc == PPK_OK) {
+      const size_t p = c - 1;
+      const int b = (int)(p & 1);
+      const size_t r0 = p * chunk, nr = r0 + chunk < n_rows ? chunk : n_rows - r0;
+      ok(hipStreamWaitEvent(s_dn, ab.done[b], 0), "hipStreamWaitEvent");
+      toucher.wait((r0 + nr) * 4);
+      g_trace.mark(0, "a_dn_begin", (long long)p);
+      ok(hipMemcpyAsync(out + r0, ab.d_out[b], nr * 4, hipMemcpyDeviceToHost, s_dn), "hipMemcpy D2H");
+      ok(hipStreamSynchronize(s_dn), "hipMemcpy D2H");
+      g_trace.mark(0, "a_dn_end", (long long)p);
+    }
+  }
+  g_trace.mark(0, "a_loop_done");
+  const std::string keep = g_err;
   if (s_up) (void)hipStreamSynchronize(s_up);
   if (s_k) ok(hipStreamSynchronize(s_k), "assign kernel");
   if (s_dn) ok(hipStreamSynchronize(s_dn), "hipMemcpy D2H");
+  g_trace.mark(0, "a_synced");
   toucher.join();
-  const std::string keep = g_err;
-  for (int i = 0; i < 2; ++i) {
-    if (d_in[i]) (void)hipFree(d_in[i]);
-    if (d_out[i]) (void)hipFree(d_out[i]);
-    if (up[i]) (void)hipEventDestroy(up[i]);
-    if (done[i]) (void)hipEventDestroy(done[i]);
-    if (freed_in[i]) (void)hipEventDestroy(freed_in[i]);
-    if (freed_out[i]) (void)hipEventDestroy(freed_out[i]);
-  }
-  if (rc != PPK_OK) g_err = keep;
+  if (rc != PPK_OK && !keep.empty()) g_err = keep;
   return rc;
 }
 
@@ -1906,21 +2024,22 @@ extern "C" int ppk_edge_threshold(const float *dist, size_t n_rows, size_t n_ref
   };
   return ppk_host_result(1, device_id, guess, cap, n_edges,
                          [&](size_t c, void **d_res, unsigned long long *want) {
-                           float *d_dist = nullptr;
+                           // the uploaded matrix sits in a persistent scratch block (hipMalloc + hipFree of
+                           // 400 MB per call cost 20+ ms)
+                           PpkCall call(device_id, nullptr);
+                           void *p_in = nullptr;
                            unsigned long long *d_n = nullptr;
-                           int rc = PPK_OK;
-                           if (hipMalloc(reinterpret_cast<void **>(&d_dist), n_rows * 8) != hipSuccess ||
-                               hipMalloc(reinterpret_cast<void **>(&d_n), 8) != hipSuccess ||
-                               hipMalloc(d_res, (c ? c : 1) * 16) != hipSuccess)
+                           int rc = scratch_get(device_id, SLOT_HOST_IN, n_rows * 8 + 8, &p_in);
+                           float *d_dist = static_cast<float *>(p_in);
+                           if (rc == PPK_OK && (hipMalloc(reinterpret_cast<void **>(&d_n), 8) != hipSuccess ||
+                                                hipMalloc(d_res, (c ? c : 1) * 16) != hipSuccess))
                              rc = ppk_fail(PPK_ERR_HIP, "hipMalloc failed");
-                           if (rc == PPK_OK && hipMemcpy(d_dist, dist, n_rows * 8, hipMemcpyHostToDevice) != hipSuccess)
-                             rc = ppk_fail(PPK_ERR_HIP, "hipMemcpy H2D failed");
+                           if (rc == PPK_OK) rc = ppk_upload(device_id, d_dist, dist, n_rows * 8, nullptr);
                            if (rc == PPK_OK)
                              rc = ppk_edge_threshold_dev(d_dist, n_rows, n_ref, slope, x_max, y_max, inclusive,
                                                          static_cast<long long *>(*d_res), c, d_n, nullptr);
                            if (rc == PPK_OK && hipMemcpy(want, d_n, 8, hipMemcpyDeviceToHost) != hipSuccess)
                              rc = ppk_fail(PPK_ERR_HIP, "hipMemcpy D2H failed");
-                           if (d_dist) (void)hipFree(d_dist);
                            if (d_n) (void)hipFree(d_n);
                            return rc;
                          },
@@ -1945,21 +2064,20 @@ extern "C" int ppk_generate_tuples(const int32_t *assignments, size_t n_rows, in
   };
   return ppk_host_result(1, device_id, guess, cap, n_edges,
                          [&](size_t c, void **d_res, unsigned long long *want) {
-                           int32_t *d_a = nullptr;
+                           PpkCall call(device_id, nullptr);
+                           void *p_in = nullptr;
                            unsigned long long *d_n = nullptr;
-                           int rc = PPK_OK;
-                           if (hipMalloc(reinterpret_cast<void **>(&d_a), n_rows * 4) != hipSuccess ||
-                               hipMalloc(reinterpret_cast<void **>(&d_n), 8) != hipSuccess ||
-                               hipMalloc(d_res, (c ? c : 1) * 16) != hipSuccess)
+                           int rc = scratch_get(device_id, SLOT_HOST_IN, n_rows * 4 + 8, &p_in);
+                           int32_t *d_a = static_cast<int32_t *>(p_in);
+                           if (rc == PPK_OK && (hipMalloc(reinterpret_cast<void **>(&d_n), 8) != hipSuccess ||
+                                                hipMalloc(d_res, (c ? c : 1) * 16) != hipSuccess))
                              rc = ppk_fail(PPK_ERR_HIP, "hipMalloc failed");
-                           if (rc == PPK_OK && hipMemcpy(d_a, assignments, n_rows * 4, hipMemcpyHostToDevice) != hipSuccess)
-                             rc = ppk_fail(PPK_ERR_HIP, "hipMemcpy H2D failed");
+                           if (rc == PPK_OK) rc = ppk_upload(device_id, d_a, assignments, n_rows * 4, nullptr);
                            if (rc == PPK_OK)
                              rc = ppk_generate_tuples_dev(d_a, n_rows, within_label, self, num_ref, int_offset,
                                                           static_cast<long long *>(*d_res), c, d_n, nullptr);
                            if (rc == PPK_OK && hipMemcpy(want, d_n, 8, hipMemcpyDeviceToHost) != hipSuccess)
                              rc = ppk_fail(PPK_ERR_HIP, "hipMemcpy D2H failed");
-                           if (d_a) (void)hipFree(d_a);
                            if (d_n) (void)hipFree(d_n);
                            return rc;
                          },

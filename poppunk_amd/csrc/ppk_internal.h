@@ -123,7 +123,7 @@ int ppk_launch_assign(const float *d_dist, size_t n_rows, int slope, float x_max
 
 // grow-only per-device scratch (ppk_api.hip)
 enum { SLOT_LUT = 0, SLOT_MASK = 1, SLOT_WS = 2, SLOT_ITER_A = 3, SLOT_ITER_B = 4, SLOT_ITER_C = 5,
-       SLOT_BOUNDS = 6, SLOT_COUNT = 7 };
+       SLOT_BOUNDS = 6, SLOT_HOST_IN = 7, SLOT_COUNT = 8 };      // HOST_IN: the uploaded input of a host-array call
 int ppk_scratch_get(int dev, int slot, size_t bytes, void **out);
 void ppk_lut_commit(int dev, const void *d_lut);
 // Scope of one entry point that uses the scratch of `dev`: holds that device's (recursive) mutex and
@@ -196,6 +196,14 @@ __device__ __forceinline__ float ppk_line_dist(float x0, float y0, float x_max, 
 typedef std::shared_ptr<std::atomic<int>> PpkTicket;
 PpkTicket ppk_pool_run(std::function<void()> fn);
 void ppk_pool_wait(const PpkTicket &t);
+
+// ---- uploads of pageable host arrays ---------------------------------------------------
+// hipMemcpy from PAGEABLE host memory goes through the runtime's bounce buffer with one thread copying:
+// ~20 GB/s on this host, a third of the link, and several copies in flight do not help (tools/
+// ab_k2_threads.py).  ppk_upload stages the array itself: helper threads copy 32 MB pieces into a pinned ring
+// (kept per device) and each piece goes on as an asynchronous DMA while the next is being copied.  Returns
+// when the last host piece has been copied (the caller may re-use `h_src`); the DMAs are ordered on `s`.
+int ppk_upload(int device, void *d_dst, const void *h_src, size_t bytes, hipStream_t s);
 
 // ---- pre-touching of host result arrays -------------------------------------------
 // A result lands in the caller's (normally freshly allocated, not yet touched) pageable array:

@@ -457,19 +457,20 @@ int host_coo(const float *dist, size_t n_rows, size_t n_off, int device_id, long
   size_t guess = n_rows / 4 > ((size_t)1 << 20) ? n_rows / 4 : ((size_t)1 << 20);
   if (guess > n_rows * (n_off ? n_off : 1)) guess = n_rows * (n_off ? n_off : 1);
   auto compute = [&](size_t c, void **d_res, unsigned long long *want) {
-    float *d_dist = nullptr;
+    // the uploaded matrix sits in a persistent scratch block (SLOT_HOST_IN), not in a per-call allocation
+    PpkCall call(device_id, nullptr);
+    void *p_in = nullptr;
     unsigned long long *d_n = nullptr;
-    int rc = PPK_OK;
-    if (hipMalloc(reinterpret_cast<void **>(&d_dist), n_rows * 8) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void **>(&d_n), 8) != hipSuccess || hipMalloc(d_res, c * 24) != hipSuccess)
+    int rc = ppk_scratch_get(device_id, SLOT_HOST_IN, n_rows * 8 + 8, &p_in);
+    float *d_dist = static_cast<float *>(p_in);
+    if (rc == PPK_OK &&
+        (hipMalloc(reinterpret_cast<void **>(&d_n), 8) != hipSuccess || hipMalloc(d_res, c * 24) != hipSuccess))
       rc = ppk_fail(PPK_ERR_HIP, "hipMalloc failed");
-    if (rc == PPK_OK && hipMemcpy(d_dist, dist, n_rows * 8, hipMemcpyHostToDevice) != hipSuccess)
-      rc = ppk_fail(PPK_ERR_HIP, "hipMemcpy H2D failed");
+    if (rc == PPK_OK) rc = ppk_upload(device_id, d_dist, dist, n_rows * 8, nullptr);
     long long *buf = static_cast<long long *>(*d_res);
     if (rc == PPK_OK) rc = enqueue(d_dist, buf, buf + c, buf + 2 * c, c, d_n);
     if (rc == PPK_OK && hipMemcpy(want, d_n, 8, hipMemcpyDeviceToHost) != hipSuccess)
       rc = ppk_fail(PPK_ERR_HIP, "hipMemcpy D2H failed");
-    if (d_dist) (void)hipFree(d_dist);
     if (d_n) (void)hipFree(d_n);
     return rc;
   };
