@@ -1453,7 +1453,7 @@ void run_part(QueryJob &job, std::vector<QueryPart> &parts, int d, bool poll, bo
 // thread per device (run_part); the calling thread runs the interrupt check and the progress meter.
 int run_query(QueryJob &job, std::vector<QueryPart> &parts, unsigned long long *n_failed) {
   const double t_begin = now_ms();
-  g_trace.t0 = t_begin;
+  if (g_trace.t0 == 0.0 || t_begin - g_trace.t0 > 1000.0) g_trace.t0 = t_begin;      // (ppk_query_dbs set it at its entry)
   const int n_dev = (int)parts.size();
   const bool self = (job.n_qry == 0);
   const size_t nq = self ? job.n_ref : job.n_qry;
@@ -1737,6 +1737,8 @@ extern "C" int ppk_query_dbs(const ppk_db *const *refs, const ppk_db *const *qry
   const size_t n_qry = q0 ? q0->n : 0;
   if (ppk_rows_in_band(refs[0]->n, n_qry, 0, q0 ? q0->n : refs[0]->n) == 0) return PPK_OK;
   std::lock_guard<std::mutex> lk(g_query_mu);
+  g_trace.t0 = now_ms();
+  g_trace.mark(-1, "enter");
   const int n_given = n_dev;
   if (n_dev == 1) {
     n_dev = single_device_entries(refs[0]->n, n_qry);
@@ -1745,6 +1747,7 @@ extern "C" int ppk_query_dbs(const ppk_db *const *refs, const ppk_db *const *qry
   std::vector<QueryPart> parts((size_t)n_dev);
   int rc = prepare_parts(parts, devices.data());
   if (rc != PPK_OK) return rc;
+  g_trace.mark(-1, "prepared");
   for (int d = 0; d < n_dev; ++d) {
     parts[(size_t)d].ref = refs[n_given == 1 ? 0 : d];
     parts[(size_t)d].qry = qrys ? qrys[n_given == 1 ? 0 : d] : nullptr;
