@@ -238,7 +238,8 @@ int ppk_threshold_iterate_2d_dev(const float *d_dist, size_t n_rows, const float
  * helper threads touch its pages ahead of the download (option "prefault_threads", default 8, 0 = off).
  * The resident form of the sketches and the two buffers are KEPT between calls, keyed by the host
  * pointer, the dimensions and a 64-bit hash of EVERY word of the array (computed on the helper threads,
- * ~1-2 ms per 90 MB): an array rewritten in place, or another one at a recycled address, is uploaded
+ * ~0.6 ms per 90 MB, WHILE the job already runs on the resident copy; checked before the call returns):
+ * an array rewritten in place, or another one at a recycled address, is uploaded again and the job run
  * again -- there is no stale-answer mode.  Option "db_cache" 0 turns the cache off; ppk_release_scratch
  * frees it; at most 4 databases per device are kept, and they are dropped first when device memory
  * runs out.  A caller that knows its data's identity avoids the hash altogether by holding ppk_db
@@ -273,7 +274,8 @@ int ppk_query_db(const ppk_db *ref, const ppk_db *qry, const int32_t *kmers,
 /* What the last ppk_query / ppk_query_dbs of the process ran side by side (measurement, tests):
  * vals[0] device entries, [1] worker threads (0 = ran on the calling thread), [2] most result
  * downloads in flight at one time, [3] most sketch uploads in flight at one time, [4] wall ms of the
- * device phase, [5] longest upload ms, [6] longest per-device ms. */
+ * device phase, [5] longest upload ms, [6] longest per-device ms, [7] ppk_query calls since the process
+ * began that ran a second time because their resident copy proved stale. */
 int ppk_query_last_stats(double *vals, int n);
 
 int ppk_assign_threshold(const float *dist, size_t n_rows, int slope, float x_max,

@@ -1139,18 +1139,39 @@ size_t db_cache_evict_locked(int device, const ppk_db *keep0, const ppk_db *keep
   return freed;
 }
 
+// the content hash the cache holds for this host array on `device` (what a speculative run used); false: no entry
+bool db_cached_fp(int device, const uint64_t *sk, size_t n, size_t nk, size_t s64, size_t bbits, uint64_t *fp) {
+  std::lock_guard<std::mutex> lk(g_cache_mu);
+  for (const CachedDb &c : g_db_cache)
+    if (c.host == sk && c.n == n && c.nk == nk && c.s64 == s64 && c.bbits == bbits && c.device == device) {
+      *fp = c.fp;
+      return true;
+    }
+  return false;
+}
+void db_cache_drop(int device, const uint64_t *sk) {
+  std::lock_guard<std::mutex> lk(g_cache_mu);
+  for (size_t i = 0; i < g_db_cache.size();)
+    if (g_db_cache[i].device == device && g_db_cache[i].host == sk) {
+      ppk_db_destroy(g_db_cache[i].db);
+      g_db_cache.erase(g_db_cache.begin() + (long)i);
+    } else {
+      ++i;
+    }
+}
+
 // the resident database of (sk, ...) on `device`: from the cache (fp = the content hash, computed once
 // per call by the caller), or created and cached.  `pinned`: a database this call already uses on the
 // device (never evicted).  Called from the device's worker thread; uploads of different devices overlap.
 int db_acquire(int device, const uint64_t *sk, size_t n, size_t nk, size_t s64, size_t bbits,
                const uint16_t *clu, uint64_t fp, bool use_cache, const ppk_db *pinned, hipStream_t s,
-               ppk_db **out, bool *owned) {
+               ppk_db **out, bool *owned, bool speculative = false) {
   *owned = false;
   if (use_cache) {
     std::lock_guard<std::mutex> lk(g_cache_mu);
     for (CachedDb &c : g_db_cache)
       if (c.host == sk && c.n == n && c.nk == nk && c.s64 == s64 && c.bbits == bbits &&
-          c.device == device && c.fp == fp) {
+          c.device == device && (speculative || c.fp == fp)) {
         c.stamp = ++g_db_stamp;
         *out = c.db;
         return PPK_OK;
@@ -1220,6 +1241,7 @@ struct QueryJob {
   const uint16_t *ref_clu = nullptr, *qry_clu = nullptr;
   uint64_t ref_fp = 0, qry_fp = 0;
   bool use_cache = false;
+  bool speculative = false;                     // the cached databases are used before their hash has been checked
   char *out = nullptr;
   size_t cols = 2;
   // The sub-bands of the whole job, device after device (a device's sub-bands are consecutive): sub-band i is
@@ -1250,6 +1272,7 @@ struct QueryJob {
 struct QueryStats {
   std::atomic<int> dl_now{0}, dl_max{0}, up_now{0}, up_max{0};
   int parts = 0, threads = 0;
+  long long respeculated = 0;      // host queries run a second time because their cached copy proved stale
   double wall_ms = 0.0, upload_ms_max = 0.0, part_ms_max = 0.0;
 } g_qstats;
 
@@ -1318,12 +1341,12 @@ void run_part(QueryJob &job, std::vector<QueryPart> &parts, int d, bool poll, bo
       const double t_up = now_ms();
       ppk_db *db = nullptr;
       rc = db_acquire(p.device, job.ref_sk, job.n_ref, job.nk, job.s64, job.bbits, job.ref_clu, job.ref_fp,
-                      job.use_cache, nullptr, p.s, &db, &p.own_ref);
+                      job.use_cache, nullptr, p.s, &db, &p.own_ref, job.speculative);
       p.ref = db;
       if (rc == PPK_OK && job.n_qry) {
         db = nullptr;
         rc = db_acquire(p.device, job.qry_sk, job.n_qry, job.nk, job.s64, job.bbits, job.qry_clu, job.qry_fp,
-                        job.use_cache, p.ref, p.s, &db, &p.own_qry);
+                        job.use_cache, p.ref, p.s, &db, &p.own_qry, job.speculative);
         p.qry = db;
       }
       p.upload_ms = now_ms() - t_up;
@@ -1680,36 +1703,81 @@ extern "C" int ppk_query(const uint64_t *ref_sk, size_t n_ref, const uint64_t *q
     devices = expanded.data();
     n_dev = (int)expanded.size();
   }
-  std::vector<QueryPart> parts((size_t)n_dev);
-  int rc = prepare_parts(parts, devices);
-  if (rc != PPK_OK) return rc;
-  QueryJob job;
-  job.n_ref = n_ref;
-  job.n_qry = n_qry;
-  job.nk = nk;
-  job.s64 = sketchsize64;
-  job.bbits = bbits;
-  job.n_clu = n_clu;
-  job.kmers = kmers;
-  job.random_tbl = random_tbl;
-  job.flags = flags;
-  job.ref_sk = ref_sk;
-  job.qry_sk = self ? nullptr : qry_sk;
-  job.ref_clu = ref_clu;
-  job.qry_clu = qry_clu;
-  job.out = static_cast<char *>(out);
-  job.use_cache = ppk_config().db_cache.load() != 0;
-  if (job.use_cache) {
-    job.ref_fp = fingerprint(ref_sk, n_ref * nk * sketchsize64 * bbits, ref_clu, n_ref);
-    if (!self) job.qry_fp = fingerprint(qry_sk, n_qry * nk * sketchsize64 * bbits, qry_clu, n_qry);
+  const bool use_cache = ppk_config().db_cache.load() != 0;
+  const size_t ref_words = n_ref * nk * sketchsize64 * bbits, qry_words = n_qry * nk * sketchsize64 * bbits;
+  // Every device of the list already holds a resident copy keyed by these host arrays?  Then the job STARTS on
+  // them while the hash of the arrays' present content is still being computed (helper threads, ~0.6 ms per
+  // 90 MB -- a tenth of a 10k call if waited for first), and is checked before the call returns: a mismatch
+  // (the array was rewritten in place, or is another one at a recycled address) drops the stale copies and
+  // runs the job again on a fresh upload.  Nothing computed from a stale copy is ever handed back.
+  bool speculative = use_cache;
+  for (int d = 0; d < n_dev && speculative; ++d) {
+    uint64_t f;
+    speculative = db_cached_fp(devices[d], ref_sk, n_ref, nk, sketchsize64, bbits, &f) &&
+                  (self || db_cached_fp(devices[d], qry_sk, n_qry, nk, sketchsize64, bbits, &f));
   }
-  rc = run_query(job, parts, n_failed);
-  const std::string keep = g_err;
-  for (QueryPart &p : parts) {
-    if (p.own_ref && p.ref) ppk_db_destroy(const_cast<ppk_db *>(p.ref));
-    if (p.own_qry && p.qry) ppk_db_destroy(const_cast<ppk_db *>(p.qry));
+  uint64_t ref_fp = 0, qry_fp = 0;
+  PpkTicket hashing;
+  if (use_cache) {
+    auto hash = [&]() {
+      ref_fp = fingerprint(ref_sk, ref_words, ref_clu, n_ref);
+      if (!self) qry_fp = fingerprint(qry_sk, qry_words, qry_clu, n_qry);
+    };
+    if (speculative) hashing = ppk_pool_run(hash);
+    else hash();
   }
-  if (rc != PPK_OK) g_err = keep;
+  int rc = PPK_OK;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    std::vector<QueryPart> parts((size_t)n_dev);
+    rc = prepare_parts(parts, devices);
+    if (rc != PPK_OK) break;
+    QueryJob job;
+    job.n_ref = n_ref;
+    job.n_qry = n_qry;
+    job.nk = nk;
+    job.s64 = sketchsize64;
+    job.bbits = bbits;
+    job.n_clu = n_clu;
+    job.kmers = kmers;
+    job.random_tbl = random_tbl;
+    job.flags = flags;
+    job.ref_sk = ref_sk;
+    job.qry_sk = self ? nullptr : qry_sk;
+    job.ref_clu = ref_clu;
+    job.qry_clu = qry_clu;
+    job.out = static_cast<char *>(out);
+    job.use_cache = use_cache;
+    job.speculative = speculative && attempt == 0;
+    job.ref_fp = ref_fp;
+    job.qry_fp = qry_fp;
+    if (n_failed) *n_failed = 0;
+    rc = run_query(job, parts, n_failed);
+    const std::string keep = g_err;
+    for (QueryPart &p : parts) {
+      if (p.own_ref && p.ref) ppk_db_destroy(const_cast<ppk_db *>(p.ref));
+      if (p.own_qry && p.qry) ppk_db_destroy(const_cast<ppk_db *>(p.qry));
+    }
+    if (rc != PPK_OK) g_err = keep;
+    if (!job.speculative) break;
+    // the speculative run is over: were the copies it used the copies of what the arrays hold NOW?
+    ppk_pool_wait(hashing);
+    hashing.reset();
+    bool stale = false;
+    for (int d = 0; d < n_dev; ++d) {
+      uint64_t f = 0;
+      if (!db_cached_fp(devices[d], ref_sk, n_ref, nk, sketchsize64, bbits, &f) || f != ref_fp) {
+        stale = true;
+        db_cache_drop(devices[d], ref_sk);
+      }
+      if (!self && (!db_cached_fp(devices[d], qry_sk, n_qry, nk, sketchsize64, bbits, &f) || f != qry_fp)) {
+        stale = true;
+        db_cache_drop(devices[d], qry_sk);
+      }
+    }
+    if (!stale) break;
+    g_qstats.respeculated += 1;
+  }
+  if (hashing) ppk_pool_wait(hashing);      // (never leave a helper reading the caller's arrays behind)
   return rc;
 }
 
@@ -1777,13 +1845,14 @@ extern "C" int ppk_query_db(const ppk_db *ref, const ppk_db *qry, const int32_t 
 //   [0] parts (device entries)        [1] worker threads spawned (0: ran on the calling thread)
 //   [2] most downloads in flight at once   [3] most uploads (database creations) in flight at once
 //   [4] wall ms of the call's device phase [5] longest upload ms   [6] longest part ms
+//   [7] ppk_query calls (since the process began) that ran twice because their cached copy proved stale
 extern "C" int ppk_query_last_stats(double *vals, int n) {
   if (!vals || n < 1) return ppk_fail(PPK_ERR_ARG, "vals is NULL");
   std::lock_guard<std::mutex> lk(g_query_mu);
-  const double v[7] = {(double)g_qstats.parts, (double)g_qstats.threads, (double)g_qstats.dl_max.load(),
+  const double v[8] = {(double)g_qstats.parts, (double)g_qstats.threads, (double)g_qstats.dl_max.load(),
                        (double)g_qstats.up_max.load(), g_qstats.wall_ms, g_qstats.upload_ms_max,
-                       g_qstats.part_ms_max};
-  for (int i = 0; i < n; ++i) vals[i] = i < 7 ? v[i] : 0.0;
+                       g_qstats.part_ms_max, (double)g_qstats.respeculated};
+  for (int i = 0; i < n; ++i) vals[i] = i < 8 ? v[i] : 0.0;
   return PPK_OK;
 }
 

@@ -19,9 +19,10 @@ TOL = 1e-6
 
 
 def _stats():
-    v = (C.c_double * 7)()
-    _lib.check(_lib.lib().ppk_query_last_stats(v, 7), "ppk_query_last_stats")
-    return dict(zip(("parts", "threads", "dl_max", "up_max", "wall_ms", "upload_ms_max", "part_ms_max"), list(v)))
+    v = (C.c_double * 8)()
+    _lib.check(_lib.lib().ppk_query_last_stats(v, 8), "ppk_query_last_stats")
+    return dict(zip(("parts", "threads", "dl_max", "up_max", "wall_ms", "upload_ms_max", "part_ms_max", "reruns"),
+                    list(v)))
 
 
 def test_fit_tables_are_rebuilt_after_release_scratch():
@@ -51,7 +52,9 @@ def test_in_place_rewrite_of_one_sample_at_70k_genomes_is_seen():
     """ppk_query keeps resident databases keyed by the host pointer, the dimensions and a hash of
     EVERY word.  Round 2 sampled 2^16 words: above ~65 000 genomes a one-sample change could go
     unnoticed and the call answered with the OLD sketches.  70 000 refs x 64 queries, default
-    options: rewrite one ref in place (same pointer, same shape) -> the new counts."""
+    options: rewrite one ref in place (same pointer, same shape) -> the new counts.  (The call starts
+    on the resident copy while the hash is still being computed and checks it before it returns: a
+    stale copy costs a second run, never a wrong answer.)"""
     rng = np.random.Generator(np.random.PCG64(11))
     n_ref, n_qry = 70000, 64
     ref = rng.integers(0, 1 << 63, size=(n_ref, 5, 224), dtype=np.int64).astype(np.uint64)
@@ -59,12 +62,16 @@ def test_in_place_rewrite_of_one_sample_at_70k_genomes_is_seen():
     assert _lib.get_option("db_cache") == 1
     first, _ = pp_sketchlib.query_arrays(ref, qry, KMERS, 16, 14, counts=True)
     assert first.max() < 64                               # unrelated words: a handful of chance matches
+    reruns0 = _stats()["reruns"]
     again, _ = pp_sketchlib.query_arrays(ref, qry, KMERS, 16, 14, counts=True)
     assert np.array_equal(first, again)
-    for victim in (41234, 69999, 0):
+    assert _stats()["reruns"] == reruns0                  # unchanged arrays: the resident copies were right
+    for n_seen, victim in enumerate((41234, 69999, 0), 1):
         ref[victim] = qry[7]                              # in place: every bin of every k now matches query 7
         got, _ = pp_sketchlib.query_arrays(ref, qry, KMERS, 16, 14, counts=True)
         assert np.array_equal(got[7 * n_ref + victim], np.full(5, 1024)), victim
+        # the call started on the resident copy, found its hash stale before returning, and ran again
+        assert _stats()["reruns"] == reruns0 + n_seen
     rows = np.concatenate([np.arange(7 * n_ref, 8 * n_ref), np.arange(0, n_ref)])
     want = oracle.match_counts(ref, qry[[7, 0]], 16, 14, threads=8)
     assert np.array_equal(got[rows], np.concatenate([want[:n_ref], want[n_ref:]]))
