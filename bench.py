@@ -157,8 +157,8 @@ def host_call(sk, kmers, tbl, devices, reps=5):
     database's resident handles -> ppk_query_dbs): host sketches in, a FRESH pageable host result array
     out, PCIe both ways, `devices` driven by ONE process (a worker thread per device).  The first call
     uploads and re-lays out the sketches on every device (side by side); later calls find them resident.
-    `arrays_ms`: the raw-array entry point ppk_query on the same job (it must hash every word of the
-    sketch array per call to know that its resident copy is still good)."""
+    `arrays_ms`: the raw-array entry point ppk_query on the same job (it hashes every word of the sketch
+    array per call, beside the job, to know that the resident copy it ran on was still good)."""
     from poppunk_amd import _lib, pp_sketchlib, sketchdb
     lib = _lib.lib()
     lib.ppk_release_scratch()                 # start cold: no cached database, no buffers
@@ -191,7 +191,8 @@ def host_call(sk, kmers, tbl, devices, reps=5):
             "note": "pp_sketchlib.queryDatabase after the file read: ppk_query_dbs on resident handles, host "
                     "buffers in / fresh host array out (np.zeros pages untouched), median of %d calls after "
                     "the first; the first call also uploads + re-lays out the %d MB of sketches per device.  "
-                    "arrays_ms: ppk_query on the raw array (adds a hash of every sketch word per call)"
+                    "arrays_ms: ppk_query on the raw array (its hash of every sketch word runs beside the job and is "
+                    "checked before the call returns)"
                     % (reps - 1, sk.nbytes >> 20)}
 
 
