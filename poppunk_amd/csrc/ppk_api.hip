@@ -1041,9 +1041,9 @@ int query_buf(int dev, int dup, int i, size_t bytes, void **out) {
 
 // worker streams per (device, occurrence): two entries naming one device run on their own streams
 int part_streams(int device, int dup, hipStream_t *out) {
-  static std::mutex mu;
+  // (each (device, occurrence) pair is only ever asked for by one thread at a time: no lock around the creation,
+  // so that the entries of a first call create their streams side by side -- 4 ms each on this stack)
   static hipStream_t cache[64][kMaxDup][2];
-  std::lock_guard<std::mutex> lk(mu);
   if (device < 0 || device >= 64 || dup < 0 || dup >= kMaxDup) return ppk_fail(PPK_ERR_ARG, "bad worker stream request");
   for (int i = 0; i < 2; ++i) {
     if (!cache[device][dup][i] && hipStreamCreate(&cache[device][dup][i]) != hipSuccess) {
@@ -1323,6 +1323,15 @@ void run_part(QueryJob &job, std::vector<QueryPart> &parts, int d, bool poll, bo
     return fail(PPK_ERR_HIP);
   }
   int rc = PPK_OK;
+  {
+    hipStream_t ws[2] = {nullptr, nullptr};
+    if ((rc = part_streams(p.device, p.dup, ws)) != PPK_OK) {
+      p.db_ready.store(-1);
+      return fail(rc);
+    }
+    p.s = ws[0];
+    p.sc = ws[1];
+  }
   g_trace.mark(d, "device_set");
   // 1. resident databases
   if (job.ref_sk) {
@@ -1649,10 +1658,6 @@ int prepare_parts(std::vector<QueryPart> &parts, const int *devices) {
     DeviceGuard g(p.device);
     if (!g.ok) return ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(p.device));
     if (int rc = check_arch(p.device)) return rc;
-    hipStream_t ws[2] = {nullptr, nullptr};
-    if (int rc = part_streams(p.device, p.dup, ws)) return rc;
-    p.s = ws[0];
-    p.sc = ws[1];
   }
   return PPK_OK;
 }
