@@ -56,7 +56,14 @@ PpkConfig &ppk_config();
 
 // Error plumbing -------------------------------------------------------------
 void ppk_set_error(const std::string &msg);
+const std::string &ppk_error();          // the calling thread's message
 int ppk_fail(int code, const std::string &msg);
+
+// shared between ppk_api.hip (device entry points) and ppk_host.hip (host-buffer entry points)
+int ppk_check_arch(int device_id);       // gfx950 / wave64 or an error, cached per device
+int ppk_check_pair(const ppk_db *ref, const ppk_db *qry, const int32_t *kmers, size_t q_begin, size_t q_end);
+void ppk_upload_rings_release();
+void ppk_assign_bufs_release_all();
 
 #define PPK_HIP(call)                                                              \
   do {                                                                             \
@@ -142,7 +149,7 @@ class PpkCall {
   unsigned prev_touched_;
 };
 void ppk_query_cache_clear();
-// host entry points with a data-dependent result size (ppk_api.hip): one pass; a result that did not
+// host entry points with a data-dependent result size (ppk_host.hip): one pass; a result that did not
 // fit the caller's buffer stays parked on the device for the calling thread's ppk_parked_fetch
 uint64_t ppk_token(const void *bytes, size_t len, uint64_t seed);
 int ppk_host_result(int arrays, int device, size_t guess, size_t cap, size_t *n_out,
@@ -190,7 +197,7 @@ __device__ __forceinline__ float ppk_line_dist(float x0, float y0, float x_max, 
 // ---- helper threads ----------------------------------------------------------------
 // A host call uses a dozen short-lived helpers (page touchers, per-device workers, hash lanes); starting
 // a thread costs 30-100 us and jitters to several hundred, which is the scale of the call's whole start-up.
-// They are therefore taken from a grow-only pool of parked threads (ppk_api.hip).  A task's completion is
+// They are therefore taken from a grow-only pool of parked threads (ppk_host.hip).  A task's completion is
 // the ticket's flag; ppk_pool_wait spins with yield (tasks here last from 0.1 to 10 ms).  A forked child
 // starts with an empty pool of its own.
 typedef std::shared_ptr<std::atomic<int>> PpkTicket;

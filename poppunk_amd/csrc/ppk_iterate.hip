@@ -442,7 +442,7 @@ extern "C" int ppk_threshold_iterate_2d_dev(const float *d_dist, size_t n_rows, 
 
 // ---- host-buffer wrappers (what the pybind functions of python_bindings.cpp:49-73 bind) ----
 namespace {
-// One upload, one device pass (ppk_host_result, ppk_api.hip): the result is computed into a device
+// One upload, one device pass (ppk_host_result, ppk_host.hip): the result is computed into a device
 // buffer of guessed capacity and, when the caller's arrays are too small, parked there until the
 // caller comes back with room.  Layout on the device: [3][cap_used] (i, j, offset index).
 template <typename F>
