@@ -69,8 +69,9 @@ def parse():
     ap.add_argument("--config5-steps", type=int, default=3)
     ap.add_argument("--spinup-ms", type=float, default=200.0,
                     help="untimed clock spin-up before the warm-up steps (0 disables)")
-    ap.add_argument("--chunks", type=int, default=4,
-                    help="sub-bands per rank: the gather of chunk c overlaps the compute of c+1")
+    ap.add_argument("--chunks", type=int, default=0,
+                    help="sub-bands per rank: the gather of chunk c overlaps the compute of c+1 (0, the default: "
+                         "1, 2, 4 and 8 are probed during the untimed set-up and the fastest is kept)")
     ap.add_argument("--watchdog-s", type=float, default=240.0,
                     help="a phase (init, spin-up, rebalance, timed steps, ...) that lasts longer prints the "
                          "JSON line with what has been measured and ends the process (0 = off)")
@@ -384,7 +385,7 @@ def build_line(rep):
                                "on rank 0" % (n, total_pairs),
                    "n_genomes": n, "pairs": total_pairs,
                    "parallelism": "band-split x%d (%s bands), %d-chunk pipelined p2p gather to rank 0"
-                                  % (world, band_note.split(" ")[0], args.chunks) if world > 1 else "1 GPU"},
+                                  % (world, band_note.split(" ")[0], f.get("chunks", args.chunks or 4)) if world > 1 else "1 GPU"},
         "roofline": roof, "cpu_baseline": f.get("cpu"), "host_call": f.get("host_call"), "config5": f.get("config5"),
     }
     if value_note:
@@ -409,7 +410,9 @@ def build_line(rep):
                     "host_call: ONE process driving all N GPUs through ppk_query_dbs (a worker thread per "
                     "device, each GPU's share over its own PCIe link into one pageable host array) -- the "
                     "multi-GPU route of a single-process PopPUNK.  config5 is the shape that scales: "
-                    "only edge lists move" % args.chunks}
+                    "only edge lists move" % f.get("chunks", args.chunks or 4)}
+        if f.get("chunks_probe_ms"):
+            mg["chunks_probe_ms_per_step"] = f["chunks_probe_ms"]
         if rep.errors:
             mg["error"] = "; ".join(rep.errors)
         line["multi_gpu"] = mg
@@ -541,7 +544,7 @@ def run(args, rep, rank, local_rank, world, fake, torch, dist, engine, synth, da
         ref = engine.SketchDB(sk, 16, 14, device=local_rank)
         band_fn = None
 
-    job = engine.ShardedQuery(ref, None, rank, world, n_chunks=args.chunks if world > 1 else 1,
+    job = engine.ShardedQuery(ref, None, rank, world, n_chunks=(args.chunks or 4) if world > 1 else 1,
                               device="cpu" if fake else None)
     f["total_pairs"] = int(job.total_rows)
 
@@ -655,6 +658,36 @@ def run(args, rep, rank, local_rank, world, fake, torch, dist, engine, synth, da
                 rep.error("rebalance", e)
                 job._layout(engine.shard_bounds(ref.n, 0, world))
                 band_note = "equal (rebalance failed)"
+    if world > 1 and pg_ok and args.chunks == 0:
+        # Set-up, like the band cut: how many sub-bands a rank's band is sent in.  Few: less launch and
+        # group-call overhead per step; many: more of the transfer hidden under the compute.  Which wins depends
+        # on N and on the links, so 1, 2, 4 and 8 are timed (3 gathered steps each, the same number on every
+        # rank: the figure is the all-reduced maximum) and the fastest is kept.
+        rep.enter("chunk_probe")
+        try:
+            def probe_chunks(n_steps=3):
+                barrier()
+                t_p = time.perf_counter()
+                for _ in range(n_steps):
+                    step()
+                barrier()
+                return reduce_max([(time.perf_counter() - t_p) / n_steps * 1e3])[0]
+            best, tried = None, {}
+            for c in (4, 1, 2, 8):
+                job.n_chunks = c
+                job._layout(job.bounds)
+                step()                                   # buffers, first-use costs of this shape
+                tried[c] = probe_chunks()
+                if best is None or tried[c] < tried[best]:
+                    best = c
+            job.n_chunks = best
+            job._layout(job.bounds)
+            f["chunks_probe_ms"] = {str(k): round(v, 4) for k, v in sorted(tried.items())}
+        except Exception as e:
+            rep.error("chunk_probe", e)
+            job.n_chunks = 4
+            job._layout(job.bounds)
+    f["chunks"] = job.n_chunks
     f["band_note"] = band_note
     rep.enter("warmup")
     for _ in range(args.warmup):

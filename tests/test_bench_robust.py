@@ -49,13 +49,14 @@ def test_clean_run_prints_the_gathered_value():
     d = _run(None)
     mg = _check_common(d)
     assert "error" not in mg and "value_note" not in d
+    assert sorted(mg["chunks_probe_ms_per_step"]) == ["1", "2", "4", "8"]      # the set-up probed the sub-band counts
     assert d["value"] > 0 and d["ms_per_step"] > 0
     assert abs(sum(mg["band_shares"]) - 1.0) < 1e-3
 
 
-@pytest.mark.parametrize("inject", ["isend:0", "isend:7", "isend:30"])
+@pytest.mark.parametrize("inject", ["isend:0", "isend:7", "isend:30", "isend:60"])
 def test_failing_send_recv_still_yields_one_line_with_per_rank_compute(inject):
-    """The first gathered step, the rebalance probe or the timed loop loses batch_isend_irecv: the line
+    """The first gathered step, the rebalance probe, the sub-band probe or the timed loop loses batch_isend_irecv: the line
     carries multi_gpu.error, every rank's compute-only ms per step (measured before any collective,
     handed over through files) and a value that says it excludes the gather."""
     d = _run(inject)
