@@ -722,7 +722,9 @@ def run(args, rep, rank, local_rank, world, fake, torch, dist, engine, synth, da
             else:
                 if rank == 0:
                     try:      # whatever happens here, rank 0 reaches the barrier the other ranks wait at
-                        if torch.cuda.device_count() >= world:
+                        if os.environ.get("PPK_BENCH_ONE_GPU"):      # debugging aid: the same GPU listed `world` times
+                            f["multi_host_call"] = host_call(sk, kmers, tbl, [0] * min(world, 4))
+                        elif torch.cuda.device_count() >= world:
                             f["multi_host_call"] = host_call(sk, kmers, tbl, list(range(world)))
                             f["multi_host_call"]["one_device"] = host_call(sk, kmers, tbl, [local_rank], reps=3)
                         else:
