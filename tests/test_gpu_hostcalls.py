@@ -240,3 +240,24 @@ def test_pin_kit_runs_its_own_half_without_upstream(tmp_path):
     for tag in ("s1024", "s19200", "s1024q", "gap"):
         assert os.path.exists(str(tmp_path / (tag + ".h5")))
     assert "our two readings differ on 6 of 66 rows" in r.stdout      # the gap pairs tell truncate from skip
+
+
+@pytest.mark.parametrize("n,threads", [(460, 8), (3750, 8), (3750, 3), (7200, 16), (3750, 0)])
+def test_staged_uploads_of_pageable_arrays(ppk_option, n, threads):
+    """Host arrays reach the device through a pinned ring filled by helper threads (32 MB pieces, two slots):
+    below the staging threshold (4 MB), one piece and a ragged second one (33.6 MB), three pieces (64.5 MB),
+    any helper count, and helpers switched off (the runtime's own path) -- the resident database is the same
+    bytes: match counts against the oracle, and the kernel-2 host calls on a 36 MB matrix."""
+    ppk_option("prefault_threads", threads)
+    pp_sketchlib.clear_cache()
+    sk = synth.make_sketches(n, KMERS, cluster_size=50, seed=70 + n)[0]
+    assert sk.nbytes == n * 8960
+    q = sk[:7]
+    got, _ = pp_sketchlib.query_arrays(sk, q, KMERS, 16, 14, counts=True)
+    assert np.array_equal(got, oracle.match_counts(sk, q, 16, 14, threads=8))
+    rng = np.random.Generator(np.random.PCG64(n))
+    m = 3000
+    d = rng.random((m * (m - 1) // 2, 2)).astype(np.float32)          # 36 MB: two ring pieces
+    assert np.array_equal(poppunk_refine.assignThreshold(d, 2, 0.4, 0.5), oracle.assign_threshold(d, 2, 0.4, 0.5))
+    assert np.array_equal(poppunk_refine.edgeThreshold_array(d, 2, 0.1, 0.1), oracle.edge_threshold(d, 2, 0.1, 0.1))
+    pp_sketchlib.clear_cache()
