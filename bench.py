@@ -233,15 +233,58 @@ def config5(args, rank, world, local_rank, dev, barrier):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     pairs = n * (n - 1) // 2
+    # the same job as ONE host call of one process (ppk_query_edges_dbs): every device the process sees takes
+    # a band on a worker thread of its own, the list arrives in a host array.  Rank 0 alone; the others wait.
+    host = None
+    if rank == 0:
+        try:
+            host = config5_host_call(ref, kmers, tbl, x_max, y_max, world, local_rank, int(sum(counts)))
+        except Exception as e:          # a figure less, never a lost line or a rank missing at the barrier
+            host = {"error": "%s: %s" % (type(e).__name__, e)}
+    barrier()
     ref.close()
     torch.cuda.empty_cache()
-    return {"workload": "%d synthetic genomes self-vs-self, s=1024, k=13,17,21,25,29, fused distance -> "
+    return {"host_call": host,
+            "workload": "%d synthetic genomes self-vs-self, s=1024, k=13,17,21,25,29, fused distance -> "
                         "slope-2 boundary -> edge list; band-split x%d, only the edge lists gathered to rank 0"
                         % (n, world),
             "pairs": pairs, "n_edges": int(sum(counts)), "steps": args.config5_steps,
             "ms_per_step": elapsed / args.config5_steps * 1e3,
             "value": pairs * args.config5_steps / elapsed, "unit": "pairs/s",
             "gathered_bytes_per_step": int(sum(counts[1:])) * 16}
+
+
+def config5_host_call(ref, kmers, tbl, x_max, y_max, world, local_rank, n_edges_expected, reps=3):
+    import torch
+    from poppunk_amd import engine
+    if world == 1 or os.environ.get("PPK_BENCH_ONE_GPU"):
+        dbs, made = [ref] * min(world, 4), []
+    elif torch.cuda.device_count() >= world:
+        # the other devices get a copy of rank 0's database (device-to-device, outside the timed region)
+        from poppunk_amd import synth
+        sk_t = synth.make_sketches_device(ref.n, kmers, device="cuda:%d" % local_rank)   # the same draw as ref's
+        made = [engine.SketchDB(sk_t.to("cuda:%d" % d), 16, 14, device=d) for d in range(world) if d != local_rank]
+        del sk_t
+        it = iter(made)
+        dbs = [ref if d == local_rank else next(it) for d in range(world)]
+    else:
+        return {"skipped": "rank 0 sees %d of %d GPUs" % (torch.cuda.device_count(), world)}
+    try:
+        edges, _ = engine.edges_host(dbs, None, kmers, tbl, slope=2, x_max=x_max, y_max=y_max, cap=16 << 20)
+        assert len(edges) == n_edges_expected, (len(edges), n_edges_expected)
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            edges, _ = engine.edges_host(dbs, None, kmers, tbl, slope=2, x_max=x_max, y_max=y_max, cap=16 << 20)
+            ts.append(time.perf_counter() - t0)
+    finally:
+        for d in made:
+            d.close()
+    pairs = ref.n * (ref.n - 1) // 2
+    return {"what": "ppk_query_edges_dbs: one process, %d device entr%s, databases resident, the edge list in a "
+                    "fresh host array" % (len(dbs), "y" if len(dbs) == 1 else "ies"),
+            "ms": min(ts) * 1e3, "ms_all": [round(t * 1e3, 2) for t in ts], "n_edges": int(len(edges)),
+            "pairs_per_s": pairs / min(ts)}
 
 
 class Report:

@@ -302,6 +302,32 @@ int ppk_generate_tuples(const int32_t *assignments, size_t n_rows, int within_la
  * a successful fetch. */
 int ppk_parked_fetch(long long *out0, long long *out1, long long *out2, size_t cap, size_t *n_out);
 
+/* Sketches in, edge list out, on one or several devices: queryDatabase -> (X / scale) ->
+ * poppunk_refine.assignThreshold -> generateTuples (PopPUNK/models.py:1065-1091,
+ * PopPUNK/network.py:1180-1184), or -> poppunk_refine.edgeThreshold (PopPUNK/refine.py:535), as ONE host
+ * call in which the [n_pairs, 2] matrix never exists, on the device or on the host: every listed device
+ * runs ppk_dist_edges_dev on its band of query rows (ppk_band_split; one worker thread per device),
+ * 16 bytes per EDGE cross PCIe instead of 8 bytes per PAIR, and the bands' lists are concatenated in
+ * device-list order = reference row order (src/boundary.cpp:101-118), so the list does not depend on the
+ * number of devices.  slope / x_max / y_max / scale / inclusive as in ppk_dist_edges_dev; ij_out int64
+ * [cap][2], *n_edges the total; with too little room the finished list is parked (on the host) for
+ * ppk_parked_fetch, as above.  Sketches whose k-mer set needs more than 128 count bits (the un-fused
+ * path) run on one device only.
+ *   ppk_query_edges_dbs : refs[d] / qrys[d] (qrys NULL = self) = the same database resident on each device
+ *   ppk_query_edges     : host sketch arrays as in ppk_query; the resident copies come from (and stay in)
+ *                         ppk_query's cache, every word hashed before anything runs */
+int ppk_query_edges_dbs(const ppk_db *const *refs, const ppk_db *const *qrys, int n_dev,
+                        const int32_t *kmers, const float *random_tbl, size_t n_clu, int flags,
+                        int slope, float x_max, float y_max, float scale_x, float scale_y,
+                        int inclusive, long long *ij_out, size_t cap, size_t *n_edges,
+                        unsigned long long *n_failed);
+int ppk_query_edges(const uint64_t *ref_sk, size_t n_ref, const uint64_t *qry_sk, size_t n_qry,
+                    const int32_t *kmers, size_t nk, size_t sketchsize64, size_t bbits,
+                    const float *random_tbl, const uint16_t *ref_clu, const uint16_t *qry_clu,
+                    size_t n_clu, int flags, int slope, float x_max, float y_max, float scale_x,
+                    float scale_y, int inclusive, const int *devices, int n_dev, long long *ij_out,
+                    size_t cap, size_t *n_edges, unsigned long long *n_failed);
+
 /* ------------------------------------------------------------------------
  * Long <-> square distance transforms and k nearest neighbours (SURVEY.md 8f
  * rank 2).  "Long" = condensed upper triangle in PopPUNK row order; element e

@@ -1186,6 +1186,7 @@ struct ParkedResult {
   int arrays = 0;                 // 1: int64 [n][2] contiguous; 3: int64 [3][cap_used] (i, j, offset index)
   void *d = nullptr;
   size_t n = 0, cap_used = 0;     // entries wanted / capacity the buffer was computed with
+  std::vector<long long> host;    // ... or a list that is already on the host (several devices' lists, concatenated)
 };
 static std::mutex g_parked_mu;
 static ParkedResult g_parked;
@@ -1246,11 +1247,16 @@ void ppk_parked_clear() {
 extern "C" int ppk_parked_fetch(long long *out0, long long *out1, long long *out2, size_t cap, size_t *n_out) {
   std::lock_guard<std::mutex> lk(g_parked_mu);
   if (n_out) *n_out = 0;
-  if (!g_parked.d || g_parked.owner != std::this_thread::get_id())
+  if ((!g_parked.d && g_parked.host.empty()) || g_parked.owner != std::this_thread::get_id())
     return ppk_fail(PPK_ERR_STATE, "ppk_parked_fetch: this thread's last call parked no result");
   if (n_out) *n_out = g_parked.n;
   if (cap < g_parked.n) return ppk_fail(PPK_ERR_CAPACITY, "output too small: need " + std::to_string(g_parked.n));
   if (!out0 || (g_parked.arrays == 3 && (!out1 || !out2))) return ppk_fail(PPK_ERR_ARG, "ppk_parked_fetch: NULL output");
+  if (!g_parked.host.empty()) {
+    memcpy(out0, g_parked.host.data(), g_parked.n * 16);
+    parked_drop_locked();
+    return PPK_OK;
+  }
   DeviceGuard g(g_parked.device);
   const long long *buf = static_cast<const long long *>(g_parked.d);
   const size_t n = g_parked.n, cu = g_parked.cap_used;
@@ -1343,4 +1349,208 @@ extern "C" int ppk_generate_tuples(const int32_t *assignments, size_t n_rows, in
                            return rc;
                          },
                          copy_out);
+}
+
+// ---- fused host entry: sketches -> distances -> boundary -> edge list, on one or several devices --------
+// What queryDatabase -> (X / scale) -> assignThreshold -> generateTuples (PopPUNK/models.py:1065-1091,
+// PopPUNK/network.py:1180-1184) or -> edgeThreshold (PopPUNK/refine.py:535) produce, without the [n_pairs, 2]
+// matrix ever existing: every listed device runs ppk_dist_edges_dev on its band of query rows (one worker
+// thread each), only the edge lists come back, and bands being consecutive row ranges their lists
+// concatenate to the list of the whole matrix in reference row order.  BASELINE config 5 for a single
+// process: 100 000 genomes on N GPUs, 16 bytes per edge over PCIe instead of 8 bytes per pair.
+namespace {
+struct EdgePart {
+  int device = 0, dup = 0;
+  const ppk_db *ref = nullptr, *qry = nullptr;
+  size_t q_begin = 0, q_end = 0;
+  std::vector<long long> edges;      // (i, j) pairs of this band, on the host
+  unsigned long long failed = 0;
+  int rc = PPK_OK;
+  std::string err;
+};
+
+void run_edge_part(EdgePart &p, const int32_t *kmers, const float *random_tbl, size_t n_clu, int flags, int slope,
+                   float x_max, float y_max, float scale_x, float scale_y, int inclusive) {
+  auto fail = [&](int code) {
+    p.rc = code;
+    p.err = ppk_error();
+  };
+  DeviceGuard g(p.device);
+  if (!g.ok) {
+    ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(p.device));
+    return fail(PPK_ERR_HIP);
+  }
+  hipStream_t ws[2] = {nullptr, nullptr};
+  int rc = part_streams(p.device, p.dup, ws);
+  if (rc != PPK_OK) return fail(rc);
+  hipStream_t s = ws[0];
+  const size_t rows = ppk_rows_in_band(p.ref->n, p.qry ? p.qry->n : 0, p.q_begin, p.q_end);
+  if (rows == 0) return;
+  size_t cap = rows / 8 > ((size_t)1 << 20) ? rows / 8 : ((size_t)1 << 20);
+  if (cap > rows) cap = rows;
+  unsigned long long *d_cnt = nullptr;      // [0] edges, [1] failed fits
+  long long *d_edges = nullptr;
+  auto done = [&](int code) {
+    if (d_edges) (void)hipFree(d_edges);
+    if (d_cnt) (void)hipFree(d_cnt);
+    if (code != PPK_OK) fail(code);
+  };
+  if (hipMalloc(reinterpret_cast<void **>(&d_cnt), 16) != hipSuccess)
+    return done(ppk_fail(PPK_ERR_HIP, "hipMalloc failed"));
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    if (hipMalloc(reinterpret_cast<void **>(&d_edges), cap * 16) != hipSuccess)
+      return done(ppk_fail(PPK_ERR_HIP, "hipMalloc(edge list) failed"));
+    if (hipMemsetAsync(d_cnt, 0, 16, s) != hipSuccess) return done(ppk_fail(PPK_ERR_HIP, "hipMemset failed"));
+    rc = ppk_dist_edges_dev(p.ref, p.qry, kmers, random_tbl, n_clu, flags, p.q_begin, p.q_end, slope, x_max, y_max,
+                            scale_x, scale_y, inclusive, d_edges, cap, d_cnt, d_cnt + 1, s);
+    if (rc != PPK_OK) return done(rc);
+    unsigned long long h[2] = {0, 0};
+    if (hipMemcpyAsync(h, d_cnt, 16, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+      return done(ppk_fail(PPK_ERR_HIP, "kernel execution failed (fused edge list)"));
+    if (h[0] <= cap) {
+      p.edges.resize((size_t)h[0] * 2);
+      p.failed = h[1];
+      if (h[0] && hipMemcpy(p.edges.data(), d_edges, (size_t)h[0] * 16, hipMemcpyDeviceToHost) != hipSuccess)
+        return done(ppk_fail(PPK_ERR_HIP, "hipMemcpy D2H failed"));
+      return done(PPK_OK);
+    }
+    (void)hipFree(d_edges);                 // the guess was too small: once more with the exact size
+    d_edges = nullptr;
+    cap = (size_t)h[0];
+  }
+  done(ppk_fail(PPK_ERR_STATE, "internal: the edge count grew between two passes"));
+}
+}  // namespace
+
+extern "C" int ppk_query_edges_dbs(const ppk_db *const *refs, const ppk_db *const *qrys, int n_dev,
+                                   const int32_t *kmers, const float *random_tbl, size_t n_clu, int flags,
+                                   int slope, float x_max, float y_max, float scale_x, float scale_y,
+                                   int inclusive, long long *ij_out, size_t cap, size_t *n_edges,
+                                   unsigned long long *n_failed) {
+  if (n_edges) *n_edges = 0;
+  if (n_failed) *n_failed = 0;
+  if (!refs || n_dev < 1 || n_dev > 64) return ppk_fail(PPK_ERR_ARG, "ppk_query_edges_dbs: no databases");
+  if (!n_edges) return ppk_fail(PPK_ERR_ARG, "n_edges is NULL");
+  if (slope < 0 || slope > 2) return ppk_fail(PPK_ERR_ARG, "slope must be 0, 1 or 2");
+  if (flags & (PPK_FLAG_JACCARD | PPK_FLAG_COUNTS)) return ppk_fail(PPK_ERR_ARG, "edge output excludes the jaccard/counts flags");
+  std::vector<EdgePart> parts((size_t)n_dev);
+  for (int d = 0; d < n_dev; ++d) {
+    const ppk_db *q = qrys ? qrys[d] : nullptr;
+    if (!refs[d] || (qrys && !q)) return ppk_fail(PPK_ERR_ARG, "ppk_query_edges_dbs: a database is missing for some device");
+    int rc = ppk_check_pair(refs[d], q, kmers, 0, 0);
+    if (rc != PPK_OK) return rc;
+    if (refs[d]->n != refs[0]->n || refs[d]->nk != refs[0]->nk || refs[d]->s64 != refs[0]->s64 ||
+        refs[d]->bbits != refs[0]->bbits || (q ? q->n : 0) != (qrys && qrys[0] ? qrys[0]->n : 0))
+      return ppk_fail(PPK_ERR_ARG, "ppk_query_edges_dbs: the per-device databases differ in shape");
+    EdgePart &p = parts[(size_t)d];
+    p.device = refs[d]->device;
+    for (int e = 0; e < d; ++e) p.dup += parts[(size_t)e].device == p.device;
+    if (p.dup >= kMaxDup) return ppk_fail(PPK_ERR_ARG, "a device may be listed at most 4 times");
+    if (int rc2 = ppk_check_arch(p.device)) return rc2;
+    p.ref = refs[d];
+    p.qry = q;
+  }
+  const size_t n_ref = refs[0]->n, n_qry = qrys ? qrys[0]->n : 0;
+  std::vector<size_t> bounds((size_t)n_dev + 1, 0);
+  int rc = ppk_band_split(n_ref, n_qry, n_dev, bounds.data());
+  if (rc != PPK_OK) return rc;
+  std::lock_guard<std::mutex> lk(g_query_mu);
+  std::vector<PpkTicket> th;
+  for (int d = 0; d < n_dev; ++d) {
+    EdgePart &p = parts[(size_t)d];
+    p.q_begin = bounds[(size_t)d];
+    p.q_end = bounds[(size_t)d + 1];
+    auto work = [&p, kmers, random_tbl, n_clu, flags, slope, x_max, y_max, scale_x, scale_y, inclusive]() {
+      run_edge_part(p, kmers, random_tbl, n_clu, flags, slope, x_max, y_max, scale_x, scale_y, inclusive);
+    };
+    if (n_dev == 1) work();
+    else th.push_back(ppk_pool_run(work));
+  }
+  for (auto &t : th) ppk_pool_wait(t);
+  size_t total = 0;
+  for (EdgePart &p : parts) {
+    if (p.rc != PPK_OK) return ppk_fail(p.rc, p.err);
+    total += p.edges.size() / 2;
+    if (n_failed) *n_failed += p.failed;
+  }
+  *n_edges = total;
+  std::lock_guard<std::mutex> lp(g_parked_mu);
+  parked_drop_locked();
+  if (total > cap) {
+    // the whole list is done: it waits (on the host) for the calling thread's ppk_parked_fetch
+    g_parked.owner = std::this_thread::get_id();
+    g_parked.arrays = 1;
+    g_parked.n = total;
+    g_parked.host.reserve(total * 2);
+    for (EdgePart &p : parts) g_parked.host.insert(g_parked.host.end(), p.edges.begin(), p.edges.end());
+    return ppk_fail(PPK_ERR_CAPACITY, "output too small: need " + std::to_string(total) + " entries (parked: ppk_parked_fetch)");
+  }
+  if (total && !ij_out) return ppk_fail(PPK_ERR_ARG, "ij_out is NULL");
+  size_t off = 0;
+  for (EdgePart &p : parts) {
+    if (!p.edges.empty()) memcpy(ij_out + off, p.edges.data(), p.edges.size() * sizeof(long long));
+    off += p.edges.size();
+  }
+  return PPK_OK;
+}
+
+extern "C" int ppk_query_edges(const uint64_t *ref_sk, size_t n_ref, const uint64_t *qry_sk, size_t n_qry,
+                               const int32_t *kmers, size_t nk, size_t sketchsize64, size_t bbits,
+                               const float *random_tbl, const uint16_t *ref_clu, const uint16_t *qry_clu,
+                               size_t n_clu, int flags, int slope, float x_max, float y_max, float scale_x,
+                               float scale_y, int inclusive, const int *devices, int n_dev, long long *ij_out,
+                               size_t cap, size_t *n_edges, unsigned long long *n_failed) {
+  if (n_edges) *n_edges = 0;
+  if (n_failed) *n_failed = 0;
+  if (!ref_sk || !kmers || n_ref == 0 || nk == 0) return ppk_fail(PPK_ERR_ARG, "ppk_query_edges: missing sketches / kmers");
+  if (n_qry && !qry_sk) return ppk_fail(PPK_ERR_ARG, "ppk_query_edges: n_qry > 0 but no query sketches");
+  const int default_dev = 0;
+  if (!devices || n_dev < 1) {
+    devices = &default_dev;
+    n_dev = 1;
+  }
+  if (n_dev > 64) return ppk_fail(PPK_ERR_ARG, "too many devices");
+  // the resident copies: from ppk_query's cache (hash of every word, checked here before anything runs) or uploaded
+  const bool use_cache = ppk_config().db_cache.load() != 0;
+  const uint64_t ref_fp = use_cache ? fingerprint(ref_sk, n_ref * nk * sketchsize64 * bbits, ref_clu, n_ref) : 0;
+  const uint64_t qry_fp = use_cache && n_qry ? fingerprint(qry_sk, n_qry * nk * sketchsize64 * bbits, qry_clu, n_qry) : 0;
+  std::vector<const ppk_db *> refs((size_t)n_dev, nullptr), qrys((size_t)n_dev, nullptr);
+  std::vector<ppk_db *> owned;
+  int rc = PPK_OK;
+  for (int d = 0; d < n_dev && rc == PPK_OK; ++d) {
+    int first = -1;
+    for (int e = 0; e < d && first < 0; ++e)
+      if (devices[e] == devices[d]) first = e;
+    if (first >= 0) {                       // the same device again: the same copies
+      refs[(size_t)d] = refs[(size_t)first];
+      qrys[(size_t)d] = qrys[(size_t)first];
+      continue;
+    }
+    if (devices[d] < 0 || devices[d] >= 64) {
+      rc = ppk_fail(PPK_ERR_ARG, "device id out of range");
+      break;
+    }
+    ppk_db *db = nullptr;
+    bool own = false;
+    rc = db_acquire(devices[d], ref_sk, n_ref, nk, sketchsize64, bbits, ref_clu, ref_fp, use_cache, nullptr, nullptr,
+                    &db, &own);
+    if (rc != PPK_OK) break;
+    refs[(size_t)d] = db;
+    if (own) owned.push_back(db);
+    if (n_qry) {
+      db = nullptr;
+      rc = db_acquire(devices[d], qry_sk, n_qry, nk, sketchsize64, bbits, qry_clu, qry_fp, use_cache, refs[(size_t)d],
+                      nullptr, &db, &own);
+      if (rc != PPK_OK) break;
+      qrys[(size_t)d] = db;
+      if (own) owned.push_back(db);
+    }
+  }
+  if (rc == PPK_OK)
+    rc = ppk_query_edges_dbs(refs.data(), n_qry ? qrys.data() : nullptr, n_dev, kmers, random_tbl, n_clu, flags, slope,
+                             x_max, y_max, scale_x, scale_y, inclusive, ij_out, cap, n_edges, n_failed);
+  const std::string keep = ppk_error();
+  for (ppk_db *db : owned) ppk_db_destroy(db);
+  if (rc != PPK_OK) ppk_set_error(keep);
+  return rc;
 }

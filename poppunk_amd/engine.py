@@ -224,6 +224,44 @@ def dist_edges(ref, qry=None, kmers=None, random_tbl=None, random_correct=True, 
             cap = n
 
 
+def edges_host(refs, qrys=None, kmers=None, random_tbl=None, random_correct=True, slope=2, x_max=0.0,
+               y_max=0.0, scale=(1.0, 1.0), inclusive=True, cap=None):
+    """ppk_query_edges_dbs: the edge list of the whole matrix as a host int64 [m, 2] array, computed by
+    every device that holds a copy of the database (`refs` / `qrys`: one SketchDB per device, or a single
+    SketchDB), each on its band of rows, one worker thread per device inside the library.
+    Returns (edges, n_failed)."""
+    import numpy as np
+    lib = _lib.lib()
+    refs = [refs] if isinstance(refs, SketchDB) else list(refs)
+    if qrys is not None:
+        qrys = [qrys] if isinstance(qrys, SketchDB) else list(qrys)
+        if len(qrys) != len(refs):
+            raise ValueError("one query database per reference database")
+        for r, q in zip(refs, qrys):
+            _check_pair(r, q)
+    ref = refs[0]
+    kmers, random_tbl, tbl_ptr, n_clu = _prep_tables(kmers, random_tbl, ref.nk)
+    n_qry = qrys[0].n if qrys is not None else 0
+    rows = rows_in_band(ref.n, n_qry, 0, n_qry if qrys is not None else ref.n)
+    if cap is None:
+        cap = min(rows, max(1 << 20, rows // 8))
+    rh = (C.c_void_p * len(refs))(*[r._h.value for r in refs])
+    qh = (C.c_void_p * len(refs))(*[q._h.value for q in qrys]) if qrys is not None else None
+    llp = C.POINTER(C.c_longlong)
+    out = np.empty((max(int(cap), 1), 2), dtype=np.int64)
+    n_edges = C.c_size_t(0)
+    n_failed = C.c_ulonglong(0)
+    rc = lib.ppk_query_edges_dbs(rh, qh, len(refs), kmers.ctypes.data_as(C.POINTER(C.c_int32)), tbl_ptr, n_clu,
+                                 FLAG_RANDOM_CORRECT if random_correct else 0, int(slope), float(x_max),
+                                 float(y_max), float(scale[0]), float(scale[1]), 1 if inclusive else 0,
+                                 out.ctypes.data_as(llp), int(cap), C.byref(n_edges), C.byref(n_failed))
+    if rc == _lib.ERR_CAPACITY:
+        out = np.empty((n_edges.value, 2), dtype=np.int64)
+        rc = lib.ppk_parked_fetch(out.ctypes.data_as(llp), None, None, n_edges.value, None)
+    _lib.check(rc, "ppk_query_edges_dbs")
+    return out[:n_edges.value], int(n_failed.value)
+
+
 def assign_threshold_dev(dist_t, slope, x_max, y_max, out=None):
     """poppunk_refine.assignThreshold on a resident float32 [n,2] CUDA tensor."""
     torch = _torch()

@@ -269,14 +269,10 @@ def query_arrays(ref_sk, qry_sk, klist, sketchsize64, bbits, random_table=None, 
     return out, int(n_failed.value)
 
 
-def queryDatabase(ref_db_name, query_db_name, rList, qList, klist, random_correct=True,
-                  jaccard=False, num_threads=1, use_gpu=False, device_id=0):
-    """See module docstring.  Returns numpy float32 [n_pairs, 2] (core, accessory), or
-    [n_pairs, len(klist)] Jaccard distances when jaccard=True; rows ordered as
-    PopPUNK.utils.iterDistRows (utils.py:199-226)."""
-    klist = [int(k) for k in np.asarray(klist).ravel()]
-    rList = [str(x) for x in rList]
-    qList = [str(x) for x in qList]
+def _open_query(ref_db_name, query_db_name, rList, qList, klist, random_correct):
+    """The loaded databases and random-match arguments of one queryDatabase-shaped call:
+    (ref entry, query entry or None, table, ref clusters, query clusters).  Transient entries are the
+    caller's to close (`_close_transient`)."""
     self_query = (ref_db_name == query_db_name) and (rList == qList)
     ref_e = _load_cached(ref_db_name, rList, klist)
     ref = ref_e.loaded
@@ -313,18 +309,165 @@ def queryDatabase(ref_db_name, query_db_name, rList, qList, klist, random_correc
                     qry_clu = mapped[1]
             if qry_clu is None:
                 qry_clu = np.zeros(len(qList), dtype=np.uint16)
-        out, n_failed = query_entries(ref_e, qry_e, klist, table, ref.clusters, qry_clu,
-                                      random_correct=random_correct, jaccard=jaccard,
-                                      devices=_devices(device_id))
-    finally:
-        for e in (ref_e, qry_e):
-            if e is not None and e.transient:
-                e.close()
+    except BaseException:
+        _close_transient(ref_e, qry_e)
+        raise
+    return ref_e, qry_e, table, ref.clusters, qry_clu
+
+
+def _close_transient(*entries):
+    for e in entries:
+        if e is not None and e.transient:
+            e.close()
+
+
+def _warn_failed(n_failed):
     if n_failed:
         sys.stderr.write("poppunk_amd: fitting k-mer gradient failed for %d pair(s) "
                          "(fewer than two k-mer lengths above the 5/s Jaccard floor); "
                          "distances set to 0. Check for low quality genomes\n" % n_failed)
+
+
+def queryDatabase(ref_db_name, query_db_name, rList, qList, klist, random_correct=True,
+                  jaccard=False, num_threads=1, use_gpu=False, device_id=0):
+    """See module docstring.  Returns numpy float32 [n_pairs, 2] (core, accessory), or
+    [n_pairs, len(klist)] Jaccard distances when jaccard=True; rows ordered as
+    PopPUNK.utils.iterDistRows (utils.py:199-226)."""
+    klist = [int(k) for k in np.asarray(klist).ravel()]
+    rList = [str(x) for x in rList]
+    qList = [str(x) for x in qList]
+    ref_e, qry_e, table, ref_clu, qry_clu = _open_query(ref_db_name, query_db_name, rList, qList, klist,
+                                                        random_correct)
+    try:
+        out, n_failed = query_entries(ref_e, qry_e, klist, table, ref_clu, qry_clu,
+                                      random_correct=random_correct, jaccard=jaccard,
+                                      devices=_devices(device_id))
+    finally:
+        _close_transient(ref_e, qry_e)
+    _warn_failed(n_failed)
     return out
+
+
+def query_edges_entries(ref, qry, klist, slope, x_max, y_max, scale=(1.0, 1.0), inclusive=True,
+                        random_table=None, ref_clusters=None, qry_clusters=None, random_correct=True,
+                        devices=(0,), cap=None):
+    """ppk_query_edges_dbs on loaded databases (`_Entry`; qry=None => self) -> (int64 [m, 2], n_failed).
+    `cap`: room offered first (default: one edge per 8 pairs, at least 1 Mi); a longer list is fetched
+    from where the call parked it, never recomputed."""
+    lib = _lib.lib()
+    rl = ref.loaded
+    n_ref, nk, _ = rl.sketches.shape
+    kmers = np.ascontiguousarray(klist, dtype=np.int32).ravel()
+    if kmers.size != nk:
+        raise RuntimeError("klist does not match the sketches")
+    n_qry = 0 if qry is None else qry.loaded.sketches.shape[0]
+    if qry is not None and qry.loaded.sketches.shape[1:] != rl.sketches.shape[1:]:
+        raise RuntimeError("query and reference sketches have different shapes")
+    n_pairs = n_ref * (n_ref - 1) // 2 if qry is None else n_ref * n_qry
+    if n_pairs == 0:
+        return np.zeros((0, 2), dtype=np.int64), 0
+    tptr, n_clu, rclu, qclu, keep = _table_args(random_table, random_correct, ref_clusters, qry_clusters,
+                                                qry is not None)
+    devices = [int(d) for d in devices]
+    rh = ref.resident(devices, rclu)
+    qh = qry.resident(devices, qclu) if qry is not None else None
+    refs = (C.c_void_p * len(devices))(*[h.value for h in rh])
+    qrys = (C.c_void_p * len(devices))(*[h.value for h in qh]) if qh is not None else None
+    if cap is None:
+        cap = min(n_pairs, max(1 << 20, n_pairs // 8))
+    cap = max(int(cap), 0)
+    llp = C.POINTER(C.c_longlong)
+    out = np.empty((max(cap, 1), 2), dtype=np.int64)
+    n_edges = C.c_size_t(0)
+    n_failed = C.c_ulonglong(0)
+    rc = lib.ppk_query_edges_dbs(refs, qrys, len(devices), kmers.ctypes.data_as(C.POINTER(C.c_int32)), tptr,
+                                 n_clu, _flags(random_correct, False, False), int(slope), float(x_max),
+                                 float(y_max), float(scale[0]), float(scale[1]), 1 if inclusive else 0,
+                                 out.ctypes.data_as(llp), cap, C.byref(n_edges), C.byref(n_failed))
+    del keep
+    if rc == _lib.ERR_CAPACITY:
+        out = np.empty((n_edges.value, 2), dtype=np.int64)
+        rc = lib.ppk_parked_fetch(out.ctypes.data_as(llp), None, None, n_edges.value, None)
+    _lib.check(rc, "ppk_query_edges_dbs")
+    return out[:n_edges.value], int(n_failed.value)
+
+
+def query_edges_arrays(ref_sk, qry_sk, klist, sketchsize64, bbits, slope, x_max, y_max, scale=(1.0, 1.0),
+                       inclusive=True, random_table=None, ref_clusters=None, qry_clusters=None,
+                       random_correct=True, devices=(0,), cap=None):
+    """ppk_query_edges on in-memory sketch arrays [n, nk, words] (qry_sk=None => self)
+    -> (int64 [m, 2], n_failed)."""
+    lib = _lib.lib()
+    ref_sk = np.ascontiguousarray(ref_sk, dtype=np.uint64)
+    n_ref, nk, words = ref_sk.shape
+    if words != sketchsize64 * bbits:
+        raise RuntimeError("sketch word count does not match sketchsize64*bbits")
+    kmers = np.ascontiguousarray(klist, dtype=np.int32).ravel()
+    if kmers.size != nk:
+        raise RuntimeError("klist does not match the sketches")
+    n_qry = 0
+    qptr = None
+    if qry_sk is not None:
+        qry_sk = np.ascontiguousarray(qry_sk, dtype=np.uint64)
+        if qry_sk.shape[1:] != ref_sk.shape[1:]:
+            raise RuntimeError("query and reference sketches have different shapes")
+        n_qry = qry_sk.shape[0]
+        qptr = qry_sk.ctypes.data_as(C.POINTER(C.c_uint64))
+    n_pairs = n_ref * (n_ref - 1) // 2 if qry_sk is None else n_ref * n_qry
+    if n_pairs == 0:
+        return np.zeros((0, 2), dtype=np.int64), 0
+    tptr, n_clu, rclu, qclu, keep = _table_args(random_table, random_correct, ref_clusters, qry_clusters,
+                                                qry_sk is not None)
+    u16 = C.POINTER(C.c_uint16)
+    rcp = None if rclu is None else rclu.ctypes.data_as(u16)
+    qcp = None if qclu is None else qclu.ctypes.data_as(u16)
+    devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+    if cap is None:
+        cap = min(n_pairs, max(1 << 20, n_pairs // 8))
+    cap = max(int(cap), 0)
+    llp = C.POINTER(C.c_longlong)
+    out = np.empty((max(cap, 1), 2), dtype=np.int64)
+    n_edges = C.c_size_t(0)
+    n_failed = C.c_ulonglong(0)
+    rc = lib.ppk_query_edges(ref_sk.ctypes.data_as(C.POINTER(C.c_uint64)), n_ref, qptr, n_qry,
+                             kmers.ctypes.data_as(C.POINTER(C.c_int32)), nk, sketchsize64, bbits, tptr, rcp, qcp,
+                             n_clu, _flags(random_correct, False, False), int(slope), float(x_max), float(y_max),
+                             float(scale[0]), float(scale[1]), 1 if inclusive else 0, devs, len(devices),
+                             out.ctypes.data_as(llp), cap, C.byref(n_edges), C.byref(n_failed))
+    del keep
+    if rc == _lib.ERR_CAPACITY:
+        out = np.empty((n_edges.value, 2), dtype=np.int64)
+        rc = lib.ppk_parked_fetch(out.ctypes.data_as(llp), None, None, n_edges.value, None)
+    _lib.check(rc, "ppk_query_edges")
+    return out[:n_edges.value], int(n_failed.value)
+
+
+def queryDatabaseEdges(ref_db_name, query_db_name, rList, qList, klist, slope, x_max, y_max,
+                       scale=(1.0, 1.0), inclusive=False, random_correct=True, num_threads=1,
+                       use_gpu=False, device_id=0):
+    """queryDatabase and the model boundary in one call: the int64 [m, 2] edge list PopPUNK builds with
+    queryDatabase -> X / scale -> poppunk_refine.assignThreshold -> generateTuples
+    (PopPUNK/models.py:1065-1091, PopPUNK/network.py:1180-1184; inclusive=False, the default) or
+    -> poppunk_refine.edgeThreshold (PopPUNK/refine.py:535; inclusive=True), without the [n_pairs, 2]
+    matrix on any side of PCIe.  Arguments up to klist as queryDatabase; slope / x_max / y_max as the
+    boundary functions take them (x_max, y_max in SCALED units when `scale` = the model's scale is given);
+    device_id / PPK_DEVICES as queryDatabase: several devices each take a band of rows and the list is the
+    same.  Not a pp_sketchlib function: the entry point SURVEY.md section 8(b) proposes for PopPUNK's
+    model-assignment path on large collections."""
+    klist = [int(k) for k in np.asarray(klist).ravel()]
+    rList = [str(x) for x in rList]
+    qList = [str(x) for x in qList]
+    ref_e, qry_e, table, ref_clu, qry_clu = _open_query(ref_db_name, query_db_name, rList, qList, klist,
+                                                        random_correct)
+    try:
+        edges, n_failed = query_edges_entries(ref_e, qry_e, klist, slope, x_max, y_max, scale=scale,
+                                              inclusive=inclusive, random_table=table, ref_clusters=ref_clu,
+                                              qry_clusters=qry_clu, random_correct=random_correct,
+                                              devices=_devices(device_id))
+    finally:
+        _close_transient(ref_e, qry_e)
+    _warn_failed(n_failed)
+    return edges
 
 
 def _f32(a, what):

@@ -261,3 +261,100 @@ def test_staged_uploads_of_pageable_arrays(ppk_option, n, threads):
     assert np.array_equal(poppunk_refine.assignThreshold(d, 2, 0.4, 0.5), oracle.assign_threshold(d, 2, 0.4, 0.5))
     assert np.array_equal(poppunk_refine.edgeThreshold_array(d, 2, 0.1, 0.1), oracle.edge_threshold(d, 2, 0.1, 0.1))
     pp_sketchlib.clear_cache()
+
+
+# ---- sketches -> edge list as one host call (ppk_query_edges / ppk_query_edges_dbs) ------------------
+
+@pytest.mark.parametrize("devices", [(0,), (0, 0, 0)])
+@pytest.mark.parametrize("inclusive", [False, True])
+def test_query_edges_host_call_equals_two_step(devices, inclusive):
+    """The fused host call gives the list of queryDatabase -> X / scale -> edgeThreshold (inclusive) or
+    assignThreshold -> generateTuples (strict) on the SAME distances, whatever the device list: bands of
+    rows, concatenated in row order."""
+    sk, _ = synth.make_sketches(900, KMERS, cluster_size=30, seed=5)
+    tbl = synth.random_match_table(KMERS)
+    dist, _ = pp_sketchlib.query_arrays(sk, None, KMERS, 16, 14, tbl)
+    odist, _ = oracle.query(sk, None, KMERS, 16, 14, tbl, threads=4)
+    assert np.abs(dist - odist).max() <= TOL
+    x_max, y_max = synth.boundary_for_quantile(dist, 0.08)
+    scale = (np.float32(dist[:, 0].max()), np.float32(dist[:, 1].max()))
+    scaled = np.ascontiguousarray(dist / np.asarray(scale, dtype=np.float32))      # PopPUNK/models.py:1085
+    xs, ys = x_max / float(scale[0]), y_max / float(scale[1])
+    for slope in (0, 1, 2):
+        want = oracle.edge_threshold(scaled, slope, xs, ys, inclusive=inclusive)
+        assert len(want) > 100
+        got, nf = pp_sketchlib.query_edges_arrays(sk, None, KMERS, 16, 14, slope, xs, ys, scale=scale,
+                                                  inclusive=inclusive, random_table=tbl, devices=devices)
+        assert nf == 0 and got.dtype == np.int64 and np.array_equal(got, want)
+        # too little room: the finished list is parked on the host and fetched, not recomputed
+        got2, _ = pp_sketchlib.query_edges_arrays(sk, None, KMERS, 16, 14, slope, xs, ys, scale=scale,
+                                                  inclusive=inclusive, random_table=tbl, devices=devices, cap=7)
+        assert np.array_equal(got2, want)
+    # the strict list is what the two library calls PopPUNK makes give (models.py:1088, network.py:1180)
+    if not inclusive:
+        a = poppunk_refine.assignThreshold(scaled, 2, xs, ys, 1)
+        t = poppunk_refine.generateTuples(a.astype(np.int32).tolist(), -1, self=True, num_ref=0, int_offset=0)
+        got, _ = pp_sketchlib.query_edges_arrays(sk, None, KMERS, 16, 14, 2, xs, ys, scale=scale,
+                                                 inclusive=False, random_table=tbl, devices=devices)
+        assert [tuple(r) for r in got.tolist()] == [tuple(x) for x in t]
+
+
+def test_query_edges_ref_query_clusters_and_errors():
+    sk, clu = synth.make_sketches(640, KMERS, cluster_size=20, seed=8)
+    tbl = synth.random_match_table(KMERS)
+    ref, qry = sk[:500], sk[500:]
+    dist, _ = pp_sketchlib.query_arrays(ref, qry, KMERS, 16, 14, tbl)
+    x_max, y_max = synth.boundary_for_quantile(dist, 0.1)
+    want = oracle.edge_threshold(dist, 2, x_max, y_max, n_ref=500, inclusive=True)
+    assert len(want) > 100
+    for devices in ((0,), (0, 0)):
+        got, _ = pp_sketchlib.query_edges_arrays(ref, qry, KMERS, 16, 14, 2, x_max, y_max, random_table=tbl,
+                                                 devices=devices)
+        assert np.array_equal(got, want)
+    # an empty list, and a boundary nothing lies outside
+    none, _ = pp_sketchlib.query_edges_arrays(ref, qry, KMERS, 16, 14, 2, 1e-9, 1e-9, random_table=tbl,
+                                              inclusive=False)
+    assert none.shape == (0, 2)
+    every, _ = pp_sketchlib.query_edges_arrays(ref, qry, KMERS, 16, 14, 2, 50.0, 50.0, random_table=tbl,
+                                               devices=(0, 0))
+    assert len(every) == 500 * 140 and np.array_equal(every[:3], [[0, 500], [1, 500], [2, 500]])
+    # a thread that parked nothing has nothing to fetch, and a fetched list is gone
+    lib = _lib.lib()
+    buf = np.empty((4, 2), dtype=np.int64)
+    n = C.c_size_t(0)
+    assert lib.ppk_parked_fetch(buf.ctypes.data_as(C.POINTER(C.c_longlong)), None, None, 4, C.byref(n)) == _lib.ERR_STATE
+    with pytest.raises(RuntimeError, match="slope"):
+        pp_sketchlib.query_edges_arrays(ref, qry, KMERS, 16, 14, 3, x_max, y_max, random_table=tbl)
+    with pytest.raises(RuntimeError, match="at most 4"):
+        pp_sketchlib.query_edges_arrays(ref, qry, KMERS, 16, 14, 2, x_max, y_max, random_table=tbl,
+                                        devices=(0,) * 5)
+
+
+def test_queryDatabaseEdges_mirror(tmp_path, monkeypatch):
+    """The database-file form: the loaded database's handles, PPK_DEVICES, and a model's scale."""
+    from poppunk_amd import sketchdb
+    sk, _ = synth.make_sketches(800, KMERS, cluster_size=40, seed=31)
+    tbl = synth.random_match_table(KMERS)
+    names = ["g%04d" % i for i in range(800)]
+    db = str(tmp_path / "db")
+    sketchdb.save_npz(db, names, KMERS, sk, 16, 14, random_table=tbl)
+    pp_sketchlib.clear_cache()
+    klist = KMERS.tolist()
+    dist = pp_sketchlib.queryDatabase(db, db, names, names, klist, True, False, 1, True, 0)
+    x_max, y_max = synth.boundary_for_quantile(dist, 0.05)
+    scale = (np.float32(dist[:, 0].max()), np.float32(dist[:, 1].max()))
+    scaled = np.ascontiguousarray(dist / np.asarray(scale, dtype=np.float32))
+    xs, ys = x_max / float(scale[0]), y_max / float(scale[1])
+    want = oracle.edge_threshold(scaled, 2, xs, ys, inclusive=False)
+    assert len(want) > 100
+    got = pp_sketchlib.queryDatabaseEdges(db, db, names, names, klist, 2, xs, ys, scale=scale)
+    assert np.array_equal(got, want)
+    monkeypatch.setenv("PPK_DEVICES", "0,0")
+    got = pp_sketchlib.queryDatabaseEdges(db, db, names, names, klist, 2, xs, ys, scale=scale)
+    assert np.array_equal(got, want)
+    # ref x query out of the same file (transient sub-sample entries)
+    rq = pp_sketchlib.queryDatabase(db, db, names[:600], names[600:], klist, True, False, 1, True, 0)
+    wq = oracle.edge_threshold(rq, 2, x_max, y_max, n_ref=600, inclusive=True)
+    gq = pp_sketchlib.queryDatabaseEdges(db, db, names[:600], names[600:], klist, 2, x_max, y_max, inclusive=True)
+    assert len(wq) > 50 and np.array_equal(gq, wq)
+    pp_sketchlib.clear_cache()
