@@ -197,7 +197,7 @@ def host_call(sk, kmers, tbl, devices, reps=5):
                     % (reps - 1, sk.nbytes >> 20)}
 
 
-def config5(args, rank, world, local_rank, dev, barrier):
+def config5(args, rank, world, local_rank, dev, barrier, fields, park):
     """BASELINE config 5's shape on N GPUs: fused distance -> boundary -> edge list per band, only
     the edge lists move (engine.edges_sharded)."""
     import torch
@@ -233,25 +233,26 @@ def config5(args, rank, world, local_rank, dev, barrier):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     pairs = n * (n - 1) // 2
+    out = {"workload": "%d synthetic genomes self-vs-self, s=1024, k=13,17,21,25,29, fused distance -> "
+                       "slope-2 boundary -> edge list; band-split x%d, only the edge lists gathered to rank 0"
+                       % (n, world),
+           "pairs": pairs, "n_edges": int(sum(counts)), "steps": args.config5_steps,
+           "ms_per_step": elapsed / args.config5_steps * 1e3,
+           "value": pairs * args.config5_steps / elapsed, "unit": "pairs/s",
+           "gathered_bytes_per_step": int(sum(counts[1:])) * 16}
+    fields["config5"] = out        # on record before the extra leg below: a watchdog line carries it
     # the same job as ONE host call of one process (ppk_query_edges_dbs): every device the process sees takes
     # a band on a worker thread of its own, the list arrives in a host array.  Rank 0 alone; the others wait.
-    host = None
     if rank == 0:
         try:
-            host = config5_host_call(ref, kmers, tbl, x_max, y_max, world, local_rank, int(sum(counts)))
+            out["host_call"] = config5_host_call(ref, kmers, tbl, x_max, y_max, world, local_rank,
+                                                 int(sum(counts)))
         except Exception as e:          # a figure less, never a lost line or a rank missing at the barrier
-            host = {"error": "%s: %s" % (type(e).__name__, e)}
-    barrier()
+            out["host_call"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    park("config5")
     ref.close()
     torch.cuda.empty_cache()
-    return {"host_call": host,
-            "workload": "%d synthetic genomes self-vs-self, s=1024, k=13,17,21,25,29, fused distance -> "
-                        "slope-2 boundary -> edge list; band-split x%d, only the edge lists gathered to rank 0"
-                        % (n, world),
-            "pairs": pairs, "n_edges": int(sum(counts)), "steps": args.config5_steps,
-            "ms_per_step": elapsed / args.config5_steps * 1e3,
-            "value": pairs * args.config5_steps / elapsed, "unit": "pairs/s",
-            "gathered_bytes_per_step": int(sum(counts[1:])) * 16}
+    return out
 
 
 def config5_host_call(ref, kmers, tbl, x_max, y_max, world, local_rank, n_edges_expected, reps=3):
@@ -603,6 +604,22 @@ def run(args, rep, rank, local_rank, world, fake, torch, dist, engine, synth, da
             dist.barrier()
         sync()
 
+    def park(tag):
+        """The barrier after a leg that rank 0 runs alone on EVERY GPU: the other ranks first wait on the
+        host (the rendezvous store) so that no collective kernel spins on their GPUs meanwhile."""
+        if world > 1:
+            try:
+                import datetime
+                store = dist.distributed_c10d._get_default_store()
+                key = "ppk_park_%s" % tag
+                if rank == 0:
+                    store.set(key, "1")
+                else:
+                    store.wait([key], datetime.timedelta(seconds=max(60, int(args.watchdog_s))))
+            except Exception:
+                pass                # no store to wait on: the plain barrier below does it, GPUs a little busier
+        barrier()
+
     def reduce_max(vals):
         if world == 1:
             return vals
@@ -775,7 +792,7 @@ def run(args, rep, rank, local_rank, world, fake, torch, dist, engine, synth, da
                                                                % (torch.cuda.device_count(), world)}
                     except Exception as e:
                         rep.error("host_call", e)
-                barrier()
+                park("host_call")
         except Exception as e:
             rep.error("host_call", e)
 
@@ -785,7 +802,7 @@ def run(args, rep, rank, local_rank, world, fake, torch, dist, engine, synth, da
             ref.close()
             job.out = None
             torch.cuda.empty_cache()
-            f["config5"] = config5(args, rank, world, local_rank, dev, barrier)
+            f["config5"] = config5(args, rank, world, local_rank, dev, barrier, f, park)
         except Exception as e:
             rep.error("config5", e)
     if rank == 0 and not args.no_cpu and world == 1:
