@@ -101,6 +101,7 @@ def _declare(h):
         "H5free_memory": (C.c_int, [C.c_void_p]),
         "H5Tenum_create": (_hid, [_hid]), "H5Tenum_insert": (C.c_int, [_hid, C.c_char_p, C.c_void_p]),
         "H5Tset_strpad": (C.c_int, [_hid, C.c_int]),
+        "H5Ocopy": (C.c_int, [_hid, C.c_char_p, _hid, C.c_char_p, _hid, _hid]),
         "H5Pcreate": (_hid, [_hid]), "H5Pset_fclose_degree": (C.c_int, [_hid, C.c_int]), "H5Pclose": (C.c_int, [_hid]),
     }
     for name, (res, args) in sig.items():
@@ -216,6 +217,13 @@ class _Attrs:
 
     def get(self, name, default=None):
         return self[name] if name in self else default
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    def create(self, name, data):
+        """h5py's AttributeManager.create(name, data)."""
+        self[name] = data
 
     def __setitem__(self, name, value):
         h = lib()
@@ -333,6 +341,28 @@ class Group:
         if g < 0:
             raise KeyError(name)
         return Group(g, self.name.rstrip("/") + "/" + name, self)
+
+    def copy(self, source, dest, name=None):
+        """h5py's Group.copy: `source` is a member name of this group or an open Group / Dataset; `dest` a
+        Group (the copy keeps the source's own name, or takes `name`) or a path relative to this group.
+        The library copies the object with everything under it and every attribute, types as stored
+        (H5Ocopy)."""
+        h = lib()
+        if isinstance(source, (Group, Dataset)):
+            src_loc, src_name, base = source._id, b".", source.name.rstrip("/").rpartition("/")[2]
+        else:
+            src_loc, src_name, base = self._id, str(source).encode(), str(source).rstrip("/").rpartition("/")[2]
+        if isinstance(dest, Group):
+            dst_loc, dst_name = dest._id, (name or base)
+        else:
+            dst_loc, dst_name = self._id, str(dest)
+        if not dst_name:
+            raise ValueError("h5lite: copy needs a destination name")
+        if h.H5Ocopy(src_loc, src_name, dst_loc, dst_name.encode(), 0, 0) < 0:
+            raise RuntimeError("h5lite: cannot copy %s to %s" % (base or "/", dst_name))
+
+    def __iter__(self):
+        return iter(self.keys())
 
     def create_group(self, name):
         g = lib().H5Gcreate2(self._id, name.encode(), 0, 0, 0)

@@ -426,3 +426,150 @@ if __name__ == "__main__":
     n_done, k_done, r_done = convert_h5_to_npz(sys.argv[1], sys.argv[2] if len(sys.argv) == 3 else None)
     print("wrote %s.npz: %d samples, k = %s, /random: %s"
           % (sys.argv[2] if len(sys.argv) == 3 else sys.argv[1], n_done, k_done, r_done))
+
+
+# ---- database files either side of the distance call: --update-db, QC pruning, reference picking -------
+
+def _prefix_file(prefix, suffix=".h5"):
+    return prefix + "/" + os.path.basename(prefix) + suffix
+
+
+def getSketchSize(dbPrefix):
+    """(sketch size in units of 64 bins, codon_phased), checked for consistency over the samples
+    (PopPUNK/sketchlib.py:109-142; `sys.exit(1)` on a mixed database)."""
+    _, h5open = _h5_backend()
+    f = h5open(_prefix_file(dbPrefix), "r")
+    try:
+        top = f["sketches"]
+        codon_phased = bool(np.asarray(top.attrs["codon_phased"]).ravel()[0]) if "codon_phased" in top.attrs else False
+        prev = 0
+        for nm in top.keys():
+            s = int(np.asarray(top[nm].attrs["sketchsize64"]).ravel()[0])
+            if prev == 0:
+                prev = s
+            elif s != prev:
+                sys.stderr.write("Problem with database; sketch sizes for sample %s is %d, but smaller kmers "
+                                 "have sketch sizes of %d\n" % (nm, prev, s))
+                sys.exit(1)
+    finally:
+        f.close()
+    return int(prev), codon_phased
+
+
+def getKmersFromReferenceDatabase(dbPrefix):
+    """Sorted k-mer lengths of the database, checked for consistency (PopPUNK/sketchlib.py:144-168)."""
+    _, h5open = _h5_backend()
+    f = h5open(_prefix_file(dbPrefix), "r")
+    try:
+        top = f["sketches"]
+        prev = None
+        for nm in top.keys():
+            ks = [int(k) for k in np.asarray(top[nm].attrs["kmers"]).ravel()]
+            if prev is None:
+                prev = ks
+            elif ks != prev:
+                sys.stderr.write("Problem with database; kmer lengths inconsistent: %s vs %s\n" % (ks, prev))
+                sys.exit(1)
+    finally:
+        f.close()
+    return np.asarray(sorted(prev or []))
+
+
+def get_database_statistics(prefix):
+    """(genome lengths, ambiguous-base counts) per sample in database order
+    (PopPUNK/sketchlib.py:672-690; callers PopPUNK/__main__.py:404,:492 for QC)."""
+    _, h5open = _h5_backend()
+    f = h5open(_prefix_file(prefix), "r")
+    try:
+        top = f["sketches"]
+        lengths, ambiguous = [], []
+        for nm in top.keys():
+            g = top[nm]
+            lengths.append(np.asarray(g.attrs["length"]).ravel()[0])
+            ambiguous.append(np.asarray(g.attrs["missing_bases"]).ravel()[0])
+    finally:
+        f.close()
+    return lengths, ambiguous
+
+
+def joinDBs(db1, db2, output, update_random=None, full_names=False):
+    """The sketches of two databases in one file, by the library's object copy -- every sample group with
+    its datasets and attributes as stored (PopPUNK/sketchlib.py:216-293; caller PopPUNK/assign.py:741,
+    PopPUNK/visualise.py:493).  Written to `<output>.tmp.h5`, renamed when complete.
+
+    /random: db1's group is carried over, as the reference does when `update_random` is None.  With
+    `update_random` given the reference re-runs pp_sketchlib.addRandom on the joined file; sketching-side
+    functions are outside this package (sketching is out of scope), so db1's table is
+    carried here too and a line on stderr says so -- a sample absent from the table takes the nearest
+    base-frequency cluster when it is queried (`random_from_raw`)."""
+    if not full_names:
+        join_prefix = output + "/" + os.path.basename(output)
+        db1_name, db2_name = _prefix_file(db1), _prefix_file(db2)
+    else:
+        db1_name, db2_name, join_prefix = db1, db2, output
+    _, h5open = _h5_backend()
+    hdf1 = h5open(db1_name, "r")
+    hdf2 = h5open(db2_name, "r")
+    hdf_join = h5open(join_prefix + ".tmp.h5", "w")       # .tmp in case the joined name is one of the inputs
+    try:
+        try:
+            hdf1.copy("sketches", hdf_join)
+            join_grp = hdf_join["sketches"]
+            read_grp = hdf2["sketches"]
+            for sample in read_grp.keys():
+                join_grp.copy(read_grp[sample], sample)
+            if "random" in hdf1:
+                hdf1.copy("random", hdf_join)
+            if update_random is not None:
+                sys.stderr.write("poppunk_amd: random match chances of %s carried over to the joined database "
+                                 "(not re-estimated: run pp_sketchlib.addRandom on it for that)\n" % db1_name)
+        finally:
+            hdf1.close()
+            hdf2.close()
+            hdf_join.close()
+    except RuntimeError as e:
+        sys.stderr.write("ERROR: " + str(e) + "\n")
+        sys.stderr.write("Joining sketches failed, try running without --update-db\n")
+        sys.exit(1)
+    os.rename(join_prefix + ".tmp.h5", join_prefix + ".h5")
+
+
+def removeFromDB(db_name, out_name, removeSeqs, full_names=False):
+    """A copy of the database without the named samples (PopPUNK/sketchlib.py:296-346; callers
+    PopPUNK/assign.py:800, PopPUNK/qc.py:515-525, PopPUNK/reference_pick.py:104).  As in the reference the
+    prefix form writes `<out_name>/<basename>.tmp.h5` and leaves the rename to the caller; /random and the
+    attributes of /sketches are kept; names that are not in the database are reported on stderr."""
+    removeSeqs = set(removeSeqs)
+    if not full_names:
+        db_file, out_file = _prefix_file(db_name), _prefix_file(out_name, ".tmp.h5")
+    else:
+        db_file, out_file = db_name, out_name
+    _, h5open = _h5_backend()
+    hdf_in = h5open(db_file, "r")
+    hdf_out = h5open(out_file, "w")
+    sample = ""
+    removed = []
+    try:
+        try:
+            if "random" in hdf_in:
+                hdf_in.copy("random", hdf_out)
+            out_grp = hdf_out.create_group("sketches")
+            read_grp = hdf_in["sketches"]
+            for attr_name, attr_val in read_grp.attrs.items():
+                out_grp.attrs.create(attr_name, attr_val)
+            for sample in read_grp.keys():
+                if sample not in removeSeqs:
+                    out_grp.copy(read_grp[sample], sample)
+                else:
+                    removed.append(sample)
+        finally:
+            hdf_in.close()
+            hdf_out.close()
+    except RuntimeError as e:
+        sys.stderr.write("ERROR: " + str(e) + "\n")
+        sys.stderr.write("Error while deleting sequence " + sample + "\n")
+        sys.exit(1)
+    missed = removeSeqs.difference(removed)
+    if missed:
+        sys.stderr.write("WARNING: Did not find samples to remove:\n")
+        sys.stderr.write("\t".join(missed) + "\n")

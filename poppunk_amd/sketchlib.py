@@ -6,10 +6,13 @@ error behaviour, backed by the HIP engine instead of pp_sketchlib.
 jaccard=True, raw and random-corrected, and fits the curve with `fitKmerCurve`; the numbers are
 written next to where the reference writes its figure (`*_fit_example_<i>.tsv`), and the figure
 itself too when matplotlib is importable (drawing it is PopPUNK.plot's job, out of scope).
-`readDBParams` / `getSeqsInDb` are the database-parameter readers of :170-214.
+`readDBParams` / `getSeqsInDb` / `getSketchSize` / `getKmersFromReferenceDatabase` /
+`get_database_statistics` are the database readers of :109-214 and :672-690; `joinDBs` / `removeFromDB`
+(:216-346) the file operations --update-db, QC and reference picking run either side of the distance
+call (poppunk_amd/sketchdb.py).
 
-Out of scope here (sketch I/O plumbing):
-constructDatabase, addRandom, joinDBs, removeFromDB.
+Out of scope here (sketching: SURVEY.md section 8(d) "no genomes are sketched"):
+constructDatabase, addRandom.
 """
 import os
 import sys
@@ -19,7 +22,8 @@ import numpy as np
 
 from . import pp_sketchlib
 from .utils import iterDistRows, stderr_redirected  # noqa: F401  (PopPUNK/utils.py:61-83,:199-226)
-from .sketchdb import getSeqsInDb, readDBParams  # noqa: F401  (PopPUNK/sketchlib.py:170-214)
+from .sketchdb import (getSeqsInDb, readDBParams, getSketchSize, getKmersFromReferenceDatabase,  # noqa: F401
+                       get_database_statistics, joinDBs, removeFromDB)  # (PopPUNK/sketchlib.py:109-346,:672-690)
 
 
 def fitKmerCurve(pairwise, klist, jacobian=None):
