@@ -295,7 +295,15 @@ int ppk_edge_threshold(const float *dist, size_t n_rows, size_t n_ref, int slope
 int ppk_generate_tuples(const int32_t *assignments, size_t n_rows, int within_label,
                         int self, size_t num_ref, long long int_offset, int device_id,
                         long long *ij_out, size_t cap, size_t *n_edges);
-/* The result the calling thread's last ppk_edge_threshold / ppk_generate_tuples (out0 = int64 [n][2];
+/* replaces the numpy masks + .tolist() + poppunk_refine.generateTuples of qcDistMat on a HOST matrix
+ * (PopPUNK/qc.py:332-337: core > max_pi or accessory > max_a; :349-354: core == 0 or accessory == 0), both
+ * lists from one upload: `modes` bit 0 = the long-distance list, bit 1 = the zero-distance list, written one
+ * after the other to ij_out; *n_edges = entries of both, *n_first = entries of the first list asked for.
+ * n_ref == 0: self (condensed) matrix, else row = q*n_ref + r as in ppk_edge_threshold. */
+int ppk_qc_edges(const float *dist, size_t n_rows, size_t n_ref, int modes, float max_pi,
+                 float max_a, int device_id, long long *ij_out, size_t cap, size_t *n_edges,
+                 size_t *n_first);
+/* The result the calling thread's last ppk_edge_threshold / ppk_generate_tuples / ppk_qc_edges (out0 = int64 [n][2];
  * out1, out2 ignored) or ppk_threshold_iterate_1d / _2d (out0, out1, out2 = i, j, offset index, int64
  * [n] each) call parked when it returned PPK_ERR_CAPACITY.  cap = room in entries; *n_out (nullable)
  * receives the entry count.  PPK_ERR_STATE when this thread has nothing parked; the result is freed by

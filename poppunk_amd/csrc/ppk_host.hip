@@ -1313,6 +1313,63 @@ extern "C" int ppk_edge_threshold(const float *dist, size_t n_rows, size_t n_ref
                          copy_out);
 }
 
+// qcDistMat's two edge lists from ONE upload of the host matrix (PopPUNK/qc.py:332-337 long distances,
+// :349-354 zero distances): `modes` bit 0 = the long-distance list, bit 1 = the zero-distance list; the
+// lists come back one after the other in ij_out, *n_first = entries of the first one present.
+extern "C" int ppk_qc_edges(const float *dist, size_t n_rows, size_t n_ref, int modes, float max_pi,
+                            float max_a, int device_id, long long *ij_out, size_t cap, size_t *n_edges,
+                            size_t *n_first) {
+  if (n_edges) *n_edges = 0;
+  if (n_first) *n_first = 0;
+  if (n_rows == 0) return PPK_OK;
+  if (!dist) return ppk_fail(PPK_ERR_ARG, "dist is NULL");
+  if (!n_edges || !n_first) return ppk_fail(PPK_ERR_ARG, "n_edges / n_first is NULL");
+  if ((modes & 3) == 0 || (modes & ~3)) return ppk_fail(PPK_ERR_ARG, "modes: bit 0 long distances, bit 1 zero distances");
+  DeviceGuard guard(device_id);
+  if (!guard.ok) return ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(device_id));
+  size_t guess = n_rows / 16 > ((size_t)1 << 20) ? n_rows / 16 : ((size_t)1 << 20);   // QC failures are the exception
+  if (guess > 2 * n_rows) guess = 2 * n_rows;
+  bool uploaded = false;
+  auto copy_out = [&](const void *d, size_t n, size_t) {
+    if (!ij_out) return ppk_fail(PPK_ERR_ARG, "ij_out is NULL");
+    if (hipMemcpy(ij_out, d, n * 16, hipMemcpyDeviceToHost) != hipSuccess) return ppk_fail(PPK_ERR_HIP, "hipMemcpy D2H failed");
+    return (int)PPK_OK;
+  };
+  return ppk_host_result(1, device_id, guess, cap, n_edges,
+                         [&](size_t c, void **d_res, unsigned long long *want) {
+                           PpkCall call(device_id, nullptr);
+                           void *p_in = nullptr;
+                           unsigned long long *d_n = nullptr;
+                           int rc = ppk_scratch_get(device_id, SLOT_HOST_IN, n_rows * 8 + 8, &p_in);
+                           float *d_dist = static_cast<float *>(p_in);
+                           if (rc == PPK_OK && (hipMalloc(reinterpret_cast<void **>(&d_n), 8) != hipSuccess ||
+                                                hipMalloc(d_res, (c ? c : 1) * 16) != hipSuccess))
+                             rc = ppk_fail(PPK_ERR_HIP, "hipMalloc failed");
+                           if (rc == PPK_OK && !uploaded) {     // a second pass (guess too small) re-uses the copy
+                             rc = ppk_upload(device_id, d_dist, dist, n_rows * 8, nullptr);
+                             uploaded = rc == PPK_OK;
+                           }
+                           unsigned long long total = 0;
+                           bool first = true;
+                           for (int mode = 0; mode < 2 && rc == PPK_OK; ++mode) {
+                             if (!(modes & (1 << mode))) continue;
+                             const size_t used = total < c ? (size_t)total : c;
+                             unsigned long long got = 0;
+                             rc = ppk_qc_edges_dev(d_dist, n_rows, n_ref, mode, max_pi, max_a,
+                                                   static_cast<long long *>(*d_res) + 2 * used, c - used, d_n, nullptr);
+                             if (rc == PPK_OK && hipMemcpy(&got, d_n, 8, hipMemcpyDeviceToHost) != hipSuccess)
+                               rc = ppk_fail(PPK_ERR_HIP, "hipMemcpy D2H failed");
+                             total += got;
+                             if (first) *n_first = (size_t)got;
+                             first = false;
+                           }
+                           *want = total;
+                           if (d_n) (void)hipFree(d_n);
+                           return rc;
+                         },
+                         copy_out);
+}
+
 extern "C" int ppk_generate_tuples(const int32_t *assignments, size_t n_rows, int within_label,
                                    int self, size_t num_ref, long long int_offset, int device_id,
                                    long long *ij_out, size_t cap, size_t *n_edges) {

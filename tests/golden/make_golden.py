@@ -27,6 +27,10 @@ Fixtures written:
                        sets of its thresholdIterate1D/2D sections (:84-138) with
                        withinBoundary in the role poppunk_refine.assignThreshold plays there.
                        This is the pin of the kernel-2 oracle (oracle/ppk_oracle.c).
+  qc.json, qc_autodist.npz
+                       PopPUNK.qc.qcDistMat / prune_edges / autoDistFind (PopPUNK/qc.py:238-369,:419-468)
+                       on small seeded matrices (see golden_qc for what stands in for the compiled
+                       poppunk_refine.generateTuples)
 boundary_known_answers.json is NOT generated here and pins nothing: it holds values
 hand-transcribed from SURVEY.md Appendix B and is kept only as a cross-check.
 """
@@ -182,6 +186,99 @@ def golden_prune():
     print("prune.json:", len(out["self"]), "self cases,", len(out["query"]), "query cases")
 
 
+def golden_qc():
+    """PopPUNK.qc.qcDistMat / prune_edges / autoDistFind (PopPUNK/qc.py:238-369,:419-468) run on small
+    seeded matrices.  qcDistMat calls the compiled poppunk_refine.generateTuples, which cannot be built
+    here; in its role runs oracle.generate_tuples -- this repo's restatement of src/boundary.cpp:97-123,
+    itself pinned by boundary_refine.npz -- and every other line is the reference's own."""
+    from collections import Counter
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import oracle
+
+    class Refine:
+        @staticmethod
+        def generateTuples(assignments, within_label, self=True, num_ref=0, int_offset=0):
+            e = oracle.generate_tuples(np.asarray(assignments, dtype=np.int32), within_label, self=self,
+                                       num_ref=num_ref, int_offset=int_offset)
+            return [tuple(int(v) for v in row) for row in np.asarray(e).tolist()]
+
+    ns = {"np": np, "sys": sys, "Counter": Counter, "poppunk_refine": Refine}
+    extract_functions(os.path.join(REF, "PopPUNK", "qc.py"), ["qcDistMat", "prune_edges", "autoDistFind"], ns)
+    rng = np.random.Generator(np.random.PCG64(20260930))
+    out = {"source": "PopPUNK/qc.py:238-369,:419-468 qcDistMat / prune_edges / autoDistFind, run by "
+                     "make_golden.py with oracle.generate_tuples in the role of poppunk_refine.generateTuples",
+           "qcDistMat": [], "prune_edges": [], "autoDistFind": []}
+
+    def population(n_ref, n_qry, bad, zero):
+        """distances of n samples; `bad` samples sit far from everything, `zero` pairs are duplicates"""
+        rows = n_ref * (n_ref - 1) // 2 if n_qry == 0 else n_ref * n_qry
+        d = np.stack([rng.uniform(0.001, 0.02, rows), rng.uniform(0.01, 0.3, rows)], axis=1).astype(np.float32)
+        pairs = ([(i, j) for i in range(n_ref) for j in range(i + 1, n_ref)] if n_qry == 0
+                 else [(r, n_ref + q) for q in range(n_qry) for r in range(n_ref)])
+        for row, (i, j) in enumerate(pairs):
+            if i in bad or j in bad:
+                d[row] = (rng.uniform(0.06, 0.2), rng.uniform(0.55, 0.9))
+            if (i, j) in zero:
+                d[row, rng.integers(0, 2)] = 0.0
+        return d
+
+    stderr = sys.stderr
+    sys.stderr = open(os.devnull, "w")
+    try:
+        cases = [  # n_ref, n_qry, bad samples, zero pairs, prop_zero
+            (12, 0, {3}, set(), 1.0),
+            (20, 0, {0, 7, 19}, {(1, 2), (1, 5), (1, 9), (4, 6)}, 0.1),
+            (30, 0, set(), {(2, 3), (2, 4), (2, 5), (2, 6), (8, 9)}, 0.1),
+            (15, 0, {5, 6}, {(5, 6), (0, 1)}, 0.05),
+            (8, 5, {9, 12}, {(0, 8), (1, 8), (2, 8)}, 0.2),
+            (10, 6, {2}, set(), 0.5),
+            (6, 4, set(), set(), 0.05),
+        ]
+        for n_ref, n_qry, bad, zero, prop_zero in cases:
+            d = population(n_ref, n_qry, bad, zero)
+            refs = ["r%02d" % i for i in range(n_ref)]
+            qrys = refs if n_qry == 0 else ["q%02d" % i for i in range(n_qry)]
+            qc = {"max_pi_dist": 0.05, "max_a_dist": 0.5, "prop_zero": prop_zero}
+            kept, failed = ns["qcDistMat"](d, refs, qrys, "unused_db", qc)
+            out["qcDistMat"].append({"refs": refs, "queries": qrys, "dist": d.tolist(), "qc_dict": qc,
+                                     "retained": list(kept), "failed": {k: list(v) for k, v in failed.items()}})
+        for n_nodes, n_edges, query_start, min_count, allow, pre in (
+                (10, 12, 10, 1, True, None), (10, 20, 6, 1, False, None), (12, 30, 7, 3, True, {2}),
+                (9, 15, 4, 2, False, {0, 8}), (16, 40, 16, 4, True, None), (5, 0, 3, 1, True, None)):
+            e = set()
+            while len(e) < n_edges:
+                a, b = sorted(int(v) for v in rng.integers(0, n_nodes, 2))
+                if a != b:
+                    e.add((a, b))
+            edges = sorted(e)
+            failed = ns["prune_edges"](list(edges), query_start, failed=None if pre is None else set(pre),
+                                       min_count=min_count, allow_ref_ref=allow)
+            out["prune_edges"].append({"edges": [list(x) for x in edges], "query_start": query_start,
+                                       "min_count": min_count, "allow_ref_ref": allow,
+                                       "failed_before": None if pre is None else sorted(pre),
+                                       "failed": sorted(int(v) for v in failed)})
+        mats = {}
+        for i, (rows, r, x, n_out) in enumerate(((8000, 20, 0.2, 60), (8000, 20, 0.2, 0), (12000, 30, 0.1, 200),
+                                                 (6000, 10, 0.5, 20))):
+            d = np.stack([rng.gamma(4.0, 0.002, rows), rng.gamma(4.0, 0.03, rows)], axis=1).astype(np.float32)
+            if n_out:
+                idx = rng.choice(rows, n_out, replace=False)
+                d[idx, 0] *= rng.uniform(4, 6, n_out).astype(np.float32)
+                d[idx[: n_out // 2], 1] *= rng.uniform(5, 8, n_out // 2).astype(np.float32)
+            max_pi, max_a = ns["autoDistFind"](d, {"x": x, "r": r})
+            mats["dist%d" % i] = d
+            out["autoDistFind"].append({"dist": "qc_autodist.npz:dist%d" % i, "r": r, "x": x,
+                                        "max_pi": float(max_pi), "max_a": float(max_a)})
+    finally:
+        sys.stderr.close()
+        sys.stderr = stderr
+    np.savez_compressed(os.path.join(HERE, "qc_autodist.npz"), **mats)
+    with open(os.path.join(HERE, "qc.json"), "w") as f:
+        json.dump(out, f, indent=0)
+    print("qc.json:", len(out["qcDistMat"]), "qcDistMat,", len(out["prune_edges"]), "prune_edges,",
+          len(out["autoDistFind"]), "autoDistFind cases")
+
+
 def golden_refine():
     """test/test-refine.py:10-38.  withinBoundary evaluates the float32 rows with the numpy of
     this interpreter (numpy >= 2: float32 * python float stays float32, un-fused) and calls a row
@@ -273,6 +370,7 @@ def golden_refine():
 
 
 if __name__ == "__main__":
+    golden_qc()
     golden_refine()
     golden_prune()
     golden_fit()
