@@ -189,6 +189,14 @@ int ppk_generate_tuples_dev(const int32_t *d_assign, size_t n_rows, int within_l
                             long long *d_edges, size_t cap,
                             unsigned long long *d_n_edges, void *stream);
 
+/* replaces poppunk_refine.generateAllTuples (src/python_bindings.cpp:42-47,:98-101;
+ * src/boundary.cpp:125-150; caller PopPUNK/network.py:1087, the dense network): every pair.  self: the
+ * condensed rows in order, (i, j) + int_offset; else the reference's loop nest as it stands -- entry
+ * j*num_queries + i = (i, j + num_ref) for j < num_ref, i < num_queries, no offset.  The count is known
+ * beforehand: *n_edges = n(n-1)/2 or num_ref*num_queries, PPK_ERR_CAPACITY (nothing written) below it. */
+int ppk_generate_all_tuples_dev(size_t num_ref, size_t num_queries, int self, long long int_offset,
+                                long long *d_edges, size_t cap, size_t *n_edges, void *stream);
+
 /* Distance-QC edge lists: replaces the numpy masks +
  * generateTuples of qcDistMat (PopPUNK/qc.py:332-337 mode 0: core > max_pi or
  * accessory > max_a; qc.py:349-354 mode 1: core == 0 or accessory == 0) on the
@@ -295,6 +303,8 @@ int ppk_edge_threshold(const float *dist, size_t n_rows, size_t n_ref, int slope
 int ppk_generate_tuples(const int32_t *assignments, size_t n_rows, int within_label,
                         int self, size_t num_ref, long long int_offset, int device_id,
                         long long *ij_out, size_t cap, size_t *n_edges);
+int ppk_generate_all_tuples(size_t num_ref, size_t num_queries, int self, long long int_offset,
+                            int device_id, long long *ij_out, size_t cap, size_t *n_edges);
 /* replaces the numpy masks + .tolist() + poppunk_refine.generateTuples of qcDistMat on a HOST matrix
  * (PopPUNK/qc.py:332-337: core > max_pi or accessory > max_a; :349-354: core == 0 or accessory == 0), both
  * lists from one upload: `modes` bit 0 = the long-distance list, bit 1 = the zero-distance list, written one

@@ -184,6 +184,18 @@ def generate_tuples(assignments, within_label, self=True, num_ref=0, int_offset=
     return ij[:ne].copy()
 
 
+def generate_all_tuples(num_ref, num_queries=0, self=True, int_offset=0):
+    """poppunk_refine.generateAllTuples (boundary.cpp:125-150) as an int64 [m, 2] array."""
+    cap = num_ref * (num_ref - 1) // 2 if self else num_ref * num_queries
+    ij = np.zeros((max(cap, 1), 2), dtype=np.int64)
+    f = lib().ppk_oracle_generate_all_tuples
+    f.argtypes = [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_int64,
+                  ctypes.POINTER(ctypes.c_int64), ctypes.c_size_t]
+    f.restype = ctypes.c_size_t
+    ne = f(num_ref, num_queries, int(self), int_offset, _p(ij, ctypes.c_int64), cap)
+    return ij[:ne].copy()
+
+
 def threshold_iterate_1d(dist, offsets, slope, x0, y0, x1, y1):
     """(i, j, offset_idx) int64 arrays, as poppunk_refine.thresholdIterate1D (boundary.cpp:154-210)."""
     dist = np.ascontiguousarray(dist, dtype=np.float32)

@@ -384,6 +384,39 @@ size_t ppk_oracle_generate_tuples(const int32_t *assignments, size_t n_rows,
   return ne;
 }
 
+/* ---- generate_all_tuples (src/boundary.cpp:125-150): every pair, for the dense network
+ * (PopPUNK/network.py:1087).  Self: the condensed rows in order, (i, j) + int_offset.  Non-self, as the
+ * reference has it: outer loop j over num_ref, inner loop i over num_queries, entry (i, j + num_ref) --
+ * int_offset is not applied and nothing is swapped.  Returns the number of pairs (<= cap stored). */
+size_t ppk_oracle_generate_all_tuples(size_t num_ref, size_t num_queries, int self, int64_t int_offset,
+                                      int64_t *ij_out, size_t cap) {
+  size_t ne = 0;
+  if (self) {
+    const size_t n_rows = num_ref ? num_ref * (num_ref - 1) / 2 : 0;
+    for (size_t row = 0; row < n_rows; row++, ne++) {
+      if (ne >= cap) continue;
+      const size_t ii = cond_row_idx(row, num_ref);
+      int64_t i = (int64_t)ii + int_offset;
+      int64_t j = (int64_t)(row - row_start(ii, num_ref) + ii + 1) + int_offset;
+      if (i > j) {
+        int64_t t = i;
+        i = j;
+        j = t;
+      }
+      ij_out[2 * ne] = i;
+      ij_out[2 * ne + 1] = j;
+    }
+  } else {
+    for (size_t j = 0; j < num_ref; j++)
+      for (size_t i = 0; i < num_queries; i++, ne++) {
+        if (ne >= cap) continue;
+        ij_out[2 * ne] = (int64_t)i;
+        ij_out[2 * ne + 1] = (int64_t)(j + num_ref);
+      }
+  }
+  return ne;
+}
+
 /* ---- next row: threshold_iterate_1D (src/boundary.cpp:154-210) --------------------------
  * Boundary o passes through (x0,y0) + offsets[o] * unit(x1-x0, y1-y0); rows are ordered by
  * their line distance to boundary 0 (stable), and for each offset in turn the sweep emits

@@ -835,6 +835,18 @@ extern "C" int ppk_generate_tuples_dev(const int32_t *d_assign, size_t n_rows, i
   return edges_from_mask(dev, n_rows, g, static_cast<uint64_t *>(d_mask), d_edges, cap, d_n_edges, s);
 }
 
+extern "C" int ppk_generate_all_tuples_dev(size_t num_ref, size_t num_queries, int self, long long int_offset,
+                                           long long *d_edges, size_t cap, size_t *n_edges, void *stream) {
+  if (!n_edges) return ppk_fail(PPK_ERR_ARG, "n_edges is NULL");
+  const size_t n = self ? (num_ref ? num_ref * (num_ref - 1) / 2 : 0) : num_ref * num_queries;
+  *n_edges = n;
+  if (n == 0) return PPK_OK;
+  if (n > cap) return ppk_fail(PPK_ERR_CAPACITY, "output too small: need " + std::to_string(n));
+  if (!d_edges) return ppk_fail(PPK_ERR_ARG, "d_edges is NULL");
+  return ppk_launch_all_tuples(n, num_ref, num_queries, self ? 1 : 0, int_offset, d_edges,
+                               static_cast<hipStream_t>(stream));
+}
+
 uint64_t ppk_token(const void *bytes, size_t len, uint64_t seed) {
   const unsigned char *b = static_cast<const unsigned char *>(bytes);
   uint64_t h = 1469598103934665603ull ^ seed;

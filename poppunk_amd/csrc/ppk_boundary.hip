@@ -343,7 +343,52 @@ inline unsigned grid_for(size_t items, size_t per_block, unsigned cap_blocks) {
   return (unsigned)b;
 }
 
+// Every pair of the dense network (src/boundary.cpp:125-150), no input: a thread takes kAllPerThread
+// consecutive entries, so the self form pays its sqrt once and walks the condensed rows from there.
+constexpr int kAllPerThread = 8;
+__global__ void __launch_bounds__(kBlock)
+all_tuples_kernel(size_t n_entries, size_t num_ref, size_t num_queries, int self, long long int_offset,
+                  longlong2 *__restrict__ edges) {
+  for (size_t e0 = ((size_t)blockIdx.x * kBlock + threadIdx.x) * kAllPerThread; e0 < n_entries;
+       e0 += (size_t)gridDim.x * kBlock * kAllPerThread) {
+    const size_t e1 = e0 + kAllPerThread < n_entries ? e0 + kAllPerThread : n_entries;
+    if (self) {
+      size_t ii = cond_row_idx(e0, num_ref);
+      size_t rs = cond_row_start(ii, num_ref);
+      for (size_t row = e0; row < e1; ++row) {
+        while (row >= rs + (num_ref - 1 - ii)) {
+          rs += num_ref - 1 - ii;
+          ++ii;
+        }
+        longlong2 e;
+        e.x = (long long)ii + int_offset;
+        e.y = (long long)(ii + 1 + (row - rs)) + int_offset;
+        edges[row] = e;
+      }
+    } else {
+      // the reference's loop nest as it stands: j over num_ref (outer), i over num_queries (inner),
+      // entry (i, j + num_ref); no offset, no swap
+      for (size_t row = e0; row < e1; ++row) {
+        longlong2 e;
+        e.x = (long long)(row % num_queries);
+        e.y = (long long)(row / num_queries + num_ref);
+        edges[row] = e;
+      }
+    }
+  }
+}
+
 }  // namespace
+
+int ppk_launch_all_tuples(size_t n_entries, size_t num_ref, size_t num_queries, int self, long long int_offset,
+                          long long *d_edges, hipStream_t s) {
+  if (n_entries == 0) return PPK_OK;
+  const unsigned grid = grid_for(n_entries, (size_t)kBlock * kAllPerThread, 8192);
+  hipLaunchKernelGGL(all_tuples_kernel, dim3(grid), dim3(kBlock), 0, s, n_entries, num_ref, num_queries, self,
+                     int_offset, reinterpret_cast<longlong2 *>(d_edges));
+  PPK_HIP(hipGetLastError());
+  return PPK_OK;
+}
 
 size_t ppk_mask_words_linear(size_t n_rows) { return (n_rows + 63) / 64; }
 

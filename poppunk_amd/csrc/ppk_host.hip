@@ -1313,6 +1313,30 @@ extern "C" int ppk_edge_threshold(const float *dist, size_t n_rows, size_t n_ref
                          copy_out);
 }
 
+// poppunk_refine.generateAllTuples on a host array: the count is known beforehand (no parking); the list is
+// written on the device (scratch) and copied out in one piece.
+extern "C" int ppk_generate_all_tuples(size_t num_ref, size_t num_queries, int self, long long int_offset,
+                                       int device_id, long long *ij_out, size_t cap, size_t *n_edges) {
+  if (!n_edges) return ppk_fail(PPK_ERR_ARG, "n_edges is NULL");
+  const size_t n = self ? (num_ref ? num_ref * (num_ref - 1) / 2 : 0) : num_ref * num_queries;
+  *n_edges = n;
+  if (n == 0) return PPK_OK;
+  if (n > cap) return ppk_fail(PPK_ERR_CAPACITY, "output too small: need " + std::to_string(n));
+  if (!ij_out) return ppk_fail(PPK_ERR_ARG, "ij_out is NULL");
+  DeviceGuard guard(device_id);
+  if (!guard.ok) return ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(device_id));
+  if (int rc = ppk_check_arch(device_id)) return rc;
+  PpkCall call(device_id, nullptr);
+  void *d = nullptr;
+  int rc = ppk_scratch_get(device_id, SLOT_HOST_IN, n * 16, &d);
+  if (rc != PPK_OK) return rc;
+  rc = ppk_launch_all_tuples(n, num_ref, num_queries, self ? 1 : 0, int_offset, static_cast<long long *>(d), nullptr);
+  if (rc != PPK_OK) return rc;
+  if (hipMemcpy(ij_out, d, n * 16, hipMemcpyDeviceToHost) != hipSuccess)
+    return ppk_fail(PPK_ERR_HIP, "hipMemcpy D2H failed (all tuples)");
+  return PPK_OK;
+}
+
 // qcDistMat's two edge lists from ONE upload of the host matrix (PopPUNK/qc.py:332-337 long distances,
 // :349-354 zero distances): `modes` bit 0 = the long-distance list, bit 1 = the zero-distance list; the
 // lists come back one after the other in ij_out, *n_first = entries of the first one present.

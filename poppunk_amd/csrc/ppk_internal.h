@@ -122,6 +122,8 @@ int ppk_launch_mask_from_qc(const float *d_dist, size_t n_rows, int mode, float 
                             uint64_t *d_mask, hipStream_t s);
 int ppk_launch_mask_from_assign(const int32_t *d_assign, size_t n_rows, int within_label,
                                 uint64_t *d_mask, hipStream_t s);
+int ppk_launch_all_tuples(size_t n_entries, size_t num_ref, size_t num_queries, int self, long long int_offset,
+                          long long *d_edges, hipStream_t s);
 int ppk_launch_compact(const uint64_t *d_mask, size_t n_words, const EdgeGeom &g, void *d_ws,
                        long long *d_edges, size_t cap, unsigned long long *d_n_edges,
                        hipStream_t s);

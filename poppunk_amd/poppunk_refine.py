@@ -98,6 +98,28 @@ def generateTuples(assignments, within_label, self=True, num_ref=0, int_offset=0
             generateTuples_array(assignments, within_label, self, num_ref, int_offset).tolist()]
 
 
+def generateAllTuples_array(num_ref, num_queries=0, self=True, int_offset=0):
+    """Every pair as an int64 [m, 2] array (see generateAllTuples)."""
+    num_ref, num_queries = int(num_ref), int(num_queries)
+    if num_ref < 0 or num_queries < 0:
+        raise TypeError("generateAllTuples(): incompatible function arguments")
+    n = num_ref * (num_ref - 1) // 2 if self else num_ref * num_queries
+    out = np.empty((n, 2), dtype=np.int64)
+    if n:
+        ne = C.c_size_t(0)
+        rc = _lib.lib().ppk_generate_all_tuples(num_ref, num_queries, 1 if self else 0, int(int_offset), _DEVICE,
+                                                out.ctypes.data_as(C.POINTER(C.c_longlong)), n, C.byref(ne))
+        _lib.check(rc, "generateAllTuples")
+    return out
+
+
+def generateAllTuples(num_ref, num_queries=0, self=True, int_offset=0):
+    """All pairs of the dense network as (i, j) tuples (src/boundary.cpp:125-150; caller
+    PopPUNK/network.py:1087).  Non-self follows the reference's loop nest as it stands: (i, j + num_ref)
+    for j < num_ref (outer), i < num_queries (inner)."""
+    return [tuple(e) for e in generateAllTuples_array(num_ref, num_queries, self, int_offset).tolist()]
+
+
 def _coo(call, rows_hint=0):
     """As _edges, for the (i, j, offset index) triplets of the sweeps."""
     n_out = C.c_size_t(0)

@@ -482,3 +482,42 @@ def test_quickstart_example_runs_end_to_end(tmp_path):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert "identical" in r.stdout
+
+
+# ---- generateAllTuples (src/boundary.cpp:125-150): the dense network's pair list ------------------
+
+@pytest.mark.parametrize("num_ref,num_queries,self_,off", [
+    (2, 0, True, 0), (3, 0, True, 0), (65, 0, True, 0), (1000, 0, True, 17), (2049, 0, True, -3),
+    (1, 0, True, 0), (0, 0, True, 0), (3, 5, False, 0), (5, 3, False, 4), (640, 97, False, 0), (7, 0, False, 0),
+])
+def test_generate_all_tuples(num_ref, num_queries, self_, off):
+    want = oracle.generate_all_tuples(num_ref, num_queries, self_, off)
+    got = poppunk_refine.generateAllTuples_array(num_ref, num_queries, self_, off)
+    assert got.dtype == np.int64 and np.array_equal(got, want.reshape(-1, 2))
+    if len(want) < 5000:
+        t = poppunk_refine.generateAllTuples(num_ref, num_queries, self=self_, int_offset=off)
+        assert isinstance(t, list) and t == [tuple(r) for r in want.tolist()]
+
+
+def test_generate_all_tuples_full_size_and_device_entry():
+    """10 000 samples -> 49 995 000 pairs: first, last, a checksum and sortedness instead of a second copy."""
+    import ctypes as C
+    import torch
+    from poppunk_amd import _lib
+    n = 10000
+    got = poppunk_refine.generateAllTuples_array(n)
+    assert got.shape == (n * (n - 1) // 2, 2)
+    assert got[0].tolist() == [0, 1] and got[-1].tolist() == [n - 2, n - 1]
+    assert int(got[:, 0].sum()) == sum(i * (n - 1 - i) for i in range(n))
+    assert int(got[:, 1].sum()) == sum(j * j for j in range(n))
+    key = got[:, 0] * n + got[:, 1]
+    assert bool(np.all(np.diff(key) > 0))
+    # the device entry point: too little room is an error with the count, nothing written
+    buf = torch.zeros((10, 2), dtype=torch.int64, device="cuda:0")
+    ne = C.c_size_t(0)
+    rc = _lib.lib().ppk_generate_all_tuples_dev(7, 0, 1, 0, C.c_void_p(buf.data_ptr()), 10, C.byref(ne), None)
+    assert rc == _lib.ERR_CAPACITY and ne.value == 21 and int(buf.abs().sum()) == 0
+    buf = torch.zeros((21, 2), dtype=torch.int64, device="cuda:0")
+    rc = _lib.lib().ppk_generate_all_tuples_dev(7, 0, 1, 0, C.c_void_p(buf.data_ptr()), 21, C.byref(ne), None)
+    torch.cuda.synchronize()
+    assert rc == 0 and np.array_equal(buf.cpu().numpy(), oracle.generate_all_tuples(7))
