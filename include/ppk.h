@@ -347,6 +347,32 @@ int ppk_query_edges(const uint64_t *ref_sk, size_t n_ref, const uint64_t *qry_sk
                     size_t cap, size_t *n_edges, unsigned long long *n_failed);
 
 /* ------------------------------------------------------------------------
+ * The sparse neighbour matrices of the lineage models (COO triplets, rows ascending; int64 indices,
+ * float32 distances; host arrays).  Outputs in row order as the reference concatenates them; *n_out
+ * always receives the entry count, PPK_ERR_CAPACITY when it exceeds cap (worst cases below).
+ */
+/* replaces poppunk_refine.lowerRank(rr_mat, n_samples, kNN, reciprocal_only, count_unique_distances,
+ * lineage_resolution, num_threads) (src/python_bindings.cpp:121-128; src/extend.cpp:128-246; caller
+ * PopPUNK/models.py:1177): per row, entries in stable order of distance, the sample itself skipped, kept
+ * while the count of kept entries -- or, with count_unique_distances, of distinct distances (steps of at
+ * least epsilon) -- is <= kNN (so kNN + 1 entries without it, as in the reference); reciprocal_only keeps
+ * (i, j), i < j, whose (j, i) was kept too.  Worst case nnz entries. */
+int ppk_lower_rank(const long long *rr_i, const long long *rr_j, const float *rr_d, size_t nnz,
+                   size_t n_samples, size_t knn, int reciprocal_only, int count_unique_distances,
+                   float epsilon, int device_id, long long *i_out, long long *j_out, float *d_out,
+                   size_t cap, size_t *n_out);
+/* replaces poppunk_refine.extend(rr_mat, qq_mat, qr_mat, kNN, num_threads) (src/python_bindings.cpp:114-119;
+ * src/extend.cpp:52-126; caller PopPUNK/models.py:1367): the kNN nearest of every reference (its sparse row
+ * merged with its n_qry distances to the queries, qr_rect float32 [n_ref][n_qry]) and of every query (its
+ * distances to the references merged with its row of qq_square, float32 [n_qry][n_qry]); stable order of
+ * distance, the query side first on a tie, the sample itself skipped; queries are numbered n_ref + q.
+ * Worst case kNN * (n_ref + n_qry) entries. */
+int ppk_extend(const long long *rr_i, const long long *rr_j, const float *rr_d, size_t nnz,
+               const float *qq_square, const float *qr_rect, size_t n_ref, size_t n_qry, size_t knn,
+               int device_id, long long *i_out, long long *j_out, float *d_out, size_t cap,
+               size_t *n_out);
+
+/* ------------------------------------------------------------------------
  * Long <-> square distance transforms and k nearest neighbours (SURVEY.md 8f
  * rank 2).  "Long" = condensed upper triangle in PopPUNK row order; element e
  * of a long vector is read at d_long[e*stride + col], so a column of the

@@ -322,3 +322,93 @@ def prune_long(dist, n, keep):
     kept[np.asarray(keep, dtype=np.int64)] = True
     i, j = np.triu_indices(n, k=1)          # row-major upper triangle == PopPUNK's condensed order
     return np.ascontiguousarray(dist[kept[i] & kept[j]])
+
+
+# ---- the sparse neighbour matrices of the lineage models (src/extend.cpp:15-246) ---------------------
+# Restated from the reference source by reading: extend.cpp needs Eigen and pybind11 to compile, so no
+# reference build and no reference-made vectors exist for these two -- parity unpinned.
+
+def _row_starts(ri, n_rows):
+    """extend.cpp:15-38 row_start_indices for a row-sorted COO: entries of row r are [s[r], s[r+1])."""
+    s = np.searchsorted(np.asarray(ri), np.arange(n_rows + 1), side="left")
+    s[n_rows] = len(ri)
+    return s
+
+
+def lower_rank(ri, rj, rd, n_samples, knn, reciprocal_only=False, count_unique_distances=False,
+               epsilon=0.0):
+    """poppunk_refine.lowerRank (src/extend.cpp:128-246).  Per row: entries in stable order of distance,
+    the row's own sample skipped; kept while `unique_neighbors <= kNN`, where unique_neighbors is the
+    number already kept (so kNN + 1 entries survive, :176-178) or, with count_unique_distances, the
+    number of distinct distances met so far -- a distance is new when it differs from the last NEW one by
+    at least epsilon, in float (:168-174).  reciprocal_only: of those, (i, j) with i < j whose (j, i) was
+    kept too (:197-236).  Returns (i, j, dist) arrays in row order."""
+    ri, rj = np.asarray(ri, dtype=np.int64), np.asarray(rj, dtype=np.int64)
+    rd = np.asarray(rd, dtype=np.float32)
+    eps = np.float32(epsilon)
+    starts = _row_starts(ri, n_samples)
+    kept = []
+    for i in range(n_samples):
+        lo, hi = starts[i], starts[i + 1]
+        row = []
+        if hi > lo:
+            unique, prev = 0, np.float32(0.0)
+            for e in lo + np.argsort(rd[lo:hi], kind="stable"):
+                j, d = int(rj[e]), rd[e]
+                if j == i:
+                    continue
+                if count_unique_distances:
+                    if np.abs(np.float32(d - prev)) >= eps:
+                        unique += 1
+                        prev = d
+                else:
+                    unique = len(row)
+                if unique <= knn:
+                    row.append((j, d))
+                else:
+                    break
+        kept.append(row)
+    if reciprocal_only:
+        lower = {(i, j) for i, row in enumerate(kept) for j, _ in row if i > j}
+        kept = [[(j, d) for j, d in row if i < j and (j, i) in lower] for i, row in enumerate(kept)]
+    oi = np.asarray([i for i, row in enumerate(kept) for _ in row], dtype=np.int64)
+    oj = np.asarray([j for row in kept for j, _ in row], dtype=np.int64)
+    od = np.asarray([d for row in kept for _, d in row], dtype=np.float32)
+    return oi, oj, od
+
+
+def extend(ri, rj, rd, qq_square, qr_rect, knn):
+    """poppunk_refine.extend (src/extend.cpp:52-126): the k nearest of every reference (its sparse row
+    merged with its distances to the queries) and of every query (its distances to the references merged
+    with its row of the query square).  Both lists in stable order of distance, the merge takes the query
+    side on a tie (:96-99), the sample itself is skipped, exactly kNN kept when there are that many.
+    Queries are numbered n_ref + q.  Returns (i, j, dist) arrays in row order."""
+    ri, rj = np.asarray(ri, dtype=np.int64), np.asarray(rj, dtype=np.int64)
+    rd = np.asarray(rd, dtype=np.float32)
+    qq = np.asarray(qq_square, dtype=np.float32)
+    qr = np.asarray(qr_rect, dtype=np.float32)
+    nr, nq = qr.shape
+    starts = _row_starts(ri, nr)
+    oi, oj, od = [], [], []
+    for i in range(nr + nq):
+        if i < nr:
+            lo, hi = starts[i], starts[i + 1]
+            q_d, r_d, r_j = qr[i], rd[lo:hi], rj[lo:hi]
+        else:
+            q_d, r_d, r_j = qq[i - nr], qr[:, i - nr], np.arange(nr, dtype=np.int64)
+        q_ord, r_ord = np.argsort(q_d, kind="stable"), np.argsort(r_d, kind="stable")
+        a = b = n_kept = 0
+        while (a < len(q_ord) or b < len(r_ord)) and n_kept < knn:
+            if b == len(r_ord) or (a < len(q_ord) and q_d[q_ord[a]] <= r_d[r_ord[b]]):
+                j, d = int(q_ord[a]) + nr, q_d[q_ord[a]]
+                a += 1
+            else:
+                j, d = int(r_j[r_ord[b]]), r_d[r_ord[b]]
+                b += 1
+            if j == i:
+                continue
+            oi.append(i)
+            oj.append(j)
+            od.append(d)
+            n_kept += 1
+    return (np.asarray(oi, dtype=np.int64), np.asarray(oj, dtype=np.int64), np.asarray(od, dtype=np.float32))

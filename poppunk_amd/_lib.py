@@ -87,6 +87,10 @@ SIGNATURES = {
     "ppk_parked_fetch": (C.c_int, [_llp, _llp, _llp, _sz, _szp]),
     "ppk_generate_all_tuples_dev": (C.c_int, [_sz, _sz, C.c_int, C.c_longlong, _vp, _sz, _szp, _vp]),
     "ppk_generate_all_tuples": (C.c_int, [_sz, _sz, C.c_int, C.c_longlong, C.c_int, _llp, _sz, _szp]),
+    "ppk_lower_rank": (C.c_int, [_llp, _llp, _f32p, _sz, _sz, _sz, C.c_int, C.c_int, C.c_float, C.c_int, _llp, _llp,
+                                 _f32p, _sz, _szp]),
+    "ppk_extend": (C.c_int, [_llp, _llp, _f32p, _sz, _f32p, _f32p, _sz, _sz, _sz, C.c_int, _llp, _llp, _f32p, _sz,
+                             _szp]),
     "ppk_qc_edges": (C.c_int, [_f32p, _sz, _sz, C.c_int, C.c_float, C.c_float, C.c_int, _llp, _sz, _szp, _szp]),
     "ppk_query_edges_dbs": (C.c_int, [C.POINTER(_vp), C.POINTER(_vp), C.c_int, _i32p, _f32p, _sz, C.c_int,
                                       C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, _llp, _sz,

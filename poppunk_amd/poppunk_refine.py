@@ -8,6 +8,12 @@ extension (src/python_bindings.cpp:79-96), backed by libppk_hip.so.
     thresholdIterate1D(distMat, offsets, slope, x0, y0, x1, y1, num_threads=1)
                                                                  -> (i_vec, j_vec, offset_idx)
     thresholdIterate2D(distMat, x_max, y_max)                    -> (i_vec, j_vec, offset_idx)
+    generateAllTuples(num_ref, num_queries=0, self=True, int_offset=0) -> list[(i, j)]
+    get_kNN_distances(distMat, kNN, dist_col=0, num_threads=1)   -> (i_vec, j_vec, dists)
+    extend(rr_mat, qq_mat, qr_mat, kNN, num_threads=1)           -> (i_vec, j_vec, dists)
+    lowerRank(rr_mat, n_samples, kNN, reciprocal_only=False, count_unique_distances=False,
+              lineage_resolution, num_threads=1)                 -> (i_vec, j_vec, dists)
+(every function the module exports, src/python_bindings.cpp:76-129)
 
 As in the pybind11 module, `distMat` must already be a C-contiguous float32
 [n, 2] array (`py::arg("distMat").noconvert()`, src/python_bindings.cpp:82,:89):
@@ -202,3 +208,86 @@ def get_kNN_distances(distMat, kNN, dist_col=0, num_threads=1):
                                 d.ctypes.data_as(C.POINTER(C.c_float)))
         _lib.check(rc, "get_kNN_distances")
     return i.tolist(), j.tolist(), d.tolist()
+
+
+# ---- the sparse neighbour matrices of the lineage models (src/extend.cpp:52-246) --------------------
+
+def _coo_in(mat, what):
+    """(row, col, data) of a sparse matrix given as the reference's callers give it: a tuple of three
+    sequences (PopPUNK/models.py:1368 passes `(nn_dists.row, nn_dists.col, nn_dists.data)`; pybind takes any
+    three sequences as std::vector<long>, <long>, <float>)."""
+    try:
+        r, c, d = mat
+    except (TypeError, ValueError):
+        raise TypeError("%s must be a (row, col, data) tuple" % what)
+    r = np.ascontiguousarray(np.asarray(r).astype(np.int64, copy=False)).ravel()
+    c = np.ascontiguousarray(np.asarray(c).astype(np.int64, copy=False)).ravel()
+    d = np.ascontiguousarray(np.asarray(d).astype(np.float32, copy=False)).ravel()
+    if not (r.size == c.size == d.size):
+        raise RuntimeError("%s: row, col and data differ in length" % what)
+    return r, c, d
+
+
+def _dense_f32(m, what):
+    # py::arg(...).noconvert() on a dense Eigen matrix: float32 or a TypeError; any layout is copied in
+    if not (isinstance(m, np.ndarray) and m.dtype == np.float32 and m.ndim == 2):
+        raise TypeError("%s must be a two-dimensional float32 numpy array" % what)
+    return np.ascontiguousarray(m)
+
+
+def _triplets(call, cap):
+    i = np.empty(cap, dtype=np.int64)
+    j = np.empty(cap, dtype=np.int64)
+    d = np.empty(cap, dtype=np.float32)
+    n = C.c_size_t(0)
+    ll = C.POINTER(C.c_longlong)
+    rc = call(i.ctypes.data_as(ll), j.ctypes.data_as(ll), d.ctypes.data_as(C.POINTER(C.c_float)), cap, C.byref(n))
+    return rc, i[:n.value], j[:n.value], d[:n.value]
+
+
+def lowerRank_arrays(rr_mat, n_samples, kNN, reciprocal_only=False, count_unique_distances=False,
+                     lineage_resolution=0.0, num_threads=1):
+    r, c, d = _coo_in(rr_mat, "rr_mat")
+    ll, fp = C.POINTER(C.c_longlong), C.POINTER(C.c_float)
+    lib = _lib.lib()
+    rc, i, j, v = _triplets(lambda pi, pj, pd, cap, n: lib.ppk_lower_rank(
+        r.ctypes.data_as(ll), c.ctypes.data_as(ll), d.ctypes.data_as(fp), r.size, int(n_samples), int(kNN),
+        1 if reciprocal_only else 0, 1 if count_unique_distances else 0, float(lineage_resolution), _DEVICE,
+        pi, pj, pd, cap, n), max(r.size, 1))
+    _lib.check(rc, "lowerRank")
+    return i, j, v
+
+
+def lowerRank(rr_mat, n_samples, kNN, reciprocal_only=False, count_unique_distances=False,
+              lineage_resolution=0.0, num_threads=1):
+    """Reduce a sparse neighbour matrix to a lower rank: (i_vec, j_vec, dists) lists
+    (src/extend.cpp:128-246; caller PopPUNK/models.py:1177).  As in the reference kNN + 1 entries per row
+    survive when distances are not counted by distinct value (`unique_neighbors <= kNN`, :176-178)."""
+    i, j, v = lowerRank_arrays(rr_mat, n_samples, kNN, reciprocal_only, count_unique_distances,
+                               lineage_resolution, num_threads)
+    return i.tolist(), j.tolist(), v.tolist()
+
+
+def extend_arrays(rr_mat, qq_mat, qr_mat, kNN, num_threads=1):
+    r, c, d = _coo_in(rr_mat, "rr_mat")
+    qq = _dense_f32(qq_mat, "qq_mat")
+    qr = _dense_f32(qr_mat, "qr_mat")
+    n_ref, n_qry = qr.shape
+    if qq.shape != (n_qry, n_qry):
+        raise RuntimeError("qq_mat must be square with one row per column of qr_mat")
+    ll, fp = C.POINTER(C.c_longlong), C.POINTER(C.c_float)
+    lib = _lib.lib()
+    rc, i, j, v = _triplets(lambda pi, pj, pd, cap, n: lib.ppk_extend(
+        r.ctypes.data_as(ll), c.ctypes.data_as(ll), d.ctypes.data_as(fp), r.size, qq.ctypes.data_as(fp),
+        qr.ctypes.data_as(fp), n_ref, n_qry, int(kNN), _DEVICE, pi, pj, pd, cap, n),
+        max(int(kNN) * (n_ref + n_qry), 1))
+    _lib.check(rc, "extend")
+    return i, j, v
+
+
+def extend(rr_mat, qq_mat, qr_mat, kNN, num_threads=1):
+    """Extend a sparse reference neighbour matrix with queries, keeping the kNN nearest of every sample:
+    (i_vec, j_vec, dists) lists, queries numbered n_ref + q (src/extend.cpp:52-126; caller
+    PopPUNK/models.py:1367)."""
+    i, j, v = extend_arrays(rr_mat, qq_mat, qr_mat, kNN, num_threads)
+    return i.tolist(), j.tolist(), v.tolist()

@@ -1,0 +1,129 @@
+"""poppunk_refine.extend / lowerRank on the MI355X against the oracle's restatement of src/extend.cpp:52-246
+(parity unpinned: extend.cpp cannot be built here).  Distances are drawn from a few values so that ties --
+whose order is the whole content of these functions -- are everywhere."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from poppunk_amd import poppunk_refine
+
+pytestmark = pytest.mark.gpu
+
+
+def _square(rng, n, levels):
+    v = rng.integers(1, levels + 1, size=(n, n)).astype(np.float32) / np.float32(levels * 4)
+    v = np.triu(v, 1)
+    return v + v.T
+
+
+def _knn_coo(sq, k):
+    i, j, d = poppunk_refine.get_kNN_distances(sq, k)
+    return np.asarray(i, dtype=np.int64), np.asarray(j, dtype=np.int64), np.asarray(d, dtype=np.float32)
+
+
+def _same(got, want):
+    gi, gj, gd = got
+    wi, wj, wd = want
+    assert np.array_equal(gi, wi) and np.array_equal(gj, wj)
+    assert gd.dtype == np.float32 and np.array_equal(gd, wd)
+
+
+@pytest.mark.parametrize("n,depth,levels", [(40, 6, 5), (257, 10, 50), (1000, 12, 7), (3, 2, 2)])
+@pytest.mark.parametrize("unique", [False, True])
+@pytest.mark.parametrize("recip", [False, True])
+def test_lower_rank(n, depth, levels, unique, recip):
+    rng = np.random.Generator(np.random.PCG64(n * 7 + depth))
+    sq = _square(rng, n, levels)
+    coo = _knn_coo(sq, min(depth, n - 1))
+    for knn in (1, 2, 3, depth + 2):
+        for eps in ((0.0, 1e-3, 0.06) if unique else (0.0,)):
+            want = oracle.lower_rank(*coo, n, knn, reciprocal_only=recip, count_unique_distances=unique, epsilon=eps)
+            got = poppunk_refine.lowerRank_arrays(coo, n, knn, recip, unique, eps)
+            _same(got, want)
+    i, j, d = poppunk_refine.lowerRank(coo, n, 1, recip, unique, 0.001, 4)
+    assert isinstance(i, list) and isinstance(d, list) and len(i) == len(j) == len(d)
+
+
+def test_lower_rank_rows_with_self_entries_gaps_and_bad_input():
+    # rows 1 and 4 are empty, row 2 holds its own sample, row 3 has equal distances in input order
+    ri = np.asarray([0, 0, 0, 2, 2, 2, 3, 3, 3, 3, 5], dtype=np.int64)
+    rj = np.asarray([3, 1, 2, 2, 0, 5, 0, 1, 2, 5, 3], dtype=np.int64)
+    rd = np.asarray([.3, .1, .2, 0., .2, .1, .5, .5, .5, .5, .5], dtype=np.float32)
+    for knn in (0, 1, 2, 5):
+        for unique in (False, True):
+            for recip in (False, True):
+                want = oracle.lower_rank(ri, rj, rd, 6, knn, recip, unique, 1e-5)
+                _same(poppunk_refine.lowerRank_arrays((ri, rj, rd), 6, knn, recip, unique, 1e-5), want)
+    # lists, as pybind accepts them; an empty matrix
+    got = poppunk_refine.lowerRank((ri.tolist(), rj.tolist(), rd.tolist()), 6, 1)
+    want = oracle.lower_rank(ri, rj, rd, 6, 1)
+    assert got[0] == want[0].tolist() and got[1] == want[1].tolist() and np.allclose(got[2], want[2])
+    assert poppunk_refine.lowerRank(([], [], []), 4, 2) == ([], [], [])
+    with pytest.raises(RuntimeError, match="ascending"):
+        poppunk_refine.lowerRank_arrays((ri[::-1].copy(), rj, rd), 6, 1)
+    with pytest.raises(RuntimeError, match="ascending"):
+        poppunk_refine.lowerRank_arrays((ri + 3, rj, rd), 6, 1)
+    with pytest.raises(TypeError):
+        poppunk_refine.lowerRank_arrays(ri, 6, 1)
+
+
+@pytest.mark.parametrize("n_ref,n_qry,depth,levels", [(30, 7, 4, 4), (500, 61, 9, 6), (64, 200, 5, 40), (5, 1, 3, 2),
+                                                      (1, 3, 2, 3)])
+def test_extend(n_ref, n_qry, depth, levels):
+    rng = np.random.Generator(np.random.PCG64(n_ref * 3 + n_qry))
+    rr = _square(rng, n_ref, levels)
+    coo = _knn_coo(rr, min(depth, n_ref - 1)) if n_ref > 1 else (np.zeros(0, np.int64), np.zeros(0, np.int64),
+                                                                  np.zeros(0, np.float32))
+    qq = _square(rng, n_qry, levels)
+    qr = (rng.integers(1, levels + 1, size=(n_ref, n_qry)).astype(np.float32) / np.float32(levels * 4))
+    for knn in (1, depth, depth + 3):
+        want = oracle.extend(*coo, qq, qr, knn)
+        _same(poppunk_refine.extend_arrays(coo, qq, qr, knn), want)
+    # the caller's shape (PopPUNK/models.py:1355-1372): qr arrives as a transposed view, the sparse matrix as
+    # scipy-style attributes; the result feeds lowerRank
+    qr_view = np.ascontiguousarray(qr.T).T
+    assert not qr_view.flags["C_CONTIGUOUS"] or min(qr.shape) == 1
+    i, j, d = poppunk_refine.extend((coo[0], coo[1], coo[2]), qq, qr_view, depth, 2)
+    want = oracle.extend(*coo, qq, qr, depth)
+    assert i == want[0].tolist() and j == want[1].tolist() and np.array_equal(np.asarray(d, dtype=np.float32), want[2])
+    low = poppunk_refine.lowerRank_arrays((i, j, d), n_ref + n_qry, 2)
+    _same(low, oracle.lower_rank(want[0], want[1], want[2], n_ref + n_qry, 2))
+    with pytest.raises(TypeError):
+        poppunk_refine.extend(coo, qq.astype(np.float64), qr, 2)
+    with pytest.raises(RuntimeError):
+        poppunk_refine.extend(coo, qq[:-1], qr, 2) if n_qry > 1 else poppunk_refine.extend(coo, np.zeros((2, 2), np.float32), qr, 2)
+
+
+def test_extend_then_ranks_of_a_lineage_model_at_size():
+    """20 000 references with 10 neighbours each + 300 queries (6.5 M candidate distances): spot rows
+    against the rule written out ((distance, query side first, place) order, self skipped), and the invariants
+    of the whole result."""
+    rng = np.random.Generator(np.random.PCG64(99))
+    n_ref, n_qry, depth = 20000, 300, 10
+    ri = np.repeat(np.arange(n_ref, dtype=np.int64), depth)
+    rj = (ri + rng.integers(1, n_ref, size=ri.size)) % n_ref
+    rd = np.sort(rng.integers(1, 2000, size=(n_ref, depth)).astype(np.float32) / np.float32(8000), axis=1).ravel()
+    qq = _square(rng, n_qry, 500)
+    qr = rng.integers(1, 2000, size=(n_ref, n_qry)).astype(np.float32) / np.float32(8000)
+    i, j, d = poppunk_refine.extend_arrays((ri, rj, rd), qq, qr, depth)
+    assert len(i) == depth * (n_ref + n_qry) and np.array_equal(i, np.repeat(np.arange(n_ref + n_qry), depth))
+    assert not np.any(i == j)
+    dd = d.reshape(-1, depth)
+    assert bool(np.all(np.diff(dd, axis=1) >= 0))
+    rows = np.concatenate([rng.integers(0, n_ref, 40), n_ref + rng.integers(0, n_qry, 40)])
+    for r in rows.tolist():
+        if r < n_ref:
+            sel = slice(r * depth, (r + 1) * depth)
+            cand = ([(qr[r, c], 0, c, n_ref + c) for c in range(n_qry)]
+                    + [(rd[sel][p], 1, p, int(rj[sel][p])) for p in range(depth)])
+            cand = [c for c in sorted(cand) if c[3] != r][:depth]
+            wj, wd = np.asarray([c[3] for c in cand]), np.asarray([c[0] for c in cand], dtype=np.float32)
+        else:
+            q = r - n_ref
+            order_q = np.argsort(qq[q], kind="stable")
+            order_r = np.argsort(qr[:, q], kind="stable")
+            cand = [(qq[q][c], 0, c, n_ref + c) for c in order_q[:depth + 1]] + [(qr[c, q], 1, c, c) for c in order_r[:depth + 1]]
+            cand = [c for c in sorted(cand) if c[3] != r][:depth]
+            wj, wd = np.asarray([c[3] for c in cand]), np.asarray([c[0] for c in cand], dtype=np.float32)
+        assert np.array_equal(j[r * depth:(r + 1) * depth], wj), r
+        assert np.array_equal(d[r * depth:(r + 1) * depth], wd), r
