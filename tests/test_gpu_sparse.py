@@ -127,3 +127,31 @@ def test_extend_then_ranks_of_a_lineage_model_at_size():
             wj, wd = np.asarray([c[3] for c in cand]), np.asarray([c[0] for c in cand], dtype=np.float32)
         assert np.array_equal(j[r * depth:(r + 1) * depth], wj), r
         assert np.array_equal(d[r * depth:(r + 1) * depth], wd), r
+
+
+def test_sparse_fuzz():
+    """300 random small problems: empty sides, kNN beyond what a row holds, rows without entries, sparse
+    rows that name their own sample, few distinct distances."""
+    rng = np.random.Generator(np.random.PCG64(4242))
+    for case in range(300):
+        n_ref = int(rng.integers(0, 25))
+        n_qry = int(rng.integers(0, 9))
+        levels = int(rng.integers(1, 6))
+        nnz_per = rng.integers(0, 7, size=n_ref)
+        ri = np.repeat(np.arange(n_ref, dtype=np.int64), nnz_per)
+        rj = rng.integers(0, max(n_ref, 1), size=ri.size).astype(np.int64)
+        rd = (rng.integers(0, levels + 1, size=ri.size) / np.float32(8)).astype(np.float32)
+        qq = _square(rng, n_qry, levels) if n_qry else np.zeros((0, 0), np.float32)
+        qr = (rng.integers(0, levels + 1, size=(n_ref, n_qry)) / np.float32(8)).astype(np.float32)
+        knn = int(rng.integers(0, 9))
+        got = poppunk_refine.extend_arrays((ri, rj, rd), qq, qr, knn)
+        want = oracle.extend(ri, rj, rd, qq, qr, knn)
+        _same(got, want)
+        n = n_ref + n_qry
+        unique, recip = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        eps = float(rng.choice([0.0, 0.125, 0.2, 1e-6]))
+        k2 = int(rng.integers(0, 6))
+        _same(poppunk_refine.lowerRank_arrays(want, n, k2, recip, unique, eps),
+              oracle.lower_rank(*want, n, k2, recip, unique, eps))
+        _same(poppunk_refine.lowerRank_arrays((ri, rj, rd), n_ref, k2, recip, unique, eps),
+              oracle.lower_rank(ri, rj, rd, n_ref, k2, recip, unique, eps))
