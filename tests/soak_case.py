@@ -99,6 +99,17 @@ def soak_case(rng, big=False):
             fe = torch.cat(fe).cpu().numpy()
             if not np.array_equal(fe, np.asarray(we).reshape(-1, 2)):
                 msgs.append("fused edges differ (%d vs %d)" % (len(fe), len(we)))
+            # the same list as ONE host call (ppk_query_edges): the device listed 1 - 3 times when bands may
+            # be cut, too little room now and then (the parked list is fetched)
+            n_ent = int(rng.integers(1, 4)) if nk * cnt_bits <= 128 else 1
+            he, hf = pp_sketchlib.query_edges_arrays(ref, qry, kmers, s64, bbits, slope, x_max, y_max, scale=scale,
+                                                     inclusive=inclusive, random_table=t_tbl,
+                                                     ref_clusters=rclu if use_tbl else None,
+                                                     qry_clusters=qclu if use_tbl and qry is not None else None,
+                                                     random_correct=use_tbl, devices=(0,) * n_ent,
+                                                     cap=3 if rng.integers(0, 4) == 0 else None)
+            if hf != gf or not np.array_equal(he, np.asarray(we).reshape(-1, 2)):
+                msgs.append("host fused edges differ (%d vs %d, %d entries)" % (len(he), len(we), n_ent))
         # neighbours straight from the tiles == get_kNN_distances(longToSquare(.)) of the same distances
         cnt_bits_k = int(64 * s64).bit_length()
         if qry is None and bbits == 14 and nk * cnt_bits_k <= 128 and nr > 1:
