@@ -329,8 +329,9 @@ int ppk_parked_fetch(long long *out0, long long *out1, long long *out2, size_t c
  * device-list order = reference row order (src/boundary.cpp:101-118), so the list does not depend on the
  * number of devices.  slope / x_max / y_max / scale / inclusive as in ppk_dist_edges_dev; ij_out int64
  * [cap][2], *n_edges the total; with too little room the finished list is parked (on the host) for
- * ppk_parked_fetch, as above.  Sketches whose k-mer set needs more than 128 count bits (the un-fused
- * path) run on one device only.
+ * ppk_parked_fetch, as above.  A device works through its band in pieces whose edge bitmask stays below
+ * 2 GiB (option "chunk_rows" scales it), so the job size is bounded by the edge list, not by n^2 bits.
+ * Sketches whose k-mer set needs more than 128 count bits (the un-fused path) run on one device only.
  *   ppk_query_edges_dbs : refs[d] / qrys[d] (qrys NULL = self) = the same database resident on each device
  *   ppk_query_edges     : host sketch arrays as in ppk_query; the resident copies come from (and stay in)
  *                         ppk_query's cache, every word hashed before anything runs */

@@ -1465,12 +1465,26 @@ void run_edge_part(EdgePart &p, const int32_t *kmers, const float *random_tbl, s
   int rc = part_streams(p.device, p.dup, ws);
   if (rc != PPK_OK) return fail(rc);
   hipStream_t s = ws[0];
-  const size_t rows = ppk_rows_in_band(p.ref->n, p.qry ? p.qry->n : 0, p.q_begin, p.q_end);
-  if (rows == 0) return;
-  size_t cap = rows / 8 > ((size_t)1 << 20) ? rows / 8 : ((size_t)1 << 20);
-  if (cap > rows) cap = rows;
+  const size_t n_qry = p.qry ? p.qry->n : 0;
+  if (ppk_rows_in_band(p.ref->n, n_qry, p.q_begin, p.q_end) == 0) return;
+  // the band in pieces whose edge bitmask (one bit per pair) stays below 2 GiB: 100 000 genomes are one piece,
+  // a million are a few hundred
+  const size_t n_rtiles = (p.ref->n + 63) / 64;
+  size_t mask_words = (size_t)1 << 28;
+  if (const long long cr = ppk_config().chunk_rows.load(); cr > 0)     // scales with the sub-band size of ppk_query:
+    mask_words = (size_t)cr * 32;                                      // 8 Mi rows (default) <-> 2^28 words
+  size_t step = (mask_words / n_rtiles) / 64 * 64;
+  if (step < 64) step = 64;
+  {
+    // sketches whose counts need more than 128 bits per pair have no fused path: ppk_dist_edges_dev serves the
+    // whole matrix only (through a distance buffer), so the band stays in one piece
+    int bits = 1;
+    while (((size_t)1 << bits) <= p.ref->s64 * 64) ++bits;
+    if (p.ref->nk > PPK_MAX_NK || p.ref->nk * (size_t)bits > 128) step = p.q_end - p.q_begin;
+  }
   unsigned long long *d_cnt = nullptr;      // [0] edges, [1] failed fits
   long long *d_edges = nullptr;
+  size_t cap = 0;
   auto done = [&](int code) {
     if (d_edges) (void)hipFree(d_edges);
     if (d_cnt) (void)hipFree(d_cnt);
@@ -1478,28 +1492,43 @@ void run_edge_part(EdgePart &p, const int32_t *kmers, const float *random_tbl, s
   };
   if (hipMalloc(reinterpret_cast<void **>(&d_cnt), 16) != hipSuccess)
     return done(ppk_fail(PPK_ERR_HIP, "hipMalloc failed"));
-  for (int attempt = 0; attempt < 2; ++attempt) {
-    if (hipMalloc(reinterpret_cast<void **>(&d_edges), cap * 16) != hipSuccess)
-      return done(ppk_fail(PPK_ERR_HIP, "hipMalloc(edge list) failed"));
-    if (hipMemsetAsync(d_cnt, 0, 16, s) != hipSuccess) return done(ppk_fail(PPK_ERR_HIP, "hipMemset failed"));
-    rc = ppk_dist_edges_dev(p.ref, p.qry, kmers, random_tbl, n_clu, flags, p.q_begin, p.q_end, slope, x_max, y_max,
-                            scale_x, scale_y, inclusive, d_edges, cap, d_cnt, d_cnt + 1, s);
-    if (rc != PPK_OK) return done(rc);
-    unsigned long long h[2] = {0, 0};
-    if (hipMemcpyAsync(h, d_cnt, 16, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
-      return done(ppk_fail(PPK_ERR_HIP, "kernel execution failed (fused edge list)"));
-    if (h[0] <= cap) {
-      p.edges.resize((size_t)h[0] * 2);
-      p.failed = h[1];
-      if (h[0] && hipMemcpy(p.edges.data(), d_edges, (size_t)h[0] * 16, hipMemcpyDeviceToHost) != hipSuccess)
-        return done(ppk_fail(PPK_ERR_HIP, "hipMemcpy D2H failed"));
-      return done(PPK_OK);
+  for (size_t lo = p.q_begin; lo < p.q_end;) {
+    const size_t hi = lo + step < p.q_end ? lo + step : p.q_end;
+    const size_t rows = ppk_rows_in_band(p.ref->n, n_qry, lo, hi);
+    size_t want = rows / 8 > ((size_t)1 << 20) ? rows / 8 : ((size_t)1 << 20);
+    if (want > rows) want = rows;
+    bool fits = rows == 0;
+    for (int attempt = 0; attempt < 2 && !fits; ++attempt) {
+      if (want > cap) {                     // the list buffer only grows, piece after piece
+        if (d_edges) (void)hipFree(d_edges);
+        d_edges = nullptr;
+        cap = 0;
+        if (hipMalloc(reinterpret_cast<void **>(&d_edges), want * 16) != hipSuccess)
+          return done(ppk_fail(PPK_ERR_HIP, "hipMalloc(edge list) failed"));
+        cap = want;
+      }
+      if (hipMemsetAsync(d_cnt, 0, 16, s) != hipSuccess) return done(ppk_fail(PPK_ERR_HIP, "hipMemset failed"));
+      rc = ppk_dist_edges_dev(p.ref, p.qry, kmers, random_tbl, n_clu, flags, lo, hi, slope, x_max, y_max, scale_x,
+                              scale_y, inclusive, d_edges, cap, d_cnt, d_cnt + 1, s);
+      if (rc != PPK_OK) return done(rc);
+      unsigned long long h[2] = {0, 0};
+      if (hipMemcpyAsync(h, d_cnt, 16, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+        return done(ppk_fail(PPK_ERR_HIP, "kernel execution failed (fused edge list)"));
+      if (h[0] <= cap) {
+        const size_t at = p.edges.size();
+        p.edges.resize(at + (size_t)h[0] * 2);
+        p.failed += h[1];
+        if (h[0] && hipMemcpy(p.edges.data() + at, d_edges, (size_t)h[0] * 16, hipMemcpyDeviceToHost) != hipSuccess)
+          return done(ppk_fail(PPK_ERR_HIP, "hipMemcpy D2H failed"));
+        fits = true;
+      } else {
+        want = (size_t)h[0];                // the guess was too small: once more with the exact size
+      }
     }
-    (void)hipFree(d_edges);                 // the guess was too small: once more with the exact size
-    d_edges = nullptr;
-    cap = (size_t)h[0];
+    if (!fits) return done(ppk_fail(PPK_ERR_STATE, "internal: the edge count grew between two passes"));
+    lo = hi;
   }
-  done(ppk_fail(PPK_ERR_STATE, "internal: the edge count grew between two passes"));
+  done(PPK_OK);
 }
 }  // namespace
 

@@ -299,6 +299,27 @@ def test_query_edges_host_call_equals_two_step(devices, inclusive):
         assert [tuple(r) for r in got.tolist()] == [tuple(x) for x in t]
 
 
+def test_query_edges_works_through_a_band_in_pieces(ppk_option):
+    """The edge bitmask of a device's band is bounded: with a small piece size the same lists come out of
+    many passes (self and ref x query, one entry and three, buffer regrown between pieces)."""
+    sk, _ = synth.make_sketches(1100, KMERS, cluster_size=25, seed=15)
+    tbl = synth.random_match_table(KMERS)
+    dist, _ = pp_sketchlib.query_arrays(sk, None, KMERS, 16, 14, tbl)
+    x_max, y_max = synth.boundary_for_quantile(dist, 0.1)
+    want = oracle.edge_threshold(dist, 2, x_max, y_max, inclusive=True)
+    rq, _ = pp_sketchlib.query_arrays(sk[:700], sk[700:], KMERS, 16, 14, tbl)
+    want_rq = oracle.edge_threshold(rq, 2, x_max, y_max, n_ref=700, inclusive=True)
+    assert len(want) > 1000 and len(want_rq) > 500
+    ppk_option("chunk_rows", 64)          # pieces of 64 * 32 mask words: 64 - 128 query rows each
+    for devices in ((0,), (0, 0, 0)):
+        got, _ = pp_sketchlib.query_edges_arrays(sk, None, KMERS, 16, 14, 2, x_max, y_max, random_table=tbl,
+                                                 devices=devices)
+        assert np.array_equal(got, want)
+        got, _ = pp_sketchlib.query_edges_arrays(sk[:700], sk[700:], KMERS, 16, 14, 2, x_max, y_max,
+                                                 random_table=tbl, devices=devices)
+        assert np.array_equal(got, want_rq)
+
+
 def test_query_edges_ref_query_clusters_and_errors():
     sk, clu = synth.make_sketches(640, KMERS, cluster_size=20, seed=8)
     tbl = synth.random_match_table(KMERS)
