@@ -1,0 +1,68 @@
+"""Beyond BASELINE config 5: N genomes (default 1 000 000: 5e11 pairs) self-vs-self -> slope-2 boundary -> edge
+list in a host array, ONE host call on one GPU (ppk_query_edges_dbs working through the band in pieces).
+Checks: the list of a second run with another piece size is identical; rows ascending, i < j; sampled pairs
+-- edges and non-edges -- agree with the CPU oracle's distances and the boundary.
+
+    gpurun -- python tools/scale_million.py [n_genomes]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from oracle import oracle  # noqa: E402
+from poppunk_amd import _lib, engine, synth  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+kmers = np.asarray(synth.DEFAULT_KMERS, dtype=np.int32)
+tbl = synth.random_match_table(kmers)
+t0 = time.perf_counter()
+sk_t = synth.make_sketches_device(n, kmers, device="cuda:0")
+torch.cuda.synchronize()
+print("%d genomes: sketches drawn on the device in %.1f s (%.2f GB)" % (n, time.perf_counter() - t0, sk_t.numel() * 8 / 1e9))
+db = engine.SketchDB(sk_t, 16, 14, device=0)
+sub = engine.SketchDB(synth.make_sketches_device(2000, kmers, device="cuda:0"), 16, 14, device=0)
+d_sub, _ = engine.dist(sub, None, kmers, tbl)
+x_max, y_max = synth.boundary_for_quantile(d_sub.cpu().numpy(), 0.02)
+sub.close()
+pairs = n * (n - 1) // 2
+runs = []
+for chunk_rows in (8 << 20, 3 << 20):
+    _lib.set_option("chunk_rows", chunk_rows)
+    t0 = time.perf_counter()
+    edges, n_failed = engine.edges_host(db, None, kmers, tbl, slope=2, x_max=x_max, y_max=y_max, cap=64 << 20)
+    t = time.perf_counter() - t0
+    runs.append(edges)
+    print("chunk_rows %8d: %.2f s, %.2f G pairs/s, %d edges, %d failed fits" % (chunk_rows, t, pairs / t / 1e9, len(edges), n_failed))
+_lib.set_option("chunk_rows", 8 << 20)
+e = runs[0]
+print("second run identical:", bool(np.array_equal(e, runs[1])))
+key = e[:, 0] * n + e[:, 1]
+print("i < j:", bool(np.all(e[:, 0] < e[:, 1])), " rows ascending:", bool(np.all(np.diff(key) > 0)))
+# sampled pairs against the oracle
+rng = np.random.Generator(np.random.PCG64(3))
+n_clusters = max(1, n // 50)
+is_edge = set()
+pick = rng.choice(len(e), size=min(300, len(e)), replace=False)
+sample = [(int(a), int(b), True) for a, b in e[pick]]
+for _ in range(300):       # pairs of one cluster (members are c, c + n_clusters, ...): a mix of edges and non-edges
+    c = int(rng.integers(0, n_clusters))
+    a, b = sorted(int(v) for v in rng.choice(np.arange(c, n, n_clusters), size=2, replace=False))
+    sample.append((a, b, None))
+for _ in range(100):       # arbitrary pairs
+    a, b = sorted(int(v) for v in rng.choice(n, size=2, replace=False))
+    sample.append((a, b, None))
+bad = 0
+for a, b, known in sample:
+    pair = sk_t[[a, b]].cpu().numpy().view(np.uint64)
+    d, _ = oracle.query(pair[:1], pair[1:], kmers, 16, 14, tbl, threads=1)
+    want = bool(oracle.edge_threshold(d, 2, x_max, y_max, n_ref=1, inclusive=True).shape[0])
+    pos = np.searchsorted(key, a * n + b)
+    got = bool(pos < len(key) and key[pos] == a * n + b)
+    if got != want or (known is not None and got != known):
+        bad += 1
+print("sampled pairs checked against the oracle: %d, disagreements: %d" % (len(sample), bad))
