@@ -63,7 +63,11 @@ int ppk_device_count(int *n);
 /* Run-time options.  Each has a PPK_<NAME> environment variable that is read ONCE, when the
  * library is first used; afterwards only ppk_set_option changes it.
  *   tuning (never change results): "map", "strip", "ksplit", "chunk_rows", "prefault_threads",
- *     "db_cache", "progress", "host_parts" (worker threads of a ONE-device host query of >= 16 Mi rows,
+ *     "db_cache", "progress", "launch_tiles" (pair tiles per kernel launch, at most and by default 8 000 000:
+ *     a dispatch holds fewer than 2^32 work-items, so bands of more tiles -- 370 000 genomes against
+ *     themselves and up -- go out as several launches), "knn_list" (entries of the neighbour-candidate list of
+ *     ppk_knn_sketches_dev, 0 = sized from n and knn: the list is cut back to the best knn per sample whenever
+ *     it is half full, so a job of any size runs in a bounded list), "host_parts" (worker threads of a ONE-device host query of >= 16 Mi rows,
  *     default 2: the device is entered twice, each entry with its own streams and buffers, so that one
  *     download is in flight while the next is being set up)
  *   measurement only: "host_trace" 1: a timeline of every host query (launches, page touching, downloads,

@@ -51,6 +51,8 @@ const OptionEntry kOptions[] = {
     {"prefault_threads", "PPK_PREFAULT_THREADS", &PpkConfig::prefault_threads},
     {"db_cache", "PPK_DB_CACHE", &PpkConfig::db_cache},
     {"progress", "PPK_PROGRESS", &PpkConfig::progress},
+    {"launch_tiles", "PPK_LAUNCH_TILES", &PpkConfig::launch_tiles},
+    {"knn_list", "PPK_KNN_LIST", &PpkConfig::knn_list},
     {"host_parts", "PPK_HOST_PARTS", &PpkConfig::host_parts},
     {"host_trace", "PPK_HOST_TRACE", &PpkConfig::host_trace},
     {"ext_collision_adjust", "PPK_EXT_COLLISION_ADJUST", &PpkConfig::ext_collision_adjust},
@@ -626,42 +628,94 @@ extern "C" int ppk_knn_sketches_dev(const ppk_db *db, const int32_t *kmers, cons
   // Measured (k = 5): ~200 / 530 / 1 000 candidates per sample at 10k / 50k / 100k samples.  A bound is the
   // k-th smallest of ONE tile's candidates (bounds are not merged across tiles: that would need a
   // lock per sample), so it settles near the (k / 256) / (tiles per row) quantile rather than at the
-  // true k-th distance; 12 bytes per candidate make that a non-issue (1.8 GB of scratch at 100k).  An
-  // overflow costs a second run of the kernel, which then starts from the settled bounds.
+  // true k-th distance; 12 bytes per candidate make that a non-issue (1.8 GB of scratch at 100k).
   // (Tried: three launches of growing size so that the bulk runs under settled bounds -- emitted more,
   // not less, in the first two.)
+  // Large jobs go piece by piece (a dispatch holds < 2^32 work-items: ppk_rows_per_dispatch): when the list
+  // has filled half its room, or a piece did not fit, the list is cut down to the best knn per sample -- which
+  // also sets every bound to the true k-th distance so far -- and the job goes on.  A million genomes run
+  // in a few dozen pieces with a list of at most 2^31 entries, whatever n^2 is.
   size_t cap = n * (size_t)(256 + 256 * knn);
   if (cap < ((size_t)1 << 20)) cap = (size_t)1 << 20;
   if (cap > all) cap = all;
   if (cap == 0) cap = 1;
+  const size_t sort_limit = (size_t)0x7fffffff - 1024;             // one radix sort takes fewer than 2^31 items
+  if (cap > sort_limit) cap = sort_limit;
+  if (const long long want = ppk_config().knn_list.load(); want > 0) {      // (tests: a short list, many selections)
+    cap = (size_t)want;
+    if (cap < 2 * n * (size_t)knn + 4096) cap = 2 * n * (size_t)knn + 4096;
+    if (cap > sort_limit) cap = sort_limit;
+  }
+  if (n * (size_t)knn * 2 > sort_limit) return ppk_fail(PPK_ERR_ARG, "neighbours from tiles: n * knn must stay below 2^30");
   const int knn_args[2] = {knn, dist_col};
-  unsigned long long count = 0;
   void *d_cand = nullptr;
   size_t vals_off = 0;
-  for (int attempt = 0;; ++attempt) {
-    vals_off = (cap * 4 + 255) & ~(size_t)255;
-    rc = scratch_get(db->device, SLOT_ITER_B, vals_off + cap * 8 + 256, &d_cand);
-    if (rc != PPK_OK) return rc;
-    // the bounds of an earlier attempt stay valid (they only ever tighten): the re-run emits less
-    rc = ppk_launch_knn_state_init(d_state, n, cap, vals_off, attempt == 0, s);
-    if (rc != PPK_OK) return rc;
-    if (n > 1) {
-      rc = ppk_launch_dist(db, nullptr, kmers, d_rtab, d_rtab ? n_clu : 1, flags, 0, n, d_cand, nullptr,
-                           static_cast<uint64_t *>(d_state), 2, 0.f, 0.f, 1.f, 1.f, 1, d_lut, s, knn_args,
-                           lut_ready || attempt > 0);
-      if (rc != PPK_OK) return rc;
-    }
-    PPK_HIP(hipMemcpyAsync(&count, d_state, sizeof(count), hipMemcpyDeviceToHost, s));
+  auto room = [&](size_t entries) {        // (re)allocates the list for `entries`; only while it is empty
+    vals_off = (entries * 4 + 255) & ~(size_t)255;
+    return scratch_get(db->device, SLOT_ITER_B, vals_off + entries * 8 + 256, &d_cand);
+  };
+  rc = room(cap);
+  if (rc != PPK_OK) return rc;
+  rc = ppk_launch_knn_state_init(d_state, n, cap, vals_off, 1, s);
+  if (rc != PPK_OK) return rc;
+  auto read_count = [&](unsigned long long *c) {
+    PPK_HIP(hipMemcpyAsync(c, d_state, sizeof(*c), hipMemcpyDeviceToHost, s));
     PPK_HIP(hipStreamSynchronize(s));
-    if (count <= cap) break;
-    if (attempt >= 4) return ppk_fail(PPK_ERR_CAPACITY, "neighbour candidates keep overflowing their buffer");
-    cap = (size_t)count + (size_t)count / 4 + 1024;
-    if (cap > all) cap = all;
+    return (int)PPK_OK;
+  };
+  auto set_count = [&](unsigned long long c) {
+    PPK_HIP(hipMemcpyAsync(d_state, &c, sizeof(c), hipMemcpyHostToDevice, s));
+    PPK_HIP(hipStreamSynchronize(s));
+    return (int)PPK_OK;
+  };
+  auto keys = [&]() { return static_cast<uint32_t *>(d_cand); };
+  auto vals = [&]() { return reinterpret_cast<uint64_t *>(static_cast<char *>(d_cand) + vals_off); };
+  unsigned long long count = 0;
+  size_t piece = ppk_rows_per_dispatch(db);
+  bool tables_built = lut_ready;
+  for (size_t lo = 0; lo < n && n > 1;) {
+    const size_t hi = lo + piece < n ? lo + piece : n;
+    const unsigned long long before = count;
+    rc = ppk_launch_dist(db, nullptr, kmers, d_rtab, d_rtab ? n_clu : 1, flags, lo, hi, d_cand, nullptr,
+                         static_cast<uint64_t *>(d_state), 2, 0.f, 0.f, 1.f, 1.f, 1, d_lut, s, knn_args, tables_built);
+    if (rc != PPK_OK) return rc;
+    tables_built = true;
+    rc = read_count(&count);
+    if (rc != PPK_OK) return rc;
+    if (count > cap) {
+      // the piece did not fit: what it wrote is dropped (a second copy of a pair would break the selection),
+      // room is made, and the piece runs again -- under the bounds it has tightened meanwhile
+      const unsigned long long wanted = count - before;
+      rc = set_count(before);
+      if (rc != PPK_OK) return rc;
+      count = before;
+      if (before > n * (unsigned long long)knn) {
+        rc = ppk_knn_compact(db->device, keys(), vals(), (size_t)before, n, knn, d_state, d_i, d_j, d_dist, s);
+        if (rc != PPK_OK) return rc;
+        count = n * (unsigned long long)knn;
+      } else if (before == 0 && cap < sort_limit && cap < all) {
+        cap = (size_t)wanted + (size_t)wanted / 4 + 1024;           // an empty list: simply more room
+        if (cap > sort_limit) cap = sort_limit;
+        if (cap > all) cap = all;
+        rc = room(cap);
+        if (rc == PPK_OK) rc = ppk_launch_knn_state_init(d_state, n, cap, vals_off, 0, s);
+        if (rc != PPK_OK) return rc;
+      } else if (piece > 64) {
+        piece = (piece / 2 + 63) / 64 * 64;                         // nothing left to drop: smaller pieces
+      } else {
+        return ppk_fail(PPK_ERR_CAPACITY, "neighbour candidates keep overflowing their buffer");
+      }
+      continue;
+    }
+    lo = hi;
+    if (lo < n && count > cap / 2 && count > n * (unsigned long long)knn) {
+      rc = ppk_knn_compact(db->device, keys(), vals(), (size_t)count, n, knn, d_state, d_i, d_j, d_dist, s);
+      if (rc != PPK_OK) return rc;
+      count = n * (unsigned long long)knn;
+    }
   }
   if (n_candidates) *n_candidates = count;
-  return ppk_knn_from_candidates(db->device, static_cast<const uint32_t *>(d_cand),
-                                 reinterpret_cast<const uint64_t *>(static_cast<char *>(d_cand) + vals_off),
-                                 (size_t)count, n, knn, d_i, d_j, d_dist, s);
+  return ppk_knn_from_candidates(db->device, keys(), vals(), (size_t)count, n, knn, d_i, d_j, d_dist, s);
 }
 
 // The two halves of the above for N GPUs: each rank emits the candidates of ITS band of query rows

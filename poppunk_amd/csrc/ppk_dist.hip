@@ -1624,7 +1624,8 @@ int launch_v2(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const f
   const size_t n_tri = !r_tiles ? 0 : p.xcd_map == 0 ? (size_t)p.tiles_per_xcd * 8
                                   : p.xcd_map == 1 ? per_xcd * 8 : r_tiles * q_tiles;
   const size_t n_blocks = n_tri + p.n_strip_pad;
-  if (n_blocks > 0x7fffffffull) return ppk_fail(PPK_ERR_ARG, "tile grid too large for one launch");
+  if (n_blocks * (size_t)(NW * 64) >= ((size_t)1 << 32))
+    return ppk_fail(PPK_ERR_ARG, "internal: tile grid too large for one launch (ppk_launch_dist splits bands before this)");
   ppk_set_kernel_name("dist_kernel_v2<256x32,lds-dma>");
   ppk_prof_begin(s);
   if (MODE == MODE_COUNTS && NW == 8 && p.k_split) {
@@ -1694,11 +1695,57 @@ int ppk_launch_transpose(const uint64_t *d_in, uint64_t *d_out, size_t n, size_t
 
 // Enqueue kernel 1 for one band.  d_scratch must hold lut_bytes (+ table).
 // mode_mask: d_mask non-null selects the fused boundary/bitmask output.
+static int launch_dist_band(const ppk_db *ref, const ppk_db *qry_or_null, const int32_t *kmers,
+                            const float *d_rtab, size_t n_clu, int flags, size_t q_begin, size_t q_end,
+                            void *d_out, unsigned long long *d_n_failed, uint64_t *d_mask, int slope,
+                            float x_max, float y_max, float scale_x, float scale_y, int inclusive,
+                            double *d_lut, hipStream_t s, const int *knn_args, bool lut_ready);
+
+size_t ppk_rows_per_dispatch(const ppk_db *ref) {
+  const size_t r_tiles = (ref->n + V2_RT - 1) / V2_RT;
+  long long per_launch = ppk_config().launch_tiles.load();
+  if (per_launch < 1 || per_launch > 8000000) per_launch = 8000000;
+  size_t q_sub = ((size_t)per_launch / (r_tiles ? r_tiles : 1)) * 32 / 64 * 64;      // 32 query rows per tile
+  if (ref->bbits != 14 && q_sub > ((size_t)1 << 17)) q_sub = (size_t)1 << 17;   // generic kernel: 2-D grid, y < 65 536
+  return q_sub < 64 ? 64 : q_sub;
+}
+
+// A dispatch holds fewer than 2^32 work-items: with 512-thread workgroups that is 8.4 M pair tiles, which
+// 370 000 genomes against themselves exceed (a million: 61 M).  Larger bands go out as several launches over
+// consecutive query rows, each writing to its own part of the output (the kernels address rows and mask
+// words relative to the band they are launched on; kNN candidates are appended through a shared counter).
 int ppk_launch_dist(const ppk_db *ref, const ppk_db *qry_or_null, const int32_t *kmers,
                     const float *d_rtab, size_t n_clu, int flags, size_t q_begin, size_t q_end,
                     void *d_out, unsigned long long *d_n_failed, uint64_t *d_mask, int slope,
                     float x_max, float y_max, float scale_x, float scale_y, int inclusive,
                     double *d_lut, hipStream_t s, const int *knn_args, bool lut_ready) {
+  const size_t q_sub = ppk_rows_per_dispatch(ref);
+  if (q_end - q_begin <= q_sub)
+    return launch_dist_band(ref, qry_or_null, kmers, d_rtab, n_clu, flags, q_begin, q_end, d_out, d_n_failed, d_mask,
+                            slope, x_max, y_max, scale_x, scale_y, inclusive, d_lut, s, knn_args, lut_ready);
+  const size_t n_qry = qry_or_null ? qry_or_null->n : 0;
+  const size_t row_bytes = (flags & (PPK_FLAG_COUNTS | PPK_FLAG_JACCARD)) ? ref->nk * 4 : 8;
+  const size_t n_rtiles = (ref->n + 63) / 64;
+  for (size_t lo = q_begin; lo < q_end; lo += q_sub) {
+    const size_t hi = lo + q_sub < q_end ? lo + q_sub : q_end;
+    void *out = d_out;
+    uint64_t *mask = d_mask;
+    if (!knn_args) {
+      if (d_out) out = static_cast<char *>(d_out) + ppk_rows_in_band(ref->n, n_qry, q_begin, lo) * row_bytes;
+      if (d_mask) mask = d_mask + (lo - q_begin) * n_rtiles;
+    }
+    int rc = launch_dist_band(ref, qry_or_null, kmers, d_rtab, n_clu, flags, lo, hi, out, d_n_failed, mask, slope,
+                              x_max, y_max, scale_x, scale_y, inclusive, d_lut, s, knn_args, lut_ready || lo > q_begin);
+    if (rc != PPK_OK) return rc;
+  }
+  return PPK_OK;
+}
+
+static int launch_dist_band(const ppk_db *ref, const ppk_db *qry_or_null, const int32_t *kmers,
+                            const float *d_rtab, size_t n_clu, int flags, size_t q_begin, size_t q_end,
+                            void *d_out, unsigned long long *d_n_failed, uint64_t *d_mask, int slope,
+                            float x_max, float y_max, float scale_x, float scale_y, int inclusive,
+                            double *d_lut, hipStream_t s, const int *knn_args, bool lut_ready) {
   const ppk_db *qry = qry_or_null ? qry_or_null : ref;
   DistParams p = {};
   p.self = qry_or_null ? 0 : 1;

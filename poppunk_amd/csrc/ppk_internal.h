@@ -45,6 +45,8 @@ struct PpkConfig {
   std::atomic<long long> db_cache{1};           // PPK_DB_CACHE: ppk_query keeps its resident databases / buffers
   std::atomic<long long> progress{1};           // PPK_PROGRESS: progress meter of long host calls on fd 2
   std::atomic<long long> host_trace{0};         // PPK_HOST_TRACE: timeline of a host query on fd 2 (measurement)
+  std::atomic<long long> launch_tiles{8000000}; // PPK_LAUNCH_TILES: pair tiles per kernel launch (a dispatch holds < 2^32 work-items)
+  std::atomic<long long> knn_list{0};           // PPK_KNN_LIST: entries of the neighbour-candidate list (0 = sized from n and knn)
   std::atomic<long long> host_parts{2};         // PPK_HOST_PARTS: worker threads of a one-device host query (>= 16 Mi rows)
   // [EXT] a4: 0 = the b-bit collision adjustment is never in effect (upstream as recalled: it is
   // gated on expected == 0, where it is the identity); 1 = applied when expected > 0
@@ -163,7 +165,11 @@ void ppk_parked_clear();
 int ppk_launch_knn_state_init(void *d_state, size_t n, unsigned long long cap, unsigned long long vals_off,
                               int reset_bounds, hipStream_t s);
 int ppk_knn_from_candidates(int dev, const uint32_t *d_keys, const uint64_t *d_vals, size_t count, size_t n,
-                            int knn, long long *d_i, long long *d_j, float *d_dist, hipStream_t s);
+                            int knn, long long *d_i, long long *d_j, float *d_dist, hipStream_t s,
+                            long long missing_j = 0);
+int ppk_knn_compact(int dev, uint32_t *d_keys, uint64_t *d_vals, size_t count, size_t n, int knn, void *d_state,
+                    long long *d_i, long long *d_j, float *d_dist, hipStream_t s);
+size_t ppk_rows_per_dispatch(const ppk_db *ref);     // query rows one kernel launch may cover (ppk_launch_dist)
 
 // spread the 32 bits of x to the even bit positions of a 64-bit word (wave-uniform: SALU)
 __device__ __forceinline__ uint64_t spread_even(uint32_t v) {

@@ -331,7 +331,7 @@ knn_state_init_kernel(unsigned long long *state, uint32_t *thr, size_t n, unsign
 template <int K>
 __global__ void __launch_bounds__(256)
 knn_select_sorted_kernel(const uint32_t *__restrict__ skeys, const uint64_t *__restrict__ svals,
-                         size_t count, size_t n, int knn, long long *__restrict__ oi,
+                         size_t count, size_t n, int knn, long long missing_j, long long *__restrict__ oi,
                          long long *__restrict__ oj, float *__restrict__ od) {
   const size_t i = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n) return;
@@ -378,10 +378,11 @@ knn_select_sorted_kernel(const uint32_t *__restrict__ skeys, const uint64_t *__r
       m = v < m ? v : m;
     }
     if (m == NONE) {
-      // fewer than knn other samples: the reference leaves i in i_vec and zeros elsewhere
+      // fewer than knn other samples: the reference leaves i in i_vec and zeros elsewhere (missing_j = 0;
+      // the intermediate selections of a large job mark the slot with -1 instead)
       for (int k = r + lane; k < knn; k += 64) {
         oi[i * knn + k] = (long long)i;
-        oj[i * knn + k] = 0;
+        oj[i * knn + k] = missing_j;
         od[i * knn + k] = 0.0f;
       }
       break;
@@ -396,6 +397,25 @@ knn_select_sorted_kernel(const uint32_t *__restrict__ skeys, const uint64_t *__r
     }
   }
 }
+// A selection becomes the head of the candidate list again (large jobs select now and then, so that the list
+// never holds more than the best k per sample plus what one piece of the job emits): slot (i, r) -> candidate
+// (i, distance bits << 32 | j), empty slots -> sample id n (sorted behind every real sample, never looked up);
+// a sample with k neighbours so far gets the k-th distance as its bound.
+__global__ void __launch_bounds__(256)
+knn_requeue_kernel(const long long *__restrict__ oj, const float *__restrict__ od, size_t n, int knn,
+                   uint32_t *__restrict__ keys, uint64_t *__restrict__ vals, unsigned long long *state,
+                   uint32_t *__restrict__ thr) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e == 0) state[0] = (unsigned long long)n * (unsigned long long)knn;
+  if (e >= n * (size_t)knn) return;
+  const size_t i = e / (size_t)knn;
+  const int r = (int)(e % (size_t)knn);
+  const long long j = oj[e];
+  const uint32_t bits = __float_as_uint(od[e]);
+  keys[e] = j >= 0 ? (uint32_t)i : (uint32_t)n;
+  vals[e] = ((uint64_t)bits << 32) | (uint32_t)(j >= 0 ? j : 0);
+  if (r == knn - 1 && j >= 0 && bits < thr[i]) thr[i] = bits;
+}
 }  // namespace
 
 int ppk_launch_knn_state_init(void *d_state, size_t n, unsigned long long cap, unsigned long long vals_off,
@@ -409,12 +429,13 @@ int ppk_launch_knn_state_init(void *d_state, size_t n, unsigned long long cap, u
 
 // keys/vals: `count` candidates; sorted copies and the sort's workspace come from SLOT_ITER_C
 int ppk_knn_from_candidates(int dev, const uint32_t *d_keys, const uint64_t *d_vals, size_t count, size_t n,
-                            int knn, long long *d_i, long long *d_j, float *d_dist, hipStream_t s) {
+                            int knn, long long *d_i, long long *d_j, float *d_dist, hipStream_t s,
+                            long long missing_j) {
   if (knn > 32) return ppk_fail(PPK_ERR_ARG, "neighbours from tiles: at most 32 neighbours per sample");
   if (count >= (size_t)0x7fffffff) return ppk_fail(PPK_ERR_ARG, "too many neighbour candidates for one sort");
   const size_t o_keys = 0, o_vals = (count * 4 + 255) & ~(size_t)255, o_tmp = o_vals + ((count * 8 + 255) & ~(size_t)255);
   int end_bit = 1;
-  while (((size_t)1 << end_bit) < n && end_bit < 32) ++end_bit;
+  while (((size_t)1 << end_bit) <= n && end_bit < 32) ++end_bit;      // sample ids 0 .. n (n = an empty slot, see requeue)
   size_t tmp = 0;
   uint32_t *nk = nullptr;
   uint64_t *nv = nullptr;
@@ -430,9 +451,25 @@ int ppk_knn_from_candidates(int dev, const uint32_t *d_keys, const uint64_t *d_v
                                                end_bit, s));
   const dim3 grid((unsigned)((n + 3) / 4));
   if (knn <= 8)
-    hipLaunchKernelGGL(knn_select_sorted_kernel<8>, grid, dim3(256), 0, s, skeys, svals, count, n, knn, d_i, d_j, d_dist);
+    hipLaunchKernelGGL(knn_select_sorted_kernel<8>, grid, dim3(256), 0, s, skeys, svals, count, n, knn, missing_j, d_i, d_j,
+                       d_dist);
   else
-    hipLaunchKernelGGL(knn_select_sorted_kernel<32>, grid, dim3(256), 0, s, skeys, svals, count, n, knn, d_i, d_j, d_dist);
+    hipLaunchKernelGGL(knn_select_sorted_kernel<32>, grid, dim3(256), 0, s, skeys, svals, count, n, knn, missing_j, d_i, d_j,
+                       d_dist);
+  PPK_HIP(hipGetLastError());
+  return PPK_OK;
+}
+
+// the candidate list [0, count) shrinks to the best knn per sample (in place; d_i / d_j / d_dist: room for
+// n * knn entries, used as scratch), bounds follow, the list's counter is set to n * knn
+int ppk_knn_compact(int dev, uint32_t *d_keys, uint64_t *d_vals, size_t count, size_t n, int knn, void *d_state,
+                    long long *d_i, long long *d_j, float *d_dist, hipStream_t s) {
+  int rc = ppk_knn_from_candidates(dev, d_keys, d_vals, count, n, knn, d_i, d_j, d_dist, s, -1);
+  if (rc != PPK_OK) return rc;
+  unsigned long long *st = static_cast<unsigned long long *>(d_state);
+  const size_t slots = n * (size_t)knn;
+  hipLaunchKernelGGL(knn_requeue_kernel, dim3((unsigned)((slots + 255) / 256 ? (slots + 255) / 256 : 1)), dim3(256), 0, s, d_j,
+                     d_dist, n, knn, d_keys, d_vals, st, reinterpret_cast<uint32_t *>(st + 3));
   PPK_HIP(hipGetLastError());
   return PPK_OK;
 }

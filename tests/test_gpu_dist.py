@@ -769,3 +769,49 @@ def test_interior_tiles_with_three_and_four_kmer_lengths(ppk_option, nk):
     ppk_option("ablate", 32)
     b, _ = pp_sketchlib.query_arrays(sk, None, kmers, 16, 14, tbl)
     assert np.array_equal(got, b)
+
+
+@pytest.mark.parametrize("bbits,s64", [(14, 16), (8, 5)])
+def test_bands_larger_than_one_dispatch_go_out_as_several_launches(ppk_option, bbits, s64):
+    """A dispatch holds fewer than 2^32 work-items (8.4 M pair tiles of 512 threads): 370 000 genomes against
+    themselves exceed it.  The launcher then cuts the band into consecutive query-row pieces, each writing to
+    its own part of the output.  Forced here with a tiny tile budget: distances, counts, Jaccard, the fused
+    edge list, neighbours from the tiles, self and ref x query, all equal to the single-launch results."""
+    kmers = np.asarray([13, 17, 21, 25], dtype=np.int32)
+    sk, _ = synth.make_sketches(700, kmers, sketchsize64=s64, bbits=bbits, cluster_size=35, seed=77)
+    tbl = synth.random_match_table(kmers)
+    ref, qry = sk[:450], sk[450:]
+    ppk_option("ksplit", 0)
+    single = {}
+    for pieces in (False, True):
+        if pieces:
+            ppk_option("launch_tiles", 8)        # 2 ref tiles of 256 -> 4 tiles of 32 query rows -> 128 -> 64-row pieces
+        out = {}
+        out["d_self"] = pp_sketchlib.query_arrays(sk, None, kmers, s64, bbits, tbl)
+        out["c_self"] = pp_sketchlib.query_arrays(sk, None, kmers, s64, bbits, counts=True)
+        out["j_rq"] = pp_sketchlib.query_arrays(ref, qry, kmers, s64, bbits, tbl, jaccard=True)
+        out["d_rq"] = pp_sketchlib.query_arrays(ref, qry, kmers, s64, bbits, tbl)
+        db = engine.SketchDB(sk, s64, bbits)
+        rdb, qdb = engine.SketchDB(ref, s64, bbits), engine.SketchDB(qry, s64, bbits)
+        band, _ = engine.dist(db, None, kmers, tbl, q_begin=100, q_end=613)
+        out["band"] = (band.cpu().numpy(), 0)
+        x_max, y_max = synth.boundary_for_quantile(out["d_self"][0], 0.1)
+        e, _ = engine.dist_edges(db, None, kmers, tbl, slope=2, x_max=x_max, y_max=y_max)
+        out["e_self"] = (e.cpu().numpy(), 0)
+        e, _ = engine.dist_edges(rdb, qdb, kmers, tbl, slope=1, x_max=x_max, y_max=y_max, q_begin=3, q_end=250)
+        out["e_rq"] = (e.cpu().numpy(), 0)
+        if bbits == 14:
+            i, j, d = engine.knn_from_sketches(db, kmers, tbl, 5, method="tiles")
+            out["knn"] = (np.stack([i.cpu().numpy(), j.cpu().numpy()]), 0)
+            out["knn_d"] = (d.cpu().numpy(), 0)
+        for x in (db, rdb, qdb):
+            x.close()
+        if not pieces:
+            single = out
+            want, _ = oracle.query(sk, None, kmers, s64, bbits, tbl, threads=4)
+            assert np.abs(out["d_self"][0] - want).max() <= 1e-6
+        else:
+            for key in single:
+                assert out[key][1] == single[key][1], key
+                assert np.array_equal(out[key][0], single[key][0]), key
+            assert len(single["e_self"][0]) > 100 and len(single["e_rq"][0]) > 10

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle
-from poppunk_amd import engine, poppunk_refine, pp_sketchlib, qc
+from poppunk_amd import engine, poppunk_refine, pp_sketchlib, qc, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -192,3 +192,29 @@ def test_prune_on_resident_buffers():
     kq = np.sort(rng.choice(n_qry, size=55, replace=False))
     got = engine.prune_query_rows_dev(torch.as_tensor(qr, device="cuda"), n_ref, kq).cpu().numpy()
     assert np.array_equal(got, qr.reshape(n_qry, n_ref, 2)[kq].reshape(-1, 2))
+
+
+@pytest.mark.parametrize("knn", [1, 5, 12])
+def test_neighbours_from_tiles_in_pieces_with_a_short_candidate_list(ppk_option, knn):
+    """Large jobs run piece by piece and cut the candidate list back to the best knn per sample whenever it
+    is half full (a million genomes would otherwise emit ~10^10 candidates).  Forced at 1 500 genomes with a
+    tiny tile budget and a short list: many selections, pieces that do not fit and run again -- the result is
+    the single-pass result, which is the oracle's."""
+    from poppunk_amd import engine
+    kmers = np.asarray(synth.DEFAULT_KMERS, dtype=np.int32)
+    sk, _ = synth.make_sketches(1500, kmers, cluster_size=40, seed=19)
+    tbl = synth.random_match_table(kmers)
+    db = engine.SketchDB(sk, 16, 14)
+    info = {}
+    wi, wj, wd = (x.cpu().numpy() for x in engine.knn_from_sketches(db, kmers, tbl, knn, method="tiles", info=info))
+    d, _ = engine.dist(db, None, kmers, tbl)
+    oi, oj, od = oracle.knn(oracle.long_to_square(d.cpu().numpy()[:, 0]), knn)
+    assert np.array_equal(wi, oi) and np.array_equal(wj, oj) and np.array_equal(wd, od)
+    single = info["candidates"]
+    for tiles, room in ((12, 40000), (6, 2 * 1500 * knn + 4096), (48, 1 << 19)):
+        ppk_option("launch_tiles", tiles)
+        ppk_option("knn_list", room)
+        gi, gj, gd = (x.cpu().numpy() for x in engine.knn_from_sketches(db, kmers, tbl, knn, method="tiles", info=info))
+        assert np.array_equal(gi, oi) and np.array_equal(gj, oj) and np.array_equal(gd, od), (tiles, room)
+    assert single > 1500 * knn
+    db.close()
