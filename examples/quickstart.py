@@ -7,7 +7,8 @@
     -> a refine / threshold boundary: assignments, edge list   PopPUNK/models.py:1065-1091,
                                                                PopPUNK/network.py:1180-1184
     -> clusters = connected components of the edge list
-  and the same edge list again from the FUSED call, in which no distance matrix is ever stored.
+  and the same edge list again from the FUSED call, in which no distance matrix is ever stored -- on resident
+  sketches and as one call from the database files -- then distance QC and the lineage models' neighbour matrices.
 
     python examples/quickstart.py [n_genomes] [workdir]          # needs an MI355X
 """
@@ -63,6 +64,23 @@ def main():
     db.close()
     assert np.array_equal(fused, edges), "fused edge list differs"
     print("fused distance -> boundary -> edge list: identical (%d edges), %d failed fits" % (len(fused), n_failed))
+
+    # 6. ... and as ONE call from the database files to a numpy edge list (every GPU in PPK_DEVICES takes a band)
+    from poppunk_amd import pp_sketchlib
+    base = os.path.join(db_prefix, os.path.basename(db_prefix))
+    one_call = pp_sketchlib.queryDatabaseEdges(base, base, names, names, kmers, boundary.slope, x_max, y_max,
+                                               scale=boundary.scale, inclusive=False)
+    assert np.array_equal(one_call, edges), "queryDatabaseEdges differs"
+
+    # 7. QC of the distances (PopPUNK/qc.py:295-369) and the lineage models' neighbour matrices
+    #    (get_kNN_distances -> lowerRank, PopPUNK/models.py:1177,:1215-1222)
+    from poppunk_amd import poppunk_refine, qc
+    kept, failed = qc.qcDistMat(X, names, names, db_prefix, {"max_pi_dist": 0.5, "max_a_dist": 0.6, "prop_zero": 0.05})
+    square = pp_sketchlib.longToSquare(np.ascontiguousarray(X[:, 0]))
+    nn = poppunk_refine.get_kNN_distances(square, 3)
+    rank1 = poppunk_refine.lowerRank(nn, n, 1, False, False, 1e-5)
+    print("distance QC keeps %d of %d samples; rank-3 neighbour matrix %d entries, rank 1 %d"
+          % (len(kept), n, len(nn[0]), len(rank1[0])))
     print("files in", db_prefix)
 
 
