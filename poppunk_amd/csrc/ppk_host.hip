@@ -1532,11 +1532,13 @@ void run_edge_part(EdgePart &p, const int32_t *kmers, const float *random_tbl, s
 }
 }  // namespace
 
-extern "C" int ppk_query_edges_dbs(const ppk_db *const *refs, const ppk_db *const *qrys, int n_dev,
-                                   const int32_t *kmers, const float *random_tbl, size_t n_clu, int flags,
-                                   int slope, float x_max, float y_max, float scale_x, float scale_y,
-                                   int inclusive, long long *ij_out, size_t cap, size_t *n_edges,
-                                   unsigned long long *n_failed) {
+namespace {
+// (the caller holds g_query_mu: one host query at a time, and nothing evicts a cached database in use)
+int query_edges_dbs_locked(const ppk_db *const *refs, const ppk_db *const *qrys, int n_dev,
+                           const int32_t *kmers, const float *random_tbl, size_t n_clu, int flags,
+                           int slope, float x_max, float y_max, float scale_x, float scale_y,
+                           int inclusive, long long *ij_out, size_t cap, size_t *n_edges,
+                           unsigned long long *n_failed) {
   if (n_edges) *n_edges = 0;
   if (n_failed) *n_failed = 0;
   if (!refs || n_dev < 1 || n_dev > 64) return ppk_fail(PPK_ERR_ARG, "ppk_query_edges_dbs: no databases");
@@ -1564,7 +1566,6 @@ extern "C" int ppk_query_edges_dbs(const ppk_db *const *refs, const ppk_db *cons
   std::vector<size_t> bounds((size_t)n_dev + 1, 0);
   int rc = ppk_band_split(n_ref, n_qry, n_dev, bounds.data());
   if (rc != PPK_OK) return rc;
-  std::lock_guard<std::mutex> lk(g_query_mu);
   std::vector<PpkTicket> th;
   for (int d = 0; d < n_dev; ++d) {
     EdgePart &p = parts[(size_t)d];
@@ -1604,6 +1605,18 @@ extern "C" int ppk_query_edges_dbs(const ppk_db *const *refs, const ppk_db *cons
   return PPK_OK;
 }
 
+}  // namespace
+
+extern "C" int ppk_query_edges_dbs(const ppk_db *const *refs, const ppk_db *const *qrys, int n_dev,
+                                   const int32_t *kmers, const float *random_tbl, size_t n_clu, int flags,
+                                   int slope, float x_max, float y_max, float scale_x, float scale_y,
+                                   int inclusive, long long *ij_out, size_t cap, size_t *n_edges,
+                                   unsigned long long *n_failed) {
+  std::lock_guard<std::mutex> lk(g_query_mu);
+  return query_edges_dbs_locked(refs, qrys, n_dev, kmers, random_tbl, n_clu, flags, slope, x_max, y_max, scale_x,
+                                scale_y, inclusive, ij_out, cap, n_edges, n_failed);
+}
+
 extern "C" int ppk_query_edges(const uint64_t *ref_sk, size_t n_ref, const uint64_t *qry_sk, size_t n_qry,
                                const int32_t *kmers, size_t nk, size_t sketchsize64, size_t bbits,
                                const float *random_tbl, const uint16_t *ref_clu, const uint16_t *qry_clu,
@@ -1620,6 +1633,7 @@ extern "C" int ppk_query_edges(const uint64_t *ref_sk, size_t n_ref, const uint6
     n_dev = 1;
   }
   if (n_dev > 64) return ppk_fail(PPK_ERR_ARG, "too many devices");
+  std::lock_guard<std::mutex> lk(g_query_mu);
   // the resident copies: from ppk_query's cache (hash of every word, checked here before anything runs) or uploaded
   const bool use_cache = ppk_config().db_cache.load() != 0;
   const uint64_t ref_fp = use_cache ? fingerprint(ref_sk, n_ref * nk * sketchsize64 * bbits, ref_clu, n_ref) : 0;
@@ -1657,8 +1671,8 @@ extern "C" int ppk_query_edges(const uint64_t *ref_sk, size_t n_ref, const uint6
     }
   }
   if (rc == PPK_OK)
-    rc = ppk_query_edges_dbs(refs.data(), n_qry ? qrys.data() : nullptr, n_dev, kmers, random_tbl, n_clu, flags, slope,
-                             x_max, y_max, scale_x, scale_y, inclusive, ij_out, cap, n_edges, n_failed);
+    rc = query_edges_dbs_locked(refs.data(), n_qry ? qrys.data() : nullptr, n_dev, kmers, random_tbl, n_clu, flags, slope,
+                                x_max, y_max, scale_x, scale_y, inclusive, ij_out, cap, n_edges, n_failed);
   const std::string keep = ppk_error();
   for (ppk_db *db : owned) ppk_db_destroy(db);
   if (rc != PPK_OK) ppk_set_error(keep);
