@@ -422,6 +422,21 @@ int ppk_knn_sketches_dev(const ppk_db *db, const int32_t *kmers, const float *ra
                          size_t n_clu, int flags, int knn, int dist_col, long long *d_i,
                          long long *d_j, float *d_dist, unsigned long long *n_candidates,
                          void *stream);
+
+/* The same as a HOST call on one or several devices: every listed device takes a band of the triangle's rows
+ * (a pair is a candidate for both of its samples, so the bands' per-sample lists merge into the whole job's),
+ * the lists -- knn entries per sample and device -- come to the host and are merged per sample in the
+ * reference's stable order.  Outputs host arrays [n*knn]: i (the sample, repeated), j, dist; a sample with
+ * fewer than knn other samples keeps (i, 0, 0.0) in its last slots as in src/extend.cpp:266-279.
+ *   ppk_query_knn_dbs : dbs[d] = the database resident on device d
+ *   ppk_query_knn     : host sketch array as in ppk_query (resident copies from / into its cache) */
+int ppk_query_knn_dbs(const ppk_db *const *dbs, int n_dev, const int32_t *kmers, const float *random_tbl,
+                      size_t n_clu, int flags, int knn, int dist_col, long long *i_out,
+                      long long *j_out, float *d_out);
+int ppk_query_knn(const uint64_t *sk, size_t n, const int32_t *kmers, size_t nk, size_t sketchsize64,
+                  size_t bbits, const float *random_tbl, const uint16_t *clu, size_t n_clu, int flags,
+                  int knn, int dist_col, const int *devices, int n_dev, long long *i_out,
+                  long long *j_out, float *d_out);
 /* The same in two pieces, for N GPUs (engine.knn_sharded): every rank emits the neighbour candidates of
  * its band of query rows [q_begin, q_end) -- (sample, distance bits << 32 | other sample) for BOTH
  * samples of each pair in the band -- into d_keys / d_vals (capacity `cap`; *n_candidates (host) gets

@@ -600,12 +600,15 @@ extern "C" int ppk_dist_edges_dev(const ppk_db *ref, const ppk_db *qry, const in
 // neighbour candidates under per-sample bounds (ppk_dist.hip MODE_KNN), a sort by sample and a per-sample
 // selection finish (ppk_square.hip).  The upper triangle is compared ONCE and neither the n x n matrix
 // nor the [n_pairs, 2] matrix ever exists: memory is the sketches + a few dozen candidates per sample.
-extern "C" int ppk_knn_sketches_dev(const ppk_db *db, const int32_t *kmers, const float *random_tbl,
-                                    size_t n_clu, int flags, int knn, int dist_col, long long *d_i,
-                                    long long *d_j, float *d_dist, unsigned long long *n_candidates,
-                                    void *stream) {
+// [q_begin, q_end): the band of the triangle's rows this call compares -- a pair belongs to the band of its
+// smaller sample and is a candidate for both of its samples, so the per-sample lists of several bands (several
+// devices) merge into the whole job's.  missing_j: what an unfilled slot gets as j (0: the reference's filler;
+// -1: a mark the merge can see).
+int ppk_knn_band_dev(const ppk_db *db, const int32_t *kmers, const float *random_tbl, size_t n_clu, int flags,
+                     int knn, int dist_col, size_t q_begin, size_t q_end, long long missing_j, long long *d_i,
+                     long long *d_j, float *d_dist, unsigned long long *n_candidates, void *stream) {
   if (n_candidates) *n_candidates = 0;
-  int rc = ppk_check_pair(db, nullptr, kmers, 0, db ? db->n : 0);
+  int rc = ppk_check_pair(db, nullptr, kmers, q_begin, q_end);
   if (rc != PPK_OK) return rc;
   if (knn < 1 || knn > 32) return ppk_fail(PPK_ERR_ARG, "knn must be in [1, 32]");
   if (dist_col != 0 && dist_col != 1) return ppk_fail(PPK_ERR_ARG, "dist_col must be 0 (core) or 1 (accessory)");
@@ -673,8 +676,8 @@ extern "C" int ppk_knn_sketches_dev(const ppk_db *db, const int32_t *kmers, cons
   unsigned long long count = 0;
   size_t piece = ppk_rows_per_dispatch(db);
   bool tables_built = lut_ready;
-  for (size_t lo = 0; lo < n && n > 1;) {
-    const size_t hi = lo + piece < n ? lo + piece : n;
+  for (size_t lo = q_begin; lo < q_end && n > 1;) {
+    const size_t hi = lo + piece < q_end ? lo + piece : q_end;
     const unsigned long long before = count;
     rc = ppk_launch_dist(db, nullptr, kmers, d_rtab, d_rtab ? n_clu : 1, flags, lo, hi, d_cand, nullptr,
                          static_cast<uint64_t *>(d_state), 2, 0.f, 0.f, 1.f, 1.f, 1, d_lut, s, knn_args, tables_built);
@@ -708,14 +711,22 @@ extern "C" int ppk_knn_sketches_dev(const ppk_db *db, const int32_t *kmers, cons
       continue;
     }
     lo = hi;
-    if (lo < n && count > cap / 2 && count > n * (unsigned long long)knn) {
+    if (lo < q_end && count > cap / 2 && count > n * (unsigned long long)knn) {
       rc = ppk_knn_compact(db->device, keys(), vals(), (size_t)count, n, knn, d_state, d_i, d_j, d_dist, s);
       if (rc != PPK_OK) return rc;
       count = n * (unsigned long long)knn;
     }
   }
   if (n_candidates) *n_candidates = count;
-  return ppk_knn_from_candidates(db->device, keys(), vals(), (size_t)count, n, knn, d_i, d_j, d_dist, s);
+  return ppk_knn_from_candidates(db->device, keys(), vals(), (size_t)count, n, knn, d_i, d_j, d_dist, s, missing_j);
+}
+
+extern "C" int ppk_knn_sketches_dev(const ppk_db *db, const int32_t *kmers, const float *random_tbl,
+                                    size_t n_clu, int flags, int knn, int dist_col, long long *d_i,
+                                    long long *d_j, float *d_dist, unsigned long long *n_candidates,
+                                    void *stream) {
+  return ppk_knn_band_dev(db, kmers, random_tbl, n_clu, flags, knn, dist_col, 0, db ? db->n : 0, 0, d_i, d_j, d_dist,
+                          n_candidates, stream);
 }
 
 // The two halves of the above for N GPUs: each rank emits the candidates of ITS band of query rows

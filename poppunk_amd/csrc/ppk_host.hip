@@ -1678,3 +1678,190 @@ extern "C" int ppk_query_edges(const uint64_t *ref_sk, size_t n_ref, const uint6
   if (rc != PPK_OK) ppk_set_error(keep);
   return rc;
 }
+
+// ---- host entry: sketches -> k nearest neighbours of every sample, on one or several devices -------------
+// What get_kNN_distances(longToSquare(queryDatabase(...)[:, dist_col]), kNN) gives (PopPUNK/models.py:
+// 1215-1222), with neither matrix: every listed device takes a band of the triangle's rows
+// (ppk_knn_band_dev: candidates from the tiles, best knn per sample of ITS band), the per-device lists come
+// to the host (knn entries per sample and device) and are merged per sample by (distance bits, neighbour) --
+// the reference's stable order (src/extend.cpp:266-279).
+namespace {
+struct KnnPart {
+  int device = 0, dup = 0;
+  const ppk_db *db = nullptr;
+  size_t q_begin = 0, q_end = 0;
+  std::vector<long long> j;
+  std::vector<float> d;
+  int rc = PPK_OK;
+  std::string err;
+};
+
+void run_knn_part(KnnPart &p, const int32_t *kmers, const float *random_tbl, size_t n_clu, int flags, int knn,
+                  int dist_col, long long missing_j) {
+  auto fail = [&](int code) {
+    p.rc = code;
+    p.err = ppk_error();
+  };
+  DeviceGuard g(p.device);
+  if (!g.ok) {
+    ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(p.device));
+    return fail(PPK_ERR_HIP);
+  }
+  hipStream_t ws[2] = {nullptr, nullptr};
+  int rc = part_streams(p.device, p.dup, ws);
+  if (rc != PPK_OK) return fail(rc);
+  const size_t m = p.db->n * (size_t)knn;
+  long long *d_i = nullptr, *d_j = nullptr;
+  float *d_d = nullptr;
+  auto done = [&](int code) {
+    if (d_i) (void)hipFree(d_i);
+    if (d_j) (void)hipFree(d_j);
+    if (d_d) (void)hipFree(d_d);
+    if (code != PPK_OK) fail(code);
+  };
+  if (hipMalloc(reinterpret_cast<void **>(&d_i), m * 8) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&d_j), m * 8) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void **>(&d_d), m * 4) != hipSuccess)
+    return done(ppk_fail(PPK_ERR_HIP, "hipMalloc(neighbour lists) failed"));
+  rc = ppk_knn_band_dev(p.db, kmers, random_tbl, n_clu, flags, knn, dist_col, p.q_begin, p.q_end, missing_j, d_i, d_j,
+                        d_d, nullptr, ws[0]);
+  if (rc != PPK_OK) return done(rc);
+  p.j.resize(m);
+  p.d.resize(m);
+  if (hipStreamSynchronize(ws[0]) != hipSuccess || hipMemcpy(p.j.data(), d_j, m * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(p.d.data(), d_d, m * 4, hipMemcpyDeviceToHost) != hipSuccess)
+    return done(ppk_fail(PPK_ERR_HIP, "neighbour lists: execution or download failed"));
+  done(PPK_OK);
+}
+
+int query_knn_dbs_locked(const ppk_db *const *dbs, int n_dev, const int32_t *kmers, const float *random_tbl,
+                         size_t n_clu, int flags, int knn, int dist_col, long long *i_out, long long *j_out,
+                         float *d_out) {
+  if (!dbs || n_dev < 1 || n_dev > 64) return ppk_fail(PPK_ERR_ARG, "ppk_query_knn_dbs: no databases");
+  if (knn < 1 || knn > 32) return ppk_fail(PPK_ERR_ARG, "knn must be in [1, 32]");
+  if (!i_out || !j_out || !d_out) return ppk_fail(PPK_ERR_ARG, "NULL output");
+  std::vector<KnnPart> parts((size_t)n_dev);
+  for (int d = 0; d < n_dev; ++d) {
+    if (!dbs[d]) return ppk_fail(PPK_ERR_ARG, "ppk_query_knn_dbs: a database is missing for some device");
+    if (dbs[d]->n != dbs[0]->n || dbs[d]->nk != dbs[0]->nk || dbs[d]->s64 != dbs[0]->s64 || dbs[d]->bbits != dbs[0]->bbits)
+      return ppk_fail(PPK_ERR_ARG, "ppk_query_knn_dbs: the per-device databases differ in shape");
+    KnnPart &p = parts[(size_t)d];
+    p.device = dbs[d]->device;
+    for (int e = 0; e < d; ++e) p.dup += parts[(size_t)e].device == p.device;
+    if (p.dup >= kMaxDup) return ppk_fail(PPK_ERR_ARG, "a device may be listed at most 4 times");
+    if (int rc = ppk_check_arch(p.device)) return rc;
+    p.db = dbs[d];
+  }
+  const size_t n = dbs[0]->n;
+  std::vector<size_t> bounds((size_t)n_dev + 1, 0);
+  int rc = ppk_band_split(n, 0, n_dev, bounds.data());
+  if (rc != PPK_OK) return rc;
+  std::vector<PpkTicket> th;
+  for (int d = 0; d < n_dev; ++d) {
+    KnnPart &p = parts[(size_t)d];
+    p.q_begin = bounds[(size_t)d];
+    p.q_end = bounds[(size_t)d + 1];
+    auto work = [&p, kmers, random_tbl, n_clu, flags, knn, dist_col, n_dev]() {
+      run_knn_part(p, kmers, random_tbl, n_clu, flags, knn, dist_col, n_dev == 1 ? 0 : -1);
+    };
+    if (n_dev == 1) work();
+    else th.push_back(ppk_pool_run(work));
+  }
+  for (auto &t : th) ppk_pool_wait(t);
+  for (KnnPart &p : parts)
+    if (p.rc != PPK_OK) return ppk_fail(p.rc, p.err);
+  const size_t k = (size_t)knn;
+  if (n_dev == 1) {
+    for (size_t e = 0; e < n * k; ++e) i_out[e] = (long long)(e / k);
+    memcpy(j_out, parts[0].j.data(), n * k * 8);
+    memcpy(d_out, parts[0].d.data(), n * k * 4);
+    return PPK_OK;
+  }
+  // merge: a sample's true neighbours are among the best knn of every band's list
+  auto merge = [&](size_t lo, size_t hi) {
+    std::vector<uint64_t> keys;
+    keys.reserve((size_t)n_dev * k);
+    for (size_t i = lo; i < hi; ++i) {
+      keys.clear();
+      for (const KnnPart &p : parts)
+        for (size_t r = 0; r < k; ++r) {
+          const long long j = p.j[i * k + r];
+          if (j < 0) break;                       // a band's list is filled from the front
+          uint32_t bits;
+          memcpy(&bits, &p.d[i * k + r], 4);
+          keys.push_back(((uint64_t)bits << 32) | (uint32_t)j);
+        }
+      const size_t take = keys.size() < k ? keys.size() : k;
+      std::partial_sort(keys.begin(), keys.begin() + (long)take, keys.end());
+      for (size_t r = 0; r < k; ++r) {
+        i_out[i * k + r] = (long long)i;
+        if (r < take) {
+          const uint32_t bits = (uint32_t)(keys[r] >> 32);
+          j_out[i * k + r] = (long long)(keys[r] & 0xffffffffull);
+          memcpy(&d_out[i * k + r], &bits, 4);
+        } else {                                   // fewer than knn other samples: the reference's filler
+          j_out[i * k + r] = 0;
+          d_out[i * k + r] = 0.0f;
+        }
+      }
+    }
+  };
+  const size_t n_chunks = n > 65536 ? 8 : 1;
+  std::vector<PpkTicket> mt;
+  for (size_t c = 1; c < n_chunks; ++c)
+    mt.push_back(ppk_pool_run([&merge, c, n, n_chunks]() { merge(n * c / n_chunks, n * (c + 1) / n_chunks); }));
+  merge(0, n / n_chunks);
+  for (auto &t : mt) ppk_pool_wait(t);
+  return PPK_OK;
+}
+}  // namespace
+
+extern "C" int ppk_query_knn_dbs(const ppk_db *const *dbs, int n_dev, const int32_t *kmers, const float *random_tbl,
+                                 size_t n_clu, int flags, int knn, int dist_col, long long *i_out,
+                                 long long *j_out, float *d_out) {
+  std::lock_guard<std::mutex> lk(g_query_mu);
+  return query_knn_dbs_locked(dbs, n_dev, kmers, random_tbl, n_clu, flags, knn, dist_col, i_out, j_out, d_out);
+}
+
+extern "C" int ppk_query_knn(const uint64_t *sk, size_t n, const int32_t *kmers, size_t nk, size_t sketchsize64,
+                             size_t bbits, const float *random_tbl, const uint16_t *clu, size_t n_clu, int flags,
+                             int knn, int dist_col, const int *devices, int n_dev, long long *i_out,
+                             long long *j_out, float *d_out) {
+  if (!sk || !kmers || n == 0 || nk == 0) return ppk_fail(PPK_ERR_ARG, "ppk_query_knn: missing sketches / kmers");
+  const int default_dev = 0;
+  if (!devices || n_dev < 1) {
+    devices = &default_dev;
+    n_dev = 1;
+  }
+  if (n_dev > 64) return ppk_fail(PPK_ERR_ARG, "too many devices");
+  std::lock_guard<std::mutex> lk(g_query_mu);
+  const bool use_cache = ppk_config().db_cache.load() != 0;
+  const uint64_t fp = use_cache ? fingerprint(sk, n * nk * sketchsize64 * bbits, clu, n) : 0;
+  std::vector<const ppk_db *> dbs((size_t)n_dev, nullptr);
+  std::vector<ppk_db *> owned;
+  int rc = PPK_OK;
+  for (int d = 0; d < n_dev && rc == PPK_OK; ++d) {
+    int first = -1;
+    for (int e = 0; e < d && first < 0; ++e)
+      if (devices[e] == devices[d]) first = e;
+    if (first >= 0) {
+      dbs[(size_t)d] = dbs[(size_t)first];
+      continue;
+    }
+    if (devices[d] < 0 || devices[d] >= 64) {
+      rc = ppk_fail(PPK_ERR_ARG, "device id out of range");
+      break;
+    }
+    ppk_db *db = nullptr;
+    bool own = false;
+    rc = db_acquire(devices[d], sk, n, nk, sketchsize64, bbits, clu, fp, use_cache, nullptr, nullptr, &db, &own);
+    if (rc != PPK_OK) break;
+    dbs[(size_t)d] = db;
+    if (own) owned.push_back(db);
+  }
+  if (rc == PPK_OK)
+    rc = query_knn_dbs_locked(dbs.data(), n_dev, kmers, random_tbl, n_clu, flags, knn, dist_col, i_out, j_out, d_out);
+  const std::string keep = ppk_error();
+  for (ppk_db *db : owned) ppk_db_destroy(db);
+  if (rc != PPK_OK) ppk_set_error(keep);
+  return rc;
+}

@@ -470,6 +470,78 @@ def queryDatabaseEdges(ref_db_name, query_db_name, rList, qList, klist, slope, x
     return edges
 
 
+def query_knn_entries(entry, klist, kNN, dist_col=0, random_table=None, clusters=None, random_correct=True,
+                      devices=(0,)):
+    """ppk_query_knn_dbs on a loaded database (`_Entry`) -> (i, j, dist) arrays of length n * kNN."""
+    lib = _lib.lib()
+    n, nk, _ = entry.loaded.sketches.shape
+    kmers = np.ascontiguousarray(klist, dtype=np.int32).ravel()
+    if kmers.size != nk:
+        raise RuntimeError("klist does not match the sketches")
+    k = int(kNN)
+    oi, oj, od = (np.zeros(n * max(k, 0), dtype=np.int64), np.zeros(n * max(k, 0), dtype=np.int64),
+                  np.zeros(n * max(k, 0), dtype=np.float32))
+    if n == 0 or k <= 0:
+        return oi, oj, od
+    tptr, n_clu, clu, _, keep = _table_args(random_table, random_correct, clusters, None, False)
+    devices = [int(d) for d in devices]
+    handles = entry.resident(devices, clu)
+    dbs = (C.c_void_p * len(devices))(*[h.value for h in handles])
+    ll = C.POINTER(C.c_longlong)
+    rc = lib.ppk_query_knn_dbs(dbs, len(devices), kmers.ctypes.data_as(C.POINTER(C.c_int32)), tptr, n_clu,
+                               _flags(random_correct, False, False), k, int(dist_col), oi.ctypes.data_as(ll),
+                               oj.ctypes.data_as(ll), od.ctypes.data_as(C.POINTER(C.c_float)))
+    del keep
+    _lib.check(rc, "ppk_query_knn_dbs")
+    return oi, oj, od
+
+
+def query_knn_arrays(sk, klist, sketchsize64, bbits, kNN, dist_col=0, random_table=None, clusters=None,
+                     random_correct=True, devices=(0,)):
+    """ppk_query_knn on an in-memory sketch array [n, nk, words] -> (i, j, dist) arrays of length n * kNN."""
+    lib = _lib.lib()
+    sk = np.ascontiguousarray(sk, dtype=np.uint64)
+    n, nk, words = sk.shape
+    if words != sketchsize64 * bbits:
+        raise RuntimeError("sketch word count does not match sketchsize64*bbits")
+    kmers = np.ascontiguousarray(klist, dtype=np.int32).ravel()
+    if kmers.size != nk:
+        raise RuntimeError("klist does not match the sketches")
+    k = int(kNN)
+    oi, oj, od = (np.zeros(n * max(k, 0), dtype=np.int64), np.zeros(n * max(k, 0), dtype=np.int64),
+                  np.zeros(n * max(k, 0), dtype=np.float32))
+    if n == 0 or k <= 0:
+        return oi, oj, od
+    tptr, n_clu, clu, _, keep = _table_args(random_table, random_correct, clusters, None, False)
+    cp = None if clu is None else clu.ctypes.data_as(C.POINTER(C.c_uint16))
+    devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+    ll = C.POINTER(C.c_longlong)
+    rc = lib.ppk_query_knn(sk.ctypes.data_as(C.POINTER(C.c_uint64)), n, kmers.ctypes.data_as(C.POINTER(C.c_int32)), nk,
+                           sketchsize64, bbits, tptr, cp, n_clu, _flags(random_correct, False, False), k, int(dist_col),
+                           devs, len(devices), oi.ctypes.data_as(ll), oj.ctypes.data_as(ll),
+                           od.ctypes.data_as(C.POINTER(C.c_float)))
+    del keep
+    _lib.check(rc, "ppk_query_knn")
+    return oi, oj, od
+
+
+def queryDatabaseKNN(db_name, names, klist, kNN, dist_col=0, random_correct=True, num_threads=1, use_gpu=False,
+                     device_id=0):
+    """The k nearest neighbours of every sample of a database, as (i, j, dist) arrays of length n * kNN: what
+    PopPUNK's lineage models build with queryDatabase -> longToSquare -> poppunk_refine.get_kNN_distances
+    (PopPUNK/models.py:1215-1222), straight from the sketches -- neither the long-form nor the square matrix is
+    ever made, on either side of PCIe.  kNN <= 32; dist_col 0 = core, 1 = accessory.  device_id / PPK_DEVICES as
+    queryDatabase: several devices each take a band of the triangle and the lists are merged.  Not a pp_sketchlib
+    function: the entry point for that chain on collections whose n x n matrix does not fit anywhere."""
+    klist = [int(k) for k in np.asarray(klist).ravel()]
+    names = [str(x) for x in names]
+    ref_e, _, table, clu, _ = _open_query(db_name, db_name, names, names, klist, random_correct)
+    try:
+        return query_knn_entries(ref_e, klist, kNN, dist_col, table, clu, random_correct, _devices(device_id))
+    finally:
+        _close_transient(ref_e)
+
+
 def _f32(a, what):
     a = np.asarray(a)
     if a.dtype != np.float32:

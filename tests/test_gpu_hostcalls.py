@@ -379,3 +379,48 @@ def test_queryDatabaseEdges_mirror(tmp_path, monkeypatch):
     gq = pp_sketchlib.queryDatabaseEdges(db, db, names[:600], names[600:], klist, 2, x_max, y_max, inclusive=True)
     assert len(wq) > 50 and np.array_equal(gq, wq)
     pp_sketchlib.clear_cache()
+
+
+# ---- sketches -> k nearest neighbours as one host call (ppk_query_knn / ppk_query_knn_dbs) -----------------
+
+@pytest.mark.parametrize("devices", [(0,), (0, 0, 0)])
+def test_query_knn_host_call(devices):
+    """Every device takes a band of the triangle, the bands' best-k lists are merged on the host: the result
+    is get_kNN_distances(longToSquare(distances)) whatever the device list -- ties (unrelated clusters: most
+    distances equal) included."""
+    for n, cluster_size, related in ((900, 30, True), (700, 700, False), (5, 5, True)):
+        sk, _ = synth.make_sketches(n, KMERS, cluster_size=cluster_size, seed=n, related=related)
+        tbl = synth.random_match_table(KMERS)
+        dist, _ = pp_sketchlib.query_arrays(sk, None, KMERS, 16, 14, tbl)
+        for knn, col in ((1, 0), (7, 1), (32, 0)):
+            wi, wj, wd = oracle.knn(oracle.long_to_square(dist[:, col]), knn)
+            gi, gj, gd = pp_sketchlib.query_knn_arrays(sk, KMERS, 16, 14, knn, col, tbl, devices=devices)
+            assert np.array_equal(gi, wi) and np.array_equal(gj, wj) and np.array_equal(gd, wd), (n, knn, col)
+    with pytest.raises(RuntimeError, match=r"knn must be in \[1, 32\]"):
+        pp_sketchlib.query_knn_arrays(sk, KMERS, 16, 14, 33, 0, tbl, devices=devices)
+
+
+def test_queryDatabaseKNN_mirror(tmp_path, monkeypatch):
+    from poppunk_amd import sketchdb
+    sk, _ = synth.make_sketches(600, KMERS, cluster_size=24, seed=41)
+    tbl = synth.random_match_table(KMERS)
+    names = ["k%04d" % i for i in range(600)]
+    db = str(tmp_path / "db")
+    sketchdb.save_npz(db, names, KMERS, sk, 16, 14, random_table=tbl)
+    pp_sketchlib.clear_cache()
+    klist = KMERS.tolist()
+    dist = pp_sketchlib.queryDatabase(db, db, names, names, klist, True, False, 1, True, 0)
+    want = poppunk_refine.get_kNN_distances(pp_sketchlib.longToSquare(np.ascontiguousarray(dist[:, 0])), 4)
+    for env in (None, "0,0"):
+        if env:
+            monkeypatch.setenv("PPK_DEVICES", env)
+        i, j, d = pp_sketchlib.queryDatabaseKNN(db, names, klist, 4)
+        assert i.tolist() == list(want[0]) and j.tolist() == list(want[1])
+        assert np.array_equal(d, np.asarray(want[2], dtype=np.float32))
+    # a subset of the database (names in another order): neighbours within the subset
+    sub = names[100:400][::-1]
+    ds = pp_sketchlib.queryDatabase(db, db, sub, sub, klist, True, False, 1, True, 0)
+    ws = oracle.knn(oracle.long_to_square(ds[:, 1]), 3)
+    i, j, d = pp_sketchlib.queryDatabaseKNN(db, sub, klist, 3, dist_col=1)
+    assert np.array_equal(j, ws[1]) and np.array_equal(d, ws[2])
+    pp_sketchlib.clear_cache()
