@@ -155,3 +155,49 @@ def test_sparse_fuzz():
               oracle.lower_rank(*want, n, k2, recip, unique, eps))
         _same(poppunk_refine.lowerRank_arrays((ri, rj, rd), n_ref, k2, recip, unique, eps),
               oracle.lower_rank(ri, rj, rd, n_ref, k2, recip, unique, eps))
+
+
+def test_lineage_ranks_from_distances_from_sketches_and_extended(tmp_path):
+    """poppunk_amd.models.LineageRanks: the matrices of LineageFit.fit (PopPUNK/models.py:1188-1237) from a
+    distance matrix, the same straight from the sketches, then queries added (models.py:1334-1385); each
+    compared with the composition of the oracle's pieces."""
+    from poppunk_amd import models, pp_sketchlib, sketchdb, synth
+    kmers = np.asarray(synth.DEFAULT_KMERS, dtype=np.int32)
+    sk, _ = synth.make_sketches(420, kmers, cluster_size=30, seed=3)
+    tbl = synth.random_match_table(kmers)
+    names = ["n%03d" % i for i in range(420)]
+    db = str(tmp_path / "db")
+    sketchdb.save_npz(db, names, kmers, sk, 16, 14, random_table=tbl)
+    pp_sketchlib.clear_cache()
+    n_ref = 300
+    X = pp_sketchlib.queryDatabase(db, db, names[:n_ref], names[:n_ref], kmers.tolist(), True, False, 1, True, 0)
+    for recip, unique in ((False, False), (True, True)):
+        a = models.LineageRanks([1, 2, 3], 4, recip, unique, 1e-4, dist_col=1)
+        y = a.fit(X)
+        b = models.LineageRanks([1, 2, 3], 4, recip, unique, 1e-4, dist_col=1)
+        assert b.fit_from_database(db, names[:n_ref], kmers.tolist()) == y
+        depth = a.max_search_depth
+        assert depth == 8
+        oi, oj, od = oracle.knn(oracle.long_to_square(X[:, 1]), depth)
+        for m in (a, b):
+            assert np.array_equal(m.nn_dists.row, oi) and np.array_equal(m.nn_dists.col, oj)
+            assert np.array_equal(m.nn_dists.data, np.maximum(od, np.float32(1e-10)))
+            for rank in (1, 2, 3):
+                wi, wj, wd = oracle.lower_rank(oi, oj, od, n_ref, rank, recip, unique, 1e-4)
+                lr = m.lower_rank_dists[rank]
+                assert np.array_equal(lr.row, wi) and np.array_equal(lr.col, wj)
+                assert np.array_equal(lr.data, np.maximum(wd, np.float32(1e-10)))
+            assert m.assign(1) == list(zip(m.lower_rank_dists[1].row.tolist(), m.lower_rank_dists[1].col.tolist()))
+        # queries join the fitted model
+        qq = pp_sketchlib.queryDatabase(db, db, names[n_ref:], names[n_ref:], kmers.tolist(), True, False, 1, True, 0)
+        qr = pp_sketchlib.queryDatabase(db, db, names[:n_ref], names[n_ref:], kmers.tolist(), True, False, 1, True, 0)
+        a.extend(qq, qr)
+        floor = np.float32(1e-10)
+        qq_sq = np.maximum(oracle.long_to_square(qq[:, 1]), floor)
+        qr_rect = np.maximum(qr[:, 1].reshape(120, n_ref).T, floor)
+        ei, ej, ed = oracle.extend(oi, oj, np.maximum(od, floor), qq_sq, qr_rect, depth)
+        assert np.array_equal(a.nn_dists.row, ei) and np.array_equal(a.nn_dists.col, ej)
+        assert np.array_equal(a.nn_dists.data, np.maximum(ed, floor))
+        wi, wj, wd = oracle.lower_rank(ei, ej, ed, 420, 2, recip, unique, 1e-4)
+        assert np.array_equal(a.lower_rank_dists[2].row, wi) and np.array_equal(a.lower_rank_dists[2].data, np.maximum(wd, floor))
+    pp_sketchlib.clear_cache()
