@@ -644,12 +644,16 @@ int ppk_knn_band_dev(const ppk_db *db, const int32_t *kmers, const float *random
   if (cap == 0) cap = 1;
   const size_t sort_limit = (size_t)0x7fffffff - 1024;             // one radix sort takes fewer than 2^31 items
   if (cap > sort_limit) cap = sort_limit;
-  if (const long long want = ppk_config().knn_list.load(); want > 0) {      // (tests: a short list, many selections)
-    cap = (size_t)want;
-    if (cap < 2 * n * (size_t)knn + 4096) cap = 2 * n * (size_t)knn + 4096;
-    if (cap > sort_limit) cap = sort_limit;
-  }
-  if (n * (size_t)knn * 2 > sort_limit) return ppk_fail(PPK_ERR_ARG, "neighbours from tiles: n * knn must stay below 2^30");
+  if (const long long want = ppk_config().knn_list.load(); want > 0) cap = (size_t)want;   // (tests: a short list)
+  // the least a list must hold: the best knn per sample (what a cut leaves) plus what the smallest piece -- 64
+  // query rows, two tiles per 256 refs -- can emit when no bound filters anything (all distances equal):
+  // 32 * knn for its queries and 2 * 256 * knn for its refs per tile, 4.25 n knn in all
+  const size_t floor_entries = 6 * n * (size_t)knn + 8192;
+  if (floor_entries > sort_limit) return ppk_fail(PPK_ERR_ARG, "neighbours from tiles: 6 * n * knn must stay below 2^31");
+  if (cap < floor_entries) cap = floor_entries;
+  if (cap > all) cap = all;
+  if (cap > sort_limit) cap = sort_limit;
+  if (cap == 0) cap = 1;
   const int knn_args[2] = {knn, dist_col};
   void *d_cand = nullptr;
   size_t vals_off = 0;

@@ -15,6 +15,9 @@ def reset_options():
     _lib.set_option("ext_collision_adjust", 0)
     _lib.set_option("ext_fit_skip", 0)
     _lib.set_option("ksplit", 215)
+    _lib.set_option("launch_tiles", 8000000)
+    _lib.set_option("knn_list", 0)
+    _lib.set_option("chunk_rows", 8 << 20)
     oracle.set_ext(0, 0)
 
 
@@ -36,6 +39,12 @@ def soak_case(rng, big=False):
         _lib.set_option("ksplit", 0)
     else:
         _lib.set_option("ksplit", 640)
+    # a quarter of the cases run as a very large job would: a few tiles per launch, a short neighbour-candidate
+    # list, small pieces in the fused host call
+    tiny = rng.integers(0, 4) == 0
+    _lib.set_option("launch_tiles", int(rng.integers(2, 40)) if tiny else 8000000)
+    _lib.set_option("knn_list", int(rng.integers(1, 1 << 16)) if tiny else 0)
+    _lib.set_option("chunk_rows", int(rng.integers(16, 4096)) if tiny else 8 << 20)
     ext = (int(rng.integers(0, 2)), int(rng.integers(0, 2))) if rng.integers(0, 3) == 0 else (0, 0)
     _lib.set_option("ext_collision_adjust", ext[0])
     _lib.set_option("ext_fit_skip", ext[1])
@@ -126,6 +135,6 @@ def soak_case(rng, big=False):
             dbq.close()
     except Exception as e:  # noqa: BLE001
         msgs.append("EXCEPTION %r" % (e,))
-    desc = ("bbits=%2d s64=%2d nk=%d n=%4d nr=%4d clu=%d tbl=%d related=%d ext=%d%d"
-            % (bbits, s64, nk, n, nr, n_clu, use_tbl, related, ext[0], ext[1]))
+    desc = ("bbits=%2d s64=%2d nk=%d n=%4d nr=%4d clu=%d tbl=%d related=%d ext=%d%d tiny=%d"
+            % (bbits, s64, nk, n, nr, n_clu, use_tbl, related, ext[0], ext[1], int(tiny)))
     return desc, msgs
