@@ -242,6 +242,36 @@ def test_pin_kit_runs_its_own_half_without_upstream(tmp_path):
     assert "our two readings differ on 6 of 66 rows" in r.stdout      # the gap pairs tell truncate from skip
 
 
+def test_pin_kit_compares_the_refine_extension_function_by_function(tmp_path):
+    """The kit's first step compares upstream `poppunk_refine` with the mirrors.  Upstream is absent here, so a
+    stand-in of that name built on the oracle is put on the path: the step must find it, run all of its
+    comparisons (ties everywhere in its inputs) and report every function identical."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    (tmp_path / "poppunk_refine.py").write_text('''
+import numpy as np
+from oracle import oracle as o
+def _t(e): return [tuple(r) for r in np.asarray(e).reshape(-1, 2).tolist()]
+def _l(t): return tuple(np.asarray(x).tolist() for x in t)
+def assignThreshold(d, slope, x, y, num_threads=1): return o.assign_threshold(d, slope, x, y)
+def edgeThreshold(d, slope, x, y): return _t(o.edge_threshold(d, slope, x, y))
+def generateTuples(a, label, self=True, num_ref=0, int_offset=0): return _t(o.generate_tuples(a, label, self, num_ref, int_offset))
+def generateAllTuples(num_ref, num_queries=0, self=True, int_offset=0): return _t(o.generate_all_tuples(num_ref, num_queries, self, int_offset))
+def thresholdIterate1D(d, offsets, slope, x0, y0, x1, y1, num_threads=1): return _l(o.threshold_iterate_1d(d, offsets, slope, x0, y0, x1, y1))
+def thresholdIterate2D(d, x_max, y_max): return _l(o.threshold_iterate_2d(d, x_max, y_max))
+def get_kNN_distances(sq, k, dist_col=0, num_threads=1): return _l(o.knn(sq, k))
+def lowerRank(m, n, k, recip, unique, eps, num_threads=1): return _l(o.lower_rank(m[0], m[1], m[2], n, k, recip, unique, eps))
+def extend(m, qq, qr, k, num_threads=1): return _l(o.extend(m[0], m[1], m[2], qq, qr, k))
+''')
+    env = dict(os.environ, PYTHONPATH=str(tmp_path) + os.pathsep + root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "pin_upstream.py")], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert "every function identical" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("identical") >= 25 and "DIFFERS" not in r.stdout
+    assert r.returncode == 2          # pp_sketchlib itself is still absent: kernel 1 stays unpinned
+
+
 @pytest.mark.parametrize("n,threads", [(460, 8), (3750, 8), (3750, 3), (7200, 16), (3750, 0)])
 def test_staged_uploads_of_pageable_arrays(ppk_option, n, threads):
     """Host arrays reach the device through a pinned ring filled by helper threads (32 MB pieces, two slots):

@@ -20,6 +20,9 @@ algorithm, and every reading that could not be checked sits behind a switch.  Wh
      shapes, dtypes, attributes), maps it with sketchdb.random_from_raw, and compares
      random_correct=True results.
 
+  0. (first) compares every function of the reference's own compiled extension `poppunk_refine` with this
+     package's mirror, where that module is installed -- the pin of extend / lowerRank / generateAllTuples.
+
     python tools/pin_upstream.py [--out DIR] [--keep] [--device N] [--ours-only]
 
 Exit status 0 = every row settled in favour of the defaults, 1 = some default differs from
@@ -93,6 +96,66 @@ def compare(name, up, mine_by_setting, tol):
     return hit
 
 
+def pin_refine():
+    """The reference's OWN compiled extension, `poppunk_refine` (src/python_bindings.cpp:76-129), function by
+    function against this package's mirrors on seeded inputs -- ties everywhere, where order is the content.
+    Kernel 2 proper is pinned in the test-suite by reference-made goldens; `extend`, `lowerRank` and
+    `generateAllTuples` are restated by reading only (extend.cpp does not build without Eigen), so this is their
+    pin.  Returns the number of functions that differ, or None when the upstream module is absent."""
+    try:
+        import poppunk_refine as up
+        if "poppunk_amd" in (getattr(up, "__file__", "") or ""):
+            raise ImportError("the module named poppunk_refine on sys.path is this package's mirror")
+    except ImportError as e:
+        log("poppunk_refine (upstream) is not importable here: %s -- extend / lowerRank / generateAllTuples stay unpinned" % e)
+        return None
+    from poppunk_amd import poppunk_refine as mine
+    log("\nupstream poppunk_refine at %s" % up.__file__)
+    rng = np.random.Generator(np.random.PCG64(20260928))
+    bad = 0
+
+    def check(name, a, b):
+        nonlocal bad
+        same = (len(a) == len(b)) and all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(a, b)) \
+            if isinstance(a, tuple) else np.array_equal(np.asarray(a), np.asarray(b))
+        log("  %-22s %s" % (name, "identical" if same else "DIFFERS"))
+        bad += not same
+
+    n = 120
+    dist = np.stack([rng.integers(0, 9, n * (n - 1) // 2) / np.float32(16), rng.integers(0, 9, n * (n - 1) // 2) / np.float32(16)],
+                    axis=1).astype(np.float32)
+    for slope in (0, 1, 2):
+        check("assignThreshold/%d" % slope, up.assignThreshold(dist, slope, 0.25, 0.3, 2), mine.assignThreshold(dist, slope, 0.25, 0.3, 2))
+        check("edgeThreshold/%d" % slope, up.edgeThreshold(dist, slope, 0.25, 0.3), mine.edgeThreshold(dist, slope, 0.25, 0.3))
+    assign = rng.integers(-1, 2, len(dist)).astype(np.int32)
+    check("generateTuples self", up.generateTuples(assign.tolist(), -1), mine.generateTuples(assign.tolist(), -1))
+    check("generateTuples ref x q", up.generateTuples(assign[:600].tolist(), 1, self=False, num_ref=30, int_offset=4),
+          mine.generateTuples(assign[:600].tolist(), 1, self=False, num_ref=30, int_offset=4))
+    for args in ((17, 0, True, 0), (17, 0, True, 5), (6, 9, False, 0), (9, 6, False, 3)):
+        check("generateAllTuples%r" % (args,), up.generateAllTuples(*args), mine.generateAllTuples(*args))
+    offsets = np.linspace(-0.2, 0.4, 13).tolist()
+    for slope in (0, 1, 2):
+        check("thresholdIterate1D/%d" % slope, tuple(up.thresholdIterate1D(dist, offsets, slope, 0.1, 0.1, 0.4, 0.5, 2)),
+              tuple(mine.thresholdIterate1D(dist, offsets, slope, 0.1, 0.1, 0.4, 0.5, 2)))
+    check("thresholdIterate2D", tuple(up.thresholdIterate2D(dist, np.linspace(0.05, 0.5, 9).tolist(), 0.3)),
+          tuple(mine.thresholdIterate2D(dist, np.linspace(0.05, 0.5, 9).tolist(), 0.3)))
+    sq = rng.integers(1, 7, (n, n)).astype(np.float32) / np.float32(32)
+    sq = np.triu(sq, 1) + np.triu(sq, 1).T
+    knn = tuple(up.get_kNN_distances(sq, 8, 0, 2))
+    check("get_kNN_distances", knn, tuple(mine.get_kNN_distances(sq, 8, 0, 2)))
+    for rank, recip, unique, eps in ((1, False, False, 1e-5), (3, True, False, 1e-5), (2, False, True, 0.04), (3, True, True, 0.02)):
+        check("lowerRank r%d recip=%d unique=%d" % (rank, recip, unique), tuple(up.lowerRank(knn, n, rank, recip, unique, eps, 2)),
+              tuple(mine.lowerRank(knn, n, rank, recip, unique, eps, 2)))
+    nq = 25
+    qq = rng.integers(1, 7, (nq, nq)).astype(np.float32) / np.float32(32)
+    qq = np.triu(qq, 1) + np.triu(qq, 1).T
+    qr = rng.integers(1, 7, (n, nq)).astype(np.float32) / np.float32(32)
+    for k in (3, 8, 11):
+        check("extend kNN=%d" % k, tuple(up.extend(knn, qq, qr, k, 2)), tuple(mine.extend(knn, qq, qr, k, 2)))
+    log("  => poppunk_refine: %s" % ("every function identical" if bad == 0 else "%d function(s) differ" % bad))
+    return bad
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None, help="directory for the databases (default: a temp dir)")
@@ -100,6 +163,7 @@ def main():
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--ours-only", action="store_true", help="run this package's half even without upstream")
     args = ap.parse_args()
+    refine_bad = pin_refine()
     try:
         import pp_sketchlib as up            # the real thing (NOT poppunk_amd.pp_sketchlib)
         if "poppunk_amd" in (getattr(up, "__file__", "") or ""):
@@ -110,7 +174,7 @@ def main():
         log("pp_sketchlib (upstream) is not importable here: %s" % e)
         log("NOTHING PINNED.  Run this script where pp-sketchlib >= 2.0.1 is installed next to this package.")
         if not args.ours_only:
-            return 2
+            return 1 if refine_bad else 2
     out = args.out or tempfile.mkdtemp(prefix="ppk_pin_")
     os.makedirs(out, exist_ok=True)
     from poppunk_amd import _lib, sketchdb
@@ -226,6 +290,9 @@ def main():
             state = "SETTLED, default stands" if hit == default else ("FLIP to %s" % hit if hit else "UNEXPLAINED")
             log("  row %d  %-62s %s" % (row, what, state))
             rc = max(rc, 0 if hit == default else 1)
+    if refine_bad:
+        log("  poppunk_refine: %d function(s) differ from the upstream extension" % refine_bad)
+        rc = max(rc, 1) if rc != 2 else 1
     if not args.keep and args.out is None:
         shutil.rmtree(out, ignore_errors=True)
     return rc
