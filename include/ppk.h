@@ -377,6 +377,18 @@ int ppk_extend(const long long *rr_i, const long long *rr_j, const float *rr_d, 
                int device_id, long long *i_out, long long *j_out, float *d_out, size_t cap,
                size_t *n_out);
 
+/* poppunk_refine.extend with the sketches in the place of its two dense matrices: `ref` / `qry` are resident
+ * databases on ONE device, the query x reference rectangle and the query square PopPUNK computes for the call
+ * (queryDatabase twice, longToSquare, PopPUNK/models.py:1355-1365) never exist -- the tiles deliver every
+ * reference's kNN nearest queries, every query's kNN nearest references and kNN nearest queries, which is all
+ * extend's merge can keep.  Distances are the kernel's (no 1e-10 floor: apply it to the output, it preserves
+ * the order); rr_* as in ppk_extend; knn <= 32, bbits = 14.  Output as ppk_extend, worst case
+ * kNN * (n_ref + n_qry). */
+int ppk_extend_sketches(const long long *rr_i, const long long *rr_j, const float *rr_d, size_t nnz,
+                        const ppk_db *ref, const ppk_db *qry, const int32_t *kmers, const float *random_tbl,
+                        size_t n_clu, int flags, int knn, int dist_col, long long *i_out, long long *j_out,
+                        float *d_out, size_t cap, size_t *n_out);
+
 /* ------------------------------------------------------------------------
  * Long <-> square distance transforms and k nearest neighbours (SURVEY.md 8f
  * rank 2).  "Long" = condensed upper triangle in PopPUNK row order; element e
@@ -422,6 +434,14 @@ int ppk_knn_sketches_dev(const ppk_db *db, const int32_t *kmers, const float *ra
                          size_t n_clu, int flags, int knn, int dist_col, long long *d_i,
                          long long *d_j, float *d_dist, unsigned long long *n_candidates,
                          void *stream);
+/* The same for a reference x query job, one pass over the rectangle: outputs [(n_ref + n_qry) * knn]; sample
+ * s < n_ref is reference s and its neighbours are its knn nearest QUERIES (numbered n_ref + q), sample n_ref + q
+ * is query q and its neighbours are its knn nearest REFERENCES -- the two dense sides of poppunk_refine.extend's
+ * merge (src/extend.cpp:52-126), see ppk_extend_sketches. */
+int ppk_knn_sketches_rq_dev(const ppk_db *ref, const ppk_db *qry, const int32_t *kmers,
+                            const float *random_tbl, size_t n_clu, int flags, int knn, int dist_col,
+                            long long *d_i, long long *d_j, float *d_dist,
+                            unsigned long long *n_candidates, void *stream);
 
 /* The same as a HOST call on one or several devices: every listed device takes a band of the triangle's rows
  * (a pair is a candidate for both of its samples, so the bands' per-sample lists merge into the whole job's),

@@ -604,21 +604,23 @@ extern "C" int ppk_dist_edges_dev(const ppk_db *ref, const ppk_db *qry, const in
 // smaller sample and is a candidate for both of its samples, so the per-sample lists of several bands (several
 // devices) merge into the whole job's.  missing_j: what an unfilled slot gets as j (0: the reference's filler;
 // -1: a mark the merge can see).
-int ppk_knn_band_dev(const ppk_db *db, const int32_t *kmers, const float *random_tbl, size_t n_clu, int flags,
-                     int knn, int dist_col, size_t q_begin, size_t q_end, long long missing_j, long long *d_i,
+// qry (nullable): a ref x query job -- the samples are the n_ref refs followed by the n_qry queries (sample
+// n_ref + q), every ref's neighbours are queries and every query's are refs; outputs hold (n_ref + n_qry) * knn.
+int ppk_knn_band_dev(const ppk_db *db, const ppk_db *qry, const int32_t *kmers, const float *random_tbl, size_t n_clu,
+                     int flags, int knn, int dist_col, size_t q_begin, size_t q_end, long long missing_j, long long *d_i,
                      long long *d_j, float *d_dist, unsigned long long *n_candidates, void *stream) {
   if (n_candidates) *n_candidates = 0;
-  int rc = ppk_check_pair(db, nullptr, kmers, q_begin, q_end);
+  int rc = ppk_check_pair(db, qry, kmers, q_begin, q_end);
   if (rc != PPK_OK) return rc;
   if (knn < 1 || knn > 32) return ppk_fail(PPK_ERR_ARG, "knn must be in [1, 32]");
   if (dist_col != 0 && dist_col != 1) return ppk_fail(PPK_ERR_ARG, "dist_col must be 0 (core) or 1 (accessory)");
   if (!d_i || !d_j || !d_dist) return ppk_fail(PPK_ERR_ARG, "NULL output buffer");
   if (flags & (PPK_FLAG_JACCARD | PPK_FLAG_COUNTS)) return ppk_fail(PPK_ERR_ARG, "neighbours are taken from distances");
-  if (db->n >= ((size_t)1 << 32)) return ppk_fail(PPK_ERR_ARG, "too many samples");
+  if (db->n + (qry ? qry->n : 0) >= ((size_t)1 << 32)) return ppk_fail(PPK_ERR_ARG, "too many samples");
   DeviceGuard guard(db->device);
   hipStream_t s = static_cast<hipStream_t>(stream);
   PpkCall call(db->device, s);
-  const size_t n = db->n;
+  const size_t n = db->n + (qry ? qry->n : 0);                     // samples with a neighbour list
   double *d_lut = nullptr;
   float *d_rtab = nullptr;
   bool lut_ready = false;
@@ -627,7 +629,7 @@ int ppk_knn_band_dev(const ppk_db *db, const int32_t *kmers, const float *random
   void *d_state = nullptr;
   rc = scratch_get(db->device, SLOT_ITER_A, 3 * sizeof(unsigned long long) + n * 4 + 256, &d_state);
   if (rc != PPK_OK) return rc;
-  const size_t all = n * (n - 1);                                  // two candidates per pair at most
+  const size_t all = qry ? 2 * db->n * qry->n : n * (n - 1);       // two candidates per pair at most
   // Measured (k = 5): ~200 / 530 / 1 000 candidates per sample at 10k / 50k / 100k samples.  A bound is the
   // k-th smallest of ONE tile's candidates (bounds are not merged across tiles: that would need a
   // lock per sample), so it settles near the (k / 256) / (tiles per row) quantile rather than at the
@@ -683,7 +685,7 @@ int ppk_knn_band_dev(const ppk_db *db, const int32_t *kmers, const float *random
   for (size_t lo = q_begin; lo < q_end && n > 1;) {
     const size_t hi = lo + piece < q_end ? lo + piece : q_end;
     const unsigned long long before = count;
-    rc = ppk_launch_dist(db, nullptr, kmers, d_rtab, d_rtab ? n_clu : 1, flags, lo, hi, d_cand, nullptr,
+    rc = ppk_launch_dist(db, qry, kmers, d_rtab, d_rtab ? n_clu : 1, flags, lo, hi, d_cand, nullptr,
                          static_cast<uint64_t *>(d_state), 2, 0.f, 0.f, 1.f, 1.f, 1, d_lut, s, knn_args, tables_built);
     if (rc != PPK_OK) return rc;
     tables_built = true;
@@ -729,7 +731,18 @@ extern "C" int ppk_knn_sketches_dev(const ppk_db *db, const int32_t *kmers, cons
                                     size_t n_clu, int flags, int knn, int dist_col, long long *d_i,
                                     long long *d_j, float *d_dist, unsigned long long *n_candidates,
                                     void *stream) {
-  return ppk_knn_band_dev(db, kmers, random_tbl, n_clu, flags, knn, dist_col, 0, db ? db->n : 0, 0, d_i, d_j, d_dist,
+  return ppk_knn_band_dev(db, nullptr, kmers, random_tbl, n_clu, flags, knn, dist_col, 0, db ? db->n : 0, 0, d_i, d_j,
+                          d_dist, n_candidates, stream);
+}
+
+// ref x query: the knn nearest QUERIES of every reference (samples 0 .. n_ref-1, neighbours numbered n_ref + q)
+// and the knn nearest REFERENCES of every query (samples n_ref + q), from one pass over the rectangle's tiles.
+extern "C" int ppk_knn_sketches_rq_dev(const ppk_db *ref, const ppk_db *qry, const int32_t *kmers,
+                                       const float *random_tbl, size_t n_clu, int flags, int knn, int dist_col,
+                                       long long *d_i, long long *d_j, float *d_dist,
+                                       unsigned long long *n_candidates, void *stream) {
+  if (!qry) return ppk_fail(PPK_ERR_ARG, "ppk_knn_sketches_rq_dev: the query database is missing");
+  return ppk_knn_band_dev(ref, qry, kmers, random_tbl, n_clu, flags, knn, dist_col, 0, qry->n, 0, d_i, d_j, d_dist,
                           n_candidates, stream);
 }
 

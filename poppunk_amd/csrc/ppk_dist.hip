@@ -98,8 +98,9 @@ __device__ __forceinline__ uint32_t pack_get(const PackW<2> &pk, int k, int bits
 
 enum { MODE_DIST = 0, MODE_JACCARD = 1, MODE_COUNTS = 2, MODE_MASK = 3, MODE_KNN = 4 };
 
-// MODE_KNN (k nearest neighbours of every sample of a self job, straight from the tiles): a pair's
-// distance is a CANDIDATE for both of its samples' neighbour lists.  Two filters keep the candidate
+// MODE_KNN (k nearest neighbours of every sample, straight from the tiles; self job: among the other samples,
+// ref x query job: of every query among the refs AND of every ref among the queries, queries numbered
+// n_ref + q): a pair's distance is a CANDIDATE for both of its samples' neighbour lists.  Two filters keep the candidate
 // stream small without ever dropping a true neighbour (keys are (distance bits, other sample):
 // distances are >= 0, so their bits order like the values, and the sample index breaks ties exactly
 // like the reference's stable sort by distance):
@@ -1302,6 +1303,8 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
       uint32_t *lctl = ld + V2_QT * V2_RT;                        // [0] workgroup total, [1..2] its base
       constexpr uint64_t NONE = ~0ull;
       const int knn = p.knn;
+      // ref x query job: refs are samples 0 .. n_ref-1, queries n_ref .. n_ref+n_qry-1, in bounds and candidates alike
+      const size_t koff = p.self ? 0 : p.n_ref;
       // ---- 1. distances to LDS; the wave's own queries: local top-k by rounds of wave-wide minima ----
       if (table_in_lds) __syncthreads();      // every wavefront is done with the (E, F) table that lives there
       if (wave == 0 && lane_late == 0) lctl[0] = 0;
@@ -1322,7 +1325,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
         won[q] = 0xffffffffu;
         cq[q] = 0;
         if (!wave_active || qq < qb || qq >= qe) continue;      // wave-uniform
-        const uint32_t thr_q = __hip_atomic_load(thr + qq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t thr_q = __hip_atomic_load(thr + koff + qq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         uint64_t key[R];
 #pragma unroll
         for (int r = 0; r < R; ++r)
@@ -1350,7 +1353,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
           cq[q] += pass ? 1 : 0;
         }
         // (only when it improves on what was read: once the bounds have settled no atomic is issued)
-        if (round == knn && (uint32_t)(kth >> 32) < thr_q && lane_late == 0) atomicMin(thr + qq, (uint32_t)(kth >> 32));
+        if (round == knn && (uint32_t)(kth >> 32) < thr_q && lane_late == 0) atomicMin(thr + koff + qq, (uint32_t)(kth >> 32));
         c1 += cq[q];
       }
       __syncthreads();
@@ -1404,7 +1407,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
         for (int r = 0; r < R; ++r) {
           const uint32_t rnd = (won[q] >> (8 * r)) & 0xffu;
           if (rnd != 0xffu && pos + rnd < cap) {
-            ckeys[pos + rnd] = (uint32_t)(qw0 + q);
+            ckeys[pos + rnd] = (uint32_t)(koff + qw0 + q);
             cvals[pos + rnd] = ((uint64_t)knn_bits[q][r] << 32) | (uint32_t)ref_of(r);
           }
         }
@@ -1416,7 +1419,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
         if (pass2 & (1u << j)) {
           if (pos < cap) {
             ckeys[pos] = (uint32_t)rf2;
-            cvals[pos] = ((uint64_t)bits2[j] << 32) | (uint32_t)(q0 + qhalf * 16 + j);
+            cvals[pos] = ((uint64_t)bits2[j] << 32) | (uint32_t)(koff + q0 + qhalf * 16 + j);
           }
           ++pos;
         }
@@ -1728,6 +1731,7 @@ int ppk_launch_dist(const ppk_db *ref, const ppk_db *qry_or_null, const int32_t 
   const size_t n_rtiles = (ref->n + 63) / 64;
   for (size_t lo = q_begin; lo < q_end; lo += q_sub) {
     const size_t hi = lo + q_sub < q_end ? lo + q_sub : q_end;
+    if (ppk_rows_in_band(ref->n, n_qry, lo, hi) == 0) continue;      // (the last sample of a self job pairs with nobody)
     void *out = d_out;
     uint64_t *mask = d_mask;
     if (!knn_args) {
@@ -1885,8 +1889,7 @@ static int launch_dist_band(const ppk_db *ref, const ppk_db *qry_or_null, const 
     return PPK_OK;
   }
   if (knn_args) {
-    // d_out: candidate arrays, d_mask: KnnState + bounds (MODE_KNN); self jobs only
-    if (!p.self) return ppk_fail(PPK_ERR_ARG, "neighbours from tiles are defined for a self comparison");
+    // d_out: candidate arrays, d_mask: KnnState + bounds over n_ref (+ n_qry: a ref x query job) samples (MODE_KNN)
     return launch_tiles_packed<MODE_KNN>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
   }
   if (d_mask) return launch_tiles_packed<MODE_MASK>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);

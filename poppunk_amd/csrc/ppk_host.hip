@@ -1722,8 +1722,8 @@ void run_knn_part(KnnPart &p, const int32_t *kmers, const float *random_tbl, siz
   if (hipMalloc(reinterpret_cast<void **>(&d_i), m * 8) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&d_j), m * 8) != hipSuccess ||
       hipMalloc(reinterpret_cast<void **>(&d_d), m * 4) != hipSuccess)
     return done(ppk_fail(PPK_ERR_HIP, "hipMalloc(neighbour lists) failed"));
-  rc = ppk_knn_band_dev(p.db, kmers, random_tbl, n_clu, flags, knn, dist_col, p.q_begin, p.q_end, missing_j, d_i, d_j,
-                        d_d, nullptr, ws[0]);
+  rc = ppk_knn_band_dev(p.db, nullptr, kmers, random_tbl, n_clu, flags, knn, dist_col, p.q_begin, p.q_end, missing_j, d_i,
+                        d_j, d_d, nullptr, ws[0]);
   if (rc != PPK_OK) return done(rc);
   p.j.resize(m);
   p.d.resize(m);
@@ -1864,4 +1864,115 @@ extern "C" int ppk_query_knn(const uint64_t *sk, size_t n, const int32_t *kmers,
   for (ppk_db *db : owned) ppk_db_destroy(db);
   if (rc != PPK_OK) ppk_set_error(keep);
   return rc;
+}
+
+// ---- poppunk_refine.extend without the dense matrices ------------------------------------------------------
+// extend (src/extend.cpp:52-126) merges, per reference, its sparse row with its distances to ALL queries, and
+// per query its distances to ALL references with its row of the query square -- and keeps kNN of them.  The kNN
+// it keeps are among the kNN nearest of each side, so the tiles deliver exactly those: one ref x query pass
+// (every ref's nearest queries and every query's nearest refs) and one self pass over the queries; the dense
+// rectangle and square that PopPUNK builds for the call (PopPUNK/models.py:1355-1365) never exist.
+// Same order as the reference: stable by distance, the query side first on a tie, the sample itself skipped.
+extern "C" int ppk_extend_sketches(const long long *rr_i, const long long *rr_j, const float *rr_d, size_t nnz,
+                                   const ppk_db *ref, const ppk_db *qry, const int32_t *kmers, const float *random_tbl,
+                                   size_t n_clu, int flags, int knn, int dist_col, long long *i_out, long long *j_out,
+                                   float *d_out, size_t cap, size_t *n_out) {
+  if (!n_out) return ppk_fail(PPK_ERR_ARG, "n_out is NULL");
+  *n_out = 0;
+  if (!ref || !qry) return ppk_fail(PPK_ERR_ARG, "ppk_extend_sketches: reference and query databases are needed");
+  if (nnz && (!rr_i || !rr_j || !rr_d)) return ppk_fail(PPK_ERR_ARG, "sparse matrix: NULL array");
+  if (knn < 1 || knn > 32) return ppk_fail(PPK_ERR_ARG, "knn must be in [1, 32]");
+  const size_t n_ref = ref->n, n_qry = qry->n, n_all = n_ref + n_qry, k = (size_t)knn;
+  for (size_t e = 0; e < nnz; ++e)
+    if (rr_i[e] < 0 || (size_t)rr_i[e] >= n_ref || (e + 1 < nnz && rr_i[e + 1] < rr_i[e]))
+      return ppk_fail(PPK_ERR_ARG, "sparse matrix: row indices must be ascending and below the number of references");
+  std::lock_guard<std::mutex> lk(g_query_mu);
+  DeviceGuard guard(ref->device);
+  if (!guard.ok) return ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(ref->device));
+  if (int rc = ppk_check_arch(ref->device)) return rc;
+  std::vector<long long> aj(n_all * k), bj(n_qry * k);
+  std::vector<float> ad(n_all * k), bd(n_qry * k);
+  {
+    long long *d_i = nullptr, *d_j = nullptr;
+    float *d_d = nullptr;
+    auto release = [&]() {
+      if (d_i) (void)hipFree(d_i);
+      if (d_j) (void)hipFree(d_j);
+      if (d_d) (void)hipFree(d_d);
+    };
+    if (hipMalloc(reinterpret_cast<void **>(&d_i), n_all * k * 8) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&d_j), n_all * k * 8) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&d_d), n_all * k * 4) != hipSuccess) {
+      release();
+      return ppk_fail(PPK_ERR_HIP, "hipMalloc(neighbour lists) failed");
+    }
+    // refs x queries: sample s < n_ref -> its nearest queries (numbered n_ref + q), sample n_ref + q -> its nearest refs
+    int rc = ppk_knn_band_dev(ref, qry, kmers, random_tbl, n_clu, flags, knn, dist_col, 0, n_qry, -1, d_i, d_j, d_d, nullptr,
+                              nullptr);
+    if (rc == PPK_OK && (hipDeviceSynchronize() != hipSuccess || hipMemcpy(aj.data(), d_j, n_all * k * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+                         hipMemcpy(ad.data(), d_d, n_all * k * 4, hipMemcpyDeviceToHost) != hipSuccess))
+      rc = ppk_fail(PPK_ERR_HIP, "neighbour lists: execution or download failed");
+    // queries among themselves
+    if (rc == PPK_OK)
+      rc = ppk_knn_band_dev(qry, nullptr, kmers, random_tbl, n_clu, flags, knn, dist_col, 0, n_qry, -1, d_i, d_j, d_d, nullptr,
+                            nullptr);
+    if (rc == PPK_OK && (hipDeviceSynchronize() != hipSuccess || hipMemcpy(bj.data(), d_j, n_qry * k * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+                         hipMemcpy(bd.data(), d_d, n_qry * k * 4, hipMemcpyDeviceToHost) != hipSuccess))
+      rc = ppk_fail(PPK_ERR_HIP, "neighbour lists: execution or download failed");
+    release();
+    if (rc != PPK_OK) return rc;
+  }
+  // row starts of the sparse matrix (src/extend.cpp:15-38)
+  std::vector<size_t> start(n_ref + 1, nnz);
+  {
+    size_t e = 0;
+    for (size_t r = 0; r <= n_ref; ++r) {
+      while (e < nnz && (size_t)rr_i[e] < r) ++e;
+      start[r] = r == n_ref ? nnz : e;
+    }
+  }
+  struct Cand {
+    float d;
+    unsigned side, order;      // side 0: the query list of the reference's merge, 1: its "rr" list
+    long long j;
+  };
+  auto before = [](const Cand &a, const Cand &b) {
+    if (a.d != b.d) return a.d < b.d;
+    if (a.side != b.side) return a.side < b.side;
+    return a.order < b.order;
+  };
+  std::vector<long long> oi, oj;
+  std::vector<float> od;
+  oi.reserve(n_all * k);
+  oj.reserve(n_all * k);
+  od.reserve(n_all * k);
+  std::vector<Cand> c;
+  for (size_t i = 0; i < n_all; ++i) {
+    c.clear();
+    if (i < n_ref) {
+      for (size_t r = 0; r < k && aj[i * k + r] >= 0; ++r) c.push_back({ad[i * k + r], 0u, (unsigned)(aj[i * k + r] - (long long)n_ref), aj[i * k + r]});
+      for (size_t e = start[i]; e < start[i + 1]; ++e) c.push_back({rr_d[e], 1u, (unsigned)(e - start[i]), rr_j[e]});
+    } else {
+      const size_t q = i - n_ref;
+      for (size_t r = 0; r < k && bj[q * k + r] >= 0; ++r) c.push_back({bd[q * k + r], 0u, (unsigned)bj[q * k + r], bj[q * k + r] + (long long)n_ref});
+      for (size_t r = 0; r < k && aj[i * k + r] >= 0; ++r) c.push_back({ad[i * k + r], 1u, (unsigned)aj[i * k + r], aj[i * k + r]});
+    }
+    std::sort(c.begin(), c.end(), before);
+    size_t kept = 0;
+    for (const Cand &x : c) {
+      if (kept == k) break;
+      if (x.j == (long long)i) continue;
+      oi.push_back((long long)i);
+      oj.push_back(x.j);
+      od.push_back(x.d);
+      ++kept;
+    }
+  }
+  *n_out = oi.size();
+  if (oi.size() > cap) return ppk_fail(PPK_ERR_CAPACITY, "output too small: need " + std::to_string(oi.size()));
+  if (!oi.empty() && (!i_out || !j_out || !d_out)) return ppk_fail(PPK_ERR_ARG, "NULL output");
+  memcpy(i_out, oi.data(), oi.size() * 8);
+  memcpy(j_out, oj.data(), oj.size() * 8);
+  memcpy(d_out, od.data(), od.size() * 4);
+  return PPK_OK;
 }

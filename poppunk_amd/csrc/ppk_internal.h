@@ -169,8 +169,8 @@ int ppk_knn_from_candidates(int dev, const uint32_t *d_keys, const uint64_t *d_v
                             long long missing_j = 0);
 int ppk_knn_compact(int dev, uint32_t *d_keys, uint64_t *d_vals, size_t count, size_t n, int knn, void *d_state,
                     long long *d_i, long long *d_j, float *d_dist, hipStream_t s);
-int ppk_knn_band_dev(const ppk_db *db, const int32_t *kmers, const float *random_tbl, size_t n_clu, int flags,
-                     int knn, int dist_col, size_t q_begin, size_t q_end, long long missing_j, long long *d_i,
+int ppk_knn_band_dev(const ppk_db *db, const ppk_db *qry, const int32_t *kmers, const float *random_tbl, size_t n_clu,
+                     int flags, int knn, int dist_col, size_t q_begin, size_t q_end, long long missing_j, long long *d_i,
                      long long *d_j, float *d_dist, unsigned long long *n_candidates, void *stream);
 size_t ppk_rows_per_dispatch(const ppk_db *ref);     // query rows one kernel launch may cover (ppk_launch_dist)
 

@@ -433,6 +433,30 @@ def prune_query_rows_dev(qr_t, n_ref, keep_q):
     return out
 
 
+def knn_ref_query(ref, qry, kmers, random_tbl, knn, dist_col=0, random_correct=True, info=None):
+    """ppk_knn_sketches_rq_dev: for every reference its knn nearest queries (numbered n_ref + q) and for every
+    query its knn nearest references, one pass over the rectangle's tiles.  CUDA tensors (i, j, dist) of length
+    (n_ref + n_qry) * knn, references first."""
+    torch = _torch()
+    _check_pair(ref, qry)
+    n = ref.n + qry.n
+    dev = "cuda:%d" % ref.device
+    oi = torch.empty(n * knn, dtype=torch.int64, device=dev)
+    oj = torch.empty(n * knn, dtype=torch.int64, device=dev)
+    od = torch.empty(n * knn, dtype=torch.float32, device=dev)
+    kmers_a, random_tbl, tbl_ptr, n_clu = _prep_tables(kmers, random_tbl, ref.nk)
+    n_cand = C.c_ulonglong(0)
+    with torch.cuda.device(ref.device):
+        rc = _lib.lib().ppk_knn_sketches_rq_dev(ref._h, qry._h, kmers_a.ctypes.data_as(C.POINTER(C.c_int32)), tbl_ptr,
+                                                n_clu, FLAG_RANDOM_CORRECT if random_correct else 0, int(knn),
+                                                int(dist_col), C.c_void_p(oi.data_ptr()), C.c_void_p(oj.data_ptr()),
+                                                C.c_void_p(od.data_ptr()), C.byref(n_cand), _stream_ptr(ref.device))
+        _lib.check(rc, "ppk_knn_sketches_rq_dev")
+    if info is not None:
+        info["candidates"] = int(n_cand.value)
+    return oi, oj, od
+
+
 def knn_from_sketches(db, kmers, random_tbl, knn, dist_col=0, random_correct=True,
                       band_items=1 << 31, method="auto", info=None):
     """k nearest neighbours of every sample straight from the resident sketches (what
@@ -496,6 +520,30 @@ def knn_from_sketches(db, kmers, random_tbl, knn, dist_col=0, random_correct=Tru
                                       C.c_void_p(od[qb * knn:].data_ptr()), _stream_ptr(db.device))
             _lib.check(rc, "ppk_knn_rect_dev")
     return oi, oj, od
+
+
+def extend_from_sketches(rr_mat, ref, qry, kmers, random_tbl, knn, dist_col=0, random_correct=True):
+    """poppunk_refine.extend(rr_mat, qq_mat, qr_mat, kNN) with the resident sketches of the references and
+    the queries in the place of the two dense matrices (ppk_extend_sketches): -> (i, j, dist) numpy arrays,
+    queries numbered n_ref + q."""
+    import numpy as np
+    _check_pair(ref, qry)
+    r, c, d = rr_mat
+    r = np.ascontiguousarray(np.asarray(r).astype(np.int64, copy=False)).ravel()
+    c = np.ascontiguousarray(np.asarray(c).astype(np.int64, copy=False)).ravel()
+    d = np.ascontiguousarray(np.asarray(d).astype(np.float32, copy=False)).ravel()
+    kmers, random_tbl, tbl_ptr, n_clu = _prep_tables(kmers, random_tbl, ref.nk)
+    cap = max(int(knn) * (ref.n + qry.n), 1)
+    oi, oj, od = np.empty(cap, dtype=np.int64), np.empty(cap, dtype=np.int64), np.empty(cap, dtype=np.float32)
+    n = C.c_size_t(0)
+    ll, fp = C.POINTER(C.c_longlong), C.POINTER(C.c_float)
+    rc = _lib.lib().ppk_extend_sketches(r.ctypes.data_as(ll), c.ctypes.data_as(ll), d.ctypes.data_as(fp), r.size,
+                                        ref._h, qry._h, kmers.ctypes.data_as(C.POINTER(C.c_int32)), tbl_ptr, n_clu,
+                                        FLAG_RANDOM_CORRECT if random_correct else 0, int(knn), int(dist_col),
+                                        oi.ctypes.data_as(ll), oj.ctypes.data_as(ll), od.ctypes.data_as(fp), cap,
+                                        C.byref(n))
+    _lib.check(rc, "ppk_extend_sketches")
+    return oi[:n.value], oj[:n.value], od[:n.value]
 
 
 def knn_candidates(db, kmers, random_tbl, knn, dist_col=0, random_correct=True, q_begin=0, q_end=None,

@@ -188,6 +188,24 @@ class LineageRanks:
         self._ranks_from(higher, n_ref + n_query)
         return self.assign(self.ranks[0])
 
+    def extend_from_databases(self, ref_db_name, query_db_name, rList, qList, klist, random_correct=True,
+                              device_id=0):
+        """`extend` for queries that are still sketches (`pp_sketchlib.extendFromDatabases`): the same matrices,
+        without the query x reference and query x query distance matrices."""
+        from . import pp_sketchlib
+        if not self.fitted:
+            raise RuntimeError("Trying to extend an unfitted model")
+        if self.max_search_depth > 32:
+            raise RuntimeError("neighbours straight from the sketches: search depth <= 32 (extend(qq, qr) has no limit)")
+        higher = pp_sketchlib.extendFromDatabases((self.nn_dists.row, self.nn_dists.col, self.nn_dists.data),
+                                                  ref_db_name, query_db_name, rList, qList, klist,
+                                                  self.max_search_depth, self.dist_col, random_correct,
+                                                  device_id=device_id)
+        n = len(rList) + len(qList)
+        self.nn_dists = self._coo(higher[2], higher[0], higher[1], n)
+        self._ranks_from((higher[0], higher[1], self.nn_dists.data), n)
+        return self.assign(self.ranks[0])
+
     def assign(self, rank):
         if not self.fitted:
             raise RuntimeError("Trying to assign using an unfitted model")

@@ -542,6 +542,43 @@ def queryDatabaseKNN(db_name, names, klist, kNN, dist_col=0, random_correct=True
         _close_transient(ref_e)
 
 
+def extendFromDatabases(rr_mat, ref_db_name, query_db_name, rList, qList, klist, kNN, dist_col=0,
+                        random_correct=True, num_threads=1, use_gpu=False, device_id=0):
+    """poppunk_refine.extend for queries that are still sketches: what PopPUNK's lineage assignment computes with
+    queryDatabase (query x ref), queryDatabase (query self), longToSquare and extend (PopPUNK/models.py:1355-1372),
+    from the two databases and the references' sparse neighbour matrix `rr_mat` = (row, col, data) -- neither
+    dense matrix is made.  Returns (i, j, dist) arrays, queries numbered len(rList) + q.  kNN <= 32."""
+    klist = [int(k) for k in np.asarray(klist).ravel()]
+    rList = [str(x) for x in rList]
+    qList = [str(x) for x in qList]
+    if ref_db_name == query_db_name and rList == qList:
+        raise RuntimeError("extendFromDatabases needs queries that differ from the references")
+    ref_e, qry_e, table, ref_clu, qry_clu = _open_query(ref_db_name, query_db_name, rList, qList, klist, random_correct)
+    try:
+        lib = _lib.lib()
+        tptr, n_clu, rclu, qclu, keep = _table_args(table, random_correct, ref_clu, qry_clu, True)
+        dev = _devices(device_id)[:1]
+        rh, qh = ref_e.resident(dev, rclu)[0], qry_e.resident(dev, qclu)[0]
+        r, c, d = rr_mat
+        r = np.ascontiguousarray(np.asarray(r).astype(np.int64, copy=False)).ravel()
+        c = np.ascontiguousarray(np.asarray(c).astype(np.int64, copy=False)).ravel()
+        d = np.ascontiguousarray(np.asarray(d).astype(np.float32, copy=False)).ravel()
+        kmers = np.ascontiguousarray(klist, dtype=np.int32)
+        cap = max(int(kNN) * (len(rList) + len(qList)), 1)
+        oi, oj, od = np.empty(cap, dtype=np.int64), np.empty(cap, dtype=np.int64), np.empty(cap, dtype=np.float32)
+        n = C.c_size_t(0)
+        ll, fp = C.POINTER(C.c_longlong), C.POINTER(C.c_float)
+        rc = lib.ppk_extend_sketches(r.ctypes.data_as(ll), c.ctypes.data_as(ll), d.ctypes.data_as(fp), r.size, rh, qh,
+                                     kmers.ctypes.data_as(C.POINTER(C.c_int32)), tptr, n_clu,
+                                     _flags(random_correct, False, False), int(kNN), int(dist_col),
+                                     oi.ctypes.data_as(ll), oj.ctypes.data_as(ll), od.ctypes.data_as(fp), cap, C.byref(n))
+        del keep
+        _lib.check(rc, "ppk_extend_sketches")
+    finally:
+        _close_transient(ref_e, qry_e)
+    return oi[:n.value], oj[:n.value], od[:n.value]
+
+
 def _f32(a, what):
     a = np.asarray(a)
     if a.dtype != np.float32:

@@ -130,6 +130,24 @@ def soak_case(rng, big=False):
             if not (np.array_equal(gi.cpu().numpy(), wi) and np.array_equal(gj.cpu().numpy(), wj)
                     and np.array_equal(gd.cpu().numpy(), wd)):
                 msgs.append("kNN from tiles differs (k=%d col=%d)" % (knn, col))
+        # ref x query: every ref's nearest queries and every query's nearest refs from one pass over the rectangle
+        if qry is not None and bbits == 14 and nk * cnt_bits_k <= 128:
+            knn = int(rng.integers(1, 33))
+            col = int(rng.integers(0, 2))
+            gi, gj, gd = (x.cpu().numpy() for x in engine.knn_ref_query(db, dbq, kmers, t_tbl, knn, dist_col=col,
+                                                                        random_correct=use_tbl))
+            rect = got[:, col].reshape(nq, nr)                      # row = q * n_ref + r
+            wj = np.zeros((nr + nq, knn), dtype=np.int64)
+            wd = np.zeros((nr + nq, knn), dtype=np.float32)
+            for r in range(nr):
+                o = np.argsort(rect[:, r], kind="stable")[:knn]
+                wj[r, :len(o)], wd[r, :len(o)] = o + nr, rect[o, r]
+            for q in range(nq):
+                o = np.argsort(rect[q], kind="stable")[:knn]
+                wj[nr + q, :len(o)], wd[nr + q, :len(o)] = o, rect[q, o]
+            if not (np.array_equal(gi, np.repeat(np.arange(nr + nq), knn)) and np.array_equal(gj, wj.ravel())
+                    and np.array_equal(gd, wd.ravel())):
+                msgs.append("ref x query kNN from tiles differs (k=%d col=%d)" % (knn, col))
         db.close()
         if dbq is not None:
             dbq.close()

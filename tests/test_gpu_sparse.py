@@ -201,3 +201,54 @@ def test_lineage_ranks_from_distances_from_sketches_and_extended(tmp_path):
         wi, wj, wd = oracle.lower_rank(ei, ej, ed, 420, 2, recip, unique, 1e-4)
         assert np.array_equal(a.lower_rank_dists[2].row, wi) and np.array_equal(a.lower_rank_dists[2].data, np.maximum(wd, floor))
     pp_sketchlib.clear_cache()
+
+
+@pytest.mark.parametrize("n_ref,n_qry,related", [(600, 150, True), (300, 500, True), (520, 90, False), (40, 3, True)])
+def test_extend_from_sketches_equals_extend_on_the_dense_matrices(n_ref, n_qry, related):
+    """ppk_extend_sketches: the tiles deliver every reference's nearest queries and every query's nearest
+    references and queries; merged with the sparse rows exactly as extend merges the dense rectangle and
+    square (which are computed here only to state the expected result).  Unrelated data: ties everywhere."""
+    from poppunk_amd import engine, pp_sketchlib, synth
+    kmers = np.asarray(synth.DEFAULT_KMERS, dtype=np.int32)
+    sk, _ = synth.make_sketches(n_ref + n_qry, kmers, cluster_size=25, seed=n_ref + n_qry, related=related)
+    tbl = synth.random_match_table(kmers)
+    ref, qry = sk[:n_ref], sk[n_ref:]
+    rr, _ = pp_sketchlib.query_arrays(ref, None, kmers, 16, 14, tbl)
+    qq, _ = pp_sketchlib.query_arrays(qry, None, kmers, 16, 14, tbl)
+    qr, _ = pp_sketchlib.query_arrays(ref, qry, kmers, 16, 14, tbl)
+    rdb, qdb = engine.SketchDB(ref, 16, 14), engine.SketchDB(qry, 16, 14)
+    for col, depth in ((0, 6), (1, 3)):
+        coo = oracle.knn(oracle.long_to_square(rr[:, col]), min(depth, n_ref - 1))
+        qq_sq = oracle.long_to_square(qq[:, col]) if n_qry > 1 else np.zeros((n_qry, n_qry), np.float32)
+        qr_rect = np.ascontiguousarray(qr[:, col].reshape(n_qry, n_ref).T)
+        for knn in (1, depth, depth + 4):
+            want = oracle.extend(*coo, qq_sq, qr_rect, knn)
+            got = engine.extend_from_sketches(coo, rdb, qdb, kmers, tbl, knn, dist_col=col)
+            _same(got, want)
+            _same(poppunk_refine.extend_arrays(coo, qq_sq, qr_rect, knn), want)
+    rdb.close()
+    qdb.close()
+
+
+def test_lineage_ranks_extended_from_databases(tmp_path):
+    from poppunk_amd import models, pp_sketchlib, sketchdb, synth
+    kmers = np.asarray(synth.DEFAULT_KMERS, dtype=np.int32)
+    sk, _ = synth.make_sketches(500, kmers, cluster_size=25, seed=8)
+    tbl = synth.random_match_table(kmers)
+    names = ["m%03d" % i for i in range(500)]
+    rdb, qdb = str(tmp_path / "refs"), str(tmp_path / "queries")
+    sketchdb.save_npz(rdb, names[:380], kmers, sk[:380], 16, 14, random_table=tbl)
+    sketchdb.save_npz(qdb, names[380:], kmers, sk[380:], 16, 14, random_table=tbl)
+    pp_sketchlib.clear_cache()
+    klist = kmers.tolist()
+    a = models.LineageRanks([1, 2], 3, dist_col=0)
+    b = models.LineageRanks([1, 2], 3, dist_col=0)
+    assert a.fit_from_database(rdb, names[:380], klist) == b.fit_from_database(rdb, names[:380], klist)
+    qq = pp_sketchlib.queryDatabase(qdb, qdb, names[380:], names[380:], klist, True, False, 1, True, 0)
+    qr = pp_sketchlib.queryDatabase(rdb, qdb, names[:380], names[380:], klist, True, False, 1, True, 0)
+    ya = a.extend(qq, qr)
+    yb = b.extend_from_databases(rdb, qdb, names[:380], names[380:], klist)
+    assert ya == yb and len(ya) > 500
+    for m, w in ((b.nn_dists, a.nn_dists), (b.lower_rank_dists[2], a.lower_rank_dists[2])):
+        assert np.array_equal(m.row, w.row) and np.array_equal(m.col, w.col) and np.array_equal(m.data, w.data)
+    pp_sketchlib.clear_cache()
