@@ -492,46 +492,58 @@ def get_database_statistics(prefix):
     return lengths, ambiguous
 
 
+def _copy_samples(src_sketches, dst_sketches, skip=frozenset()):
+    """Every sample group of `src_sketches` that is not in `skip` -> `dst_sketches`, by the library's object copy
+    (datasets and attributes as stored).  Returns (copied, skipped) name lists; the name being copied when the
+    library refuses is left in `_copy_samples.current` for the caller's message."""
+    copied, skipped = [], []
+    for name in src_sketches.keys():
+        _copy_samples.current = name
+        if name in skip:
+            skipped.append(name)
+        else:
+            dst_sketches.copy(src_sketches[name], name)
+            copied.append(name)
+    return copied, skipped
+
+
+_copy_samples.current = ""
+
+
 def joinDBs(db1, db2, output, update_random=None, full_names=False):
-    """The sketches of two databases in one file, by the library's object copy -- every sample group with
-    its datasets and attributes as stored (PopPUNK/sketchlib.py:216-293; caller PopPUNK/assign.py:741,
-    PopPUNK/visualise.py:493).  Written to `<output>.tmp.h5`, renamed when complete.
+    """The sketches of two databases in one file (PopPUNK/sketchlib.py:216-293; callers PopPUNK/assign.py:741,
+    PopPUNK/visualise.py:493): db1's /sketches group whole, db2's samples added to it one by one, written as
+    `<output>.tmp.h5` and renamed when complete (the output may be one of the inputs).
 
     /random: db1's group is carried over, as the reference does when `update_random` is None.  With
     `update_random` given the reference re-runs pp_sketchlib.addRandom on the joined file; sketching-side
     functions are outside this package (sketching is out of scope), so db1's table is
     carried here too and a line on stderr says so -- a sample absent from the table takes the nearest
     base-frequency cluster when it is queried (`random_from_raw`)."""
-    if not full_names:
-        join_prefix = output + "/" + os.path.basename(output)
-        db1_name, db2_name = _prefix_file(db1), _prefix_file(db2)
-    else:
-        db1_name, db2_name, join_prefix = db1, db2, output
+    first, second = (db1, db2) if full_names else (_prefix_file(db1), _prefix_file(db2))
+    target = output if full_names else output + "/" + os.path.basename(output)
     _, h5open = _h5_backend()
-    hdf1 = h5open(db1_name, "r")
-    hdf2 = h5open(db2_name, "r")
-    hdf_join = h5open(join_prefix + ".tmp.h5", "w")       # .tmp in case the joined name is one of the inputs
+    files = []
     try:
         try:
-            hdf1.copy("sketches", hdf_join)
-            join_grp = hdf_join["sketches"]
-            read_grp = hdf2["sketches"]
-            for sample in read_grp.keys():
-                join_grp.copy(read_grp[sample], sample)
-            if "random" in hdf1:
-                hdf1.copy("random", hdf_join)
+            for path, mode in ((first, "r"), (second, "r"), (target + ".tmp.h5", "w")):
+                files.append(h5open(path, mode))
+            src1, src2, dst = files
+            src1.copy("sketches", dst)
+            _copy_samples(src2["sketches"], dst["sketches"])
+            if "random" in src1:
+                src1.copy("random", dst)
             if update_random is not None:
                 sys.stderr.write("poppunk_amd: random match chances of %s carried over to the joined database "
-                                 "(not re-estimated: run pp_sketchlib.addRandom on it for that)\n" % db1_name)
+                                 "(not re-estimated: run pp_sketchlib.addRandom on it for that)\n" % first)
         finally:
-            hdf1.close()
-            hdf2.close()
-            hdf_join.close()
+            for f in files:
+                f.close()
     except RuntimeError as e:
         sys.stderr.write("ERROR: " + str(e) + "\n")
         sys.stderr.write("Joining sketches failed, try running without --update-db\n")
         sys.exit(1)
-    os.rename(join_prefix + ".tmp.h5", join_prefix + ".h5")
+    os.rename(target + ".tmp.h5", target + ".h5")
 
 
 def removeFromDB(db_name, out_name, removeSeqs, full_names=False):
@@ -539,37 +551,31 @@ def removeFromDB(db_name, out_name, removeSeqs, full_names=False):
     PopPUNK/assign.py:800, PopPUNK/qc.py:515-525, PopPUNK/reference_pick.py:104).  As in the reference the
     prefix form writes `<out_name>/<basename>.tmp.h5` and leaves the rename to the caller; /random and the
     attributes of /sketches are kept; names that are not in the database are reported on stderr."""
-    removeSeqs = set(removeSeqs)
-    if not full_names:
-        db_file, out_file = _prefix_file(db_name), _prefix_file(out_name, ".tmp.h5")
-    else:
-        db_file, out_file = db_name, out_name
+    unwanted = frozenset(removeSeqs)
+    source = db_name if full_names else _prefix_file(db_name)
+    target = out_name if full_names else _prefix_file(out_name, ".tmp.h5")
     _, h5open = _h5_backend()
-    hdf_in = h5open(db_file, "r")
-    hdf_out = h5open(out_file, "w")
-    sample = ""
-    removed = []
+    dropped = []
+    files = []
     try:
         try:
-            if "random" in hdf_in:
-                hdf_in.copy("random", hdf_out)
-            out_grp = hdf_out.create_group("sketches")
-            read_grp = hdf_in["sketches"]
-            for attr_name, attr_val in read_grp.attrs.items():
-                out_grp.attrs.create(attr_name, attr_val)
-            for sample in read_grp.keys():
-                if sample not in removeSeqs:
-                    out_grp.copy(read_grp[sample], sample)
-                else:
-                    removed.append(sample)
+            files.append(h5open(source, "r"))
+            files.append(h5open(target, "w"))
+            src, dst = files
+            if "random" in src:
+                src.copy("random", dst)
+            kept_group = dst.create_group("sketches")
+            for key, value in src["sketches"].attrs.items():
+                kept_group.attrs.create(key, value)
+            _, dropped = _copy_samples(src["sketches"], kept_group, unwanted)
         finally:
-            hdf_in.close()
-            hdf_out.close()
+            for f in files:
+                f.close()
     except RuntimeError as e:
         sys.stderr.write("ERROR: " + str(e) + "\n")
-        sys.stderr.write("Error while deleting sequence " + sample + "\n")
+        sys.stderr.write("Error while deleting sequence " + _copy_samples.current + "\n")
         sys.exit(1)
-    missed = removeSeqs.difference(removed)
-    if missed:
+    not_found = unwanted.difference(dropped)
+    if not_found:
         sys.stderr.write("WARNING: Did not find samples to remove:\n")
-        sys.stderr.write("\t".join(missed) + "\n")
+        sys.stderr.write("\t".join(not_found) + "\n")
