@@ -218,3 +218,21 @@ def test_neighbours_from_tiles_in_pieces_with_a_short_candidate_list(ppk_option,
         assert np.array_equal(gi, oi) and np.array_equal(gj, oj) and np.array_equal(gd, od), (tiles, room)
     assert single > 1500 * knn
     db.close()
+
+
+def test_candidate_bands_beyond_one_dispatch(ppk_option):
+    """The multi-process form (candidates per band, then one selection) when a band holds more tiles than one
+    launch may: ppk_launch_dist appends the pieces' candidates through the shared counter."""
+    import torch
+    kmers = np.asarray(synth.DEFAULT_KMERS, dtype=np.int32)
+    sk, _ = synth.make_sketches(1300, kmers, cluster_size=26, seed=23)
+    tbl = synth.random_match_table(kmers)
+    db = engine.SketchDB(sk, 16, 14)
+    wi, wj, wd = (x.cpu().numpy() for x in engine.knn_from_sketches(db, kmers, tbl, 6, dist_col=1, method="tiles"))
+    ppk_option("launch_tiles", 10)
+    parts = [engine.knn_candidates(db, kmers, tbl, 6, dist_col=1, q_begin=a, q_end=b) for a, b in ((0, 500), (500, 1300))]
+    keys = torch.cat([p[0] for p in parts])
+    vals = torch.cat([p[1] for p in parts])
+    gi, gj, gd = (x.cpu().numpy() for x in engine.knn_select(keys, vals, 1300, 6))
+    assert np.array_equal(gi, wi) and np.array_equal(gj, wj) and np.array_equal(gd, wd)
+    db.close()
