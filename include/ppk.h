@@ -378,7 +378,7 @@ int ppk_extend(const long long *rr_i, const long long *rr_j, const float *rr_d, 
                size_t *n_out);
 
 /* poppunk_refine.extend with the sketches in the place of its two dense matrices: `ref` / `qry` are resident
- * databases on ONE device, the query x reference rectangle and the query square PopPUNK computes for the call
+ * databases on one device, the query x reference rectangle and the query square PopPUNK computes for the call
  * (queryDatabase twice, longToSquare, PopPUNK/models.py:1355-1365) never exist -- the tiles deliver every
  * reference's kNN nearest queries, every query's kNN nearest references and kNN nearest queries, which is all
  * extend's merge can keep.  Distances are the kernel's (no 1e-10 floor: apply it to the output, it preserves
@@ -388,6 +388,13 @@ int ppk_extend_sketches(const long long *rr_i, const long long *rr_j, const floa
                         const ppk_db *ref, const ppk_db *qry, const int32_t *kmers, const float *random_tbl,
                         size_t n_clu, int flags, int knn, int dist_col, long long *i_out, long long *j_out,
                         float *d_out, size_t cap, size_t *n_out);
+/* ... on several devices: refs[d] / qrys[d] = the two databases resident on device d; both passes are cut into
+ * bands of query rows, one per device, and the bands' lists merged as ppk_query_knn_dbs merges them. */
+int ppk_extend_sketches_dbs(const long long *rr_i, const long long *rr_j, const float *rr_d, size_t nnz,
+                            const ppk_db *const *refs, const ppk_db *const *qrys, int n_dev,
+                            const int32_t *kmers, const float *random_tbl, size_t n_clu, int flags, int knn,
+                            int dist_col, long long *i_out, long long *j_out, float *d_out, size_t cap,
+                            size_t *n_out);
 
 /* ------------------------------------------------------------------------
  * Long <-> square distance transforms and k nearest neighbours (SURVEY.md 8f

@@ -98,6 +98,8 @@ SIGNATURES = {
     "ppk_knn_sketches_rq_dev": (C.c_int, [_vp, _vp, _i32p, _f32p, _sz, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _ullp, _vp]),
     "ppk_extend_sketches": (C.c_int, [_llp, _llp, _f32p, _sz, _vp, _vp, _i32p, _f32p, _sz, C.c_int, C.c_int, C.c_int, _llp,
                                       _llp, _f32p, _sz, _szp]),
+    "ppk_extend_sketches_dbs": (C.c_int, [_llp, _llp, _f32p, _sz, C.POINTER(_vp), C.POINTER(_vp), C.c_int, _i32p, _f32p, _sz,
+                                          C.c_int, C.c_int, C.c_int, _llp, _llp, _f32p, _sz, _szp]),
     "ppk_qc_edges": (C.c_int, [_f32p, _sz, _sz, C.c_int, C.c_float, C.c_float, C.c_int, _llp, _sz, _szp, _szp]),
     "ppk_query_edges_dbs": (C.c_int, [C.POINTER(_vp), C.POINTER(_vp), C.c_int, _i32p, _f32p, _sz, C.c_int,
                                       C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, _llp, _sz,

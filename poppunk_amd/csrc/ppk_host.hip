@@ -1679,16 +1679,17 @@ extern "C" int ppk_query_edges(const uint64_t *ref_sk, size_t n_ref, const uint6
   return rc;
 }
 
-// ---- host entry: sketches -> k nearest neighbours of every sample, on one or several devices -------------
+// ---- host entries: neighbour lists straight from the sketches, on one or several devices ------------------
 // What get_kNN_distances(longToSquare(queryDatabase(...)[:, dist_col]), kNN) gives (PopPUNK/models.py:
-// 1215-1222), with neither matrix: every listed device takes a band of the triangle's rows
+// 1215-1222), with neither matrix: every listed device takes a band of the job's query rows
 // (ppk_knn_band_dev: candidates from the tiles, best knn per sample of ITS band), the per-device lists come
 // to the host (knn entries per sample and device) and are merged per sample by (distance bits, neighbour) --
-// the reference's stable order (src/extend.cpp:266-279).
+// the reference's stable order (src/extend.cpp:266-279).  A pair is a candidate for both of its samples and
+// belongs to exactly one band, so a sample's true neighbours are among the best knn of every band's list.
 namespace {
 struct KnnPart {
   int device = 0, dup = 0;
-  const ppk_db *db = nullptr;
+  const ppk_db *db = nullptr, *qry = nullptr;
   size_t q_begin = 0, q_end = 0;
   std::vector<long long> j;
   std::vector<float> d;
@@ -1697,7 +1698,7 @@ struct KnnPart {
 };
 
 void run_knn_part(KnnPart &p, const int32_t *kmers, const float *random_tbl, size_t n_clu, int flags, int knn,
-                  int dist_col, long long missing_j) {
+                  int dist_col) {
   auto fail = [&](int code) {
     p.rc = code;
     p.err = ppk_error();
@@ -1710,7 +1711,7 @@ void run_knn_part(KnnPart &p, const int32_t *kmers, const float *random_tbl, siz
   hipStream_t ws[2] = {nullptr, nullptr};
   int rc = part_streams(p.device, p.dup, ws);
   if (rc != PPK_OK) return fail(rc);
-  const size_t m = p.db->n * (size_t)knn;
+  const size_t m = (p.db->n + (p.qry ? p.qry->n : 0)) * (size_t)knn;
   long long *d_i = nullptr, *d_j = nullptr;
   float *d_d = nullptr;
   auto done = [&](int code) {
@@ -1722,8 +1723,8 @@ void run_knn_part(KnnPart &p, const int32_t *kmers, const float *random_tbl, siz
   if (hipMalloc(reinterpret_cast<void **>(&d_i), m * 8) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&d_j), m * 8) != hipSuccess ||
       hipMalloc(reinterpret_cast<void **>(&d_d), m * 4) != hipSuccess)
     return done(ppk_fail(PPK_ERR_HIP, "hipMalloc(neighbour lists) failed"));
-  rc = ppk_knn_band_dev(p.db, nullptr, kmers, random_tbl, n_clu, flags, knn, dist_col, p.q_begin, p.q_end, missing_j, d_i,
-                        d_j, d_d, nullptr, ws[0]);
+  rc = ppk_knn_band_dev(p.db, p.qry, kmers, random_tbl, n_clu, flags, knn, dist_col, p.q_begin, p.q_end, -1, d_i, d_j, d_d,
+                        nullptr, ws[0]);
   if (rc != PPK_OK) return done(rc);
   p.j.resize(m);
   p.d.resize(m);
@@ -1733,35 +1734,40 @@ void run_knn_part(KnnPart &p, const int32_t *kmers, const float *random_tbl, siz
   done(PPK_OK);
 }
 
-int query_knn_dbs_locked(const ppk_db *const *dbs, int n_dev, const int32_t *kmers, const float *random_tbl,
-                         size_t n_clu, int flags, int knn, int dist_col, long long *i_out, long long *j_out,
-                         float *d_out) {
-  if (!dbs || n_dev < 1 || n_dev > 64) return ppk_fail(PPK_ERR_ARG, "ppk_query_knn_dbs: no databases");
+// Neighbour lists of a self job (qrys == NULL: n = dbs[0]->n samples) or of a ref x query job (n = n_ref + n_qry
+// samples, refs first: a ref's neighbours are queries numbered n_ref + q, a query's are refs), computed band by band
+// on the listed devices and merged: j / d hold knn slots per sample, filled from the front, j = -1 behind.
+int knn_lists_locked(const ppk_db *const *dbs, const ppk_db *const *qrys, int n_dev, const int32_t *kmers,
+                     const float *random_tbl, size_t n_clu, int flags, int knn, int dist_col,
+                     std::vector<long long> &j_out, std::vector<float> &d_out) {
+  if (!dbs || n_dev < 1 || n_dev > 64) return ppk_fail(PPK_ERR_ARG, "neighbour lists: no databases");
   if (knn < 1 || knn > 32) return ppk_fail(PPK_ERR_ARG, "knn must be in [1, 32]");
-  if (!i_out || !j_out || !d_out) return ppk_fail(PPK_ERR_ARG, "NULL output");
   std::vector<KnnPart> parts((size_t)n_dev);
   for (int d = 0; d < n_dev; ++d) {
-    if (!dbs[d]) return ppk_fail(PPK_ERR_ARG, "ppk_query_knn_dbs: a database is missing for some device");
-    if (dbs[d]->n != dbs[0]->n || dbs[d]->nk != dbs[0]->nk || dbs[d]->s64 != dbs[0]->s64 || dbs[d]->bbits != dbs[0]->bbits)
-      return ppk_fail(PPK_ERR_ARG, "ppk_query_knn_dbs: the per-device databases differ in shape");
+    const ppk_db *q = qrys ? qrys[d] : nullptr;
+    if (!dbs[d] || (qrys && !q)) return ppk_fail(PPK_ERR_ARG, "neighbour lists: a database is missing for some device");
+    if (dbs[d]->n != dbs[0]->n || dbs[d]->nk != dbs[0]->nk || dbs[d]->s64 != dbs[0]->s64 || dbs[d]->bbits != dbs[0]->bbits ||
+        (q && (q->n != qrys[0]->n || q->device != dbs[d]->device)))
+      return ppk_fail(PPK_ERR_ARG, "neighbour lists: the per-device databases differ in shape or device");
     KnnPart &p = parts[(size_t)d];
     p.device = dbs[d]->device;
     for (int e = 0; e < d; ++e) p.dup += parts[(size_t)e].device == p.device;
     if (p.dup >= kMaxDup) return ppk_fail(PPK_ERR_ARG, "a device may be listed at most 4 times");
     if (int rc = ppk_check_arch(p.device)) return rc;
     p.db = dbs[d];
+    p.qry = q;
   }
-  const size_t n = dbs[0]->n;
+  const size_t n_ref = dbs[0]->n, n_qry = qrys ? qrys[0]->n : 0, n = n_ref + n_qry, k = (size_t)knn;
   std::vector<size_t> bounds((size_t)n_dev + 1, 0);
-  int rc = ppk_band_split(n, 0, n_dev, bounds.data());
+  int rc = ppk_band_split(n_ref, n_qry, n_dev, bounds.data());
   if (rc != PPK_OK) return rc;
   std::vector<PpkTicket> th;
   for (int d = 0; d < n_dev; ++d) {
     KnnPart &p = parts[(size_t)d];
     p.q_begin = bounds[(size_t)d];
     p.q_end = bounds[(size_t)d + 1];
-    auto work = [&p, kmers, random_tbl, n_clu, flags, knn, dist_col, n_dev]() {
-      run_knn_part(p, kmers, random_tbl, n_clu, flags, knn, dist_col, n_dev == 1 ? 0 : -1);
+    auto work = [&p, kmers, random_tbl, n_clu, flags, knn, dist_col]() {
+      run_knn_part(p, kmers, random_tbl, n_clu, flags, knn, dist_col);
     };
     if (n_dev == 1) work();
     else th.push_back(ppk_pool_run(work));
@@ -1769,14 +1775,13 @@ int query_knn_dbs_locked(const ppk_db *const *dbs, int n_dev, const int32_t *kme
   for (auto &t : th) ppk_pool_wait(t);
   for (KnnPart &p : parts)
     if (p.rc != PPK_OK) return ppk_fail(p.rc, p.err);
-  const size_t k = (size_t)knn;
   if (n_dev == 1) {
-    for (size_t e = 0; e < n * k; ++e) i_out[e] = (long long)(e / k);
-    memcpy(j_out, parts[0].j.data(), n * k * 8);
-    memcpy(d_out, parts[0].d.data(), n * k * 4);
+    j_out.swap(parts[0].j);
+    d_out.swap(parts[0].d);
     return PPK_OK;
   }
-  // merge: a sample's true neighbours are among the best knn of every band's list
+  j_out.assign(n * k, -1);
+  d_out.assign(n * k, 0.0f);
   auto merge = [&](size_t lo, size_t hi) {
     std::vector<uint64_t> keys;
     keys.reserve((size_t)n_dev * k);
@@ -1792,16 +1797,10 @@ int query_knn_dbs_locked(const ppk_db *const *dbs, int n_dev, const int32_t *kme
         }
       const size_t take = keys.size() < k ? keys.size() : k;
       std::partial_sort(keys.begin(), keys.begin() + (long)take, keys.end());
-      for (size_t r = 0; r < k; ++r) {
-        i_out[i * k + r] = (long long)i;
-        if (r < take) {
-          const uint32_t bits = (uint32_t)(keys[r] >> 32);
-          j_out[i * k + r] = (long long)(keys[r] & 0xffffffffull);
-          memcpy(&d_out[i * k + r], &bits, 4);
-        } else {                                   // fewer than knn other samples: the reference's filler
-          j_out[i * k + r] = 0;
-          d_out[i * k + r] = 0.0f;
-        }
+      for (size_t r = 0; r < take; ++r) {
+        const uint32_t bits = (uint32_t)(keys[r] >> 32);
+        j_out[i * k + r] = (long long)(keys[r] & 0xffffffffull);
+        memcpy(&d_out[i * k + r], &bits, 4);
       }
     }
   };
@@ -1813,33 +1812,14 @@ int query_knn_dbs_locked(const ppk_db *const *dbs, int n_dev, const int32_t *kme
   for (auto &t : mt) ppk_pool_wait(t);
   return PPK_OK;
 }
-}  // namespace
 
-extern "C" int ppk_query_knn_dbs(const ppk_db *const *dbs, int n_dev, const int32_t *kmers, const float *random_tbl,
-                                 size_t n_clu, int flags, int knn, int dist_col, long long *i_out,
-                                 long long *j_out, float *d_out) {
-  std::lock_guard<std::mutex> lk(g_query_mu);
-  return query_knn_dbs_locked(dbs, n_dev, kmers, random_tbl, n_clu, flags, knn, dist_col, i_out, j_out, d_out);
-}
-
-extern "C" int ppk_query_knn(const uint64_t *sk, size_t n, const int32_t *kmers, size_t nk, size_t sketchsize64,
-                             size_t bbits, const float *random_tbl, const uint16_t *clu, size_t n_clu, int flags,
-                             int knn, int dist_col, const int *devices, int n_dev, long long *i_out,
-                             long long *j_out, float *d_out) {
-  if (!sk || !kmers || n == 0 || nk == 0) return ppk_fail(PPK_ERR_ARG, "ppk_query_knn: missing sketches / kmers");
-  const int default_dev = 0;
-  if (!devices || n_dev < 1) {
-    devices = &default_dev;
-    n_dev = 1;
-  }
-  if (n_dev > 64) return ppk_fail(PPK_ERR_ARG, "too many devices");
-  std::lock_guard<std::mutex> lk(g_query_mu);
+// the resident copies of a host sketch array on the listed devices: from (and into) ppk_query's cache
+int acquire_on_devices(const uint64_t *sk, size_t n, size_t nk, size_t s64, size_t bbits, const uint16_t *clu,
+                       const int *devices, int n_dev, std::vector<const ppk_db *> &dbs, std::vector<ppk_db *> &owned) {
   const bool use_cache = ppk_config().db_cache.load() != 0;
-  const uint64_t fp = use_cache ? fingerprint(sk, n * nk * sketchsize64 * bbits, clu, n) : 0;
-  std::vector<const ppk_db *> dbs((size_t)n_dev, nullptr);
-  std::vector<ppk_db *> owned;
-  int rc = PPK_OK;
-  for (int d = 0; d < n_dev && rc == PPK_OK; ++d) {
+  const uint64_t fp = use_cache ? fingerprint(sk, n * nk * s64 * bbits, clu, n) : 0;
+  dbs.assign((size_t)n_dev, nullptr);
+  for (int d = 0; d < n_dev; ++d) {
     int first = -1;
     for (int e = 0; e < d && first < 0; ++e)
       if (devices[e] == devices[d]) first = e;
@@ -1847,79 +1827,102 @@ extern "C" int ppk_query_knn(const uint64_t *sk, size_t n, const int32_t *kmers,
       dbs[(size_t)d] = dbs[(size_t)first];
       continue;
     }
-    if (devices[d] < 0 || devices[d] >= 64) {
-      rc = ppk_fail(PPK_ERR_ARG, "device id out of range");
-      break;
-    }
+    if (devices[d] < 0 || devices[d] >= 64) return ppk_fail(PPK_ERR_ARG, "device id out of range");
     ppk_db *db = nullptr;
     bool own = false;
-    rc = db_acquire(devices[d], sk, n, nk, sketchsize64, bbits, clu, fp, use_cache, nullptr, nullptr, &db, &own);
-    if (rc != PPK_OK) break;
+    int rc = db_acquire(devices[d], sk, n, nk, s64, bbits, clu, fp, use_cache, nullptr, nullptr, &db, &own);
+    if (rc != PPK_OK) return rc;
     dbs[(size_t)d] = db;
     if (own) owned.push_back(db);
   }
-  if (rc == PPK_OK)
-    rc = query_knn_dbs_locked(dbs.data(), n_dev, kmers, random_tbl, n_clu, flags, knn, dist_col, i_out, j_out, d_out);
+  return PPK_OK;
+}
+}  // namespace
+
+extern "C" int ppk_query_knn_dbs(const ppk_db *const *dbs, int n_dev, const int32_t *kmers, const float *random_tbl,
+                                 size_t n_clu, int flags, int knn, int dist_col, long long *i_out,
+                                 long long *j_out, float *d_out) {
+  if (!i_out || !j_out || !d_out) return ppk_fail(PPK_ERR_ARG, "NULL output");
+  std::lock_guard<std::mutex> lk(g_query_mu);
+  std::vector<long long> j;
+  std::vector<float> d;
+  int rc = knn_lists_locked(dbs, nullptr, n_dev, kmers, random_tbl, n_clu, flags, knn, dist_col, j, d);
+  if (rc != PPK_OK) return rc;
+  const size_t k = (size_t)knn, m = dbs[0]->n * k;
+  for (size_t e = 0; e < m; ++e) {
+    i_out[e] = (long long)(e / k);
+    // fewer than knn other samples: the reference leaves (i, 0, 0.0) in the slot (src/extend.cpp:266-279)
+    j_out[e] = j[e] < 0 ? 0 : j[e];
+    d_out[e] = j[e] < 0 ? 0.0f : d[e];
+  }
+  return PPK_OK;
+}
+
+extern "C" int ppk_query_knn(const uint64_t *sk, size_t n, const int32_t *kmers, size_t nk, size_t sketchsize64,
+                             size_t bbits, const float *random_tbl, const uint16_t *clu, size_t n_clu, int flags,
+                             int knn, int dist_col, const int *devices, int n_dev, long long *i_out,
+                             long long *j_out, float *d_out) {
+  if (!sk || !kmers || n == 0 || nk == 0) return ppk_fail(PPK_ERR_ARG, "ppk_query_knn: missing sketches / kmers");
+  if (!i_out || !j_out || !d_out) return ppk_fail(PPK_ERR_ARG, "NULL output");
+  const int default_dev = 0;
+  if (!devices || n_dev < 1) {
+    devices = &default_dev;
+    n_dev = 1;
+  }
+  if (n_dev > 64) return ppk_fail(PPK_ERR_ARG, "too many devices");
+  std::lock_guard<std::mutex> lk(g_query_mu);
+  std::vector<const ppk_db *> dbs;
+  std::vector<ppk_db *> owned;
+  std::vector<long long> j;
+  std::vector<float> d;
+  int rc = acquire_on_devices(sk, n, nk, sketchsize64, bbits, clu, devices, n_dev, dbs, owned);
+  if (rc == PPK_OK) rc = knn_lists_locked(dbs.data(), nullptr, n_dev, kmers, random_tbl, n_clu, flags, knn, dist_col, j, d);
   const std::string keep = ppk_error();
   for (ppk_db *db : owned) ppk_db_destroy(db);
-  if (rc != PPK_OK) ppk_set_error(keep);
-  return rc;
+  if (rc != PPK_OK) {
+    ppk_set_error(keep);
+    return rc;
+  }
+  const size_t k = (size_t)knn;
+  for (size_t e = 0; e < n * k; ++e) {
+    i_out[e] = (long long)(e / k);
+    j_out[e] = j[e] < 0 ? 0 : j[e];
+    d_out[e] = j[e] < 0 ? 0.0f : d[e];
+  }
+  return PPK_OK;
 }
 
 // ---- poppunk_refine.extend without the dense matrices ------------------------------------------------------
 // extend (src/extend.cpp:52-126) merges, per reference, its sparse row with its distances to ALL queries, and
 // per query its distances to ALL references with its row of the query square -- and keeps kNN of them.  The kNN
 // it keeps are among the kNN nearest of each side, so the tiles deliver exactly those: one ref x query pass
-// (every ref's nearest queries and every query's nearest refs) and one self pass over the queries; the dense
-// rectangle and square that PopPUNK builds for the call (PopPUNK/models.py:1355-1365) never exist.
-// Same order as the reference: stable by distance, the query side first on a tie, the sample itself skipped.
-extern "C" int ppk_extend_sketches(const long long *rr_i, const long long *rr_j, const float *rr_d, size_t nnz,
-                                   const ppk_db *ref, const ppk_db *qry, const int32_t *kmers, const float *random_tbl,
-                                   size_t n_clu, int flags, int knn, int dist_col, long long *i_out, long long *j_out,
-                                   float *d_out, size_t cap, size_t *n_out) {
+// (every ref's nearest queries and every query's nearest refs) and one self pass over the queries, each over
+// every listed device; the dense rectangle and square that PopPUNK builds for the call
+// (PopPUNK/models.py:1355-1365) never exist.  Same order as the reference: stable by distance, the query side
+// first on a tie, the sample itself skipped.
+extern "C" int ppk_extend_sketches_dbs(const long long *rr_i, const long long *rr_j, const float *rr_d, size_t nnz,
+                                       const ppk_db *const *refs, const ppk_db *const *qrys, int n_dev,
+                                       const int32_t *kmers, const float *random_tbl, size_t n_clu, int flags, int knn,
+                                       int dist_col, long long *i_out, long long *j_out, float *d_out, size_t cap,
+                                       size_t *n_out) {
   if (!n_out) return ppk_fail(PPK_ERR_ARG, "n_out is NULL");
   *n_out = 0;
-  if (!ref || !qry) return ppk_fail(PPK_ERR_ARG, "ppk_extend_sketches: reference and query databases are needed");
+  if (!refs || !qrys || n_dev < 1 || !refs[0] || !qrys[0])
+    return ppk_fail(PPK_ERR_ARG, "ppk_extend_sketches: reference and query databases are needed");
   if (nnz && (!rr_i || !rr_j || !rr_d)) return ppk_fail(PPK_ERR_ARG, "sparse matrix: NULL array");
   if (knn < 1 || knn > 32) return ppk_fail(PPK_ERR_ARG, "knn must be in [1, 32]");
-  const size_t n_ref = ref->n, n_qry = qry->n, n_all = n_ref + n_qry, k = (size_t)knn;
+  const size_t n_ref = refs[0]->n, n_qry = qrys[0]->n, n_all = n_ref + n_qry, k = (size_t)knn;
   for (size_t e = 0; e < nnz; ++e)
     if (rr_i[e] < 0 || (size_t)rr_i[e] >= n_ref || (e + 1 < nnz && rr_i[e + 1] < rr_i[e]))
       return ppk_fail(PPK_ERR_ARG, "sparse matrix: row indices must be ascending and below the number of references");
-  std::lock_guard<std::mutex> lk(g_query_mu);
-  DeviceGuard guard(ref->device);
-  if (!guard.ok) return ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(ref->device));
-  if (int rc = ppk_check_arch(ref->device)) return rc;
-  std::vector<long long> aj(n_all * k), bj(n_qry * k);
-  std::vector<float> ad(n_all * k), bd(n_qry * k);
+  std::vector<long long> aj, bj;
+  std::vector<float> ad, bd;
   {
-    long long *d_i = nullptr, *d_j = nullptr;
-    float *d_d = nullptr;
-    auto release = [&]() {
-      if (d_i) (void)hipFree(d_i);
-      if (d_j) (void)hipFree(d_j);
-      if (d_d) (void)hipFree(d_d);
-    };
-    if (hipMalloc(reinterpret_cast<void **>(&d_i), n_all * k * 8) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void **>(&d_j), n_all * k * 8) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void **>(&d_d), n_all * k * 4) != hipSuccess) {
-      release();
-      return ppk_fail(PPK_ERR_HIP, "hipMalloc(neighbour lists) failed");
-    }
+    std::lock_guard<std::mutex> lk(g_query_mu);
     // refs x queries: sample s < n_ref -> its nearest queries (numbered n_ref + q), sample n_ref + q -> its nearest refs
-    int rc = ppk_knn_band_dev(ref, qry, kmers, random_tbl, n_clu, flags, knn, dist_col, 0, n_qry, -1, d_i, d_j, d_d, nullptr,
-                              nullptr);
-    if (rc == PPK_OK && (hipDeviceSynchronize() != hipSuccess || hipMemcpy(aj.data(), d_j, n_all * k * 8, hipMemcpyDeviceToHost) != hipSuccess ||
-                         hipMemcpy(ad.data(), d_d, n_all * k * 4, hipMemcpyDeviceToHost) != hipSuccess))
-      rc = ppk_fail(PPK_ERR_HIP, "neighbour lists: execution or download failed");
+    int rc = knn_lists_locked(refs, qrys, n_dev, kmers, random_tbl, n_clu, flags, knn, dist_col, aj, ad);
     // queries among themselves
-    if (rc == PPK_OK)
-      rc = ppk_knn_band_dev(qry, nullptr, kmers, random_tbl, n_clu, flags, knn, dist_col, 0, n_qry, -1, d_i, d_j, d_d, nullptr,
-                            nullptr);
-    if (rc == PPK_OK && (hipDeviceSynchronize() != hipSuccess || hipMemcpy(bj.data(), d_j, n_qry * k * 8, hipMemcpyDeviceToHost) != hipSuccess ||
-                         hipMemcpy(bd.data(), d_d, n_qry * k * 4, hipMemcpyDeviceToHost) != hipSuccess))
-      rc = ppk_fail(PPK_ERR_HIP, "neighbour lists: execution or download failed");
-    release();
+    if (rc == PPK_OK) rc = knn_lists_locked(qrys, nullptr, n_dev, kmers, random_tbl, n_clu, flags, knn, dist_col, bj, bd);
     if (rc != PPK_OK) return rc;
   }
   // row starts of the sparse matrix (src/extend.cpp:15-38)
@@ -1975,4 +1978,12 @@ extern "C" int ppk_extend_sketches(const long long *rr_i, const long long *rr_j,
   memcpy(j_out, oj.data(), oj.size() * 8);
   memcpy(d_out, od.data(), od.size() * 4);
   return PPK_OK;
+}
+
+extern "C" int ppk_extend_sketches(const long long *rr_i, const long long *rr_j, const float *rr_d, size_t nnz,
+                                   const ppk_db *ref, const ppk_db *qry, const int32_t *kmers, const float *random_tbl,
+                                   size_t n_clu, int flags, int knn, int dist_col, long long *i_out, long long *j_out,
+                                   float *d_out, size_t cap, size_t *n_out) {
+  return ppk_extend_sketches_dbs(rr_i, rr_j, rr_d, nnz, &ref, &qry, 1, kmers, random_tbl, n_clu, flags, knn, dist_col, i_out,
+                                 j_out, d_out, cap, n_out);
 }

@@ -527,7 +527,13 @@ def extend_from_sketches(rr_mat, ref, qry, kmers, random_tbl, knn, dist_col=0, r
     the queries in the place of the two dense matrices (ppk_extend_sketches): -> (i, j, dist) numpy arrays,
     queries numbered n_ref + q."""
     import numpy as np
-    _check_pair(ref, qry)
+    refs = [ref] if isinstance(ref, SketchDB) else list(ref)        # one pair of databases per device
+    qrys = [qry] if isinstance(qry, SketchDB) else list(qry)
+    if len(refs) != len(qrys):
+        raise ValueError("one query database per reference database")
+    for a, b in zip(refs, qrys):
+        _check_pair(a, b)
+    ref, qry = refs[0], qrys[0]
     r, c, d = rr_mat
     r = np.ascontiguousarray(np.asarray(r).astype(np.int64, copy=False)).ravel()
     c = np.ascontiguousarray(np.asarray(c).astype(np.int64, copy=False)).ravel()
@@ -537,8 +543,10 @@ def extend_from_sketches(rr_mat, ref, qry, kmers, random_tbl, knn, dist_col=0, r
     oi, oj, od = np.empty(cap, dtype=np.int64), np.empty(cap, dtype=np.int64), np.empty(cap, dtype=np.float32)
     n = C.c_size_t(0)
     ll, fp = C.POINTER(C.c_longlong), C.POINTER(C.c_float)
-    rc = _lib.lib().ppk_extend_sketches(r.ctypes.data_as(ll), c.ctypes.data_as(ll), d.ctypes.data_as(fp), r.size,
-                                        ref._h, qry._h, kmers.ctypes.data_as(C.POINTER(C.c_int32)), tbl_ptr, n_clu,
+    rh = (C.c_void_p * len(refs))(*[x._h.value for x in refs])
+    qh = (C.c_void_p * len(refs))(*[x._h.value for x in qrys])
+    rc = _lib.lib().ppk_extend_sketches_dbs(r.ctypes.data_as(ll), c.ctypes.data_as(ll), d.ctypes.data_as(fp), r.size,
+                                        rh, qh, len(refs), kmers.ctypes.data_as(C.POINTER(C.c_int32)), tbl_ptr, n_clu,
                                         FLAG_RANDOM_CORRECT if random_correct else 0, int(knn), int(dist_col),
                                         oi.ctypes.data_as(ll), oj.ctypes.data_as(ll), od.ctypes.data_as(fp), cap,
                                         C.byref(n))

@@ -547,7 +547,8 @@ def extendFromDatabases(rr_mat, ref_db_name, query_db_name, rList, qList, klist,
     """poppunk_refine.extend for queries that are still sketches: what PopPUNK's lineage assignment computes with
     queryDatabase (query x ref), queryDatabase (query self), longToSquare and extend (PopPUNK/models.py:1355-1372),
     from the two databases and the references' sparse neighbour matrix `rr_mat` = (row, col, data) -- neither
-    dense matrix is made.  Returns (i, j, dist) arrays, queries numbered len(rList) + q.  kNN <= 32."""
+    dense matrix is made.  Returns (i, j, dist) arrays, queries numbered len(rList) + q.  kNN <= 32.  device_id /
+    PPK_DEVICES as queryDatabase: every listed device takes a band of the query rows of both passes."""
     klist = [int(k) for k in np.asarray(klist).ravel()]
     rList = [str(x) for x in rList]
     qList = [str(x) for x in qList]
@@ -557,8 +558,9 @@ def extendFromDatabases(rr_mat, ref_db_name, query_db_name, rList, qList, klist,
     try:
         lib = _lib.lib()
         tptr, n_clu, rclu, qclu, keep = _table_args(table, random_correct, ref_clu, qry_clu, True)
-        dev = _devices(device_id)[:1]
-        rh, qh = ref_e.resident(dev, rclu)[0], qry_e.resident(dev, qclu)[0]
+        devs = _devices(device_id)
+        rh = (C.c_void_p * len(devs))(*[h.value for h in ref_e.resident(devs, rclu)])
+        qh = (C.c_void_p * len(devs))(*[h.value for h in qry_e.resident(devs, qclu)])
         r, c, d = rr_mat
         r = np.ascontiguousarray(np.asarray(r).astype(np.int64, copy=False)).ravel()
         c = np.ascontiguousarray(np.asarray(c).astype(np.int64, copy=False)).ravel()
@@ -568,8 +570,8 @@ def extendFromDatabases(rr_mat, ref_db_name, query_db_name, rList, qList, klist,
         oi, oj, od = np.empty(cap, dtype=np.int64), np.empty(cap, dtype=np.int64), np.empty(cap, dtype=np.float32)
         n = C.c_size_t(0)
         ll, fp = C.POINTER(C.c_longlong), C.POINTER(C.c_float)
-        rc = lib.ppk_extend_sketches(r.ctypes.data_as(ll), c.ctypes.data_as(ll), d.ctypes.data_as(fp), r.size, rh, qh,
-                                     kmers.ctypes.data_as(C.POINTER(C.c_int32)), tptr, n_clu,
+        rc = lib.ppk_extend_sketches_dbs(r.ctypes.data_as(ll), c.ctypes.data_as(ll), d.ctypes.data_as(fp), r.size, rh, qh,
+                                     len(devs), kmers.ctypes.data_as(C.POINTER(C.c_int32)), tptr, n_clu,
                                      _flags(random_correct, False, False), int(kNN), int(dist_col),
                                      oi.ctypes.data_as(ll), oj.ctypes.data_as(ll), od.ctypes.data_as(fp), cap, C.byref(n))
         del keep

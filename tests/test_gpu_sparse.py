@@ -225,12 +225,13 @@ def test_extend_from_sketches_equals_extend_on_the_dense_matrices(n_ref, n_qry, 
             want = oracle.extend(*coo, qq_sq, qr_rect, knn)
             got = engine.extend_from_sketches(coo, rdb, qdb, kmers, tbl, knn, dist_col=col)
             _same(got, want)
+            _same(engine.extend_from_sketches(coo, [rdb] * 3, [qdb] * 3, kmers, tbl, knn, dist_col=col), want)
             _same(poppunk_refine.extend_arrays(coo, qq_sq, qr_rect, knn), want)
     rdb.close()
     qdb.close()
 
 
-def test_lineage_ranks_extended_from_databases(tmp_path):
+def test_lineage_ranks_extended_from_databases(tmp_path, monkeypatch):
     from poppunk_amd import models, pp_sketchlib, sketchdb, synth
     kmers = np.asarray(synth.DEFAULT_KMERS, dtype=np.int32)
     sk, _ = synth.make_sketches(500, kmers, cluster_size=25, seed=8)
@@ -247,7 +248,9 @@ def test_lineage_ranks_extended_from_databases(tmp_path):
     qq = pp_sketchlib.queryDatabase(qdb, qdb, names[380:], names[380:], klist, True, False, 1, True, 0)
     qr = pp_sketchlib.queryDatabase(rdb, qdb, names[:380], names[380:], klist, True, False, 1, True, 0)
     ya = a.extend(qq, qr)
+    monkeypatch.setenv("PPK_DEVICES", "0,0")
     yb = b.extend_from_databases(rdb, qdb, names[:380], names[380:], klist)
+    monkeypatch.delenv("PPK_DEVICES")
     assert ya == yb and len(ya) > 500
     for m, w in ((b.nn_dists, a.nn_dists), (b.lower_rank_dists[2], a.lower_rank_dists[2])):
         assert np.array_equal(m.row, w.row) and np.array_equal(m.col, w.col) and np.array_equal(m.data, w.data)
