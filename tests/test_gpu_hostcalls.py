@@ -454,3 +454,44 @@ def test_queryDatabaseKNN_mirror(tmp_path, monkeypatch):
     i, j, d = pp_sketchlib.queryDatabaseKNN(db, sub, klist, 3, dist_col=1)
     assert np.array_equal(j, ws[1]) and np.array_equal(d, ws[2])
     pp_sketchlib.clear_cache()
+
+
+def test_repeated_host_calls_do_not_leak_device_memory():
+    """Every host entry point of the round, 25 times over: after ppk_release_scratch the device has as much free
+    memory as after the first pass (what stays is scratch, caches and resident databases -- all released)."""
+    import torch
+    from poppunk_amd import qc
+    sk, _ = synth.make_sketches(600, KMERS, cluster_size=30, seed=2)
+    tbl = synth.random_match_table(KMERS)
+    dist, _ = pp_sketchlib.query_arrays(sk, None, KMERS, 16, 14, tbl)
+    x_max, y_max = synth.boundary_for_quantile(dist, 0.1)
+    sq = pp_sketchlib.longToSquare(np.ascontiguousarray(dist[:, 0]))
+    qq, _ = pp_sketchlib.query_arrays(sk[500:], None, KMERS, 16, 14, tbl)
+    qr, _ = pp_sketchlib.query_arrays(sk[:500], sk[500:], KMERS, 16, 14, tbl)
+
+    def one_pass():
+        pp_sketchlib.query_arrays(sk, None, KMERS, 16, 14, tbl, devices=(0, 0))
+        pp_sketchlib.query_edges_arrays(sk, None, KMERS, 16, 14, 2, x_max, y_max, random_table=tbl, devices=(0, 0), cap=5)
+        pp_sketchlib.query_knn_arrays(sk, KMERS, 16, 14, 4, 0, tbl, devices=(0, 0))
+        poppunk_refine.assignThreshold(dist, 2, x_max, y_max)
+        poppunk_refine.edgeThreshold_array(dist, 2, x_max, y_max)
+        poppunk_refine.thresholdIterate1D_arrays(dist, np.linspace(0, 0.2, 7), 2, 0.0, 0.0, x_max, y_max)
+        poppunk_refine.generateAllTuples_array(300)
+        qc.qc_edge_lists(dist, 0, 0.02, 0.3)
+        nn = poppunk_refine.get_kNN_distances(sq, 6)
+        poppunk_refine.lowerRank_arrays(nn, 600, 2, True, True, 1e-4)
+        sub = poppunk_refine.get_kNN_distances(np.ascontiguousarray(sq[:500, :500]), 6)
+        poppunk_refine.extend_arrays(sub, oracle.long_to_square(qq[:, 0]), np.ascontiguousarray(qr[:, 0].reshape(100, 500).T), 6)
+
+    def free_bytes():
+        pp_sketchlib.clear_cache()               # resident databases, query buffers, scratch
+        _lib.lib().ppk_release_scratch()
+        torch.cuda.synchronize()
+        return torch.cuda.mem_get_info(0)[0]
+
+    one_pass()
+    base = free_bytes()
+    for _ in range(25):
+        one_pass()
+    after = free_bytes()
+    assert base - after < (64 << 20), "device memory shrank by %d MB over 25 passes" % ((base - after) >> 20)
