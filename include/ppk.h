@@ -299,8 +299,10 @@ int ppk_assign_threshold(const float *dist, size_t n_rows, int slope, float x_ma
  * thread, which fetches it with ppk_parked_fetch into a buffer of that size -- "ask the size, then
  * fetch" costs one upload and one device pass (also for the two sweeps below).  The hand-over is
  * explicit: no call is ever answered from a parked result, so a rewritten or recycled input array
- * cannot meet a stale list; calling the same entry point again with more room simply recomputes.  A
- * parked result is dropped by the next call of this family (any thread) and by ppk_release_scratch. */
+ * cannot meet a stale list; calling the same entry point again with more room simply recomputes.  Every
+ * thread has its own slot: a parked result is dropped by the SAME thread's next call of this family, by its
+ * fetch and by ppk_release_scratch -- never by another thread's call, so concurrent callers do not disturb
+ * each other's hand-over (at most 16 threads hold one at a time; the oldest goes first). */
 int ppk_edge_threshold(const float *dist, size_t n_rows, size_t n_ref, int slope,
                        float x_max, float y_max, int inclusive, int device_id,
                        long long *ij_out, size_t cap, size_t *n_edges);

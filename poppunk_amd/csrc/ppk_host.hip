@@ -15,6 +15,8 @@
 #include <unistd.h>
 #include <vector>
 
+#include <map>
+
 #include "ppk_internal.h"
 
 // ---- pool of parked helper threads (ppk_internal.h) ------------------------------------------------
@@ -1175,13 +1177,14 @@ extern "C" int ppk_assign_threshold(const float *dist, size_t n_rows, int slope,
 // ---- host results of data-dependent size: ONE pass, explicit fetch ---------------------------------
 // The Python / pybind side cannot know the size of an edge list in advance.  A call whose buffer is
 // too small has nevertheless computed the whole list: it returns PPK_ERR_CAPACITY with the size and
-// leaves the list PARKED on the device for the calling thread, which fetches it with
-// ppk_parked_fetch() into a buffer of that size -- one upload, one device pass.  The hand-over is
-// explicit: no later call is ever answered from a parked result (round 2 matched a token of the
-// pointer and the scalar arguments, which a rewritten or recycled array would have matched too).  Any
-// other host-result call, on any thread, drops what is parked.
+// leaves the list PARKED for the calling thread, which fetches it with ppk_parked_fetch() into a buffer of
+// that size -- one upload, one device pass.  The hand-over is explicit: no later call is ever answered from
+// a parked result (round 2 matched a token of the pointer and the scalar arguments, which a rewritten or
+// recycled array would have matched too).  Every thread has its own slot: what a thread parked is dropped by
+// ITS next call of the family (or its fetch), never by another thread's -- concurrent callers do not disturb
+// each other's two-step hand-over; at most kParkedThreads slots exist (the oldest goes first).
 struct ParkedResult {
-  std::thread::id owner;
+  unsigned long long stamp = 0;
   int device = -1;
   int arrays = 0;                 // 1: int64 [n][2] contiguous; 3: int64 [3][cap_used] (i, j, offset index)
   void *d = nullptr;
@@ -1189,15 +1192,40 @@ struct ParkedResult {
   std::vector<long long> host;    // ... or a list that is already on the host (several devices' lists, concatenated)
 };
 static std::mutex g_parked_mu;
-static ParkedResult g_parked;
+static std::map<std::thread::id, ParkedResult> g_parked;
+static unsigned long long g_parked_stamp = 0;
+constexpr size_t kParkedThreads = 16;
 
-
-static void parked_drop_locked() {
-  if (g_parked.d) {
-    DeviceGuard g(g_parked.device);
-    (void)hipFree(g_parked.d);
+static void parked_free(ParkedResult &p) {
+  if (p.d) {
+    DeviceGuard g(p.device);
+    (void)hipFree(p.d);
   }
-  g_parked = ParkedResult();
+  p = ParkedResult();
+}
+
+// drops what the calling thread has parked
+static void parked_drop_own() {
+  std::lock_guard<std::mutex> lk(g_parked_mu);
+  auto it = g_parked.find(std::this_thread::get_id());
+  if (it != g_parked.end()) {
+    parked_free(it->second);
+    g_parked.erase(it);
+  }
+}
+
+// parks `r` for the calling thread (it holds nothing: parked_drop_own ran at the start of its call)
+static void parked_put(ParkedResult &&r) {
+  std::lock_guard<std::mutex> lk(g_parked_mu);
+  while (g_parked.size() >= kParkedThreads) {
+    auto oldest = g_parked.begin();
+    for (auto it = g_parked.begin(); it != g_parked.end(); ++it)
+      if (it->second.stamp < oldest->second.stamp) oldest = it;
+    parked_free(oldest->second);
+    g_parked.erase(oldest);
+  }
+  r.stamp = ++g_parked_stamp;
+  g_parked[std::this_thread::get_id()] = std::move(r);
 }
 
 // compute(cap_entries, &d_result, &n): runs the whole job into a fresh device buffer of cap entries
@@ -1206,8 +1234,7 @@ static void parked_drop_locked() {
 int ppk_host_result(int arrays, int device, size_t guess, size_t cap, size_t *n_out,
                     const std::function<int(size_t, void **, unsigned long long *)> &compute,
                     const std::function<int(const void *, size_t, size_t)> &copy_out) {
-  std::lock_guard<std::mutex> lk(g_parked_mu);
-  parked_drop_locked();
+  parked_drop_own();
   void *d = nullptr;
   unsigned long long want = 0;
   size_t cap_used = guess ? guess : 1;
@@ -1225,12 +1252,13 @@ int ppk_host_result(int arrays, int device, size_t guess, size_t cap, size_t *n_
   const size_t n = (size_t)want;
   *n_out = n;
   if (n > cap) {
-    g_parked.owner = std::this_thread::get_id();
-    g_parked.device = device;
-    g_parked.arrays = arrays;
-    g_parked.d = d;
-    g_parked.n = n;
-    g_parked.cap_used = cap_used;
+    ParkedResult r;
+    r.device = device;
+    r.arrays = arrays;
+    r.d = d;
+    r.n = n;
+    r.cap_used = cap_used;
+    parked_put(std::move(r));
     return ppk_fail(PPK_ERR_CAPACITY, "output too small: need " + std::to_string(n) +
                                           " entries (parked: ppk_parked_fetch)");
   }
@@ -1241,34 +1269,42 @@ int ppk_host_result(int arrays, int device, size_t guess, size_t cap, size_t *n_
 
 void ppk_parked_clear() {
   std::lock_guard<std::mutex> lk(g_parked_mu);
-  parked_drop_locked();
+  for (auto &kv : g_parked) parked_free(kv.second);
+  g_parked.clear();
 }
 
 extern "C" int ppk_parked_fetch(long long *out0, long long *out1, long long *out2, size_t cap, size_t *n_out) {
-  std::lock_guard<std::mutex> lk(g_parked_mu);
   if (n_out) *n_out = 0;
-  if ((!g_parked.d && g_parked.host.empty()) || g_parked.owner != std::this_thread::get_id())
-    return ppk_fail(PPK_ERR_STATE, "ppk_parked_fetch: this thread's last call parked no result");
-  if (n_out) *n_out = g_parked.n;
-  if (cap < g_parked.n) return ppk_fail(PPK_ERR_CAPACITY, "output too small: need " + std::to_string(g_parked.n));
-  if (!out0 || (g_parked.arrays == 3 && (!out1 || !out2))) return ppk_fail(PPK_ERR_ARG, "ppk_parked_fetch: NULL output");
-  if (!g_parked.host.empty()) {
-    memcpy(out0, g_parked.host.data(), g_parked.n * 16);
-    parked_drop_locked();
+  ParkedResult r;
+  {
+    std::lock_guard<std::mutex> lk(g_parked_mu);
+    auto it = g_parked.find(std::this_thread::get_id());
+    if (it == g_parked.end() || (!it->second.d && it->second.host.empty()))
+      return ppk_fail(PPK_ERR_STATE, "ppk_parked_fetch: this thread's last call parked no result");
+    if (n_out) *n_out = it->second.n;
+    if (cap < it->second.n) return ppk_fail(PPK_ERR_CAPACITY, "output too small: need " + std::to_string(it->second.n));
+    if (!out0 || (it->second.arrays == 3 && (!out1 || !out2))) return ppk_fail(PPK_ERR_ARG, "ppk_parked_fetch: NULL output");
+    r = std::move(it->second);        // the slot is this call's now: copied out and freed outside the lock
+    g_parked.erase(it);
+  }
+  if (!r.host.empty()) {
+    memcpy(out0, r.host.data(), r.n * 16);
     return PPK_OK;
   }
-  DeviceGuard g(g_parked.device);
-  const long long *buf = static_cast<const long long *>(g_parked.d);
-  const size_t n = g_parked.n, cu = g_parked.cap_used;
   hipError_t e;
-  if (g_parked.arrays == 1) {
-    e = hipMemcpy(out0, buf, n * 16, hipMemcpyDeviceToHost);
-  } else {
-    e = hipMemcpy(out0, buf, n * 8, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(out1, buf + cu, n * 8, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(out2, buf + 2 * cu, n * 8, hipMemcpyDeviceToHost);
+  {
+    DeviceGuard g(r.device);
+    const long long *buf = static_cast<const long long *>(r.d);
+    const size_t n = r.n, cu = r.cap_used;
+    if (r.arrays == 1) {
+      e = hipMemcpy(out0, buf, n * 16, hipMemcpyDeviceToHost);
+    } else {
+      e = hipMemcpy(out0, buf, n * 8, hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpy(out1, buf + cu, n * 8, hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpy(out2, buf + 2 * cu, n * 8, hipMemcpyDeviceToHost);
+    }
   }
-  parked_drop_locked();
+  parked_free(r);
   if (e != hipSuccess) return ppk_fail(PPK_ERR_HIP, std::string("hipMemcpy D2H failed: ") + hipGetErrorString(e));
   return PPK_OK;
 }
@@ -1585,15 +1621,15 @@ int query_edges_dbs_locked(const ppk_db *const *refs, const ppk_db *const *qrys,
     if (n_failed) *n_failed += p.failed;
   }
   *n_edges = total;
-  std::lock_guard<std::mutex> lp(g_parked_mu);
-  parked_drop_locked();
+  parked_drop_own();
   if (total > cap) {
     // the whole list is done: it waits (on the host) for the calling thread's ppk_parked_fetch
-    g_parked.owner = std::this_thread::get_id();
-    g_parked.arrays = 1;
-    g_parked.n = total;
-    g_parked.host.reserve(total * 2);
-    for (EdgePart &p : parts) g_parked.host.insert(g_parked.host.end(), p.edges.begin(), p.edges.end());
+    ParkedResult r;
+    r.arrays = 1;
+    r.n = total;
+    r.host.reserve(total * 2);
+    for (EdgePart &p : parts) r.host.insert(r.host.end(), p.edges.begin(), p.edges.end());
+    parked_put(std::move(r));
     return ppk_fail(PPK_ERR_CAPACITY, "output too small: need " + std::to_string(total) + " entries (parked: ppk_parked_fetch)");
   }
   if (total && !ij_out) return ppk_fail(PPK_ERR_ARG, "ij_out is NULL");

@@ -495,3 +495,44 @@ def test_repeated_host_calls_do_not_leak_device_memory():
         one_pass()
     after = free_bytes()
     assert base - after < (64 << 20), "device memory shrank by %d MB over 25 passes" % ((base - after) >> 20)
+
+
+def test_host_entry_points_from_four_threads_at_once():
+    """The library is called from any thread (PopPUNK's refine optimiser runs thresholdIterate2D from a pool;
+    a web service answers queries concurrently): four threads, each looping over a different group of entry
+    points, get what a single thread gets."""
+    from poppunk_amd import qc
+    sk, _ = synth.make_sketches(500, KMERS, cluster_size=25, seed=12)
+    tbl = synth.random_match_table(KMERS)
+    dist, _ = pp_sketchlib.query_arrays(sk, None, KMERS, 16, 14, tbl)
+    x_max, y_max = synth.boundary_for_quantile(dist, 0.1)
+    sq = pp_sketchlib.longToSquare(np.ascontiguousarray(dist[:, 1]))
+
+    jobs = [
+        lambda: pp_sketchlib.query_arrays(sk, None, KMERS, 16, 14, tbl)[0],
+        lambda: pp_sketchlib.query_edges_arrays(sk, None, KMERS, 16, 14, 2, x_max, y_max, random_table=tbl)[0],
+        lambda: np.stack(pp_sketchlib.query_knn_arrays(sk, KMERS, 16, 14, 5, 1, tbl)[1:2]),
+        lambda: poppunk_refine.edgeThreshold_array(dist, 2, x_max, y_max),
+        lambda: np.stack(poppunk_refine.lowerRank_arrays(poppunk_refine.get_kNN_distances(sq, 7), 500, 3, True, False, 0.0)[:2]),
+        lambda: qc.qc_edge_lists(dist, 0, 0.02, 0.3)[0],
+        lambda: poppunk_refine.assignThreshold(dist, 1, x_max, y_max),
+        lambda: np.stack(poppunk_refine.thresholdIterate2D_arrays(dist, np.linspace(0.01, x_max, 6), y_max)),
+    ]
+    want = [j() for j in jobs]
+    errors = []
+
+    def worker(t):
+        try:
+            for rep in range(6):
+                for idx in range(t, len(jobs), 4):          # thread t: jobs t and t + 4
+                    if not np.array_equal(jobs[idx](), want[idx]):
+                        errors.append("thread %d job %d rep %d differs" % (t, idx, rep))
+        except Exception as e:  # noqa: BLE001
+            errors.append("thread %d: %r" % (t, e))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:4]
