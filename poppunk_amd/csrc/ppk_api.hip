@@ -53,6 +53,8 @@ const OptionEntry kOptions[] = {
     {"progress", "PPK_PROGRESS", &PpkConfig::progress},
     {"launch_tiles", "PPK_LAUNCH_TILES", &PpkConfig::launch_tiles},
     {"knn_list", "PPK_KNN_LIST", &PpkConfig::knn_list},
+    {"knn_warm", "PPK_KNN_WARM", &PpkConfig::knn_warm},
+    {"knn_cut", "PPK_KNN_CUT", &PpkConfig::knn_cut},
     {"host_parts", "PPK_HOST_PARTS", &PpkConfig::host_parts},
     {"host_trace", "PPK_HOST_TRACE", &PpkConfig::host_trace},
     {"ext_collision_adjust", "PPK_EXT_COLLISION_ADJUST", &PpkConfig::ext_collision_adjust},
@@ -681,9 +683,36 @@ int ppk_knn_band_dev(const ppk_db *db, const ppk_db *qry, const int32_t *kmers, 
   auto vals = [&]() { return reinterpret_cast<uint64_t *>(static_cast<char *>(d_cand) + vals_off); };
   unsigned long long count = 0;
   size_t piece = ppk_rows_per_dispatch(db);
+  // A bound that comes from ONE tile is the k-th smallest of 256 (a query's) or 32 (a ref's) distances; the
+  // k-th smallest of a few thousand is far lower.  So a job of some size opens with a few percent of its rows,
+  // cuts the list -- which sets every bound to the k-th distance among those -- and runs the rest under them:
+  // at 100 000 genomes the stream drops from 940 (k = 5) / 3 400 (10) / 11 000 (20) candidates per sample.
+  const long long warm_opt = ppk_config().knn_warm.load();
+  size_t warm = 0;        // rows of the opening piece (0: none)
+  const bool big = q_end - q_begin >= 16384 || ppk_config().knn_list.load() > 0;   // small jobs: one pass, as ever
+  if (warm_opt != 0 && big) {
+    warm = (q_end - q_begin) / (size_t)(warm_opt > 0 ? warm_opt : 32) / 64 * 64;
+    if (warm < 64) warm = 64;
+  }
+  // Pieces: at most what one dispatch holds (`piece`).  The opening piece runs without any bound, so it is
+  // also kept below what the list can take in the worst case -- every tile emitting knn candidates for each of
+  // its 32 queries and 2 * min(knn, 16) for each of its 256 refs (a million genomes, k = 10: 3 200 rows; one of
+  // 31 000 emitted 7.9 G candidates into a list of 2.1 G).  Once bounds exist a piece emits a small fraction of
+  // that, so the length doubles after every piece that used less than a quarter of the free room.
+  const size_t r_tiles = (db->n + 255) / 256;
+  const size_t worst_per_tile = 32 * (size_t)knn + 512 * (size_t)(knn < 16 ? knn : 16);
+  auto rows_that_fit = [&](unsigned long long held) {
+    size_t rows = (size_t)((cap - (size_t)held) / worst_per_tile / r_tiles) * 32 / 64 * 64;
+    return rows < 64 ? (size_t)64 : rows;
+  };
+  size_t cur = piece;
+  if (warm && warm < cur) cur = warm;
+  if (big && rows_that_fit(0) < cur && q_end - q_begin > rows_that_fit(0)) cur = rows_that_fit(0);
+  const bool staged = cur < q_end - q_begin && cur < piece;      // the job opens with a short piece and a cut
   bool tables_built = lut_ready;
   for (size_t lo = q_begin; lo < q_end && n > 1;) {
-    const size_t hi = lo + piece < q_end ? lo + piece : q_end;
+    const size_t this_piece = cur;
+    const size_t hi = lo + this_piece < q_end ? lo + this_piece : q_end;
     const unsigned long long before = count;
     rc = ppk_launch_dist(db, qry, kmers, d_rtab, d_rtab ? n_clu : 1, flags, lo, hi, d_cand, nullptr,
                          static_cast<uint64_t *>(d_state), 2, 0.f, 0.f, 1.f, 1.f, 1, d_lut, s, knn_args, tables_built);
@@ -691,6 +720,9 @@ int ppk_knn_band_dev(const ppk_db *db, const ppk_db *qry, const int32_t *kmers, 
     tables_built = true;
     rc = read_count(&count);
     if (rc != PPK_OK) return rc;
+    if (ppk_config().host_trace.load())
+      fprintf(stderr, "[ppk knn] rows %zu..%zu: list %llu -> %llu of %zu%s\n", lo, hi, before, count, cap,
+              count > cap ? " (does not fit)" : "");
     if (count > cap) {
       // the piece did not fit: what it wrote is dropped (a second copy of a pair would break the selection),
       // room is made, and the piece runs again -- under the bounds it has tightened meanwhile
@@ -709,15 +741,23 @@ int ppk_knn_band_dev(const ppk_db *db, const ppk_db *qry, const int32_t *kmers, 
         rc = room(cap);
         if (rc == PPK_OK) rc = ppk_launch_knn_state_init(d_state, n, cap, vals_off, 0, s);
         if (rc != PPK_OK) return rc;
-      } else if (piece > 64) {
-        piece = (piece / 2 + 63) / 64 * 64;                         // nothing left to drop: smaller pieces
+      } else if (cur > 64) {
+        cur = (cur / 2 + 63) / 64 * 64;                             // nothing left to drop: smaller pieces
       } else {
         return ppk_fail(PPK_ERR_CAPACITY, "neighbour candidates keep overflowing their buffer");
       }
       continue;
     }
+    const bool opening = staged && lo == q_begin;
+    const unsigned long long emitted = count - before;
     lo = hi;
-    if (lo < q_end && count > cap / 2 && count > n * (unsigned long long)knn) {
+    if (emitted < (cap - (size_t)before) / 4 && cur < piece) cur = cur * 2 < piece ? cur * 2 : piece;
+    // cut when the list is half full -- or, in a staged job, as soon as it holds 16 lists' worth: a cut costs a
+    // sort of what is there and leaves every bound at the true k-th distance so far, after which a piece emits a
+    // small fraction of what it did (1 M genomes: 300 M per 65 000 rows before the second cut, 5 M after)
+    const unsigned long long lists = (unsigned long long)ppk_config().knn_cut.load() * n * (unsigned long long)knn;
+    const unsigned long long cut_at = staged && lists > 0 && lists < cap / 2 ? lists : cap / 2;
+    if (lo < q_end && (count > cut_at || opening) && count > n * (unsigned long long)knn) {
       rc = ppk_knn_compact(db->device, keys(), vals(), (size_t)count, n, knn, d_state, d_i, d_j, d_dist, s);
       if (rc != PPK_OK) return rc;
       count = n * (unsigned long long)knn;

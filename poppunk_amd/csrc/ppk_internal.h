@@ -46,6 +46,8 @@ struct PpkConfig {
   std::atomic<long long> progress{1};           // PPK_PROGRESS: progress meter of long host calls on fd 2
   std::atomic<long long> host_trace{0};         // PPK_HOST_TRACE: timeline of a host query on fd 2 (measurement)
   std::atomic<long long> launch_tiles{8000000}; // PPK_LAUNCH_TILES: pair tiles per kernel launch (a dispatch holds < 2^32 work-items)
+  std::atomic<long long> knn_warm{32};          // PPK_KNN_WARM: the neighbour mode opens with 1/knn_warm of its rows, then cuts the list (0 = off)
+  std::atomic<long long> knn_cut{4};            // PPK_KNN_CUT: a staged neighbour job cuts its list at knn_cut * n * knn entries (0: only when half full)
   std::atomic<long long> knn_list{0};           // PPK_KNN_LIST: entries of the neighbour-candidate list (0 = sized from n and knn)
   std::atomic<long long> host_parts{2};         // PPK_HOST_PARTS: worker threads of a one-device host query (>= 16 Mi rows)
   // [EXT] a4: 0 = the b-bit collision adjustment is never in effect (upstream as recalled: it is
