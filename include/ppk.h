@@ -448,6 +448,15 @@ int ppk_knn_sketches_dev(const ppk_db *db, const int32_t *kmers, const float *ra
                          size_t n_clu, int flags, int knn, int dist_col, long long *d_i,
                          long long *d_j, float *d_dist, unsigned long long *n_candidates,
                          void *stream);
+/* One band [q_begin, q_end) of the triangle's rows (the unit of multi-GPU sharding, ppk_band_split): the best
+ * knn per sample among the band's pairs -- a pair belongs to the band of its smaller sample and is a candidate
+ * for both of its samples -- with unfilled slots marked j = -1.  Merging the bands' lists per sample by
+ * (distance bits, j) gives ppk_knn_sketches_dev's result (engine.knn_sharded; ppk_query_knn_dbs does it for
+ * the devices of one process). */
+int ppk_knn_sketches_band_dev(const ppk_db *db, const int32_t *kmers, const float *random_tbl,
+                              size_t n_clu, int flags, int knn, int dist_col, size_t q_begin,
+                              size_t q_end, long long *d_i, long long *d_j, float *d_dist,
+                              unsigned long long *n_candidates, void *stream);
 /* The same for a reference x query job, one pass over the rectangle: outputs [(n_ref + n_qry) * knn]; sample
  * s < n_ref is reference s and its neighbours are its knn nearest QUERIES (numbered n_ref + q), sample n_ref + q
  * is query q and its neighbours are its knn nearest REFERENCES -- the two dense sides of poppunk_refine.extend's

@@ -95,6 +95,8 @@ SIGNATURES = {
                                     _f32p]),
     "ppk_query_knn": (C.c_int, [_u64p, _sz, _i32p, _sz, _sz, _sz, _f32p, _u16p, _sz, C.c_int, C.c_int, C.c_int, _intp,
                                 C.c_int, _llp, _llp, _f32p]),
+    "ppk_knn_sketches_band_dev": (C.c_int, [_vp, _i32p, _f32p, _sz, C.c_int, C.c_int, C.c_int, _sz, _sz, _vp, _vp, _vp, _ullp,
+                                            _vp]),
     "ppk_knn_sketches_rq_dev": (C.c_int, [_vp, _vp, _i32p, _f32p, _sz, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _ullp, _vp]),
     "ppk_extend_sketches": (C.c_int, [_llp, _llp, _f32p, _sz, _vp, _vp, _i32p, _f32p, _sz, C.c_int, C.c_int, C.c_int, _llp,
                                       _llp, _f32p, _sz, _szp]),

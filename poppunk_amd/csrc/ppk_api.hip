@@ -775,6 +775,16 @@ extern "C" int ppk_knn_sketches_dev(const ppk_db *db, const int32_t *kmers, cons
                           d_dist, n_candidates, stream);
 }
 
+// One band of the triangle's rows (multi-GPU: a band per rank): the best knn per sample among the band's pairs,
+// unfilled slots marked j = -1; the bands' lists merge into the whole job's (a pair belongs to one band).
+extern "C" int ppk_knn_sketches_band_dev(const ppk_db *db, const int32_t *kmers, const float *random_tbl,
+                                         size_t n_clu, int flags, int knn, int dist_col, size_t q_begin,
+                                         size_t q_end, long long *d_i, long long *d_j, float *d_dist,
+                                         unsigned long long *n_candidates, void *stream) {
+  return ppk_knn_band_dev(db, nullptr, kmers, random_tbl, n_clu, flags, knn, dist_col, q_begin, q_end, -1, d_i, d_j,
+                          d_dist, n_candidates, stream);
+}
+
 // ref x query: the knn nearest QUERIES of every reference (samples 0 .. n_ref-1, neighbours numbered n_ref + q)
 // and the knn nearest REFERENCES of every query (samples n_ref + q), from one pass over the rectangle's tiles.
 extern "C" int ppk_knn_sketches_rq_dev(const ppk_db *ref, const ppk_db *qry, const int32_t *kmers,

@@ -602,36 +602,76 @@ def knn_select(keys, vals, n, knn):
     return oi, oj, od
 
 
+def knn_band(db, kmers, random_tbl, knn, dist_col=0, random_correct=True, q_begin=0, q_end=None, info=None):
+    """ppk_knn_sketches_band_dev: the best knn per sample among the pairs of one band of the triangle's rows;
+    CUDA tensors (j int64, dist float32) of length n * knn, unfilled slots j = -1."""
+    torch = _torch()
+    n = db.n
+    q_end = n if q_end is None else int(q_end)
+    dev = "cuda:%d" % db.device
+    oi = torch.empty(n * knn, dtype=torch.int64, device=dev)
+    oj = torch.empty(n * knn, dtype=torch.int64, device=dev)
+    od = torch.empty(n * knn, dtype=torch.float32, device=dev)
+    kmers_a, random_tbl, tbl_ptr, n_clu = _prep_tables(kmers, random_tbl, db.nk)
+    n_cand = C.c_ulonglong(0)
+    with torch.cuda.device(db.device):
+        rc = _lib.lib().ppk_knn_sketches_band_dev(db._h, kmers_a.ctypes.data_as(C.POINTER(C.c_int32)), tbl_ptr, n_clu,
+                                                  FLAG_RANDOM_CORRECT if random_correct else 0, int(knn), int(dist_col),
+                                                  int(q_begin), q_end, C.c_void_p(oi.data_ptr()),
+                                                  C.c_void_p(oj.data_ptr()), C.c_void_p(od.data_ptr()),
+                                                  C.byref(n_cand), _stream_ptr(db.device))
+        _lib.check(rc, "ppk_knn_sketches_band_dev")
+    if info is not None:
+        info["candidates"] = int(n_cand.value)
+    return oj, od
+
+
+_KNN_NONE = (1 << 63) - 1      # key of an unfilled slot: sorts behind every (distance bits << 32 | j)
+
+
+def knn_merge_lists(keys, n, knn):
+    """Per-band neighbour lists as int64 keys [bands, n * knn] (distance bits << 32 | j, unfilled = 2^63 - 1)
+    -> (i, j, dist) of the whole job: per sample the knn smallest keys of all bands, i.e. the reference's stable
+    order by distance, ties to the lower index (src/extend.cpp:266-279); slots no band could fill keep the
+    reference's filler (i, 0, 0.0)."""
+    torch = _torch()
+    bands = keys.shape[0]
+    per = keys.view(bands, n, knn).permute(1, 0, 2).reshape(n, bands * knn)
+    best = torch.sort(per, dim=1).values[:, :knn].reshape(-1)
+    none = best == _KNN_NONE
+    oj = torch.where(none, torch.zeros_like(best), best & 0xFFFFFFFF)
+    od = torch.where(none, torch.zeros_like(best), best >> 32).to(torch.int32).view(torch.float32)
+    oi = torch.arange(n, device=keys.device, dtype=torch.int64).repeat_interleave(knn)
+    return oi, oj, od
+
+
 def knn_sharded(db, kmers, random_tbl, knn, rank, world_size, dist_col=0, random_correct=True, group=None,
                 band_fn=None):
-    """k nearest neighbours of every sample on N GPUs: every rank holds the full resident sketches and
-    emits the neighbour candidates of its band of the triangle (the band split of the distance job:
-    equal pair counts); the candidate lists -- tens to hundreds per sample, not the n^2 / N distances --
-    are gathered to rank 0 with the same grouped send/recv as the distance blocks, and rank 0 selects.
-    Returns (i, j, dist) on rank 0, None elsewhere.  `band_fn(q_begin, q_end) -> (keys, vals)` overrides
-    the HIP launch (CPU gloo tests of the exchange)."""
+    """k nearest neighbours of every sample on N GPUs: every rank holds the full resident sketches, takes a
+    band of the triangle (the band split of the distance job: equal pair counts) and reduces it to the best
+    knn per sample ON ITS DEVICE (`knn_band`: the staged candidate flow of the single-GPU call); what travels to
+    rank 0 is one int64 key per slot -- n * knn * 8 bytes per rank, whatever the candidate stream was -- and
+    rank 0 merges (`knn_merge_lists`).  Returns (i, j, dist) on rank 0, None elsewhere.
+    `band_fn(q_begin, q_end) -> (j, dist)` overrides the HIP launch (CPU gloo tests of the exchange)."""
     torch = _torch()
     import torch.distributed as dist_
     bounds = shard_bounds(db.n, 0, world_size)
     qb, qe = bounds[rank], bounds[rank + 1]
-    if band_fn is not None:
-        keys, vals = band_fn(qb, qe)
-    else:
-        keys, vals = knn_candidates(db, kmers, random_tbl, knn, dist_col, random_correct, qb, qe)
+    oj, od = band_fn(qb, qe) if band_fn is not None else knn_band(db, kmers, random_tbl, knn, dist_col, random_correct, qb, qe)
+    keys = (od.contiguous().view(torch.int32).to(torch.int64) << 32) | oj
+    keys = torch.where(oj < 0, torch.full_like(keys, _KNN_NONE), keys)
     if world_size > 1:
         nccl = str(dist_.get_backend(group)).lower() == "nccl"
-        cnt = torch.tensor([keys.shape[0]], dtype=torch.int64, device=keys.device if nccl else "cpu")
-        counts = [torch.zeros_like(cnt) for _ in range(world_size)]
-        dist_.all_gather(counts, cnt, group=group)
-        counts = [int(c.item()) for c in counts]
-        both = torch.stack([keys.to(torch.int64), vals], dim=1).contiguous()      # one exchange: [m, 2] int64
-        full = gather_bands(both, counts, 2, torch.int64, both.device, rank, world_size, 0, group)
+        send = keys if nccl else keys.cpu()
+        dst = 0 if group is None else dist_.get_global_rank(group, 0)
+        got = [torch.empty_like(send) for _ in range(world_size)] if rank == 0 else None
+        dist_.gather(send, got, dst=dst, group=group)
         if rank != 0:
             return None
-        keys, vals = full[:, 0].to(torch.int32).contiguous(), full[:, 1].contiguous()
-    if band_fn is not None and not keys.is_cuda:
-        return keys, vals                  # CPU test of the exchange: the caller selects
-    return knn_select(keys, vals, db.n, knn)
+        keys = torch.stack(got).to(keys.device)
+    else:
+        keys = keys.unsqueeze(0)
+    return knn_merge_lists(keys, db.n, knn)
 
 
 # ---- multi-GPU: one process per GPU, band-sharded pair space, gather to rank 0 -------------

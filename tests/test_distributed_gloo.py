@@ -85,31 +85,30 @@ def _worker(rank, world, port, n_ref, n_qry, ret):
 
     e_full, e_counts = engine.edges_sharded(DB(n_ref), DB(n_qry) if n_qry else None, kmers, tbl, rank,
                                             world, band_fn=edge_fn, device="cpu")
-    # neighbour candidates (engine.knn_sharded): variable-length (sample, key) lists per band, gathered to
-    # rank 0 in one exchange.  Stand-in candidates: EVERY pair of the band, for both its samples --
-    # the selection of the gathered lists must then be the k nearest neighbours of the whole matrix.
+    # neighbours (engine.knn_sharded): every rank reduces its band to the best k per sample, one int64 key per
+    # slot travels to rank 0, which merges.  Stand-in for the HIP launch: the band's best k by brute force
+    # (a pair belongs to the band of its smaller sample and counts for both of its samples).
     knn_ok = True
     if not n_qry:
-        import struct
+        k = 3
+        sq = oracle.long_to_square(want_all[:, 0])
 
-        def cand_fn(qb, qe):
-            keys, vals = [], []
-            for q in range(qb, qe):
-                for r in range(q + 1, n_ref):
-                    row = q * n_ref - q * (q + 1) // 2 + (r - q - 1)
-                    bits = struct.unpack("<I", struct.pack("<f", float(want_all[row, 0])))[0]
-                    keys += [q, r]
-                    vals += [(bits << 32) | r, (bits << 32) | q]
-            return torch.tensor(keys, dtype=torch.int32), torch.tensor(vals, dtype=torch.int64)
+        def band_fn(qb, qe):
+            oj = np.full((n_ref, k), -1, dtype=np.int64)
+            od = np.zeros((n_ref, k), dtype=np.float32)
+            for s_ in range(n_ref):
+                # partners of sample s_ within the band: pairs (q, r), q < r, q in [qb, qe)
+                mates = [t for t in range(n_ref) if t != s_ and qb <= min(s_, t) < qe]
+                mates.sort(key=lambda t: (sq[s_, t], t))
+                for slot, t in enumerate(mates[:k]):
+                    oj[s_, slot], od[s_, slot] = t, sq[s_, t]
+            return torch.from_numpy(oj.ravel()), torch.from_numpy(od.ravel())
 
-        got = engine.knn_sharded(DB(n_ref), kmers, tbl, 3, rank, world, band_fn=cand_fn)
+        got = engine.knn_sharded(DB(n_ref), kmers, tbl, k, rank, world, band_fn=band_fn)
         if rank == 0:
-            keys, vals = got[0].numpy(), got[1].numpy()
-            wi, wj, wd = oracle.knn(oracle.long_to_square(want_all[:, 0]), 3)
-            for smp in range(n_ref):
-                mine = np.sort(vals[keys == smp].astype(np.uint64))[:3]
-                knn_ok = knn_ok and [int(v & 0xffffffff) for v in mine] == wj[3 * smp:3 * smp + len(mine)].tolist()
-            knn_ok = knn_ok and len(keys) == n_ref * (n_ref - 1)
+            wi, wj, wd = oracle.knn(sq, k)
+            knn_ok = (np.array_equal(got[0].numpy(), wi) and np.array_equal(got[1].numpy(), wj)
+                      and np.array_equal(got[2].numpy(), wd))
         else:
             knn_ok = got is None
     if rank == 0:

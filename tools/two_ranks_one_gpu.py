@@ -33,7 +33,7 @@ e_full, e_counts = engine.edges_sharded(db, None, K, T, rank, world, slope=2, x_
 if rank == 0:
     e_whole, _ = engine.dist_edges(db, None, K, T, slope=2, x_max=xm, y_max=ym)
     print("EDGES equal=%s n=%d per rank=%s" % (bool(torch.equal(e_full, e_whole)), e_full.shape[0], e_counts))
-# neighbours on N ranks: candidates per band, gathered, selected on rank 0 == the single-GPU result
+# neighbours on N ranks: the best k per sample of every band, merged on rank 0 == the single-GPU result
 got = engine.knn_sharded(db, K, T, 5, rank, world)
 if rank == 0:
     wi, wj, wd = engine.knn_from_sketches(db, K, T, 5, method="tiles")
