@@ -70,7 +70,7 @@ int ppk_device_count(int *n);
  *     it is half full, so a job of any size runs in a bounded list), "knn_warm" (default 32: a neighbour job of
  *     16 384 rows or more opens with 1/32 of them, cuts the list -- every bound drops from the k-th of one tile's
  *     256 distances to the k-th of a few thousand -- and runs the rest under those bounds: 2 x faster at 100 000
- *     genomes for 10 or 20 neighbours; 0 = off), "knn_cut" (default 4: such a job cuts its list again whenever
+ *     genomes for 10 neighbours; 0 = the opening piece is sized by what the list can take only), "knn_cut" (default 4: such a job cuts its list again whenever
  *     it holds 4 n knn entries -- same time as cutting at half of the room, a tenth of the memory),
  *     "host_parts" (worker threads of a ONE-device host query of >= 16 Mi rows,
  *     default 2: the device is entered twice, each entry with its own streams and buffers, so that one
