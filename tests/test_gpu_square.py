@@ -236,3 +236,28 @@ def test_candidate_bands_beyond_one_dispatch(ppk_option):
     gi, gj, gd = (x.cpu().numpy() for x in engine.knn_select(keys, vals, 1300, 6))
     assert np.array_equal(gi, wi) and np.array_equal(gj, wj) and np.array_equal(gd, wd)
     db.close()
+
+
+def test_neighbours_from_tiles_at_the_default_sketch_size():
+    """PopPUNK's default sketch size (s = 9 984: 156 blocks per k, 14-bit counts, three-dword count registers):
+    neighbours from the tiles, self and ref x query, against a stable sort of the oracle's distances."""
+    kmers = np.asarray([13, 17, 21, 25, 29], dtype=np.int32)
+    sk, _ = synth.make_sketches(700, kmers, sketchsize64=156, bbits=14, cluster_size=35, seed=5)
+    tbl = synth.random_match_table(kmers)
+    db = engine.SketchDB(sk, 156, 14)
+    want, _ = oracle.query(sk, None, kmers, 156, 14, tbl, threads=8)
+    for knn, col in ((4, 0), (11, 1)):
+        wi, wj, wd = oracle.knn(oracle.long_to_square(want[:, col]), knn)
+        gi, gj, gd = (x.cpu().numpy() for x in engine.knn_from_sketches(db, kmers, tbl, knn, dist_col=col, method="tiles"))
+        assert np.array_equal(gj, wj) and np.abs(gd - wd).max() <= 1e-6
+    rdb, qdb = engine.SketchDB(sk[:500], 156, 14), engine.SketchDB(sk[500:], 156, 14)
+    rq, _ = oracle.query(sk[:500], sk[500:], kmers, 156, 14, tbl, threads=8)
+    rect = rq[:, 0].reshape(200, 500)
+    gi, gj, gd = (x.cpu().numpy() for x in engine.knn_ref_query(rdb, qdb, kmers, tbl, 3))
+    gj = gj.reshape(700, 3)
+    for r in (0, 17, 499):
+        assert gj[r].tolist() == (np.argsort(rect[:, r], kind="stable")[:3] + 500).tolist()
+    for q in (0, 99, 199):
+        assert gj[500 + q].tolist() == np.argsort(rect[q], kind="stable")[:3].tolist()
+    for x in (db, rdb, qdb):
+        x.close()
