@@ -170,3 +170,46 @@ def test_default_sketch_size_many_ref_tiles(nk):
     want2, wf2 = oracle.query(sk[:nr], sk[nr:], kmers, 156, 14, tbl, threads=THREADS)
     assert gf2 == wf2
     _compare(got, want2, "s=9984 nk=%d, %d x %d" % (nk, nr, n - nr))
+
+
+def test_400000_genomes_one_device_call_spans_several_dispatches():
+    """400 000 genomes against themselves are 9.8 M pair tiles, more than one dispatch holds (2^32 work-items =
+    8.4 M tiles of 512 threads): ppk_launch_dist sends the band out as several launches.  The fused edge list of
+    ONE device call must equal the host call's, which works through the band in pieces of its own (another
+    cut), rows ascending, and sampled pairs -- edges and non-edges -- must agree with the oracle."""
+    import torch
+    n = 400000
+    kmers = np.asarray(synth.DEFAULT_KMERS, dtype=np.int32)
+    tbl = synth.random_match_table(kmers)
+    sk_t = synth.make_sketches_device(n, kmers, device="cuda:0")
+    db = engine.SketchDB(sk_t, 16, 14, device=0)
+    sub = engine.SketchDB(synth.make_sketches_device(2000, kmers, device="cuda:0"), 16, 14, device=0)
+    d_sub, _ = engine.dist(sub, None, kmers, tbl)
+    x_max, y_max = synth.boundary_for_quantile(d_sub.cpu().numpy(), 0.02)
+    sub.close()
+    e1, _ = engine.dist_edges(db, None, kmers, tbl, slope=2, x_max=x_max, y_max=y_max, cap=32 << 20)
+    e1 = e1.cpu().numpy()
+    e2, nf = engine.edges_host(db, None, kmers, tbl, slope=2, x_max=x_max, y_max=y_max, cap=32 << 20)
+    assert nf == 0 and len(e1) > 1000000 and np.array_equal(e1, e2)
+    key = e1[:, 0] * n + e1[:, 1]
+    assert bool(np.all(e1[:, 0] < e1[:, 1])) and bool(np.all(np.diff(key) > 0))
+    rng = np.random.Generator(np.random.PCG64(5))
+    n_clusters = n // 50
+    sample = [tuple(int(v) for v in e1[i]) for i in rng.choice(len(e1), 60, replace=False)]
+    for _ in range(60):          # pairs of one cluster (members c, c + n_clusters, ...): edges and non-edges
+        c = int(rng.integers(0, n_clusters))
+        sample.append(tuple(sorted(int(v) for v in rng.choice(np.arange(c, n, n_clusters), 2, replace=False))))
+    sample += [tuple(sorted(int(v) for v in rng.choice(n, 2, replace=False))) for _ in range(30)]
+    # pairs late in the triangle: rows that only the later launches cover
+    sample += [tuple(sorted((int(a), int(b)))) for a, b in zip(rng.integers(390000, n, 30), rng.integers(380000, 390000, 30))]
+    for a, b in sample:
+        pair = sk_t[[a, b]].cpu().numpy().view(np.uint64)
+        d, _ = oracle.query(pair[:1], pair[1:], kmers, 16, 14, tbl, threads=1)
+        want = bool(oracle.edge_threshold(d, 2, x_max, y_max, n_ref=1, inclusive=True).shape[0])
+        pos = np.searchsorted(key, a * n + b)
+        assert bool(pos < len(key) and key[pos] == a * n + b) == want, (a, b)
+    db.close()
+    del sk_t
+    torch.cuda.empty_cache()
+    from poppunk_amd import _lib
+    _lib.lib().ppk_release_scratch()
