@@ -213,3 +213,29 @@ def test_400000_genomes_one_device_call_spans_several_dispatches():
     torch.cuda.empty_cache()
     from poppunk_amd import _lib
     _lib.lib().ppk_release_scratch()
+
+
+@pytest.mark.parametrize("knn", [10, 32])
+def test_neighbours_of_40000_genomes_staged_flow_against_brute_force_rows(knn):
+    """Jobs of 16 384 rows or more run the neighbour mode staged (a short opening, a cut, growing pieces, cuts at
+    4 n k): 40 000 genomes with the real thresholds, sampled samples against a brute-force row of the oracle
+    (all 40 000 distances of that sample, stable order, ties to the lower index)."""
+    n = 40000
+    kmers = np.asarray(synth.DEFAULT_KMERS, dtype=np.int32)
+    tbl = synth.random_match_table(kmers)
+    sk_t = synth.make_sketches_device(n, kmers, device="cuda:0")
+    db = engine.SketchDB(sk_t, 16, 14, device=0)
+    info = {}
+    oi, oj, od = engine.knn_from_sketches(db, kmers, tbl, knn, dist_col=0, method="tiles", info=info)
+    oj, od = oj.cpu().numpy().reshape(n, knn), od.cpu().numpy().reshape(n, knn)
+    assert np.array_equal(oi.cpu().numpy(), np.repeat(np.arange(n), knn))
+    assert info["candidates"] < 12 * n * knn            # the list was cut on the way (un-staged: hundreds per sample and k)
+    host = sk_t.cpu().numpy().view(np.uint64)
+    rng = np.random.Generator(np.random.PCG64(knn))
+    for r in rng.choice(n, size=10, replace=False).tolist() + [0, n - 1]:
+        d, _ = oracle.query(host, host[r:r + 1], kmers, 16, 14, tbl, threads=8)
+        col = d[:, 0]
+        order = np.argsort(col, kind="stable")
+        order = order[order != r][:knn]
+        assert np.array_equal(oj[r], order) and np.array_equal(od[r], col[order]), r
+    db.close()
