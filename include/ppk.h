@@ -523,6 +523,48 @@ int ppk_threshold_iterate_2d(const float *dist, size_t n_rows, const float *x_ma
                              long long *off_out, size_t cap, size_t *n_out);
 
 /* ------------------------------------------------------------------------
+ * Sketch database files: bulk read of `<db>/<db>.h5` (layout PopPUNK/web.py:14-61:
+ * /sketches/<sample>/<k> uint64 datasets, attributes sketchsize64, bbits, kmers, length,
+ * missing_bases, base_freq on the sample group).  Replaces the per-sample, per-k h5py reads of
+ * PopPUNK/sketchlib.py:86-88,:124-133,:155-158,:197-214,:672-690 and the HighFive reads inside
+ * pp_sketchlib.queryDatabase(ref_db_name, query_db_name, rList, qList, ...) [EXT], which takes database
+ * PREFIXES and opens the files itself (PopPUNK/sketchlib.py:520,:528-537).  Host code; needs no device.
+ *   backend 0 = choose: 1 the direct reader (the file is mmap-ed and its superblock-0/1, version-1
+ *     object-header, symbol-table-group, contiguous-dataset structures -- what h5py and HighFive write by
+ *     default -- are read in place by several threads: < 1 us per dataset); when the file holds anything
+ *     else, 2: libhdf5's C API, dlopen-ed ($HDF5_LIB, the loader path, ppk_h5_set_library), one H5Fopen,
+ *     per sample one H5Gopen2 and nk H5Dopen2 + H5Dread into the caller's array (~23 us per dataset).
+ *     1 or 2 force that backend (PPK_ERR_STATE when the direct reader does not read the file).
+ *   names: `n` NUL-terminated strings back to back.  ppk_h5_names gives every sample of the file in
+ *     name order (what h5py's keys() yields); *need = bytes, buf may be NULL to ask.
+ *   ppk_h5_params: sketchsize64 / bbits / kmers attributes of `sample` (NULL = the first).
+ *   ppk_h5_read: out uint64 [n][nk][words] in the order of `names` and `kmers`, words = sketchsize64*bbits
+ *     (a dataset of another length is an error, as are a missing sample or k: messages as the Python
+ *     reader's); lengths / missing int64 [n], base_freq double [n][4] (NaN where the attribute is absent
+ *     or not of length 4) -- each nullable; threads 0 = default.
+ */
+typedef struct ppk_h5 ppk_h5;
+int ppk_h5_set_library(const char *libhdf5_path);
+int ppk_h5_open(const char *path, int backend, ppk_h5 **out);
+void ppk_h5_close(ppk_h5 *h);
+int ppk_h5_backend(const ppk_h5 *h);
+const char *ppk_h5_declined(const ppk_h5 *h); /* why the direct reader passed the file on ("" if it did not) */
+int ppk_h5_has_random(const ppk_h5 *h);       /* a /random group is present (PopPUNK/sketchlib.py:461-466) */
+size_t ppk_h5_count(ppk_h5 *h);
+int ppk_h5_names(ppk_h5 *h, char *buf, size_t cap, size_t *need);
+int ppk_h5_params(ppk_h5 *h, const char *sample, size_t *sketchsize64, size_t *bbits, int64_t *kmers,
+                  size_t kmers_cap, size_t *n_kmers);
+/* codon_phased attribute of /sketches (PopPUNK/sketchlib.py:120-121): 1 / 0, -1 when absent */
+int ppk_h5_codon_phased(const ppk_h5 *h);
+/* sketchsize64 / bbits / kmers of EVERY sample, file order: int64 [count], int64 [count], int64 [count][kmers_cap],
+ * size_t [count] (number of k-mer lengths stored; 0 = attribute absent) -- the consistency checks of
+ * getSketchSize / getKmersFromReferenceDatabase (PopPUNK/sketchlib.py:109-168) in one native pass */
+int ppk_h5_all_params(ppk_h5 *h, int64_t *sketchsize64, int64_t *bbits, int64_t *kmers, size_t kmers_cap,
+                      size_t *n_kmers);
+int ppk_h5_read(ppk_h5 *h, const char *names, size_t n, const int32_t *kmers, size_t nk, size_t words,
+                uint64_t *out, int64_t *lengths, int64_t *missing, double *base_freq, int threads);
+
+/* ------------------------------------------------------------------------
  * Measurement hooks (bench.py): when enabled, the dominant kernel of each
  * ppk_dist*_dev call is bracketed by hipEvents on its own stream.
  */

@@ -109,6 +109,18 @@ SIGNATURES = {
     "ppk_query_edges": (C.c_int, [_u64p, _sz, _u64p, _sz, _i32p, _sz, _sz, _sz, _f32p, _u16p, _u16p, _sz,
                                   C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, _intp,
                                   C.c_int, _llp, _sz, _szp, _ullp]),
+    "ppk_h5_set_library": (C.c_int, [C.c_char_p]),
+    "ppk_h5_open": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(_vp)]),
+    "ppk_h5_close": (None, [_vp]),
+    "ppk_h5_backend": (C.c_int, [_vp]),
+    "ppk_h5_declined": (C.c_char_p, [_vp]),
+    "ppk_h5_has_random": (C.c_int, [_vp]),
+    "ppk_h5_count": (_sz, [_vp]),
+    "ppk_h5_names": (C.c_int, [_vp, _vp, _sz, _szp]),
+    "ppk_h5_params": (C.c_int, [_vp, C.c_char_p, _szp, _szp, _llp, _sz, _szp]),
+    "ppk_h5_codon_phased": (C.c_int, [_vp]),
+    "ppk_h5_all_params": (C.c_int, [_vp, _llp, _llp, _llp, _sz, _szp]),
+    "ppk_h5_read": (C.c_int, [_vp, C.c_char_p, _sz, _i32p, _sz, _sz, _vp, _vp, _vp, _vp, C.c_int]),
 }
 
 _lib = None

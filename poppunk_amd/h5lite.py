@@ -172,7 +172,8 @@ def _read_typed(read, tid, space):
                 raw = C.create_string_buffer(size * n)
                 if read(mem, raw) < 0:
                     raise RuntimeError("h5lite: string read failed")
-                out = [raw.raw[i * size:(i + 1) * size].split(b"\0")[0].decode("utf-8", "replace") for i in range(n)]
+                data = raw.raw                   # one copy, not one per element
+                out = [data[i * size:(i + 1) * size].split(b"\0")[0].decode("utf-8", "replace") for i in range(n)]
         finally:
             h.H5Tclose(mem)
         return out[0] if not shape else np.asarray(out, dtype=object).reshape(shape)

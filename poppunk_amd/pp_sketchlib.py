@@ -35,6 +35,7 @@ import ctypes as C
 import os
 import sys
 import threading
+import time
 
 import numpy as np
 
@@ -110,6 +111,13 @@ class _Entry:
 _DB_CACHE = {}          # key -> _Entry
 _DB_CACHE_MAX = 4
 
+# Where the last queryDatabase-shaped call spent its time, in ms (measurement; bench.py's `file_call` leg):
+#   open      the database files: sidecar mapping or native bulk read (0 when the sample lists were cached)
+#   resident  upload + re-layout of sketches that were not yet on the device(s)
+#   query     the engine call itself: compute and download into the fresh result array
+#   source    "sidecar" / "h5" / "npz" / "cache" per database read
+last_call = {}
+
 
 def _slice(loaded, rows):
     rows = np.asarray(rows, dtype=np.int64)
@@ -141,6 +149,7 @@ def _load_cached(db_name, names, klist):
                 if all(nm in pos for nm in names):
                     return _Entry(_slice(_DB_CACHE[k2].loaded, [pos[nm] for nm in names]), transient=True)
     entry = _Entry(sketchdb.load(db_name, names, klist))
+    last_call.setdefault("source", []).append("npz" if path.endswith(".npz") else sketchdb.last_load.get("source", "h5"))
     if stamp is not None:
         _DB_CACHE[key] = entry
         while len(_DB_CACHE) > _DB_CACHE_MAX:
@@ -214,8 +223,10 @@ def query_entries(ref, qry, klist, random_table=None, ref_clusters=None, qry_clu
     tptr, n_clu, rclu, qclu, keep = _table_args(random_table, random_correct, ref_clusters, qry_clusters,
                                                 qry is not None)
     devices = [int(d) for d in devices]
+    t0 = time.perf_counter()
     rh = ref.resident(devices, rclu)
     qh = qry.resident(devices, qclu) if qry is not None else None
+    t1 = time.perf_counter()
     refs = (C.c_void_p * len(devices))(*[h.value for h in rh])
     qrys = (C.c_void_p * len(devices))(*[h.value for h in qh]) if qh is not None else None
     n_failed = C.c_ulonglong(0)
@@ -223,6 +234,8 @@ def query_entries(ref, qry, klist, random_table=None, ref_clusters=None, qry_clu
         rc = lib.ppk_query_dbs(refs, qrys, len(devices), kmers.ctypes.data_as(C.POINTER(C.c_int32)), tptr, n_clu,
                                _flags(random_correct, jaccard, counts), C.c_void_p(out.ctypes.data),
                                C.byref(n_failed))
+    last_call["resident"] = (t1 - t0) * 1e3
+    last_call["query"] = (time.perf_counter() - t1) * 1e3
     del keep
     _lib.check(rc, "ppk_query_dbs")
     return out, int(n_failed.value)
@@ -336,8 +349,12 @@ def queryDatabase(ref_db_name, query_db_name, rList, qList, klist, random_correc
     klist = [int(k) for k in np.asarray(klist).ravel()]
     rList = [str(x) for x in rList]
     qList = [str(x) for x in qList]
+    last_call.clear()
+    t0 = time.perf_counter()
     ref_e, qry_e, table, ref_clu, qry_clu = _open_query(ref_db_name, query_db_name, rList, qList, klist,
                                                         random_correct)
+    last_call["open"] = (time.perf_counter() - t0) * 1e3
+    last_call.setdefault("source", ["cache"])
     try:
         out, n_failed = query_entries(ref_e, qry_e, klist, table, ref_clu, qry_clu,
                                       random_correct=random_correct, jaccard=jaccard,

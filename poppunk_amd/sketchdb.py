@@ -224,54 +224,98 @@ def _load_npz(path, names, klist):
 
 # ---- .h5 ------------------------------------------------------------------------------------------
 
-def _load_h5(path, names, klist):
-    if len(names) == 0:
-        raise RuntimeError("no sample names given")
+def _random_of_file(path):
+    """The /random group's raw content ({} when it has no datasets), through h5py or libhdf5."""
     _, h5open = _h5_backend()
     f = h5open(path, "r")
     try:
-        grp = f["sketches"]
-        if names[0] not in grp:
-            raise RuntimeError("sample %s not found in sketch database %s" % (names[0], path))
-        first = grp[names[0]]
-        s64 = int(np.asarray(first.attrs["sketchsize64"]).ravel()[0])
-        bbits = int(np.asarray(first.attrs["bbits"]).ravel()[0])
-        sk = np.empty((len(names), len(klist), s64 * bbits), dtype=np.uint64)
-        lengths = np.zeros(len(names), dtype=np.int64)
-        base_freq = np.zeros((len(names), 4), dtype=np.float64)
-        have_freq = True
-        for i, nm in enumerate(names):
-            if nm not in grp:
-                raise RuntimeError("sample %s not found in sketch database %s" % (nm, path))
-            g = grp[nm]
-            for j, k in enumerate(klist):
-                if str(int(k)) not in g:
-                    raise RuntimeError("k-mer length %d not found for sample %s in %s" % (int(k), nm, path))
-                words = np.asarray(_ds_read(g[str(int(k))]), dtype=np.uint64).ravel()
-                if words.size != s64 * bbits:
-                    raise RuntimeError("sketch of %s at k=%d has %d words, expected sketchsize64*bbits = %d"
-                                       % (nm, int(k), words.size, s64 * bbits))
-                sk[i, j] = words
-            if "length" in g.attrs:
-                lengths[i] = int(np.asarray(g.attrs["length"]).ravel()[0])
-            bf = np.asarray(g.attrs["base_freq"], dtype=np.float64).ravel() if "base_freq" in g.attrs else None
-            if bf is not None and bf.size == 4:
-                base_freq[i] = bf
-            else:
-                have_freq = False
-        raw, tbl, clu, status = None, None, None, "absent"
-        if "random" in f:
-            raw = read_random_raw(f["random"])
-            mapped = random_from_raw(raw, names, klist, base_freq if have_freq else None)
-            if mapped is not None:
-                tbl, clu = mapped
-                status = "mapped"
-            else:
-                status = "unrecognised"
-        return LoadedSketches(list(names), np.asarray(klist, dtype=np.int32), sk, s64, bbits, tbl, clu,
-                              raw, lengths, base_freq if have_freq else None, status)
+        return read_random_raw(f["random"]) if "random" in f else None
     finally:
         f.close()
+
+
+def _finish_h5(names, klist, sk, s64, bbits, lengths, base_freq, raw):
+    have_freq = base_freq is not None and not np.isnan(base_freq).any()
+    tbl, clu, status = None, None, "absent"
+    if raw is not None:
+        mapped = random_from_raw(raw, names, klist, base_freq if have_freq else None)
+        if mapped is not None:
+            tbl, clu = mapped
+            status = "mapped"
+        else:
+            status = "unrecognised"
+    return LoadedSketches(list(names), np.asarray(klist, dtype=np.int32), sk, s64, bbits, tbl, clu, raw,
+                          lengths, base_freq if have_freq else None, status)
+
+
+def _pick(path, file_names, file_kmers, names, klist):
+    """Row and k indices of a request in a whole-file image (None, None = the image as it is)."""
+    kidx = [file_kmers.index(int(k)) for k in klist]
+    if names == file_names and kidx == list(range(len(file_kmers))):
+        return None, None
+    pos = {nm: i for i, nm in enumerate(file_names)}
+    rows = np.empty(len(names), dtype=np.int64)
+    for i, nm in enumerate(names):
+        r = pos.get(nm)
+        if r is None:
+            raise RuntimeError("sample %s not found in sketch database %s" % (nm, path))
+        rows[i] = r
+    return rows, kidx
+
+
+def _take(a, rows, kidx=None):
+    if a is None or rows is None:
+        return a
+    a = a[rows]
+    return np.ascontiguousarray(a[:, kidx]) if kidx is not None else a
+
+
+# what the last _load_h5 did: {"source": "sidecar" | "h5", "backend": 1 direct reader | 2 libhdf5,
+# "packed": a sidecar was written, "declined": why the direct reader passed the file on}
+last_load = {}
+
+
+def _load_h5(path, names, klist):
+    """`names` x `klist` from a reference-layout `.h5` (PopPUNK/web.py:14-61): from its packed sidecar when
+    there is a valid one (poppunk_amd/h5bulk.py), else ONE native bulk read (`ppk_h5_read`, include/ppk.h)
+    -- which packs the whole file into the sidecar when the request covers at least half of it."""
+    from . import h5bulk
+    if len(names) == 0:
+        raise RuntimeError("no sample names given")
+    names = list(names)
+    klist = [int(k) for k in klist]
+    last_load.clear()
+    side = h5bulk.sidecar_open(path)
+    if side is not None and all(k in side.kmers for k in klist):
+        rows, kidx = _pick(path, side.names, side.kmers, names, klist)
+        raw = side.random_raw
+        if side.has_random and raw is None:
+            raw = {}
+        last_load.update(source="sidecar", backend=0, packed=False, declined="")
+        return _finish_h5(names, klist, _take(side.sketches, rows, kidx), side.sketchsize64, side.bbits,
+                          np.asarray(_take(side.lengths, rows)), _take(side.base_freq, rows), raw)
+    stamp = h5bulk.h5_stamp(path)
+    with h5bulk.H5Bulk(path) as f:
+        s64, bbits, _ = f.params()
+        words = s64 * bbits
+        pack = h5bulk.sidecar_enabled() and 2 * len(names) >= f.count()
+        want = f.names() if pack else names
+        try:
+            sk, lengths, missing, freq = f.read(want, klist, words)
+        except RuntimeError:
+            if not pack:
+                raise
+            pack = False                      # e.g. a k-mer length only some samples have: read what was asked
+            sk, lengths, missing, freq = f.read(names, klist, words)
+        raw = _random_of_file(path) if f.has_random else None
+        last_load.update(source="h5", backend=f.backend, packed=False, declined=f.declined)
+    if not pack:
+        return _finish_h5(names, klist, sk, s64, bbits, lengths, freq, raw)
+    have_freq = not np.isnan(freq).any()
+    last_load["packed"] = h5bulk.sidecar_write(path, stamp, want, klist, sk, s64, bbits, lengths, missing,
+                                               freq if have_freq else None, raw is not None, raw)
+    rows, _ = _pick(path, want, klist, names, klist)
+    return _finish_h5(names, klist, _take(sk, rows), s64, bbits, _take(lengths, rows), _take(freq, rows), raw)
 
 
 def save_h5(db_name, names, kmers, sketches, sketchsize64, bbits, random_table=None, clusters=None,
@@ -378,12 +422,46 @@ def getSeqsInDb(dbname):
     if dbname.endswith(".npz"):
         with np.load(dbname, allow_pickle=False) as z:
             return [str(x) for x in z["names"]]
-    _, h5open = _h5_backend()
-    f = h5open(dbname, "r")
-    try:
-        return list(f["sketches"].keys())
-    finally:
-        f.close()
+    from . import h5bulk
+    with h5bulk.H5Bulk(dbname) as f:
+        return f.names()
+
+
+def _checked_params(path, dbPrefix, what):
+    """One native pass over every sample's sketchsize64 / kmers attributes with the reference's consistency
+    checks (PopPUNK/sketchlib.py:109-168: a message on stderr and `sys.exit(1)` on a mixed database).
+    Returns (sorted kmers of the first sample, its sketchsize64, codon_phased)."""
+    from . import h5bulk
+    with h5bulk.H5Bulk(path) as f:
+        names = f.names()
+        if not names:
+            if what != "size":
+                sys.stderr.write("Couldn't find sketches in " + dbPrefix + "\n")
+                sys.exit(1)
+            return [], 0, bool(f.codon_phased)
+        s64, _, km, nk = f.all_params()
+        phased = bool(f.codon_phased)
+    first = [int(k) for k in km[0, :int(nk[0])]]
+    if what in ("kmers", "both"):
+        same = (nk == nk[0]) & (km[:, :int(nk[0])] == km[0, :int(nk[0])]).all(axis=1)
+        if what == "both":                      # readDBParams compares the sorted lists
+            same = (nk == nk[0]) & (np.sort(km[:, :int(nk[0])], axis=1) == np.sort(km[0, :int(nk[0])])).all(axis=1)
+        if not same.all():
+            bad = int(np.flatnonzero(~same)[0])
+            ks = [int(k) for k in km[bad, :min(int(nk[bad]), km.shape[1])]]
+            ref = first
+            if what == "both":
+                ks, ref = sorted(ks), sorted(first)
+            sys.stderr.write("Problem with database; kmer lengths inconsistent: %s vs %s\n" % (ks, ref))
+            sys.exit(1)
+    if what in ("size", "both"):
+        diff = np.flatnonzero(s64 != s64[0])
+        if diff.size:
+            bad = int(diff[0])
+            sys.stderr.write("Problem with database; sketch sizes for sample %s is %d, but smaller kmers "
+                             "have sketch sizes of %d\n" % (names[bad], int(s64[0]), int(s64[bad])))
+            sys.exit(1)
+    return first, int(s64[0]), phased
 
 
 def readDBParams(dbPrefix):
@@ -391,31 +469,8 @@ def readDBParams(dbPrefix):
     (PopPUNK/sketchlib.py:170-195, with the consistency checks of :109-168)."""
     base = dbPrefix + "/" + os.path.basename(dbPrefix)
     if os.path.exists(base + ".h5"):
-        _, h5open = _h5_backend()
-        f = h5open(base + ".h5", "r")
-        try:
-            top = f["sketches"]
-            codon_phased = bool(np.asarray(top.attrs["codon_phased"]).ravel()[0]) if "codon_phased" in top.attrs else False
-            prev_k, prev_s = None, 0
-            for nm in top.keys():
-                g = top[nm]
-                ks = sorted(int(k) for k in np.asarray(g.attrs["kmers"]).ravel())
-                s = int(np.asarray(g.attrs["sketchsize64"]).ravel()[0])
-                if prev_k is None:
-                    prev_k, prev_s = ks, s
-                elif ks != prev_k:
-                    sys.stderr.write("Problem with database; kmer lengths inconsistent: %s vs %s\n" % (ks, prev_k))
-                    sys.exit(1)
-                elif s != prev_s:
-                    sys.stderr.write("Problem with database; sketch sizes for sample %s is %d, but smaller kmers "
-                                     "have sketch sizes of %d\n" % (nm, prev_s, s))
-                    sys.exit(1)
-        finally:
-            f.close()
-        if not prev_k:
-            sys.stderr.write("Couldn't find sketches in " + dbPrefix + "\n")
-            sys.exit(1)
-        return np.asarray(prev_k), prev_s, codon_phased
+        ks, s64, phased = _checked_params(base + ".h5", dbPrefix, "both")
+        return np.asarray(sorted(ks)), s64, phased
     with np.load(base + ".npz", allow_pickle=False) as z:
         return np.sort(np.asarray(z["kmers"], dtype=np.int64)), int(z["sketchsize64"]), False
 
@@ -437,59 +492,31 @@ def _prefix_file(prefix, suffix=".h5"):
 def getSketchSize(dbPrefix):
     """(sketch size in units of 64 bins, codon_phased), checked for consistency over the samples
     (PopPUNK/sketchlib.py:109-142; `sys.exit(1)` on a mixed database)."""
-    _, h5open = _h5_backend()
-    f = h5open(_prefix_file(dbPrefix), "r")
-    try:
-        top = f["sketches"]
-        codon_phased = bool(np.asarray(top.attrs["codon_phased"]).ravel()[0]) if "codon_phased" in top.attrs else False
-        prev = 0
-        for nm in top.keys():
-            s = int(np.asarray(top[nm].attrs["sketchsize64"]).ravel()[0])
-            if prev == 0:
-                prev = s
-            elif s != prev:
-                sys.stderr.write("Problem with database; sketch sizes for sample %s is %d, but smaller kmers "
-                                 "have sketch sizes of %d\n" % (nm, prev, s))
-                sys.exit(1)
-    finally:
-        f.close()
-    return int(prev), codon_phased
+    _, s64, phased = _checked_params(_prefix_file(dbPrefix), dbPrefix, "size")
+    return int(s64), phased
 
 
 def getKmersFromReferenceDatabase(dbPrefix):
     """Sorted k-mer lengths of the database, checked for consistency (PopPUNK/sketchlib.py:144-168)."""
-    _, h5open = _h5_backend()
-    f = h5open(_prefix_file(dbPrefix), "r")
-    try:
-        top = f["sketches"]
-        prev = None
-        for nm in top.keys():
-            ks = [int(k) for k in np.asarray(top[nm].attrs["kmers"]).ravel()]
-            if prev is None:
-                prev = ks
-            elif ks != prev:
-                sys.stderr.write("Problem with database; kmer lengths inconsistent: %s vs %s\n" % (ks, prev))
-                sys.exit(1)
-    finally:
-        f.close()
-    return np.asarray(sorted(prev or []))
+    ks, _, _ = _checked_params(_prefix_file(dbPrefix), dbPrefix, "kmers")
+    return np.asarray(sorted(ks))
 
 
 def get_database_statistics(prefix):
     """(genome lengths, ambiguous-base counts) per sample in database order
     (PopPUNK/sketchlib.py:672-690; callers PopPUNK/__main__.py:404,:492 for QC)."""
-    _, h5open = _h5_backend()
-    f = h5open(_prefix_file(prefix), "r")
-    try:
-        top = f["sketches"]
-        lengths, ambiguous = [], []
-        for nm in top.keys():
-            g = top[nm]
-            lengths.append(np.asarray(g.attrs["length"]).ravel()[0])
-            ambiguous.append(np.asarray(g.attrs["missing_bases"]).ravel()[0])
-    finally:
-        f.close()
-    return lengths, ambiguous
+    from . import h5bulk
+    path = _prefix_file(prefix)
+    side = h5bulk.sidecar_open(path)
+    if side is not None:
+        return list(side.lengths), list(side.missing)
+    with h5bulk.H5Bulk(path) as f:
+        names = f.names()
+        if not names:
+            return [], []
+        s64, bbits, ks = f.params()
+        _, lengths, missing, _ = f.read(names, ks[:1], s64 * bbits)
+    return list(lengths), list(missing)
 
 
 def _copy_samples(src_sketches, dst_sketches, skip=frozenset()):
