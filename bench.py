@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-host-call", action="store_true", help="skip the host_call leg")
+    ap.add_argument("--no-file-call", action="store_true", help="skip the file_call leg (database file -> distances)")
     ap.add_argument("--no-config5", action="store_true", help="skip the config-5 (fused edge list) leg")
     ap.add_argument("--config5-genomes", type=int, default=100000)
     ap.add_argument("--config5-steps", type=int, default=3)
@@ -195,6 +196,83 @@ def host_call(sk, kmers, tbl, devices, reps=5):
                     "arrays_ms: ppk_query on the raw array (its hash of every sketch word runs beside the job and is "
                     "checked before the call returns)"
                     % (reps - 1, sk.nbytes >> 20)}
+
+
+def _stats(ms):
+    """min / median / max of a list of milliseconds (the line reports all three: a stall must show)."""
+    v = sorted(float(x) for x in ms)
+    return {"min_ms": round(v[0], 3), "median_ms": round(v[len(v) // 2], 3), "max_ms": round(v[-1], 3), "n": len(v)}
+
+
+def file_call(sk, kmers, tbl, device, reps=3):
+    """`pp_sketchlib.queryDatabase(ref_db_name, ...)` FROM THE DATABASE FILE, as a PopPUNK process meets it: a
+    reference-layout `<db>/<db>.h5` (PopPUNK/web.py:14-61; written here once, untimed), nothing of it loaded or
+    resident.  Three states, `reps` calls each, every call split into open (file -> host arrays) / resident
+    (upload + re-layout) / query (compute + download into a fresh host array):
+      cold_h5        no sidecar: the native bulk read of the .h5 (ppk_h5_read), which also packs `<db>.ppk`
+      warm_sidecar   the packed sidecar is there: mmap, staged to the GPU from the page cache
+      loaded         the same process asks again (poppunk_assign's later batches, --plot-fit re-queries)
+    "cold" is the state of the process and of the GPU, not of the page cache (the file was just written)."""
+    import shutil
+    import tempfile
+    from poppunk_amd import _lib, pp_sketchlib, sketchdb, h5bulk
+    n = sk.shape[0]
+    names = ["genome_%06d" % i for i in range(n)]
+    root = tempfile.mkdtemp(prefix="ppk_bench_db_")
+    db = os.path.join(root, "db", "db")
+    klist = [int(k) for k in kmers]
+    try:
+        t0 = time.perf_counter()
+        sketchdb.save_h5(db, names, klist, sk, 16, 14, random_table=tbl, clusters=np.zeros(n, dtype=np.uint16))
+        write_s = time.perf_counter() - t0
+        pairs = n * (n - 1) // 2
+
+        def one(state):
+            pp_sketchlib.clear_cache()
+            if state == "cold_h5" and os.path.exists(db + ".ppk"):
+                os.unlink(db + ".ppk")
+            t0 = time.perf_counter()
+            out = pp_sketchlib.queryDatabase(db, db, names, names, klist, True, False, 1, True, device)
+            total = (time.perf_counter() - t0) * 1e3
+            assert out.shape == (pairs, 2)
+            del out
+            lc = dict(pp_sketchlib.last_call)
+            return {"total": total, "open": lc.get("open", 0.0), "resident": lc.get("resident", 0.0),
+                    "query": lc.get("query", 0.0), "source": lc.get("source"), "backend": sketchdb.last_load.get("backend")}
+
+        res = {"workload": "%d genomes, reference-layout .h5 of %.1f MB (%d datasets), self query, names and k as "
+                           "stored" % (n, os.path.getsize(db + ".h5") / 1e6, n * len(klist)),
+               "h5_write_s_untimed": round(write_s, 2)}
+        for state in ("cold_h5", "warm_sidecar"):
+            runs = [one(state) for _ in range(reps)]
+            res[state] = dict(_stats([r["total"] for r in runs]),
+                              open_ms=round(sorted(r["open"] for r in runs)[len(runs) // 2], 3),
+                              resident_ms=round(sorted(r["resident"] for r in runs)[len(runs) // 2], 3),
+                              query_ms=round(sorted(r["query"] for r in runs)[len(runs) // 2], 3),
+                              source=runs[-1]["source"], h5_backend=runs[-1]["backend"])
+            res[state]["pairs_per_s"] = pairs / (res[state]["median_ms"] * 1e-3)
+        res["sidecar_bytes"] = os.path.getsize(db + ".ppk") if os.path.exists(db + ".ppk") else 0
+        loaded = []
+        for _ in range(reps + 2):
+            t0 = time.perf_counter()
+            out = pp_sketchlib.queryDatabase(db, db, names, names, klist, True, False, 1, True, device)
+            loaded.append((time.perf_counter() - t0) * 1e3)
+            del out
+        res["loaded"] = _stats(loaded[1:])
+        os.environ["PPK_SIDECAR"] = "0"
+        try:
+            runs = [one("cold_h5") for _ in range(reps)]
+            res["cold_h5_no_packing"] = dict(_stats([r["total"] for r in runs]),
+                                             open_ms=round(sorted(r["open"] for r in runs)[len(runs) // 2], 3))
+        finally:
+            del os.environ["PPK_SIDECAR"]
+        res["note"] = ("every figure is pp_sketchlib.queryDatabase(db, db, names, names, klist, True, False, 1, True, dev) "
+                       "end to end after pp_sketchlib.clear_cache() (no host arrays, no resident sketches, no result "
+                       "buffers); open = sketchdb.load, resident = ppk_db_create, query = ppk_query_dbs")
+        return res
+    finally:
+        pp_sketchlib.clear_cache()
+        shutil.rmtree(root, ignore_errors=True)
 
 
 def config5(args, rank, world, local_rank, dev, barrier, fields, park):
@@ -430,7 +508,8 @@ def build_line(rep):
                    "n_genomes": n, "pairs": total_pairs,
                    "parallelism": "band-split x%d (%s bands), %d-chunk pipelined p2p gather to rank 0"
                                   % (world, band_note.split(" ")[0], f.get("chunks", args.chunks or 4)) if world > 1 else "1 GPU"},
-        "roofline": roof, "cpu_baseline": f.get("cpu"), "host_call": f.get("host_call"), "config5": f.get("config5"),
+        "roofline": roof, "cpu_baseline": f.get("cpu"), "host_call": f.get("host_call"),
+        "file_call": f.get("file_call"), "config5": f.get("config5"),
     }
     if value_note:
         line["value_note"] = value_note
@@ -795,6 +874,13 @@ def run(args, rep, rank, local_rank, world, fake, torch, dist, engine, synth, da
                 park("host_call")
         except Exception as e:
             rep.error("host_call", e)
+
+    if world == 1 and not args.no_file_call:
+        rep.enter("file_call")
+        try:
+            f["file_call"] = file_call(sk, kmers, tbl, local_rank)
+        except Exception as e:
+            rep.error("file_call", e)
 
     if not args.no_config5:
         rep.enter("config5")

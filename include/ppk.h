@@ -75,6 +75,9 @@ int ppk_device_count(int *n);
  *     "host_parts" (worker threads of a ONE-device host query of >= 16 Mi rows,
  *     default 2: the device is entered twice, each entry with its own streams and buffers, so that one
  *     download is in flight while the next is being set up)
+ *   measurement only: "edge_list_keep" 0: the fused host edge call (ppk_query_edges*) allocates its device edge list
+ *     per call with the round-3 guess of rows / 8 entries and frees it again, instead of keeping a grow-only buffer
+ *     per device entry (default 1; tools/stall_hunt.py)
  *   measurement only: "host_trace" 1: a timeline of every host query (launches, page touching, downloads,
  *     ms since the call began) on file descriptor 2
  *   measurement only: "ablate", a bit mask that SKIPS parts of the distance kernel to time the rest

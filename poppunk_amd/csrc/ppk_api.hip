@@ -57,6 +57,7 @@ const OptionEntry kOptions[] = {
     {"knn_cut", "PPK_KNN_CUT", &PpkConfig::knn_cut},
     {"host_parts", "PPK_HOST_PARTS", &PpkConfig::host_parts},
     {"host_trace", "PPK_HOST_TRACE", &PpkConfig::host_trace},
+    {"edge_list_keep", "PPK_EDGE_LIST_KEEP", &PpkConfig::edge_list_keep},
     {"ext_collision_adjust", "PPK_EXT_COLLISION_ADJUST", &PpkConfig::ext_collision_adjust},
     {"ext_fit_skip", "PPK_EXT_FIT_SKIP", &PpkConfig::ext_fit_skip},
 };

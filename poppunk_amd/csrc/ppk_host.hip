@@ -209,6 +209,7 @@ struct QueryBufs {
   void *buf[2] = {nullptr, nullptr};
   size_t bytes[2] = {0, 0};
   unsigned long long *d_failed = nullptr;
+  unsigned long long *d_cnt2 = nullptr;      // {edges, failed fits} of the fused edge-list calls
   hipEvent_t done[2] = {nullptr, nullptr};
 };
 constexpr int kMaxDup = 4;       // a device may be listed up to kMaxDup times in one ppk_query call
@@ -865,7 +866,7 @@ void ppk_query_cache_clear() {
   for (int d = 0; d < 64; ++d)
     for (int u = 0; u < kMaxDup; ++u) {
       QueryBufs &q = g_qbufs[d][u];
-      if (!q.buf[0] && !q.buf[1] && !q.d_failed && !q.done[0] && !q.done[1]) continue;
+      if (!q.buf[0] && !q.buf[1] && !q.d_failed && !q.d_cnt2 && !q.done[0] && !q.done[1]) continue;
       DeviceGuard guard(d);
       (void)hipDeviceSynchronize();
       for (int i = 0; i < 2; ++i) {
@@ -873,6 +874,7 @@ void ppk_query_cache_clear() {
         if (q.done[i]) (void)hipEventDestroy(q.done[i]);
       }
       if (q.d_failed) (void)hipFree(q.d_failed);
+      if (q.d_cnt2) (void)hipFree(q.d_cnt2);
       q = QueryBufs();
     }
 }
@@ -1518,44 +1520,74 @@ void run_edge_part(EdgePart &p, const int32_t *kmers, const float *random_tbl, s
     while (((size_t)1 << bits) <= p.ref->s64 * 64) ++bits;
     if (p.ref->nk > PPK_MAX_NK || p.ref->nk * (size_t)bits > 128) step = p.q_end - p.q_begin;
   }
+  // Device buffers of this (device, occurrence) entry: the counters and the edge list.  They are KEPT between
+  // calls like the result buffers of ppk_query (g_qbufs; ppk_release_scratch frees them): until round 4 every call
+  // allocated a list of rows / 8 entries -- 10 GB at 100 000 genomes -- and freed it again, and a hipMalloc /
+  // hipFree pair of that size costs anything between a few and several hundred milliseconds on a fresh box (the
+  // 801 ms call among 271 ms ones of BENCH_r03's config5.host_call).  The first guess is one edge per 64 pairs
+  // (at least 1 Mi entries); a denser list re-runs its piece once with the exact size, and the buffer then
+  // stays that large.  Option "edge_list_keep" 0 restores allocate-and-free per call with the old guess
+  // (measurement: tools/stall_hunt.py).
+  const bool keep = ppk_config().edge_list_keep.load() != 0;
+  QueryBufs &qb = g_qbufs[p.device][p.dup];
   unsigned long long *d_cnt = nullptr;      // [0] edges, [1] failed fits
   long long *d_edges = nullptr;
   size_t cap = 0;
   auto done = [&](int code) {
-    if (d_edges) (void)hipFree(d_edges);
-    if (d_cnt) (void)hipFree(d_cnt);
+    if (!keep) {
+      if (d_edges) (void)hipFree(d_edges);
+      if (d_cnt) (void)hipFree(d_cnt);
+    }
     if (code != PPK_OK) fail(code);
   };
-  if (hipMalloc(reinterpret_cast<void **>(&d_cnt), 16) != hipSuccess)
+  if (keep) {
+    if (!qb.d_cnt2 && hipMalloc(reinterpret_cast<void **>(&qb.d_cnt2), 16) != hipSuccess)
+      return done(ppk_fail(PPK_ERR_HIP, "hipMalloc failed"));
+    d_cnt = qb.d_cnt2;
+    d_edges = static_cast<long long *>(qb.buf[0]);
+    cap = qb.bytes[0] / 16;
+  } else if (hipMalloc(reinterpret_cast<void **>(&d_cnt), 16) != hipSuccess)
     return done(ppk_fail(PPK_ERR_HIP, "hipMalloc failed"));
+  const size_t guess_div = keep ? 64 : 8;
   for (size_t lo = p.q_begin; lo < p.q_end;) {
     const size_t hi = lo + step < p.q_end ? lo + step : p.q_end;
     const size_t rows = ppk_rows_in_band(p.ref->n, n_qry, lo, hi);
-    size_t want = rows / 8 > ((size_t)1 << 20) ? rows / 8 : ((size_t)1 << 20);
+    size_t want = rows / guess_div > ((size_t)1 << 20) ? rows / guess_div : ((size_t)1 << 20);
     if (want > rows) want = rows;
     bool fits = rows == 0;
     for (int attempt = 0; attempt < 2 && !fits; ++attempt) {
-      if (want > cap) {                     // the list buffer only grows, piece after piece
-        if (d_edges) (void)hipFree(d_edges);
-        d_edges = nullptr;
-        cap = 0;
-        if (hipMalloc(reinterpret_cast<void **>(&d_edges), want * 16) != hipSuccess)
-          return done(ppk_fail(PPK_ERR_HIP, "hipMalloc(edge list) failed"));
+      if (want > cap) {                     // the list buffer only grows, piece after piece and call after call
+        g_trace.mark(p.dup, "e_alloc", (long long)want);
+        if (keep) {
+          void *b = nullptr;
+          if ((rc = query_buf(p.device, p.dup, 0, want * 16, &b)) != PPK_OK) return done(rc);
+          d_edges = static_cast<long long *>(b);
+        } else {
+          if (d_edges) (void)hipFree(d_edges);
+          d_edges = nullptr;
+          cap = 0;
+          if (hipMalloc(reinterpret_cast<void **>(&d_edges), want * 16) != hipSuccess)
+            return done(ppk_fail(PPK_ERR_HIP, "hipMalloc(edge list) failed"));
+        }
         cap = want;
+        g_trace.mark(p.dup, "e_alloc_done", (long long)want);
       }
       if (hipMemsetAsync(d_cnt, 0, 16, s) != hipSuccess) return done(ppk_fail(PPK_ERR_HIP, "hipMemset failed"));
       rc = ppk_dist_edges_dev(p.ref, p.qry, kmers, random_tbl, n_clu, flags, lo, hi, slope, x_max, y_max, scale_x,
                               scale_y, inclusive, d_edges, cap, d_cnt, d_cnt + 1, s);
       if (rc != PPK_OK) return done(rc);
+      g_trace.mark(p.dup, "e_launched", (long long)lo);
       unsigned long long h[2] = {0, 0};
       if (hipMemcpyAsync(h, d_cnt, 16, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
         return done(ppk_fail(PPK_ERR_HIP, "kernel execution failed (fused edge list)"));
+      g_trace.mark(p.dup, "e_counted", (long long)h[0]);
       if (h[0] <= cap) {
         const size_t at = p.edges.size();
         p.edges.resize(at + (size_t)h[0] * 2);
         p.failed += h[1];
         if (h[0] && hipMemcpy(p.edges.data() + at, d_edges, (size_t)h[0] * 16, hipMemcpyDeviceToHost) != hipSuccess)
           return done(ppk_fail(PPK_ERR_HIP, "hipMemcpy D2H failed"));
+        g_trace.mark(p.dup, "e_downloaded", (long long)h[0]);
         fits = true;
       } else {
         want = (size_t)h[0];                // the guess was too small: once more with the exact size
@@ -1649,8 +1681,12 @@ extern "C" int ppk_query_edges_dbs(const ppk_db *const *refs, const ppk_db *cons
                                    int inclusive, long long *ij_out, size_t cap, size_t *n_edges,
                                    unsigned long long *n_failed) {
   std::lock_guard<std::mutex> lk(g_query_mu);
-  return query_edges_dbs_locked(refs, qrys, n_dev, kmers, random_tbl, n_clu, flags, slope, x_max, y_max, scale_x,
-                                scale_y, inclusive, ij_out, cap, n_edges, n_failed);
+  g_trace.t0 = now_ms();
+  g_trace.mark(-1, "e_enter");
+  const int rc = query_edges_dbs_locked(refs, qrys, n_dev, kmers, random_tbl, n_clu, flags, slope, x_max, y_max, scale_x,
+                                        scale_y, inclusive, ij_out, cap, n_edges, n_failed);
+  g_trace.mark(-1, "e_return", n_edges ? (long long)*n_edges : -1);
+  return rc;
 }
 
 extern "C" int ppk_query_edges(const uint64_t *ref_sk, size_t n_ref, const uint64_t *qry_sk, size_t n_qry,

@@ -50,6 +50,7 @@ struct PpkConfig {
   std::atomic<long long> knn_cut{4};            // PPK_KNN_CUT: a staged neighbour job cuts its list at knn_cut * n * knn entries (0: only when half full)
   std::atomic<long long> knn_list{0};           // PPK_KNN_LIST: entries of the neighbour-candidate list (0 = sized from n and knn)
   std::atomic<long long> host_parts{2};         // PPK_HOST_PARTS: worker threads of a one-device host query (>= 16 Mi rows)
+  std::atomic<long long> edge_list_keep{1};     // PPK_EDGE_LIST_KEEP: the fused host edge call keeps its device list buffer between calls (0: allocate + free per call, measurement)
   // [EXT] a4: 0 = the b-bit collision adjustment is never in effect (upstream as recalled: it is
   // gated on expected == 0, where it is the identity); 1 = applied when expected > 0
   std::atomic<long long> ext_collision_adjust{0};

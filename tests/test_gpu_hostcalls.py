@@ -497,6 +497,42 @@ def test_repeated_host_calls_do_not_leak_device_memory():
     assert base - after < (64 << 20), "device memory shrank by %d MB over 25 passes" % ((base - after) >> 20)
 
 
+def test_fused_host_edge_call_is_steady_at_100k_genomes():
+    """BENCH_r03 recorded [271, 801, 271] ms for three calls of ppk_query_edges_dbs at 100 000 genomes.  Until round 4
+    every call allocated its device edge list (rows / 8 entries: 10 GB here) and freed it again; the list is now kept
+    per device entry (grow-only, tools/stall_hunt.py).  20 calls: none above 1.3 x the median, the buffer is
+    allocated once, and ppk_release_scratch gives the memory back."""
+    import time
+    import torch
+    n = 100000
+    tbl = synth.random_match_table(KMERS)
+    ref = engine.SketchDB(synth.make_sketches_device(n, KMERS, device="cuda:0"), 16, 14, device=0)
+    sub = engine.SketchDB(synth.make_sketches_device(2000, KMERS, device="cuda:0"), 16, 14, device=0)
+    d_sub, _ = engine.dist(sub, None, KMERS, tbl)
+    x_max, y_max = synth.boundary_for_quantile(d_sub.cpu().numpy(), 0.02)
+    sub.close()
+    del d_sub
+    _lib.lib().ppk_release_scratch()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    first, _ = engine.edges_host([ref], None, KMERS, tbl, slope=2, x_max=x_max, y_max=y_max, cap=16 << 20)
+    held = free0 - torch.cuda.mem_get_info(0)[0]
+    ms = []
+    for _ in range(20):
+        t0 = time.perf_counter()
+        edges, _ = engine.edges_host([ref], None, KMERS, tbl, slope=2, x_max=x_max, y_max=y_max, cap=16 << 20)
+        ms.append((time.perf_counter() - t0) * 1e3)
+        assert len(edges) == len(first)
+    assert np.array_equal(edges, first)
+    assert abs((free0 - torch.cuda.mem_get_info(0)[0]) - held) < (64 << 20)       # nothing allocated after call 1
+    med = float(np.median(ms))
+    assert max(ms) <= 1.3 * med, "a stalled call: %s" % " ".join("%.0f" % x for x in ms)
+    ref.close()
+    _lib.lib().ppk_release_scratch()
+    torch.cuda.synchronize()
+    assert free0 - torch.cuda.mem_get_info(0)[0] < (64 << 20) + n * 8960 * 0        # scratch and list released
+
+
 def test_host_entry_points_from_four_threads_at_once():
     """The library is called from any thread (PopPUNK's refine optimiser runs thresholdIterate2D from a pool;
     a web service answers queries concurrently): four threads, each looping over a different group of entry
