@@ -512,6 +512,13 @@ int ppk_prune_long(const float *dist, size_t n, size_t cols, const long long *ke
 int ppk_long_to_square(const float *vec, size_t n, int device_id, float *square);
 int ppk_long_to_square_multi(const float *rr, const float *qr, const float *qq, size_t n_ref,
                              size_t n_qry, int device_id, float *square);
+/* replaces the body of PopPUNK.utils.update_distance_matrices (PopPUNK/utils.py:357-408): BOTH square
+ * matrices (core, accessory) from the two-column long matrices [rows][2] as PopPUNK holds them -- one upload of
+ * each, the kernels read the columns in place.  qr == NULL and n_qry == 0: refs only (its longToSquare branch);
+ * else rr [n_ref(n_ref-1)/2][2], qr [n_qry*n_ref][2] (row = q*n_ref + r), qq [n_qry(n_qry-1)/2][2] (may be NULL
+ * when n_qry == 1) -> two (n_ref+n_qry)^2 matrices (its longToSquareMulti branch). */
+int ppk_long_to_square2(const float *rr, const float *qr, const float *qq, size_t n_ref, size_t n_qry,
+                        int device_id, float *core_square, float *acc_square);
 int ppk_square_to_long(const float *square, size_t n, int device_id, float *vec);
 int ppk_knn(const float *square, size_t n, int knn, int device_id, long long *i_out,
             long long *j_out, float *dist_out);

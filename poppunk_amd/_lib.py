@@ -72,6 +72,7 @@ SIGNATURES = {
     "ppk_prune_long": (C.c_int, [_f32p, _sz, _sz, _llp, _sz, C.c_int, _f32p]),
     "ppk_long_to_square": (C.c_int, [_f32p, _sz, C.c_int, _f32p]),
     "ppk_long_to_square_multi": (C.c_int, [_f32p, _f32p, _f32p, _sz, _sz, C.c_int, _f32p]),
+    "ppk_long_to_square2": (C.c_int, [_f32p, _f32p, _f32p, _sz, _sz, C.c_int, _f32p, _f32p]),
     "ppk_square_to_long": (C.c_int, [_f32p, _sz, C.c_int, _f32p]),
     "ppk_knn": (C.c_int, [_f32p, _sz, C.c_int, C.c_int, _llp, _llp, _f32p]),
     "ppk_qc_edges_dev": (C.c_int, [_vp, _sz, _sz, C.c_int, C.c_float, C.c_float, _vp, _sz, _vp, _vp]),

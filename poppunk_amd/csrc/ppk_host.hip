@@ -369,6 +369,19 @@ int db_acquire(int device, const uint64_t *sk, size_t n, size_t nk, size_t s64, 
         *out = c.db;
         return PPK_OK;
       }
+    // the same host array under another content hash: it was rewritten in place, the copy is stale.  Dropped
+    // here, so that the next speculative run does not start on it (and pay a second run), and so that it
+    // does not count against the per-device limit (round-3 advisor finding)
+    for (size_t i = 0; i < g_db_cache.size();) {
+      const CachedDb &c = g_db_cache[i];
+      if (!speculative && c.host == sk && c.n == n && c.nk == nk && c.s64 == s64 && c.bbits == bbits &&
+          c.device == device && c.fp != fp && c.db != pinned) {
+        ppk_db_destroy(c.db);
+        g_db_cache.erase(g_db_cache.begin() + (long)i);
+      } else {
+        ++i;
+      }
+    }
     // room first: the cache never holds more than kDbCachePerDevice databases per device, new one included
     size_t on_dev = 0;
     for (const CachedDb &c : g_db_cache) on_dev += c.device == device;
@@ -1391,7 +1404,6 @@ extern "C" int ppk_qc_edges(const float *dist, size_t n_rows, size_t n_ref, int 
   if (!guard.ok) return ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(device_id));
   size_t guess = n_rows / 16 > ((size_t)1 << 20) ? n_rows / 16 : ((size_t)1 << 20);   // QC failures are the exception
   if (guess > 2 * n_rows) guess = 2 * n_rows;
-  bool uploaded = false;
   auto copy_out = [&](const void *d, size_t n, size_t) {
     if (!ij_out) return ppk_fail(PPK_ERR_ARG, "ij_out is NULL");
     if (hipMemcpy(ij_out, d, n * 16, hipMemcpyDeviceToHost) != hipSuccess) return ppk_fail(PPK_ERR_HIP, "hipMemcpy D2H failed");
@@ -1407,10 +1419,10 @@ extern "C" int ppk_qc_edges(const float *dist, size_t n_rows, size_t n_ref, int 
                            if (rc == PPK_OK && (hipMalloc(reinterpret_cast<void **>(&d_n), 8) != hipSuccess ||
                                                 hipMalloc(d_res, (c ? c : 1) * 16) != hipSuccess))
                              rc = ppk_fail(PPK_ERR_HIP, "hipMalloc failed");
-                           if (rc == PPK_OK && !uploaded) {     // a second pass (guess too small) re-uses the copy
-                             rc = ppk_upload(device_id, d_dist, dist, n_rows * 8, nullptr);
-                             uploaded = rc == PPK_OK;
-                           }
+                           // Every pass uploads: the device mutex (PpkCall) is released between the two passes
+                           // of a too-small guess, and another host thread's call on this device may have
+                           // rewritten, moved or freed SLOT_HOST_IN meanwhile (round-3 advisor finding).
+                           if (rc == PPK_OK) rc = ppk_upload(device_id, d_dist, dist, n_rows * 8, nullptr);
                            unsigned long long total = 0;
                            bool first = true;
                            for (int mode = 0; mode < 2 && rc == PPK_OK; ++mode) {

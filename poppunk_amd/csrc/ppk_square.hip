@@ -545,6 +545,47 @@ extern "C" int ppk_long_to_square_multi(const float *rr, const float *qr, const 
   return rc;
 }
 
+// Both square matrices of update_distance_matrices (PopPUNK/utils.py:357-408) from the two-column long
+// matrices as they are: one upload of each [rows][2] matrix, the kernels read column 0 and column 1 in place
+// (stride 2), two downloads.  The reference slices `distMat[:, [0]]` / `[:, [1]]` on the host (a strided copy
+// each) and converts each column separately; qr == NULL: the plain longToSquare pair.
+extern "C" int ppk_long_to_square2(const float *rr, const float *qr, const float *qq, size_t n_ref, size_t n_qry,
+                                   int device_id, float *core_square, float *acc_square) {
+  if (!rr || !core_square || !acc_square || n_ref == 0) return ppk_fail(PPK_ERR_ARG, "ppk_long_to_square2: NULL buffer / empty input");
+  if ((n_qry != 0) != (qr != nullptr) || (n_qry != 0 && !qq && n_qry > 1))
+    return ppk_fail(PPK_ERR_ARG, "ppk_long_to_square2: query matrices and n_qry do not match");
+  DeviceGuard guard(device_id);
+  if (!guard.ok) return ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(device_id));
+  const size_t n_rr = n_ref * (n_ref - 1) / 2, n_qr = n_ref * n_qry, n_qq = n_qry ? n_qry * (n_qry - 1) / 2 : 0;
+  const size_t n = n_ref + n_qry;
+  HostToucher touch_core(core_square, n * n * 4);
+  HostToucher touch_acc(acc_square, n * n * 4);
+  DevBuf a, b, c, d, e;
+  int rc = a.alloc(n_rr * 8);
+  if (rc == PPK_OK && n_qry) rc = b.alloc(n_qr * 8);
+  if (rc == PPK_OK && n_qq) rc = c.alloc(n_qq * 8);
+  if (rc == PPK_OK) rc = d.alloc(n * n * 4);
+  if (rc == PPK_OK) rc = e.alloc(n * n * 4);
+  if (rc == PPK_OK && n_rr) rc = h2d(a.p, rr, n_rr * 8);
+  if (rc == PPK_OK && n_qry) rc = h2d(b.p, qr, n_qr * 8);
+  if (rc == PPK_OK && n_qq) rc = h2d(c.p, qq, n_qq * 8);
+  float *sq[2] = {static_cast<float *>(d.p), static_cast<float *>(e.p)};
+  for (size_t col = 0; col < 2 && rc == PPK_OK; ++col) {
+    if (n_qry == 0) {
+      rc = ppk_long_to_square_dev(static_cast<float *>(a.p), 2, col, n_ref, sq[col], nullptr);
+    } else {
+      // (one query: its query-query matrix has no rows; the kernel reads nothing of it)
+      rc = ppk_long_to_square_multi_dev(static_cast<float *>(a.p), static_cast<float *>(b.p),
+                                        static_cast<float *>(n_qq ? c.p : b.p), 2, col, n_ref, n_qry, sq[col], nullptr);
+    }
+  }
+  touch_core.join();
+  if (rc == PPK_OK) rc = d2h(core_square, d.p, n * n * 4);
+  touch_acc.join();
+  if (rc == PPK_OK) rc = d2h(acc_square, e.p, n * n * 4);
+  return rc;
+}
+
 extern "C" int ppk_square_to_long(const float *square, size_t n, int device_id, float *vec) {
   if (n < 2) return PPK_OK;
   if (!vec || !square) return ppk_fail(PPK_ERR_ARG, "NULL buffer");

@@ -99,6 +99,7 @@ def _declare(h):
         "H5Tcopy": (_hid, [_hid]), "H5Tset_size": (C.c_int, [_hid, sz]), "H5Tis_variable_str": (C.c_int, [_hid]),
         "H5Tget_super": (_hid, [_hid]), "H5Tclose": (C.c_int, [_hid]), "H5Tset_cset": (C.c_int, [_hid, C.c_int]),
         "H5free_memory": (C.c_int, [C.c_void_p]),
+        "H5Tget_nmembers": (C.c_int, [_hid]), "H5Tget_member_name": (C.c_void_p, [_hid, C.c_uint]),
         "H5Tenum_create": (_hid, [_hid]), "H5Tenum_insert": (C.c_int, [_hid, C.c_char_p, C.c_void_p]),
         "H5Tset_strpad": (C.c_int, [_hid, C.c_int]),
         "H5Ocopy": (C.c_int, [_hid, C.c_char_p, _hid, C.c_char_p, _hid, _hid]),
@@ -147,6 +148,21 @@ def _shape_of(space):
     return tuple(int(d) for d in dims)
 
 
+def _is_bool_enum(tid):
+    """An enum with exactly the members FALSE and TRUE (what h5py stores a numpy bool as)."""
+    h = lib()
+    if h.H5Tget_nmembers(tid) != 2:
+        return False
+    names = set()
+    for i in range(2):
+        p = h.H5Tget_member_name(tid, i)
+        if not p:
+            return False
+        names.add(C.string_at(p))
+        h.H5free_memory(p)
+    return names == {b"FALSE", b"TRUE"}
+
+
 def _read_typed(read, tid, space):
     """Shared body of dataset / attribute reads: numeric arrays, enums, strings."""
     h = lib()
@@ -183,6 +199,8 @@ def _read_typed(read, tid, space):
     mem = tid if is_enum else _native(dt)      # an enum is read in its own type (= its base integers)
     if read(mem, arr.ctypes.data_as(C.c_void_p)) < 0:
         raise RuntimeError("h5lite: read failed")
+    if is_enum and _is_bool_enum(tid):
+        arr = arr.astype(np.bool_)          # h5py's bool: written back as the same enum, not as a bare int8
     return arr if shape else arr[0]
 
 

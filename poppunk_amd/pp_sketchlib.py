@@ -641,6 +641,39 @@ def longToSquareMulti(distVec, query_ref_distVec, query_query_distVec, num_threa
     return out
 
 
+def squareMatrices(distMat, query_ref_distMat=None, query_query_distMat=None):
+    """(core, accessory) square matrices from PopPUNK's two-column long matrices [rows, 2] in ONE engine call
+    (`ppk_long_to_square2`): each matrix is uploaded once as it is and the kernels read its two columns in
+    place.  Refs only, or refs + queries (query_ref rows ordered q * n_ref + r).  Not a pp_sketchlib function:
+    what `poppunk_amd.utils.update_distance_matrices` runs on."""
+    def two_col(a, what):
+        a = np.asarray(a)
+        if a.dtype != np.float32:
+            raise TypeError("%s must be float32" % what)
+        if a.ndim != 2 or a.shape[1] != 2:
+            raise RuntimeError("%s must have two columns (core, accessory)" % what)
+        return np.ascontiguousarray(a)
+    rr = two_col(distMat, "distMat")
+    n_ref = _n_of_rows(rr.shape[0]) if rr.shape[0] else 1
+    fp = C.POINTER(C.c_float)
+    n_qry, qr, qq = 0, None, None
+    if query_ref_distMat is not None:
+        qr = two_col(query_ref_distMat, "query_ref_distMat")
+        qq = two_col(query_query_distMat, "query_query_distMat")
+        n_qry = _n_of_rows(qq.shape[0]) if qq.shape[0] else 1
+        if qr.shape[0] != n_ref * n_qry:
+            raise RuntimeError("query-ref matrix has %d rows, expected %d" % (qr.shape[0], n_ref * n_qry))
+    n = n_ref + n_qry
+    core = np.zeros((n, n), dtype=np.float32)
+    acc = np.zeros((n, n), dtype=np.float32)
+    if n > 1:
+        ptr = (lambda a: None if a is None or a.size == 0 else a.ctypes.data_as(fp))
+        _lib.check(_lib.lib().ppk_long_to_square2(rr.ctypes.data_as(fp), ptr(qr), ptr(qq), n_ref, n_qry,
+                                                  _devices(0)[0], core.ctypes.data_as(fp), acc.ctypes.data_as(fp)),
+                   "squareMatrices")
+    return core, acc
+
+
 def squareToLong(distMat, num_threads=1):
     """Upper triangle of a square matrix in PopPUNK's long order (pp_sketchlib.squareToLong;
     PopPUNK/network.py:2133-2134)."""

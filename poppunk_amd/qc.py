@@ -37,9 +37,10 @@ def prune_distance_matrix(refList, remove_seqs_in, distMat, output, device_id=0)
         sys.stderr.write("Removing " + str(len(remove_seqs)) + " sequences\n")
         keep = np.asarray([i for i in range(len(refList)) if i not in removal], dtype=np.int64)
         newRefList = [refList[i] for i in keep]
-        d = np.asarray(distMat)
-        if d.dtype != np.float32 or not d.flags.c_contiguous:
-            raise TypeError("distMat must be a C-contiguous float32 array")
+        # the reference takes any dtype and layout here (newDistMat = np.empty(..., dtype=distMat.dtype)): the
+        # engine works on a contiguous float32 copy and the result goes back to the caller's dtype
+        src = np.asarray(distMat)
+        d = np.ascontiguousarray(src, dtype=np.float32)
         n, m = len(refList), len(keep)
         if d.shape[0] != n * (n - 1) // 2:
             raise RuntimeError("distMat does not have one row per pair of refList")
@@ -51,6 +52,8 @@ def prune_distance_matrix(refList, remove_seqs_in, distMat, output, device_id=0)
                                            int(device_id),
                                            newDistMat.ctypes.data_as(C.POINTER(C.c_float)))
             _lib.check(rc, "ppk_prune_long")
+        if newDistMat.dtype != src.dtype:
+            newDistMat = newDistMat.astype(src.dtype)
     else:
         newRefList = refList
         newDistMat = distMat
@@ -89,8 +92,9 @@ def qc_edge_lists(distMat, n_ref, max_pi_dist, max_a_dist, zeros=True, device_id
     where the reference builds two full-length Python lists of 0/1 and hands them to
     poppunk_refine.generateTuples (PopPUNK/qc.py:331-337,:348-354).  n_ref = 0: self."""
     d = np.asarray(distMat)
-    if d.dtype != np.float32 or not d.flags.c_contiguous or d.ndim != 2 or d.shape[1] != 2:
-        raise TypeError("distMat must be a C-contiguous float32 [n, 2] array")
+    if d.ndim != 2 or d.shape[1] != 2:
+        raise TypeError("distMat must be an [n, 2] array")
+    d = np.ascontiguousarray(d, dtype=np.float32)     # (the reference's numpy comparisons take any dtype / layout)
     lib = _lib.lib()
     llp = C.POINTER(C.c_longlong)
     modes = 3 if zeros else 1

@@ -2,8 +2,10 @@
 
 `update_distance_matrices` (PopPUNK/utils.py:357-408) is what `poppunk_assign --update-db` and the
 visualisation code use to merge the stored ref-ref distances with freshly computed query-ref and
-query-query distances: three long-form matrices -> two (n_ref + n_query)^2 square matrices, through
-`pp_sketchlib.longToSquare` / `longToSquareMulti` (here: libppk_hip.so, ppk_square.hip).  The file
+query-query distances: three long-form matrices -> two (n_ref + n_query)^2 square matrices.  The reference
+slices each column out on the host and converts it by itself (`pp_sketchlib.longToSquare[Multi]`, which stay
+available in `poppunk_amd.pp_sketchlib` for PopPUNK's own copy of this function); here both squares come from
+one engine call on the two-column matrices (`ppk_long_to_square2`, ppk_square.hip).  The file
 helpers (`storePickle`, `readPickle`, utils.py:135-196), the row iterator (`iterDistRows`,
 utils.py:199-226) and the fd-level `stderr_redirected` (utils.py:61-83) live here too, so that
 `from poppunk_amd.utils import ...` reads like the reference's import lines.
@@ -64,23 +66,13 @@ def iterDistRows(refSeqs, querySeqs, self=True):
 
 def update_distance_matrices(refList, distMat, queryList=None, query_ref_distMat=None,
                              query_query_distMat=None, threads=1):
-    """Long form (n_comparisons x 2: core, accessory) -> square form, merging query distances when
-    given.  Same arguments, keyword calls and return value as PopPUNK/utils.py:357-408:
-    (seqLabels, coreMat, accMat) with seqLabels = refList (+ queryList)."""
-    seqLabels = refList
-    if queryList is not None:
-        seqLabels = seqLabels + queryList
-
+    """Long form (n_comparisons x 2: core, accessory) -> the two square matrices, merging query distances when
+    a query list is given: (seqLabels, coreMat, accMat), the contract of PopPUNK/utils.py:357-408.  Both squares
+    come from ONE engine call on the two-column matrices as they are (`pp_sketchlib.squareMatrices` ->
+    `ppk_long_to_square2`: each matrix crosses PCIe once and the kernels read its columns in place); `threads` is
+    accepted for the signature and unused."""
     if queryList is None:
-        coreMat = pp_sketchlib.longToSquare(distVec=distMat[:, [0]], num_threads=threads)
-        accMat = pp_sketchlib.longToSquare(distVec=distMat[:, [1]], num_threads=threads)
-    else:
-        coreMat = pp_sketchlib.longToSquareMulti(distVec=distMat[:, [0]],
-                                                 query_ref_distVec=query_ref_distMat[:, [0]],
-                                                 query_query_distVec=query_query_distMat[:, [0]],
-                                                 num_threads=threads)
-        accMat = pp_sketchlib.longToSquareMulti(distVec=distMat[:, [1]],
-                                                query_ref_distVec=query_ref_distMat[:, [1]],
-                                                query_query_distVec=query_query_distMat[:, [1]],
-                                                num_threads=threads)
-    return seqLabels, coreMat, accMat
+        core, acc = pp_sketchlib.squareMatrices(distMat)
+        return refList, core, acc
+    core, acc = pp_sketchlib.squareMatrices(distMat, query_ref_distMat, query_query_distMat)
+    return refList + queryList, core, acc

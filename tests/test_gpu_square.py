@@ -170,8 +170,10 @@ def test_prune_distance_matrix_golden_and_random(tmp_path, capsys):
     keep = [i for i in range(n) if i not in set(gone)]
     assert new_names == [names[i] for i in keep]
     assert np.array_equal(new, oracle.prune_long(dist, n, keep))
-    with pytest.raises(TypeError):
-        qc.prune_distance_matrix(names, [names[0]], dist.astype(np.float64), None)
+    # any dtype / layout goes in and the caller's dtype comes out, as in the reference (newDistMat takes
+    # distMat.dtype, PopPUNK/qc.py:75): round-3 advisor finding
+    names64, new64 = qc.prune_distance_matrix(names, [names[i] for i in gone], np.asfortranarray(dist.astype(np.float64)), None)
+    assert names64 == new_names and new64.dtype == np.float64 and np.array_equal(new64, new.astype(np.float64))
 
 
 def test_prune_on_resident_buffers():

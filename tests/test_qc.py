@@ -77,5 +77,10 @@ def test_qc_edge_lists_equal_masks_and_oracle_tuples(n_ref, n_qry):
         only_long, none = qc.qc_edge_lists(d, 0 if n_qry == 0 else n_ref, max_pi, max_a, zeros=False)
         assert none is None and np.array_equal(only_long, got_long)
     assert len(got_zero) > 1000 and len(got_long) == 0
+    # any dtype / layout, as the reference's numpy comparisons take them (round-3 advisor finding)
+    as64, _ = qc.qc_edge_lists(d.astype(np.float64), 0 if n_qry == 0 else n_ref, max_pi, max_a)
+    assert np.array_equal(as64, got_long)
+    strided, _ = qc.qc_edge_lists(np.asfortranarray(d), 0 if n_qry == 0 else n_ref, max_pi, max_a)
+    assert np.array_equal(strided, got_long)
     with pytest.raises(TypeError):
-        qc.qc_edge_lists(d.astype(np.float64), 0, 0.1, 0.1)
+        qc.qc_edge_lists(d[:, 0], 0, 0.1, 0.1)
