@@ -47,6 +47,8 @@ const OptionEntry kOptions[] = {
     {"map", "PPK_MAP", &PpkConfig::map},
     {"strip", "PPK_STRIP", &PpkConfig::strip},
     {"ksplit", "PPK_KSPLIT", &PpkConfig::ksplit},
+    {"ksplit_slices", "PPK_KSPLIT_SLICES", &PpkConfig::ksplit_slices},
+    {"ksplit_fused", "PPK_KSPLIT_FUSED", &PpkConfig::ksplit_fused},
     {"chunk_rows", "PPK_CHUNK_ROWS", &PpkConfig::chunk_rows},
     {"prefault_threads", "PPK_PREFAULT_THREADS", &PpkConfig::prefault_threads},
     {"db_cache", "PPK_DB_CACHE", &PpkConfig::db_cache},
@@ -406,6 +408,8 @@ int scratch_get(int dev, int slot, size_t bytes, void **out) {
     hipError_t e = hipMalloc(&s.p, want);
     if (e != hipSuccess) return ppk_fail(PPK_ERR_HIP, std::string("hipMalloc(scratch): ") + hipGetErrorString(e));
     s.bytes = want;
+    // the per-tile counters of the k-split kernel start at zero and every launch leaves them there
+    if (slot == SLOT_TICKETS && hipMemset(s.p, 0, want) != hipSuccess) return ppk_fail(PPK_ERR_HIP, "hipMemset(scratch) failed");
   }
   tl_call.touched |= 1u << slot;
   *out = s.p;

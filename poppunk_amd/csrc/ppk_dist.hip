@@ -151,6 +151,9 @@ struct DistParams {
   size_t lut_total;       // doubles in the log-J table; the (E, F) table of the fast path follows it
   int k_split;            // > 0: the KSPLIT instantiation (gridDim.y = nk * k_split: one k, or a half / quarter of one, per workgroup)
   size_t ks_rows;         // KSPLIT: rows of the band; its counts go to scratch k-major, [k][row]
+  int ks_blocks;          // KSPLIT: 64-bin blocks one workgroup compares (s64 / k_split)
+  unsigned ks_units;      // KSPLIT, fused fit: workgroups per tile (nk * k_split = gridDim.y)
+  size_t ks_part_off;     // KSPLIT, fused fit: byte offset of the partial counts behind the tile counters
   unsigned r_tiles, q_tiles;   // v2 tile grid
   unsigned n_strip_pad;        // n_strip rounded up to a multiple of 8 (keeps block % 8 = XCD for the rest)
   unsigned n_tiles;            // non-empty tiles of the triangle / rectangle part
@@ -647,9 +650,13 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
   // double buffer: 63 KB.  The modes with a per-pair fit take 80 KB -- two workgroups then own all
   // 160 KB of a CU -- so that the epilogue of an interior tile can hold the whole (E, F) table
   // (5 k x 1024 counts x 16 B) in LDS, see below.
-  constexpr bool LDS_TABLE = NW == 8 && W == 2 && !KSPLIT && (MODE == MODE_DIST || MODE == MODE_MASK || MODE == MODE_KNN);
+  constexpr bool LDS_TABLE = NW == 8 && W == 2 && (MODE == MODE_DIST || MODE == MODE_MASK || MODE == MODE_KNN);
   constexpr int TAB_U4 = 5 * 1024;
-  __shared__ u32x4 lds[LDS_TABLE && TAB_U4 > 2 * CHUNK_U4 ? TAB_U4 : 2 * CHUNK_U4];
+  // KS_FUSED: a k-split job whose tiles are fitted by their last workgroup (below); one more entry behind the
+  // compare buffers holds the workgroup's grid position across the loop, in LDS instead of two SGPRs
+  constexpr bool KS_FUSED = KSPLIT && MODE == MODE_DIST;
+  constexpr int KS_SLOT = 2 * CHUNK_U4;
+  __shared__ u32x4 lds[LDS_TABLE && TAB_U4 > 2 * CHUNK_U4 + 1 ? TAB_U4 : 2 * CHUNK_U4 + (KS_FUSED ? 1 : 0)];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -724,8 +731,20 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
   // one chunk per (k, 64-bin block); with k_split a workgroup owns the chunks of k = blockIdx.y only
   // (a template parameter, not a launch parameter: the tile kernels sit at the SGPR limit and one
   // more live scalar spills into VGPR lanes and from there into scratch inside the loop)
+  // (KSPLIT: workgroup y owns the ks_blocks consecutive blocks of unit y -- the resident layout is
+  // [k][block][plane][sample], so unit y = k * k_split + piece starts at block y * ks_blocks)
   const int k_first = KSPLIT ? (int)blockIdx.y : 0;
-  const int total = (KSPLIT ? 1 : p.nk) * p.s64;
+  const int ublocks = KSPLIT ? p.ks_blocks : p.s64;       // blocks per k (per unit)
+  const int total = KSPLIT ? ublocks : p.nk * p.s64;
+  if constexpr (KS_FUSED) {
+    if (threadIdx.x == 0) {
+      u32x4 pos;
+      pos.x = blockIdx.x;
+      pos.y = blockIdx.y;
+      pos.z = pos.w = 0;
+      lds[KS_SLOT] = pos;
+    }
+  }
 
   // DMA sources: each wavefront copies PW of the chunk's one-KB pieces (28 ref pieces: row i/2,
   // half i%2; then the query pieces: PPP rows x LPP lanes each).  A piece's address is a
@@ -743,13 +762,13 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
     doff[t] = 0;
     if (i < 2 * BB) {
       dkind[t] = 0;
-      dbase[t] = reinterpret_cast<const char *>(refT + ((size_t)k_first * p.s64 * BB + (size_t)(i >> 1)) * p.npad_r + r0 + (i & 1) * 128);
+      dbase[t] = reinterpret_cast<const char *>(refT + ((size_t)k_first * ublocks * BB + (size_t)(i >> 1)) * p.npad_r + r0 + (i & 1) * 128);
       dstep[t] = (size_t)BB * p.npad_r * 8;
       doff[t] = i * 64;
     } else if (i < NPIECE) {
       const int j = i - 2 * BB;
       dkind[t] = 1;
-      dbase[t] = reinterpret_cast<const char *>(qryT + ((size_t)k_first * p.s64 * BB + (size_t)(PPP * j)) * p.npad_q + q0);
+      dbase[t] = reinterpret_cast<const char *>(qryT + ((size_t)k_first * ublocks * BB + (size_t)(PPP * j)) * p.npad_q + q0);
       dstep[t] = (size_t)BB * p.npad_q * 8;
       doff[t] = REF_U4 + j * 64;
     } else {
@@ -853,7 +872,9 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
       }
 #undef PPK_BLOCK_OPERANDS
 
-      if (blk == p.s64 - 1) {
+      if constexpr (KS_FUSED) {
+        // one unit = part of one k: nothing happens between blocks, the counts leave after the loop
+      } else if (blk == ublocks - 1) {
         // ---- end of one k --------------------------------------------------------
         if constexpr (MODE == MODE_DIST || MODE == MODE_MASK || MODE == MODE_KNN) {
           // another k follows: the count register moves up by one field
@@ -902,9 +923,11 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
         }
       }
     }
-    if (++blk == p.s64) {
-      blk = 0;
-      ++k;
+    if constexpr (!KS_FUSED) {
+      if (++blk == ublocks) {
+        blk = 0;
+        ++k;
+      }
     }
     // my DMA pieces have landed; after the barrier everyone's have, and everyone has
     // finished reading `buf` (all ds_read results were consumed above)
@@ -922,7 +945,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
   // ---- epilogue: regression (+ boundary) per pair ---------------------------
   if constexpr (MODE == MODE_DIST || MODE == MODE_MASK || MODE == MODE_KNN) {
     if (p.ablate & 1) return;
-    if (MODE != MODE_KNN && !wave_active) return;      // (KNN: every wave takes part in the LDS exchange)
+    if (!KS_FUSED && MODE != MODE_KNN && !wave_active) return;      // (KNN, k-split: every wave takes part in an exchange)
     // the compare stream leaves the wave at priority 0 (it falls through each block, see
     // tools/gen_block_asm.py); the epilogue is the last thing between this workgroup's slot and the next
     // tile, so it runs at the top priority (measured: another -0.5..-1 %)
@@ -959,6 +982,150 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
     asm volatile("" : "+s"(ka));
     typedef const __attribute__((address_space(4))) DistParams LateParams;
     LateParams &p_late = *reinterpret_cast<LateParams *>(ka + V2_PARAMS_KERNARG_OFFSET);
+    uint32_t ks_tile = 0;
+    if constexpr (KS_FUSED) {
+      // ---- k-split job: ONE launch -----------------------------------------------------------------
+      // Jobs of less than a round of tiles give every tile to ks_units workgroups (one k, or a half / a
+      // quarter of one, each).  A workgroup leaves its 16 partial counts per lane in scratch -- a private
+      // 32-byte slot per (tile, unit, thread), so nothing is indexed by row -- and takes a ticket of its
+      // tile; the one that draws the last ticket adds the units up, rebuilds the count registers exactly
+      // as the whole-tile loop would have left them (k by k: move up one field, add) and runs the same
+      // epilogue as every tile of a large job.  Same expressions on the same registers: the distances are
+      // bit-identical to the tile kernel's and to the former counts pass + regress_packed_kernel pair,
+      // whose second launch (and its gap) this replaces.
+      LateParams &pl = p_late;
+      const u32x4 pos = lds[KS_SLOT];
+      const uint32_t tile = __builtin_amdgcn_readfirstlane(pos.x), unit = __builtin_amdgcn_readfirstlane(pos.y);
+      const uint32_t units = pl.ks_units;
+      const uint32_t tid = (uint32_t)wave * 64u + (uint32_t)lane_late;
+      unsigned *tickets = reinterpret_cast<unsigned *>(mask_out);
+      // partial counts: uint64 [tile][unit][4][512 threads] -- a wavefront's store covers 512 consecutive bytes
+      uint64_t *part = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(mask_out) + pl.ks_part_off);
+      // Visibility between workgroups, which may run on different XCDs (each with its own L2): every access to
+      // the partial counts and to the ticket is an AGENT-scope atomic (relaxed: stores written through, loads
+      // served coherently -- the sc1 forms), and the ticket is taken only after this wavefront's stores have
+      // completed (s_waitcnt vmcnt(0)) and the workgroup's other wavefronts have said the same at the barrier.
+      // That is the compiler's agent-scope release / acquire pair without its two cache-wide operations -- a
+      // write-back of the whole L2 (the data here is never left dirty in it) and an invalidate of the whole L2
+      // (nothing here is read through a plain load): with a `__threadfence()` per workgroup the 400 workgroups
+      // of a 1 000-genome job each flushed and emptied their XCD's L2 and the job took 22 us longer.
+      {
+        // 16 counts of at most 64 * ks_blocks < 2^16 each
+        const uint64_t v0 = (uint64_t)(pw[0][0][0] | (pw[0][1][0] << 16)) | ((uint64_t)(pw[0][2][0] | (pw[0][3][0] << 16)) << 32);
+        const uint64_t v1 = (uint64_t)(pw[0][0][1] | (pw[0][1][1] << 16)) | ((uint64_t)(pw[0][2][1] | (pw[0][3][1] << 16)) << 32);
+        const uint64_t v2 = (uint64_t)(pw[0][0][2] | (pw[0][1][2] << 16)) | ((uint64_t)(pw[0][2][2] | (pw[0][3][2] << 16)) << 32);
+        const uint64_t v3 = (uint64_t)(pw[0][0][3] | (pw[0][1][3] << 16)) | ((uint64_t)(pw[0][2][3] | (pw[0][3][3] << 16)) << 32);
+        uint64_t *mine = part + ((size_t)tile * units + unit) * (4 * NW * 64) + tid;
+        __hip_atomic_store(mine, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine + NW * 64, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine + 2 * NW * 64, v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine + 3 * NW * 64, v3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wavefront's stores are done
+      __syncthreads();
+      if (tid == 0) {
+        const unsigned t = __hip_atomic_fetch_add(tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *reinterpret_cast<volatile unsigned *>(&lds[KS_SLOT]) = t;
+      }
+      __syncthreads();
+      const unsigned ticket = *reinterpret_cast<volatile unsigned *>(&lds[KS_SLOT]);
+      __syncthreads();                                       // (read by all before the table copy below may land on it)
+      if (ticket + 1 != units) return;                       // another workgroup will fit this tile
+      if (tid == 0) __hip_atomic_store(tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every launch leaves the counters at zero
+      ks_tile = tile;
+    }
+    // the tile's partial counts -> the count registers the whole-tile loop would have left (k by k: move up one
+    // field, add the k's pieces).  The counts come from memory, not from this XCD's L2 (agent-scope loads): a
+    // round trip each, so a tile of whole k (at most 5) has ALL its loads in flight at once (40 VGPRs, free
+    // at this point), others two k at a time; the caller issues this behind the epilogue's table copy, which
+    // does not depend on it.
+    auto ks_reload = [&]() __attribute__((always_inline)) {
+      if constexpr (KS_FUSED) {
+        LateParams &pl = p_late;
+        const int slices = pl.k_split, nkk = pl.nk, up = 32 - pl.cnt_bits;
+        const uint32_t tid = (uint32_t)wave * 64u + (uint32_t)lane_late;
+        uint64_t *src = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(mask_out) + pl.ks_part_off) +
+                        (size_t)ks_tile * pl.ks_units * (4 * NW * 64) + tid;
+#pragma unroll
+        for (int i = 0; i < W; ++i)
+#pragma unroll
+          for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int q = 0; q < TQ; ++q) pw[i][r][q] = 0;
+#define PPK_KS_MOVE_UP()                                                                   \
+  _Pragma("unroll") for (int r = 0; r < R; ++r) _Pragma("unroll") for (int q = 0; q < TQ; ++q) { \
+    _Pragma("unroll") for (int i = W - 1; i > 0; --i)                                      \
+        pw[i][r][q] = __builtin_amdgcn_alignbit(pw[i][r][q], pw[i - 1][r][q], up);         \
+    pw[0][r][q] <<= pl.cnt_bits;                                                           \
+  }
+#define PPK_KS_ADD(cq, q)                                                \
+  {                                                                      \
+    const uint32_t a_ = (uint32_t)(cq), b_ = (uint32_t)((cq) >> 32);    \
+    pw[0][0][q] += a_ & 0xffffu;                                         \
+    pw[0][1][q] += a_ >> 16;                                             \
+    pw[0][2][q] += b_ & 0xffffu;                                         \
+    pw[0][3][q] += b_ >> 16;                                             \
+  }
+#define PPK_KS_LOAD(unit_, q) \
+  __hip_atomic_load(src + (size_t)(unit_) * (4 * NW * 64) + (q) * NW * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+        if (nkk <= 5 && slices == 1) {
+          uint64_t c[5][TQ];
+#pragma unroll
+          for (int k = 0; k < 5; ++k)
+            if (k < nkk) {      // wave-uniform
+#pragma unroll
+              for (int q = 0; q < TQ; ++q) c[k][q] = PPK_KS_LOAD(k, q);
+            }
+#pragma unroll
+          for (int k = 0; k < 5; ++k) {
+            if (k < nkk) {
+              if (k) {
+                PPK_KS_MOVE_UP()
+              }
+#pragma unroll
+              for (int q = 0; q < TQ; ++q) PPK_KS_ADD(c[k][q], q)
+            }
+          }
+        } else {
+          uint64_t c[2][4][TQ];
+#pragma unroll
+          for (int h = 0; h < 4; ++h)
+            if (h < slices) {
+#pragma unroll
+              for (int q = 0; q < TQ; ++q) c[0][h][q] = PPK_KS_LOAD(h, q);
+            }
+#pragma unroll 1
+          for (int k2 = 0; k2 < nkk; k2 += 2) {
+#pragma unroll
+            for (int par = 0; par < 2; ++par) {
+              const int k = k2 + par;
+              if (k < nkk) {
+                if (k + 1 < nkk) {
+#pragma unroll
+                  for (int h = 0; h < 4; ++h)
+                    if (h < slices) {
+#pragma unroll
+                      for (int q = 0; q < TQ; ++q) c[par ^ 1][h][q] = PPK_KS_LOAD((k + 1) * slices + h, q);
+                    }
+                }
+                if (k) {
+                  PPK_KS_MOVE_UP()
+                }
+#pragma unroll
+                for (int h = 0; h < 4; ++h)
+                  if (h < slices) {
+#pragma unroll
+                    for (int q = 0; q < TQ; ++q) PPK_KS_ADD(c[par][h][q], q)
+                  }
+              }
+            }
+          }
+        }
+#undef PPK_KS_MOVE_UP
+#undef PPK_KS_ADD
+#undef PPK_KS_LOAD
+      }
+    };
     auto epilogue = [&](LateParams &p) {
     int cr[R];
 #pragma unroll
@@ -991,6 +1158,16 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
       interior = p.lut32 && p.nk >= 3 && p.nk <= 5 && p.cnt_bits == 11 && p.lut_kstride == 1025 &&
                  !strip && !half && !(p.ablate & 32) && r0 + V2_RT <= p.r_limit && q0 >= qb &&
                  q0 + V2_QT <= qe && (!p.self || r0 >= q0 + V2_QT);      // workgroup-uniform
+      if constexpr (KS_FUSED) {
+        // A k-split job fits ONE tile per workgroup with nothing else on the CU to hide behind, and its tiles
+        // are mostly diagonal or band-edge ones: the general statement's sixteen dependent rounds of divergent
+        // gathers were 25 - 30 us of such a job's 80.  Here every tile but the strip ones takes the LDS table;
+        // pairs that do not exist (r <= q, padding, outside the band, the uncompared half of a half tile) are
+        // fitted like the others and simply not written, and only a REAL pair with a k below the floor sends
+        // its wavefront to the general statement.
+        interior = p.lut32 && p.nk >= 3 && p.nk <= 5 && p.cnt_bits == 11 && p.lut_kstride == 1025 && !strip &&
+                   !(p.ablate & 32);
+      }
       if (interior && (ref_clu || qry_clu)) {
         // Several random-match clusters (a real database has ~3, by base composition): the samples of
         // one tile -- one species, neighbours in the database -- almost always share one, and then the
@@ -1011,6 +1188,9 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
       }
     }
     const bool table_in_lds = interior;      // (a wavefront may still leave the interior path: `interior` is cleared)
+    if constexpr (KS_FUSED) {
+      if (!interior && wave_active) ks_reload();
+    }
     if constexpr (LDS_TABLE) {
     if (interior) {
       {
@@ -1031,8 +1211,14 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
             *reinterpret_cast<f64x2 *>(lds + piece * 64) = f64x2{1.0, 1.0};
           }
         }
+        if constexpr (KS_FUSED) {
+          if (wave_active) ks_reload();      // its loads travel beside the table copy
+        }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+      }
+      if constexpr (KS_FUSED) {
+        if (!wave_active) return;      // it has copied its share of the table
       }
       // two register sets of 5 look-ups: pair b+1's are in flight while pair b is finished (three sets
       // measure the same, four spill)
@@ -1072,7 +1258,13 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
           const double pe = e[0].x * e[1].x * e[2].x * e[3].x * e[4].x;
           const double pf = e[0].y * e[1].y * e[2].y * e[3].y * e[4].y;
           // some lane has a k below the floor: the whole wavefront goes through the general statement below
-          if (!__all(pe == pe) && !(p.ablate & 64)) {
+          bool usable = pe == pe;
+          if constexpr (KS_FUSED) {
+            const uint32_t rf = (uint32_t)ref_of(r), q32 = (uint32_t)(qw0 + q);
+            usable = usable || !(q32 >= (uint32_t)qb && q32 < (uint32_t)qe && rf < (uint32_t)p.r_limit &&
+                                 (!p.self || rf > q32) && !(half && r < 2));
+          }
+          if (!__all(usable) && !(p.ablate & 64)) {
             interior = false;
             break;
           }
@@ -1089,6 +1281,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
           const size_t rowq = (p.self ? qq * p.n_ref - (qq * (qq + 1)) / 2 - qq - 1 : qq * p.n_ref) - p.row_base;
           float2 *orow = static_cast<float2 *>(out) + (rowq + r0);
           typedef float f32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+          const bool q_in_band = !KS_FUSED || (qq >= qb && qq < qe);      // wave-uniform
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             f32x4_a8 v;
@@ -1096,7 +1289,19 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
             v.y = acc[2 * h];
             v.z = core[2 * h + 1];
             v.w = acc[2 * h + 1];
-            if (!(p.ablate & 128))      // (measurement only)
+            if constexpr (KS_FUSED) {
+              // the pairs that exist: the general statement's own rule
+              const uint32_t loc = 2u * (uint32_t)lane_late + 128u * h;
+              const uint32_t rf0 = (uint32_t)r0 + loc, q32 = (uint32_t)qq;
+              const bool v0 = q_in_band && !(half && h == 0) && rf0 < (uint32_t)p.r_limit && (!p.self || rf0 > q32);
+              const bool v1 = q_in_band && !(half && h == 0) && rf0 + 1 < (uint32_t)p.r_limit && (!p.self || rf0 + 1 > q32);
+              if (v0 && v1) {
+                *reinterpret_cast<f32x4_a8 *>(orow + loc) = v;
+              } else {
+                if (v0) orow[loc] = make_float2(v.x, v.y);
+                if (v1) orow[loc + 1] = make_float2(v.z, v.w);
+              }
+            } else if (!(p.ablate & 128))      // (measurement only)
               *reinterpret_cast<f32x4_a8 *>(orow + (2u * (uint32_t)lane_late + 128u * h)) = v;
           }
         } else if constexpr (MODE == MODE_MASK) {
@@ -1127,6 +1332,9 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
     }
     }
     if (!interior) {
+    if constexpr (KS_FUSED) {
+      if (!wave_active) return;
+    }
     // A batch = the lane's refs 2h, 2h+1 against query q (2 x nk gathers).  With the default k list
     // the gathers of batch b+1 are issued BEFORE batch b is consumed (two register sets, alternating):
     // the table look-ups are the only memory latency in the epilogue, and there are 8 batches of it.
@@ -1629,6 +1837,28 @@ int launch_v2(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const f
   const size_t n_blocks = n_tri + p.n_strip_pad;
   if (n_blocks * (size_t)(NW * 64) >= ((size_t)1 << 32))
     return ppk_fail(PPK_ERR_ARG, "internal: tile grid too large for one launch (ppk_launch_dist splits bands before this)");
+  if (MODE == MODE_DIST && NW == 8 && p.k_split) {
+    // k-split job in one launch: ks_units workgroups per tile, the last one to finish fits it (KS_FUSED in the
+    // kernel).  Scratch: one zero-initialised counter per tile; 32 bytes per (tile, unit, thread) of partial counts.
+    if constexpr (MODE == MODE_DIST && NW == 8) {
+      void *d_tickets = nullptr, *d_part = nullptr;
+      const size_t ticket_bytes = (n_blocks * 4 + 255) / 256 * 256;
+      int rc = ppk_scratch_get(ref->device, SLOT_TICKETS, ticket_bytes, &d_tickets);
+      if (rc != PPK_OK) return rc;
+      rc = ppk_scratch_get(ref->device, SLOT_ITER_A, n_blocks * (size_t)p.ks_units * (NW * 64) * 32 + 256, &d_part);
+      if (rc != PPK_OK) return rc;
+      p.ks_part_off = (size_t)(static_cast<char *>(d_part) - static_cast<char *>(d_tickets));
+      ppk_set_kernel_name("dist_kernel_v2<256x32,lds-dma,k-split fused>");
+      ppk_prof_begin(s);
+      hipLaunchKernelGGL((dist_kernel_v2<NW, MODE, W, true>), dim3((unsigned)n_blocks, p.ks_units),
+                         dim3(NW * 64), 0, s, ref->d_skT, qry->d_skT, d_lut,
+                         use_clu ? ref->d_clu : nullptr, use_clu ? qry->d_clu : nullptr, d_rtab, d_out,
+                         d_n_failed, static_cast<uint64_t *>(d_tickets), p);
+      ppk_prof_end(s);
+      PPK_HIP(hipGetLastError());
+      return PPK_OK;
+    }
+  }
   ppk_set_kernel_name("dist_kernel_v2<256x32,lds-dma>");
   ppk_prof_begin(s);
   if (MODE == MODE_COUNTS && NW == 8 && p.k_split) {
@@ -1868,12 +2098,18 @@ static int launch_dist_band(const ppk_db *ref, const ppk_db *qry_or_null, const 
       const size_t rt = (ref->n + V2_RT - 1) / V2_RT, qt = (q_end - q_begin + 31) / 32;
       const size_t wgs = (p.self ? rt * qt / 2 + qt : rt * qt) * (size_t)p.nk;
       while (slices < 4 && wgs * (size_t)slices * 2 <= 512 && p.s64 % (slices * 2) == 0) slices *= 2;
+      if (const long long force = ppk_config().ksplit_slices.load(); force > 0 && p.s64 % force == 0) slices = (int)force;
     }
+    p.k_split = slices;
+    p.ks_rows = rows;
+    p.ks_blocks = p.s64 / slices;
+    p.ks_units = (unsigned)(p.nk * slices);
+    // ONE launch: every tile's last unit fits it (a unit's counts travel as 16-bit numbers)
+    if (ppk_config().ksplit_fused.load() != 0 && 64 * (size_t)p.ks_blocks < 65536)
+      return launch_tiles_packed<MODE_DIST>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, nullptr, p, s);
     void *p_cnt = nullptr;
     int rc = ppk_scratch_get(ref->device, SLOT_ITER_A, rows * (size_t)p.nk * slices * 4 + 256, &p_cnt);
     if (rc != PPK_OK) return rc;
-    p.k_split = slices;
-    p.ks_rows = rows;
     {
       DistParams pc = p;
       pc.nk = p.nk * slices;

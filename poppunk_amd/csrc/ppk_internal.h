@@ -40,6 +40,8 @@ struct PpkConfig {
   std::atomic<long long> map{0};                // PPK_MAP: tile order of dist_kernel_v2 (0 = XCD-contiguous runs)
   std::atomic<long long> strip{1};              // PPK_STRIP: strip tiles for the ragged right edge
   std::atomic<long long> ksplit{215};           // PPK_KSPLIT: tile-count threshold (at 5 k) of the small-job path
+  std::atomic<long long> ksplit_fused{1};       // PPK_KSPLIT_FUSED: small jobs run ONE launch (the last unit of a tile fits it); 0 = counts pass + regression pass
+  std::atomic<long long> ksplit_slices{0};      // PPK_KSPLIT_SLICES: pieces each k is cut into on the small-job path (0 = chosen from the job's size; measurement)
   std::atomic<long long> chunk_rows{8ll << 20};     // PPK_CHUNK_ROWS: rows per device buffer of ppk_query
   std::atomic<long long> prefault_threads{8};   // PPK_PREFAULT_THREADS
   std::atomic<long long> db_cache{1};           // PPK_DB_CACHE: ppk_query keeps its resident databases / buffers
@@ -137,7 +139,9 @@ int ppk_launch_assign(const float *d_dist, size_t n_rows, int slope, float x_max
 
 // grow-only per-device scratch (ppk_api.hip)
 enum { SLOT_LUT = 0, SLOT_MASK = 1, SLOT_WS = 2, SLOT_ITER_A = 3, SLOT_ITER_B = 4, SLOT_ITER_C = 5,
-       SLOT_BOUNDS = 6, SLOT_HOST_IN = 7, SLOT_COUNT = 8 };      // HOST_IN: the uploaded input of a host-array call
+       SLOT_BOUNDS = 6, SLOT_HOST_IN = 7,      // HOST_IN: the uploaded input of a host-array call
+       SLOT_TICKETS = 8,                       // one counter per tile of a k-split job: zero when allocated, left zero by every launch
+       SLOT_COUNT = 9 };
 int ppk_scratch_get(int dev, int slot, size_t bytes, void **out);
 void ppk_lut_commit(int dev, const void *d_lut);
 // Scope of one entry point that uses the scratch of `dev`: holds that device's (recursive) mutex and

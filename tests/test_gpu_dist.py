@@ -460,6 +460,57 @@ def test_small_job_k_split_is_bit_identical_to_the_tile_epilogue(ppk_option):
         dq.close()
 
 
+@pytest.mark.parametrize("s64,nk", [(16, 5), (16, 3), (16, 6), (156, 5), (40, 2), (8, 11)])
+def test_small_jobs_in_one_launch_equal_the_two_pass_path_and_the_tile_kernel(ppk_option, s64, nk):
+    """Round 4: a job of less than a round of tiles is ONE launch -- every tile is compared by nk * slices
+    workgroups, each leaves its partial counts in scratch and takes a ticket, the last one rebuilds the count
+    registers and runs the tile kernel's own epilogue (DESIGN.md 3.1 'Small jobs').  Against the former counts
+    pass + regression pass (`ksplit_fused` 0) and the tile kernel itself (`ksplit` 0): bit for bit, for every
+    way of cutting a k into pieces, self and ref x query (a few queries against many refs: poppunk_assign),
+    bands, several clusters, identical and unrelated samples (counts of nbins and of 0), ragged edges (strip
+    tiles), the default sketch size (three-dword count registers); and against the oracle."""
+    import torch
+    kmers = np.arange(13, 13 + 3 * nk, 3, dtype=np.int32)
+    rng = np.random.Generator(np.random.PCG64(s64 * 100 + nk))
+    n = 1000 if s64 == 16 else 420
+    sk, member = synth.make_sketches(n, kmers, sketchsize64=s64, cluster_size=35, seed=nk + s64, related=(nk != 3))
+    sk[7] = sk[3]                                   # duplicates: every bin of every k equal
+    sk[n - 1] = sk[n - 2]
+    clu = (member % 3).astype(np.uint16)
+    tbl3 = (rng.random((nk, 3, 3)) * 0.03).astype(np.float32)
+    n_q = 37
+    for table, clusters in ((synth.random_match_table(kmers), None), (tbl3, clu)):
+        db = engine.SketchDB(sk[:n - n_q], s64, 14, clusters=None if clusters is None else clusters[:n - n_q])
+        dq = engine.SketchDB(sk[n - n_q:], s64, 14, clusters=None if clusters is None else clusters[n - n_q:])
+        jobs = {"self": lambda: engine.dist(db, None, kmers, table),
+                "band": lambda: engine.dist(db, None, kmers, table, q_begin=130, q_end=351),
+                "assign": lambda: engine.dist(db, dq, kmers, table),
+                "one query": lambda: engine.dist(db, dq, kmers, table, q_begin=5, q_end=6)}
+        ppk_option("ksplit", 0)
+        want = {k: (a.clone(), int(f)) for k, (a, f) in ((k, fn()) for k, fn in jobs.items())}
+        ppk_option("ksplit", 100000)
+        ppk_option("ksplit_fused", 0)
+        for k, fn in jobs.items():
+            a, f = fn()
+            assert torch.equal(a, want[k][0]) and int(f) == want[k][1], ("two-pass", k)
+        ppk_option("ksplit_fused", 1)
+        for slices in (0, 1, 2, 4):
+            if slices and s64 % slices:
+                continue
+            ppk_option("ksplit_slices", slices)
+            for rep in range(3):                    # the tile counters must come back to zero after every launch
+                for k, fn in jobs.items():
+                    a, f = fn()
+                    assert _lib.lib().ppk_last_kernel_name().endswith(b"k-split fused>"), k
+                    assert torch.equal(a, want[k][0]) and int(f) == want[k][1], ("fused", slices, rep, k)
+        ppk_option("ksplit_slices", 0)
+        ref_want, ref_failed = oracle.query(sk[:n - n_q], None, kmers, s64, 14, table,
+                                            ref_clu=None if clusters is None else clusters[:n - n_q], threads=8)
+        assert want["self"][1] == ref_failed and np.abs(want["self"][0].cpu().numpy() - ref_want).max() <= TOL
+        db.close()
+        dq.close()
+
+
 def test_host_call_chunks_the_result_through_bounded_device_memory(ppk_option):
     """ppk_query computes its band in sub-bands through two alternating device buffers (the
     reference CUDA path's device-memory chunking): many tiny sub-bands, one or several devices in
