@@ -27,7 +27,15 @@ Rank 0 prints ONE JSON line (see the driver contract) carrying
                  `multi_gpu.host_call`, ONE process driving all N GPUs (a worker thread per device);
   `config5`      BASELINE config 5's shape -- 100 000 genomes self, fused distance -> boundary ->
                  edge list, only the edge lists gathered (engine.edges_sharded) -- timed separately
-                 after the headline steps; `multi_gpu` (N > 1) compute vs gather time.
+                 after the headline steps; `multi_gpu` (N > 1) compute vs gather time;
+  `file_call`    (N = 1) pp_sketchlib.queryDatabase from a reference-layout .h5: cold (native bulk read),
+                 warm (packed sidecar), loaded -- each split into open / resident / query;
+  `config2`, `config4`, `default_sketch`, `kernel2`   (N = 1) the other BASELINE configurations and kernel 2 on
+                 this line, each with its own kernel, kernel_ms (HIP events) and roofline fraction, wall times as
+                 min / median / max.
+N > 1: the two legs that need NO process group -- `multi_gpu.host_call` and `config5.host_call`, one process
+driving all N GPUs -- run on rank 0 BEFORE torch.distributed is initialised (the other ranks wait on a file),
+so a process group that never forms cannot lose them.
 """
 import argparse
 import ctypes as C
@@ -66,6 +74,8 @@ def parse():
     ap.add_argument("--no-host-call", action="store_true", help="skip the host_call leg")
     ap.add_argument("--no-file-call", action="store_true", help="skip the file_call leg (database file -> distances)")
     ap.add_argument("--no-config5", action="store_true", help="skip the config-5 (fused edge list) leg")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the config2 / config4 / default_sketch / kernel2 legs (N = 1)")
     ap.add_argument("--config5-genomes", type=int, default=100000)
     ap.add_argument("--config5-steps", type=int, default=3)
     ap.add_argument("--spinup-ms", type=float, default=200.0,
@@ -275,6 +285,154 @@ def file_call(sk, kmers, tbl, device, reps=3):
         shutil.rmtree(root, ignore_errors=True)
 
 
+def _valu_roof(pairs, ops_per_pair, kernel_ms):
+    lane_ops = ops_per_pair * pairs / (kernel_ms * 1e-3)
+    return {"bound": "valu", "achieved": round(lane_ops / 1e12, 3), "peak": round(VALU_PEAK_LANE_OPS / 1e12, 2),
+            "unit": "T lane-op/s", "frac": round(lane_ops / VALU_PEAK_LANE_OPS, 4), "ops_per_pair": ops_per_pair}
+
+
+def dist_leg(lib, engine, torch, ref, qry, kmers, tbl, steps, ops_per_pair, what, spin_ms=60.0):
+    """One BASELINE configuration on resident sketches: `steps` calls of ppk_dist_dev, each bracketed by a device
+    synchronisation (wall: what a caller that waits sees) and by the library's HIP events around its kernel(s)."""
+    pairs = engine.rows_in_band(ref.n, qry.n if qry is not None else 0, 0, qry.n if qry is not None else ref.n)
+    out = torch.empty((pairs, 2), dtype=torch.float32, device="cuda:%d" % ref.device)
+    nf = torch.zeros(1, dtype=torch.int64, device="cuda:%d" % ref.device)      # one counter: no fill kernel per call
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < spin_ms * 1e-3:
+        engine.dist(ref, qry, kmers, tbl, out=out, n_failed=nf)
+        torch.cuda.synchronize()
+    lib.ppk_prof_enable(1)
+    lib.ppk_prof_read(None, None, 1)
+    wall = []
+    for _ in range(steps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        engine.dist(ref, qry, kmers, tbl, out=out, n_failed=nf)
+        torch.cuda.synchronize()
+        wall.append((time.perf_counter() - t0) * 1e3)
+    lib.ppk_prof_enable(0)
+    kms, kn = C.c_double(0), C.c_longlong(0)
+    lib.ppk_prof_read(C.byref(kms), C.byref(kn), 1)
+    # back to back: `steps` calls queued, one synchronisation (what a pipeline of such calls sustains)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        engine.dist(ref, qry, kmers, tbl, out=out, n_failed=nf)
+    torch.cuda.synchronize()
+    b2b = (time.perf_counter() - t0) / steps * 1e3
+    kernel_ms = kms.value / max(steps, 1)           # all bracketed launches of one call
+    res = {"workload": what, "pairs": pairs, "steps": steps, "wall": _stats(wall), "back_to_back_ms": round(b2b, 4),
+           "kernel": lib.ppk_last_kernel_name().decode(), "kernel_ms": round(kernel_ms, 5),
+           "launches_per_step": kn.value / max(steps, 1), "pairs_per_s": pairs / (kernel_ms * 1e-3),
+           "roofline": _valu_roof(pairs, ops_per_pair, kernel_ms)}
+    del out
+    return res
+
+
+def kernel2_leg(lib, torch, dist_t, x_max, y_max, steps):
+    """Kernel 2 on the resident 10 000-genome matrix: assignThreshold (8 B in + 4 B out per row) and edgeThreshold
+    (8 B in + the mask + 16 B per edge), HIP events on the stream the launches go to (torch's current stream)."""
+    n = dist_t.shape[0]
+    dev = dist_t.device
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    assign_out = torch.empty(n, dtype=torch.float32, device=dev)
+    cap = 1 << 22
+    edges = torch.empty((cap, 2), dtype=torch.int64, device=dev)
+    n_edges = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def assign():
+        rc = lib.ppk_assign_threshold_dev(C.c_void_p(dist_t.data_ptr()), n, 2, float(x_max), float(y_max),
+                                          C.c_void_p(assign_out.data_ptr()), stream)
+        assert rc == 0
+
+    def edge():
+        rc = lib.ppk_edge_threshold_dev(C.c_void_p(dist_t.data_ptr()), n, 0, 2, float(x_max), float(y_max), 1,
+                                        C.c_void_p(edges.data_ptr()), cap, C.c_void_p(n_edges.data_ptr()), stream)
+        assert rc == 0
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        for a, b in ev:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize()
+        return [a.elapsed_time(b) for a, b in ev]
+
+    t_a, t_e = timed(assign), timed(edge)
+    m = int(n_edges.item())
+    a_med, e_med = sorted(t_a)[len(t_a) // 2], sorted(t_e)[len(t_e) // 2]
+    a_bytes, e_bytes = 12.0 * n, 8.0 * n + n / 8.0 * 2 + 16.0 * m
+    return {"rows": n, "steps": steps,
+            "assign": dict(_stats(t_a), kernel="assign_kernel_x2", kernel_ms=round(a_med, 5), bytes=a_bytes,
+                           roofline={"bound": "hbm", "achieved": round(a_bytes / a_med / 1e6, 1), "peak": HBM_PEAK_GBS,
+                                     "unit": "GB/s", "frac": round(a_bytes / a_med / 1e6 / HBM_PEAK_GBS, 4)}),
+            "edges": dict(_stats(t_e), kernel="mask_from_dist_kernel_x2 + mask_count + scan + mask_expand",
+                          kernel_ms=round(e_med, 5), n_edges=m, bytes=e_bytes,
+                          roofline={"bound": "hbm", "achieved": round(e_bytes / e_med / 1e6, 1), "peak": HBM_PEAK_GBS,
+                                    "unit": "GB/s", "frac": round(e_bytes / e_med / 1e6 / HBM_PEAK_GBS, 4)}),
+            "note": "HIP events (torch.cuda.Event on the stream the launches use) around each call; assign = 12 B "
+                    "per row, edges = 8 B per row read + the bit mask written and read + 16 B per edge"}
+
+
+def other_configs(args, lib, engine, torch, synth, ref10k, dist10k, kmers, tbl, local_rank, f, rep):
+    """BASELINE configs 2 and 4, PopPUNK's default sketch size and kernel 2 on the driver's line (N = 1)."""
+    dev = "cuda:%d" % local_rank
+    legs = (("config2", lambda: _config2(lib, engine, torch, synth, kmers, tbl, dev, local_rank)),
+            ("config4", lambda: _config4(lib, engine, torch, synth, ref10k, kmers, tbl, dev, local_rank)),
+            ("default_sketch", lambda: _default_sketch(lib, engine, torch, synth, kmers, dev, local_rank)),
+            ("kernel2", lambda: _kernel2(lib, torch, synth, dist10k)))
+    for name, fn in legs:
+        rep.enter(name)
+        try:
+            f[name] = fn()
+        except Exception as e:
+            rep.error(name, e)
+        torch.cuda.empty_cache()
+
+
+def _config2(lib, engine, torch, synth, kmers, tbl, dev, local_rank):
+    db = engine.SketchDB(synth.make_sketches_device(1000, kmers, device=dev), 16, 14, device=local_rank)
+    try:
+        return dist_leg(lib, engine, torch, db, None, kmers, tbl, 50, VALU_OPS_PER_PAIR,
+                        "BASELINE config 2: 1 000 synthetic genomes self-vs-self, s=1024, k=13,17,21,25,29 (a job of "
+                        "less than one round of tiles: k-split units, the tile's last unit fits it)")
+    finally:
+        db.close()
+
+
+def _config4(lib, engine, torch, synth, ref10k, kmers, tbl, dev, local_rank):
+    qry = engine.SketchDB(synth.make_sketches_device(50000, kmers, device=dev, seed=synth.DEFAULT_SEED + 4), 16, 14,
+                          device=local_rank)
+    try:
+        return dist_leg(lib, engine, torch, ref10k, qry, kmers, tbl, 5, VALU_OPS_PER_PAIR,
+                        "BASELINE config 4 (poppunk_assign): 50 000 queries x the 10 000 resident refs, s=1024, "
+                        "k=13,17,21,25,29, 4 GB of distances left on the device", spin_ms=0.0)
+    finally:
+        qry.close()
+
+
+def _default_sketch(lib, engine, torch, synth, kmers, dev, local_rank):
+    n, s64 = 2650, 156
+    db = engine.SketchDB(synth.make_sketches_device(n, kmers, sketchsize64=s64, device=dev), s64, 14, device=local_rank)
+    t1 = synth.random_match_table(kmers)
+    try:
+        return dist_leg(lib, engine, torch, db, None, kmers, t1, 5, len(kmers) * s64 * 30,
+                        "PopPUNK's default sketch size (--sketch-size 10000 -> sketchsize64 = 156, 9 984 bins, "
+                        "docs/sketching.rst:78-80): %d genomes self-vs-self, k=13,17,21,25,29" % n, spin_ms=0.0)
+    finally:
+        db.close()
+
+
+def _kernel2(lib, torch, synth, dist10k):
+    sample = dist10k[torch.randint(0, dist10k.shape[0], (200000,), device=dist10k.device)].cpu().numpy()
+    x_max, y_max = synth.boundary_for_quantile(sample, 0.02)
+    return kernel2_leg(lib, torch, dist10k, x_max, y_max, 20)
+
+
 def config5(args, rank, world, local_rank, dev, barrier, fields, park):
     """BASELINE config 5's shape on N GPUs: fused distance -> boundary -> edge list per band, only
     the edge lists move (engine.edges_sharded)."""
@@ -321,19 +479,24 @@ def config5(args, rank, world, local_rank, dev, barrier, fields, park):
     fields["config5"] = out        # on record before the extra leg below: a watchdog line carries it
     # the same job as ONE host call of one process (ppk_query_edges_dbs): every device the process sees takes
     # a band on a worker thread of its own, the list arrives in a host array.  Rank 0 alone; the others wait.
-    if rank == 0:
+    if rank == 0 and world == 1:
         try:
             out["host_call"] = config5_host_call(ref, kmers, tbl, x_max, y_max, world, local_rank,
                                                  int(sum(counts)))
-        except Exception as e:          # a figure less, never a lost line or a rank missing at the barrier
+        except Exception as e:          # a figure less, never a lost line
             out["host_call"] = {"error": "%s: %s" % (type(e).__name__, e)}
-    park("config5")
+    elif rank == 0 and fields.get("config5_host_call_solo") is not None:
+        # N > 1: measured by rank 0 alone before the process group existed (solo_legs)
+        out["host_call"] = fields["config5_host_call_solo"]
+        hc = out["host_call"]
+        if isinstance(hc, dict) and "n_edges" in hc and hc["n_edges"] != int(sum(counts)):
+            hc["warning"] = "the host call found %d edges, the sharded step %d" % (hc["n_edges"], int(sum(counts)))
     ref.close()
     torch.cuda.empty_cache()
     return out
 
 
-def config5_host_call(ref, kmers, tbl, x_max, y_max, world, local_rank, n_edges_expected, reps=3):
+def config5_host_call(ref, kmers, tbl, x_max, y_max, world, local_rank, n_edges_expected, reps=5):
     import torch
     from poppunk_amd import engine
     if world == 1 or os.environ.get("PPK_BENCH_ONE_GPU"):
@@ -350,7 +513,7 @@ def config5_host_call(ref, kmers, tbl, x_max, y_max, world, local_rank, n_edges_
         return {"skipped": "rank 0 sees %d of %d GPUs" % (torch.cuda.device_count(), world)}
     try:
         edges, _ = engine.edges_host(dbs, None, kmers, tbl, slope=2, x_max=x_max, y_max=y_max, cap=16 << 20)
-        assert len(edges) == n_edges_expected, (len(edges), n_edges_expected)
+        assert n_edges_expected is None or len(edges) == n_edges_expected, (len(edges), n_edges_expected)
         ts = []
         for _ in range(reps):
             t0 = time.perf_counter()
@@ -360,10 +523,69 @@ def config5_host_call(ref, kmers, tbl, x_max, y_max, world, local_rank, n_edges_
         for d in made:
             d.close()
     pairs = ref.n * (ref.n - 1) // 2
-    return {"what": "ppk_query_edges_dbs: one process, %d device entr%s, databases resident, the edge list in a "
-                    "fresh host array" % (len(dbs), "y" if len(dbs) == 1 else "ies"),
-            "ms": min(ts) * 1e3, "ms_all": [round(t * 1e3, 2) for t in ts], "n_edges": int(len(edges)),
-            "pairs_per_s": pairs / min(ts)}
+    st = _stats([t * 1e3 for t in ts])
+    return dict({"what": "ppk_query_edges_dbs: one process, %d device entr%s, databases resident, the edge list in a "
+                         "fresh host array" % (len(dbs), "y" if len(dbs) == 1 else "ies"),
+                 "ms": st["median_ms"], "ms_all": [round(t * 1e3, 2) for t in ts], "n_edges": int(len(edges)),
+                 "pairs_per_s": pairs / (st["median_ms"] * 1e-3)}, **st)
+
+
+def solo_legs(args, rank, world, local_rank, sk, kmers, tbl, f, rep, fake):
+    """N > 1: the two legs that need no process group, on rank 0 alone, BEFORE torch.distributed is initialised --
+    ONE process driving all N GPUs: `multi_gpu.host_call` (ppk_query_dbs on the 10 000-genome job) and
+    `config5.host_call` (ppk_query_edges_dbs at config-5 size).  The other ranks wait for a file rank 0 writes when
+    it is done (they have not touched their GPUs yet); whatever happens to RCCL afterwards, these are on the line."""
+    flag = os.path.join(rep.per_rank_dir, "solo_done") if rep.per_rank_dir else None
+    if rank != 0:
+        t_end = time.time() + max(60.0, args.watchdog_s if args.watchdog_s > 0 else 600.0)
+        while flag and not os.path.exists(flag) and time.time() < t_end:
+            time.sleep(0.02)
+        return
+    try:
+        if fake:
+            time.sleep(0.01)
+            f["multi_host_call"] = {"fake": True, "devices": list(range(world))}
+            f["config5_host_call_solo"] = {"fake": True}
+            return
+        import torch
+        from poppunk_amd import _lib, engine, synth
+        seen = torch.cuda.device_count()
+        one = bool(os.environ.get("PPK_BENCH_ONE_GPU"))
+        if not args.no_host_call:
+            try:
+                if one:                      # debugging aid: the same GPU listed `world` times
+                    f["multi_host_call"] = host_call(sk, kmers, tbl, [0] * min(world, 4))
+                elif seen >= world:
+                    f["multi_host_call"] = host_call(sk, kmers, tbl, list(range(world)))
+                    f["multi_host_call"]["one_device"] = host_call(sk, kmers, tbl, [local_rank], reps=3)
+                else:
+                    f["multi_host_call"] = {"skipped": "rank 0 sees %d of %d GPUs" % (seen, world)}
+            except Exception as e:
+                rep.error("solo host_call", e)
+        if not args.no_config5:
+            try:
+                n5 = args.config5_genomes
+                dev = "cuda:%d" % local_rank
+                ref5 = engine.SketchDB(synth.make_sketches_device(n5, kmers, device=dev), 16, 14, device=local_rank)
+                sub = engine.SketchDB(synth.make_sketches_device(2000, kmers, device=dev), 16, 14, device=local_rank)
+                d_sub, _ = engine.dist(sub, None, kmers, tbl)
+                x_max, y_max = synth.boundary_for_quantile(d_sub.cpu().numpy(), 0.02)
+                sub.close()
+                del d_sub
+                try:
+                    f["config5_host_call_solo"] = config5_host_call(ref5, kmers, tbl, x_max, y_max, world, local_rank, None)
+                finally:
+                    ref5.close()
+            except Exception as e:
+                f["config5_host_call_solo"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        _lib.lib().ppk_release_scratch()          # the other ranks get their GPUs back empty
+        torch.cuda.empty_cache()
+    finally:
+        if flag:
+            try:
+                open(flag, "w").write("1")
+            except OSError:
+                pass
 
 
 class Report:
@@ -442,6 +664,29 @@ class Report:
             sys.stdout.flush()
 
 
+def recorded_traffic(n, path=None, built_from=None):
+    """(bytes per launch, source, stale) from profiles/pmc_traffic.json -- a figure recorded by rocprofv3 --pmc passes
+    (tools/collect_profiles.sh), stamped there with the hash of the library sources it was measured on.  It is used
+    only when the library loaded NOW was built from the same sources (`ppk_version()` ends in that hash): after any
+    kernel change the recorded bytes are someone else's, and the line says `traffic: null, traffic_stale: true`
+    until the profiles are collected again."""
+    path = path or os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        tj = json.load(open(path))
+    except Exception:
+        return None, None, False
+    if built_from is None:
+        try:
+            from poppunk_amd import _lib
+            built_from = _lib.source_hash()
+        except Exception:
+            built_from = None
+    source = tj.get("source", "profiles/pmc_traffic.json")
+    if not tj.get("src_hash") or tj.get("src_hash") != built_from:
+        return None, "%s [recorded on sources %s, the loaded library is %s]" % (source, tj.get("src_hash"), built_from), True
+    return tj.get("n%d" % n), source, False
+
+
 def build_line(rep):
     """Everything rank 0 knows at this point -> the driver's JSON line."""
     args, world, f = rep.args, rep.world, rep.fields
@@ -467,19 +712,11 @@ def build_line(rep):
         per_launch, k_s = f["per_launch"], kernel_ms * 1e-3
         lane_ops = VALU_OPS_PER_PAIR * per_launch / k_s
         algo_gbs = ALGO_BYTES_PER_PAIR * per_launch / k_s / 1e9
-        traffic, traffic_source = None, None
-        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tfile) and world == 1:
-            try:
-                tj = json.load(open(tfile))
-                traffic = tj.get("n%d" % n)
-                traffic_source = tj.get("source", "profiles/pmc_traffic.json")
-            except Exception:
-                traffic = None
+        traffic, traffic_source, traffic_stale = recorded_traffic(n) if world == 1 else (None, None, False)
         roof = {"bound": "valu", "achieved": round(lane_ops / 1e12, 3), "peak": round(VALU_PEAK_LANE_OPS / 1e12, 2),
                 "unit": "T lane-op/s", "frac": round(lane_ops / VALU_PEAK_LANE_OPS, 4),
                 "frac_of_measured_bitop3_stream": round(lane_ops / VALU_MEASURED_LANE_OPS, 4),
-                "traffic": traffic, "traffic_source": traffic_source,
+                "traffic": traffic, "traffic_source": traffic_source, "traffic_stale": traffic_stale,
                 "hbm_frac_counter": round(traffic / k_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                 "hbm_naive_x": round(algo_gbs / HBM_PEAK_GBS, 2),
                 "hbm_naive_GBs": round(algo_gbs, 1),
@@ -493,8 +730,9 @@ def build_line(rep):
                         "re-uses every sketch row ~250x, so SURVEY 8(d)'s algorithmic bytes (17928 B/pair) "
                         "over the kernel time are hbm_naive_x TIMES the 8 TB/s peak (a reuse factor, not a "
                         "fraction); hbm_frac_counter = PMC-measured fabric bytes per launch (traffic, from "
-                        "traffic_source -- a recorded rocprofv3 run, not measured in this process) / kernel "
-                        "time / 8 TB/s"}
+                        "traffic_source -- a recorded rocprofv3 run, not measured in this process, used only when it "
+                        "was recorded from a library built from the same sources as the one loaded now: otherwise "
+                        "traffic is null and traffic_stale true) / kernel time / 8 TB/s"}
     band_note = f.get("band_note", "1 GPU")
     line = {
         "metric": "genome-pair distances/sec (10k self, s=1024, k=13-29)",
@@ -509,8 +747,13 @@ def build_line(rep):
                    "parallelism": "band-split x%d (%s bands), %d-chunk pipelined p2p gather to rank 0"
                                   % (world, band_note.split(" ")[0], f.get("chunks", args.chunks or 4)) if world > 1 else "1 GPU"},
         "roofline": roof, "cpu_baseline": f.get("cpu"), "host_call": f.get("host_call"),
-        "file_call": f.get("file_call"), "config5": f.get("config5"),
+        "file_call": f.get("file_call"), "config2": f.get("config2"), "config4": f.get("config4"),
+        "default_sketch": f.get("default_sketch"), "kernel2": f.get("kernel2"), "config5": f.get("config5"),
     }
+    if world > 1 and line["config5"] is None and f.get("config5_host_call_solo") is not None:
+        # the sharded leg never ran (no process group): what rank 0 measured alone is still config 5's host call
+        line["config5"] = {"host_call": f["config5_host_call_solo"],
+                           "note": "the band-split leg did not run; host_call: one process, all GPUs (solo_legs)"}
     if value_note:
         line["value_note"] = value_note
     if world > 1:
@@ -613,10 +856,30 @@ def run(args, rep, rank, local_rank, world, fake, torch, dist, engine, synth, da
         torch.cuda.set_device(local_rank)
     backend = "gloo" if fake else os.environ.get("PPK_BENCH_BACKEND", "nccl")   # "gloo": debugging aid with PPK_BENCH_ONE_GPU
     pg_ok = world == 1
+    inject = os.environ.get("PPK_BENCH_INJECT", "")          # self-test: make a collective (or the group itself) fail
+    rep.enter("setup")
+    n = int(round(args.n * world ** 0.5)) if (args.weak and world > 1) else args.n
+    kmers = np.asarray(synth.DEFAULT_KMERS, dtype=np.int32)
+    tbl = synth.random_match_table(kmers)
+    f["n"] = n
+    sk = None
+    if fake:
+        f["data"] = "FAKE (bench.py self-test on CPU: no kernels ran, the numbers mean nothing)"
+    else:
+        sk, _ = synth.make_sketches(n, kmers, sketchsize64=16, bbits=14)
+    if world > 1:
+        # what needs no process group comes first (rank 0 alone, every GPU; the others wait on a file)
+        rep.enter("solo_legs")
+        try:
+            solo_legs(args, rank, world, local_rank, sk, kmers, tbl, f, rep, fake)
+        except Exception as e:
+            rep.error("solo_legs", e)
     rep.enter("init_process_group")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         try:
+            if inject.startswith("init"):
+                raise RuntimeError("injected failure of init_process_group (PPK_BENCH_INJECT)")
             timeout = datetime.timedelta(seconds=args.collective_timeout)
             if backend == "nccl":
                 dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=timeout)
@@ -625,7 +888,6 @@ def run(args, rep, rank, local_rank, world, fake, torch, dist, engine, synth, da
             pg_ok = True
         except Exception as e:
             rep.error("init_process_group", e)
-    inject = os.environ.get("PPK_BENCH_INJECT", "")          # self-test: make a collective fail
     if inject.startswith("isend"):
         after = int(inject.split(":")[1]) if ":" in inject else 0
         real, calls = dist.batch_isend_irecv, [0]
@@ -648,13 +910,8 @@ def run(args, rep, rank, local_rank, world, fake, torch, dist, engine, synth, da
         dist.batch_isend_irecv = hanging
 
     rep.enter("setup")
-    n = int(round(args.n * world ** 0.5)) if (args.weak and world > 1) else args.n
-    kmers = np.asarray(synth.DEFAULT_KMERS, dtype=np.int32)
-    tbl = synth.random_match_table(kmers)
-    f["n"] = n
     if fake:
-        f["data"] = "FAKE (bench.py self-test on CPU: no kernels ran, the numbers mean nothing)"
-        lib, sk = None, None
+        lib = None
         ref = _FakeDB(n)
 
         def band_fn(qb, qe, view):
@@ -663,7 +920,6 @@ def run(args, rep, rank, local_rank, world, fake, torch, dist, engine, synth, da
     else:
         from poppunk_amd import _lib
         lib = _lib.lib()
-        sk, _ = synth.make_sketches(n, kmers, sketchsize64=16, bbits=14)
         ref = engine.SketchDB(sk, 16, 14, device=local_rank)
         band_fn = None
 
@@ -851,27 +1107,11 @@ def run(args, rep, rank, local_rank, world, fake, torch, dist, engine, synth, da
 
     if fake:
         return
-    # ---- the call PopPUNK makes, PCIe both ways.  N = 1: one device.  N > 1: rank 0 alone drives all N GPUs
-    # in-process (ppk_query_dbs, a worker thread per device) while the other ranks wait at the barrier.
-    if not args.no_host_call:
+    # ---- the call PopPUNK makes, PCIe both ways (N = 1; N > 1: measured in solo_legs, before the process group)
+    if not args.no_host_call and world == 1:
         rep.enter("host_call")
         try:
-            if world == 1:
-                f["host_call"] = host_call(sk, kmers, tbl, [local_rank])
-            else:
-                if rank == 0:
-                    try:      # whatever happens here, rank 0 reaches the barrier the other ranks wait at
-                        if os.environ.get("PPK_BENCH_ONE_GPU"):      # debugging aid: the same GPU listed `world` times
-                            f["multi_host_call"] = host_call(sk, kmers, tbl, [0] * min(world, 4))
-                        elif torch.cuda.device_count() >= world:
-                            f["multi_host_call"] = host_call(sk, kmers, tbl, list(range(world)))
-                            f["multi_host_call"]["one_device"] = host_call(sk, kmers, tbl, [local_rank], reps=3)
-                        else:
-                            f["multi_host_call"] = {"skipped": "rank 0 sees %d of %d GPUs"
-                                                               % (torch.cuda.device_count(), world)}
-                    except Exception as e:
-                        rep.error("host_call", e)
-                park("host_call")
+            f["host_call"] = host_call(sk, kmers, tbl, [local_rank])
         except Exception as e:
             rep.error("host_call", e)
 
@@ -881,6 +1121,11 @@ def run(args, rep, rank, local_rank, world, fake, torch, dist, engine, synth, da
             f["file_call"] = file_call(sk, kmers, tbl, local_rank)
         except Exception as e:
             rep.error("file_call", e)
+
+    # ---- BASELINE configs 2 and 4, the default sketch size, kernel 2 (N = 1): the 10 000-genome database and its
+    # distance matrix are still resident
+    if world == 1 and not args.no_other_configs:
+        other_configs(args, lib, engine, torch, synth, ref, job.out, kmers, tbl, local_rank, f, rep)
 
     if not args.no_config5:
         rep.enter("config5")

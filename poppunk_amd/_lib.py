@@ -168,6 +168,29 @@ def lib():
     return _lib
 
 
+def source_hash():
+    """The hash of the sources libppk_hip.so was built from (`ppk_version()` ends in "src:<hash>")."""
+    v = lib().ppk_version().decode()
+    return v.rsplit("src:", 1)[1] if "src:" in v else None
+
+
+def sources_hash_now():
+    """The same hash computed from the sources as they are on disk now (csrc/Makefile HASHED): differs from
+    `source_hash()` when the library has not been rebuilt since an edit.  None when a source is missing."""
+    import hashlib
+    here = os.path.join(_HERE, "csrc")
+    names = ["ppk_api.hip", "ppk_host.hip", "ppk_dist.hip", "ppk_boundary.hip", "ppk_iterate.hip", "ppk_square.hip",
+             "ppk_sparse.hip", "ppk_h5.cpp", "ppk_internal.h", "ppk_block_asm.inc", "../../include/ppk.h"]
+    h = hashlib.sha256()
+    try:
+        for n in names:
+            with open(os.path.join(here, n), "rb") as f:
+                h.update(f.read())
+    except OSError:
+        return None
+    return h.hexdigest()[:16]
+
+
 def set_option(name, value):
     """ppk_set_option: measurement knobs and the [EXT] switches (include/ppk.h)."""
     check(lib().ppk_set_option(name.encode(), int(value)), "ppk_set_option(%s)" % name)

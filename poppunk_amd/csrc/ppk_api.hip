@@ -34,7 +34,11 @@ int ppk_fail(int code, const std::string &msg) {
   return code;
 }
 extern "C" const char *ppk_last_error(void) { return g_err.c_str(); }
-extern "C" const char *ppk_version(void) { return "poppunk_amd 0.3.0 (gfx950)"; }
+#ifndef PPK_SRC_HASH
+#define PPK_SRC_HASH "unhashed"
+#endif
+// "... src:<hash>": sha256 (16 hex digits) of the library's sources at build time (csrc/Makefile HASHED)
+extern "C" const char *ppk_version(void) { return "poppunk_amd 0.4.0 (gfx950) src:" PPK_SRC_HASH; }
 
 // ---- run-time options: PPK_* environment read once, then ppk_set_option only ------------------
 namespace {

@@ -77,3 +77,41 @@ def test_even_bands_flag_skips_the_rebalance():
     d = _run(None, ["--even-bands"])
     mg = _check_common(d)
     assert mg["bands"].startswith("equal (--even-bands)") and "error" not in mg
+
+
+def test_no_collective_legs_survive_a_process_group_that_never_forms():
+    """Round-3 verdict: `multi_gpu.host_call` and `config5.host_call` -- one process driving all N GPUs, no
+    collective -- are measured by rank 0 BEFORE torch.distributed is initialised, so a failing init_process_group
+    still leaves both on the line (FAKE mode: stand-ins, the control flow is what is tested)."""
+    d = _run("init")
+    mg = _check_common(d)
+    assert "injected failure of init_process_group" in mg["error"]
+    assert mg["host_call"] == {"fake": True, "devices": [0, 1]}
+    assert d["config5"]["host_call"] == {"fake": True}
+    assert d["value"] > 0 and "EXCLUDES the gather" in d["value_note"]
+
+
+def test_clean_run_carries_the_solo_legs_too():
+    d = _run(None)
+    assert d["multi_gpu"]["host_call"] == {"fake": True, "devices": [0, 1]}
+
+
+def test_recorded_traffic_is_refused_when_the_library_was_built_from_other_sources(tmp_path):
+    """profiles/pmc_traffic.json is a RECORDED figure (rocprofv3 --pmc passes); bench.py may print it only beside a
+    kernel built from the sources it was measured on (the stamp = ppk_version()'s source hash)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from poppunk_amd import _lib
+    built = _lib.source_hash()
+    assert built and built == _lib.sources_hash_now(), "libppk_hip.so is older than its sources: rebuild"
+    good = tmp_path / "t.json"
+    good.write_text(json.dumps({"n10000": 123.0, "source": "x", "src_hash": built}))
+    assert bench.recorded_traffic(10000, str(good)) == (123.0, "x", False)
+    stale = tmp_path / "s.json"
+    stale.write_text(json.dumps({"n10000": 123.0, "source": "x", "src_hash": "0123456789abcdef"}))
+    t, src, is_stale = bench.recorded_traffic(10000, str(stale))
+    assert t is None and is_stale and "0123456789abcdef" in src
+    unstamped = tmp_path / "u.json"
+    unstamped.write_text(json.dumps({"n10000": 123.0, "source": "x"}))
+    assert bench.recorded_traffic(10000, str(unstamped))[0] is None and bench.recorded_traffic(10000, str(unstamped))[2]
+    assert bench.recorded_traffic(10000, str(tmp_path / "absent.json")) == (None, None, False)

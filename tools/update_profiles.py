@@ -15,7 +15,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = os.environ.get("ROUND", "r03")
+ROUND = os.environ.get("ROUND", "r04")
 SRC = os.path.join(ROOT, "gpurun_out", ROUND)
 DST = os.path.join(ROOT, "profiles", ROUND)
 KERNEL = "dist_kernel_v2"
@@ -23,21 +23,26 @@ KERNEL = "dist_kernel_v2"
 
 def main():
     os.makedirs(DST, exist_ok=True)
-    shutil.copy(os.path.join(SRC, "kt", "kt_kernel_stats.csv"), os.path.join(DST, "bench_kernel_stats.csv"))
+    stats = (glob.glob(os.path.join(SRC, "kt", "*", "kt_kernel_stats.csv")) + glob.glob(os.path.join(SRC, "kt", "kt_kernel_stats.csv")))[0]
+    shutil.copy(stats, os.path.join(DST, "bench_kernel_stats.csv"))
+    if os.path.exists(os.path.join(SRC, "bench_kernel_rows.csv")):      # the same trace split by (kernel, grid)
+        shutil.copy(os.path.join(SRC, "bench_kernel_rows.csv"), DST)
     line = [l for l in open(os.path.join(SRC, "bench.json")) if l.startswith("{")][-1]
     open(os.path.join(DST, "bench_default.json"), "w").write(line)
-    shutil.copy(os.path.join(SRC, "configs.json"), os.path.join(DST, "configs_1gpu.json"))
+    if os.path.exists(os.path.join(SRC, "configs.json")):
+        shutil.copy(os.path.join(SRC, "configs.json"), os.path.join(DST, "configs_1gpu.json"))
     ktc = os.path.join(SRC, "ktc", "c_kernel_stats.csv")
     if os.path.exists(ktc):       # every kernel of tools/measure_configs.py (kernel 2, sweeps, kNN, ...)
         shutil.copy(ktc, os.path.join(DST, "configs_kernel_stats.csv"))
     for f in glob.glob(os.path.join(SRC, "ubench_*.txt")) + [os.path.join(SRC, x) for x in (
-            "power_clocks.txt", "ab_host.txt", "ab_host_parts.txt", "knn_from_tiles.txt", "two_ranks_one_gpu.json")]:
+            "power_clocks.txt", "ab_host.txt", "ab_host_parts.txt", "knn_from_tiles.txt", "two_ranks_one_gpu.json",
+            "smalljob.txt", "smalljob_two_pass.txt", "stall_hunt.txt")]:
         if os.path.exists(f):
             shutil.copy(f, DST)
     counters = {}
     kname = None
     for d in sorted(glob.glob(os.path.join(SRC, "pmc_*"))):
-        for f in glob.glob(os.path.join(d, "*_counter_collection.csv")):
+        for f in glob.glob(os.path.join(d, "*_counter_collection.csv")) + glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
             agg = collections.defaultdict(list)
             for r in csv.DictReader(open(f)):
                 if KERNEL in r["Kernel_Name"]:
@@ -53,7 +58,12 @@ def main():
     json.dump(doc, open(os.path.join(DST, "bench_pmc_counters.json"), "w"), indent=1)
     fetch, write = counters["FETCH_SIZE"]["avg_per_launch"], counters["WRITE_SIZE"]["avg_per_launch"]
     import datetime
+    sys.path.insert(0, ROOT)
+    from poppunk_amd import _lib
     traffic = {"n%d" % bench["config"]["n_genomes"]: (2.0 * fetch + write) * 1024.0,
+               # the sources the measured library was built from (ppk_version()): bench.py uses the figure only
+               # with a library of the same hash
+               "src_hash": _lib.source_hash(),
                "source": "profiles/%s/bench_pmc_counters.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over "
                          "bench.py, %s)" % (ROUND, datetime.date.today().isoformat()),
                "how": "2 x FETCH_SIZE (gfx950 rocprofv3 reports half the bytes of a 16 B/lane stream: "
