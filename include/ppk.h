@@ -20,6 +20,16 @@
  *  - "d_" arguments are device pointers on the database's device; `stream` is
  *    a hipStream_t passed as void* (NULL = the default stream).  Device entry
  *    points only enqueue work; they do not synchronise.
+ *
+ * CONTRACT SURFACE vs EXTRAS.  Everything here is the hot path of SURVEY.md section 8 (kernel 1, kernel 2, the
+ * sweeps, long <-> square, kNN, distance QC, the database-file reader) EXCEPT the entry points tagged
+ *     [OUTSIDE SURVEY 8]
+ * below: ppk_generate_all_tuples[_dev], ppk_lower_rank, ppk_extend, ppk_extend_sketches[_dbs].  Those mirror
+ * the rest of the reference's extension module (src/boundary.cpp:125-150, src/extend.cpp:52-246), which SURVEY.md
+ * section 2 marks out of scope.  Their CPU oracles (oracle/oracle.py) are restatements made by READING the
+ * reference source -- src/extend.cpp needs Eigen and pybind11 to build, absent here -- so their parity is
+ * UNPINNED; the only way to pin them is the `poppunk_refine` half of tools/pin_upstream.py on a machine with the
+ * reference's extension installed.  They are kept working and tested, and not developed further.
  */
 #ifndef PPK_H
 #define PPK_H
@@ -201,7 +211,7 @@ int ppk_generate_tuples_dev(const int32_t *d_assign, size_t n_rows, int within_l
                             long long *d_edges, size_t cap,
                             unsigned long long *d_n_edges, void *stream);
 
-/* replaces poppunk_refine.generateAllTuples (src/python_bindings.cpp:42-47,:98-101;
+/* [OUTSIDE SURVEY 8]  replaces poppunk_refine.generateAllTuples (src/python_bindings.cpp:42-47,:98-101;
  * src/boundary.cpp:125-150; caller PopPUNK/network.py:1087, the dense network): every pair.  self: the
  * condensed rows in order, (i, j) + int_offset; else the reference's loop nest as it stands -- entry
  * j*num_queries + i = (i, j + num_ref) for j < num_ref, i < num_queries, no offset.  The count is known
@@ -317,6 +327,7 @@ int ppk_edge_threshold(const float *dist, size_t n_rows, size_t n_ref, int slope
 int ppk_generate_tuples(const int32_t *assignments, size_t n_rows, int within_label,
                         int self, size_t num_ref, long long int_offset, int device_id,
                         long long *ij_out, size_t cap, size_t *n_edges);
+/* [OUTSIDE SURVEY 8] host form of ppk_generate_all_tuples_dev */
 int ppk_generate_all_tuples(size_t num_ref, size_t num_queries, int self, long long int_offset,
                             int device_id, long long *ij_out, size_t cap, size_t *n_edges);
 /* replaces the numpy masks + .tolist() + poppunk_refine.generateTuples of qcDistMat on a HOST matrix
@@ -362,6 +373,7 @@ int ppk_query_edges(const uint64_t *ref_sk, size_t n_ref, const uint64_t *qry_sk
                     size_t cap, size_t *n_edges, unsigned long long *n_failed);
 
 /* ------------------------------------------------------------------------
+ * [OUTSIDE SURVEY 8: every entry point of this block; oracle restated by reading, parity unpinned]
  * The sparse neighbour matrices of the lineage models (COO triplets, rows ascending; int64 indices,
  * float32 distances; host arrays).  Outputs in row order as the reference concatenates them; *n_out
  * always receives the entry count, PPK_ERR_CAPACITY when it exceeds cap (worst cases below).
