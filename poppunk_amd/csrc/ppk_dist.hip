@@ -2098,14 +2098,20 @@ static int launch_dist_band(const ppk_db *ref, const ppk_db *qry_or_null, const 
       const size_t rt = (ref->n + V2_RT - 1) / V2_RT, qt = (q_end - q_begin + 31) / 32;
       const size_t wgs = (p.self ? rt * qt / 2 + qt : rt * qt) * (size_t)p.nk;
       while (slices < 4 && wgs * (size_t)slices * 2 <= 512 && p.s64 % (slices * 2) == 0) slices *= 2;
-      if (const long long force = ppk_config().ksplit_slices.load(); force > 0 && p.s64 % force == 0) slices = (int)force;
+      if (const long long force = ppk_config().ksplit_slices.load(); force > 0 && force <= 4 && p.s64 % force == 0) slices = (int)force;
     }
+    // The compare loop's in-stream copies always fetch "the next block"; after the last block they re-fetch it.  A
+    // unit of ONE block has no block to re-fetch and would read the block behind its range -- for the last unit of
+    // the last k, behind the array (found by the randomised campaign: s64 = 2 cut in two).  One launch needs units of
+    // at least two blocks; single-block units (sketchsize64 1, or 2 cut in two) keep the two-pass path.
+    if (ppk_config().ksplit_fused.load() != 0)
+      while (slices > 1 && p.s64 / slices < 2) slices /= 2;
     p.k_split = slices;
     p.ks_rows = rows;
     p.ks_blocks = p.s64 / slices;
     p.ks_units = (unsigned)(p.nk * slices);
     // ONE launch: every tile's last unit fits it (a unit's counts travel as 16-bit numbers)
-    if (ppk_config().ksplit_fused.load() != 0 && 64 * (size_t)p.ks_blocks < 65536)
+    if (ppk_config().ksplit_fused.load() != 0 && p.ks_blocks >= 2 && 64 * (size_t)p.ks_blocks < 65536)
       return launch_tiles_packed<MODE_DIST>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, nullptr, p, s);
     void *p_cnt = nullptr;
     int rc = ppk_scratch_get(ref->device, SLOT_ITER_A, rows * (size_t)p.nk * slices * 4 + 256, &p_cnt);

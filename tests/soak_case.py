@@ -15,6 +15,8 @@ def reset_options():
     _lib.set_option("ext_collision_adjust", 0)
     _lib.set_option("ext_fit_skip", 0)
     _lib.set_option("ksplit", 215)
+    _lib.set_option("ksplit_slices", 0)
+    _lib.set_option("ksplit_fused", 1)
     _lib.set_option("launch_tiles", 8000000)
     _lib.set_option("knn_list", 0)
     _lib.set_option("chunk_rows", 8 << 20)
@@ -39,6 +41,9 @@ def soak_case(rng, big=False):
         _lib.set_option("ksplit", 0)
     else:
         _lib.set_option("ksplit", 640)
+    # small jobs: ONE launch (round 4) with every way of cutting a k into pieces, now and then the two-pass path
+    _lib.set_option("ksplit_slices", int(rng.choice([0, 0, 1, 2, 4])))
+    _lib.set_option("ksplit_fused", int(rng.integers(0, 8) != 0))
     # a quarter of the cases run as a very large job would: a few tiles per launch, a short neighbour-candidate
     # list, small pieces in the fused host call
     tiny = rng.integers(0, 4) == 0
@@ -66,11 +71,20 @@ def soak_case(rng, big=False):
     okw = dict(random_tbl=tbl if use_tbl else None, ref_clu=rclu if use_tbl else None,
                qry_clu=qclu if (use_tbl and qry is not None) else None, random_correct=use_tbl, threads=8)
     msgs = []
+    import os
+    import sys
+    trace = (lambda what: (sys.stderr.write("soak: %s\n" % what), sys.stderr.flush())) if os.environ.get("SOAK_TRACE") \
+        else (lambda what: None)
+    trace("bbits=%d s64=%d nk=%d n=%d nr=%d clu=%d tbl=%d related=%d ext=%s tiny=%d ksplit=%d slices=%d fused=%d" % (
+        bbits, s64, nk, n, nr, n_clu, use_tbl, related, ext, tiny, _lib.get_option("ksplit"),
+        _lib.get_option("ksplit_slices"), _lib.get_option("ksplit_fused")))
     try:
         c, _ = pp_sketchlib.query_arrays(ref, qry, kmers, s64, bbits, counts=True)
+        trace("counts done")
         if not np.array_equal(c, oracle.match_counts(ref, qry, s64, bbits, threads=8)):
             msgs.append("counts differ")
         got, gf = pp_sketchlib.query_arrays(ref, qry, kmers, s64, bbits, **kw)
+        trace("dist done")
         want, wf = oracle.query(ref, qry, kmers, s64, bbits, **okw)
         err = float(np.abs(got - want).max(initial=0))
         if gf != wf or not err <= 1e-6:
@@ -88,6 +102,7 @@ def soak_case(rng, big=False):
         parts = [engine.dist(db, dbq, kmers, t_tbl, random_correct=use_tbl, q_begin=a, q_end=b)[0]
                  for a, b in zip(cuts[:-1], cuts[1:])]
         whole = torch.cat(parts).cpu().numpy() if parts else np.zeros((0, 2), np.float32)
+        trace("bands done %s" % cuts)
         if not np.abs(whole - want).max(initial=0) <= 1e-6:
             msgs.append("bands differ")
         if want.shape[0]:
@@ -106,6 +121,7 @@ def soak_case(rng, big=False):
                                     y_max=y_max, scale=scale, inclusive=inclusive, q_begin=a, q_end=b, cap=16)[0]
                   for a, b in zip(ecuts[:-1], ecuts[1:])]
             fe = torch.cat(fe).cpu().numpy()
+            trace("fused edges done")
             if not np.array_equal(fe, np.asarray(we).reshape(-1, 2)):
                 msgs.append("fused edges differ (%d vs %d)" % (len(fe), len(we)))
             # the same list as ONE host call (ppk_query_edges): the device listed 1 - 3 times when bands may
