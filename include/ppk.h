@@ -72,7 +72,8 @@ int ppk_device_count(int *n);
 
 /* Run-time options.  Each has a PPK_<NAME> environment variable that is read ONCE, when the
  * library is first used; afterwards only ppk_set_option changes it.
- *   tuning (never change results): "map", "strip", "ksplit", "chunk_rows", "prefault_threads",
+ *   tuning (never change results): "map", "strip", "ksplit", "ksplit_wide", "ksplit_fused", "ksplit_slices" (the
+ *     small-job path: DESIGN.md section 3.1 and its options table), "chunk_rows", "prefault_threads",
  *     "db_cache", "progress", "launch_tiles" (pair tiles per kernel launch, at most and by default 8 000 000:
  *     a dispatch holds fewer than 2^32 work-items, so bands of more tiles -- 370 000 genomes against
  *     themselves and up -- go out as several launches), "knn_list" (entries of the neighbour-candidate list of

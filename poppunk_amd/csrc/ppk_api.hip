@@ -52,6 +52,7 @@ const OptionEntry kOptions[] = {
     {"strip", "PPK_STRIP", &PpkConfig::strip},
     {"ksplit", "PPK_KSPLIT", &PpkConfig::ksplit},
     {"ksplit_slices", "PPK_KSPLIT_SLICES", &PpkConfig::ksplit_slices},
+    {"ksplit_wide", "PPK_KSPLIT_WIDE", &PpkConfig::ksplit_wide},
     {"ksplit_fused", "PPK_KSPLIT_FUSED", &PpkConfig::ksplit_fused},
     {"chunk_rows", "PPK_CHUNK_ROWS", &PpkConfig::chunk_rows},
     {"prefault_threads", "PPK_PREFAULT_THREADS", &PpkConfig::prefault_threads},

@@ -2043,11 +2043,18 @@ static int launch_dist_band(const ppk_db *ref, const ppk_db *qry_or_null, const 
   bool small = false;
   if (!too_wide && !d_mask && !knn_args && p.bbits == 14 && p.nk >= 2) {
     const size_t rt = (ref->n + V2_RT - 1) / V2_RT, qt = (q_end - q_begin + 31) / 32;
-    // default 215 tiles at 5 k (scaled by 5 / nk: the comparison is between nk * tiles short workgroups
+    // default 1 200 tiles at 5 k since the one-launch form (round 4; profiles/r04/ksplit_threshold*.txt: it wins by
+    // 10 - 50 % up to 4 000 genomes / 1 125 tiles and ties from there to 1 800 tiles; 215 with the two-pass form)
+    // (scaled by 5 / nk: the comparison is between nk * tiles short workgroups
     // and `tiles` long ones).  Measured with the round-2 kernels, 5 k, s = 1024 (k-split vs tile
     // kernel, us): 1 000 genomes / 80 tiles 81 vs 163; 1 500 / 200: 142 vs 158; 1 600 / 225: 168 vs 164;
     // 1 800 / 285: 190 vs 149; 2 400 / 450: 276 vs 215; 2 600 / 533: 326 vs 214; 2 800 / 572: 332 vs 353
-    const long long ks = ppk_config().ksplit.load();   // tile-count threshold at 5 k, 0 = off
+    // (the raised threshold holds where it was measured: sketches whose tiles are fitted from the LDS table -- 3 to 5 k
+    // of 11-bit counts, i.e. s = 1024.  Other shapes fit a tile with the general statement, a long tail for a
+    // k-split tile; PopPUNK's default s = 9 984 at 540 tiles: 2.16 ms against 2.08 through the tile kernel)
+    const bool lds_fit = p.nk >= 3 && p.nk <= 5 && p.cnt_bits == 11;
+    long long ks = ppk_config().ksplit.load();   // tile-count threshold at 5 k, 0 = off
+    if (!lds_fit && ks > ppk_config().ksplit_wide.load()) ks = ppk_config().ksplit_wide.load();
     const size_t limit = ks > 0 ? (size_t)ks * 5 / (size_t)p.nk : 0;
     small = (p.self ? rt * qt / 2 + qt : rt * qt) <= limit;
   }

@@ -492,21 +492,27 @@ struct ppk_h5 {
 
 namespace {
 
-static void walker_sample_params(ppk_h5 *h) {
-  if (h->samples.empty()) return;
+static void sample_params_of(const ppk_h5 *h, size_t idx, size_t *s64, size_t *bbits, std::vector<int64_t> *kmers) {
   std::vector<Msg> msgs;
-  object_messages(h->map, h->samples[0].ohdr, msgs);
+  object_messages(h->map, h->samples[idx].ohdr, msgs);
+  *s64 = *bbits = 0;
+  kmers->clear();
   for (const Msg &g : msgs) {
     if (g.type != 0x000C) continue;
     Attr a;
     if (!parse_attr(g, a) || a.count == 0) continue;
-    if (a.name == "sketchsize64") h->s64 = (size_t)attr_int(a, 0);
-    if (a.name == "bbits") h->bbits = (size_t)attr_int(a, 0);
+    if (a.name == "sketchsize64") *s64 = (size_t)attr_int(a, 0);
+    if (a.name == "bbits") *bbits = (size_t)attr_int(a, 0);
     if (a.name == "kmers") {
-      h->kmers.resize(a.count);
-      for (uint64_t i = 0; i < a.count; i++) h->kmers[i] = attr_int(a, i);
+      kmers->resize(a.count);
+      for (uint64_t i = 0; i < a.count; i++) (*kmers)[i] = attr_int(a, i);
     }
   }
+}
+
+static void walker_sample_params(ppk_h5 *h) {
+  if (h->samples.empty()) return;
+  sample_params_of(h, 0, &h->s64, &h->bbits, &h->kmers);
   if (h->s64 == 0 || h->bbits == 0) throw Unsupported{"first sample lacks sketchsize64 / bbits attributes"};
   if (h->s64 > h->map.size || h->bbits > 64 || h->s64 * h->bbits * 8 > h->map.size)
     throw Unsupported{"sketch size attributes larger than the file"};
@@ -892,7 +898,7 @@ int ppk_h5_names(ppk_h5 *h, char *buf, size_t cap, size_t *need) {
 int ppk_h5_params(ppk_h5 *h, const char *sample, size_t *sketchsize64, size_t *bbits, int64_t *kmers, size_t kmers_cap,
                   size_t *n_kmers) {
   if (!h) return ppk_fail(PPK_ERR_ARG, "ppk_h5_params: bad argument");
-  if (h->backend == 2 && h->s64 == 0) {
+  if (h->backend == 2 && (h->s64 == 0 || sample)) {
     std::string first;
     if (!sample) {
       lib_names(h);
@@ -904,6 +910,24 @@ int ppk_h5_params(ppk_h5 *h, const char *sample, size_t *sketchsize64, size_t *b
     if (rc != PPK_OK) return ppk_fail(rc, "ppk_h5_params: " + err);
   }
   if (h->backend == 1 && h->samples.empty()) return ppk_fail(PPK_ERR_ARG, "ppk_h5_params: no samples in " + h->path);
+  if (h->backend == 1 && sample) {
+    auto it = h->index.find(sample);
+    if (it == h->index.end())
+      return ppk_fail(PPK_ERR_ARG, std::string("ppk_h5_params: sample ") + sample + " not found in sketch database " + h->path);
+    size_t s64 = 0, bb = 0;
+    std::vector<int64_t> ks;
+    try {
+      sample_params_of(h, it->second, &s64, &bb, &ks);
+    } catch (const Unsupported &u) {
+      return ppk_fail(PPK_ERR_STATE, "ppk_h5_params: the direct reader does not read " + h->path + ": " + u.why);
+    }
+    if (sketchsize64) *sketchsize64 = s64;
+    if (bbits) *bbits = bb;
+    if (n_kmers) *n_kmers = ks.size();
+    if (kmers)
+      for (size_t i = 0; i < ks.size() && i < kmers_cap; i++) kmers[i] = ks[i];
+    return PPK_OK;
+  }
   if (sketchsize64) *sketchsize64 = h->s64;
   if (bbits) *bbits = h->bbits;
   if (n_kmers) *n_kmers = h->kmers.size();

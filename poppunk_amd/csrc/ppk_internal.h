@@ -39,7 +39,8 @@ struct PpkConfig {
   std::atomic<long long> ablate{0};             // PPK_ABLATE: skip 1 epilogue, 2 compare, 4 DMA, 8 barriers, 16 first-copy wait, 64 the interior tiles' table copy, 128 stores; 32 LDS-table path off
   std::atomic<long long> map{0};                // PPK_MAP: tile order of dist_kernel_v2 (0 = XCD-contiguous runs)
   std::atomic<long long> strip{1};              // PPK_STRIP: strip tiles for the ragged right edge
-  std::atomic<long long> ksplit{215};           // PPK_KSPLIT: tile-count threshold (at 5 k) of the small-job path
+  std::atomic<long long> ksplit{1200};           // PPK_KSPLIT: tile-count threshold (at 5 k) of the small-job path
+  std::atomic<long long> ksplit_wide{215};      // PPK_KSPLIT_WIDE: the same threshold for sketches whose tiles are not fitted from the LDS table (never above ksplit)
   std::atomic<long long> ksplit_fused{1};       // PPK_KSPLIT_FUSED: small jobs run ONE launch (the last unit of a tile fits it); 0 = counts pass + regression pass
   std::atomic<long long> ksplit_slices{0};      // PPK_KSPLIT_SLICES: pieces each k is cut into on the small-job path (0 = chosen from the job's size; measurement)
   std::atomic<long long> chunk_rows{8ll << 20};     // PPK_CHUNK_ROWS: rows per device buffer of ppk_query

@@ -116,7 +116,14 @@ def random_from_raw(raw, names, klist, base_freq=None):
     need = ("table_keys", "table_values", "matches_keys", "matches_values")
     if raw is None or any(k not in raw for k in need):
         return None
-    keys = [x.decode() if isinstance(x, bytes) else str(x) for x in np.asarray(raw["table_keys"]).ravel()]
+    tk = np.asarray(raw["table_keys"]).ravel()
+    try:
+        # (one C-level conversion for the common fixed-length byte strings; anything else name by name)
+        keys = tk.astype(str).tolist() if tk.dtype.kind in "SU" else None
+    except (UnicodeDecodeError, ValueError):
+        keys = None
+    if keys is None:
+        keys = [x.decode("utf-8", "replace") if isinstance(x, bytes) else str(x) for x in tk]
     vals = np.asarray(raw["table_values"]).ravel()
     mk = [int(x) for x in np.asarray(raw["matches_keys"]).ravel()]
     mv = np.asarray(raw["matches_values"], dtype=np.float64)
@@ -139,16 +146,18 @@ def random_from_raw(raw, names, klist, base_freq=None):
             tbl[i] = 0.0
         else:
             return None
-    of = dict(zip(keys, (int(v) for v in vals)))
     cent = np.asarray(raw["centroids"], dtype=np.float64) if "centroids" in raw else None
     if cent is not None and (cent.ndim != 2 or cent.shape[0] != n_clu):
         cent = None
-    clusters = np.zeros(len(names), dtype=np.uint16)
-    for i, nm in enumerate(names):
-        if nm in of:
-            clusters[i] = of[nm]
-        elif cent is not None and base_freq is not None and cent.shape[1] == np.asarray(base_freq).shape[1]:
-            clusters[i] = int(np.argmin(((cent - np.asarray(base_freq)[i][None, :]) ** 2).sum(axis=1)))
+    if list(names) == keys:                       # the table lists exactly these samples in this order
+        return tbl, np.ascontiguousarray(vals, dtype=np.uint16)
+    of = dict(zip(keys, vals.tolist()))
+    found = np.fromiter((of.get(nm, -1) for nm in names), dtype=np.int64, count=len(names))
+    clusters = np.where(found >= 0, found, 0).astype(np.uint16)
+    absent = np.flatnonzero(found < 0)
+    if absent.size and cent is not None and base_freq is not None and cent.shape[1] == np.asarray(base_freq).shape[1]:
+        bf = np.asarray(base_freq, dtype=np.float64)[absent]
+        clusters[absent] = np.argmin(((cent[None, :, :] - bf[:, None, :]) ** 2).sum(axis=2), axis=1).astype(np.uint16)
     return tbl, clusters
 
 

@@ -14,7 +14,7 @@ from poppunk_amd import _lib, engine, pp_sketchlib, synth
 def reset_options():
     _lib.set_option("ext_collision_adjust", 0)
     _lib.set_option("ext_fit_skip", 0)
-    _lib.set_option("ksplit", 215)
+    _lib.set_option("ksplit", 1200)
     _lib.set_option("ksplit_slices", 0)
     _lib.set_option("ksplit_fused", 1)
     _lib.set_option("launch_tiles", 8000000)

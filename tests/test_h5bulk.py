@@ -62,6 +62,9 @@ def test_direct_reader_libhdf5_loop_and_python_reader_agree(tmp_path):
             assert f.backend == backend and f.declined == ""
             assert f.count() == 2500 and f.names() == sorted(names) and f.has_random
             assert f.params() == (3, 14, KMERS) and f.codon_phased is False
+            assert f.params(names[17]) == (3, 14, KMERS)
+            with pytest.raises(RuntimeError, match="not found"):
+                f.params("nope")
             got, ln, ms, fr = f.read(names, KMERS, 42)
             assert np.array_equal(got, sk) and np.array_equal(ln, lengths) and np.array_equal(fr, freq)
             assert not ms.any()
