@@ -957,6 +957,12 @@ int ppk_h5_read(ppk_h5 *h, const char *names, size_t n, const int32_t *kmers, si
     job.lengths = lengths;
     job.missing = missing;
     job.base_freq = base_freq;
+    // the destination is fresh memory as a rule (np.empty): ask for huge pages before the threads touch it -- 45 faults
+    // instead of 23 000 for a 90 MB array (the copy is bound by them, not by the decoding)
+    {
+      const uintptr_t a = ((uintptr_t)out + 4095) & ~(uintptr_t)4095, e = ((uintptr_t)out + n * nk * words * 8) & ~(uintptr_t)4095;
+      if (e > a + (4u << 20)) (void)madvise((void *)a, e - a, MADV_HUGEPAGE);
+    }
     // most of the file is wanted: map its pages in one call instead of one fault per 4 KB from every thread
     // (MADV_POPULATE_READ, Linux 5.14; older kernels refuse the advice and the faults happen as the copy goes)
     if (n >= h->samples.size() / 4) madvise((void *)h->map.p, h->map.size, 22 /* MADV_POPULATE_READ */);
