@@ -428,7 +428,7 @@ def _default_sketch(lib, engine, torch, synth, kmers, dev, local_rank):
 
 
 def _kernel2(lib, torch, synth, dist10k):
-    sample = dist10k[torch.randint(0, dist10k.shape[0], (200000,), device=dist10k.device)].cpu().numpy()
+    sample = synth.tensor_to_numpy(dist10k[torch.randint(0, dist10k.shape[0], (200000,), device=dist10k.device)])
     x_max, y_max = synth.boundary_for_quantile(sample, 0.02)
     return kernel2_leg(lib, torch, dist10k, x_max, y_max, 20)
 
@@ -449,7 +449,7 @@ def config5(args, rank, world, local_rank, dev, barrier, fields, park):
     sub = engine.SketchDB(synth.make_sketches_device(2000, kmers, device="cuda:%d" % local_rank), 16, 14,
                           device=local_rank)
     d_sub, _ = engine.dist(sub, None, kmers, tbl)
-    x_max, y_max = synth.boundary_for_quantile(d_sub.cpu().numpy(), 0.02)
+    x_max, y_max = synth.boundary_for_quantile(synth.tensor_to_numpy(d_sub), 0.02)
     sub.close()
     del d_sub
 
@@ -569,7 +569,7 @@ def solo_legs(args, rank, world, local_rank, sk, kmers, tbl, f, rep, fake):
                 ref5 = engine.SketchDB(synth.make_sketches_device(n5, kmers, device=dev), 16, 14, device=local_rank)
                 sub = engine.SketchDB(synth.make_sketches_device(2000, kmers, device=dev), 16, 14, device=local_rank)
                 d_sub, _ = engine.dist(sub, None, kmers, tbl)
-                x_max, y_max = synth.boundary_for_quantile(d_sub.cpu().numpy(), 0.02)
+                x_max, y_max = synth.boundary_for_quantile(synth.tensor_to_numpy(d_sub), 0.02)
                 sub.close()
                 del d_sub
                 try:

@@ -314,9 +314,10 @@ extern "C" int ppk_db_create(int device_id, const uint64_t *sk, size_t n, size_t
   if (rc == PPK_OK && clu) {
     e = hipMalloc(reinterpret_cast<void **>(&db->d_clu), db->npad * sizeof(uint16_t));
     if (e == hipSuccess) e = hipMemsetAsync(db->d_clu, 0, db->npad * sizeof(uint16_t), s);
-    if (e == hipSuccess)
-      e = hipMemcpyAsync(db->d_clu, clu, n * sizeof(uint16_t),
-                         src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && src_on_device)
+      e = hipMemcpyAsync(db->d_clu, clu, n * sizeof(uint16_t), hipMemcpyDeviceToDevice, s);
+    else if (e == hipSuccess && ppk_upload(device_id, db->d_clu, clu, n * sizeof(uint16_t), s) != PPK_OK)
+      e = hipErrorUnknown;
     if (e != hipSuccess) rc = PPK_ERR_HIP;
   }
   // the staging copy must outlive the transpose; the host-source path blocks here

@@ -115,10 +115,14 @@ int ppk_upload(int device, void *d_dst, const void *h_src, size_t bytes, hipStre
   if (bytes == 0) return PPK_OK;
   if (device < 0 || device >= 64) return ppk_fail(PPK_ERR_ARG, "device id out of range");
   int nt = (int)ppk_config().prefault_threads.load();
-  if (bytes < ((size_t)4 << 20) || nt < 1) {      // small: the runtime's own path
+  if (bytes < ((size_t)256 << 10) || nt < 1) {      // small: the runtime's own (staged) path
     PPK_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, s));
     return PPK_OK;
   }
+  // (from there up the runtime would register the caller's pages with the driver for the transfer and keep the
+  // registration cached; when the caller frees that array later the driver stops the process's GPU queues to revoke
+  // it and restores them off a timer -- the next kernel starts 10 - 25 ms late: DESIGN.md 3.6, tools/ab_pinning.py)
+  if (bytes < ((size_t)4 << 20)) nt = 1;
   if (nt > 16) nt = 16;
   UploadRing &r = g_ring[device];
   std::lock_guard<std::mutex> lk(r.mu);

@@ -213,8 +213,9 @@ ext_pick_kernel(const uint64_t *__restrict__ skeys, const int *__restrict__ sval
 unsigned blocks_for(size_t items) { return (unsigned)((items + 255) / 256 ? (items + 255) / 256 : 1); }
 
 int h2d(void *d, const void *h, size_t bytes) {
-  if (bytes && hipMemcpy(d, h, bytes, hipMemcpyHostToDevice) != hipSuccess) return ppk_fail(PPK_ERR_HIP, "hipMemcpy H2D failed");
-  return PPK_OK;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return ppk_fail(PPK_ERR_HIP, "hipGetDevice failed");
+  return ppk_upload(dev, d, h, bytes, nullptr);      // staged through the pinned ring; ordered on the null stream
 }
 int d2h(void *h, const void *d, size_t bytes) {
   if (bytes && hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost) != hipSuccess) return ppk_fail(PPK_ERR_HIP, "hipMemcpy D2H failed");

@@ -95,6 +95,18 @@ def boundary_for_quantile(dist, q=0.02):
     return 2.0 * max(x, 1e-4), 2.0 * max(y, 1e-4)
 
 
+def tensor_to_numpy(t):
+    """A CUDA tensor as a numpy array, through a PINNED staging tensor.  `t.cpu()` hands the runtime a pageable
+    destination, which it registers with the driver for the copy; when such an array (or memory next to it) is
+    freed later the driver stops the process's GPU queues for 10 - 25 ms (`ppk_download`) -- the
+    benchmarks must not do that to the calls they time."""
+    import torch
+    stage = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    stage.copy_(t)
+    torch.cuda.current_stream(t.device).synchronize()
+    return stage.numpy().copy()
+
+
 def make_sketches_device(n, kmers=DEFAULT_KMERS, sketchsize64=16, bbits=14, cluster_size=50,
                          seed=DEFAULT_SEED, device="cuda:0", chunk=8192):
     """The `related=True` population model of make_sketches, drawn and bit-sliced ON the device

@@ -509,7 +509,7 @@ def test_fused_host_edge_call_is_steady_at_100k_genomes():
     ref = engine.SketchDB(synth.make_sketches_device(n, KMERS, device="cuda:0"), 16, 14, device=0)
     sub = engine.SketchDB(synth.make_sketches_device(2000, KMERS, device="cuda:0"), 16, 14, device=0)
     d_sub, _ = engine.dist(sub, None, KMERS, tbl)
-    x_max, y_max = synth.boundary_for_quantile(d_sub.cpu().numpy(), 0.02)
+    x_max, y_max = synth.boundary_for_quantile(synth.tensor_to_numpy(d_sub), 0.02)
     sub.close()
     del d_sub
     _lib.lib().ppk_release_scratch()

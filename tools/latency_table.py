@@ -41,7 +41,7 @@ def gpu_side(ref, qry, reps=100):
         engine.dist(ref, qry, K, T, out=out, n_failed=nf)
         b.record()
         torch.cuda.synchronize()
-    return med([a.elapsed_time(b) for a, b in ev]), out.cpu().numpy()
+    return med([a.elapsed_time(b) for a, b in ev]), synth.tensor_to_numpy(out)
 
 
 def host_call(ref_sk, qry_sk, reps=20):

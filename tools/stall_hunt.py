@@ -26,7 +26,7 @@ tbl = synth.random_match_table(kmers)
 ref = engine.SketchDB(synth.make_sketches_device(n, kmers, device="cuda:0"), 16, 14, device=0)
 sub = engine.SketchDB(synth.make_sketches_device(2000, kmers, device="cuda:0"), 16, 14, device=0)
 d_sub, _ = engine.dist(sub, None, kmers, tbl)
-x_max, y_max = synth.boundary_for_quantile(d_sub.cpu().numpy(), 0.02)
+x_max, y_max = synth.boundary_for_quantile(synth.tensor_to_numpy(d_sub), 0.02)
 sub.close()
 del d_sub
 engine.edges_sharded(ref, None, kmers, tbl, 0, 1, slope=2, x_max=x_max, y_max=y_max, cap=16 << 20)
