@@ -22,6 +22,8 @@ rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM GRBM_GUI_AC
 python tools/ab_smalljob.py > $OUT/smalljob.txt 2>&1
 python tools/ab_smalljob.py ksplit_fused=0 > $OUT/smalljob_two_pass.txt 2>&1
 python tools/stall_hunt.py 100000 30 > $OUT/stall_hunt.txt 2> /dev/null
+python tools/ab_pinning.py 2>&1 | grep -v amdgpu > $OUT/ab_pinning.txt
+python tools/latency_table.py 2>&1 | grep -v amdgpu > $OUT/latency_table.txt
 PPK_BENCH_ONE_GPU=1 PPK_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 2 --steps 5 --warmup 2 --config5-genomes 20000 --no-cpu > $OUT/two_ranks_one_gpu.json 2> $OUT/two_ranks_one_gpu.err
 if [ "${FULL:-0}" = "1" ]; then
   timeout 1500 python tools/measure_configs.py $OUT/configs.json > $OUT/configs.log 2>&1

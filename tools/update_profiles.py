@@ -36,7 +36,7 @@ def main():
         shutil.copy(ktc, os.path.join(DST, "configs_kernel_stats.csv"))
     for f in glob.glob(os.path.join(SRC, "ubench_*.txt")) + [os.path.join(SRC, x) for x in (
             "power_clocks.txt", "ab_host.txt", "ab_host_parts.txt", "knn_from_tiles.txt", "two_ranks_one_gpu.json",
-            "smalljob.txt", "smalljob_two_pass.txt", "stall_hunt.txt")]:
+            "smalljob.txt", "smalljob_two_pass.txt", "stall_hunt.txt", "ab_pinning.txt", "latency_table.txt")]:
         if os.path.exists(f):
             shutil.copy(f, DST)
     counters = {}
