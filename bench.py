@@ -164,7 +164,7 @@ def cpu_baseline(sk, kmers, tbl, seconds):
                       % (n_s, sk.shape[0], pairs, reps, total, threads, os.cpu_count() or 0)}
 
 
-def host_call(sk, kmers, tbl, devices, reps=5):
+def host_call(sk, kmers, tbl, devices, reps=9):
     """The call PopPUNK itself makes, after the file read (pp_sketchlib.queryDatabase: the loaded
     database's resident handles -> ppk_query_dbs): host sketches in, a FRESH pageable host result array
     out, PCIe both ways, `devices` driven by ONE process (a worker thread per device).  The first call
@@ -197,7 +197,8 @@ def host_call(sk, kmers, tbl, devices, reps=5):
     warm = sorted(times[1:])
     med = warm[len(warm) // 2]
     return {"devices": list(devices), "first_call_ms": round(times[0], 3), "ms": round(med, 3),
-            "min_ms": round(warm[0], 3), "pairs_per_s": pairs / (med * 1e-3), "result_bytes": pairs * 8,
+            "min_ms": round(warm[0], 3), "max_ms": round(warm[-1], 3), "ms_all": [round(t, 2) for t in times[1:]],
+            "pairs_per_s": pairs / (med * 1e-3), "result_bytes": pairs * 8,
             "worker_threads": int(st[1]), "max_downloads_in_flight": int(st[2]),
             "arrays_ms": round(sorted(arr[1:])[0], 3),
             "note": "pp_sketchlib.queryDatabase after the file read: ppk_query_dbs on resident handles, host "
