@@ -170,7 +170,13 @@ static void group_links(const Map &m, uint64_t btree, uint64_t heap, std::vector
   }
 }
 
-// B-tree and heap of a group from its object header (when the symbol table entry did not cache them).
+// B-tree and heap of a group, ALWAYS from its object header.  A symbol table entry also caches the two addresses of
+// the group it points to, but that cache goes stale: when a link that a symbol table cannot hold is added to an
+// old-style group -- a sample whose name is not plain ASCII is enough -- the library converts the group to link
+// messages, drops the Symbol Table message from its header and leaves the old B-tree, and the parent's cached
+// addresses, behind.  Read through the cache such a database shows the samples it had BEFORE the conversion and
+// nothing else (tests/test_h5bulk.py::test_odd_but_legal_databases found exactly that).  A header without the
+// message is a new-style group: the direct reader declines and libhdf5 reads the file.
 static void group_of_object(const Map &m, uint64_t ohdr, uint64_t &btree, uint64_t &heap, std::vector<Msg> &scratch) {
   object_messages(m, ohdr, scratch);
   for (const Msg &g : scratch)
@@ -331,7 +337,8 @@ static Extent dataset_extent(const Map &m, uint64_t ohdr, uint64_t *count, std::
     if (layout->size < 18) throw Unsupported{"short layout message"};
     uint64_t addr = rd(l + 2, 8), bytes = rd(l + 10, 8);
     if (bytes != *count * 8) throw Unsupported{"dataset size does not match its space"};
-    if (addr == UNDEF) return {nullptr, bytes};
+    // (storage never allocated: the values are the dataset's fill value, which the library knows how to find)
+    if (addr == UNDEF) throw Unsupported{"dataset without allocated storage"};
     return {m.at(addr, bytes), bytes};
   }
   if (l[1] == 0) {
@@ -542,11 +549,7 @@ static void walker_open(ppk_h5 *h) {
   const uint8_t *root = sb + pos + 32;
   uint64_t root_ohdr = rd(root + 8, 8), rb = UNDEF, rh = UNDEF;
   std::vector<Msg> scratch;
-  if (rd(root + 16, 4) == 1) {
-    rb = rd(root + 24, 8);
-    rh = rd(root + 32, 8);
-  } else
-    group_of_object(h->map, root_ohdr, rb, rh, scratch);
+  group_of_object(h->map, root_ohdr, rb, rh, scratch);
   std::vector<Link> top;
   group_links(h->map, rb, rh, top, h->map.size / 40 + 16);
   const Link *sk = nullptr;
@@ -564,8 +567,8 @@ static void walker_open(ppk_h5 *h) {
       if (g.type == 0x000C && parse_attr(g, a) && a.count >= 1 && a.name == "codon_phased") h->codon_phased = attr_int(a, 0) != 0;
     }
   }
-  uint64_t sb_ = sk->btree, sh_ = sk->heap;
-  if (sk->cache != 1) group_of_object(h->map, sk->ohdr, sb_, sh_, scratch);
+  uint64_t sb_ = UNDEF, sh_ = UNDEF;
+  group_of_object(h->map, sk->ohdr, sb_, sh_, scratch);
   group_links(h->map, sb_, sh_, h->samples, h->map.size / 40 + 16);
   h->index.reserve(h->samples.size() * 2);
   for (size_t i = 0; i < h->samples.size(); i++) h->index.emplace(h->samples[i].name, i);
@@ -603,20 +606,18 @@ static void walker_read_range(ReadJob &job) {
         auto it = h->index.find((*job.names)[i]);
         if (it == h->index.end()) throw std::string("sample ") + (*job.names)[i] + " not found in sketch database " + h->path;
         const Link &s = h->samples[it->second];
-        uint64_t bt = s.btree, hp = s.heap;
-        bool need_attrs = job.lengths || job.missing || job.base_freq;
-        if (need_attrs || s.cache != 1) {
+        uint64_t bt = UNDEF, hp = UNDEF;
+        {
+          // (the sample group's own header, never the addresses cached next to its name: see group_of_object)
           object_messages(m, s.ohdr, msgs);
-          if (s.cache != 1) {
-            bool found = false;
-            for (const Msg &g : msgs)
-              if (g.type == 0x0011 && g.size >= 16 && !(g.flags & 2)) {
-                bt = rd(g.data, 8);
-                hp = rd(g.data + 8, 8);
-                found = true;
-              }
-            if (!found) throw Unsupported{"sample group without a symbol table"};
-          }
+          bool found = false;
+          for (const Msg &g : msgs)
+            if (g.type == 0x0011 && g.size >= 16 && !(g.flags & 2)) {
+              bt = rd(g.data, 8);
+              hp = rd(g.data + 8, 8);
+              found = true;
+            }
+          if (!found) throw Unsupported{"sample group without a symbol table (new-style links)"};
           if (job.lengths) job.lengths[i] = 0;
           if (job.missing) job.missing[i] = 0;
           if (job.base_freq)

@@ -299,3 +299,85 @@ def test_database_parameter_readers_go_through_one_native_pass(tmp_path, capsys)
     assert "kmer lengths inconsistent: [13, 17, 21] vs [13, 17, 21, 25]" in capsys.readouterr().err
     with pytest.raises(SystemExit):
         sketchdb.readDBParams(d)
+
+
+@pytest.mark.skipif(not have_h5py(), reason="needs the interpreter with h5py")
+def test_odd_but_legal_databases(tmp_path):
+    """What h5py users' files may hold: sample names with spaces, very long names, attributes stored as int32 /
+    uint8 / float32, a sample without `base_freq` or `length`, an extra dataset and a nested group inside a sample,
+    variable-length string attributes next to the numeric ones, a single k, sketches of one word, an empty
+    database.  Both native backends and the loader agree with what was written.
+
+    And ONE sample whose name is not plain ASCII: libhdf5 then converts /sketches from a symbol table to link
+    messages and leaves the old table -- with the samples added before -- behind, still pointed at by the cache in
+    the root group's entry.  The direct reader must see that the group's own header has no symbol table any more and
+    hand the file to libhdf5, not list the samples of the stale table (it did, until this test)."""
+    rng = np.random.Generator(np.random.PCG64(21))
+    sk = rng.integers(0, 1 << 63, size=(6, 2, 5), dtype=np.uint64)
+    np.savez(tmp_path / "src.npz", sk=sk)
+    script = r'''
+import sys, numpy as np, h5py
+sk = np.load(sys.argv[1])["sk"]
+def write(path, names):
+    with h5py.File(path, "w") as f:
+        g = f.create_group("sketches"); g.attrs["sketch_version"] = "v"; g.attrs["codon_phased"] = np.bool_(False)
+        for i, nm in enumerate(names):
+            s = g.create_group(nm)
+            s.attrs["sketchsize64"] = np.int32(1); s.attrs["bbits"] = np.uint8(5); s.attrs["kmers"] = np.asarray([15, 31], dtype=np.int32)
+            s.attrs["comment"] = "a variable-length string"; s.attrs["reads"] = np.bool_(True)
+            if i != 1:
+                s.attrs["length"] = np.uint32(5000 + i); s.attrs["base_freq"] = np.asarray([0.1, 0.2, 0.3, 0.4])
+            s.attrs["missing_bases"] = np.int16(i)
+            for j, k in enumerate((15, 31)):
+                s.create_dataset(str(k), data=sk[i, j])
+            if i == 3:
+                s.create_dataset("notes", data=np.arange(7)); s.create_group("sub").create_dataset("deep", data=np.zeros(3))
+write(sys.argv[2] + "/ascii.h5", ["plain", "with space", "tab\tinside", "x" * 200, "0", "zz_not-a-path"])
+write(sys.argv[2] + "/odd.h5", ["plain", "with space", "\u00dcn\u00efc\u00f6d\u00e9_\u682a", "x" * 200, "0", "zz_not-a-path"])
+with h5py.File(sys.argv[2] + "/empty.h5", "w") as f:
+    f.create_group("sketches")
+with h5py.File(sys.argv[2] + "/onek.h5", "w") as f:
+    g = f.create_group("sketches")
+    s = g.create_group("only"); s.attrs["sketchsize64"] = 1; s.attrs["bbits"] = 1; s.attrs["kmers"] = [21]
+    s.create_dataset("21", data=np.asarray([12345], dtype=np.uint64))
+'''
+    r = subprocess.run([H5_PYTHON, "-c", script, str(tmp_path / "src.npz"), str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+
+    def check(f, names):
+        order = sorted(range(6), key=lambda i: names[i].encode())
+        assert f.names() == [names[i] for i in order]
+        assert f.params() == (1, 5, [15, 31]) and f.params("with space") == (1, 5, [15, 31]) and f.codon_phased is False
+        got, ln, ms, fr = f.read(names, [31, 15], 5, threads=2)
+        assert np.array_equal(got, sk[:, [1, 0]])
+        assert list(ln) == [5000, 0, 5002, 5003, 5004, 5005] and list(ms) == [0, 1, 2, 3, 4, 5]
+        assert np.isnan(fr[1]).all() and np.allclose(fr[[0, 2, 3, 4, 5]], [0.1, 0.2, 0.3, 0.4])
+        s64, bb, km, nk = f.all_params()
+        assert (s64 == 1).all() and (bb == 5).all() and (nk == 2).all()
+
+    ascii_names = ["plain", "with space", "tab\tinside", "x" * 200, "0", "zz_not-a-path"]
+    odd_names = ["plain", "with space", "Ünïcödé_株", "x" * 200, "0", "zz_not-a-path"]
+    for backend in (1, 2):
+        with h5bulk.H5Bulk(str(tmp_path / "ascii.h5"), backend) as f:
+            assert f.backend == backend
+            check(f, ascii_names)
+        with h5bulk.H5Bulk(str(tmp_path / "empty.h5"), backend) as f:
+            assert f.count() == 0 and f.names() == []
+            with pytest.raises(RuntimeError):
+                f.params()
+        with h5bulk.H5Bulk(str(tmp_path / "onek.h5"), backend) as f:
+            assert f.params() == (1, 1, [21])
+            assert int(f.read(["only"], [21], 1)[0][0, 0, 0]) == 12345
+    with pytest.raises(RuntimeError, match="direct reader does not read"):
+        h5bulk.H5Bulk(str(tmp_path / "odd.h5"), 1)
+    with h5bulk.H5Bulk(str(tmp_path / "odd.h5")) as f:
+        assert f.backend == 2 and "symbol table" in f.declined and f.count() == 6
+        check(f, odd_names)
+    for stem, names in (("ascii", ascii_names), ("odd", odd_names)):
+        ld = sketchdb.load(str(tmp_path / stem), names[::-1], [15, 31])
+        assert np.array_equal(ld.sketches, sk[::-1]) and ld.base_freq is None and ld.random_status == "absent"
+        assert sketchdb.last_load["backend"] == (1 if stem == "ascii" else 2)
+        assert sketchdb.getSeqsInDb(str(tmp_path / (stem + ".h5"))) == sorted(names, key=lambda x: x.encode())
+        warm = sketchdb.load(str(tmp_path / stem), names, [31])
+        assert sketchdb.last_load["source"] == "sidecar" and np.array_equal(warm.sketches, sk[:, [1]])
+        assert list(warm.lengths) == [5000, 0, 5002, 5003, 5004, 5005] and warm.names == names
