@@ -9,7 +9,9 @@
 //                  with their default (earliest-format) settings, i.e. every PopPUNK database.  Samples
 //                  are independent, so the per-sample work runs on several threads; nothing is decoded
 //                  that is not needed (no property lists, no type conversion paths, no metadata cache).
-//   2 "libhdf5" -- anything the walker does not recognise (superblock 2/3, dense or compact-link groups,
+//                  (A /sketches group that libhdf5 has converted to new-style links -- one non-ASCII sample name does
+//                  that -- is LISTED through libhdf5, one H5Literate, and its samples read here all the same.)
+//   2 "libhdf5" -- anything the walker does not recognise (superblock 2/3, new-style groups elsewhere,
 //                  chunked / filtered / big-endian / shared-message objects) is read through libhdf5's own
 //                  C API, dlopen-ed at first need: one H5Fopen, per sample one H5Gopen2 and nk
 //                  H5Dopen2 + H5Dread straight into the caller's array.  ~23 us per dataset against the
@@ -493,6 +495,7 @@ struct ppk_h5 {
   // parameters of the first sample
   size_t s64 = 0, bbits = 0;
   std::vector<int64_t> kmers;
+  bool listed_by_library = false;   // /sketches is a new-style group: names and addresses came from H5Literate
   int codon_phased = -1;      // attribute of /sketches: -1 absent
   uint64_t sketches_ohdr = UNDEF;
 };
@@ -523,6 +526,49 @@ static void walker_sample_params(ppk_h5 *h) {
   if (h->s64 == 0 || h->bbits == 0) throw Unsupported{"first sample lacks sketchsize64 / bbits attributes"};
   if (h->s64 > h->map.size || h->bbits > 64 || h->s64 * h->bbits * 8 > h->map.size)
     throw Unsupported{"sketch size attributes larger than the file"};
+}
+
+// /sketches as a NEW-style group inside an otherwise old-style file (what one non-ASCII sample name leaves behind: the
+// links live in messages or in a fractal heap indexed by a v2 B-tree).  The direct reader does not decode those; it
+// asks libhdf5 for the one thing it needs from them -- every link's name and object address, one H5Literate over the
+// group (the 1.10 / H5Literate1 form of the callback's `info`, whose hard-link address sits at byte 24) -- and reads
+// the samples, whose own groups are ordinary symbol tables, itself.  An address that does not lead to such a group
+// makes the read decline like any other surprise, so a wrong guess about `info` costs speed, never correctness.
+struct HybridList {
+  std::vector<Link> *out;
+};
+static herr_t hybrid_collect(hid_t, const char *name, const void *info, void *ud) {
+  const uint8_t *p = static_cast<const uint8_t *>(info);
+  int type;
+  memcpy(&type, p, 4);
+  if (type != 0) return 0;                 // (hard links only: H5L_TYPE_HARD)
+  Link l;
+  l.name = name;
+  memcpy(&l.ohdr, p + 24, 8);
+  l.cache = 0;
+  l.btree = l.heap = UNDEF;
+  static_cast<HybridList *>(ud)->out->push_back(std::move(l));
+  return 0;
+}
+static bool hybrid_list_sketches(ppk_h5 *h) {
+  std::lock_guard<std::mutex> g(g_h5_mutex);
+  std::string err;
+  Hdf5 *L = hdf5_library(err);
+  if (!L) return false;
+  const hid_t file = L->H5Fopen(h->path.c_str(), 0, 0);
+  if (file < 0) return false;
+  const hid_t top = L->H5Gopen2(file, "sketches", 0);
+  bool ok = false;
+  if (top >= 0) {
+    HybridList hl{&h->samples};
+    hsize_t idx = 0;
+    ok = L->H5Literate(top, 0 /* H5_INDEX_NAME */, 0 /* H5_ITER_INC */, &idx, hybrid_collect, &hl) >= 0;
+    L->H5Gclose(top);
+  }
+  L->H5Fclose(file);
+  if (!ok) h->samples.clear();
+  std::sort(h->samples.begin(), h->samples.end(), [](const Link &a, const Link &b) { return a.name < b.name; });
+  return ok;
 }
 
 static void walker_open(ppk_h5 *h) {
@@ -568,8 +614,15 @@ static void walker_open(ppk_h5 *h) {
     }
   }
   uint64_t sb_ = UNDEF, sh_ = UNDEF;
-  group_of_object(h->map, sk->ohdr, sb_, sh_, scratch);
-  group_links(h->map, sb_, sh_, h->samples, h->map.size / 40 + 16);
+  try {
+    group_of_object(h->map, sk->ohdr, sb_, sh_, scratch);
+    group_links(h->map, sb_, sh_, h->samples, h->map.size / 40 + 16);
+  } catch (const Unsupported &u) {
+    // a new-style /sketches: its listing through the library, the samples through this reader
+    h->samples.clear();
+    if (u.why.find("new-style") == std::string::npos || !hybrid_list_sketches(h)) throw;
+    h->listed_by_library = true;
+  }
   h->index.reserve(h->samples.size() * 2);
   for (size_t i = 0; i < h->samples.size(); i++) h->index.emplace(h->samples[i].name, i);
   walker_sample_params(h);

@@ -310,8 +310,9 @@ def test_odd_but_legal_databases(tmp_path):
 
     And ONE sample whose name is not plain ASCII: libhdf5 then converts /sketches from a symbol table to link
     messages and leaves the old table -- with the samples added before -- behind, still pointed at by the cache in
-    the root group's entry.  The direct reader must see that the group's own header has no symbol table any more and
-    hand the file to libhdf5, not list the samples of the stale table (it did, until this test)."""
+    the root group's entry.  The direct reader must see that the group's own header has no symbol table any more --
+    it listed the samples of the stale table until this test -- and take the group's listing from libhdf5 (it still
+    reads the samples itself)."""
     rng = np.random.Generator(np.random.PCG64(21))
     sk = rng.integers(0, 1 << 63, size=(6, 2, 5), dtype=np.uint64)
     np.savez(tmp_path / "src.npz", sk=sk)
@@ -368,16 +369,55 @@ with h5py.File(sys.argv[2] + "/onek.h5", "w") as f:
         with h5bulk.H5Bulk(str(tmp_path / "onek.h5"), backend) as f:
             assert f.params() == (1, 1, [21])
             assert int(f.read(["only"], [21], 1)[0][0, 0, 0]) == 12345
-    with pytest.raises(RuntimeError, match="direct reader does not read"):
-        h5bulk.H5Bulk(str(tmp_path / "odd.h5"), 1)
-    with h5bulk.H5Bulk(str(tmp_path / "odd.h5")) as f:
-        assert f.backend == 2 and "symbol table" in f.declined and f.count() == 6
-        check(f, odd_names)
+    # (the converted group's listing comes from libhdf5 -- one H5Literate --, the samples are read directly)
+    for backend in (0, 1, 2):
+        with h5bulk.H5Bulk(str(tmp_path / "odd.h5"), backend) as f:
+            assert f.backend == (backend or 1) and f.count() == 6
+            check(f, odd_names)
     for stem, names in (("ascii", ascii_names), ("odd", odd_names)):
         ld = sketchdb.load(str(tmp_path / stem), names[::-1], [15, 31])
         assert np.array_equal(ld.sketches, sk[::-1]) and ld.base_freq is None and ld.random_status == "absent"
-        assert sketchdb.last_load["backend"] == (1 if stem == "ascii" else 2)
+        assert sketchdb.last_load["backend"] == 1
         assert sketchdb.getSeqsInDb(str(tmp_path / (stem + ".h5"))) == sorted(names, key=lambda x: x.encode())
         warm = sketchdb.load(str(tmp_path / stem), names, [31])
         assert sketchdb.last_load["source"] == "sidecar" and np.array_equal(warm.sketches, sk[:, [1]])
         assert list(warm.lengths) == [5000, 0, 5002, 5003, 5004, 5005] and warm.names == names
+
+
+@pytest.mark.skipif(not have_h5py(), reason="needs the interpreter with h5py")
+def test_thousands_of_samples_and_one_accent(tmp_path):
+    """A realistic database -- 1 500 samples -- in which ONE name is not ASCII: /sketches ends up in dense new-style
+    storage (fractal heap + v2 B-tree).  The direct reader lists it through libhdf5 and reads the samples itself;
+    same words as the pure libhdf5 loop, in any order asked."""
+    rng = np.random.Generator(np.random.PCG64(77))
+    n = 1500
+    sk = rng.integers(0, 1 << 63, size=(n, 2, 6), dtype=np.uint64)
+    np.savez(tmp_path / "src.npz", sk=sk)
+    script = r'''
+import sys, numpy as np, h5py
+sk = np.load(sys.argv[1])["sk"]
+with h5py.File(sys.argv[2] + "/many.h5", "w") as f:
+    g = f.create_group("sketches")
+    for i in range(sk.shape[0]):
+        s = g.create_group("iso_%04d" % i if i != 700 else "iso_0700_\u00e9chantillon")
+        s.attrs["sketchsize64"] = 2; s.attrs["bbits"] = 3; s.attrs["kmers"] = [13, 29]; s.attrs["length"] = 1000 + i
+        s.attrs["base_freq"] = [0.25, 0.25, 0.25, 0.25]
+        s.create_dataset("13", data=sk[i, 0]); s.create_dataset("29", data=sk[i, 1])
+'''
+    r = subprocess.run([H5_PYTHON, "-c", script, str(tmp_path / "src.npz"), str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    names = ["iso_%04d" % i if i != 700 else "iso_0700_échantillon" for i in range(n)]
+    order = rng.permutation(n)
+    pick = [names[i] for i in order]
+    res = {}
+    for backend in (1, 2):
+        with h5bulk.H5Bulk(str(tmp_path / "many.h5"), backend) as f:
+            assert f.backend == backend and f.count() == n and f.names() == sorted(names, key=lambda x: x.encode())
+            res[backend] = f.read(pick, [29, 13], 6)
+            assert f.backend == backend
+    assert np.array_equal(res[1][0], sk[order][:, [1, 0]])
+    for a, b in zip(res[1], res[2]):
+        assert np.array_equal(a, b)
+    assert list(res[1][1]) == [1000 + int(i) for i in order]
+    ld = sketchdb.load(str(tmp_path / "many"), names, [13, 29])
+    assert np.array_equal(ld.sketches, sk) and sketchdb.last_load["backend"] == 1 and sketchdb.last_load["packed"]
