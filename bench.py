@@ -663,6 +663,11 @@ class Report:
             line = build_line(self)
             print(json.dumps(line))
             sys.stdout.flush()
+            if self.per_rank_dir:           # the other ranks may leave now (see main)
+                try:
+                    open(os.path.join(self.per_rank_dir, "emitted"), "w").write("1")
+                except OSError:
+                    pass
 
 
 def recorded_traffic(n, path=None, built_from=None):
@@ -847,6 +852,11 @@ def main():
             pass
         if rep.errors:
             sys.stdout.flush()
+            if rank != 0 and rep.per_rank_dir:
+                # a rank that exits non-zero makes the launcher stop the others: not before rank 0 has printed
+                t_end = time.time() + 60.0
+                while not os.path.exists(os.path.join(rep.per_rank_dir, "emitted")) and time.time() < t_end:
+                    time.sleep(0.05)
             os._exit(0 if rank == 0 else 1)      # do not hang in atexit handlers of a broken process group
 
 
