@@ -38,7 +38,9 @@ driving all N GPUs -- run on rank 0 BEFORE torch.distributed is initialised (the
 so a process group that never forms cannot lose them.
 """
 import argparse
+import contextlib
 import ctypes as C
+import gc
 import json
 import os
 import socket
@@ -178,20 +180,22 @@ def host_call(sk, kmers, tbl, devices, reps=9):
     entry = pp_sketchlib._Entry(sketchdb.LoadedSketches(["g%d" % i for i in range(n)], kmers, sk, 16, 14, tbl,
                                                         None, random_status="mapped"))
     times = []
-    for _ in range(reps):
-        t0 = time.perf_counter()
-        out, _ = pp_sketchlib.query_entries(entry, None, kmers, tbl, devices=devices)
-        times.append((time.perf_counter() - t0) * 1e3)
-        del out
+    with timed_region("host_call"):
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            out, _ = pp_sketchlib.query_entries(entry, None, kmers, tbl, devices=devices)
+            times.append((time.perf_counter() - t0) * 1e3)
+            del out
     st = (C.c_double * 7)()
     lib.ppk_query_last_stats(st, 7)
     entry.close()
     arr = []
-    for _ in range(3):
-        t0 = time.perf_counter()
-        out, _ = pp_sketchlib.query_arrays(sk, None, kmers, 16, 14, tbl, devices=tuple(devices))
-        arr.append((time.perf_counter() - t0) * 1e3)
-        del out
+    with timed_region("host_call.arrays"):
+        for _ in range(3):
+            t0 = time.perf_counter()
+            out, _ = pp_sketchlib.query_arrays(sk, None, kmers, 16, 14, tbl, devices=tuple(devices))
+            arr.append((time.perf_counter() - t0) * 1e3)
+            del out
     lib.ppk_release_scratch()
     pairs = n * (n - 1) // 2
     warm = sorted(times[1:])
@@ -207,6 +211,58 @@ def host_call(sk, kmers, tbl, devices, reps=9):
                     "arrays_ms: ppk_query on the raw array (its hash of every sketch word runs beside the job and is "
                     "checked before the call returns)"
                     % (reps - 1, sk.nbytes >> 20)}
+
+
+# ---- the interpreter's garbage collector and the timed regions ------------------------------------------------
+# A full (generation 2) collection in a process that has imported torch walks ~10^6 objects: 30 - 45 ms, against an
+# 8 ms host call or a 2.7 ms step.  When it fires depends on the allocation count, i.e. on the script, not on the
+# code under test: round 4's lines showed exactly one `host_call` in eight at 45 - 55 ms, always at the same
+# index, while the library's own trace of that call read 7.9 ms (profiles/r04/bench_gc.txt).  Timed regions
+# therefore run with the collector paused, as `timeit` does; every collection that does happen is logged with its
+# duration and the phase it fell in, and the line carries the log.
+GC_EVENTS = []
+_gc_state = {"t0": 0.0, "phase": "setup"}
+
+
+def _gc_callback(phase, info):
+    if phase == "start":
+        _gc_state["t0"] = time.perf_counter()
+    else:
+        GC_EVENTS.append({"phase": _gc_state["phase"], "generation": info.get("generation"),
+                          "ms": round((time.perf_counter() - _gc_state["t0"]) * 1e3, 2)})
+
+
+gc.callbacks.append(_gc_callback)
+
+
+@contextlib.contextmanager
+def timed_region(name):
+    """Collector paused (after one full collection outside the region); PPK_BENCH_GC=on leaves it running."""
+    keep = os.environ.get("PPK_BENCH_GC") == "on"
+    was = gc.isenabled()
+    prev = _gc_state["phase"]
+    if not keep:
+        _gc_state["phase"] = name + " (before)"
+        gc.collect()
+        gc.disable()
+    _gc_state["phase"] = name
+    try:
+        yield
+    finally:
+        _gc_state["phase"] = prev
+        if was:
+            gc.enable()
+
+
+def gc_summary():
+    inside = [e for e in GC_EVENTS if e["phase"] != "setup" and not e["phase"].endswith("(before)")]
+    full = sorted(e["ms"] for e in GC_EVENTS if e["generation"] == 2 and e["phase"].endswith("(before)"))
+    return {"policy": "running (PPK_BENCH_GC=on)" if os.environ.get("PPK_BENCH_GC") == "on" else
+            "paused inside timed regions (what timeit does), one full collection before each",
+            "collections": len(GC_EVENTS), "inside_timed_regions": inside[:16],
+            "full_collection_ms_median": full[len(full) // 2] if full else None,
+            "note": "a full collection of this process (torch imported) takes tens of ms: left running it lands in one "
+                    "host_call in eight (profiles/r04/bench_gc.txt)"}
 
 
 def _stats(ms):
@@ -242,9 +298,10 @@ def file_call(sk, kmers, tbl, device, reps=3):
             pp_sketchlib.clear_cache()
             if state == "cold_h5" and os.path.exists(db + ".ppk"):
                 os.unlink(db + ".ppk")
-            t0 = time.perf_counter()
-            out = pp_sketchlib.queryDatabase(db, db, names, names, klist, True, False, 1, True, device)
-            total = (time.perf_counter() - t0) * 1e3
+            with timed_region("file_call." + state):
+                t0 = time.perf_counter()
+                out = pp_sketchlib.queryDatabase(db, db, names, names, klist, True, False, 1, True, device)
+                total = (time.perf_counter() - t0) * 1e3
             assert out.shape == (pairs, 2)
             del out
             lc = dict(pp_sketchlib.last_call)
@@ -264,11 +321,12 @@ def file_call(sk, kmers, tbl, device, reps=3):
             res[state]["pairs_per_s"] = pairs / (res[state]["median_ms"] * 1e-3)
         res["sidecar_bytes"] = os.path.getsize(db + ".ppk") if os.path.exists(db + ".ppk") else 0
         loaded = []
-        for _ in range(reps + 2):
-            t0 = time.perf_counter()
-            out = pp_sketchlib.queryDatabase(db, db, names, names, klist, True, False, 1, True, device)
-            loaded.append((time.perf_counter() - t0) * 1e3)
-            del out
+        with timed_region("file_call.loaded"):
+            for _ in range(reps + 2):
+                t0 = time.perf_counter()
+                out = pp_sketchlib.queryDatabase(db, db, names, names, klist, True, False, 1, True, device)
+                loaded.append((time.perf_counter() - t0) * 1e3)
+                del out
         res["loaded"] = _stats(loaded[1:])
         os.environ["PPK_SIDECAR"] = "0"
         try:
@@ -380,6 +438,11 @@ def kernel2_leg(lib, torch, dist_t, x_max, y_max, steps):
 
 
 def other_configs(args, lib, engine, torch, synth, ref10k, dist10k, kmers, tbl, local_rank, f, rep):
+    with timed_region("other_configs"):
+        _other_configs(args, lib, engine, torch, synth, ref10k, dist10k, kmers, tbl, local_rank, f, rep)
+
+
+def _other_configs(args, lib, engine, torch, synth, ref10k, dist10k, kmers, tbl, local_rank, f, rep):
     """BASELINE configs 2 and 4, PopPUNK's default sketch size and kernel 2 on the driver's line (N = 1)."""
     dev = "cuda:%d" % local_rank
     legs = (("config2", lambda: _config2(lib, engine, torch, synth, kmers, tbl, dev, local_rank)),
@@ -516,10 +579,11 @@ def config5_host_call(ref, kmers, tbl, x_max, y_max, world, local_rank, n_edges_
         edges, _ = engine.edges_host(dbs, None, kmers, tbl, slope=2, x_max=x_max, y_max=y_max, cap=16 << 20)
         assert n_edges_expected is None or len(edges) == n_edges_expected, (len(edges), n_edges_expected)
         ts = []
-        for _ in range(reps):
-            t0 = time.perf_counter()
-            edges, _ = engine.edges_host(dbs, None, kmers, tbl, slope=2, x_max=x_max, y_max=y_max, cap=16 << 20)
-            ts.append(time.perf_counter() - t0)
+        with timed_region("config5.host_call"):
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                edges, _ = engine.edges_host(dbs, None, kmers, tbl, slope=2, x_max=x_max, y_max=y_max, cap=16 << 20)
+                ts.append(time.perf_counter() - t0)
     finally:
         for d in made:
             d.close()
@@ -755,6 +819,7 @@ def build_line(rep):
         "roofline": roof, "cpu_baseline": f.get("cpu"), "host_call": f.get("host_call"),
         "file_call": f.get("file_call"), "config2": f.get("config2"), "config4": f.get("config4"),
         "default_sketch": f.get("default_sketch"), "kernel2": f.get("kernel2"), "config5": f.get("config5"),
+        "gc": gc_summary(),
     }
     if world > 1 and line["config5"] is None and f.get("config5_host_call_solo") is not None:
         # the sharded leg never ran (no process group): what rank 0 measured alone is still config 5's host call
@@ -1100,13 +1165,14 @@ def run(args, rep, rank, local_rank, world, fake, torch, dist, engine, synth, da
         step()
     barrier()
     rep.enter("timed_steps")
-    prof_on()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kms, kn = prof_off()
+    with timed_region("timed_steps"):
+        prof_on()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        kms, kn = prof_off()
     f["kernel_ms"] = kms / max(kn, 1)
     f["kernel_name"] = lib.ppk_last_kernel_name().decode() if lib is not None else "none (fake)"
     f["per_launch"] = job.band_rows[0] / job.n_chunks          # pairs one launch of the dominant kernel covers
