@@ -43,6 +43,7 @@ import ctypes as C
 import gc
 import json
 import os
+import signal
 import socket
 import sys
 import threading
@@ -688,6 +689,36 @@ class Report:
             sys.stdout.flush()
             os._exit(3)
 
+    def watch_sigterm(self):
+        """The launcher answers ANY rank's non-zero exit with SIGTERM to the others (torch.distributed.run), and the
+        main thread may sit in a collective that never returns to the interpreter: the signal's byte arrives on a
+        wake-up pipe (written by the C-level handler, whatever the main thread does) and a thread of its own
+        prints the line with what has been measured."""
+        try:
+            r, w = os.pipe()
+            os.set_blocking(w, False)
+            signal.signal(signal.SIGTERM, lambda *a: None)      # (a Python-level handler must exist for the wake-up fd)
+            signal.set_wakeup_fd(w, warn_on_full_buffer=False)
+        except (ValueError, OSError):      # not the main thread / no pipes
+            return
+
+        def wait():
+            while True:
+                try:
+                    b = os.read(r, 1)
+                except OSError:
+                    return
+                if b and b[0] == signal.SIGTERM:
+                    self.errors.append("SIGTERM in phase '%s' (the launcher stops the job when another rank exits "
+                                       "non-zero)" % self.phase)
+                    try:
+                        self.emit()
+                    finally:
+                        sys.stdout.flush()
+                        os._exit(3)
+        t = threading.Thread(target=wait, daemon=True)
+        t.start()
+
     def error(self, where, exc):
         self.errors.append("%s: %s: %s" % (where, type(exc).__name__, str(exc).splitlines()[0][:300] if str(exc) else ""))
 
@@ -903,6 +934,8 @@ def main():
     if world > 1:
         rep.per_rank_dir = os.path.join("/tmp", "ppk_bench_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid()))
         os.makedirs(rep.per_rank_dir, exist_ok=True)
+        if rank == 0:
+            rep.watch_sigterm()
     try:
         run(args, rep, rank, local_rank, world, fake, torch, dist, engine, synth, datetime)
     except BaseException as e:                   # whatever it was: the line still goes out
@@ -921,7 +954,8 @@ def main():
             sys.stdout.flush()
             if rank != 0 and rep.per_rank_dir:
                 # a rank that exits non-zero makes the launcher stop the others: not before rank 0 has printed
-                t_end = time.time() + 60.0
+                # (it may be waiting for this rank in a collective until that times out or its watchdog fires)
+                t_end = time.time() + max(args.watchdog_s, args.collective_timeout) + 30.0
                 while not os.path.exists(os.path.join(rep.per_rank_dir, "emitted")) and time.time() < t_end:
                     time.sleep(0.05)
             os._exit(0 if rank == 0 else 1)      # do not hang in atexit handlers of a broken process group
@@ -976,6 +1010,9 @@ def run(args, rep, rank, local_rank, world, fake, torch, dist, engine, synth, da
                 raise RuntimeError("injected failure of batch_isend_irecv (PPK_BENCH_INJECT)")
             return real(ops)
         dist.batch_isend_irecv = failing
+    elif inject.startswith("die") and rank == world - 1:       # self-test: the last rank is gone, exit status 1
+        sys.stdout.flush()
+        os._exit(1)
     elif inject.startswith("hang") and rank == world - 1:      # self-test: the last rank stops answering
         after = int(inject.split(":")[1]) if ":" in inject else 0
         real, calls = dist.batch_isend_irecv, [0]

@@ -115,3 +115,15 @@ def test_recorded_traffic_is_refused_when_the_library_was_built_from_other_sourc
     unstamped.write_text(json.dumps({"n10000": 123.0, "source": "x"}))
     assert bench.recorded_traffic(10000, str(unstamped))[0] is None and bench.recorded_traffic(10000, str(unstamped))[2]
     assert bench.recorded_traffic(10000, str(tmp_path / "absent.json")) == (None, None, False)
+
+
+def test_a_rank_that_dies_still_leaves_rank_0s_line():
+    """torch.distributed.run answers a rank's non-zero exit with SIGTERM to the others; rank 0 may be inside a
+    collective at that moment.  The signal reaches a thread of its own through a wake-up pipe and the line goes
+    out with the error and rank 0's own compute-only figure."""
+    d = _run("die")
+    assert d["n_gpus"] == 2 and "FAKE" in d["data"]
+    mg = d["multi_gpu"]
+    assert mg["error"]          # "SIGTERM in phase ..." and / or the broken collective rank 0 was in
+    assert mg["per_rank_compute_only_ms_per_step"][0] is None or mg["per_rank_compute_only_ms_per_step"][0] > 0
+    assert mg["host_call"] == {"fake": True, "devices": [0, 1]}          # measured before the process group
