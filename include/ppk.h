@@ -83,9 +83,10 @@ int ppk_device_count(int *n);
  *     256 distances to the k-th of a few thousand -- and runs the rest under those bounds: 2 x faster at 100 000
  *     genomes for 10 neighbours; 0 = the opening piece is sized by what the list can take only), "knn_cut" (default 4: such a job cuts its list again whenever
  *     it holds 4 n knn entries -- same time as cutting at half of the room, a tenth of the memory),
- *     "host_parts" (worker threads of a ONE-device host query of >= 16 Mi rows,
+ *     "host_parts" (worker threads of a ONE-device host query of >= "host_parts_rows" = 16 Mi rows,
  *     default 2: the device is entered twice, each entry with its own streams and buffers, so that one
- *     download is in flight while the next is being set up)
+ *     download is in flight while the next is being set up) ("chunk_rows": rows per sub-band of a host query;
+ *     0 = 8 Mi, and about an eighth of the job, at least 1 Mi, below 16 Mi rows)
  *   measurement only: "edge_list_keep" 0: the fused host edge call (ppk_query_edges*) allocates its device edge list
  *     per call with the round-3 guess of rows / 8 entries and frees it again, instead of keeping a grow-only buffer
  *     per device entry (default 1; tools/stall_hunt.py)

@@ -63,6 +63,7 @@ const OptionEntry kOptions[] = {
     {"knn_warm", "PPK_KNN_WARM", &PpkConfig::knn_warm},
     {"knn_cut", "PPK_KNN_CUT", &PpkConfig::knn_cut},
     {"host_parts", "PPK_HOST_PARTS", &PpkConfig::host_parts},
+    {"host_parts_rows", "PPK_HOST_PARTS_ROWS", &PpkConfig::host_parts_rows},
     {"host_trace", "PPK_HOST_TRACE", &PpkConfig::host_trace},
     {"edge_list_keep", "PPK_EDGE_LIST_KEEP", &PpkConfig::edge_list_keep},
     {"ext_collision_adjust", "PPK_EXT_COLLISION_ADJUST", &PpkConfig::ext_collision_adjust},

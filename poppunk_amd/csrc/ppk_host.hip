@@ -704,6 +704,10 @@ int run_query(QueryJob &job, std::vector<QueryPart> &parts, unsigned long long *
   // ~64 MB of float2 rows per buffer: the first download starts after 1/6 of a 10k job instead of 1/2
   // (PCIe is the bound of the host call: 11.2 -> 10.2 ms there; tools/ab_host.py)
   size_t target_rows = (size_t)8 << 20;
+  // below 16 Mi rows (no short opening, one entry): about eight sub-bands of at least 1 Mi rows -- the first download
+  // starts once 8 - 16 MB of the result array have been touched instead of half of it, and every later one runs
+  // beside the next sub-band's page faults (1 000 queries x 10 000 refs: 2.46 -> 2.22 ms; tools/ab_midsize.py)
+  if (total_rows < ((size_t)16 << 20)) target_rows = std::max<size_t>((size_t)1 << 20, total_rows / 8);
   if (const long long cr = ppk_config().chunk_rows.load(); cr > 0) target_rows = (size_t)cr;
   // devices in the order of their first entry, and how many entries each has
   job.work.clear();
@@ -849,7 +853,7 @@ int run_query(QueryJob &job, std::vector<QueryPart> &parts, unsigned long long *
 int single_device_entries(size_t n_ref, size_t n_qry) {
   const long long hp = ppk_config().host_parts.load();
   const size_t rows = ppk_rows_in_band(n_ref, n_qry, 0, n_qry ? n_qry : n_ref);
-  if (hp < 2 || rows < ((size_t)16 << 20)) return 1;
+  if (hp < 2 || rows < (size_t)ppk_config().host_parts_rows.load()) return 1;
   return hp > kMaxDup ? kMaxDup : (int)hp;
 }
 

@@ -52,6 +52,7 @@ struct PpkConfig {
   std::atomic<long long> knn_warm{32};          // PPK_KNN_WARM: the neighbour mode opens with 1/knn_warm of its rows, then cuts the list (0 = off)
   std::atomic<long long> knn_cut{4};            // PPK_KNN_CUT: a staged neighbour job cuts its list at knn_cut * n * knn entries (0: only when half full)
   std::atomic<long long> knn_list{0};           // PPK_KNN_LIST: entries of the neighbour-candidate list (0 = sized from n and knn)
+  std::atomic<long long> host_parts_rows{16 << 20};   // PPK_HOST_PARTS_ROWS: ... from this many rows up
   std::atomic<long long> host_parts{2};         // PPK_HOST_PARTS: worker threads of a one-device host query (>= 16 Mi rows)
   std::atomic<long long> edge_list_keep{1};     // PPK_EDGE_LIST_KEEP: the fused host edge call keeps its device list buffer between calls (0: allocate + free per call, measurement)
   // [EXT] a4: 0 = the b-bit collision adjustment is never in effect (upstream as recalled: it is
