@@ -51,8 +51,8 @@ def host_call(ref_sk, qry_sk, reps=20):
     ts = []
     out = None
     for _ in range(reps + 2):
-        prev = out          # (the previous result is freed OUTSIDE the timed region: unmapping an array the runtime had
-        t0 = time.perf_counter()   # registered for the copy costs ~50 us per MB -- the caller's, when it drops a result)
+        prev = out          # (the previous result is freed OUTSIDE the timed region: unmapping a touched array costs
+        t0 = time.perf_counter()   # ~50 us per MB -- the caller's, when it drops a result)
         out, _ = pp_sketchlib.query_entries(r, q, K, T, devices=[0])
         ts.append((time.perf_counter() - t0) * 1e3)
         del prev
