@@ -489,7 +489,7 @@ def _default_sketch(lib, engine, torch, synth, kmers, dev, local_rank):
     try:
         return dist_leg(lib, engine, torch, db, None, kmers, t1, 3, len(kmers) * s64 * 30,
                         "PopPUNK's default sketch size (--sketch-size 10000 -> sketchsize64 = 156, 9 984 bins, "
-                        "docs/sketching.rst:78-80): %d genomes self-vs-self, k=13,17,21,25,29" % n, spin_ms=0.0)
+                        "docs/sketching.rst:78-80): %d genomes self-vs-self, k=13,17,21,25,29" % n, spin_ms=50.0)
     finally:
         db.close()
 
@@ -1199,12 +1199,20 @@ def run(args, rep, rank, local_rank, world, fake, torch, dist, engine, synth, da
             job._layout(job.bounds)
     f["chunks"] = job.n_chunks
     f["band_note"] = band_note
-    rep.enter("warmup")
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    rep.enter("timed_steps")
+    # the collector is paused from BEFORE the warm-up steps: its full collection (tens of ms of host time, the GPU
+    # idle meanwhile -- long enough for the clock to fall back, and different on every rank) must not sit between
+    # the warm-up and the first timed step
     with timed_region("timed_steps"):
+        if world == 1:                       # (N > 1: the probes above have just kept every GPU busy)
+            t_spin = time.perf_counter()
+            while time.perf_counter() - t_spin < 0.5 * args.spinup_ms * 1e-3:
+                step()
+                sync()
+        rep.enter("warmup")
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        rep.enter("timed_steps")
         prof_on()
         t0 = time.perf_counter()
         for _ in range(args.steps):
