@@ -77,6 +77,8 @@ def parse():
     ap.add_argument("--no-host-call", action="store_true", help="skip the host_call leg")
     ap.add_argument("--no-file-call", action="store_true", help="skip the file_call leg (database file -> distances)")
     ap.add_argument("--no-config5", action="store_true", help="skip the config-5 (fused edge list) leg")
+    ap.add_argument("--no-peer-store", action="store_true",
+                    help="N > 1: skip the leg in which every rank stores its band straight into rank 0's matrix")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the config2 / config4 / default_sketch / kernel2 legs (N = 1)")
     ap.add_argument("--config5-genomes", type=int, default=100000)
@@ -343,6 +345,42 @@ def file_call(sk, kmers, tbl, device, reps=3):
     finally:
         pp_sketchlib.clear_cache()
         shutil.rmtree(root, ignore_errors=True)
+
+
+def peer_store_leg(args, engine, torch, dist, ref, kmers, tbl, rank, world, gathered, barrier, reduce_max):
+    """The headline job on N GPUs with NO transfer step (engine.PeerStoreQuery): rank 0's [n_pairs, 2] matrix is one
+    device allocation that every rank maps (IPC) and stores its band into from inside kernel 1, over its own xGMI
+    link; a step = every rank's kernel + one barrier.  Runs AFTER the gathered steps have been timed and recorded
+    (whatever happens here, they are on the line), is checked bit for bit against the gathered matrix, and is
+    timed like them: W warm-up steps, then exactly K steps between barriers, the maximum over ranks."""
+    psq = engine.PeerStoreQuery(ref, None, rank, world)
+    try:
+        psq.open()
+    except RuntimeError as e:
+        return {"available": False, "why": str(e)[:300]}
+    try:
+        psq.run(kmers, tbl)
+        shares = psq.rebalance(kmers, tbl)
+        m = psq.run(kmers, tbl)
+        same = psq.flag_tensor(1 if (rank != 0 or bool(torch.equal(m, gathered))) else 0)
+        dist.all_reduce(same, op=dist.ReduceOp.MIN)
+        with timed_region("peer_store"):
+            for _ in range(args.warmup):
+                psq.run(kmers, tbl)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                psq.run(kmers, tbl)
+            barrier()
+            elapsed = reduce_max([time.perf_counter() - t0])[0]
+        pairs = psq.total_rows
+        return {"available": True, "identical_to_gathered": bool(int(same.item())),
+                "ms_per_step": elapsed / args.steps * 1e3, "pairs_per_s": pairs * args.steps / elapsed,
+                "band_shares": [round(x, 4) for x in shares],
+                "what": "every rank's kernel stores its band into ONE matrix on rank 0's GPU, mapped by the other "
+                        "ranks through IPC (ppk_window_*): no send, no receive, one barrier per step"}
+    finally:
+        psq.close()
 
 
 def _valu_roof(pairs, ops_per_pair, kernel_ms):
@@ -809,6 +847,14 @@ def build_line(rep):
         value = sum(per_rank_pairs) / (ms_per_step * 1e-3)
         value_note = ("the gathered steps did not complete (multi_gpu.error): value is the aggregate of the "
                       "ranks' compute-only steps (HIP events, no collective) and EXCLUDES the gather to rank 0")
+    gathered = None
+    ps = f.get("peer_store")
+    if (world > 1 and isinstance(ps, dict) and ps.get("available") and ps.get("identical_to_gathered")
+            and ms_per_step and ps.get("ms_per_step") and ps["ms_per_step"] < ms_per_step and "elapsed" in f):
+        # both transports were timed over the same K steps between barriers; the line's value is the faster one,
+        # the other stays beside it (multi_gpu.gathered)
+        gathered = {"ms_per_step": ms_per_step, "value": value}
+        ms_per_step, value = ps["ms_per_step"], ps["pairs_per_s"]
     roof = None
     kernel_ms = f.get("kernel_ms")
     if kernel_ms and f.get("per_launch"):
@@ -847,8 +893,10 @@ def build_line(rep):
                                "bbits=14), k=13,17,21,25,29, %d pairs, output [n_pairs,2] f32 "
                                "on rank 0" % (n, total_pairs),
                    "n_genomes": n, "pairs": total_pairs,
-                   "parallelism": "band-split x%d (%s bands), %d-chunk pipelined p2p gather to rank 0"
-                                  % (world, band_note.split(" ")[0], f.get("chunks", args.chunks or 4)) if world > 1 else "1 GPU"},
+                   "parallelism": ("band-split x%d, every rank's kernel stores its band into rank 0's matrix (IPC window "
+                                   "over xGMI), one barrier per step" % world) if gathered else
+                                  ("band-split x%d (%s bands), %d-chunk pipelined p2p gather to rank 0"
+                                   % (world, band_note.split(" ")[0], f.get("chunks", args.chunks or 4)) if world > 1 else "1 GPU")},
         "roofline": roof, "cpu_baseline": f.get("cpu"), "host_call": f.get("host_call"),
         "file_call": f.get("file_call"), "config2": f.get("config2"), "config4": f.get("config4"),
         "default_sketch": f.get("default_sketch"), "kernel2": f.get("kernel2"), "config5": f.get("config5"),
@@ -883,6 +931,14 @@ def build_line(rep):
                     "only edge lists move" % f.get("chunks", args.chunks or 4)}
         if f.get("chunks_probe_ms"):
             mg["chunks_probe_ms_per_step"] = f["chunks_probe_ms"]
+        mg["peer_store"] = ps
+        if gathered:
+            mg["gathered"] = gathered
+            mg["transport"] = ("value = the peer-store steps (multi_gpu.peer_store: identical matrix, timed like the "
+                               "gathered steps, faster); multi_gpu.gathered = the p2p gather's figure")
+            mg["gather_exposed_ms_per_step"] = round(max(gathered["ms_per_step"] - compute_ms, 0.0), 4) if compute_ms else None
+        else:
+            mg["transport"] = "value = the gathered steps (grouped isend / irecv into rank 0's matrix)"
         if rep.errors:
             mg["error"] = "; ".join(rep.errors)
         line["multi_gpu"] = mg
@@ -1251,15 +1307,27 @@ def run(args, rep, rank, local_rank, world, fake, torch, dist, engine, synth, da
     if world == 1 and not args.no_other_configs:
         other_configs(args, lib, engine, torch, synth, ref, job.out, kmers, tbl, local_rank, f, rep)
 
+    peer_store = world > 1 and pg_ok and not args.no_peer_store
     if not args.no_config5:
         rep.enter("config5")
         try:
-            ref.close()
-            job.out = None
-            torch.cuda.empty_cache()
+            if not peer_store:           # (the last leg still needs the 10 000-genome database and the gathered matrix)
+                ref.close()
+                job.out = None
+                torch.cuda.empty_cache()
             f["config5"] = config5(args, rank, world, local_rank, dev, barrier, f, park)
         except Exception as e:
             rep.error("config5", e)
+    # ---- N > 1: the headline job with no transfer step.  LAST: everything else is measured and in `f` by now, so a
+    # node on which peer stores misbehave (no peer access is a clean "not available"; a fault would end the rank and,
+    # through the launcher's SIGTERM, this process -- whose line then goes out from the signal thread) loses nothing.
+    if peer_store:
+        rep.enter("peer_store")
+        try:
+            f["peer_store"] = peer_store_leg(args, engine, torch, dist, ref, kmers, tbl, rank, world,
+                                             job.out if rank == 0 else None, barrier, reduce_max)
+        except Exception as e:       # (a failure of the leg is the leg's: the gathered value stands)
+            f["peer_store"] = {"available": False, "why": "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:300] if str(e) else "")}
     if rank == 0 and not args.no_cpu and world == 1:
         rep.enter("cpu_baseline")
         rep._timer and rep._timer.cancel()       # bounded by --cpu-seconds itself

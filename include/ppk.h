@@ -190,6 +190,28 @@ int ppk_dist_edges_dev(const ppk_db *ref, const ppk_db *qry, const int32_t *kmer
                        unsigned long long *d_n_failed, void *stream);
 
 /* ------------------------------------------------------------------------
+ * N processes, N GPUs of one node, ONE result matrix ("peers write directly at final
+ * offsets via ... IPC").  The root rank allocates the [n_pairs][2] matrix with ppk_window_alloc and exports it;
+ * every other rank opens the 64-byte handle (sent through any channel: a broadcast, a file) and passes
+ * `d_window + (first row of its band) * row bytes` as ppk_dist_dev's d_out: its kernel then stores its rows
+ * straight into the root's HBM over its own xGMI link -- no send buffer, no gather, no collective on the data
+ * path.  A step is complete on the root once every rank's stream has drained (a barrier).  There is no
+ * counterpart in the reference (one process, one device: pp_sketchlib's device_id, PopPUNK/sketchlib.py:536).
+ *   ppk_window_alloc : a device allocation of its own (hipMalloc), not from any caching allocator, so that the
+ *                      handle covers exactly it; freed by ppk_window_free (not by ppk_release_scratch)
+ *   ppk_window_export: handle of an allocation made by ppk_window_alloc in THIS process
+ *   ppk_window_open  : maps another process's allocation for `device` (peer access is enabled by the mapping);
+ *                      PPK_ERR_HIP when the two devices cannot reach each other -- the caller then gathers
+ *   ppk_window_close : unmaps (the owner's allocation stays)
+ */
+#define PPK_WINDOW_HANDLE_BYTES 64
+int ppk_window_alloc(int device, size_t bytes, void **d_window);
+int ppk_window_free(int device, void *d_window);
+int ppk_window_export(int device, const void *d_window, unsigned char handle[PPK_WINDOW_HANDLE_BYTES]);
+int ppk_window_open(int device, const unsigned char handle[PPK_WINDOW_HANDLE_BYTES], void **d_window);
+int ppk_window_close(int device, void *d_window);
+
+/* ------------------------------------------------------------------------
  * Kernel 2 on a resident [n_rows][2] float32 distance buffer.
  */
 /* replaces poppunk_refine.assignThreshold (src/python_bindings.cpp:18-25,:79-83;

@@ -76,6 +76,11 @@ SIGNATURES = {
     "ppk_square_to_long": (C.c_int, [_f32p, _sz, C.c_int, _f32p]),
     "ppk_knn": (C.c_int, [_f32p, _sz, C.c_int, C.c_int, _llp, _llp, _f32p]),
     "ppk_qc_edges_dev": (C.c_int, [_vp, _sz, _sz, C.c_int, C.c_float, C.c_float, _vp, _sz, _vp, _vp]),
+    "ppk_window_alloc": (C.c_int, [C.c_int, _sz, C.POINTER(C.c_void_p)]),
+    "ppk_window_free": (C.c_int, [C.c_int, _vp]),
+    "ppk_window_export": (C.c_int, [C.c_int, _vp, C.c_char_p]),
+    "ppk_window_open": (C.c_int, [C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]),
+    "ppk_window_close": (C.c_int, [C.c_int, _vp]),
     "ppk_prof_enable": (C.c_int, [C.c_int]),
     "ppk_prof_read": (C.c_int, [C.POINTER(C.c_double), _llp, C.c_int]),
     "ppk_last_kernel_name": (C.c_char_p, []),

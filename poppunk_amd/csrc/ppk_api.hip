@@ -522,6 +522,72 @@ extern "C" int ppk_release_scratch(void) {
   return PPK_OK;
 }
 
+// ---- one result matrix, N processes (ppk.h) -----------------------------------------------------------
+static_assert(sizeof(hipIpcMemHandle_t) == PPK_WINDOW_HANDLE_BYTES, "hipIpcMemHandle_t is not 64 bytes");
+
+extern "C" int ppk_window_alloc(int device, size_t bytes, void **d_window) {
+  if (!d_window || bytes == 0) return ppk_fail(PPK_ERR_ARG, "window: no size / no output pointer");
+  DeviceGuard g(device);
+  if (!g.ok) return ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(device));
+  void *p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) return ppk_fail(PPK_ERR_HIP, std::string("hipMalloc(window): ") + hipGetErrorString(e));
+  *d_window = p;
+  return PPK_OK;
+}
+
+extern "C" int ppk_window_free(int device, void *d_window) {
+  if (!d_window) return PPK_OK;
+  DeviceGuard g(device);
+  if (!g.ok) return ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(device));
+  (void)hipDeviceSynchronize();
+  PPK_HIP(hipFree(d_window));
+  return PPK_OK;
+}
+
+extern "C" int ppk_window_export(int device, const void *d_window, unsigned char handle[PPK_WINDOW_HANDLE_BYTES]) {
+  if (!d_window || !handle) return ppk_fail(PPK_ERR_ARG, "window: null argument");
+  DeviceGuard g(device);
+  if (!g.ok) return ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(device));
+  hipIpcMemHandle_t h;
+  hipError_t e = hipIpcGetMemHandle(&h, const_cast<void *>(d_window));
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return ppk_fail(PPK_ERR_HIP, std::string("hipIpcGetMemHandle: ") + hipGetErrorString(e));
+  }
+  memcpy(handle, &h, sizeof(h));
+  return PPK_OK;
+}
+
+extern "C" int ppk_window_open(int device, const unsigned char handle[PPK_WINDOW_HANDLE_BYTES], void **d_window) {
+  if (!d_window || !handle) return ppk_fail(PPK_ERR_ARG, "window: null argument");
+  DeviceGuard g(device);
+  if (!g.ok) return ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(device));
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle, sizeof(h));
+  void *p = nullptr;
+  hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+  if (e != hipSuccess || !p) {
+    (void)hipGetLastError();
+    return ppk_fail(PPK_ERR_HIP, std::string("hipIpcOpenMemHandle: ") + hipGetErrorString(e));
+  }
+  *d_window = p;
+  return PPK_OK;
+}
+
+extern "C" int ppk_window_close(int device, void *d_window) {
+  if (!d_window) return PPK_OK;
+  DeviceGuard g(device);
+  if (!g.ok) return ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(device));
+  (void)hipDeviceSynchronize();
+  hipError_t e = hipIpcCloseMemHandle(d_window);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return ppk_fail(PPK_ERR_HIP, std::string("hipIpcCloseMemHandle: ") + hipGetErrorString(e));
+  }
+  return PPK_OK;
+}
+
 extern "C" int ppk_dist_dev(const ppk_db *ref, const ppk_db *qry, const int32_t *kmers,
                             const float *random_tbl, size_t n_clu, int flags, size_t q_begin,
                             size_t q_end, void *d_out, unsigned long long *d_n_failed,

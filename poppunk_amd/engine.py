@@ -909,6 +909,187 @@ def query_sharded(ref, qry, kmers, random_tbl, rank, world_size, random_correct=
     return full, rows
 
 
+class _DeviceRows:
+    """What `dist` asks of its `out` argument, over raw device memory (rows of a window another process owns)."""
+
+    def __init__(self, ptr, rows, cols):
+        self._ptr, self.shape = int(ptr), (int(rows), int(cols))
+
+    def numel(self):
+        return self.shape[0] * self.shape[1]
+
+    def is_contiguous(self):
+        return True
+
+    def element_size(self):
+        return 4
+
+    def data_ptr(self):
+        return self._ptr
+
+
+class _WindowArray:
+    """`__cuda_array_interface__` over a window: torch.as_tensor makes a tensor on it without a copy."""
+
+    def __init__(self, ptr, rows, cols):
+        self.__cuda_array_interface__ = {"shape": (int(rows), int(cols)), "typestr": "<f4", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+class PeerStoreQuery:
+    """The N-GPU distance job with NO transfer step ("peers write directly at final offsets via
+    ... IPC"): the [n_pairs, 2] matrix is ONE device allocation on the root's GPU (`ppk_window_alloc`), every other
+    rank of the node maps it (`ppk_window_export` / `ppk_window_open`: the 64-byte handle travels in one
+    broadcast) and launches kernel 1 on its band with `out` = its rows of that window -- the float2 stores of its
+    epilogue go over its own xGMI link into the root's HBM while the compare loop runs.  No send buffer, no
+    receive, nothing on the data path but the kernel; a step ends with every rank's stream drained and one
+    barrier, after which the root holds the whole PopPUNK-ordered matrix.
+
+    Bands are equal in pair count to begin with (a peer's 8 B per pair are far below what its link carries) and
+    `rebalance` re-cuts them from measured per-rank times, like ShardedQuery's.  Collective calls: `open`, `run`,
+    `rebalance`, `close`.  `open` raises RuntimeError ON EVERY RANK when any rank could not map the window
+    (devices without peer access, processes that see different devices): the caller then uses ShardedQuery."""
+
+    def __init__(self, ref, qry, rank, world_size, cols=2, group=None):
+        self.ref, self.qry = ref, qry
+        self.rank, self.world = int(rank), int(world_size)
+        self.group = group
+        self.cols = cols
+        self.n_qry = qry.n if qry is not None else 0
+        self.device = "cuda:%d" % ref.device
+        self.window = None            # device pointer: the root's allocation, or this rank's mapping of it
+        self.n_failed = None
+        self._matrix = None
+        self._set_bounds(shard_bounds(ref.n, self.n_qry, self.world))
+
+    def _set_bounds(self, bounds):
+        self.bounds = [int(b) for b in bounds]
+        self.band_rows = [rows_in_band(self.ref.n, self.n_qry, self.bounds[r], self.bounds[r + 1])
+                          for r in range(self.world)]
+        self.band_off = [0]
+        for r in range(self.world):
+            self.band_off.append(self.band_off[-1] + self.band_rows[r])
+        self.total_rows = self.band_off[-1]
+
+    def flag_tensor(self, value):
+        import torch.distributed as dist_
+        torch = _torch()
+        on_dev = self.world > 1 and str(dist_.get_backend(self.group)).lower() == "nccl"
+        return torch.tensor([value], dtype=torch.int32, device=self.device if on_dev else "cpu")
+
+    def open(self):
+        import torch.distributed as dist_
+        torch = _torch()
+        lib = _lib.lib()
+        nbytes = max(self.total_rows, 1) * self.cols * 4
+        ok, why = 1, ""
+        p = C.c_void_p()
+        if self.rank == 0:
+            rc = lib.ppk_window_alloc(self.ref.device, nbytes, C.byref(p))
+            if rc != 0:
+                ok, why = 0, _lib.last_error()
+            else:
+                self.window = p.value
+        if self.world > 1:
+            handle = C.create_string_buffer(64)
+            if self.rank == 0 and ok:
+                if lib.ppk_window_export(self.ref.device, C.c_void_p(self.window), handle) != 0:
+                    ok, why = 0, _lib.last_error()
+            t = self.flag_tensor(0).new_zeros(64, dtype=torch.uint8)
+            if self.rank == 0:
+                t.copy_(torch.frombuffer(bytearray(handle.raw), dtype=torch.uint8))
+            dist_.broadcast(t, 0, group=self.group)
+            if self.rank != 0:
+                raw = bytes(t.cpu().numpy().tobytes())
+                if not any(raw):
+                    ok, why = 0, "the root exported no handle"
+                elif lib.ppk_window_open(self.ref.device, raw, C.byref(p)) != 0:
+                    ok, why = 0, _lib.last_error()
+                else:
+                    self.window = p.value
+            flag = self.flag_tensor(ok)
+            dist_.all_reduce(flag, op=dist_.ReduceOp.MIN, group=self.group)
+            if int(flag.item()) == 0:
+                self.close(collective=False)
+                raise RuntimeError("PeerStoreQuery: the window could not be mapped on every rank" +
+                                   (" (rank %d: %s)" % (self.rank, why) if why else ""))
+        elif not ok:
+            raise RuntimeError("PeerStoreQuery: " + why)
+        if self.rank == 0:
+            self._matrix = torch.as_tensor(_WindowArray(self.window, self.total_rows, self.cols), device=self.device)
+        return self
+
+    def matrix(self):
+        """The whole matrix (rank 0; a tensor over the window, no copy)."""
+        return self._matrix
+
+    def _launch(self, kmers, random_tbl, random_correct):
+        torch = _torch()
+        rows = self.band_rows[self.rank]
+        if rows == 0:
+            return
+        if self.n_failed is None:
+            self.n_failed = torch.zeros(1, dtype=torch.int64, device=self.device)
+        view = _DeviceRows(self.window + self.band_off[self.rank] * self.cols * 4, rows, self.cols)
+        dist(self.ref, self.qry, kmers, random_tbl, random_correct=random_correct, q_begin=self.bounds[self.rank],
+             q_end=self.bounds[self.rank + 1], out=view, n_failed=self.n_failed)
+
+    def run(self, kmers=None, random_tbl=None, random_correct=True):
+        """One whole-job step; returns the matrix on rank 0 (None elsewhere) once EVERY rank's rows are in it."""
+        import torch.distributed as dist_
+        torch = _torch()
+        if self.window is None:
+            raise RuntimeError("PeerStoreQuery.run before open()")
+        self._launch(kmers, random_tbl, random_correct)
+        torch.cuda.current_stream(self.device).synchronize()      # this rank's stores have left (kernel end = release)
+        if self.world > 1:
+            dist_.barrier(self.group)
+            torch.cuda.current_stream(self.device).synchronize()
+        return self._matrix if self.rank == 0 else None
+
+    def rebalance(self, kmers=None, random_tbl=None, random_correct=True, steps=2):
+        """Re-cut the bands in proportion to each rank's measured pairs per second (its kernel INCLUDING its stores
+        into the window: a rank behind a slower link gets fewer rows).  Collective.  Returns the new shares."""
+        import torch.distributed as dist_
+        torch = _torch()
+        if self.world == 1:
+            return [1.0]
+        for _ in range(max(1, steps)):
+            dist_.barrier(self.group)
+            torch.cuda.synchronize(self.device)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(self.device))
+            self._launch(kmers, random_tbl, random_correct)
+            e1.record(torch.cuda.current_stream(self.device))
+            e1.synchronize()
+            mine = max(e0.elapsed_time(e1), 1e-3)
+            t = self.flag_tensor(0).new_zeros(self.world, dtype=torch.float32)
+            t[self.rank] = self.band_rows[self.rank] / mine
+            dist_.all_reduce(t, op=dist_.ReduceOp.SUM, group=self.group)
+            rates = [max(float(x), 1e-9) for x in t.cpu().tolist()]
+            self._set_bounds(band_split_weighted(self.ref.n, self.n_qry, rates))     # (the window is sized by the
+            #                                                    pair space, not by the cut: nothing to re-allocate)
+        dist_.barrier(self.group)
+        return [b / max(self.total_rows, 1) for b in self.band_rows]
+
+    def close(self, collective=True):
+        import torch.distributed as dist_
+        torch = _torch()
+        lib = _lib.lib()
+        if collective and self.world > 1:
+            torch.cuda.synchronize(self.device)
+            dist_.barrier(self.group)        # nobody is still storing into a window that is about to go
+        self._matrix = None
+        if self.window is not None and self.rank != 0:
+            lib.ppk_window_close(self.ref.device, C.c_void_p(self.window))
+            self.window = None
+        if collective and self.world > 1:
+            dist_.barrier(self.group)        # every mapping is gone before the allocation is
+        if self.window is not None:
+            lib.ppk_window_free(self.ref.device, C.c_void_p(self.window))
+            self.window = None
+
+
 def edges_sharded(ref, qry, kmers, random_tbl, rank, world_size, slope=2, x_max=0.0, y_max=0.0,
                   scale=(1.0, 1.0), inclusive=True, random_correct=True, band_fn=None, group=None,
                   device=None, cap=None):

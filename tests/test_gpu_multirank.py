@@ -26,3 +26,5 @@ def test_two_ranks_one_gpu_matches_single_launch():
     assert "RESULT equal=True" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     assert "EDGES equal=True" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     assert "KNN equal=True" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    # every rank's kernel stores its band straight into ONE matrix owned by rank 0 (PeerStoreQuery, IPC window)
+    assert "PEERSTORE equal=True" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

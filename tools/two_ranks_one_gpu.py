@@ -38,5 +38,16 @@ got = engine.knn_sharded(db, K, T, 5, rank, world)
 if rank == 0:
     wi, wj, wd = engine.knn_from_sketches(db, K, T, 5, method="tiles")
     print("KNN equal=%s" % bool(torch.equal(got[0], wi) and torch.equal(got[1], wj) and torch.equal(got[2], wd)))
+# one matrix, every rank stores its band into it (the window is mapped through IPC: here both ranks sit on GPU 0, on
+# an N-GPU node the same stores cross xGMI)
+psq = engine.PeerStoreQuery(db, None, rank, world).open()
+m = psq.run(K, T)
+m = psq.run(K, T)
+ok1 = bool(torch.equal(m, whole)) if rank == 0 else True
+shares = psq.rebalance(K, T)
+m = psq.run(K, T)
+if rank == 0:
+    print("PEERSTORE equal=%s bands=%s shares=%s" % (ok1 and bool(torch.equal(m, whole)), psq.band_rows, ["%.3f" % x for x in shares]))
+psq.close()
 dist.barrier()
 dist.destroy_process_group()
