@@ -361,9 +361,20 @@ def peer_store_leg(args, engine, torch, dist, ref, kmers, tbl, rank, world, gath
     try:
         psq.run(kmers, tbl)
         shares = psq.rebalance(kmers, tbl)
-        m = psq.run(kmers, tbl)
-        same = psq.flag_tensor(1 if (rank != 0 or bool(torch.equal(m, gathered))) else 0)
-        dist.all_reduce(same, op=dist.ReduceOp.MIN)
+
+        def checked_step():
+            """rank 0 overwrites the whole window with a sentinel (through its own caches), then every rank stores
+            its band: the window must equal the gathered matrix -- a peer's row that did not arrive, or a stale
+            line served from the root's L2, shows as a sentinel."""
+            if rank == 0:
+                psq.matrix().fill_(-1.0)
+                torch.cuda.synchronize()
+            barrier()
+            m = psq.run(kmers, tbl)
+            flag = psq.flag_tensor(1 if (rank != 0 or bool(torch.equal(m, gathered))) else 0)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return bool(int(flag.item()))
+        same = checked_step()
         with timed_region("peer_store"):
             for _ in range(args.warmup):
                 psq.run(kmers, tbl)
@@ -373,12 +384,15 @@ def peer_store_leg(args, engine, torch, dist, ref, kmers, tbl, rank, world, gath
                 psq.run(kmers, tbl)
             barrier()
             elapsed = reduce_max([time.perf_counter() - t0])[0]
+        same = checked_step() and same
         pairs = psq.total_rows
-        return {"available": True, "identical_to_gathered": bool(int(same.item())),
+        return {"available": True, "identical_to_gathered": same,
                 "ms_per_step": elapsed / args.steps * 1e3, "pairs_per_s": pairs * args.steps / elapsed,
                 "band_shares": [round(x, 4) for x in shares],
                 "what": "every rank's kernel stores its band into ONE matrix on rank 0's GPU, mapped by the other "
-                        "ranks through IPC (ppk_window_*): no send, no receive, one barrier per step"}
+                        "ranks through IPC (ppk_window_*): no send, no receive, one barrier per step; "
+                        "identical_to_gathered: before and after the timed steps rank 0 fills the window with a "
+                        "sentinel, one step runs, and the window equals the gathered matrix bit for bit"}
     finally:
         psq.close()
 

@@ -45,6 +45,10 @@ m = psq.run(K, T)
 m = psq.run(K, T)
 ok1 = bool(torch.equal(m, whole)) if rank == 0 else True
 shares = psq.rebalance(K, T)
+if rank == 0:
+    psq.matrix().fill_(-1.0)        # (a row that does not arrive, or a stale cached line, would show)
+    torch.cuda.synchronize()
+dist.barrier()
 m = psq.run(K, T)
 if rank == 0:
     print("PEERSTORE equal=%s bands=%s shares=%s" % (ok1 and bool(torch.equal(m, whole)), psq.band_rows, ["%.3f" % x for x in shares]))
