@@ -127,3 +127,30 @@ def test_a_rank_that_dies_still_leaves_rank_0s_line():
     assert mg["error"]          # "SIGTERM in phase ..." and / or the broken collective rank 0 was in
     assert mg["per_rank_compute_only_ms_per_step"][0] is None or mg["per_rank_compute_only_ms_per_step"][0] > 0
     assert mg["host_call"] == {"fake": True, "devices": [0, 1]}          # measured before the process group
+
+
+def test_the_line_takes_the_faster_of_the_two_transports_only_when_the_matrices_were_identical(monkeypatch):
+    """N > 1: the gathered steps and the peer-store steps (every rank's kernel stores its band into rank 0's matrix)
+    are both timed over K steps; `value` is the peer-store figure only if that leg ran, produced the gathered matrix
+    bit for bit and was faster -- the other figure stays on the line either way."""
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "10", "--warmup", "1", "--genomes", "2000"])
+    args = bench.parse()
+
+    def line(ps):
+        rep = bench.Report(0, 2, args)
+        rep.fields.update({"n": 2000, "elapsed": 0.05, "compute_ms_max": 2.0, "peer_store": ps})
+        return bench.build_line(rep)
+
+    pairs = 2000 * 1999 // 2
+    good = {"available": True, "identical_to_gathered": True, "ms_per_step": 2.5, "pairs_per_s": pairs / 2.5e-3}
+    d = line(good)
+    assert d["ms_per_step"] == 2.5 and d["value"] == good["pairs_per_s"]
+    assert d["multi_gpu"]["gathered"]["ms_per_step"] == pytest.approx(5.0)
+    assert "peer-store" in d["multi_gpu"]["transport"] and "stores its band" in d["config"]["parallelism"]
+    for ps in (dict(good, identical_to_gathered=False), dict(good, ms_per_step=7.0), {"available": False, "why": "x"}, None):
+        d = line(ps)
+        assert d["ms_per_step"] == pytest.approx(5.0) and d["value"] == pytest.approx(pairs * 10 / 0.05)
+        assert "gathered" not in d["multi_gpu"] and d["multi_gpu"]["transport"].startswith("value = the gathered")
+        assert d["multi_gpu"]["peer_store"] == ps
