@@ -28,3 +28,21 @@ def test_two_ranks_one_gpu_matches_single_launch():
     assert "KNN equal=True" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     # every rank's kernel stores its band straight into ONE matrix owned by rank 0 (PeerStoreQuery, IPC window)
     assert "PEERSTORE equal=True" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_window_entry_points_alone():
+    """ppk_window_*: an allocation can be exported, a handle of noise is refused with an error (no crash), freeing
+    and closing nothing is fine."""
+    import ctypes as C
+    sys.path.insert(0, ROOT)
+    from poppunk_amd import _lib
+    lib = _lib.lib()
+    p = C.c_void_p()
+    assert lib.ppk_window_alloc(0, 1 << 20, C.byref(p)) == 0 and p.value
+    h = C.create_string_buffer(64)
+    assert lib.ppk_window_export(0, p, h) == 0 and any(h.raw)
+    q = C.c_void_p()
+    assert lib.ppk_window_open(0, bytes(range(64)), C.byref(q)) != 0 and "hipIpcOpenMemHandle" in _lib.last_error()
+    assert lib.ppk_window_alloc(0, 0, C.byref(q)) != 0
+    assert lib.ppk_window_free(0, p) == 0
+    assert lib.ppk_window_free(0, None) == 0 and lib.ppk_window_close(0, None) == 0
