@@ -27,7 +27,7 @@ print("%d genomes: sketches drawn on the device in %.1f s (%.2f GB)" % (n, time.
 db = engine.SketchDB(sk_t, 16, 14, device=0)
 sub = engine.SketchDB(synth.make_sketches_device(2000, kmers, device="cuda:0"), 16, 14, device=0)
 d_sub, _ = engine.dist(sub, None, kmers, tbl)
-x_max, y_max = synth.boundary_for_quantile(d_sub.cpu().numpy(), 0.02)
+x_max, y_max = synth.boundary_for_quantile(synth.tensor_to_numpy(d_sub), 0.02)
 sub.close()
 pairs = n * (n - 1) // 2
 runs = []
