@@ -16,20 +16,27 @@ sys.path.insert(0, %r)
 from poppunk_amd import _lib
 _lib.SO_PATH = os.path.abspath(sys.argv[1])
 import torch
+# an older build lacks the entry points added since: bind what it has (the jobs below use ppk_dist_dev only)
+import ctypes
+_lib._preload_hip_runtime()
+_h = ctypes.CDLL(_lib.SO_PATH)
+for _n in list(_lib.SIGNATURES):
+    if not hasattr(_h, _n):
+        del _lib.SIGNATURES[_n]
 from poppunk_amd import engine, synth
 K = np.asarray(synth.DEFAULT_KMERS, dtype=np.int32); T = synth.random_match_table(K)
 n = int(os.environ.get("N", "10000"))
 sk, _ = synth.make_sketches(max(n, 10240), K)
 out = {}
-for name, (nr, nq) in (("self%%d" %% n, (n, 0)), ("rq10240", (10240, 10240))):
+for name, (nr, nq) in (("self%%d" %% n, (n, 0)), ("rq10240", (10240, 10240)), ("c4_50000x10000", (10000, 50000))):
     ref = engine.SketchDB(sk[:nr], 16, 14)
-    qry = engine.SketchDB(sk[:nq], 16, 14) if nq else None
+    qry = engine.SketchDB(np.concatenate([sk[:10000]] * ((nq + 9999) // 10000))[:nq], 16, 14) if nq else None
     buf = None
-    for _ in range(40):
+    for _ in range(40 if nq <= 10240 else 5):
         buf, _f = engine.dist(ref, qry, K, T, out=buf)
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 60
+    reps = 60 if nq <= 10240 else 10
     ev0.record()
     for _ in range(reps):
         engine.dist(ref, qry, K, T, out=buf)
