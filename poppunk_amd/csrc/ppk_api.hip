@@ -52,6 +52,7 @@ const OptionEntry kOptions[] = {
     {"strip", "PPK_STRIP", &PpkConfig::strip},
     {"ksplit", "PPK_KSPLIT", &PpkConfig::ksplit},
     {"ksplit_slices", "PPK_KSPLIT_SLICES", &PpkConfig::ksplit_slices},
+    {"wide_kpg", "PPK_WIDE_KPG", &PpkConfig::wide_kpg},
     {"ksplit_wide", "PPK_KSPLIT_WIDE", &PpkConfig::ksplit_wide},
     {"ksplit_fused", "PPK_KSPLIT_FUSED", &PpkConfig::ksplit_fused},
     {"chunk_rows", "PPK_CHUNK_ROWS", &PpkConfig::chunk_rows},
@@ -417,6 +418,8 @@ int scratch_get(int dev, int slot, size_t bytes, void **out) {
     s.bytes = want;
     // the per-tile counters of the k-split kernel start at zero and every launch leaves them there
     if (slot == SLOT_TICKETS && hipMemset(s.p, 0, want) != hipSuccess) return ppk_fail(PPK_ERR_HIP, "hipMemset(scratch) failed");
+    // the slot bitmap of the wide-k kernel likewise
+    if (slot == SLOT_WIDE && hipMemset(s.p, 0, 4096) != hipSuccess) return ppk_fail(PPK_ERR_HIP, "hipMemset(scratch) failed");
   }
   tl_call.touched |= 1u << slot;
   *out = s.p;
@@ -634,15 +637,13 @@ extern "C" int ppk_dist_edges_dev(const ppk_db *ref, const ppk_db *qry, const in
   rc = stage_tables(ref, kmers, random_tbl, n_clu, flags, s, &d_lut, &d_rtab, &lut_ready);
   if (rc != PPK_OK) return rc;
   {
-    // nk * count-bits > 128: no fused path; distances (pre-divided by scale) go to scratch and the
-    // row-linear edge kernel runs on them -- whole matrices only (band edge lists need the fused path)
-    const size_t nbins = ref->s64 * 64;
-    int bits = 1;
-    while (((size_t)1 << bits) <= nbins) ++bits;
-    if (ref->nk > PPK_MAX_NK || ref->nk * (size_t)bits > 128) {
+    // sketches the tile kernels cannot fit (ppk_unfused: bbits other than 14 with more than 128 count bits --
+    // nothing PopPUNK writes): distances (pre-divided by scale) go to scratch and the row-linear edge kernel
+    // runs on them, whole matrices only
+    if (ppk_unfused(ref)) {
       const size_t nq = qry ? qry->n : ref->n;
       if (q_begin != 0 || q_end != nq)
-        return ppk_fail(PPK_ERR_ARG, "edge lists of a band need nk * count bits <= 128 (the fused path)");
+        return ppk_fail(PPK_ERR_ARG, "edge lists of a band need bbits = 14 or nk * count bits <= 128");
       const size_t rows = ppk_rows_in_band(ref->n, qry ? qry->n : 0, 0, nq);
       void *d_dist = nullptr;
       rc = scratch_get(ref->device, SLOT_ITER_B, rows * 8 + 8, &d_dist);

@@ -160,7 +160,14 @@ struct DistParams {
   unsigned tiles_per_xcd;      // ceil(n_tiles / 8)
   int tri_m, tri_c0;           // self job: ref tile r pairs with clamp(tri_m * r + tri_c0, 0, q_tiles) query tiles
   int knn, knn_col;       // MODE_KNN: neighbours per sample, distance column (0 core, 1 accessory)
-  int ablate;             // measurement only (PPK_ABLATE): 1 skip epilogue, 2 skip compare, 4 skip DMA, 8 skip barriers, 64 skip the (E, F) table copy
+  int ablate;             // experiments build only (PPK_ABLATE): 1 skip epilogue, 2 skip compare, 4 skip DMA, 8 skip barriers, 64 skip the (E, F) table copy
+  // WIDE instantiation (nk * cnt_bits > 128): the 128-bit count register holds wide_kpg k-mer lengths; when it is
+  // full the workgroup parks it in its spill slot (see PackWide) and starts the next group from zero
+  int wide_kpg;                    // k-mer lengths per group = 128 / cnt_bits (0: not a wide launch)
+  int wide_groups;                 // ceil(nk / wide_kpg)
+  unsigned wide_nslots;            // spill slots (a power of two, >= 2 x the workgroups a device can hold)
+  unsigned *wide_bitmap;           // one bit per slot: taken (zero between launches)
+  unsigned long long *wide_slots;  // [slot][group][32][512 threads] uint64
   int ext_adjust;         // [EXT] a4 gate (PpkConfig::ext_collision_adjust)
   int ext_skip;           // [EXT] a6: skip instead of truncate at J < 5/s (PpkConfig::ext_fit_skip)
 
@@ -307,7 +314,10 @@ __device__ __forceinline__ void fit_general(const PackT &pk, const double *__res
   for (int k = 0; k < p.nk; ++k) {
     const uint32_t c = pack_get(pk, k, p.cnt_bits, cmask, p.nk);
     const double y = lutp[(size_t)k * p.lut_kstride + c];
-    open = (p.ext_skip || open) && (y <= 0.0);      // [EXT] truncate at (default) / skip the k below the floor
+    // [EXT] truncate at (default) / skip the k below the floor.  `!(y > 0)`, not `y <= 0`: a NaN Jaccard (a random-match
+    // entry of exactly 1: 0 / 0 in observed_excess) is not "below the floor" -- upstream's `jaccard < tolerance` is
+    // false for it -- so the point stays, the sums turn NaN and both distances come out 0, not counted as failed
+    open = (p.ext_skip || open) && !(y > 0.0);
     if (open) {
       const double x = (double)p.kmers[k];
       sx += x;
@@ -416,10 +426,11 @@ __device__ __forceinline__ bool ef_finish(const f64x2 (&ef)[NR][NK], float (&cor
 }
 
 // any nk: running products (no gather batch to keep in registers)
+struct PackWide;
 template <typename PackT, int NR, typename ParamsT>
-__device__ __forceinline__ bool fit_rows_fast_anyk(const PackT (&pk)[NR], const double *__restrict__ lut,
-                                                   const uint32_t (&loff)[NR], const ParamsT &p,
-                                                   float (&core)[NR], float (&acc)[NR]) {
+__device__ __forceinline__ std::enable_if_t<!std::is_same<PackT, PackWide>::value, bool>
+fit_rows_fast_anyk(const PackT (&pk)[NR], const double *__restrict__ lut, const uint32_t (&loff)[NR],
+                   const ParamsT &p, float (&core)[NR], float (&acc)[NR]) {
   const uint32_t cmask = (1u << p.cnt_bits) - 1u;
   const uint32_t kstride = (uint32_t)p.lut_kstride;
   const char *base = reinterpret_cast<const char *>(lut + p.lut_total);
@@ -432,6 +443,133 @@ __device__ __forceinline__ bool fit_rows_fast_anyk(const PackT (&pk)[NR], const 
       const f64x2 v = *reinterpret_cast<const f64x2 *>(base + boff);
       pe[r] = k == 0 ? v.x : pe[r] * v.x;
       pf[r] = k == 0 ? v.y : pf[r] * v.y;
+    }
+  }
+  bool all_ok = p.nk >= 2;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) all_ok = all_ok && (pe[r] == pe[r]);
+  if (!__all(all_ok)) return false;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) fit_finish(pe[r], pf[r], core[r], acc[r]);
+  return true;
+}
+
+// ---- wide k-mer sets: nk * cnt_bits > 128 ------------------------------------------------------
+// PopPUNK's default sketch size (9 984 bins, 14-bit counts) fits 9 k-mer lengths in the tile kernel's
+// 128-bit count register; the documented wider lists (k = 6..15 step 1, 13..31 step 2:
+// docs/sketching.rst:123-139,152-156; any np.arange(min_k, max_k + 1, k_step), PopPUNK/__main__.py:299) do not.
+// The WIDE instantiation keeps the same 4x4 register tile and instruction stream and treats the register as
+// a window over the k list: every wide_kpg = 128 / cnt_bits k-mer lengths a lane parks its 16 registers in
+// the workgroup's SPILL SLOT -- 128 KB per group, [group][pair * 4 + dword][thread] uint32, so every store of
+// a wavefront covers 256 consecutive bytes -- and starts the next group from zero; the last group follows
+// after the loop and the epilogue reads every count back from the slot (each lane only ever reads what it
+// wrote).  A slot belongs to a RESIDENT workgroup, not to a tile: 1 024 of them (twice what the device can
+// hold) are handed out through a bitmap at the start of a workgroup and given back at its end, so the pool
+// is a few hundred MB whatever the job size -- a 100 000-genome band has millions of tiles.  A slot's next
+// owner may run on another XCD (another L2): every access to a slot is an agent-scope atomic (written
+// through / served coherently, as in the k-split hand-over below), and the pool is touched once per
+// wide_kpg * s64 compare blocks, i.e. never on the critical path.
+// The fit takes the counts in k order with the same expressions as fit_packed / fit_general: a job forced
+// through this path (option "wide_kpg") returns the bits the register path returns.
+struct PackWide {
+  const uint32_t *src;      // the lane's first dword of the pair, group 0
+};
+constexpr size_t WIDE_GROUP_U64 = 32 * 512;      // uint64 per (slot, group): 16 pairs x 2 x 512 threads
+
+__device__ __forceinline__ PackW<4> wide_load(const PackWide &pk, int g) {
+  const uint32_t *s = pk.src + (size_t)g * (2 * WIDE_GROUP_U64);
+  PackW<4> v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v.w[i] = __hip_atomic_load(s + i * 512, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return v;
+}
+
+template <typename ParamsT>
+__device__ __forceinline__ void fit_general(const PackWide &pk, const double *__restrict__ lutp,
+                                            const ParamsT &p, float &core, float &acc, bool &failed) {
+  const uint32_t cmask = (1u << p.cnt_bits) - 1u;
+  double sx = 0.0, sxx = 0.0, sy = 0.0, sxy = 0.0;
+  int n = 0, k = 0;
+  bool open = true;
+  for (int g = 0; k < p.nk; ++g) {
+    const int m = p.nk - k < p.wide_kpg ? p.nk - k : p.wide_kpg;
+    const PackW<4> v = wide_load(pk, g);
+    for (int i = 0; i < m; ++i, ++k) {
+      const uint32_t c = pack_get(v, i, p.cnt_bits, cmask, m);
+      const double y = lutp[(size_t)k * p.lut_kstride + c];
+      open = (p.ext_skip || open) && !(y > 0.0);      // (NaN stays in: see the register version)
+      if (open) {
+        const double x = (double)p.kmers[k];
+        sx += x;
+        sxx += x * x;
+        sy += y;
+        sxy = __builtin_fma(x, y, sxy);
+        ++n;
+      }
+    }
+  }
+  if (n < 2) {
+    core = 0.0f;
+    acc = 0.0f;
+    failed = true;
+    return;
+  }
+  const double dn = (double)n;
+  const double slope = (dn * sxy - sx * sy) / (dn * sxx - sx * sx);
+  const double icpt = (sy - slope * sx) / dn;
+  core = slope < 0.0 ? (float)(1.0 - exp_nonpos(slope)) : 0.0f;
+  acc = icpt < 0.0 ? (float)(1.0 - exp_nonpos(icpt)) : 0.0f;
+  failed = false;
+}
+
+template <typename ParamsT>
+__device__ __forceinline__ void fit_packed(const PackWide &pk, const double *__restrict__ lut, size_t cp_off,
+                                           const ParamsT &p, float &core, float &acc, bool &failed) {
+  const uint32_t cmask = (1u << p.cnt_bits) - 1u;
+  const double *ef_base = lut + p.lut_total + 2 * cp_off;
+  double pe = 1.0, pf = 1.0;
+  int k = 0;
+  for (int g = 0; k < p.nk; ++g) {
+    const int m = p.nk - k < p.wide_kpg ? p.nk - k : p.wide_kpg;
+    const PackW<4> v = wide_load(pk, g);
+    for (int i = 0; i < m; ++i, ++k) {
+      const uint32_t c = pack_get(v, i, p.cnt_bits, cmask, m);
+      const double *ef = ef_base + 2 * ((size_t)k * p.lut_kstride + c);
+      pe = k == 0 ? ef[0] : pe * ef[0];
+      pf = k == 0 ? ef[1] : pf * ef[1];
+    }
+  }
+  if (pe == pe && p.nk >= 2) {
+    fit_finish(pe, pf, core, acc);
+    failed = false;
+    return;
+  }
+  fit_general(pk, lut + cp_off, p, core, acc, failed);
+}
+
+template <typename PackT, int NR, typename ParamsT>
+__device__ __forceinline__ std::enable_if_t<std::is_same<PackT, PackWide>::value, bool>
+fit_rows_fast_anyk(const PackWide (&pk)[NR], const double *__restrict__ lut, const uint32_t (&loff)[NR],
+                   const ParamsT &p, float (&core)[NR], float (&acc)[NR]) {
+  const uint32_t cmask = (1u << p.cnt_bits) - 1u;
+  const uint32_t kstride = (uint32_t)p.lut_kstride;
+  const char *base = reinterpret_cast<const char *>(lut + p.lut_total);
+  double pe[NR], pf[NR];
+  int k = 0;
+  for (int g = 0; k < p.nk; ++g) {
+    const int m = p.nk - k < p.wide_kpg ? p.nk - k : p.wide_kpg;
+    PackW<4> v[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) v[r] = wide_load(pk[r], g);
+    for (int i = 0; i < m; ++i, ++k) {
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const uint32_t c = pack_get(v[r], i, p.cnt_bits, cmask, m);
+        const uint32_t boff = (loff[r] + (uint32_t)k * kstride + c) * 16u;
+        const f64x2 e = *reinterpret_cast<const f64x2 *>(base + boff);
+        pe[r] = k == 0 ? e.x : pe[r] * e.x;
+        pf[r] = k == 0 ? e.y : pf[r] * e.y;
+      }
     }
   }
   bool all_ok = p.nk >= 2;
@@ -629,7 +767,10 @@ __device__ __forceinline__ unsigned tiles_before(unsigned r, int self, unsigned 
 // (256 x 64 tile, one workgroup per CU) was measured and rejected (tools/ubench_pipe.hip).
 // W = dwords of the per-pair count register (1 in the COUNTS / JACCARD modes, which consume each
 // k's counts at once)
-template <int NW, int MODE, int W, bool KSPLIT = false>
+// WIDE: the count register is a window over the k list (PackWide above).  EXP: the experiments build's
+// instantiation -- `ablate` and the rejected tile orders exist only there, so the product kernel carries neither
+// their tests nor a live scalar for them.
+template <int NW, int MODE, int W, bool KSPLIT = false, bool WIDE = false, bool EXP = false>
 __global__ void __launch_bounds__(NW * 64, 4)
 dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ qryT,
                const double *__restrict__ lut, const uint16_t *__restrict__ ref_clu,
@@ -637,6 +778,9 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
                void *__restrict__ out, unsigned long long *__restrict__ n_failed,
                uint64_t *__restrict__ mask_out, const DistParams p) {
   static_assert(NW == 8, "the product tile is 256 refs x 32 queries (8 wavefronts)");
+  static_assert(!WIDE || (W == 4 && !KSPLIT && (MODE == MODE_DIST || MODE == MODE_MASK || MODE == MODE_KNN)),
+                "the wide instantiation windows the 128-bit register");
+  const int ablate = EXP ? p.ablate : 0;
   constexpr int R = V2_R, TQ = V2_TQ, BB = V2_BB;
   constexpr int V2_QT = NW * TQ;              // queries per workgroup tile (32)
   constexpr int REF_U4 = BB * 128;            // 14 rows x 256 samples x 8 B = 28 KB
@@ -655,8 +799,8 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
   // KS_FUSED: a k-split job whose tiles are fitted by their last workgroup (below); one more entry behind the
   // compare buffers holds the workgroup's grid position across the loop, in LDS instead of two SGPRs
   constexpr bool KS_FUSED = KSPLIT && MODE == MODE_DIST;
-  constexpr int KS_SLOT = 2 * CHUNK_U4;
-  __shared__ u32x4 lds[LDS_TABLE && TAB_U4 > 2 * CHUNK_U4 + 1 ? TAB_U4 : 2 * CHUNK_U4 + (KS_FUSED ? 1 : 0)];
+  constexpr int KS_SLOT = 2 * CHUNK_U4;      // (WIDE: the workgroup's spill slot index lives there)
+  __shared__ u32x4 lds[LDS_TABLE && TAB_U4 > 2 * CHUNK_U4 + 1 ? TAB_U4 : 2 * CHUNK_U4 + (KS_FUSED || WIDE ? 1 : 0)];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -678,7 +822,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
   } else {
     if (blockIdx.x < p.n_strip_pad) return;
     const unsigned b = blockIdx.x - p.n_strip_pad;
-    if (p.xcd_map == 0) {
+    if (!EXP || p.xcd_map == 0) {
       // Default order.  Workgroup b is dispatched to XCD b % 8 (observed; used for speed only) and
       // every XCD has a private 4 MB L2.  The non-empty tiles, taken ref-tile-major, are cut into
       // 8 equal contiguous runs, one per XCD: the ~64 workgroups resident on an XCD then work on
@@ -728,6 +872,24 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
   int lane_late = lane;   // DIST / MASK: re-derived after the loop, see below
   auto ref_of = [&](int r) -> size_t { return r0 + 2 * lane_late + (r & 1) + (r >> 1) * 128; };
 
+  if constexpr (WIDE) {
+    // take a spill slot: the first free bit from a start that spreads neighbouring workgroups over the words
+    if (threadIdx.x == 0) {
+      const unsigned mask = p.wide_nslots - 1u;
+      unsigned sl = (blockIdx.x * 37u) & mask;
+      for (;;) {
+        const unsigned bit = 1u << (sl & 31u);
+        const unsigned old = __hip_atomic_fetch_or(p.wide_bitmap + (sl >> 5), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!(old & bit)) break;
+        sl = (sl + 1u) & mask;
+        if ((sl & 31u) == 0) __builtin_amdgcn_s_sleep(8);
+      }
+      u32x4 pos;
+      pos.x = sl;
+      pos.y = pos.z = pos.w = 0;
+      lds[KS_SLOT] = pos;      // (read after the first barrier below)
+    }
+  }
   // one chunk per (k, 64-bin block); with k_split a workgroup owns the chunks of k = blockIdx.y only
   // (a template parameter, not a launch parameter: the tile kernels sit at the SGPR limit and one
   // more live scalar spills into VGPR lanes and from there into scratch inside the loop)
@@ -804,8 +966,35 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
 #pragma unroll
       for (int q = 0; q < TQ; ++q) pw[i][r][q] = 0;
 
+  typedef const __attribute__((address_space(4))) DistParams LateParams;
+  // WIDE: park the count registers of group g in the workgroup's spill slot (PackWide).  Everything it needs
+  // beyond the registers themselves is fetched when it runs -- once per wide_kpg * s64 blocks -- so the loop
+  // carries one more scalar (`wide_next`) and nothing else.
+  auto wide_park = [&](int g) __attribute__((always_inline)) {
+    if constexpr (WIDE) {
+      const char __attribute__((address_space(4))) *ka =
+          (const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(ka));
+      LateParams &pl = *reinterpret_cast<LateParams *>(ka + V2_PARAMS_KERNARG_OFFSET);
+      const uint32_t slot = __builtin_amdgcn_readfirstlane(*(volatile __attribute__((address_space(3))) uint32_t *)(__attribute__((address_space(3))) void *)(lds + KS_SLOT));
+      // uniform base + one 32-bit lane offset (the saddr form): dword stores, written through (sc1 = agent scope)
+      const char *dst = reinterpret_cast<const char *>(pl.wide_slots + ((size_t)slot * (size_t)pl.wide_groups + (size_t)g) * WIDE_GROUP_U64);
+      const uint32_t voff = (uint32_t)wave * 256u + (voff_ref >> 2);      // 4 * thread
+#pragma unroll
+      for (int q = 0; q < TQ; ++q)
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int i = 0; i < W; ++i) {
+            // dword i of pair (q, r): [(q * R + r) * 4 + i][512 threads]
+            const char *d = dst + (size_t)(((q * R + r) * 4 + i) * 2048);
+            asm volatile("global_store_dword %0, %1, %2 sc1" ::"v"(voff), "v"(pw[i][r][q]), "s"(d) : "memory");
+          }
+    }
+  };
+
   issue_dma(0, half);
-  if (!(p.ablate & 16)) {   // (bit 16, measurement only: what hiding the tile's first copy could win)
+  if (!(ablate & 16)) {   // (bit 16, measurement only: what hiding the tile's first copy could win)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
@@ -822,9 +1011,9 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
     // wave's four DMA pieces from INSIDE its instruction stream (in VALU-only stretches instead of
     // next to the opening burst of ds_reads); waves with nothing to compare still copy from here.
     constexpr bool DMA_IN_STREAM = NW == 8 && W >= 2 && !HALF;
-    if (g + 1 < total && !(p.ablate & 4) && !(DMA_IN_STREAM && wave_active)) issue_dma(buf ^ 1, HALF);
+    if (g + 1 < total && !(ablate & 4) && !(DMA_IN_STREAM && wave_active)) issue_dma(buf ^ 1, HALF);
 
-    if (wave_active && !(p.ablate & 2)) {
+    if (wave_active && !(ablate & 2)) {
       // One 64-bin block of the 4x4 register tile: 14 x (4 ds_read_b128 + 32 v_bitop3) + 32
       // v_bcnt, as the generated bank-aware instruction stream (tools/gen_block_asm.py).
       const uint32_t rp =
@@ -878,7 +1067,25 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
         // ---- end of one k --------------------------------------------------------
         if constexpr (MODE == MODE_DIST || MODE == MODE_MASK || MODE == MODE_KNN) {
           // another k follows: the count register moves up by one field
-          if (k + 1 < p.nk) {
+          bool parked = false;
+          if constexpr (WIDE) {
+            // (the group size is fetched here, opaquely: held across the loop it costs the scalar -- and, hoisted,
+            // the reciprocal -- the loop does not have; this runs once per s64 blocks)
+            int kpg = p.wide_kpg;
+            asm volatile("" : "+s"(kpg));
+            if (k + 1 < p.nk && (k + 1) % kpg == 0) {
+              // the register holds a whole group: out it goes, the next group starts from zero
+              wide_park((k + 1) / kpg - 1);
+#pragma unroll
+              for (int i = 0; i < W; ++i)
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                  for (int q = 0; q < TQ; ++q) pw[i][r][q] = 0;
+              parked = true;
+            }
+          }
+          if (k + 1 < p.nk && !parked) {
             const int up = 32 - p.cnt_bits;
 #pragma unroll
             for (int r = 0; r < R; ++r)
@@ -931,7 +1138,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
     }
     // my DMA pieces have landed; after the barrier everyone's have, and everyone has
     // finished reading `buf` (all ds_read results were consumed above)
-    if (!(p.ablate & 8)) {
+    if (!(ablate & 8)) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
@@ -944,8 +1151,8 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
 
   // ---- epilogue: regression (+ boundary) per pair ---------------------------
   if constexpr (MODE == MODE_DIST || MODE == MODE_MASK || MODE == MODE_KNN) {
-    if (p.ablate & 1) return;
-    if (!KS_FUSED && MODE != MODE_KNN && !wave_active) return;      // (KNN, k-split: every wave takes part in an exchange)
+    if (ablate & 1) return;
+    if (!KS_FUSED && !WIDE && MODE != MODE_KNN && !wave_active) return;      // (KNN, k-split, wide: every wave takes part in an exchange)
     // the compare stream leaves the wave at priority 0 (it falls through each block, see
     // tools/gen_block_asm.py); the epilogue is the last thing between this workgroup's slot and the next
     // tile, so it runs at the top priority (measured: another -0.5..-1 %)
@@ -980,9 +1187,20 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
     const char __attribute__((address_space(4))) *ka =
         (const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(ka));
-    typedef const __attribute__((address_space(4))) DistParams LateParams;
     LateParams &p_late = *reinterpret_cast<LateParams *>(ka + V2_PARAMS_KERNARG_OFFSET);
     uint32_t ks_tile = 0;
+    // WIDE: the last group joins the others in the slot; from here on the counts are read from there
+    uint32_t wide_slot = 0;
+    const uint32_t *wide_src = nullptr;
+    if constexpr (WIDE) {
+      wide_slot = __builtin_amdgcn_readfirstlane(*(volatile __attribute__((address_space(3))) uint32_t *)(__attribute__((address_space(3))) void *)(lds + KS_SLOT));
+      if (wave_active) {
+        wide_park(p_late.wide_groups - 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      wide_src = reinterpret_cast<const uint32_t *>(p_late.wide_slots + (size_t)wide_slot * (size_t)p_late.wide_groups * WIDE_GROUP_U64) +
+                 ((uint32_t)wave * 64u + (uint32_t)lane_late);
+    }
     if constexpr (KS_FUSED) {
       // ---- k-split job: ONE launch -----------------------------------------------------------------
       // Jobs of less than a round of tiles give every tile to ks_units workgroups (one k, or a half / a
@@ -1127,6 +1345,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
       }
     };
     auto epilogue = [&](LateParams &p) {
+    const int ablate_l = EXP ? p.ablate : 0;      // (experiments build only)
     int cr[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) cr[r] = (ref_clu && ref_of(r) < p.n_ref) ? ref_clu[ref_of(r)] : 0;
@@ -1156,7 +1375,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
     size_t cp_tile = 0;      // the tile's one cluster pair: its block of the table (entries)
     if constexpr (LDS_TABLE) {
       interior = p.lut32 && p.nk >= 3 && p.nk <= 5 && p.cnt_bits == 11 && p.lut_kstride == 1025 &&
-                 !strip && !half && !(p.ablate & 32) && r0 + V2_RT <= p.r_limit && q0 >= qb &&
+                 !strip && !half && !(ablate_l & 32) && r0 + V2_RT <= p.r_limit && q0 >= qb &&
                  q0 + V2_QT <= qe && (!p.self || r0 >= q0 + V2_QT);      // workgroup-uniform
       if constexpr (KS_FUSED) {
         // A k-split job fits ONE tile per workgroup with nothing else on the CU to hide behind, and its tiles
@@ -1166,7 +1385,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
         // fitted like the others and simply not written, and only a REAL pair with a k below the floor sends
         // its wavefront to the general statement.
         interior = p.lut32 && p.nk >= 3 && p.nk <= 5 && p.cnt_bits == 11 && p.lut_kstride == 1025 && !strip &&
-                   !(p.ablate & 32);
+                   !(ablate_l & 32);
       }
       if (interior && (ref_clu || qry_clu)) {
         // Several random-match clusters (a real database has ~3, by base composition): the samples of
@@ -1199,7 +1418,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
 #pragma unroll
         for (int t = 0; t < PIECES; ++t) {
           const int piece = wave * PIECES + t;        // k = piece / 16, rows 64 * (piece % 16) ..
-          if (p.ablate & 64) {
+          if (ablate_l & 64) {
             // (bit 64, measurement only: what the table copy costs -- an upper bound on what issuing part of
             // it under the last compare block could win; the look-ups then read whatever the buffers hold)
           } else if ((piece >> 4) < p.nk) {
@@ -1264,7 +1483,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
             usable = usable || !(q32 >= (uint32_t)qb && q32 < (uint32_t)qe && rf < (uint32_t)p.r_limit &&
                                  (!p.self || rf > q32) && !(half && r < 2));
           }
-          if (!__all(usable) && !(p.ablate & 64)) {
+          if (!__all(usable) && !(ablate_l & 64)) {
             interior = false;
             break;
           }
@@ -1301,7 +1520,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
                 if (v0) orow[loc] = make_float2(v.x, v.y);
                 if (v1) orow[loc + 1] = make_float2(v.z, v.w);
               }
-            } else if (!(p.ablate & 128))      // (measurement only)
+            } else if (!(ablate_l & 128))      // (measurement only)
               *reinterpret_cast<f32x4_a8 *>(orow + (2u * (uint32_t)lane_late + 128u * h)) = v;
           }
         } else if constexpr (MODE == MODE_MASK) {
@@ -1345,7 +1564,8 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
     constexpr int NRB = PIPE ? 1 : 2;      // refs per batch (pipelined: one, 5 gathers = 20 VGPRs per register set)
     constexpr int NB = R * TQ / NRB;       // batches, query-major: b = q * (R / NRB) + r / NRB
     f64x2 ef[2][NRB][5];
-    auto batch_operands = [&](int bq, int br0, size_t (&cpo)[NRB], uint32_t (&loff)[NRB], PackT (&pk)[NRB]) {
+    using EpiPack = std::conditional_t<WIDE, PackWide, PackT>;
+    auto batch_operands = [&](int bq, int br0, size_t (&cpo)[NRB], uint32_t (&loff)[NRB], EpiPack (&pk)[NRB]) {
       const size_t qq = qw0 + bq;
       const int cq = (qry_clu && qq >= qb && qq < qe) ? qry_clu[qq] : 0;
 #pragma unroll
@@ -1356,16 +1576,22 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
         const size_t cp = (size_t)(strip ? cq * p.n_clu + cr[r] : cr[r] * p.n_clu + cq) * p.lut_cpstride;
         cpo[j] = cp;
         loff[j] = (uint32_t)cp;
+        if constexpr (WIDE) {
+          pk[j].src = wide_src + (size_t)((bq * R + r) * 4) * 512;
+        } else {
 #pragma unroll
-        for (int i = 0; i < W; ++i) pk[j].w[i] = pw[i][r][bq];
+          for (int i = 0; i < W; ++i) pk[j].w[i] = pw[i][r][bq];
+        }
       }
     };
-    if (pipelined) {
-      size_t cpo[NRB];
-      uint32_t loff[NRB];
-      PackT pk[NRB];
-      batch_operands(0, 0, cpo, loff, pk);
-      ef_gather<PackT, NRB, 5>(pk, lut, loff, p, ef[0]);
+    if constexpr (PIPE) {
+      if (pipelined) {
+        size_t cpo[NRB];
+        uint32_t loff[NRB];
+        PackT pk[NRB];
+        batch_operands(0, 0, cpo, loff, pk);
+        ef_gather<PackT, NRB, 5>(pk, lut, loff, p, ef[0]);
+      }
     }
     uint64_t ball[R];
     bool valid[R], failed[R];
@@ -1377,13 +1603,15 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
       const size_t qq = qw0 + q;   // wave-uniform
       const bool in_band = qq >= qb && qq < qe;
       const size_t rowq = (p.self ? qq * p.n_ref - (qq * (qq + 1)) / 2 - qq - 1 : qq * p.n_ref) - p.row_base;
-      if (pipelined && b + 1 < NB) {
-        size_t cpo_n[NRB];
-        uint32_t loff_n[NRB];
-        PackT pk_n[NRB];
-        batch_operands((b + 1) / (R / NRB), ((b + 1) % (R / NRB)) * NRB, cpo_n, loff_n, pk_n);
-        ef_gather<PackT, NRB, 5>(pk_n, lut, loff_n, p, ef[(b + 1) & 1]);
-        asm volatile("" ::: "memory");    // the gathers of b+1 stay ahead of everything batch b does
+      if constexpr (PIPE) {
+        if (pipelined && b + 1 < NB) {
+          size_t cpo_n[NRB];
+          uint32_t loff_n[NRB];
+          PackT pk_n[NRB];
+          batch_operands((b + 1) / (R / NRB), ((b + 1) % (R / NRB)) * NRB, cpo_n, loff_n, pk_n);
+          ef_gather<PackT, NRB, 5>(pk_n, lut, loff_n, p, ef[(b + 1) & 1]);
+          asm volatile("" ::: "memory");    // the gathers of b+1 stay ahead of everything batch b does
+        }
       }
       // the fit runs for every lane (counts of padding samples index the table like any other);
       // `valid` only gates what is written
@@ -1396,7 +1624,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
       } else {
         size_t cpo[NRB];
         uint32_t loff[NRB];
-        PackT pk[NRB];
+        EpiPack pk[NRB];
         float c2[NRB], a2[NRB];
         bool f2[NRB];
         batch_operands(q, r0b, cpo, loff, pk);
@@ -1410,8 +1638,12 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
         }
         // the fast path (every k usable in every lane), else pair by pair (unrolled: a rolled loop
         // would index the operand arrays dynamically and push them into scratch)
-        const bool fast = pipelined ? ef_finish<NRB, 5>(ef[b & 1], c2, a2)
-                                    : (p.lut32 && fit_rows_fast_anyk<PackT, NRB>(pk, lut, loff, p, c2, a2));
+        bool fast;
+        if constexpr (PIPE)
+          fast = pipelined ? ef_finish<NRB, 5>(ef[b & 1], c2, a2)
+                           : (p.lut32 && fit_rows_fast_anyk<EpiPack, NRB>(pk, lut, loff, p, c2, a2));
+        else
+          fast = p.lut32 && fit_rows_fast_anyk<EpiPack, NRB>(pk, lut, loff, p, c2, a2);
         if (!fast) {
 #pragma unroll
           for (int j = 0; j < NRB; ++j) fit_packed(pk[j], lut, cpo[j], p, c2[j], a2[j], f2[j]);
@@ -1633,7 +1865,17 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
         }
     }
     };
-    epilogue(p_late);
+    if constexpr (WIDE) {
+      // a wavefront with nothing to compare has nothing to fit (the neighbour mode's exchange needs all eight)
+      if (wave_active || MODE == MODE_KNN) epilogue(p_late);
+      // every wavefront has read its counts back: the slot returns to the pool
+      __syncthreads();
+      if (threadIdx.x == 0)
+        __hip_atomic_fetch_and(p_late.wide_bitmap + (wide_slot >> 5), ~(1u << (wide_slot & 31u)), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      epilogue(p_late);
+    }
   }
 }
 
@@ -1784,7 +2026,7 @@ int launch_variant(const ppk_db *ref, const ppk_db *qry, const double *d_lut, co
   return PPK_OK;
 }
 
-template <int NW, int MODE, int W>
+template <int NW, int MODE, int W, bool WIDE = false>
 int launch_v2(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const float *d_rtab,
               void *d_out, unsigned long long *d_n_failed, uint64_t *d_mask, DistParams &p,
               hipStream_t s) {
@@ -1821,7 +2063,7 @@ int launch_v2(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const f
   const bool use_clu = p.random_correct && p.n_clu > 1;
   p.r_tiles = (unsigned)(r_tiles ? r_tiles : 1);
   p.q_tiles = (unsigned)(r_tiles ? q_tiles : 0);
-  p.xcd_map = (int)ppk_config().map.load();  // A/B of tile orders; 0 = XCD-contiguous runs (default)
+  p.xcd_map = (int)ppk_config().map.load();  // experiments build: A/B of tile orders; 0 = XCD-contiguous runs
   p.n_strip_pad = (p.n_strip + 7u) & ~7u;
   p.tri_m = V2_RT / V2_QT;
   p.tri_c0 = p.tri_m - (int)p.q_tile0;
@@ -1858,6 +2100,27 @@ int launch_v2(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const f
       PPK_HIP(hipGetLastError());
       return PPK_OK;
     }
+  }
+  if constexpr (WIDE) {
+    // the spill-slot pool (PackWide): a bitmap page + nslots x groups x 128 KB, kept per device
+    p.wide_kpg = 128 / p.cnt_bits;
+    if (const long long force = ppk_config().wide_kpg.load(); force > 0 && force < p.wide_kpg) p.wide_kpg = (int)force;
+    p.wide_groups = (p.nk + p.wide_kpg - 1) / p.wide_kpg;
+    p.wide_nslots = 1024;
+    void *pool = nullptr;
+    const size_t pool_bytes = 4096 + (size_t)p.wide_nslots * (size_t)p.wide_groups * WIDE_GROUP_U64 * 8;
+    int rc = ppk_scratch_get(ref->device, SLOT_WIDE, pool_bytes, &pool);
+    if (rc != PPK_OK) return rc;
+    p.wide_bitmap = static_cast<unsigned *>(pool);
+    p.wide_slots = reinterpret_cast<unsigned long long *>(static_cast<char *>(pool) + 4096);
+    ppk_set_kernel_name("dist_kernel_v2<256x32,lds-dma,wide>");
+    ppk_prof_begin(s);
+    hipLaunchKernelGGL((dist_kernel_v2<NW, MODE, W, false, true>), dim3((unsigned)n_blocks), dim3(NW * 64), 0, s,
+                       ref->d_skT, qry->d_skT, d_lut, use_clu ? ref->d_clu : nullptr, use_clu ? qry->d_clu : nullptr,
+                       d_rtab, d_out, d_n_failed, d_mask, p);
+    ppk_prof_end(s);
+    PPK_HIP(hipGetLastError());
+    return PPK_OK;
   }
   ppk_set_kernel_name("dist_kernel_v2<256x32,lds-dma>");
   ppk_prof_begin(s);
@@ -1911,6 +2174,10 @@ int launch_tiles_packed(const ppk_db *ref, const ppk_db *qry, const double *d_lu
     return launch_variant<8, 4, MODE, u128>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask,
                                             p, s, "dist_kernel<8,4,generic>");
   }
+  // (option "wide_kpg": a narrower window, i.e. the wide path on a k list the register would hold -- tests)
+  const long long force_kpg = ppk_config().wide_kpg.load();
+  if (total_bits > 128 || (force_kpg > 0 && force_kpg < p.nk && !p.k_split))
+    return launch_v2<8, MODE, 4, true>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
   if (total_bits <= 64) return launch_v2<8, MODE, 2>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
   if (total_bits <= 96) return launch_v2<8, MODE, 3>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
   return launch_v2<8, MODE, 4>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
@@ -2036,12 +2303,14 @@ static int launch_dist_band(const ppk_db *ref, const ppk_db *qry_or_null, const 
   if (want_jac)
     return launch_tiles_unpacked<MODE_JACCARD>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
 
-  const bool too_wide = p.nk > PPK_MAX_NK || p.nk * p.cnt_bits > 128;
+  // more than 128 count bits per pair: the tile kernel's WIDE instantiation (bbits = 14); other bbits (never
+  // written by PopPUNK: sketchlib fixes bbits = 14) keep the two-pass counts route for plain distances
+  const bool too_wide = p.nk > PPK_MAX_NK || (p.nk * p.cnt_bits > 128 && p.bbits != 14);
   // Small jobs (up to about one round of pair tiles on the 512 workgroup slots, e.g. 1 000 genomes or a handful
   // of queries): one workgroup per (tile, k) instead of per tile -- nk times the parallelism, a
   // serial chain of s64 blocks instead of nk * s64 -- writing raw counts, then the regression pass.
   bool small = false;
-  if (!too_wide && !d_mask && !knn_args && p.bbits == 14 && p.nk >= 2) {
+  if (!too_wide && p.nk * p.cnt_bits <= 128 && !d_mask && !knn_args && p.bbits == 14 && p.nk >= 2) {
     const size_t rt = (ref->n + V2_RT - 1) / V2_RT, qt = (q_end - q_begin + 31) / 32;
     // default 1 200 tiles at 5 k since the one-launch form (round 4; profiles/r04/ksplit_threshold*.txt: it wins by
     // 10 - 50 % up to 4 000 genomes / 1 125 tiles and ties from there to 1 800 tiles; 215 with the two-pass form)
@@ -2058,7 +2327,7 @@ static int launch_dist_band(const ppk_db *ref, const ppk_db *qry_or_null, const 
     const size_t limit = ks > 0 ? (size_t)ks * 5 / (size_t)p.nk : 0;
     small = (p.self ? rt * qt / 2 + qt : rt * qt) <= limit;
   }
-  if (too_wide && knn_args) return ppk_fail(PPK_ERR_ARG, "neighbours from tiles need nk * count bits <= 128");
+  if (too_wide && knn_args) return ppk_fail(PPK_ERR_ARG, "neighbours from tiles need bbits = 14");
   if (too_wide) {
     // the packed per-pair state does not fit: raw counts to scratch, then a generic regression pass
     int dev = ref->device;

@@ -1534,11 +1534,9 @@ void run_edge_part(EdgePart &p, const int32_t *kmers, const float *random_tbl, s
   size_t step = (mask_words / n_rtiles) / 64 * 64;
   if (step < 64) step = 64;
   {
-    // sketches whose counts need more than 128 bits per pair have no fused path: ppk_dist_edges_dev serves the
+    // sketches the tile kernels cannot fit (ppk_unfused; nothing PopPUNK writes): ppk_dist_edges_dev serves the
     // whole matrix only (through a distance buffer), so the band stays in one piece
-    int bits = 1;
-    while (((size_t)1 << bits) <= p.ref->s64 * 64) ++bits;
-    if (p.ref->nk > PPK_MAX_NK || p.ref->nk * (size_t)bits > 128) step = p.q_end - p.q_begin;
+    if (ppk_unfused(p.ref)) step = p.q_end - p.q_begin;
   }
   // Device buffers of this (device, occurrence) entry: the counters and the edge list.  They are KEPT between
   // calls like the result buffers of ppk_query (g_qbufs; ppk_release_scratch frees them): until round 4 every call

@@ -18,7 +18,7 @@
 
 #include "../../include/ppk.h"
 
-#define PPK_MAX_NK 32          // k-mer lengths per query on the fused fast path
+#define PPK_MAX_NK 128         // k-mer lengths per query (the reference accepts k = 3 .. 101: PopPUNK/__main__.py)
 #define PPK_LANES 64           // wavefront width on CDNA
 #define PPK_NPAD 256           // sample axis padded to a multiple of this
 
@@ -28,6 +28,15 @@ struct ppk_db {
   uint64_t *d_skT;                         // [(k*words + w)*npad + sample]
   uint16_t *d_clu;                         // [npad] or nullptr
 };
+
+// A database whose per-pair counts the tile kernels cannot hold: more k-mer lengths than the fit tables are laid
+// out for, or more than 128 count bits at a bbits other than PopPUNK's 14 (the wide-k tile kernel is built for
+// bbits = 14).  Such sketches take the two-pass counts route: plain distances and whole-matrix edge lists only.
+inline bool ppk_unfused(const ppk_db *db) {
+  int bits = 1;
+  while (((size_t)1 << bits) <= db->s64 * 64) ++bits;
+  return db->nk > PPK_MAX_NK || (db->nk * (size_t)bits > 128 && db->bbits != 14);
+}
 
 // Run-time options ---------------------------------------------------------------
 // Every PPK_* environment knob is read ONCE, when the library is first used (ppk_config()); after
@@ -42,6 +51,7 @@ struct PpkConfig {
   std::atomic<long long> ksplit{1200};           // PPK_KSPLIT: tile-count threshold (at 5 k) of the small-job path
   std::atomic<long long> ksplit_wide{215};      // PPK_KSPLIT_WIDE: the same threshold for sketches whose tiles are not fitted from the LDS table (never above ksplit)
   std::atomic<long long> ksplit_fused{1};       // PPK_KSPLIT_FUSED: small jobs run ONE launch (the last unit of a tile fits it); 0 = counts pass + regression pass
+  std::atomic<long long> wide_kpg{0};           // PPK_WIDE_KPG: k-mer lengths per window of the wide-k tile kernel (0 = as many as 128 bits hold; smaller values send narrower k lists through it: tests)
   std::atomic<long long> ksplit_slices{0};      // PPK_KSPLIT_SLICES: pieces each k is cut into on the small-job path (0 = chosen from the job's size; measurement)
   std::atomic<long long> chunk_rows{8ll << 20};     // PPK_CHUNK_ROWS: rows per device buffer of ppk_query
   std::atomic<long long> prefault_threads{8};   // PPK_PREFAULT_THREADS
@@ -143,7 +153,8 @@ int ppk_launch_assign(const float *d_dist, size_t n_rows, int slope, float x_max
 enum { SLOT_LUT = 0, SLOT_MASK = 1, SLOT_WS = 2, SLOT_ITER_A = 3, SLOT_ITER_B = 4, SLOT_ITER_C = 5,
        SLOT_BOUNDS = 6, SLOT_HOST_IN = 7,      // HOST_IN: the uploaded input of a host-array call
        SLOT_TICKETS = 8,                       // one counter per tile of a k-split job: zero when allocated, left zero by every launch
-       SLOT_COUNT = 9 };
+       SLOT_WIDE = 9,                          // spill-slot pool of the wide-k tile kernel: its first page (the slot bitmap) zero when allocated, left zero by every launch
+       SLOT_COUNT = 10 };
 int ppk_scratch_get(int dev, int slot, size_t bytes, void **out);
 void ppk_lut_commit(int dev, const void *d_lut);
 // Scope of one entry point that uses the scratch of `dev`: holds that device's (recursive) mutex and

@@ -405,7 +405,8 @@ def test_config5_shape_100k_self_fused_boundary_band(big, tbl1):
 @pytest.mark.parametrize("s64,kstep", [(16, 1), (156, 1)])
 def test_many_kmer_lengths_counts_fallback(s64, kstep):
     """--k-step 1 (17 k-mer lengths): 17 x 11 (or 14) count bits > 128, so the packed per-pair
-    state does not fit and the generic counts -> regression path runs; same answers."""
+    state does not fit the count register: the wide-k tile kernel (tests/test_gpu_wide.py) -- until round 5 a
+    generic counts -> regression path; same answers."""
     kmers = np.arange(13, 30, kstep, dtype=np.int32)
     n = 150 if s64 == 16 else 40
     sk, member = synth.make_sketches(n, kmers, sketchsize64=s64, bbits=14, cluster_size=10, seed=6)
@@ -426,8 +427,10 @@ def test_many_kmer_lengths_counts_fallback(s64, kstep):
     x_max, y_max = synth.boundary_for_quantile(dn, 0.2)
     e, _ = engine.dist_edges(db, None, kmers, tbl, slope=2, x_max=x_max, y_max=y_max)
     assert np.array_equal(e.cpu().numpy(), oracle.edge_threshold(dn, 2, x_max, y_max))
-    with pytest.raises(RuntimeError, match="band"):
-        engine.dist_edges(db, None, kmers, tbl, slope=2, x_max=x_max, y_max=y_max, q_begin=0, q_end=n // 2)
+    # ... and of a band (round 5: the wide-k tile kernel; until then a refusal)
+    e1, _ = engine.dist_edges(db, None, kmers, tbl, slope=2, x_max=x_max, y_max=y_max, q_begin=0, q_end=n // 2)
+    e2, _ = engine.dist_edges(db, None, kmers, tbl, slope=2, x_max=x_max, y_max=y_max, q_begin=n // 2, q_end=n)
+    assert np.array_equal(np.concatenate([e1.cpu().numpy(), e2.cpu().numpy()]), e.cpu().numpy())
     db.close()
 
 
