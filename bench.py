@@ -93,6 +93,12 @@ def parse():
                          "JSON line with what has been measured and ends the process (0 = off)")
     ap.add_argument("--collective-timeout", type=float, default=120.0,
                     help="process-group timeout in seconds (a stuck collective raises instead of hanging)")
+    ap.add_argument("--transport", choices=("gather", "peer", "best"), default="best",
+                    help="N > 1: which of the two timed transports `value` is taken from -- the grouped RCCL send/recv "
+                         "gather, the peer stores into rank 0's IPC window, or (default) the faster of the two.  Both "
+                         "are always timed and both figures are always on the line (multi_gpu.gathered, "
+                         "multi_gpu.peer_store); `value_transport` names the one `value` came from, so a scaling curve "
+                         "can be taken on ONE transport")
     ap.add_argument("--even-bands", action="store_true",
                     help="N > 1: keep equal bands (default: re-cut them from measured rates during "
                          "the untimed set-up, so that the root, whose band needs no transfer, takes more)")
@@ -279,7 +285,8 @@ def file_call(sk, kmers, tbl, device, reps=3):
     reference-layout `<db>/<db>.h5` (PopPUNK/web.py:14-61; written here once, untimed), nothing of it loaded or
     resident.  Three states, `reps` calls each, every call split into open (file -> host arrays) / resident
     (upload + re-layout) / query (compute + download into a fresh host array):
-      cold_h5        no sidecar: the native bulk read of the .h5 (ppk_h5_read), which also packs `<db>.ppk`
+      cold_h5        no sidecar: the native bulk read of the .h5 (ppk_h5_read), which also packs the image into the
+                     cache directory (never into the database directory)
       warm_sidecar   the packed sidecar is there: mmap, staged to the GPU from the page cache
       loaded         the same process asks again (poppunk_assign's later batches, --plot-fit re-queries)
     "cold" is the state of the process and of the GPU, not of the page cache (the file was just written)."""
@@ -290,6 +297,8 @@ def file_call(sk, kmers, tbl, device, reps=3):
     names = ["genome_%06d" % i for i in range(n)]
     root = tempfile.mkdtemp(prefix="ppk_bench_db_")
     db = os.path.join(root, "db", "db")
+    os.environ["PPK_SIDECAR_DIR"] = os.path.join(root, "cache")      # (the image's home is the user's cache directory; the bench keeps it with its scratch files)
+    side = h5bulk.sidecar_path(db + ".h5")
     klist = [int(k) for k in kmers]
     try:
         t0 = time.perf_counter()
@@ -299,8 +308,8 @@ def file_call(sk, kmers, tbl, device, reps=3):
 
         def one(state):
             pp_sketchlib.clear_cache()
-            if state == "cold_h5" and os.path.exists(db + ".ppk"):
-                os.unlink(db + ".ppk")
+            if state == "cold_h5" and os.path.exists(side):
+                os.unlink(side)
             with timed_region("file_call." + state):
                 t0 = time.perf_counter()
                 out = pp_sketchlib.queryDatabase(db, db, names, names, klist, True, False, 1, True, device)
@@ -322,7 +331,8 @@ def file_call(sk, kmers, tbl, device, reps=3):
                               query_ms=round(sorted(r["query"] for r in runs)[len(runs) // 2], 3),
                               source=runs[-1]["source"], h5_backend=runs[-1]["backend"])
             res[state]["pairs_per_s"] = pairs / (res[state]["median_ms"] * 1e-3)
-        res["sidecar_bytes"] = os.path.getsize(db + ".ppk") if os.path.exists(db + ".ppk") else 0
+        res["sidecar_bytes"] = os.path.getsize(side) if os.path.exists(side) else 0
+        res["database_dir_untouched"] = sorted(os.listdir(os.path.dirname(db))) == ["db.h5"]
         loaded = []
         with timed_region("file_call.loaded"):
             for _ in range(reps + 2):
@@ -345,6 +355,7 @@ def file_call(sk, kmers, tbl, device, reps=3):
     finally:
         pp_sketchlib.clear_cache()
         shutil.rmtree(root, ignore_errors=True)
+        os.environ.pop("PPK_SIDECAR_DIR", None)
 
 
 def peer_store_leg(args, engine, torch, dist, ref, kmers, tbl, rank, world, gathered, barrier, reduce_max):
@@ -441,9 +452,15 @@ def dist_leg(lib, engine, torch, ref, qry, kmers, tbl, steps, ops_per_pair, what
     return res
 
 
+HBM_STREAM_GBS = 6300.0            # MI355X_MICROARCH.md: the measured streaming ceiling (~6.3 TB/s of the 8 TB/s spec)
+
+
 def kernel2_leg(lib, torch, dist_t, x_max, y_max, steps):
     """Kernel 2 on the resident 10 000-genome matrix: assignThreshold (8 B in + 4 B out per row) and edgeThreshold
-    (8 B in + the mask + 16 B per edge), HIP events on the stream the launches go to (torch's current stream)."""
+    (8 B in + the mask + 16 B per edge), HIP events on the stream the launches go to (torch's current stream).
+    Two figures each: `cold` rotates through four distinct copies of the 400 MB matrix (1.6 GB: no pass finds its
+    input in the 256 MB Infinity Cache -- the figure a real pipeline sees, and the one the roofline fraction is quoted
+    on); `hot` re-runs ONE matrix, part of which every pass is served from that cache."""
     n = dist_t.shape[0]
     dev = dist_t.device
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
@@ -451,43 +468,52 @@ def kernel2_leg(lib, torch, dist_t, x_max, y_max, steps):
     cap = 1 << 22
     edges = torch.empty((cap, 2), dtype=torch.int64, device=dev)
     n_edges = torch.zeros(1, dtype=torch.int64, device=dev)
+    mats = [dist_t] + [dist_t.clone() for _ in range(3)]
 
-    def assign():
-        rc = lib.ppk_assign_threshold_dev(C.c_void_p(dist_t.data_ptr()), n, 2, float(x_max), float(y_max),
+    def assign(m):
+        rc = lib.ppk_assign_threshold_dev(C.c_void_p(m.data_ptr()), n, 2, float(x_max), float(y_max),
                                           C.c_void_p(assign_out.data_ptr()), stream)
         assert rc == 0
 
-    def edge():
-        rc = lib.ppk_edge_threshold_dev(C.c_void_p(dist_t.data_ptr()), n, 0, 2, float(x_max), float(y_max), 1,
+    def edge(m):
+        rc = lib.ppk_edge_threshold_dev(C.c_void_p(m.data_ptr()), n, 0, 2, float(x_max), float(y_max), 1,
                                         C.c_void_p(edges.data_ptr()), cap, C.c_void_p(n_edges.data_ptr()), stream)
         assert rc == 0
 
-    def timed(fn):
-        for _ in range(3):
-            fn()
+    def timed(fn, rotate):
+        for i in range(4):
+            fn(mats[i % 4 if rotate else 0])
         torch.cuda.synchronize()
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-        for a, b in ev:
+        for i, (a, b) in enumerate(ev):
             a.record()
-            fn()
+            fn(mats[i % 4 if rotate else 0])
             b.record()
         torch.cuda.synchronize()
         return [a.elapsed_time(b) for a, b in ev]
 
-    t_a, t_e = timed(assign), timed(edge)
+    def roof(nbytes, ms):
+        gbs = nbytes / ms / 1e6
+        return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_of_measured_stream": round(gbs / HBM_STREAM_GBS, 4)}
+
+    t_a, t_e = timed(assign, True), timed(edge, True)
+    h_a, h_e = timed(assign, False), timed(edge, False)
     m = int(n_edges.item())
-    a_med, e_med = sorted(t_a)[len(t_a) // 2], sorted(t_e)[len(t_e) // 2]
+    med = lambda t: sorted(t)[len(t) // 2]
     a_bytes, e_bytes = 12.0 * n, 8.0 * n + n / 8.0 * 2 + 16.0 * m
+    del mats
     return {"rows": n, "steps": steps,
-            "assign": dict(_stats(t_a), kernel="assign_kernel_x2", kernel_ms=round(a_med, 5), bytes=a_bytes,
-                           roofline={"bound": "hbm", "achieved": round(a_bytes / a_med / 1e6, 1), "peak": HBM_PEAK_GBS,
-                                     "unit": "GB/s", "frac": round(a_bytes / a_med / 1e6 / HBM_PEAK_GBS, 4)}),
-            "edges": dict(_stats(t_e), kernel="mask_from_dist_kernel_x2 + mask_count + scan + mask_expand",
-                          kernel_ms=round(e_med, 5), n_edges=m, bytes=e_bytes,
-                          roofline={"bound": "hbm", "achieved": round(e_bytes / e_med / 1e6, 1), "peak": HBM_PEAK_GBS,
-                                    "unit": "GB/s", "frac": round(e_bytes / e_med / 1e6 / HBM_PEAK_GBS, 4)}),
+            "assign": dict(_stats(t_a), kernel="assign_kernel_x2", kernel_ms=round(med(t_a), 5), bytes=a_bytes,
+                           roofline=roof(a_bytes, med(t_a)),
+                           hot=dict(kernel_ms=round(med(h_a), 5), roofline=roof(a_bytes, med(h_a)))),
+            "edges": dict(_stats(t_e), kernel="mask_from_dist_counted + scan + mask_expand (3 launches)",
+                          kernel_ms=round(med(t_e), 5), n_edges=m, bytes=e_bytes, roofline=roof(e_bytes, med(t_e)),
+                          hot=dict(kernel_ms=round(med(h_e), 5), roofline=roof(e_bytes, med(h_e)))),
             "note": "HIP events (torch.cuda.Event on the stream the launches use) around each call; assign = 12 B "
-                    "per row, edges = 8 B per row read + the bit mask written and read + 16 B per edge"}
+                    "per row, edges = 8 B per row read + the bit mask written and read + 16 B per edge.  The headline "
+                    "figures rotate through four copies of the matrix (cold Infinity Cache); `hot` = the same matrix "
+                    "every pass; frac_of_measured_stream is against the guide's 6.3 TB/s streaming ceiling"}
 
 
 def other_configs(args, lib, engine, torch, synth, ref10k, dist10k, kmers, tbl, local_rank, f, rep):
@@ -501,6 +527,8 @@ def _other_configs(args, lib, engine, torch, synth, ref10k, dist10k, kmers, tbl,
     legs = (("config2", lambda: _config2(lib, engine, torch, synth, kmers, tbl, dev, local_rank)),
             ("config4", lambda: _config4(lib, engine, torch, synth, ref10k, kmers, tbl, dev, local_rank)),
             ("default_sketch", lambda: _default_sketch(lib, engine, torch, synth, kmers, dev, local_rank)),
+            ("wide_k", lambda: _wide_k(lib, engine, torch, synth, dev, local_rank)),
+            ("latency", lambda: _latency(engine, torch, synth, ref10k, kmers, tbl, dev, local_rank)),
             ("kernel2", lambda: _kernel2(lib, torch, synth, dist10k)))
     for name, fn in legs:
         rep.enter(name)
@@ -521,15 +549,114 @@ def _config2(lib, engine, torch, synth, kmers, tbl, dev, local_rank):
         db.close()
 
 
+PCIE_PEAK_GBS = 64.0          # PCIe 5.0 x16, one direction (what one GPU's host link can carry at best)
+
+
+def _db_ptrs(dbs):
+    return (C.c_void_p * len(dbs))(*[d._h.value for d in dbs])
+
+
+def query_dbs_host(lib, ref, qry, kmers, tbl):
+    """ppk_query_dbs on RESIDENT handles: the engine call behind pp_sketchlib.queryDatabase once the databases are
+    loaded (PopPUNK/assign.py:502-510 -> sketchlib.py:584-593): a fresh pageable host array out."""
+    rows = ref.n * (qry.n if qry is not None else 0) if qry is not None else ref.n * (ref.n - 1) // 2
+    out = np.zeros((rows, 2), dtype=np.float32)
+    nf = C.c_ulonglong(0)
+    t32 = np.ascontiguousarray(tbl, dtype=np.float32)
+    rc = lib.ppk_query_dbs(_db_ptrs([ref]), _db_ptrs([qry]) if qry is not None else None, 1,
+                           kmers.ctypes.data_as(C.POINTER(C.c_int32)), t32.ctypes.data_as(C.POINTER(C.c_float)), 1, 1,
+                           C.c_void_p(out.ctypes.data), C.byref(nf))
+    assert rc == 0, rc
+    return out
+
+
 def _config4(lib, engine, torch, synth, ref10k, kmers, tbl, dev, local_rank):
     qry = engine.SketchDB(synth.make_sketches_device(50000, kmers, device=dev, seed=synth.DEFAULT_SEED + 4), 16, 14,
                           device=local_rank)
     try:
-        return dist_leg(lib, engine, torch, ref10k, qry, kmers, tbl, 5, VALU_OPS_PER_PAIR,
-                        "BASELINE config 4 (poppunk_assign): 50 000 queries x the 10 000 resident refs, s=1024, "
-                        "k=13,17,21,25,29, 4 GB of distances left on the device", spin_ms=0.0)
+        res = dist_leg(lib, engine, torch, ref10k, qry, kmers, tbl, 5, VALU_OPS_PER_PAIR,
+                       "BASELINE config 4 (poppunk_assign): 50 000 queries x the 10 000 resident refs, s=1024, "
+                       "k=13,17,21,25,29, 4 GB of distances left on the device", spin_ms=0.0)
+        # ---- the call poppunk_assign really makes (PopPUNK/assign.py:502-510): queryDatabase(self=False) hands the
+        # 50 000 x 10 000 matrix to the HOST -- 4 GB over one PCIe link into a fresh pageable array
+        pairs = ref10k.n * qry.n
+        ts = []
+        with timed_region("config4.host_call"):
+            for _ in range(4):
+                t0 = time.perf_counter()
+                out = query_dbs_host(lib, ref10k, qry, kmers, tbl)
+                ts.append((time.perf_counter() - t0) * 1e3)
+                sample = out[::4999].copy()
+                del out
+        warm = ts[1:]
+        st = _stats(warm)
+        res["host_call"] = dict({"what": "ppk_query_dbs (resident refs and queries) -> a fresh 4 GB host array: median of "
+                                         "%d calls after the first" % len(warm), "first_call_ms": round(ts[0], 2),
+                                 "ms": st["median_ms"], "ms_all": [round(t, 2) for t in warm],
+                                 "pairs_per_s": pairs / (st["median_ms"] * 1e-3), "result_bytes": pairs * 8,
+                                 "pcie_GBs": round(pairs * 8 / st["median_ms"] / 1e6, 2),
+                                 "pcie_frac": round(pairs * 8 / st["median_ms"] / 1e6 / PCIE_PEAK_GBS, 3)}, **st)
+        # ---- ... and the call that makes the matrix unnecessary: distances -> boundary -> (ref, query) edge list on
+        # the device, 16 bytes per EDGE to the host (ppk_query_edges_dbs; PopPUNK/network.py:1411-1418 adds the
+        # query-ref edges to the network).  Boundary through the 2 % quantiles of a sample of the distances.
+        x_max, y_max = synth.boundary_for_quantile(sample, 0.02)
+        te = []
+        with timed_region("config4.edges_host_call"):
+            for _ in range(4):
+                t0 = time.perf_counter()
+                edges, _ = engine.edges_host([ref10k], [qry], kmers, tbl, slope=2, x_max=x_max, y_max=y_max, cap=32 << 20)
+                te.append((time.perf_counter() - t0) * 1e3)
+        se = _stats(te[1:])
+        res["edges_host_call"] = dict({"what": "ppk_query_edges_dbs non-self, slope-2 boundary at the 2 % quantiles: the "
+                                               "matrix never exists, the (ref, n_ref + query) list lands in a fresh host array",
+                                       "first_call_ms": round(te[0], 2), "ms": se["median_ms"],
+                                       "ms_all": [round(t, 2) for t in te[1:]], "n_edges": int(len(edges)),
+                                       "pairs_per_s": pairs / (se["median_ms"] * 1e-3),
+                                       "result_bytes": int(len(edges)) * 16}, **se)
+        return res
     finally:
         qry.close()
+
+
+def _latency(engine, torch, synth, ref10k, kmers, tbl, dev, local_rank):
+    """poppunk_assign with a handful of genomes: Q queries x the 10 000 resident refs as HOST calls (ppk_query_dbs,
+    databases resident, fresh host array), Q = 1 .. 1 000; the device-side call beside it."""
+    from poppunk_amd import _lib
+    lib = _lib.lib()
+    allq = synth.make_sketches_device(1000, kmers, device=dev, seed=synth.DEFAULT_SEED + 9)
+    rows = []
+    for q in (1, 10, 100, 1000):
+        qdb = engine.SketchDB(allq[:q].contiguous(), 16, 14, device=local_rank)
+        try:
+            for _ in range(5):
+                query_dbs_host(lib, ref10k, qdb, kmers, tbl)
+            ts = []
+            with timed_region("latency"):
+                for _ in range(30):
+                    t0 = time.perf_counter()
+                    query_dbs_host(lib, ref10k, qdb, kmers, tbl)
+                    ts.append((time.perf_counter() - t0) * 1e3)
+            out = torch.empty((q * ref10k.n, 2), dtype=torch.float32, device=dev)
+            nf = torch.zeros(1, dtype=torch.int64, device=dev)
+            for _ in range(5):
+                engine.dist(ref10k, qdb, kmers, tbl, out=out, n_failed=nf)
+            torch.cuda.synchronize()
+            td = []
+            for _ in range(30):
+                t0 = time.perf_counter()
+                engine.dist(ref10k, qdb, kmers, tbl, out=out, n_failed=nf)
+                torch.cuda.synchronize()
+                td.append((time.perf_counter() - t0) * 1e3)
+            st = _stats(ts)
+            rows.append({"queries": q, "pairs": q * ref10k.n, "host_call_ms": st["median_ms"], "host_call_min_ms": st["min_ms"],
+                         "host_call_max_ms": st["max_ms"], "device_call_ms": _stats(td)["median_ms"],
+                         "pairs_per_s": q * ref10k.n / (st["median_ms"] * 1e-3)})
+        finally:
+            qdb.close()
+    del allq
+    return {"refs": ref10k.n, "rows": rows,
+            "note": "host_call_ms: ppk_query_dbs, both databases resident, result in a fresh host array (median of 30); "
+                    "device_call_ms: ppk_dist_dev + a device synchronisation, result left on the device"}
 
 
 def _default_sketch(lib, engine, torch, synth, kmers, dev, local_rank):
@@ -542,6 +669,22 @@ def _default_sketch(lib, engine, torch, synth, kmers, dev, local_rank):
         return dist_leg(lib, engine, torch, db, None, kmers, t1, 3, len(kmers) * s64 * 30,
                         "PopPUNK's default sketch size (--sketch-size 10000 -> sketchsize64 = 156, 9 984 bins, "
                         "docs/sketching.rst:78-80): %d genomes self-vs-self, k=13,17,21,25,29" % n, spin_ms=50.0)
+    finally:
+        db.close()
+
+
+def _wide_k(lib, engine, torch, synth, dev, local_rank):
+    # a documented k list that does not fit the 128-bit count register at the default sketch size: k = 6..15
+    # (docs/sketching.rst:123-139, beta-coronaviruses; 10 x 14 count bits) -- the wide-k instantiation of the tile kernel
+    n, s64 = 10000, 156
+    kmers = np.arange(6, 16, dtype=np.int32)
+    db = engine.SketchDB(synth.make_sketches_device(n, kmers, sketchsize64=s64, device=dev, chunk=2048), s64, 14, device=local_rank)
+    t1 = synth.random_match_table(kmers, genome_length=20_000)
+    try:
+        return dist_leg(lib, engine, torch, db, None, kmers, t1, 3, len(kmers) * s64 * 30,
+                        "wide k list at PopPUNK's default sketch size: %d genomes self-vs-self, sketchsize64 = 156, "
+                        "k = 6..15 (10 lengths x 14 count bits > the 128-bit count register: the register windows the k "
+                        "list, full groups parked in spill slots)" % n, spin_ms=50.0)
     finally:
         db.close()
 
@@ -862,13 +1005,23 @@ def build_line(rep):
         value_note = ("the gathered steps did not complete (multi_gpu.error): value is the aggregate of the "
                       "ranks' compute-only steps (HIP events, no collective) and EXCLUDES the gather to rank 0")
     gathered = None
+    took_peer = False
+    value_transport = "none (1 GPU)" if world == 1 else ("gather" if "elapsed" in f else "compute_only (no collective completed)")
     ps = f.get("peer_store")
-    if (world > 1 and isinstance(ps, dict) and ps.get("available") and ps.get("identical_to_gathered")
-            and ms_per_step and ps.get("ms_per_step") and ps["ms_per_step"] < ms_per_step and "elapsed" in f):
-        # both transports were timed over the same K steps between barriers; the line's value is the faster one,
-        # the other stays beside it (multi_gpu.gathered)
-        gathered = {"ms_per_step": ms_per_step, "value": value}
+    want = getattr(args, "transport", "best")
+    if world > 1 and "elapsed" in f:
+        gathered = {"ms_per_step": ms_per_step, "value": value}      # always on the line (multi_gpu.gathered)
+    ps_good = (world > 1 and isinstance(ps, dict) and ps.get("available") and ps.get("identical_to_gathered")
+               and ms_per_step and ps.get("ms_per_step") and "elapsed" in f)
+    if ps_good and want != "gather" and (want == "peer" or ps["ms_per_step"] < ms_per_step):
+        # both transports were timed over the same K steps between barriers; --transport best: the line's value is
+        # the faster one; --transport peer: the peer stores whenever they ran and reproduced the gathered matrix
         ms_per_step, value = ps["ms_per_step"], ps["pairs_per_s"]
+        took_peer = True
+        value_transport = "peer_store"
+    elif world > 1 and want == "peer" and "elapsed" in f:
+        value_note = ((value_note + "; ") if value_note else "") + \
+            "--transport peer asked for the peer-store figure, which is not available (multi_gpu.peer_store): value is the gathered steps'"
     roof = None
     kernel_ms = f.get("kernel_ms")
     if kernel_ms and f.get("per_launch"):
@@ -908,12 +1061,14 @@ def build_line(rep):
                                "on rank 0" % (n, total_pairs),
                    "n_genomes": n, "pairs": total_pairs,
                    "parallelism": ("band-split x%d, every rank's kernel stores its band into rank 0's matrix (IPC window "
-                                   "over xGMI), one barrier per step" % world) if gathered else
+                                   "over xGMI), one barrier per step" % world) if took_peer else
                                   ("band-split x%d (%s bands), %d-chunk pipelined p2p gather to rank 0"
                                    % (world, band_note.split(" ")[0], f.get("chunks", args.chunks or 4)) if world > 1 else "1 GPU")},
+        "value_transport": value_transport,
         "roofline": roof, "cpu_baseline": f.get("cpu"), "host_call": f.get("host_call"),
         "file_call": f.get("file_call"), "config2": f.get("config2"), "config4": f.get("config4"),
-        "default_sketch": f.get("default_sketch"), "kernel2": f.get("kernel2"), "config5": f.get("config5"),
+        "default_sketch": f.get("default_sketch"), "wide_k": f.get("wide_k"), "kernel2": f.get("kernel2"),
+        "latency": f.get("latency"), "config5": f.get("config5"),
         "gc": gc_summary(),
     }
     if world > 1 and line["config5"] is None and f.get("config5_host_call_solo") is not None:
@@ -945,11 +1100,16 @@ def build_line(rep):
                     "only edge lists move" % f.get("chunks", args.chunks or 4)}
         if f.get("chunks_probe_ms"):
             mg["chunks_probe_ms_per_step"] = f["chunks_probe_ms"]
-        mg["peer_store"] = ps
-        if gathered:
-            mg["gathered"] = gathered
+        # both transports, always: what was (or was not) measured for each, whichever `value` came from
+        mg["peer_store"] = ps if ps is not None else {"available": False, "why": "the leg did not run (--no-peer-store, no process group, or an earlier failure)"}
+        mg["gathered"] = gathered if gathered is not None else {"available": False, "why": "the gathered steps did not complete (multi_gpu.error)"}
+        mg["rccl"] = f.get("rccl") or {"backend": None, "world_size": None, "allreduce_of_ones": None,
+                                       "why": "no process group formed (multi_gpu.error)"}
+        mg["transport_requested"] = want
+        if took_peer:
             mg["transport"] = ("value = the peer-store steps (multi_gpu.peer_store: identical matrix, timed like the "
-                               "gathered steps, faster); multi_gpu.gathered = the p2p gather's figure")
+                               "gathered steps%s); multi_gpu.gathered = the p2p gather's figure"
+                               % (", faster" if want == "best" else "; --transport peer"))
             mg["gather_exposed_ms_per_step"] = round(max(gathered["ms_per_step"] - compute_ms, 0.0), 4) if compute_ms else None
         else:
             mg["transport"] = "value = the gathered steps (grouped isend / irecv into rank 0's matrix)"
@@ -1070,6 +1230,23 @@ def run(args, rep, rank, local_rank, world, fake, torch, dist, engine, synth, da
             pg_ok = True
         except Exception as e:
             rep.error("init_process_group", e)
+        if pg_ok:
+            # proof that the backend connected all N ranks: every rank contributes a one ON ITS DEVICE, the sum must be N
+            try:
+                ones = torch.ones(1, dtype=torch.float32, device=dev if backend == "nccl" else "cpu")
+                dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+                f["rccl"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                             "allreduce_of_ones": float(ones.item()),
+                             "devices": "one rank per GPU (cuda:LOCAL_RANK)" if backend == "nccl" else "cpu tensors (%s)" % backend}
+                if backend == "nccl":
+                    try:
+                        f["rccl"]["version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+                    except Exception:
+                        pass
+                if f["rccl"]["allreduce_of_ones"] != float(world):
+                    raise RuntimeError("all-reduce of ones over %d ranks returned %r" % (world, f["rccl"]["allreduce_of_ones"]))
+            except Exception as e:
+                rep.error("rccl_check", e)
     if inject.startswith("isend"):
         after = int(inject.split(":")[1]) if ":" in inject else 0
         real, calls = dist.batch_isend_irecv, [0]

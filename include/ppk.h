@@ -197,8 +197,11 @@ int ppk_dist_edges_dev(const ppk_db *ref, const ppk_db *qry, const int32_t *kmer
  * straight into the root's HBM over its own xGMI link -- no send buffer, no gather, no collective on the data
  * path.  A step is complete on the root once every rank's stream has drained (a barrier).  There is no
  * counterpart in the reference (one process, one device: pp_sketchlib's device_id, PopPUNK/sketchlib.py:536).
- *   ppk_window_alloc : a device allocation of its own (hipMalloc), not from any caching allocator, so that the
- *                      handle covers exactly it; freed by ppk_window_free (not by ppk_release_scratch)
+ *   ppk_window_alloc : a device allocation of its own, FINE-GRAINED (hipExtMallocWithFlags): peers' stores are
+ *                      coherent with the owner's later reads by hardware, not by the timing of a cache flush; not
+ *                      from any caching allocator, so that the handle covers exactly it; freed by ppk_window_free
+ *                      (not by ppk_release_scratch).  UNVERIFIED ACROSS DEVICES: the window has only ever run with
+ *                      both ranks on one GPU (no multi-GPU box was available to the builder)
  *   ppk_window_export: handle of an allocation made by ppk_window_alloc in THIS process
  *   ppk_window_open  : maps another process's allocation for `device` (peer access is enabled by the mapping);
  *                      PPK_ERR_HIP when the two devices cannot reach each other -- the caller then gathers
@@ -605,8 +608,11 @@ int ppk_h5_codon_phased(const ppk_h5 *h);
 /* sketchsize64 / bbits / kmers of EVERY sample, file order: int64 [count], int64 [count], int64 [count][kmers_cap],
  * size_t [count] (number of k-mer lengths stored; 0 = attribute absent) -- the consistency checks of
  * getSketchSize / getKmersFromReferenceDatabase (PopPUNK/sketchlib.py:109-168) in one native pass */
-int ppk_h5_all_params(ppk_h5 *h, int64_t *sketchsize64, int64_t *bbits, int64_t *kmers, size_t kmers_cap,
-                      size_t *n_kmers);
+/* count_cap: rows the arrays hold.  PPK_ERR_CAPACITY when the file lists more samples than that -- also when the
+ * direct reader hands the file to libhdf5 in the middle of the pass and the library's listing (every link) is longer
+ * than the one the arrays were sized from (hard links only): re-list (ppk_h5_count / ppk_h5_names) and call again. */
+int ppk_h5_all_params(ppk_h5 *h, size_t count_cap, int64_t *sketchsize64, int64_t *bbits, int64_t *kmers,
+                      size_t kmers_cap, size_t *n_kmers);
 int ppk_h5_read(ppk_h5 *h, const char *names, size_t n, const int32_t *kmers, size_t nk, size_t words,
                 uint64_t *out, int64_t *lengths, int64_t *missing, double *base_freq, int threads);
 

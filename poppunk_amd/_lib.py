@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "csrc", "libppk_hip.so")
+# PPK_LIBRARY: another build of the same library (the measurement tools load csrc/libppk_hip_exp.so, tools/_exp.py)
+SO_PATH = os.environ.get("PPK_LIBRARY") or os.path.join(_HERE, "csrc", "libppk_hip.so")
 
 OK, ERR_ARG, ERR_HIP, ERR_CAPACITY, ERR_STATE, ERR_INTERRUPTED = 0, 1, 2, 3, 4, 5
 FLAG_RANDOM_CORRECT, FLAG_JACCARD, FLAG_COUNTS = 1, 2, 4
@@ -125,7 +126,7 @@ SIGNATURES = {
     "ppk_h5_names": (C.c_int, [_vp, _vp, _sz, _szp]),
     "ppk_h5_params": (C.c_int, [_vp, C.c_char_p, _szp, _szp, _llp, _sz, _szp]),
     "ppk_h5_codon_phased": (C.c_int, [_vp]),
-    "ppk_h5_all_params": (C.c_int, [_vp, _llp, _llp, _llp, _sz, _szp]),
+    "ppk_h5_all_params": (C.c_int, [_vp, _sz, _llp, _llp, _llp, _sz, _szp]),
     "ppk_h5_read": (C.c_int, [_vp, C.c_char_p, _sz, _i32p, _sz, _sz, _vp, _vp, _vp, _vp, C.c_int]),
 }
 

@@ -47,9 +47,14 @@ struct OptionEntry {
   std::atomic<long long> PpkConfig::*field;
 };
 const OptionEntry kOptions[] = {
+#ifdef PPK_EXPERIMENTS
+    // measured-and-rejected alternatives and the ablation mask: libppk_hip_exp.so only (make experiments)
     {"ablate", "PPK_ABLATE", &PpkConfig::ablate},
     {"map", "PPK_MAP", &PpkConfig::map},
     {"strip", "PPK_STRIP", &PpkConfig::strip},
+    {"edge_list_keep", "PPK_EDGE_LIST_KEEP", &PpkConfig::edge_list_keep},
+#endif
+    {"lds_table", "PPK_LDS_TABLE", &PpkConfig::lds_table},
     {"ksplit", "PPK_KSPLIT", &PpkConfig::ksplit},
     {"ksplit_slices", "PPK_KSPLIT_SLICES", &PpkConfig::ksplit_slices},
     {"wide_kpg", "PPK_WIDE_KPG", &PpkConfig::wide_kpg},
@@ -66,7 +71,6 @@ const OptionEntry kOptions[] = {
     {"host_parts", "PPK_HOST_PARTS", &PpkConfig::host_parts},
     {"host_parts_rows", "PPK_HOST_PARTS_ROWS", &PpkConfig::host_parts_rows},
     {"host_trace", "PPK_HOST_TRACE", &PpkConfig::host_trace},
-    {"edge_list_keep", "PPK_EDGE_LIST_KEEP", &PpkConfig::edge_list_keep},
     {"ext_collision_adjust", "PPK_EXT_COLLISION_ADJUST", &PpkConfig::ext_collision_adjust},
     {"ext_fit_skip", "PPK_EXT_FIT_SKIP", &PpkConfig::ext_fit_skip},
 };
@@ -532,9 +536,19 @@ extern "C" int ppk_window_alloc(int device, size_t bytes, void **d_window) {
   if (!d_window || bytes == 0) return ppk_fail(PPK_ERR_ARG, "window: no size / no output pointer");
   DeviceGuard g(device);
   if (!g.ok) return ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(device));
+  // FINE-GRAINED device memory: peers store into it over xGMI while the owner's kernels read it later.  Those stores
+  // arrive at the owner's memory side, not through its L2s; with a plain (coarse-grained) allocation a line of the
+  // window that an earlier kernel of the owner left in one of its eight L2s could be served stale afterwards -- only
+  // a stream synchronisation and a barrier separate a peer's store from the owner's read, and neither invalidates
+  // anything.  Fine-grained memory is kept coherent at system scope by the hardware (the owner's accesses are
+  // write-through / re-validated), so visibility does not rest on when a cache happens to be flushed.  (Round-4
+  // advisor finding; the window has so far only run with both ranks on ONE GPU)
   void *p = nullptr;
-  hipError_t e = hipMalloc(&p, bytes);
-  if (e != hipSuccess) return ppk_fail(PPK_ERR_HIP, std::string("hipMalloc(window): ") + hipGetErrorString(e));
+  hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return ppk_fail(PPK_ERR_HIP, std::string("hipExtMallocWithFlags(window, fine-grained): ") + hipGetErrorString(e));
+  }
   *d_window = p;
   return PPK_OK;
 }
@@ -982,6 +996,17 @@ extern "C" int ppk_edge_threshold_dev(const float *d_dist, size_t n_rows, size_t
   void *d_mask = nullptr;
   int rc = scratch_get(dev, SLOT_MASK, ppk_mask_words_linear(n_rows) * sizeof(uint64_t) + 8, &d_mask);
   if (rc != PPK_OK) return rc;
+  if ((reinterpret_cast<uintptr_t>(d_dist) & 15) == 0) {
+    // 16-byte loads, and the compaction's counting pass folded into the predicate pass (three launches, not four)
+    void *d_ws = nullptr;
+    const size_t n_words = ppk_mask_words_linear(n_rows);
+    rc = scratch_get(dev, SLOT_WS, ppk_compact_ws_bytes(n_words), &d_ws);
+    if (rc != PPK_OK) return rc;
+    rc = ppk_launch_mask_from_dist_counted(d_dist, n_rows, slope, x_max, y_max, inclusive,
+                                           static_cast<uint64_t *>(d_mask), d_ws, s);
+    if (rc != PPK_OK) return rc;
+    return ppk_launch_compact(static_cast<uint64_t *>(d_mask), n_words, g, d_ws, d_edges, cap, d_n_edges, s, true);
+  }
   rc = ppk_launch_mask_from_dist(d_dist, n_rows, slope, x_max, y_max, inclusive,
                                  static_cast<uint64_t *>(d_mask), s);
   if (rc != PPK_OK) return rc;

@@ -123,6 +123,66 @@ mask_from_dist_kernel_x2(const f32x4 *__restrict__ dist, size_t n_rows, int slop
   }
 }
 
+// The same predicate pass for the edge-list route, with the compaction's first pass folded in: ONE workgroup covers
+// exactly the kWordsPerBlock = 256 mask words (16 384 rows, 128 KB of distances) of one compaction block, so the
+// number of set bits in them -- what mask_count_kernel re-read the whole mask for -- leaves with the words.
+__global__ void __launch_bounds__(kBlock)
+mask_from_dist_counted_kernel(const f32x4 *__restrict__ dist, size_t n_rows, int slope, float x_max, float y_max,
+                              int inclusive, uint64_t *__restrict__ mask, size_t n_words,
+                              unsigned long long *__restrict__ block_sums) {
+  __shared__ unsigned sh[kBlock / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int src_a = (lane >> 1) * 4, src_b = (32 + (lane >> 1)) * 4;
+  const size_t w2_0 = (size_t)blockIdx.x * (kWordsPerBlock / 2);
+  unsigned bits = 0;      // wave-uniform
+  constexpr int kIters = kWordsPerBlock / 2 / (kBlock / 64);      // 32 word pairs per wavefront
+  constexpr int kBatch = 4;      // loads in flight per lane: the pass is a pure stream, latency is hidden by depth
+  for (int it0 = 0; it0 < kIters; it0 += kBatch) {
+    f32x4 d[kBatch];
+#pragma unroll
+    for (int j = 0; j < kBatch; ++j) {
+      const size_t row = (w2_0 + (size_t)(it0 + j) * (kBlock / 64) + wave) * 128 + 2 * (size_t)lane;
+      d[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (row + 1 < n_rows) {
+        d[j] = __builtin_nontemporal_load(dist + (row >> 1));
+      } else if (row < n_rows) {
+        const float2 t = reinterpret_cast<const float2 *>(dist)[row];
+        d[j].x = t.x;
+        d[j].y = t.y;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kBatch; ++j) {
+      const size_t w2 = w2_0 + (size_t)(it0 + j) * (kBlock / 64) + wave;
+      if (2 * w2 >= n_words) break;      // wave-uniform
+      const size_t row = w2 * 128 + 2 * (size_t)lane;
+      int p = 0;
+      if (row < n_rows) {
+        const float s0 = ppk_line_dist(d[j].x, d[j].y, x_max, y_max, slope);
+        p = (inclusive ? (s0 <= 0.0f) : (s0 < 0.0f)) ? 1 : 0;
+      }
+      if (row + 1 < n_rows) {
+        const float s1 = ppk_line_dist(d[j].z, d[j].w, x_max, y_max, slope);
+        p |= (inclusive ? (s1 <= 0.0f) : (s1 < 0.0f)) ? 2 : 0;
+      }
+      const int pa = __builtin_amdgcn_ds_bpermute(src_a, p), pb = __builtin_amdgcn_ds_bpermute(src_b, p);
+      const uint64_t wa = __ballot((pa >> (lane & 1)) & 1), wb = __ballot((pb >> (lane & 1)) & 1);
+      if (lane == 0) {
+        mask[2 * w2] = wa;
+        if (2 * w2 + 1 < n_words) mask[2 * w2 + 1] = wb;
+      }
+      bits += (unsigned)__popcll(wa) + (2 * w2 + 1 < n_words ? (unsigned)__popcll(wb) : 0u);
+    }
+  }
+  if (lane == 0) sh[wave] = bits;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned t = 0;
+    for (int i = 0; i < kBlock / 64; ++i) t += sh[i];
+    block_sums[blockIdx.x] = t;
+  }
+}
+
 __global__ void __launch_bounds__(kBlock)
 mask_from_assign_kernel(const int32_t *__restrict__ assign, size_t n_rows, int within_label,
                         uint64_t *__restrict__ mask, size_t n_words) {
@@ -439,6 +499,20 @@ int ppk_launch_mask_from_dist(const float *d_dist, size_t n_rows, int slope, flo
   return PPK_OK;
 }
 
+// mask + per-block bit counts in one pass (d_ws as for ppk_launch_compact, which is then told the counts exist)
+int ppk_launch_mask_from_dist_counted(const float *d_dist, size_t n_rows, int slope, float x_max, float y_max,
+                                      int inclusive, uint64_t *d_mask, void *d_ws, hipStream_t s) {
+  const size_t n_words = ppk_mask_words_linear(n_rows);
+  if (n_words == 0) return PPK_OK;
+  const size_t nb = (n_words + kWordsPerBlock - 1) / kWordsPerBlock;
+  if (nb > 0x7fffffffull) return ppk_fail(PPK_ERR_ARG, "edge mask too large for one launch");
+  hipLaunchKernelGGL(mask_from_dist_counted_kernel, dim3((unsigned)nb), dim3(kBlock), 0, s,
+                     reinterpret_cast<const f32x4 *>(d_dist), n_rows, slope, x_max, y_max, inclusive, d_mask, n_words,
+                     static_cast<unsigned long long *>(d_ws));
+  PPK_HIP(hipGetLastError());
+  return PPK_OK;
+}
+
 int ppk_launch_mask_from_qc(const float *d_dist, size_t n_rows, int mode, float max_pi, float max_a,
                             uint64_t *d_mask, hipStream_t s) {
   const size_t n_words = ppk_mask_words_linear(n_rows);
@@ -464,7 +538,7 @@ int ppk_launch_mask_from_assign(const int32_t *d_assign, size_t n_rows, int with
 
 int ppk_launch_compact(const uint64_t *d_mask, size_t n_words, const EdgeGeom &g, void *d_ws,
                        long long *d_edges, size_t cap, unsigned long long *d_n_edges,
-                       hipStream_t s) {
+                       hipStream_t s, bool counted) {
   if (n_words == 0) {
     PPK_HIP(hipMemsetAsync(d_n_edges, 0, sizeof(unsigned long long), s));
     return PPK_OK;
@@ -472,8 +546,9 @@ int ppk_launch_compact(const uint64_t *d_mask, size_t n_words, const EdgeGeom &g
   const size_t nb = (n_words + kWordsPerBlock - 1) / kWordsPerBlock;
   if (nb > 0x7fffffffull) return ppk_fail(PPK_ERR_ARG, "edge mask too large for one launch");
   unsigned long long *block_sums = static_cast<unsigned long long *>(d_ws);
-  hipLaunchKernelGGL(mask_count_kernel, dim3((unsigned)nb), dim3(kBlock), 0, s, d_mask, n_words,
-                     block_sums);
+  if (!counted)      // (the mask's producer has left the block counts in d_ws already)
+    hipLaunchKernelGGL(mask_count_kernel, dim3((unsigned)nb), dim3(kBlock), 0, s, d_mask, n_words,
+                       block_sums);
   hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, block_sums, nb, d_n_edges);
   hipLaunchKernelGGL(mask_expand_kernel, dim3((unsigned)nb), dim3(kBlock), 0, s, d_mask, n_words,
                      block_sums, g, reinterpret_cast<longlong2 *>(d_edges), cap);

@@ -160,6 +160,7 @@ struct DistParams {
   unsigned tiles_per_xcd;      // ceil(n_tiles / 8)
   int tri_m, tri_c0;           // self job: ref tile r pairs with clamp(tri_m * r + tri_c0, 0, q_tiles) query tiles
   int knn, knn_col;       // MODE_KNN: neighbours per sample, distance column (0 core, 1 accessory)
+  int lds_table;          // interior tiles fit from the (E, F) table in LDS (option "lds_table"; 0: every tile takes the general statement -- same bits)
   int ablate;             // experiments build only (PPK_ABLATE): 1 skip epilogue, 2 skip compare, 4 skip DMA, 8 skip barriers, 64 skip the (E, F) table copy
   // WIDE instantiation (nk * cnt_bits > 128): the 128-bit count register holds wide_kpg k-mer lengths; when it is
   // full the workgroup parks it in its spill slot (see PackWide) and starts the next group from zero
@@ -1375,7 +1376,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
     size_t cp_tile = 0;      // the tile's one cluster pair: its block of the table (entries)
     if constexpr (LDS_TABLE) {
       interior = p.lut32 && p.nk >= 3 && p.nk <= 5 && p.cnt_bits == 11 && p.lut_kstride == 1025 &&
-                 !strip && !half && !(ablate_l & 32) && r0 + V2_RT <= p.r_limit && q0 >= qb &&
+                 !strip && !half && p.lds_table && r0 + V2_RT <= p.r_limit && q0 >= qb &&
                  q0 + V2_QT <= qe && (!p.self || r0 >= q0 + V2_QT);      // workgroup-uniform
       if constexpr (KS_FUSED) {
         // A k-split job fits ONE tile per workgroup with nothing else on the CU to hide behind, and its tiles
@@ -1385,7 +1386,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
         // fitted like the others and simply not written, and only a REAL pair with a k below the floor sends
         // its wavefront to the general statement.
         interior = p.lut32 && p.nk >= 3 && p.nk <= 5 && p.cnt_bits == 11 && p.lut_kstride == 1025 && !strip &&
-                   !(ablate_l & 32);
+                   p.lds_table;
       }
       if (interior && (ref_clu || qry_clu)) {
         // Several random-match clusters (a real database has ~3, by base composition): the samples of
@@ -2064,6 +2065,7 @@ int launch_v2(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const f
   p.r_tiles = (unsigned)(r_tiles ? r_tiles : 1);
   p.q_tiles = (unsigned)(r_tiles ? q_tiles : 0);
   p.xcd_map = (int)ppk_config().map.load();  // experiments build: A/B of tile orders; 0 = XCD-contiguous runs
+  if (p.k_split || WIDE) p.xcd_map = 0;      // (the alternatives exist in the EXP instantiation only)
   p.n_strip_pad = (p.n_strip + 7u) & ~7u;
   p.tri_m = V2_RT / V2_QT;
   p.tri_c0 = p.tri_m - (int)p.q_tile0;
@@ -2122,6 +2124,19 @@ int launch_v2(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const f
     PPK_HIP(hipGetLastError());
     return PPK_OK;
   }
+#ifdef PPK_EXPERIMENTS
+  // the experiments build (make experiments): `ablate` and the rejected tile orders run their own instantiation
+  if ((p.ablate || p.xcd_map) && !p.k_split) {
+    ppk_set_kernel_name("dist_kernel_v2<256x32,lds-dma,exp>");
+    ppk_prof_begin(s);
+    hipLaunchKernelGGL((dist_kernel_v2<NW, MODE, W, false, false, true>), dim3((unsigned)n_blocks), dim3(NW * 64), 0, s,
+                       ref->d_skT, qry->d_skT, d_lut, use_clu ? ref->d_clu : nullptr, use_clu ? qry->d_clu : nullptr,
+                       d_rtab, d_out, d_n_failed, d_mask, p);
+    ppk_prof_end(s);
+    PPK_HIP(hipGetLastError());
+    return PPK_OK;
+  }
+#endif
   ppk_set_kernel_name("dist_kernel_v2<256x32,lds-dma>");
   ppk_prof_begin(s);
   if (MODE == MODE_COUNTS && NW == 8 && p.k_split) {
@@ -2292,7 +2307,8 @@ static int launch_dist_band(const ppk_db *ref, const ppk_db *qry_or_null, const 
   p.lut32 = (p.lut_total * 16 < ((size_t)1 << 32)) ? 1 : 0;
   p.knn = knn_args ? knn_args[0] : 0;
   p.knn_col = knn_args ? knn_args[1] : 0;
-  p.ablate = (int)ppk_config().ablate.load();
+  p.ablate = (int)ppk_config().ablate.load();      // (only the experiments build can set it)
+  p.lds_table = ppk_config().lds_table.load() != 0 && !(p.ablate & 32) ? 1 : 0;
   p.ext_adjust = ppk_config().ext_collision_adjust.load() ? 1 : 0;
   p.ext_skip = ppk_config().ext_fit_skip.load() ? 1 : 0;
 

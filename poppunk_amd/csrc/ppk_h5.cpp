@@ -127,17 +127,25 @@ static void group_links(const Map &m, uint64_t btree, uint64_t heap, std::vector
   uint64_t hsz = rd(hp + 8, 8), hdata = rd(hp + 24, 8);
   const uint8_t *names = m.at(hdata, hsz);
   // depth-first, children left to right
+  // A crafted file may point every entry of an internal node at the same child: levels must strictly descend
+  // (a child of a level-L node is a level-(L-1) node) and the walk visits at most as many nodes as the file
+  // could hold (a node is at least 24 bytes), so it always ends.
   struct Frame {
     uint64_t addr;
     size_t next;
+    int want_level;      // -1: the root, any level
   };
-  std::vector<Frame> frames{{btree, 0}};
+  std::vector<Frame> frames{{btree, 0, -1}};
+  size_t visited = 0;
+  const size_t max_nodes = limit + 64;
   while (!frames.empty()) {
     if (frames.size() > 32) throw Unsupported{"B-tree too deep"};
     Frame &f = frames.back();
     const uint8_t *n = m.at(f.addr, 24);
     if (memcmp(n, "TREE", 4) != 0 || n[4] != 0) throw Unsupported{"group B-tree node"};
     unsigned level = n[5];
+    if (f.want_level >= 0 && (int)level != f.want_level) throw Unsupported{"B-tree levels do not descend"};
+    if (f.next == 0 && ++visited > max_nodes) throw Unsupported{"B-tree larger than the file can hold"};
     size_t used = rd(n + 6, 2);
     const uint8_t *body = m.at(f.addr + 24, (2 * used + 1) * 8);
     if (f.next >= used) {
@@ -147,9 +155,10 @@ static void group_links(const Map &m, uint64_t btree, uint64_t heap, std::vector
     uint64_t child = rd(body + 8 + 16 * f.next, 8);
     f.next++;
     if (level > 0) {
-      frames.push_back({child, 0});
+      frames.push_back({child, 0, (int)level - 1});
       continue;
     }
+    if (++visited > max_nodes) throw Unsupported{"B-tree larger than the file can hold"};
     const uint8_t *s = m.at(child, 8);
     if (memcmp(s, "SNOD", 4) != 0) throw Unsupported{"symbol table node"};
     size_t nsym = rd(s + 6, 2);
@@ -778,7 +787,10 @@ static bool lib_attr(Hdf5 *L, hid_t obj, const char *name, hid_t type, void *out
   return ok;
 }
 
-static int lib_sample_params(ppk_h5 *h, const char *sample, std::string &err) {
+// The named sample's own parameters, into the caller's variables: nothing is inherited from another sample and
+// nothing cached on the handle is touched (the handle caches the FIRST sample's parameters only, see ppk_h5_params).
+static int lib_sample_params(ppk_h5 *h, const char *sample, size_t *s64, size_t *bbits, std::vector<int64_t> *kmers,
+                             std::string &err) {
   std::lock_guard<std::mutex> g(g_h5_mutex);
   Hdf5 *L = h->lib;
   hid_t grp = L->H5Gopen2(h->top, sample, 0);
@@ -786,14 +798,16 @@ static int lib_sample_params(ppk_h5 *h, const char *sample, std::string &err) {
     err = std::string("sample ") + sample + " not found in sketch database " + h->path;
     return PPK_ERR_ARG;
   }
+  *s64 = *bbits = 0;
+  kmers->clear();
   int64_t v = 0;
-  if (lib_attr(L, grp, "sketchsize64", L->t_i64, &v, 1, nullptr)) h->s64 = (size_t)v;
-  if (lib_attr(L, grp, "bbits", L->t_i64, &v, 1, nullptr)) h->bbits = (size_t)v;
+  if (lib_attr(L, grp, "sketchsize64", L->t_i64, &v, 1, nullptr)) *s64 = (size_t)v;
+  if (lib_attr(L, grp, "bbits", L->t_i64, &v, 1, nullptr)) *bbits = (size_t)v;
   int64_t ks[256];
   size_t got = 0;
-  if (lib_attr(L, grp, "kmers", L->t_i64, ks, 256, &got)) h->kmers.assign(ks, ks + got);
+  if (lib_attr(L, grp, "kmers", L->t_i64, ks, 256, &got)) kmers->assign(ks, ks + got);
   L->H5Gclose(grp);
-  if (h->s64 == 0 || h->bbits == 0) {
+  if (*s64 == 0 || *bbits == 0) {
     err = std::string("sample ") + sample + " of " + h->path + " lacks sketchsize64 / bbits attributes";
     return PPK_ERR_ARG;
   }
@@ -952,16 +966,32 @@ int ppk_h5_names(ppk_h5 *h, char *buf, size_t cap, size_t *need) {
 int ppk_h5_params(ppk_h5 *h, const char *sample, size_t *sketchsize64, size_t *bbits, int64_t *kmers, size_t kmers_cap,
                   size_t *n_kmers) {
   if (!h) return ppk_fail(PPK_ERR_ARG, "ppk_h5_params: bad argument");
-  if (h->backend == 2 && (h->s64 == 0 || sample)) {
-    std::string first;
-    if (!sample) {
-      lib_names(h);
-      if (h->names5.empty()) return ppk_fail(PPK_ERR_ARG, "ppk_h5_params: no samples in " + h->path);
-      first = h->names5[0];
-    }
+  if (h->backend == 2 && sample) {
+    // a named sample: its own parameters, straight to the caller
+    size_t s64 = 0, bb = 0;
+    std::vector<int64_t> ks;
     std::string err;
-    int rc = lib_sample_params(h, sample ? sample : first.c_str(), err);
+    int rc = lib_sample_params(h, sample, &s64, &bb, &ks, err);
     if (rc != PPK_OK) return ppk_fail(rc, "ppk_h5_params: " + err);
+    if (sketchsize64) *sketchsize64 = s64;
+    if (bbits) *bbits = bb;
+    if (n_kmers) *n_kmers = ks.size();
+    if (kmers)
+      for (size_t i = 0; i < ks.size() && i < kmers_cap; i++) kmers[i] = ks[i];
+    return PPK_OK;
+  }
+  if (h->backend == 2 && h->s64 == 0) {
+    // no sample named: the first sample's, cached on the handle
+    lib_names(h);
+    if (h->names5.empty()) return ppk_fail(PPK_ERR_ARG, "ppk_h5_params: no samples in " + h->path);
+    size_t s64 = 0, bb = 0;
+    std::vector<int64_t> ks;
+    std::string err;
+    int rc = lib_sample_params(h, h->names5[0].c_str(), &s64, &bb, &ks, err);
+    if (rc != PPK_OK) return ppk_fail(rc, "ppk_h5_params: " + err);
+    h->s64 = s64;
+    h->bbits = bb;
+    h->kmers = ks;
   }
   if (h->backend == 1 && h->samples.empty()) return ppk_fail(PPK_ERR_ARG, "ppk_h5_params: no samples in " + h->path);
   if (h->backend == 1 && sample) {
@@ -1049,9 +1079,12 @@ const char *ppk_h5_declined(const ppk_h5 *h) { return h ? h->declined.c_str() : 
 
 int ppk_h5_codon_phased(const ppk_h5 *h) { return h ? h->codon_phased : -1; }
 
-int ppk_h5_all_params(ppk_h5 *h, int64_t *sketchsize64, int64_t *bbits, int64_t *kmers, size_t kmers_cap, size_t *n_kmers) {
+int ppk_h5_all_params(ppk_h5 *h, size_t count_cap, int64_t *sketchsize64, int64_t *bbits, int64_t *kmers, size_t kmers_cap,
+                      size_t *n_kmers) {
   if (!h || !sketchsize64 || !bbits || !kmers || !n_kmers) return ppk_fail(PPK_ERR_ARG, "ppk_h5_all_params: bad argument");
   if (h->backend == 1) {
+    if (h->samples.size() > count_cap)
+      return ppk_fail(PPK_ERR_CAPACITY, "ppk_h5_all_params: the arrays hold fewer rows than the file has samples (ppk_h5_count)");
     try {
       std::vector<Msg> msgs;
       for (size_t i = 0; i < h->samples.size(); i++) {
@@ -1082,6 +1115,11 @@ int ppk_h5_all_params(ppk_h5 *h, int64_t *sketchsize64, int64_t *bbits, int64_t 
     }
   }
   lib_names(h);
+  // The caller sized its arrays from ppk_h5_count() -- possibly the direct reader's listing (hard links only), while
+  // the library lists every link: after a hand-over the two counts can differ, and the rows must never outrun the
+  // arrays.  The caller re-lists (ppk_h5_count / ppk_h5_names now answer from the library) and calls again.
+  if (h->names5.size() > count_cap)
+    return ppk_fail(PPK_ERR_CAPACITY, "ppk_h5_all_params: the sample list changed with the reader (re-list and call again)");
   std::lock_guard<std::mutex> g(g_h5_mutex);
   Hdf5 *L = h->lib;
   std::vector<int64_t> ks(4096);

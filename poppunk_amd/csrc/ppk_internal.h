@@ -40,14 +40,19 @@ inline bool ppk_unfused(const ppk_db *db) {
 
 // Run-time options ---------------------------------------------------------------
 // Every PPK_* environment knob is read ONCE, when the library is first used (ppk_config()); after
-// that only ppk_set_option() changes a value.  None of the tuning knobs changes results (`ablate`
-// skips work to time the rest: measurement only, 0 in any real use); the
+// that only ppk_set_option() changes a value.  None of the tuning knobs changes results (the experiments build's
+// `ablate` skips work to time the rest); the
 // two ext_* options select between the readings of pp-sketchlib behaviour that cannot be checked
 // in this tree (DESIGN.md "[EXT] assumptions").
 struct PpkConfig {
+  // -- experiments build only (make -C poppunk_amd/csrc experiments; tools/ab_*.py): the product library has no
+  //    option of these names and always runs the defaults
   std::atomic<long long> ablate{0};             // PPK_ABLATE: skip 1 epilogue, 2 compare, 4 DMA, 8 barriers, 16 first-copy wait, 64 the interior tiles' table copy, 128 stores; 32 LDS-table path off
   std::atomic<long long> map{0};                // PPK_MAP: tile order of dist_kernel_v2 (0 = XCD-contiguous runs)
   std::atomic<long long> strip{1};              // PPK_STRIP: strip tiles for the ragged right edge
+  std::atomic<long long> edge_list_keep{1};     // PPK_EDGE_LIST_KEEP: the fused host edge call keeps its device list buffer between calls (0: allocate + free per call, measurement)
+  // -- product options
+  std::atomic<long long> lds_table{1};          // PPK_LDS_TABLE: interior tiles of the default sketch shape fit from the (E, F) table in LDS (0: the general statement everywhere; same bits)
   std::atomic<long long> ksplit{1200};           // PPK_KSPLIT: tile-count threshold (at 5 k) of the small-job path
   std::atomic<long long> ksplit_wide{215};      // PPK_KSPLIT_WIDE: the same threshold for sketches whose tiles are not fitted from the LDS table (never above ksplit)
   std::atomic<long long> ksplit_fused{1};       // PPK_KSPLIT_FUSED: small jobs run ONE launch (the last unit of a tile fits it); 0 = counts pass + regression pass
@@ -64,7 +69,6 @@ struct PpkConfig {
   std::atomic<long long> knn_list{0};           // PPK_KNN_LIST: entries of the neighbour-candidate list (0 = sized from n and knn)
   std::atomic<long long> host_parts_rows{16 << 20};   // PPK_HOST_PARTS_ROWS: ... from this many rows up
   std::atomic<long long> host_parts{2};         // PPK_HOST_PARTS: worker threads of a one-device host query (>= 16 Mi rows)
-  std::atomic<long long> edge_list_keep{1};     // PPK_EDGE_LIST_KEEP: the fused host edge call keeps its device list buffer between calls (0: allocate + free per call, measurement)
   // [EXT] a4: 0 = the b-bit collision adjustment is never in effect (upstream as recalled: it is
   // gated on expected == 0, where it is the identity); 1 = applied when expected > 0
   std::atomic<long long> ext_collision_adjust{0};
@@ -145,7 +149,9 @@ int ppk_launch_all_tuples(size_t n_entries, size_t num_ref, size_t num_queries, 
                           long long *d_edges, hipStream_t s);
 int ppk_launch_compact(const uint64_t *d_mask, size_t n_words, const EdgeGeom &g, void *d_ws,
                        long long *d_edges, size_t cap, unsigned long long *d_n_edges,
-                       hipStream_t s);
+                       hipStream_t s, bool counted = false);
+int ppk_launch_mask_from_dist_counted(const float *d_dist, size_t n_rows, int slope, float x_max, float y_max,
+                                      int inclusive, uint64_t *d_mask, void *d_ws, hipStream_t s);
 int ppk_launch_assign(const float *d_dist, size_t n_rows, int slope, float x_max, float y_max,
                       float *d_out, hipStream_t s);
 

@@ -11,20 +11,25 @@ behind it:
               call.  The direct reader walks the mmap-ed file's own structures on several threads; files it
               does not recognise go through libhdf5's C API in a native loop.
 
-`<db>.ppk` -- a packed image of the `.h5`'s sketches next to it, written the first time (most of) a
-              database is read and mmap-ed afterwards: the `[n][nk][words]` array is then a zero-copy view
-              of the page cache that `ppk_db_create` stages to the GPU directly.  The image is stamped with
-              the `.h5`'s size and modification time and refused when they differ; it holds ALL samples of
+sidecar    -- a packed image of the `.h5`'s sketches, written the first time (most of) a database is read and
+              mmap-ed afterwards: the `[n][nk][words]` array is then a zero-copy view of the page cache that
+              `ppk_db_create` stages to the GPU directly.  It lives in the USER'S CACHE directory
+              ($PPK_SIDECAR_DIR, else $XDG_CACHE_HOME/poppunk_amd, else ~/.cache/poppunk_amd) under a name made
+              from the database file's real path -- never in the database directory: the reference only ever
+              READS a database it queries (PopPUNK/sketchlib.py:86-88,:124-133), and a drop-in must leave that
+              directory byte for byte as it found it.  The image is stamped with the `.h5`'s size, modification
+              time, inode and a hash of its first 4 KB, and refused when any differs; it holds ALL samples of
               the file (name order) for the k-mer lengths it was made with, the per-sample `length` /
-              `missing_bases` / `base_freq`, and the /random group's raw datasets.  PPK_SIDECAR=0 switches
-              it off (no reads, no writes); a directory that cannot be written to is not an error.
+              `missing_bases` / `base_freq`, and the /random group's raw datasets.  PPK_SIDECAR=0 switches it
+              off (no reads, no writes); a cache directory that cannot be written to is not an error.
 
-    layout (little-endian)   0  magic "PPKSKDB1"      8  u64 body offset (4096-aligned)
+    layout (little-endian)   0  magic "PPKSKDB2"      8  u64 body offset (4096-aligned)
       16 u64 h5 size        24  i64 h5 mtime_ns      32  u64 n          40 u64 nk
       48 u64 sketchsize64   56  u64 bbits            64  u64 names bytes
       72 u64 flags (1: base_freq present for every sample; 2: the .h5 has a /random group)
-      80 u64 random blob bytes (an .npz of the group's raw content)     88 u64 reserved
-      96 int64 kmers[nk] | int64 length[n] | int64 missing_bases[n] | float64 base_freq[n][4]
+      80 u64 random blob bytes (an .npz of the group's raw content)     88 u64 h5 inode
+      96 u64 hash of the h5's first 4 KB
+     104 int64 kmers[nk] | int64 length[n] | int64 missing_bases[n] | float64 base_freq[n][4]
          | names (NUL-terminated, back to back) | random blob       body: uint64 [n][nk][words]
 """
 import ctypes as C
@@ -36,8 +41,8 @@ import numpy as np
 
 from . import _lib
 
-MAGIC = b"PPKSKDB1"
-_HEAD = 96
+MAGIC = b"PPKSKDB2"
+_HEAD = 104
 
 
 class H5Bulk:
@@ -114,16 +119,21 @@ class H5Bulk:
 
     def all_params(self):
         """(sketchsize64 int64 [n], bbits int64 [n], kmers: list of n lists) of every sample, file order."""
-        n = self.count()
-        cap = max(len(self.params()[2]) + 1, 8) if n else 8
-        s64 = np.zeros(n, dtype=np.int64)
-        bb = np.zeros(n, dtype=np.int64)
-        km = np.zeros((n, cap), dtype=np.int64)
-        nk = np.zeros(n, dtype=np.uintp)
         i64 = C.POINTER(C.c_longlong)
-        _lib.check(self._lib.ppk_h5_all_params(self._h, s64.ctypes.data_as(i64), bb.ctypes.data_as(i64),
-                                               km.ctypes.data_as(i64), cap, nk.ctypes.data_as(C.POINTER(C.c_size_t))),
-                   "ppk_h5_all_params")
+        for _ in range(3):
+            n = self.count()
+            cap = max(len(self.params()[2]) + 1, 8) if n else 8
+            s64 = np.zeros(n, dtype=np.int64)
+            bb = np.zeros(n, dtype=np.int64)
+            km = np.zeros((n, cap), dtype=np.int64)
+            nk = np.zeros(n, dtype=np.uintp)
+            rc = self._lib.ppk_h5_all_params(self._h, n, s64.ctypes.data_as(i64), bb.ctypes.data_as(i64),
+                                             km.ctypes.data_as(i64), cap, nk.ctypes.data_as(C.POINTER(C.c_size_t)))
+            if rc != _lib.ERR_CAPACITY:
+                break
+            # the direct reader handed the file to libhdf5 in mid-pass and the library lists more links: size the
+            # arrays again from the new count (names() asks the handle afresh every time: call it AFTER this)
+        _lib.check(rc, "ppk_h5_all_params")
         return s64, bb, km, nk
 
     def read(self, names, klist, words, attributes=True, threads=0):
@@ -173,13 +183,33 @@ def sidecar_enabled():
     return os.environ.get("PPK_SIDECAR", "1") not in ("0", "off", "no")
 
 
+def sidecar_dir():
+    d = os.environ.get("PPK_SIDECAR_DIR")
+    if d:
+        return d
+    base = os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache")
+    return os.path.join(base, "poppunk_amd")
+
+
 def sidecar_path(h5_path):
-    return h5_path[:-3] + ".ppk" if h5_path.endswith(".h5") else h5_path + ".ppk"
+    """Where the image of `h5_path` lives: the cache directory, named by the file's real path."""
+    import hashlib
+    real = os.path.realpath(h5_path)
+    stem = os.path.basename(real)
+    stem = stem[:-3] if stem.endswith(".h5") else stem
+    tag = hashlib.sha256(os.fsencode(real)).hexdigest()[:24]
+    return os.path.join(sidecar_dir(), "%s.%s.ppk" % ("".join(c if c.isalnum() or c in "-_." else "_" for c in stem)[:64], tag))
 
 
 def h5_stamp(h5_path):
+    """(size, mtime_ns, inode, hash of the first 4 KB): the superblock and the root group's first structures sit
+    there, so a file rewritten in place within one mtime tick and to the same length still differs."""
+    import hashlib
     st = os.stat(h5_path)
-    return int(st.st_size), int(st.st_mtime_ns)
+    with open(h5_path, "rb") as f:
+        head = f.read(4096)
+    h = int.from_bytes(hashlib.blake2b(head, digest_size=8).digest(), "little")
+    return int(st.st_size), int(st.st_mtime_ns), int(st.st_ino), h
 
 
 class Sidecar:
@@ -196,7 +226,8 @@ class Sidecar:
         head = np.frombuffer(mm, dtype="<u8", count=12, offset=0)
         body, size, _, n, nk, s64, bbits, nbytes, flags, rbytes = (int(x) for x in head[1:11])
         mtime = int(np.frombuffer(mm, dtype="<i8", count=1, offset=24)[0])
-        if (size, mtime) != tuple(stamp):
+        inode, hhash = (int(x) for x in np.frombuffer(mm, dtype="<u8", count=2, offset=88))
+        if (size, mtime, inode, hhash) != tuple(stamp):
             self.close()
             raise ValueError("stale sketch sidecar")
         words = s64 * bbits
@@ -248,11 +279,15 @@ def sidecar_open(h5_path):
 
 def sidecar_write(h5_path, stamp, names, kmers, sketches, sketchsize64, bbits, lengths, missing, base_freq,
                   has_random, random_raw):
-    """Write `<db>.ppk` atomically (temporary file + rename).  Returns True when it was written; any OSError
-    (read-only directory, full disk) leaves no sidecar and is not an error."""
+    """Write the image atomically (temporary file + rename) into the cache directory.  Returns True when it was
+    written; any OSError (no cache directory to be had, full disk) leaves no sidecar and is not an error."""
     if not sidecar_enabled():
         return False
     path = sidecar_path(h5_path)
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+    except OSError:
+        return False
     n, nk, words = sketches.shape
     blob = ("\0".join(names) + "\0").encode() if n else b""
     rblob = b""
@@ -269,6 +304,7 @@ def sidecar_write(h5_path, stamp, names, kmers, sketches, sketchsize64, bbits, l
     flags = (1 if base_freq is not None else 0) | (2 if has_random else 0)
     head = np.zeros(12, dtype="<u8")
     head[1:11] = [body, stamp[0], 0, n, nk, sketchsize64, bbits, len(blob), flags, len(rblob)]
+    head[11] = stamp[2]
     tmp = "%s.tmp.%d" % (path, os.getpid())
     try:
         with open(tmp, "wb") as f:
@@ -276,6 +312,8 @@ def sidecar_write(h5_path, stamp, names, kmers, sketches, sketchsize64, bbits, l
             f.write(head[1:].tobytes())
             f.seek(24)
             f.write(np.asarray([stamp[1]], dtype="<i8").tobytes())
+            f.seek(96)
+            f.write(np.asarray([stamp[3]], dtype="<u8").tobytes())
             f.seek(_HEAD)
             f.write(np.asarray(kmers, dtype="<i8").tobytes())
             f.write(np.ascontiguousarray(lengths if lengths is not None else np.zeros(n), dtype="<i8").tobytes())

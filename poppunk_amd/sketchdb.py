@@ -320,9 +320,10 @@ def _load_h5(path, names, klist):
         last_load.update(source="h5", backend=f.backend, packed=False, declined=f.declined)
     if not pack:
         return _finish_h5(names, klist, sk, s64, bbits, lengths, freq, raw)
-    have_freq = not np.isnan(freq).any()
+    # (base_freq rows of samples without the attribute are NaN in the image too: whether a request has the
+    # frequencies is decided over the rows it selects, _finish_h5, exactly as on the direct read)
     last_load["packed"] = h5bulk.sidecar_write(path, stamp, want, klist, sk, s64, bbits, lengths, missing,
-                                               freq if have_freq else None, raw is not None, raw)
+                                               freq, raw is not None, raw)
     rows, _ = _pick(path, want, klist, names, klist)
     return _finish_h5(names, klist, _take(sk, rows), s64, bbits, _take(lengths, rows), _take(freq, rows), raw)
 
@@ -349,7 +350,9 @@ def save_h5(db_name, names, kmers, sketches, sketchsize64, bbits, random_table=N
             g.attrs["kmers"] = np.asarray(kmers, dtype=np.int64)
             g.attrs["length"] = np.int64(lengths[i] if lengths is not None else 0)
             g.attrs["missing_bases"] = np.int64(0)
-            g.attrs["base_freq"] = np.asarray(base_freq[i] if base_freq is not None else [0.25] * 4, dtype=np.float64)
+            bf = np.asarray(base_freq[i] if base_freq is not None else [0.25] * 4, dtype=np.float64)
+            if not np.isnan(bf).any():        # a NaN row = a sample that had no base_freq attribute: it gets none
+                g.attrs["base_freq"] = bf
             for j, k in enumerate(kmers):
                 d = g.create_dataset(str(k), data=sketches[i, j])
                 d.attrs["kmer-size"] = np.int64(k)
@@ -442,13 +445,15 @@ def _checked_params(path, dbPrefix, what):
     Returns (sorted kmers of the first sample, its sketchsize64, codon_phased)."""
     from . import h5bulk
     with h5bulk.H5Bulk(path) as f:
-        names = f.names()
-        if not names:
-            if what != "size":
+        if f.count() == 0:
+            # getKmersFromReferenceDatabase returns an empty array for a database without samples
+            # (PopPUNK/sketchlib.py:154-168); only readDBParams turns that into the message and the exit (:188-191)
+            if what == "both":
                 sys.stderr.write("Couldn't find sketches in " + dbPrefix + "\n")
                 sys.exit(1)
             return [], 0, bool(f.codon_phased)
         s64, _, km, nk = f.all_params()
+        names = f.names()          # (after the pass: a reader hand-over inside it changes the listing)
         phased = bool(f.codon_phased)
     first = [int(k) for k in km[0, :int(nk[0])]]
     if what in ("kmers", "both"):

@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # packed sketch images (poppunk_amd/h5bulk.py) go to the user's cache directory: the suite gets its own
+    import tempfile
+    os.environ["XDG_CACHE_HOME"] = tempfile.mkdtemp(prefix="ppk_test_cache_")
+    os.environ.pop("PPK_SIDECAR_DIR", None)
 
 
 @pytest.fixture(scope="session")

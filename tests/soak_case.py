@@ -1,6 +1,6 @@
 """One randomised differential case, GPU path (through the C ABI) vs the CPU oracle -- shared by
 tests/test_gpu_soak.py (the driver's GPU suite runs 600 + a few large ones) and tools/soak.py (the
-builder's longer campaigns): random n / split / bands, nk 2..11, sketchsize64 1..40, bbits in {14 (tile
+builder's longer campaigns): random n / split / bands, nk 2..11 (12..33: the wide-k tile kernel), sketchsize64 1..40, bbits in {14 (tile
 kernel), 8, 16 (generic kernel)}, multi-cluster random tables in random or contiguous runs, related /
 unrelated data, counts / jaccard / distance / fused-edge modes, neighbours from the tiles, both
 settings of the two [EXT] switches (kernel and oracle flipped together).
@@ -20,6 +20,10 @@ def reset_options():
     _lib.set_option("launch_tiles", 8000000)
     _lib.set_option("knn_list", 0)
     _lib.set_option("chunk_rows", 8 << 20)
+    for name, default in (("wide_kpg", 0), ("lds_table", 1), ("ksplit_wide", 215), ("knn_warm", 32), ("knn_cut", 4),
+                          ("host_parts", 2), ("host_parts_rows", 16 << 20), ("prefault_threads", 8), ("db_cache", 1),
+                          ("progress", 1), ("host_trace", 0)):
+        _lib.set_option(name, default)
     oracle.set_ext(0, 0)
 
 
@@ -29,8 +33,11 @@ def soak_case(rng, big=False):
     bbits = int(rng.choice([14, 14, 14, 8, 16]))
     s64 = int(rng.choice([1, 2, 3, 16, 16, 16, 5, 40]))
     nk = int(rng.integers(2, 12))      # count registers of 2, 3 and 4 dwords
-    k0 = int(rng.integers(9, 16))
-    kmers = (k0 + np.arange(nk) * int(rng.integers(1, 5))).astype(np.int32)
+    wide_list = bbits == 14 and rng.integers(0, 5) == 0
+    if wide_list:                      # the wide-k tile kernel: more than 128 count bits per pair
+        nk = int(rng.integers(12, 34))
+    k0 = int(rng.integers(9, 16)) if not wide_list else int(rng.integers(7, 12))
+    kmers = (k0 + np.arange(nk) * (int(rng.integers(1, 5)) if not wide_list else int(rng.integers(1, 3)))).astype(np.int32)
     n = int(rng.integers(2, 1400 if s64 <= 16 else 500))
     if big:        # many ref tiles: the default-shape kernel at scale
         bbits, s64 = 14, 16
@@ -44,6 +51,20 @@ def soak_case(rng, big=False):
     # small jobs: ONE launch (round 4) with every way of cutting a k into pieces, now and then the two-pass path
     _lib.set_option("ksplit_slices", int(rng.choice([0, 0, 1, 2, 4])))
     _lib.set_option("ksplit_fused", int(rng.integers(0, 8) != 0))
+    _lib.set_option("ksplit_wide", int(rng.choice([215, 215, 0, 2000])))
+    # every sixth case windows the count register narrower than it is (the wide-k path on short k lists); now and
+    # then the LDS-table fit of interior tiles is off
+    _lib.set_option("wide_kpg", int(rng.integers(1, 6)) if rng.integers(0, 6) == 0 else 0)
+    _lib.set_option("lds_table", int(rng.integers(0, 6) != 0))
+    # host-call plumbing (never changes results): staged neighbour opening / cuts, worker entries per device, page
+    # pre-touching, the resident-database cache, progress meter and trace on fd 2
+    _lib.set_option("knn_warm", int(rng.choice([32, 32, 0, 4])))
+    _lib.set_option("knn_cut", int(rng.choice([4, 4, 0, 1])))
+    _lib.set_option("host_parts", int(rng.choice([2, 2, 1, 3])))
+    _lib.set_option("host_parts_rows", int(rng.choice([16 << 20, 16 << 20, 1, 5000])))
+    _lib.set_option("prefault_threads", int(rng.choice([8, 8, 0, 3])))
+    _lib.set_option("db_cache", int(rng.integers(0, 4) != 0))
+    _lib.set_option("progress", int(rng.integers(0, 4) != 0))
     # a quarter of the cases run as a very large job would: a few tiles per launch, a short neighbour-candidate
     # list, small pieces in the fused host call
     tiny = rng.integers(0, 4) == 0
@@ -113,10 +134,10 @@ def soak_case(rng, big=False):
             scaled = (got / np.asarray(scale, dtype=np.float32)).astype(np.float32)
             we = oracle.edge_threshold(scaled, slope, x_max, y_max, n_ref=0 if qry is None else nr,
                                        inclusive=inclusive)
-            # counts wider than 128 bits per pair: only the whole matrix has an edge list (documented
-            # limit of the fused path: a band is refused)
+            # counts wider than 128 bits per pair at a bbits other than PopPUNK's 14 (the generic kernel): only the
+            # whole matrix has an edge list (documented limit: a band is refused)
             cnt_bits = int(64 * s64).bit_length()
-            ecuts = cuts if nk * cnt_bits <= 128 else [0, nq]
+            ecuts = cuts if (nk * cnt_bits <= 128 or bbits == 14) else [0, nq]
             fe = [engine.dist_edges(db, dbq, kmers, t_tbl, random_correct=use_tbl, slope=slope, x_max=x_max,
                                     y_max=y_max, scale=scale, inclusive=inclusive, q_begin=a, q_end=b, cap=16)[0]
                   for a, b in zip(ecuts[:-1], ecuts[1:])]
@@ -126,7 +147,7 @@ def soak_case(rng, big=False):
                 msgs.append("fused edges differ (%d vs %d)" % (len(fe), len(we)))
             # the same list as ONE host call (ppk_query_edges): the device listed 1 - 3 times when bands may
             # be cut, too little room now and then (the parked list is fetched)
-            n_ent = int(rng.integers(1, 4)) if nk * cnt_bits <= 128 else 1
+            n_ent = int(rng.integers(1, 4)) if (nk * cnt_bits <= 128 or bbits == 14) else 1
             he, hf = pp_sketchlib.query_edges_arrays(ref, qry, kmers, s64, bbits, slope, x_max, y_max, scale=scale,
                                                      inclusive=inclusive, random_table=t_tbl,
                                                      ref_clusters=rclu if use_tbl else None,
@@ -137,7 +158,7 @@ def soak_case(rng, big=False):
                 msgs.append("host fused edges differ (%d vs %d, %d entries)" % (len(he), len(we), n_ent))
         # neighbours straight from the tiles == get_kNN_distances(longToSquare(.)) of the same distances
         cnt_bits_k = int(64 * s64).bit_length()
-        if qry is None and bbits == 14 and nk * cnt_bits_k <= 128 and nr > 1:
+        if qry is None and bbits == 14 and nr > 1:
             knn = int(rng.integers(1, 33))
             col = int(rng.integers(0, 2))
             gi, gj, gd = engine.knn_from_sketches(db, kmers, t_tbl, knn, dist_col=col, random_correct=use_tbl,
@@ -147,7 +168,7 @@ def soak_case(rng, big=False):
                     and np.array_equal(gd.cpu().numpy(), wd)):
                 msgs.append("kNN from tiles differs (k=%d col=%d)" % (knn, col))
         # ref x query: every ref's nearest queries and every query's nearest refs from one pass over the rectangle
-        if qry is not None and bbits == 14 and nk * cnt_bits_k <= 128:
+        if qry is not None and bbits == 14:
             knn = int(rng.integers(1, 33))
             col = int(rng.integers(0, 2))
             gi, gj, gd = (x.cpu().numpy() for x in engine.knn_ref_query(db, dbq, kmers, t_tbl, knn, dist_col=col,

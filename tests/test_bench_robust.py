@@ -52,6 +52,12 @@ def test_clean_run_prints_the_gathered_value():
     assert sorted(mg["chunks_probe_ms_per_step"]) == ["1", "2", "4", "8"]      # the set-up probed the sub-band counts
     assert d["value"] > 0 and d["ms_per_step"] > 0
     assert abs(sum(mg["band_shares"]) - 1.0) < 1e-3
+    # the scaling run describes itself: the backend really connected both ranks, both transports are on the line
+    # (the FAKE run has no IPC window: the peer-store entry says why), `value` names its transport
+    assert mg["rccl"]["backend"] == "gloo" and mg["rccl"]["world_size"] == 2 and mg["rccl"]["allreduce_of_ones"] == 2.0
+    assert mg["gathered"]["value"] == d["value"] and mg["gathered"]["ms_per_step"] == d["ms_per_step"]
+    assert isinstance(mg["peer_store"], dict) and mg["peer_store"].get("available") is False
+    assert d["value_transport"] == "gather" and mg["transport_requested"] == "best"
 
 
 @pytest.mark.parametrize("inject", ["isend:0", "isend:7", "isend:30", "isend:60"])
@@ -63,6 +69,8 @@ def test_failing_send_recv_still_yields_one_line_with_per_rank_compute(inject):
     mg = _check_common(d)
     assert "injected failure" in mg["error"]
     assert d["value"] > 0 and "EXCLUDES the gather" in d["value_note"]
+    assert d["value_transport"].startswith("compute_only") and mg["gathered"]["available"] is False
+    assert mg["rccl"]["allreduce_of_ones"] == 2.0          # the group itself had formed
     assert d["ms_per_step"] == max(mg["per_rank_compute_only_ms_per_step"])
 
 
@@ -149,8 +157,24 @@ def test_the_line_takes_the_faster_of_the_two_transports_only_when_the_matrices_
     assert d["ms_per_step"] == 2.5 and d["value"] == good["pairs_per_s"]
     assert d["multi_gpu"]["gathered"]["ms_per_step"] == pytest.approx(5.0)
     assert "peer-store" in d["multi_gpu"]["transport"] and "stores its band" in d["config"]["parallelism"]
+    assert d["value_transport"] == "peer_store"
     for ps in (dict(good, identical_to_gathered=False), dict(good, ms_per_step=7.0), {"available": False, "why": "x"}, None):
         d = line(ps)
         assert d["ms_per_step"] == pytest.approx(5.0) and d["value"] == pytest.approx(pairs * 10 / 0.05)
-        assert "gathered" not in d["multi_gpu"] and d["multi_gpu"]["transport"].startswith("value = the gathered")
-        assert d["multi_gpu"]["peer_store"] == ps
+        assert d["multi_gpu"]["gathered"]["ms_per_step"] == pytest.approx(5.0)       # both figures, always
+        assert d["multi_gpu"]["transport"].startswith("value = the gathered") and d["value_transport"] == "gather"
+        if ps is not None:
+            assert d["multi_gpu"]["peer_store"] == ps
+        else:
+            assert d["multi_gpu"]["peer_store"]["available"] is False
+    # one transport for a whole curve: --transport gather never takes the peer figure, --transport peer takes it even
+    # when it is the slower one (and says so when it is missing)
+    args.transport = "gather"
+    d = line(good)
+    assert d["value_transport"] == "gather" and d["ms_per_step"] == pytest.approx(5.0)
+    assert d["multi_gpu"]["peer_store"] == good
+    args.transport = "peer"
+    d = line(dict(good, ms_per_step=7.0, pairs_per_s=pairs / 7e-3))
+    assert d["value_transport"] == "peer_store" and d["ms_per_step"] == 7.0
+    d = line({"available": False, "why": "x"})
+    assert d["value_transport"] == "gather" and "not available" in d["value_note"]

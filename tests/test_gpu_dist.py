@@ -787,9 +787,9 @@ def test_interior_tiles_with_identical_and_unrelated_pairs(tbl1, ppk_option):
     want, wf = oracle.query(ref, qry, KMERS, 16, 14, random_tbl=tbl3, ref_clu=clu[:1024], qry_clu=clu[1024:], threads=8)
     assert gf == wf
     assert np.abs(got - want).max() <= TOL
-    # the interior path off (ablate bit 32): bit-identical results either way
+    # the interior path off (option "lds_table" 0): bit-identical results either way
     a, _ = pp_sketchlib.query_arrays(sk, None, KMERS, 16, 14, tbl1)
-    ppk_option("ablate", 32)
+    ppk_option("lds_table", 0)
     b, _ = pp_sketchlib.query_arrays(sk, None, KMERS, 16, 14, tbl1)
     assert np.array_equal(a, b)
     b3, _ = pp_sketchlib.query_arrays(sk, None, KMERS, 16, 14, tbl3, ref_clusters=clu)
@@ -821,7 +821,7 @@ def test_interior_tiles_with_three_and_four_kmer_lengths(ppk_option, nk):
     assert np.array_equal(gi.cpu().numpy(), wi) and np.array_equal(gj.cpu().numpy(), wj)
     assert np.array_equal(gd.cpu().numpy(), wd)
     db.close()
-    ppk_option("ablate", 32)
+    ppk_option("lds_table", 0)
     b, _ = pp_sketchlib.query_arrays(sk, None, kmers, 16, 14, tbl)
     assert np.array_equal(got, b)
 

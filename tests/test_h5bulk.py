@@ -211,7 +211,14 @@ def test_damaged_files_end_in_an_error_or_the_right_answer_never_a_crash(tmp_pat
 def test_sidecar_is_written_once_used_afterwards_and_refused_when_stale(tmp_path, monkeypatch):
     monkeypatch.delenv("PPK_SIDECAR", raising=False)
     prefix, names, sk, lengths, freq = write_db(tmp_path, "side", 300)
-    h5, ppk = prefix + ".h5", prefix + ".ppk"
+    h5 = prefix + ".h5"
+    ppk = h5bulk.sidecar_path(h5)
+    # the image lives in the user's cache directory (conftest points it at a scratch directory), never next to the
+    # database: what the database directory holds must not change, whatever is read from it
+    assert os.path.dirname(ppk) == os.path.join(os.environ["XDG_CACHE_HOME"], "poppunk_amd")
+    db_dir = os.path.dirname(h5)
+    listing = lambda: sorted((f, os.path.getsize(os.path.join(db_dir, f))) for f in os.listdir(db_dir))
+    before = listing()
     # a request for a small part of the file reads just that and packs nothing
     few = sketchdb.load(prefix, names[:20], KMERS)
     assert np.array_equal(few.sketches, sk[:20]) and sketchdb.last_load["source"] == "h5" and not os.path.exists(ppk)
@@ -227,6 +234,11 @@ def test_sidecar_is_written_once_used_afterwards_and_refused_when_stale(tmp_path
     warm = sketchdb.load(prefix, names, KMERS)
     assert sketchdb.last_load["source"] == "sidecar"
     assert np.array_equal(warm.sketches, sk)
+    assert listing() == before                                              # the database directory is untouched
+    # a hard link / another path to the same file shares nothing by accident: the image is keyed by real path and
+    # stamped with inode + a hash of the file's first 4 KB
+    st = h5bulk.h5_stamp(h5)
+    assert len(st) == 4 and st[2] == os.stat(h5).st_ino
     in_file_order = sketchdb.load(prefix, sorted(names), KMERS)
     assert not in_file_order.sketches.flags.writeable                       # a view of the mapping, no copy
     assert np.array_equal(in_file_order.sketches, sk[np.argsort(names)])
@@ -421,3 +433,55 @@ with h5py.File(sys.argv[2] + "/many.h5", "w") as f:
     assert list(res[1][1]) == [1000 + int(i) for i in order]
     ld = sketchdb.load(str(tmp_path / "many"), names, [13, 29])
     assert np.array_equal(ld.sketches, sk) and sketchdb.last_load["backend"] == 1 and sketchdb.last_load["packed"]
+
+
+def test_group_btree_that_points_at_itself_is_refused_not_walked_forever(tmp_path):
+    """Round-4 advisor finding: B-tree levels need not decrease in a crafted file -- an internal node whose
+    entries all point back at a node of its own level made the listing walk ~2^31 nodes.  The walker now
+    requires child level == parent level - 1 and bounds the nodes it visits by what the file can hold."""
+    import time
+    prefix, names, sk, _, _ = write_db(tmp_path, "loop", 2500, with_random=False)
+    path = prefix + ".h5"
+    blob = bytearray(open(path, "rb").read())
+    # every version-1 group node: "TREE", type 0, level, entries used, left, right siblings, then key / child pairs
+    hits = [i for i in range(0, len(blob) - 24, 8) if blob[i:i + 4] == b"TREE" and blob[i + 4] == 0 and blob[i + 5] > 0]
+    assert hits, "the test database's /sketches B-tree has an internal node"
+    node = hits[0]
+    used = int.from_bytes(blob[node + 6:node + 8], "little")
+    for e in range(used):
+        off = node + 24 + 8 + 16 * e          # child pointer of entry e
+        blob[off:off + 8] = node.to_bytes(8, "little")
+    bad = str(tmp_path / "loop_self.h5")
+    open(bad, "wb").write(bytes(blob))
+    t0 = time.time()
+    with pytest.raises(RuntimeError, match="direct reader|descend|B-tree"):
+        h5bulk.H5Bulk(bad, backend=1).names()
+    assert time.time() - t0 < 5.0
+
+
+def test_empty_database_and_partial_base_freq(tmp_path, capsys):
+    """Round-4 advisor findings: (1) getKmersFromReferenceDatabase of a database without samples returns an empty
+    array -- only readDBParams prints "Couldn't find sketches" and exits (PopPUNK/sketchlib.py:144-168,:188-191);
+    (2) served from the packed image, a request has base frequencies when the samples IT names have them, not
+    only when every sample of the file does."""
+    # (2): 12 samples, two of them without base_freq
+    prefix, names, sk, lengths, freq = write_db(tmp_path, "part", 12, with_random=False)
+    holes = freq.copy()
+    holes[[3, 7]] = np.nan                                           # save_h5 writes no base_freq for a NaN row
+    sketchdb.save_h5(prefix, names, KMERS, sk, 3, 14, lengths=lengths, base_freq=holes)
+    full = sketchdb.load(prefix, names, KMERS)                       # packs the image
+    assert sketchdb.last_load["source"] == "h5" and sketchdb.last_load["packed"] and full.base_freq is None
+    have = [nm for i, nm in enumerate(names) if i not in (3, 7)]
+    warm = sketchdb.load(prefix, have, KMERS)
+    assert sketchdb.last_load["source"] == "sidecar"
+    assert warm.base_freq is not None and np.array_equal(warm.base_freq, freq[[i for i in range(12) if i not in (3, 7)]])
+    assert sketchdb.load(prefix, names[:5], KMERS).base_freq is None   # includes a sample without them
+    # (1)
+    empty = str(tmp_path / "none" / "none")
+    os.makedirs(os.path.dirname(empty))
+    with h5lite.File(empty + ".h5", "w") as f:
+        f.create_group("sketches")
+    assert list(sketchdb.getKmersFromReferenceDatabase(os.path.dirname(empty))) == []
+    with pytest.raises(SystemExit):
+        sketchdb.readDBParams(os.path.dirname(empty))
+    assert "Couldn't find sketches" in capsys.readouterr().err

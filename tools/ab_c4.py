@@ -3,6 +3,7 @@ import os, sys, ctypes as C
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import _exp; _exp.use()      # ablate / map / edge_list_keep: the experiments build
 from poppunk_amd import _lib, engine, synth
 K = np.asarray(synth.DEFAULT_KMERS, dtype=np.int32); T = synth.random_match_table(K)
 lib = _lib.lib()

@@ -11,6 +11,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import _exp; _exp.use()      # ablate / map / edge_list_keep: the experiments build
 from poppunk_amd import _lib, engine, synth  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
