@@ -70,38 +70,41 @@ int ppk_release_scratch(void);
 const char *ppk_version(void); /* replaces pp_sketchlib.version (PopPUNK/sketchlib.py:34) */
 int ppk_device_count(int *n);
 
-/* Run-time options.  Each has a PPK_<NAME> environment variable that is read ONCE, when the
- * library is first used; afterwards only ppk_set_option changes it.
- *   tuning (never change results): "map", "strip", "ksplit", "ksplit_wide", "ksplit_fused", "ksplit_slices" (the
- *     small-job path: DESIGN.md section 3.1 and its options table), "chunk_rows", "prefault_threads",
- *     "db_cache", "progress", "launch_tiles" (pair tiles per kernel launch, at most and by default 8 000 000:
- *     a dispatch holds fewer than 2^32 work-items, so bands of more tiles -- 370 000 genomes against
- *     themselves and up -- go out as several launches), "knn_list" (entries of the neighbour-candidate list of
- *     ppk_knn_sketches_dev, 0 = sized from n and knn: the list is cut back to the best knn per sample whenever
- *     it is half full, so a job of any size runs in a bounded list), "knn_warm" (default 32: a neighbour job of
- *     16 384 rows or more opens with 1/32 of them, cuts the list -- every bound drops from the k-th of one tile's
- *     256 distances to the k-th of a few thousand -- and runs the rest under those bounds: 2 x faster at 100 000
- *     genomes for 10 neighbours; 0 = the opening piece is sized by what the list can take only), "knn_cut" (default 4: such a job cuts its list again whenever
- *     it holds 4 n knn entries -- same time as cutting at half of the room, a tenth of the memory),
- *     "host_parts" (worker threads of a ONE-device host query of >= "host_parts_rows" = 16 Mi rows,
- *     default 2: the device is entered twice, each entry with its own streams and buffers, so that one
- *     download is in flight while the next is being set up) ("chunk_rows": rows per sub-band of a host query;
- *     0 = 8 Mi, and about an eighth of the job, at least 1 Mi, below 16 Mi rows)
- *   measurement only: "edge_list_keep" 0: the fused host edge call (ppk_query_edges*) allocates its device edge list
- *     per call with the round-3 guess of rows / 8 entries and frees it again, instead of keeping a grow-only buffer
- *     per device entry (default 1; tools/stall_hunt.py)
- *   measurement only: "host_trace" 1: a timeline of every host query (launches, page touching, downloads,
- *     ms since the call began) on file descriptor 2
- *   measurement only: "ablate", a bit mask that SKIPS parts of the distance kernel to time the rest
- *     (1 epilogue, 2 compare, 4 DMA, 8 barriers, 16 first-copy wait, 64 the interior tiles' table copy, 128 stores: results are
- *     garbage) or switches a path off (32: the LDS-table epilogue; results unchanged); 0 in any
- *     real use
+/* Run-time options.  Each has a PPK_<NAME> environment variable that is read ONCE, when the library is first
+ * used; afterwards only ppk_set_option changes it.  None changes a result except the two [EXT] switches.  Every one
+ * of them is drawn by the randomised campaign (tests/soak_case.py).
+ *   kernel 1
+ *     "ksplit" (1200), "ksplit_wide" (215)  tile-count threshold (at 5 k) below which a job runs one workgroup per
+ *                       (tile, k) -- the small-job path; the second applies to sketch shapes whose
+ *                       tiles are not fitted from the LDS table; 0 = off
+ *     "ksplit_fused" (1)   small jobs run ONE launch (the tile's last unit fits it); 0 = counts pass + fit pass
+ *     "ksplit_slices" (0)  pieces each k is cut into on the small-job path (0 = from the job's size)
+ *     "lds_table" (1)      interior tiles of the default shape (3-5 k, s = 1024) fit from the (E, F) table in LDS
+ *     "wide_kpg" (0)       k-mer lengths per window of the wide-k tile kernel (0 = as many as 128 count bits hold;
+ *                          a smaller value sends narrower k lists through that kernel)
+ *     "launch_tiles" (8 000 000)  pair tiles per kernel launch: a dispatch holds fewer than 2^32 work-items, so bands
+ *                          of more tiles -- 370 000 genomes against themselves and up -- go out as several launches
+ *   neighbours from tiles
+ *     "knn_list" (0 = sized from n and knn), "knn_warm" (32), "knn_cut" (4)  the candidate list, its staged
+ *                          opening and where it is cut back to the best knn per sample
+ *   host calls
+ *     "chunk_rows" (8 Mi)  rows per sub-band of a host query (about an eighth of the job, at least 1 Mi, below 16 Mi
+ *                          rows); also scales the pieces of the fused host edge call
+ *     "host_parts" (2), "host_parts_rows" (16 Mi)  worker entries of a ONE-device host query of at least that many
+ *                          rows: one download is in flight while the next is being set up
+ *     "prefault_threads" (8)  helper threads that touch the pages of a fresh result array ahead of the downloads
+ *     "db_cache" (1)       ppk_query / ppk_query_edges keep their resident databases and buffers between calls
+ *     "progress" (1)       progress meter of long host calls on file descriptor 2
+ *     "host_trace" (0)     a timeline of every host query (launches, page touching, downloads) on file descriptor 2
  *   [EXT] readings of pp-sketchlib behaviour that this tree cannot verify:
  *     "ext_collision_adjust" 0 (default): the b-bit collision adjustment of calc_intersize is
  *                              never in effect (upstream gates it on expected == 0, as recalled);
  *                            1: applied when expected = nbins >> bbits is > 0
  *     "ext_fit_skip"         0 (default): the regression uses the k-mer lengths before the first
- *                              J < 5/nbins; 1: it skips every such k and keeps the rest */
+ *                              J < 5/nbins; 1: it skips every such k and keeps the rest
+ * Not options of this library: the ablation mask ("ablate"), the rejected tile orders ("map"), "strip" and
+ * "edge_list_keep" exist only in the experiments build (make -C poppunk_amd/csrc experiments ->
+ * libppk_hip_exp.so, loaded by the measurement tools through tools/_exp.py). */
 int ppk_set_option(const char *name, long long value);
 int ppk_get_option(const char *name, long long *value);
 
@@ -383,7 +386,8 @@ int ppk_parked_fetch(long long *out0, long long *out1, long long *out2, size_t c
  * [cap][2], *n_edges the total; with too little room the finished list is parked (on the host) for
  * ppk_parked_fetch, as above.  A device works through its band in pieces whose edge bitmask stays below
  * 2 GiB (option "chunk_rows" scales it), so the job size is bounded by the edge list, not by n^2 bits.
- * Sketches whose k-mer set needs more than 128 count bits (the un-fused path) run on one device only.
+ * Any k list runs here (more than 128 count bits per pair: the wide-k tile kernel); only sketches with a bbits other
+ * than PopPUNK's 14 AND more than 128 count bits -- nothing PopPUNK writes -- keep the band in one piece.
  *   ppk_query_edges_dbs : refs[d] / qrys[d] (qrys NULL = self) = the same database resident on each device
  *   ppk_query_edges     : host sketch arrays as in ppk_query; the resident copies come from (and stay in)
  *                         ppk_query's cache, every word hashed before anything runs */

@@ -994,7 +994,7 @@ extern "C" int ppk_edge_threshold_dev(const float *d_dist, size_t n_rows, size_t
     if (n_rows % n_ref) return ppk_fail(PPK_ERR_ARG, "row count is not a multiple of n_ref");
   }
   void *d_mask = nullptr;
-  int rc = scratch_get(dev, SLOT_MASK, ppk_mask_words_linear(n_rows) * sizeof(uint64_t) + 8, &d_mask);
+  int rc = scratch_get(dev, SLOT_MASK, ppk_mask_words_linear(n_rows) * sizeof(uint64_t) + 16, &d_mask);
   if (rc != PPK_OK) return rc;
   if ((reinterpret_cast<uintptr_t>(d_dist) & 15) == 0) {
     // 16-byte loads, and the compaction's counting pass folded into the predicate pass (three launches, not four)
@@ -1005,6 +1005,7 @@ extern "C" int ppk_edge_threshold_dev(const float *d_dist, size_t n_rows, size_t
     rc = ppk_launch_mask_from_dist_counted(d_dist, n_rows, slope, x_max, y_max, inclusive,
                                            static_cast<uint64_t *>(d_mask), d_ws, s);
     if (rc != PPK_OK) return rc;
+    g.pair_interleaved = 1;
     return ppk_launch_compact(static_cast<uint64_t *>(d_mask), n_words, g, d_ws, d_edges, cap, d_n_edges, s, true);
   }
   rc = ppk_launch_mask_from_dist(d_dist, n_rows, slope, x_max, y_max, inclusive,

@@ -123,63 +123,69 @@ mask_from_dist_kernel_x2(const f32x4 *__restrict__ dist, size_t n_rows, int slop
   }
 }
 
-// The same predicate pass for the edge-list route, with the compaction's first pass folded in: ONE workgroup covers
-// exactly the kWordsPerBlock = 256 mask words (16 384 rows, 128 KB of distances) of one compaction block, so the
-// number of set bits in them -- what mask_count_kernel re-read the whole mask for -- leaves with the words.
+// The predicate pass of the edge-list route (rows in, one bit per row out), with the compaction's first pass folded
+// in: a workgroup covers whole compaction blocks (kWordsPerBlock = 256 mask words, 16 384 rows, 128 KB of distances),
+// so the number of set bits in each -- what mask_count_kernel re-read the whole mask for -- leaves with the words.
+// 16-byte loads: lane l of a wavefront holds rows 2l and 2l+1 of 128 consecutive rows.  The two comparisons ARE the
+// two ballots (v_cmp writes a lane mask), and they are stored as they come -- word A = the even rows, word B = the
+// odd rows of the 128 -- instead of being shuffled into row order here (two ds_bpermute and two more compares per
+// kilobyte read: the pass ran at 5.3 TB/s against the assign pass's 6.7).  mask_expand_kernel, which touches a mask
+// word only to list its few set bits, puts the pair back in row order (EdgeGeom::pair_interleaved).
 __global__ void __launch_bounds__(kBlock)
 mask_from_dist_counted_kernel(const f32x4 *__restrict__ dist, size_t n_rows, int slope, float x_max, float y_max,
                               int inclusive, uint64_t *__restrict__ mask, size_t n_words,
-                              unsigned long long *__restrict__ block_sums) {
+                              unsigned long long *__restrict__ block_sums, size_t n_cblocks, unsigned per) {
   __shared__ unsigned sh[kBlock / 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int src_a = (lane >> 1) * 4, src_b = (32 + (lane >> 1)) * 4;
-  const size_t w2_0 = (size_t)blockIdx.x * (kWordsPerBlock / 2);
-  unsigned bits = 0;      // wave-uniform
-  constexpr int kIters = kWordsPerBlock / 2 / (kBlock / 64);      // 32 word pairs per wavefront
-  constexpr int kBatch = 4;      // loads in flight per lane: the pass is a pure stream, latency is hidden by depth
-  for (int it0 = 0; it0 < kIters; it0 += kBatch) {
-    f32x4 d[kBatch];
+  // `per` consecutive compaction blocks per workgroup, the same number for every workgroup of the grid
+  for (unsigned c = 0; c < per; ++c) {
+    const size_t cb = (size_t)blockIdx.x * per + c;      // workgroup-uniform
+    if (cb >= n_cblocks) break;
+    const size_t w2_0 = cb * (kWordsPerBlock / 2);
+    unsigned bits = 0;      // wave-uniform
+    constexpr int kIters = kWordsPerBlock / 2 / (kBlock / 64);      // 32 word pairs per wavefront
+    constexpr int kBatch = 8;      // loads in flight per lane (tools/ubench_mask.hip: 1 / 2 / 4 / 8 / 16 loads = 91.6 / 78.8 / 70.6 / 67.7 / 188 us; a pure read of the same 400 MB: 62)
+    for (int it0 = 0; it0 < kIters; it0 += kBatch) {
+      f32x4 d[kBatch];
 #pragma unroll
-    for (int j = 0; j < kBatch; ++j) {
-      const size_t row = (w2_0 + (size_t)(it0 + j) * (kBlock / 64) + wave) * 128 + 2 * (size_t)lane;
-      d[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (row + 1 < n_rows) {
-        d[j] = __builtin_nontemporal_load(dist + (row >> 1));
-      } else if (row < n_rows) {
-        const float2 t = reinterpret_cast<const float2 *>(dist)[row];
-        d[j].x = t.x;
-        d[j].y = t.y;
+      for (int j = 0; j < kBatch; ++j) {
+        const size_t row = (w2_0 + (size_t)(it0 + j) * (kBlock / 64) + wave) * 128 + 2 * (size_t)lane;
+        d[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (row + 1 < n_rows) {
+          d[j] = __builtin_nontemporal_load(dist + (row >> 1));
+        } else if (row < n_rows) {
+          const float2 t = reinterpret_cast<const float2 *>(dist)[row];
+          d[j].x = t.x;
+          d[j].y = t.y;
+        }
       }
-    }
 #pragma unroll
-    for (int j = 0; j < kBatch; ++j) {
-      const size_t w2 = w2_0 + (size_t)(it0 + j) * (kBlock / 64) + wave;
-      if (2 * w2 >= n_words) break;      // wave-uniform
-      const size_t row = w2 * 128 + 2 * (size_t)lane;
-      int p = 0;
-      if (row < n_rows) {
+      for (int j = 0; j < kBatch; ++j) {
+        const size_t w2 = w2_0 + (size_t)(it0 + j) * (kBlock / 64) + wave;
+        if (2 * w2 >= n_words) break;      // wave-uniform
+        const size_t row = w2 * 128 + 2 * (size_t)lane;
         const float s0 = ppk_line_dist(d[j].x, d[j].y, x_max, y_max, slope);
-        p = (inclusive ? (s0 <= 0.0f) : (s0 < 0.0f)) ? 1 : 0;
-      }
-      if (row + 1 < n_rows) {
         const float s1 = ppk_line_dist(d[j].z, d[j].w, x_max, y_max, slope);
-        p |= (inclusive ? (s1 <= 0.0f) : (s1 < 0.0f)) ? 2 : 0;
+        const uint64_t wa = __ballot(row < n_rows && (inclusive ? (s0 <= 0.0f) : (s0 < 0.0f)));
+        const uint64_t wb = __ballot(row + 1 < n_rows && (inclusive ? (s1 <= 0.0f) : (s1 < 0.0f)));
+        if (lane == 0) {
+          typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+          u64x2 v;
+          v.x = wa;
+          v.y = wb;
+          *reinterpret_cast<u64x2 *>(mask + 2 * w2) = v;      // (the buffer holds an even number of words)
+        }
+        bits += (unsigned)__popcll(wa) + (unsigned)__popcll(wb);
       }
-      const int pa = __builtin_amdgcn_ds_bpermute(src_a, p), pb = __builtin_amdgcn_ds_bpermute(src_b, p);
-      const uint64_t wa = __ballot((pa >> (lane & 1)) & 1), wb = __ballot((pb >> (lane & 1)) & 1);
-      if (lane == 0) {
-        mask[2 * w2] = wa;
-        if (2 * w2 + 1 < n_words) mask[2 * w2 + 1] = wb;
-      }
-      bits += (unsigned)__popcll(wa) + (2 * w2 + 1 < n_words ? (unsigned)__popcll(wb) : 0u);
     }
-  }
-  if (lane == 0) sh[wave] = bits;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned t = 0;
-    for (int i = 0; i < kBlock / 64; ++i) t += sh[i];
-    block_sums[blockIdx.x] = t;
+    if (lane == 0) sh[wave] = bits;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned t = 0;
+      for (int i = 0; i < kBlock / 64; ++i) t += sh[i];
+      block_sums[cb] = t;
+    }
+    __syncthreads();      // (sh is written again by the next compaction block)
   }
 }
 
@@ -225,33 +231,35 @@ mask_count_kernel(const uint64_t *__restrict__ mask, size_t n_words,
   if (threadIdx.x == 0) block_sums[blockIdx.x] = t;
 }
 
-// Pass 2: exclusive scan of the block sums by ONE workgroup (the array is
-// n_words/2048 long: 38k entries at 100k genomes), total -> *n_edges.
+// Pass 2: exclusive scan of the block sums by ONE workgroup (the array is n_words/256 long: 3 052 entries at 10 000
+// genomes, 305 000 at 100 000), total -> *n_edges.  Every thread sums its run of entries, the runs are scanned with
+// wavefront shuffles (one barrier; the LDS Hillis-Steele scan this replaces took twenty), and written back as offsets.
 __global__ void __launch_bounds__(1024)
 scan_block_sums_kernel(unsigned long long *__restrict__ block_sums, size_t n_blocks,
                        unsigned long long *__restrict__ n_edges) {
-  __shared__ unsigned long long sh[1024];
+  __shared__ unsigned long long wsum[16];
   const size_t per = (n_blocks + 1023) / 1024;
   const size_t b0 = (size_t)threadIdx.x * per;
   const size_t b1 = b0 + per < n_blocks ? b0 + per : n_blocks;
   unsigned long long s = 0;
   for (size_t b = b0; b < b1; ++b) s += block_sums[b];
-  sh[threadIdx.x] = s;
-  __syncthreads();
-  // Hillis-Steele inclusive scan over 1024 partials
-  for (int o = 1; o < 1024; o <<= 1) {
-    unsigned long long v = (threadIdx.x >= (unsigned)o) ? sh[threadIdx.x - o] : 0ull;
-    __syncthreads();
-    sh[threadIdx.x] += v;
-    __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long inc = s;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned long long v = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += v;
   }
-  unsigned long long run = (threadIdx.x == 0) ? 0ull : sh[threadIdx.x - 1];
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  unsigned long long run = inc - s;
+  for (int i = 0; i < wave; ++i) run += wsum[i];
+  if (threadIdx.x == 1023) *n_edges = run + s;
   for (size_t b = b0; b < b1; ++b) {
     const unsigned long long v = block_sums[b];
     block_sums[b] = run;
     run += v;
   }
-  if (threadIdx.x == 1023) *n_edges = sh[1023];
 }
 
 __device__ __forceinline__ size_t cond_row_start(size_t i, size_t n) {
@@ -272,11 +280,32 @@ __device__ __forceinline__ size_t cond_row_idx(size_t k, size_t n) {
 
 // Pass 3: every thread re-counts its 8 words, a block-level exclusive scan gives
 // its output offset, and it writes one (i,j) per set bit -- in row order.
+// SELF_SCAN (masks of up to kSelfScanBlocks compaction blocks -- 8 192 blocks = 134 M rows; the 10 000-genome matrix has
+// 3 052): `block_offsets` still holds the raw block COUNTS and every workgroup sums the ones before it itself (a few
+// coalesced reads of an L2-resident array) instead of a one-workgroup scan kernel running between the two passes -- one
+// launch and its gap less (4.7 + ~1.5 us of a ~90 us call); the last workgroup leaves the total in *n_edges.
+constexpr size_t kSelfScanBlocks = 8192;
+template <bool SELF_SCAN>
 __global__ void __launch_bounds__(kBlock)
 mask_expand_kernel(const uint64_t *__restrict__ mask, size_t n_words,
                    const unsigned long long *__restrict__ block_offsets, EdgeGeom g,
-                   longlong2 *__restrict__ edges, size_t cap) {
+                   longlong2 *__restrict__ edges, size_t cap, unsigned long long *__restrict__ n_edges) {
   __shared__ unsigned sh_wave[kBlock / 64];
+  __shared__ unsigned long long sh_pre[kBlock / 64];
+  unsigned long long block_off = 0;
+  if constexpr (SELF_SCAN) {
+    unsigned long long part = 0;
+    for (size_t b = threadIdx.x; b < blockIdx.x; b += kBlock) part += block_offsets[b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
+    if ((threadIdx.x & 63) == 0) sh_pre[threadIdx.x >> 6] = part;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kBlock / 64; ++i) block_off += sh_pre[i];
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n_edges = block_off + block_offsets[blockIdx.x];
+  } else {
+    block_off = block_offsets[blockIdx.x];
+  }
   const size_t w0 = ((size_t)blockIdx.x * kBlock + threadIdx.x) * kWordsPerThread;
   uint64_t m[kWordsPerThread];
   unsigned c = 0;
@@ -284,6 +313,13 @@ mask_expand_kernel(const uint64_t *__restrict__ mask, size_t n_words,
   for (int i = 0; i < kWordsPerThread; ++i) {
     const size_t w = w0 + i;
     m[i] = (w < n_words) ? mask[w] : 0ull;
+    if (g.pair_interleaved && w < n_words) {
+      // words (w & ~1, w | 1) = (even rows, odd rows) of 128 consecutive rows: word w in row order is one half of
+      // each, bit by bit alternating
+      const uint64_t a = mask[w & ~(size_t)1], b = mask[w | 1];
+      const uint32_t a32 = (w & 1) ? (uint32_t)(a >> 32) : (uint32_t)a, b32 = (w & 1) ? (uint32_t)(b >> 32) : (uint32_t)b;
+      m[i] = spread_even(a32) | (spread_even(b32) << 1);
+    }
     c += __popcll(m[i]);
   }
   // exclusive scan of c over the block: wave scan + wave totals
@@ -297,7 +333,7 @@ mask_expand_kernel(const uint64_t *__restrict__ mask, size_t n_words,
   __syncthreads();
   unsigned wave_off = 0;
   for (int i = 0; i < wave; ++i) wave_off += sh_wave[i];
-  size_t pos = (size_t)block_offsets[blockIdx.x] + wave_off + (inc - c);
+  size_t pos = (size_t)block_off + wave_off + (inc - c);
   if (c == 0) return;
 
 #pragma unroll
@@ -506,9 +542,11 @@ int ppk_launch_mask_from_dist_counted(const float *d_dist, size_t n_rows, int sl
   if (n_words == 0) return PPK_OK;
   const size_t nb = (n_words + kWordsPerBlock - 1) / kWordsPerBlock;
   if (nb > 0x7fffffffull) return ppk_fail(PPK_ERR_ARG, "edge mask too large for one launch");
-  hipLaunchKernelGGL(mask_from_dist_counted_kernel, dim3((unsigned)nb), dim3(kBlock), 0, s,
+  const size_t slots = 256 * 8;      // workgroups of 256 threads the device holds at once
+  const unsigned per = (unsigned)((nb + slots - 1) / slots);
+  hipLaunchKernelGGL(mask_from_dist_counted_kernel, dim3((unsigned)((nb + per - 1) / per)), dim3(kBlock), 0, s,
                      reinterpret_cast<const f32x4 *>(d_dist), n_rows, slope, x_max, y_max, inclusive, d_mask, n_words,
-                     static_cast<unsigned long long *>(d_ws));
+                     static_cast<unsigned long long *>(d_ws), nb, per);
   PPK_HIP(hipGetLastError());
   return PPK_OK;
 }
@@ -549,9 +587,14 @@ int ppk_launch_compact(const uint64_t *d_mask, size_t n_words, const EdgeGeom &g
   if (!counted)      // (the mask's producer has left the block counts in d_ws already)
     hipLaunchKernelGGL(mask_count_kernel, dim3((unsigned)nb), dim3(kBlock), 0, s, d_mask, n_words,
                        block_sums);
-  hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, block_sums, nb, d_n_edges);
-  hipLaunchKernelGGL(mask_expand_kernel, dim3((unsigned)nb), dim3(kBlock), 0, s, d_mask, n_words,
-                     block_sums, g, reinterpret_cast<longlong2 *>(d_edges), cap);
+  if (nb <= kSelfScanBlocks) {
+    hipLaunchKernelGGL(mask_expand_kernel<true>, dim3((unsigned)nb), dim3(kBlock), 0, s, d_mask, n_words,
+                       block_sums, g, reinterpret_cast<longlong2 *>(d_edges), cap, d_n_edges);
+  } else {
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, block_sums, nb, d_n_edges);
+    hipLaunchKernelGGL(mask_expand_kernel<false>, dim3((unsigned)nb), dim3(kBlock), 0, s, d_mask, n_words,
+                       block_sums, g, reinterpret_cast<longlong2 *>(d_edges), cap, d_n_edges);
+  }
   PPK_HIP(hipGetLastError());
   return PPK_OK;
 }

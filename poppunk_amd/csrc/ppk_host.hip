@@ -1502,10 +1502,19 @@ struct EdgePart {
   int device = 0, dup = 0;
   const ppk_db *ref = nullptr, *qry = nullptr;
   size_t q_begin = 0, q_end = 0;
-  std::vector<long long> edges;      // (i, j) pairs of this band, on the host
+  // The band's list, in row order: `spill` (host; normally empty) followed by the first n_dev entries of the entry's
+  // kept device buffer.  The list STAYS on the device until every entry's count is known: it then goes straight to
+  // its place in the caller's array (until round 5 it went piece by piece into a growing host vector -- value-
+  // initialised, faulted in page by page, filled through the runtime's pageable path -- and from there into the
+  // caller's array: 60 ms of an 89 ms call at 10 M edges).
+  std::vector<long long> spill;
+  long long *d_list = nullptr;
+  size_t n_dev = 0;
+  hipStream_t s = nullptr;
   unsigned long long failed = 0;
   int rc = PPK_OK;
   std::string err;
+  size_t count() const { return spill.size() / 2 + n_dev; }
 };
 
 void run_edge_part(EdgePart &p, const int32_t *kmers, const float *random_tbl, size_t n_clu, int flags, int slope,
@@ -1523,6 +1532,7 @@ void run_edge_part(EdgePart &p, const int32_t *kmers, const float *random_tbl, s
   int rc = part_streams(p.device, p.dup, ws);
   if (rc != PPK_OK) return fail(rc);
   hipStream_t s = ws[0];
+  p.s = s;
   const size_t n_qry = p.qry ? p.qry->n : 0;
   if (ppk_rows_in_band(p.ref->n, n_qry, p.q_begin, p.q_end) == 0) return;
   // the band in pieces whose edge bitmask (one bit per pair) stays below 2 GiB: 100 000 genomes are one piece,
@@ -1533,88 +1543,83 @@ void run_edge_part(EdgePart &p, const int32_t *kmers, const float *random_tbl, s
     mask_words = (size_t)cr * 32;                                      // 8 Mi rows (default) <-> 2^28 words
   size_t step = (mask_words / n_rtiles) / 64 * 64;
   if (step < 64) step = 64;
-  {
-    // sketches the tile kernels cannot fit (ppk_unfused; nothing PopPUNK writes): ppk_dist_edges_dev serves the
-    // whole matrix only (through a distance buffer), so the band stays in one piece
-    if (ppk_unfused(p.ref)) step = p.q_end - p.q_begin;
-  }
+  // sketches the tile kernels cannot fit (ppk_unfused; nothing PopPUNK writes): ppk_dist_edges_dev serves the
+  // whole matrix only (through a distance buffer), so the band stays in one piece
+  if (ppk_unfused(p.ref)) step = p.q_end - p.q_begin;
   // Device buffers of this (device, occurrence) entry: the counters and the edge list.  They are KEPT between
   // calls like the result buffers of ppk_query (g_qbufs; ppk_release_scratch frees them): until round 4 every call
   // allocated a list of rows / 8 entries -- 10 GB at 100 000 genomes -- and freed it again, and a hipMalloc /
-  // hipFree pair of that size costs anything between a few and several hundred milliseconds on a fresh box (the
-  // 801 ms call among 271 ms ones of BENCH_r03's config5.host_call).  The first guess is one edge per 64 pairs
-  // (at least 1 Mi entries); a denser list re-runs its piece once with the exact size, and the buffer then
-  // stays that large.  Option "edge_list_keep" 0 restores allocate-and-free per call with the old guess
-  // (measurement: tools/stall_hunt.py).
-  const bool keep = ppk_config().edge_list_keep.load() != 0;
+  // hipFree pair of that size costs anything between a few and several hundred milliseconds on a fresh box.  A
+  // piece is first offered the room that is left (at least one edge per 64 pairs, 1 Mi entries); a piece that does
+  // not fit runs once more with the exact size in a buffer that then stays that large.
   QueryBufs &qb = g_qbufs[p.device][p.dup];
-  unsigned long long *d_cnt = nullptr;      // [0] edges, [1] failed fits
-  long long *d_edges = nullptr;
-  size_t cap = 0;
-  auto done = [&](int code) {
-    if (!keep) {
-      if (d_edges) (void)hipFree(d_edges);
-      if (d_cnt) (void)hipFree(d_cnt);
-    }
-    if (code != PPK_OK) fail(code);
-  };
-  if (keep) {
-    if (!qb.d_cnt2 && hipMalloc(reinterpret_cast<void **>(&qb.d_cnt2), 16) != hipSuccess)
-      return done(ppk_fail(PPK_ERR_HIP, "hipMalloc failed"));
-    d_cnt = qb.d_cnt2;
-    d_edges = static_cast<long long *>(qb.buf[0]);
-    cap = qb.bytes[0] / 16;
-  } else if (hipMalloc(reinterpret_cast<void **>(&d_cnt), 16) != hipSuccess)
-    return done(ppk_fail(PPK_ERR_HIP, "hipMalloc failed"));
-  const size_t guess_div = keep ? 64 : 8;
+  if (!qb.d_cnt2 && hipMalloc(reinterpret_cast<void **>(&qb.d_cnt2), 16) != hipSuccess)
+    return fail(ppk_fail(PPK_ERR_HIP, "hipMalloc failed"));
+  unsigned long long *d_cnt = qb.d_cnt2;      // [0] edges, [1] failed fits
+  long long *d_edges = static_cast<long long *>(qb.buf[0]);
+  size_t cap = qb.bytes[0] / 16, acc = 0;      // entries the buffer holds / entries of this band already in it
   for (size_t lo = p.q_begin; lo < p.q_end;) {
     const size_t hi = lo + step < p.q_end ? lo + step : p.q_end;
     const size_t rows = ppk_rows_in_band(p.ref->n, n_qry, lo, hi);
-    size_t want = rows / guess_div > ((size_t)1 << 20) ? rows / guess_div : ((size_t)1 << 20);
+    size_t want = rows / 64 > ((size_t)1 << 20) ? rows / 64 : ((size_t)1 << 20);
     if (want > rows) want = rows;
     bool fits = rows == 0;
     for (int attempt = 0; attempt < 2 && !fits; ++attempt) {
-      if (want > cap) {                     // the list buffer only grows, piece after piece and call after call
-        g_trace.mark(p.dup, "e_alloc", (long long)want);
-        if (keep) {
-          void *b = nullptr;
-          if ((rc = query_buf(p.device, p.dup, 0, want * 16, &b)) != PPK_OK) return done(rc);
-          d_edges = static_cast<long long *>(b);
-        } else {
-          if (d_edges) (void)hipFree(d_edges);
-          d_edges = nullptr;
-          cap = 0;
-          if (hipMalloc(reinterpret_cast<void **>(&d_edges), want * 16) != hipSuccess)
-            return done(ppk_fail(PPK_ERR_HIP, "hipMalloc(edge list) failed"));
+      if (acc + want > cap && (attempt == 1 || cap - acc < want / 4 || cap == 0)) {
+        // no room behind what the band has gathered so far: that part goes to the host (rare: the buffer has
+        // normally grown to the job's size by an earlier call), and the buffer grows if the piece alone needs it
+        if (acc) {
+          const size_t at = p.spill.size();
+          p.spill.resize(at + acc * 2);
+          if (hipMemcpy(p.spill.data() + at, d_edges, acc * 16, hipMemcpyDeviceToHost) != hipSuccess)
+            return fail(ppk_fail(PPK_ERR_HIP, "hipMemcpy D2H failed"));
+          g_trace.mark(p.dup, "e_spilled", (long long)acc);
+          acc = 0;
         }
-        cap = want;
-        g_trace.mark(p.dup, "e_alloc_done", (long long)want);
+        if (want > cap) {
+          g_trace.mark(p.dup, "e_alloc", (long long)want);
+          void *b = nullptr;
+          if ((rc = query_buf(p.device, p.dup, 0, want * 16, &b)) != PPK_OK) return fail(rc);
+          d_edges = static_cast<long long *>(b);
+          cap = want;
+          g_trace.mark(p.dup, "e_alloc_done", (long long)want);
+        }
       }
-      if (hipMemsetAsync(d_cnt, 0, 16, s) != hipSuccess) return done(ppk_fail(PPK_ERR_HIP, "hipMemset failed"));
+      const size_t room = cap - acc;
+      if (hipMemsetAsync(d_cnt, 0, 16, s) != hipSuccess) return fail(ppk_fail(PPK_ERR_HIP, "hipMemset failed"));
       rc = ppk_dist_edges_dev(p.ref, p.qry, kmers, random_tbl, n_clu, flags, lo, hi, slope, x_max, y_max, scale_x,
-                              scale_y, inclusive, d_edges, cap, d_cnt, d_cnt + 1, s);
-      if (rc != PPK_OK) return done(rc);
+                              scale_y, inclusive, d_edges + 2 * acc, room, d_cnt, d_cnt + 1, s);
+      if (rc != PPK_OK) return fail(rc);
       g_trace.mark(p.dup, "e_launched", (long long)lo);
       unsigned long long h[2] = {0, 0};
       if (hipMemcpyAsync(h, d_cnt, 16, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
-        return done(ppk_fail(PPK_ERR_HIP, "kernel execution failed (fused edge list)"));
+        return fail(ppk_fail(PPK_ERR_HIP, "kernel execution failed (fused edge list)"));
       g_trace.mark(p.dup, "e_counted", (long long)h[0]);
-      if (h[0] <= cap) {
-        const size_t at = p.edges.size();
-        p.edges.resize(at + (size_t)h[0] * 2);
+      if (h[0] <= room) {
+        acc += (size_t)h[0];
         p.failed += h[1];
-        if (h[0] && hipMemcpy(p.edges.data() + at, d_edges, (size_t)h[0] * 16, hipMemcpyDeviceToHost) != hipSuccess)
-          return done(ppk_fail(PPK_ERR_HIP, "hipMemcpy D2H failed"));
-        g_trace.mark(p.dup, "e_downloaded", (long long)h[0]);
         fits = true;
       } else {
-        want = (size_t)h[0];                // the guess was too small: once more with the exact size
+        want = (size_t)h[0];                // too little room: once more, with the exact size to itself
       }
     }
-    if (!fits) return done(ppk_fail(PPK_ERR_STATE, "internal: the edge count grew between two passes"));
+    if (!fits) return fail(ppk_fail(PPK_ERR_STATE, "internal: the edge count grew between two passes"));
     lo = hi;
   }
-  done(PPK_OK);
+  p.d_list = d_edges;
+  p.n_dev = acc;
+}
+
+// a finished band's list -> `dst` (room for p.count() entries): the spilled part, then the device part
+int fetch_edge_part(const EdgePart &p, long long *dst) {
+  if (!p.spill.empty()) memcpy(dst, p.spill.data(), p.spill.size() * sizeof(long long));
+  if (p.n_dev) {
+    DeviceGuard g(p.device);
+    if (!g.ok) return ppk_fail(PPK_ERR_HIP, "cannot select device " + std::to_string(p.device));
+    if (hipMemcpy(dst + p.spill.size(), p.d_list, p.n_dev * 16, hipMemcpyDeviceToHost) != hipSuccess)
+      return ppk_fail(PPK_ERR_HIP, "hipMemcpy D2H failed");
+  }
+  return PPK_OK;
 }
 }  // namespace
 
@@ -1667,7 +1672,7 @@ int query_edges_dbs_locked(const ppk_db *const *refs, const ppk_db *const *qrys,
   size_t total = 0;
   for (EdgePart &p : parts) {
     if (p.rc != PPK_OK) return ppk_fail(p.rc, p.err);
-    total += p.edges.size() / 2;
+    total += p.count();
     if (n_failed) *n_failed += p.failed;
   }
   *n_edges = total;
@@ -1677,17 +1682,39 @@ int query_edges_dbs_locked(const ppk_db *const *refs, const ppk_db *const *qrys,
     ParkedResult r;
     r.arrays = 1;
     r.n = total;
-    r.host.reserve(total * 2);
-    for (EdgePart &p : parts) r.host.insert(r.host.end(), p.edges.begin(), p.edges.end());
+    r.host.resize(total * 2);
+    size_t off = 0;
+    for (EdgePart &p : parts) {
+      if ((rc = fetch_edge_part(p, r.host.data() + off)) != PPK_OK) return rc;
+      off += p.count() * 2;
+    }
     parked_put(std::move(r));
     return ppk_fail(PPK_ERR_CAPACITY, "output too small: need " + std::to_string(total) + " entries (parked: ppk_parked_fetch)");
   }
   if (total && !ij_out) return ppk_fail(PPK_ERR_ARG, "ij_out is NULL");
+  // every band's list goes from its device straight to its place in the caller's array, whose pages (a fresh array:
+  // never touched) are faulted in ahead of the copies by the helper threads, 2 MB at a time
+  HostToucher toucher(ij_out, total * 16);
+  std::vector<PpkTicket> fetchers;
+  std::vector<int> frc(parts.size(), PPK_OK);
+  std::vector<std::string> ferr(parts.size());
   size_t off = 0;
-  for (EdgePart &p : parts) {
-    if (!p.edges.empty()) memcpy(ij_out + off, p.edges.data(), p.edges.size() * sizeof(long long));
-    off += p.edges.size();
+  for (size_t d = 0; d < parts.size(); ++d) {
+    EdgePart &p = parts[d];
+    const size_t at = off;
+    off += p.count() * 2;
+    if (p.count() == 0) continue;
+    auto work = [&p, &toucher, &frc, &ferr, d, at, ij_out]() {
+      toucher.wait((at + p.count() * 2) * sizeof(long long));
+      frc[d] = fetch_edge_part(p, ij_out + at);
+      if (frc[d] != PPK_OK) ferr[d] = ppk_error();
+    };
+    if (parts.size() == 1) work();
+    else fetchers.push_back(ppk_pool_run(work));
   }
+  for (auto &t : fetchers) ppk_pool_wait(t);
+  for (size_t d = 0; d < parts.size(); ++d)
+    if (frc[d] != PPK_OK) return ppk_fail(frc[d], ferr[d]);
   return PPK_OK;
 }
 

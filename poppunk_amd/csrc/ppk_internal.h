@@ -134,6 +134,7 @@ struct EdgeGeom {
   size_t seg_words;         // EDGE_COO_SEGMENTS: mask words per segment
   long long *coo_j;         // EDGE_COO_SEGMENTS: second and third output arrays (first = d_edges)
   long long *coo_seg;
+  int pair_interleaved;     // linear layouts: the mask came from ppk_launch_mask_from_dist_counted (even / odd rows of 128 in word pairs)
 };
 
 // Workspace sizes / launchers; all enqueue on `s` and never synchronise.

@@ -28,6 +28,8 @@ def test_two_ranks_one_gpu_matches_single_launch():
     assert "KNN equal=True" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     # every rank's kernel stores its band straight into ONE matrix owned by rank 0 (PeerStoreQuery, IPC window)
     assert "PEERSTORE equal=True" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    # ... and the owner's own kernels re-read a window they had cached before the peers' stores (fine-grained window)
+    assert "PEERSTORE_REREAD equal=True" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_window_entry_points_alone():

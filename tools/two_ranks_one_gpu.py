@@ -52,6 +52,23 @@ dist.barrier()
 m = psq.run(K, T)
 if rank == 0:
     print("PEERSTORE equal=%s bands=%s shares=%s" % (ok1 and bool(torch.equal(m, whole)), psq.band_rows, ["%.3f" % x for x in shares]))
+# the stale-cache case: the owner fills the window with a sentinel and READS it back (its lines now sit, clean, in the
+# owner's L2s), the ranks store their bands, and after the barrier the owner's OWN kernels -- kernel 2's assign pass
+# and a reduction -- read the window again: any line served from before the stores shows as a sentinel
+ok_rr = True
+for rep in range(3):
+    if rank == 0:
+        psq.matrix().fill_(-1.0)
+        torch.cuda.synchronize()
+        assert float(psq.matrix().sum().item()) == -2.0 * psq.total_rows      # pulled through the owner's caches
+    dist.barrier()
+    m = psq.run(K, T)
+    if rank == 0:
+        a_win = engine.assign_threshold_dev(m, 2, xm, ym)
+        a_ref = engine.assign_threshold_dev(whole, 2, xm, ym)
+        ok_rr = ok_rr and bool(torch.equal(a_win, a_ref)) and bool((m >= 0).all().item()) and bool(torch.equal(m, whole))
+if rank == 0:
+    print("PEERSTORE_REREAD equal=%s" % ok_rr)
 psq.close()
 dist.barrier()
 dist.destroy_process_group()
