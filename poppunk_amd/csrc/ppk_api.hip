@@ -59,6 +59,7 @@ const OptionEntry kOptions[] = {
     {"ksplit_slices", "PPK_KSPLIT_SLICES", &PpkConfig::ksplit_slices},
     {"wide_kpg", "PPK_WIDE_KPG", &PpkConfig::wide_kpg},
     {"ksplit_wide", "PPK_KSPLIT_WIDE", &PpkConfig::ksplit_wide},
+    {"ksplit_long", "PPK_KSPLIT_LONG", &PpkConfig::ksplit_long},
     {"ksplit_fused", "PPK_KSPLIT_FUSED", &PpkConfig::ksplit_fused},
     {"chunk_rows", "PPK_CHUNK_ROWS", &PpkConfig::chunk_rows},
     {"prefault_threads", "PPK_PREFAULT_THREADS", &PpkConfig::prefault_threads},

@@ -1955,6 +1955,68 @@ regress_counts_kernel(const uint32_t *__restrict__ counts, size_t n_rows, size_t
 }
 
 // ---- k-split jobs: counts -> distances with the SAME fit as the tile epilogue -------------------
+// The row's counts where the counts pass left them, [k * slices + piece][row]: read k by k, in the order and with the
+// expressions of fit_packed / fit_general, so a k list of any length (the wide ones too) gets the bits the tile kernel
+// gives.
+struct PackRows {
+  const uint32_t *counts;      // the row's first count
+  size_t n_rows;
+  int slices;
+};
+__device__ __forceinline__ uint32_t rows_get(const PackRows &pk, int k) {
+  uint32_t c = 0;
+  for (int h = 0; h < pk.slices; ++h) c += pk.counts[((size_t)k * pk.slices + h) * pk.n_rows];
+  return c;
+}
+template <typename ParamsT>
+__device__ __forceinline__ void fit_general(const PackRows &pk, const double *__restrict__ lutp, const ParamsT &p,
+                                            float &core, float &acc, bool &failed) {
+  double sx = 0.0, sxx = 0.0, sy = 0.0, sxy = 0.0;
+  int n = 0;
+  bool open = true;
+  for (int k = 0; k < p.nk; ++k) {
+    const double y = lutp[(size_t)k * p.lut_kstride + rows_get(pk, k)];
+    open = (p.ext_skip || open) && !(y > 0.0);
+    if (open) {
+      const double x = (double)p.kmers[k];
+      sx += x;
+      sxx += x * x;
+      sy += y;
+      sxy = __builtin_fma(x, y, sxy);
+      ++n;
+    }
+  }
+  if (n < 2) {
+    core = 0.0f;
+    acc = 0.0f;
+    failed = true;
+    return;
+  }
+  const double dn = (double)n;
+  const double slope = (dn * sxy - sx * sy) / (dn * sxx - sx * sx);
+  const double icpt = (sy - slope * sx) / dn;
+  core = slope < 0.0 ? (float)(1.0 - exp_nonpos(slope)) : 0.0f;
+  acc = icpt < 0.0 ? (float)(1.0 - exp_nonpos(icpt)) : 0.0f;
+  failed = false;
+}
+template <typename ParamsT>
+__device__ __forceinline__ void fit_packed(const PackRows &pk, const double *__restrict__ lut, size_t cp_off,
+                                           const ParamsT &p, float &core, float &acc, bool &failed) {
+  const double *ef_base = lut + p.lut_total + 2 * cp_off;
+  double pe = 1.0, pf = 1.0;
+  for (int k = 0; k < p.nk; ++k) {
+    const double *ef = ef_base + 2 * ((size_t)k * p.lut_kstride + rows_get(pk, k));
+    pe = k == 0 ? ef[0] : pe * ef[0];
+    pf = k == 0 ? ef[1] : pf * ef[1];
+  }
+  if (pe == pe && p.nk >= 2) {
+    fit_finish(pe, pf, core, acc);
+    failed = false;
+    return;
+  }
+  fit_general(pk, lut + cp_off, p, core, acc, failed);
+}
+
 __global__ void __launch_bounds__(256)
 regress_packed_kernel(const uint32_t *__restrict__ counts, size_t n_rows, const double *__restrict__ lut,
                       const uint16_t *__restrict__ ref_clu, const uint16_t *__restrict__ qry_clu,
@@ -1982,15 +2044,12 @@ regress_packed_kernel(const uint32_t *__restrict__ counts, size_t n_rows, const 
       }
       cp = (size_t)ref_clu[r] * p.n_clu + (qry_clu ? qry_clu[q] : 0);
     }
-    u128 pk = 0;
-    const int slices = p.k_split;      // a k's blocks were counted in `slices` pieces: [k * slices + piece][row]
-    for (int k = 0; k < p.nk; ++k) {
-      uint32_t c = 0;
-      for (int h = 0; h < slices; ++h) c += counts[((size_t)k * slices + h) * n_rows + i];
-      pk |= (u128)c << (p.cnt_bits * k);
-    }
+    PackRows pk;      // a k's blocks were counted in `k_split` pieces: [k * slices + piece][row]
+    pk.counts = counts + i;
+    pk.n_rows = n_rows;
+    pk.slices = p.k_split;
     float core, acc;
-    fit_packed<u128>(pk, lut, cp * p.lut_cpstride, p, core, acc, failed);
+    fit_packed(pk, lut, cp * p.lut_cpstride, p, core, acc, failed);
     out[i] = make_float2(core, acc);
   }
   if (n_failed) {
@@ -2326,7 +2385,8 @@ static int launch_dist_band(const ppk_db *ref, const ppk_db *qry_or_null, const 
   // of queries): one workgroup per (tile, k) instead of per tile -- nk times the parallelism, a
   // serial chain of s64 blocks instead of nk * s64 -- writing raw counts, then the regression pass.
   bool small = false;
-  if (!too_wide && p.nk * p.cnt_bits <= 128 && !d_mask && !knn_args && p.bbits == 14 && p.nk >= 2) {
+  const bool wide_list = p.nk * p.cnt_bits > 128;      // (small jobs: the two-pass form -- the counts never enter a register)
+  if (!too_wide && !d_mask && !knn_args && p.bbits == 14 && p.nk >= 2) {
     const size_t rt = (ref->n + V2_RT - 1) / V2_RT, qt = (q_end - q_begin + 31) / 32;
     // default 1 200 tiles at 5 k since the one-launch form (round 4; profiles/r04/ksplit_threshold*.txt: it wins by
     // 10 - 50 % up to 4 000 genomes / 1 125 tiles and ties from there to 1 800 tiles; 215 with the two-pass form)
@@ -2340,8 +2400,24 @@ static int launch_dist_band(const ppk_db *ref, const ppk_db *qry_or_null, const 
     const bool lds_fit = p.nk >= 3 && p.nk <= 5 && p.cnt_bits == 11;
     long long ks = ppk_config().ksplit.load();   // tile-count threshold at 5 k, 0 = off
     if (!lds_fit && ks > ppk_config().ksplit_wide.load()) ks = ppk_config().ksplit_wide.load();
-    const size_t limit = ks > 0 ? (size_t)ks * 5 / (size_t)p.nk : 0;
-    small = (p.self ? rt * qt / 2 + qt : rt * qt) <= limit;
+    size_t limit = ks > 0 ? (size_t)ks * 5 / (size_t)p.nk : 0;
+    const size_t tiles = p.self ? rt * qt / 2 + qt : rt * qt;
+    // LONG sketches (sketchsize64 >= 32; PopPUNK's default is 156): a pair tile is a serial chain of nk * s64 blocks --
+    // 780 at the default, ~1 ms -- so whole tiles fill the last round of workgroup slots badly at ANY job size, and
+    // they cycle through every k's rows while a k-split job works through the database one k at a time (a k of
+    // 10 000 default-size sketches is 175 MB: it stays in the 256 MB Infinity Cache, all five do not).  Measured
+    // (round 5, profiles/r05/ksplit_long_sketches.txt; tile kernel -> k-split, ms, same box): s = 9 984, 5 k: 1 000
+    // genomes 1.26 -> 0.44, 3 000: 3.74 -> 2.61, 10 000: 27.3 -> 25.9, 20 000: 105.0 -> 102.0; 9 k: 10 000: 50.2 ->
+    // 46.4; 10 k (wide list, two-pass form): 10 000: 58.0 -> 56.6; sketchsize64 64: ahead to 14 000 genomes, 32: to
+    // 10 000, level beyond.  The path is therefore taken whenever its scratch (partial counts: 16 KB per (tile,
+    // unit), or 4 B per (row, k) in the two-pass form) stays within 4 GB; option "ksplit_long" 0 restores the
+    // tile-count rule above.
+    if (ks > 0 && p.s64 >= 32 && ppk_config().ksplit_long.load() != 0) {
+      const size_t rows = p.self ? (q_end * ref->n - (q_end * (q_end + 1)) / 2) - p.row_base : (q_end - q_begin) * ref->n;
+      const size_t scratch = wide_list ? rows * (size_t)p.nk * 4 : tiles * (size_t)p.nk * (16 << 10);
+      if (scratch <= ((size_t)4 << 30) && (p.s64 >= 64 || tiles <= 6600)) limit = tiles;
+    }
+    small = tiles <= limit;
   }
   if (too_wide && knn_args) return ppk_fail(PPK_ERR_ARG, "neighbours from tiles need bbits = 14");
   if (too_wide) {
@@ -2396,14 +2472,14 @@ static int launch_dist_band(const ppk_db *ref, const ppk_db *qry_or_null, const 
     // unit of ONE block has no block to re-fetch and would read the block behind its range -- for the last unit of
     // the last k, behind the array (found by the randomised campaign: s64 = 2 cut in two).  One launch needs units of
     // at least two blocks; single-block units (sketchsize64 1, or 2 cut in two) keep the two-pass path.
-    if (ppk_config().ksplit_fused.load() != 0)
+    if (ppk_config().ksplit_fused.load() != 0 && !wide_list)
       while (slices > 1 && p.s64 / slices < 2) slices /= 2;
     p.k_split = slices;
     p.ks_rows = rows;
     p.ks_blocks = p.s64 / slices;
     p.ks_units = (unsigned)(p.nk * slices);
     // ONE launch: every tile's last unit fits it (a unit's counts travel as 16-bit numbers)
-    if (ppk_config().ksplit_fused.load() != 0 && p.ks_blocks >= 2 && 64 * (size_t)p.ks_blocks < 65536)
+    if (ppk_config().ksplit_fused.load() != 0 && !wide_list && p.ks_blocks >= 2 && 64 * (size_t)p.ks_blocks < 65536)
       return launch_tiles_packed<MODE_DIST>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, nullptr, p, s);
     void *p_cnt = nullptr;
     int rc = ppk_scratch_get(ref->device, SLOT_ITER_A, rows * (size_t)p.nk * slices * 4 + 256, &p_cnt);
@@ -2416,9 +2492,12 @@ static int launch_dist_band(const ppk_db *ref, const ppk_db *qry_or_null, const 
     }
     if (rc != PPK_OK) return rc;
     const bool use_clu = p.random_correct && p.n_clu > 1;
+    ppk_set_kernel_name("dist_kernel_v2<256x32,lds-dma,k-split counts> + regress_packed_kernel");
+    ppk_prof_begin(s);
     hipLaunchKernelGGL(regress_packed_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s,
                        static_cast<const uint32_t *>(p_cnt), rows, d_lut, use_clu ? ref->d_clu : nullptr,
                        use_clu ? qry->d_clu : nullptr, static_cast<float2 *>(d_out), d_n_failed, p);
+    ppk_prof_end(s);
     PPK_HIP(hipGetLastError());
     return PPK_OK;
   }

@@ -55,6 +55,7 @@ struct PpkConfig {
   std::atomic<long long> lds_table{1};          // PPK_LDS_TABLE: interior tiles of the default sketch shape fit from the (E, F) table in LDS (0: the general statement everywhere; same bits)
   std::atomic<long long> ksplit{1200};           // PPK_KSPLIT: tile-count threshold (at 5 k) of the small-job path
   std::atomic<long long> ksplit_wide{215};      // PPK_KSPLIT_WIDE: the same threshold for sketches whose tiles are not fitted from the LDS table (never above ksplit)
+  std::atomic<long long> ksplit_long{1};        // PPK_KSPLIT_LONG: sketches of sketchsize64 >= 32 take the k-split path at any job size its scratch allows (0: the tile-count thresholds only)
   std::atomic<long long> ksplit_fused{1};       // PPK_KSPLIT_FUSED: small jobs run ONE launch (the last unit of a tile fits it); 0 = counts pass + regression pass
   std::atomic<long long> wide_kpg{0};           // PPK_WIDE_KPG: k-mer lengths per window of the wide-k tile kernel (0 = as many as 128 bits hold; smaller values send narrower k lists through it: tests)
   std::atomic<long long> ksplit_slices{0};      // PPK_KSPLIT_SLICES: pieces each k is cut into on the small-job path (0 = chosen from the job's size; measurement)

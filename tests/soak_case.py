@@ -21,7 +21,7 @@ def reset_options():
     _lib.set_option("knn_list", 0)
     _lib.set_option("chunk_rows", 8 << 20)
     for name, default in (("wide_kpg", 0), ("lds_table", 1), ("ksplit_wide", 215), ("knn_warm", 32), ("knn_cut", 4),
-                          ("host_parts", 2), ("host_parts_rows", 16 << 20), ("prefault_threads", 8), ("db_cache", 1),
+                          ("ksplit_long", 1), ("host_parts", 2), ("host_parts_rows", 16 << 20), ("prefault_threads", 8), ("db_cache", 1),
                           ("progress", 1), ("host_trace", 0)):
         _lib.set_option(name, default)
     oracle.set_ext(0, 0)
@@ -52,6 +52,7 @@ def soak_case(rng, big=False):
     _lib.set_option("ksplit_slices", int(rng.choice([0, 0, 1, 2, 4])))
     _lib.set_option("ksplit_fused", int(rng.integers(0, 8) != 0))
     _lib.set_option("ksplit_wide", int(rng.choice([215, 215, 0, 2000])))
+    _lib.set_option("ksplit_long", int(rng.integers(0, 3) != 0))
     # every sixth case windows the count register narrower than it is (the wide-k path on short k lists); now and
     # then the LDS-table fit of interior tiles is off
     _lib.set_option("wide_kpg", int(rng.integers(1, 6)) if rng.integers(0, 6) == 0 else 0)

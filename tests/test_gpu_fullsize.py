@@ -140,7 +140,7 @@ def test_config5_100000_genomes_one_band_fused_edges():
 
 
 @pytest.mark.parametrize("nk", [5, 6])
-def test_default_sketch_size_many_ref_tiles(nk):
+def test_default_sketch_size_many_ref_tiles(nk, ppk_option):
     """PopPUNK's DEFAULT sketch size (s = 9 984: sketchsize64 156, 14-bit counts -> the three-dword count
     register) on a job with 11 ref tiles and a ragged right edge: 3.5 M pairs of 780 / 936 blocks each.
     Counts bit-identical, distances within 1e-6 on every row, query bands equal to the whole job, the
@@ -155,8 +155,15 @@ def test_default_sketch_size_many_ref_tiles(nk):
     del counts
     want, wf = oracle.query(sk, None, kmers, 156, 14, tbl, threads=THREADS)
     db = engine.SketchDB(sk, 156, 14)
+    # long sketches take the k-split path at any size by default (round 5); the tile kernel itself with "ksplit_long" 0:
+    # the same bits either way
+    by_units, gf_u = engine.dist(db, None, kmers, tbl)
+    assert engine._lib.lib().ppk_last_kernel_name().decode().endswith("k-split fused>")
+    ppk_option("ksplit_long", 0)
     whole, gf = engine.dist(db, None, kmers, tbl)
-    assert int(gf.item()) == wf
+    assert engine._lib.lib().ppk_last_kernel_name().decode().endswith("lds-dma>")
+    assert int(gf.item()) == wf == int(gf_u.item()) and torch.equal(by_units.view(torch.int32), whole.view(torch.int32))
+    del by_units
     _compare(whole.cpu().numpy(), want, "s=9984 nk=%d, %d genomes self" % (nk, n))
     cuts = [0, 37, 1024, 1111, 2600, n]
     pieces = [engine.dist(db, None, kmers, tbl, q_begin=a, q_end=b)[0] for a, b in zip(cuts[:-1], cuts[1:])]

@@ -50,18 +50,24 @@ def _close(got, want, what):
 
 
 @pytest.mark.parametrize("kmers", [K_CORONA, K_STEP2, K_12, K_STEP1], ids=["k6-15", "k13-31s2", "k7-29s2", "k13-29s1"])
-def test_documented_k_lists_at_the_default_sketch_size(kmers):
-    """2 700 genomes (11 ref tiles, a ragged right edge, diagonal half tiles) at s = 9 984: distances, the fused
-    edge list of the whole job and of three bands, neighbours from the tiles -- against the oracle."""
+def test_documented_k_lists_at_the_default_sketch_size(kmers, ppk_option):
+    """2 700 genomes (11 ref tiles, a ragged right edge, diagonal half tiles) at s = 9 984: distances (through the wide
+    tile kernel and through the k-split path long sketches take by default: same bits), the fused edge list of the
+    whole job and of three bands, neighbours from the tiles -- against the oracle."""
     n, s64 = 2700, 156
     sk, member = synth.make_sketches(n, kmers, sketchsize64=s64, bbits=14, cluster_size=30, seed=len(kmers))
     clu = (member % 2).astype(np.uint16)
     tbl = _table(kmers, n_clu=2)
     want, wf = oracle.query(sk, None, kmers, s64, 14, tbl, clu, clu, threads=THREADS)
     db = engine.SketchDB(sk, s64, 14, clusters=clu)
+    d_ks, f_ks = engine.dist(db, None, kmers, tbl)          # default: one workgroup per (tile, k) + the fit pass
+    assert not engine._lib.lib().ppk_last_kernel_name().decode().endswith("wide>")
+    ppk_option("ksplit_long", 0)
     d, f = engine.dist(db, None, kmers, tbl)
     assert engine._lib.lib().ppk_last_kernel_name().decode().endswith("wide>")
-    assert int(f.item()) == wf
+    ppk_option("ksplit_long", 1)
+    assert int(f.item()) == wf == int(f_ks.item())
+    assert np.array_equal(d.cpu().numpy().view(np.uint32), d_ks.cpu().numpy().view(np.uint32))
     _close(d.cpu().numpy(), want, "distances nk=%d" % len(kmers))
     # fused edges: whole job, then bands (none of them aligned to the 32-query tile)
     got = d.cpu().numpy()
@@ -209,7 +215,7 @@ def test_wide_slots_are_recycled_across_many_more_tiles_than_slots():
     tbl = _table(kmers)
     db = engine.SketchDB(sk, 16, 14)
     d1, f1 = engine.dist(db, None, kmers, tbl)
-    assert engine._lib.lib().ppk_last_kernel_name().decode().endswith("wide>")
+    assert engine._lib.lib().ppk_last_kernel_name().decode().endswith("wide>")      # (s = 1 024: 5 100 tiles are no small job)
     a = d1.cpu().numpy().copy()
     d2, f2 = engine.dist(db, None, kmers, tbl, out=d1)
     torch.cuda.synchronize()
@@ -243,7 +249,15 @@ def test_one_100000_genome_band_with_ten_kmer_lengths():
     x_max, y_max = synth.boundary_for_quantile(sub, 0.02)
     rect, wf = oracle.query(sk, sk[qb:qe], kmers, s64, 14, tbl, threads=THREADS)     # row = (q - qb) * n + r
     a = oracle.assign_threshold(rect, 2, x_max, y_max, threads=THREADS).reshape(qe - qb, n)
-    d, f = engine.dist(db, None, kmers, tbl, q_begin=qb, q_end=qe)
+    d, f = engine.dist(db, None, kmers, tbl, q_begin=qb, q_end=qe)          # (782 tiles of long sketches: the k-split path)
+    _lib_name = engine._lib.lib().ppk_last_kernel_name().decode()
+    engine._lib.set_option("ksplit_long", 0)
+    try:
+        d2, _ = engine.dist(db, None, kmers, tbl, q_begin=qb, q_end=qe)
+        assert engine._lib.lib().ppk_last_kernel_name().decode().endswith("wide>") and not _lib_name.endswith("wide>")
+    finally:
+        engine._lib.set_option("ksplit_long", 1)
+    assert np.array_equal(d.cpu().numpy().view(np.uint32), d2.cpu().numpy().view(np.uint32))
     got = d.cpu().numpy()
     rows = np.concatenate([rect.reshape(qe - qb, n, 2)[q - qb, q + 1:] for q in range(qb, qe)])
     _close(got, rows, "100 000-genome band, nk = 10")
@@ -256,3 +270,53 @@ def test_one_100000_genome_band_with_ten_kmer_lengths():
         assert len(want) > 1000
         assert np.array_equal(e.cpu().numpy(), want), (inclusive, len(e), len(want))
     db.close()
+
+
+def test_small_wide_jobs_take_the_k_split_path_and_return_the_tile_kernels_bits(ppk_option):
+    """poppunk_assign with a handful of genomes at the default sketch size and a wide k list: a job of less than a
+    round of pair tiles runs one workgroup per (tile, k) and a fit pass (two launches: the counts of a wide list never
+    enter a register) -- same expressions in the same order as the tile kernel's epilogue, so the same bits."""
+    kmers, s64 = K_CORONA, 156
+    sk, member = synth.make_sketches(1400, kmers, sketchsize64=s64, bbits=14, cluster_size=20, seed=21)
+    clu = (member % 2).astype(np.uint16)
+    tbl = _table(kmers, n_clu=2)
+    rdb = engine.SketchDB(sk[:1000], s64, 14, clusters=clu[:1000])
+    name = lambda: engine._lib.lib().ppk_last_kernel_name().decode()
+    for q in (1, 7, 64, 400):
+        qdb = engine.SketchDB(sk[1000:1000 + q], s64, 14, clusters=clu[1000:1000 + q])
+        a, fa = engine.dist(rdb, qdb, kmers, tbl)
+        small = not name().endswith("wide>")
+        ppk_option("ksplit", 0)
+        b, fb = engine.dist(rdb, qdb, kmers, tbl)
+        assert name().endswith("wide>")
+        ppk_option("ksplit", 1200)
+        assert small, q                                    # (4 ref tiles x ceil(q / 32) query tiles against 215 * 5 / 10 = 107)
+        assert torch_equal_bits(a, b) and int(fa.item()) == int(fb.item())
+        want, wf = oracle.query(sk[:1000], sk[1000:1000 + q], kmers, s64, 14, tbl, clu[:1000], clu[1000:1000 + q], threads=THREADS)
+        assert int(fa.item()) == wf and np.abs(a.cpu().numpy() - want).max() <= TOL
+        qdb.close()
+    # self, with every way of cutting a k into pieces
+    sdb = engine.SketchDB(sk[:500], s64, 14, clusters=clu[:500])
+    ppk_option("ksplit", 0)
+    base, _ = engine.dist(sdb, None, kmers, tbl)
+    ppk_option("ksplit", 1200)
+    for slices in (0, 1, 2, 4):
+        ppk_option("ksplit_slices", slices)
+        got, _ = engine.dist(sdb, None, kmers, tbl)
+        assert not name().endswith("wide>")
+        assert torch_equal_bits(got, base), slices
+    # ... long sketches take that path at any size its scratch allows (option "ksplit_long"); without it a job of
+    # more than 215 * 5 / nk tiles (1 400 self: 176 tiles) is the tile kernel's
+    big = engine.SketchDB(sk, s64, 14, clusters=clu)
+    engine.dist(big, None, kmers, tbl)
+    assert not name().endswith("wide>")
+    ppk_option("ksplit_long", 0)
+    engine.dist(big, None, kmers, tbl)
+    assert name().endswith("wide>")
+    for db in (rdb, sdb, big):
+        db.close()
+
+
+def torch_equal_bits(a, b):
+    import torch
+    return bool(torch.equal(a.view(torch.int32), b.view(torch.int32)))
