@@ -2408,14 +2408,16 @@ static int launch_dist_band(const ppk_db *ref, const ppk_db *qry_or_null, const 
     // 10 000 default-size sketches is 175 MB: it stays in the 256 MB Infinity Cache, all five do not).  Measured
     // (round 5, profiles/r05/ksplit_long_sketches.txt; tile kernel -> k-split, ms, same box): s = 9 984, 5 k: 1 000
     // genomes 1.26 -> 0.44, 3 000: 3.74 -> 2.61, 10 000: 27.3 -> 25.9, 20 000: 105.0 -> 102.0; 9 k: 10 000: 50.2 ->
-    // 46.4; 10 k (wide list, two-pass form): 10 000: 58.0 -> 56.6; sketchsize64 64: ahead to 14 000 genomes, 32: to
-    // 10 000, level beyond.  The path is therefore taken whenever its scratch (partial counts: 16 KB per (tile,
+    // 46.4; sketchsize64 64: ahead to 14 000 genomes, 32: to 10 000, level beyond.  The path is therefore taken whenever its scratch (partial counts: 16 KB per (tile,
     // unit), or 4 B per (row, k) in the two-pass form) stays within 4 GB; option "ksplit_long" 0 restores the
     // tile-count rule above.
     if (ks > 0 && p.s64 >= 32 && ppk_config().ksplit_long.load() != 0) {
       const size_t rows = p.self ? (q_end * ref->n - (q_end * (q_end + 1)) / 2) - p.row_base : (q_end - q_begin) * ref->n;
       const size_t scratch = wide_list ? rows * (size_t)p.nk * 4 : tiles * (size_t)p.nk * (16 << 10);
-      if (scratch <= ((size_t)4 << 30) && (p.s64 >= 64 || tiles <= 6600)) limit = tiles;
+      // (a wide list runs the two-pass form, whose fit pass -- nk table gathers per row with nothing to hide behind --
+      // costs 0.2 us per 1 000 rows at 10 k: it pays up to about 700 tiles, beyond that the wide tile kernel is faster:
+      // 10 000 genomes, k = 6..15: 66.6 ms against 57.0)
+      if (scratch <= ((size_t)4 << 30) && (p.s64 >= 64 || tiles <= 6600) && (!wide_list || tiles <= 700)) limit = tiles;
     }
     small = tiles <= limit;
   }

@@ -249,7 +249,7 @@ def test_one_100000_genome_band_with_ten_kmer_lengths():
     x_max, y_max = synth.boundary_for_quantile(sub, 0.02)
     rect, wf = oracle.query(sk, sk[qb:qe], kmers, s64, 14, tbl, threads=THREADS)     # row = (q - qb) * n + r
     a = oracle.assign_threshold(rect, 2, x_max, y_max, threads=THREADS).reshape(qe - qb, n)
-    d, f = engine.dist(db, None, kmers, tbl, q_begin=qb, q_end=qe)          # (782 tiles of long sketches: the k-split path)
+    d, f = engine.dist(db, None, kmers, tbl, q_begin=qb, q_end=qe)          # (a band of ~400 pair tiles: the k-split path's two-pass form)
     _lib_name = engine._lib.lib().ppk_last_kernel_name().decode()
     engine._lib.set_option("ksplit_long", 0)
     try:
