@@ -428,8 +428,9 @@ __device__ __forceinline__ bool ef_finish(const f64x2 (&ef)[NR][NK], float (&cor
 
 // any nk: running products (no gather batch to keep in registers)
 struct PackWide;
+struct PackParts;
 template <typename PackT, int NR, typename ParamsT>
-__device__ __forceinline__ std::enable_if_t<!std::is_same<PackT, PackWide>::value, bool>
+__device__ __forceinline__ std::enable_if_t<!std::is_same<PackT, PackWide>::value && !std::is_same<PackT, PackParts>::value, bool>
 fit_rows_fast_anyk(const PackT (&pk)[NR], const double *__restrict__ lut, const uint32_t (&loff)[NR],
                    const ParamsT &p, float (&core)[NR], float (&acc)[NR]) {
   const uint32_t cmask = (1u << p.cnt_bits) - 1u;
@@ -571,6 +572,102 @@ fit_rows_fast_anyk(const PackWide (&pk)[NR], const double *__restrict__ lut, con
         pe[r] = k == 0 ? e.x : pe[r] * e.x;
         pf[r] = k == 0 ? e.y : pf[r] * e.y;
       }
+    }
+  }
+  bool all_ok = p.nk >= 2;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) all_ok = all_ok && (pe[r] == pe[r]);
+  if (!__all(all_ok)) return false;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) fit_finish(pe[r], pf[r], core[r], acc[r]);
+  return true;
+}
+
+// ---- k-split jobs, fit straight from the units' partial counts --------------------------------------------
+// The units of a k-split tile leave their counts as 16-bit fields: uint64 [unit][query 0..3][512 threads], field r =
+// the lane's ref r (dist_kernel_v2, KS_FUSED).  The tile's last unit normally rebuilds the count registers from
+// them; with a wide k list there is no register to rebuild, and it fits every pair from the fields as they lie --
+// count k = the sum of the k's `slices` units -- in k order with the expressions of fit_packed / fit_general.
+struct PackParts {
+  const unsigned long long *src;      // the lane's uint64 of (unit 0, the pair's query)
+  int shift;                          // 16 * (the pair's ref within the lane)
+};
+constexpr size_t KS_UNIT_U64 = 4 * 512;      // uint64 per (tile, unit)
+template <typename ParamsT>
+__device__ __forceinline__ unsigned long long parts_word(const PackParts &pk, int k, const ParamsT &p) {
+  // (fields of the k's pieces add without carrying into their neighbours: a k has at most 64 * s64 < 2^16 bins)
+  unsigned long long w = 0;
+  for (int h = 0; h < p.k_split; ++h)
+    w += __hip_atomic_load(pk.src + (size_t)(k * p.k_split + h) * KS_UNIT_U64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return w;
+}
+template <typename ParamsT>
+__device__ __forceinline__ void fit_general(const PackParts &pk, const double *__restrict__ lutp, const ParamsT &p,
+                                            float &core, float &acc, bool &failed) {
+  double sx = 0.0, sxx = 0.0, sy = 0.0, sxy = 0.0;
+  int n = 0;
+  bool open = true;
+  for (int k = 0; k < p.nk; ++k) {
+    const uint32_t c = (uint32_t)(parts_word(pk, k, p) >> pk.shift) & 0xffffu;
+    const double y = lutp[(size_t)k * p.lut_kstride + c];
+    open = (p.ext_skip || open) && !(y > 0.0);
+    if (open) {
+      const double x = (double)p.kmers[k];
+      sx += x;
+      sxx += x * x;
+      sy += y;
+      sxy = __builtin_fma(x, y, sxy);
+      ++n;
+    }
+  }
+  if (n < 2) {
+    core = 0.0f;
+    acc = 0.0f;
+    failed = true;
+    return;
+  }
+  const double dn = (double)n;
+  const double slope = (dn * sxy - sx * sy) / (dn * sxx - sx * sx);
+  const double icpt = (sy - slope * sx) / dn;
+  core = slope < 0.0 ? (float)(1.0 - exp_nonpos(slope)) : 0.0f;
+  acc = icpt < 0.0 ? (float)(1.0 - exp_nonpos(icpt)) : 0.0f;
+  failed = false;
+}
+template <typename ParamsT>
+__device__ __forceinline__ void fit_packed(const PackParts &pk, const double *__restrict__ lut, size_t cp_off,
+                                           const ParamsT &p, float &core, float &acc, bool &failed) {
+  const double *ef_base = lut + p.lut_total + 2 * cp_off;
+  double pe = 1.0, pf = 1.0;
+  for (int k = 0; k < p.nk; ++k) {
+    const uint32_t c = (uint32_t)(parts_word(pk, k, p) >> pk.shift) & 0xffffu;
+    const double *ef = ef_base + 2 * ((size_t)k * p.lut_kstride + c);
+    pe = k == 0 ? ef[0] : pe * ef[0];
+    pf = k == 0 ? ef[1] : pf * ef[1];
+  }
+  if (pe == pe && p.nk >= 2) {
+    fit_finish(pe, pf, core, acc);
+    failed = false;
+    return;
+  }
+  fit_general(pk, lut + cp_off, p, core, acc, failed);
+}
+// the NR refs of a batch share their query, i.e. their words: one load per (k, piece) serves all of them
+template <typename PackT, int NR, typename ParamsT>
+__device__ __forceinline__ std::enable_if_t<std::is_same<PackT, PackParts>::value, bool>
+fit_rows_fast_anyk(const PackParts (&pk)[NR], const double *__restrict__ lut, const uint32_t (&loff)[NR],
+                   const ParamsT &p, float (&core)[NR], float (&acc)[NR]) {
+  const uint32_t kstride = (uint32_t)p.lut_kstride;
+  const char *base = reinterpret_cast<const char *>(lut + p.lut_total);
+  double pe[NR], pf[NR];
+  for (int k = 0; k < p.nk; ++k) {
+    const unsigned long long w = parts_word(pk[0], k, p);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const uint32_t c = (uint32_t)(w >> pk[r].shift) & 0xffffu;
+      const uint32_t boff = (loff[r] + (uint32_t)k * kstride + c) * 16u;
+      const f64x2 e = *reinterpret_cast<const f64x2 *>(base + boff);
+      pe[r] = k == 0 ? e.x : pe[r] * e.x;
+      pf[r] = k == 0 ? e.y : pf[r] * e.y;
     }
   }
   bool all_ok = p.nk >= 2;
@@ -779,8 +876,12 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
                void *__restrict__ out, unsigned long long *__restrict__ n_failed,
                uint64_t *__restrict__ mask_out, const DistParams p) {
   static_assert(NW == 8, "the product tile is 256 refs x 32 queries (8 wavefronts)");
-  static_assert(!WIDE || (W == 4 && !KSPLIT && (MODE == MODE_DIST || MODE == MODE_MASK || MODE == MODE_KNN)),
-                "the wide instantiation windows the 128-bit register");
+  // WIDE without KSPLIT: the tile kernel whose count register windows the k list (PackWide).  WIDE with KSPLIT: a
+  // k-split unit (it counts ONE k, or a piece of one: W = 2 holds it) whose tile is fitted by its last unit straight
+  // from the units' partial counts (PackParts) -- no count register is ever rebuilt, so any k list fits.
+  static_assert(!WIDE || (KSPLIT ? (W == 2 && MODE == MODE_DIST) : (W == 4 && (MODE == MODE_DIST || MODE == MODE_MASK || MODE == MODE_KNN))),
+                "the wide instantiations");
+  constexpr bool WIDE_TILE = WIDE && !KSPLIT;
   const int ablate = EXP ? p.ablate : 0;
   constexpr int R = V2_R, TQ = V2_TQ, BB = V2_BB;
   constexpr int V2_QT = NW * TQ;              // queries per workgroup tile (32)
@@ -795,11 +896,12 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
   // double buffer: 63 KB.  The modes with a per-pair fit take 80 KB -- two workgroups then own all
   // 160 KB of a CU -- so that the epilogue of an interior tile can hold the whole (E, F) table
   // (5 k x 1024 counts x 16 B) in LDS, see below.
-  constexpr bool LDS_TABLE = NW == 8 && W == 2 && (MODE == MODE_DIST || MODE == MODE_MASK || MODE == MODE_KNN);
+  constexpr bool LDS_TABLE = NW == 8 && W == 2 && !WIDE && (MODE == MODE_DIST || MODE == MODE_MASK || MODE == MODE_KNN);
   constexpr int TAB_U4 = 5 * 1024;
   // KS_FUSED: a k-split job whose tiles are fitted by their last workgroup (below); one more entry behind the
   // compare buffers holds the workgroup's grid position across the loop, in LDS instead of two SGPRs
   constexpr bool KS_FUSED = KSPLIT && MODE == MODE_DIST;
+  constexpr bool KS_MEM = KS_FUSED && WIDE;
   constexpr int KS_SLOT = 2 * CHUNK_U4;      // (WIDE: the workgroup's spill slot index lives there)
   __shared__ u32x4 lds[LDS_TABLE && TAB_U4 > 2 * CHUNK_U4 + 1 ? TAB_U4 : 2 * CHUNK_U4 + (KS_FUSED || WIDE ? 1 : 0)];
 
@@ -873,7 +975,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
   int lane_late = lane;   // DIST / MASK: re-derived after the loop, see below
   auto ref_of = [&](int r) -> size_t { return r0 + 2 * lane_late + (r & 1) + (r >> 1) * 128; };
 
-  if constexpr (WIDE) {
+  if constexpr (WIDE_TILE) {
     // take a spill slot: the first free bit from a start that spreads neighbouring workgroups over the words
     if (threadIdx.x == 0) {
       const unsigned mask = p.wide_nslots - 1u;
@@ -972,7 +1074,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
   // beyond the registers themselves is fetched when it runs -- once per wide_kpg * s64 blocks -- so the loop
   // carries one more scalar (`wide_next`) and nothing else.
   auto wide_park = [&](int g) __attribute__((always_inline)) {
-    if constexpr (WIDE) {
+    if constexpr (WIDE_TILE) {
       const char __attribute__((address_space(4))) *ka =
           (const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
       asm volatile("" : "+s"(ka));
@@ -1069,7 +1171,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
         if constexpr (MODE == MODE_DIST || MODE == MODE_MASK || MODE == MODE_KNN) {
           // another k follows: the count register moves up by one field
           bool parked = false;
-          if constexpr (WIDE) {
+          if constexpr (WIDE_TILE) {
             // (the group size is fetched here, opaquely: held across the loop it costs the scalar -- and, hoisted,
             // the reciprocal -- the loop does not have; this runs once per s64 blocks)
             int kpg = p.wide_kpg;
@@ -1153,7 +1255,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
   // ---- epilogue: regression (+ boundary) per pair ---------------------------
   if constexpr (MODE == MODE_DIST || MODE == MODE_MASK || MODE == MODE_KNN) {
     if (ablate & 1) return;
-    if (!KS_FUSED && !WIDE && MODE != MODE_KNN && !wave_active) return;      // (KNN, k-split, wide: every wave takes part in an exchange)
+    if (!KS_FUSED && !WIDE_TILE && MODE != MODE_KNN && !wave_active) return;      // (KNN, k-split, wide: every wave takes part in an exchange)
     // the compare stream leaves the wave at priority 0 (it falls through each block, see
     // tools/gen_block_asm.py); the epilogue is the last thing between this workgroup's slot and the next
     // tile, so it runs at the top priority (measured: another -0.5..-1 %)
@@ -1193,7 +1295,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
     // WIDE: the last group joins the others in the slot; from here on the counts are read from there
     uint32_t wide_slot = 0;
     const uint32_t *wide_src = nullptr;
-    if constexpr (WIDE) {
+    if constexpr (WIDE_TILE) {
       wide_slot = __builtin_amdgcn_readfirstlane(*(volatile __attribute__((address_space(3))) uint32_t *)(__attribute__((address_space(3))) void *)(lds + KS_SLOT));
       if (wave_active) {
         wide_park(p_late.wide_groups - 1);
@@ -1408,7 +1510,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
       }
     }
     const bool table_in_lds = interior;      // (a wavefront may still leave the interior path: `interior` is cleared)
-    if constexpr (KS_FUSED) {
+    if constexpr (KS_FUSED && !KS_MEM) {
       if (!interior && wave_active) ks_reload();
     }
     if constexpr (LDS_TABLE) {
@@ -1558,14 +1660,18 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
     // A batch = the lane's refs 2h, 2h+1 against query q (2 x nk gathers).  With the default k list
     // the gathers of batch b+1 are issued BEFORE batch b is consumed (two register sets, alternating):
     // the table look-ups are the only memory latency in the epilogue, and there are 8 batches of it.
-    constexpr bool PIPE = MODE == MODE_DIST && W == 2;
+    constexpr bool PIPE = MODE == MODE_DIST && W == 2 && !WIDE;
     // (the plain distance kernel with the two-dword count register only: the other instantiations have
     // no registers to spare for the second set, and spill)
     const bool pipelined = PIPE && p.lut32 && p.nk == 5;      // wave-uniform
     constexpr int NRB = PIPE ? 1 : 2;      // refs per batch (pipelined: one, 5 gathers = 20 VGPRs per register set)
     constexpr int NB = R * TQ / NRB;       // batches, query-major: b = q * (R / NRB) + r / NRB
     f64x2 ef[2][NRB][5];
-    using EpiPack = std::conditional_t<WIDE, PackWide, PackT>;
+    using EpiPack = std::conditional_t<WIDE_TILE, PackWide, std::conditional_t<KS_MEM, PackParts, PackT>>;
+    const unsigned long long *parts_src = nullptr;      // KS_MEM: the lane's first partial-count word of this tile
+    if constexpr (KS_MEM)
+      parts_src = reinterpret_cast<const unsigned long long *>(reinterpret_cast<const char *>(mask_out) + p.ks_part_off) +
+                  (size_t)ks_tile * p.ks_units * KS_UNIT_U64 + ((uint32_t)wave * 64u + (uint32_t)lane_late);
     auto batch_operands = [&](int bq, int br0, size_t (&cpo)[NRB], uint32_t (&loff)[NRB], EpiPack (&pk)[NRB]) {
       const size_t qq = qw0 + bq;
       const int cq = (qry_clu && qq >= qb && qq < qe) ? qry_clu[qq] : 0;
@@ -1577,8 +1683,11 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
         const size_t cp = (size_t)(strip ? cq * p.n_clu + cr[r] : cr[r] * p.n_clu + cq) * p.lut_cpstride;
         cpo[j] = cp;
         loff[j] = (uint32_t)cp;
-        if constexpr (WIDE) {
+        if constexpr (WIDE_TILE) {
           pk[j].src = wide_src + (size_t)((bq * R + r) * 4) * 512;
+        } else if constexpr (KS_MEM) {
+          pk[j].src = parts_src + (size_t)bq * 512;
+          pk[j].shift = 16 * r;
         } else {
 #pragma unroll
           for (int i = 0; i < W; ++i) pk[j].w[i] = pw[i][r][bq];
@@ -1866,7 +1975,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
         }
     }
     };
-    if constexpr (WIDE) {
+    if constexpr (WIDE_TILE) {
       // a wavefront with nothing to compare has nothing to fit (the neighbour mode's exchange needs all eight)
       if (wave_active || MODE == MODE_KNN) epilogue(p_late);
       // every wavefront has read its counts back: the slot returns to the pool
@@ -2143,7 +2252,7 @@ int launch_v2(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const f
   if (MODE == MODE_DIST && NW == 8 && p.k_split) {
     // k-split job in one launch: ks_units workgroups per tile, the last one to finish fits it (KS_FUSED in the
     // kernel).  Scratch: one zero-initialised counter per tile; 32 bytes per (tile, unit, thread) of partial counts.
-    if constexpr (MODE == MODE_DIST && NW == 8) {
+    if constexpr (MODE == MODE_DIST && NW == 8 && W == 2) {
       void *d_tickets = nullptr, *d_part = nullptr;
       const size_t ticket_bytes = (n_blocks * 4 + 255) / 256 * 256;
       int rc = ppk_scratch_get(ref->device, SLOT_TICKETS, ticket_bytes, &d_tickets);
@@ -2151,9 +2260,9 @@ int launch_v2(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const f
       rc = ppk_scratch_get(ref->device, SLOT_ITER_A, n_blocks * (size_t)p.ks_units * (NW * 64) * 32 + 256, &d_part);
       if (rc != PPK_OK) return rc;
       p.ks_part_off = (size_t)(static_cast<char *>(d_part) - static_cast<char *>(d_tickets));
-      ppk_set_kernel_name("dist_kernel_v2<256x32,lds-dma,k-split fused>");
+      ppk_set_kernel_name(WIDE ? "dist_kernel_v2<256x32,lds-dma,k-split fused,fit from parts>" : "dist_kernel_v2<256x32,lds-dma,k-split fused>");
       ppk_prof_begin(s);
-      hipLaunchKernelGGL((dist_kernel_v2<NW, MODE, W, true>), dim3((unsigned)n_blocks, p.ks_units),
+      hipLaunchKernelGGL((dist_kernel_v2<NW, MODE, W, true, WIDE>), dim3((unsigned)n_blocks, p.ks_units),
                          dim3(NW * 64), 0, s, ref->d_skT, qry->d_skT, d_lut,
                          use_clu ? ref->d_clu : nullptr, use_clu ? qry->d_clu : nullptr, d_rtab, d_out,
                          d_n_failed, static_cast<uint64_t *>(d_tickets), p);
@@ -2162,7 +2271,9 @@ int launch_v2(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const f
       return PPK_OK;
     }
   }
-  if constexpr (WIDE) {
+  if constexpr (WIDE && W != 4) {
+    return ppk_fail(PPK_ERR_STATE, "internal: the fit-from-parts instantiation is a k-split kernel");
+  } else if constexpr (WIDE) {
     // the spill-slot pool (PackWide): a bitmap page + nslots x groups x 128 KB, kept per device
     p.wide_kpg = 128 / p.cnt_bits;
     if (const long long force = ppk_config().wide_kpg.load(); force > 0 && force < p.wide_kpg) p.wide_kpg = (int)force;
@@ -2250,6 +2361,14 @@ int launch_tiles_packed(const ppk_db *ref, const ppk_db *qry, const double *d_lu
   }
   // (option "wide_kpg": a narrower window, i.e. the wide path on a k list the register would hold -- tests)
   const long long force_kpg = ppk_config().wide_kpg.load();
+  if constexpr (MODE == MODE_DIST) {
+    // a k-split job whose tiles are fitted from the units' partial counts as they lie (any k list)
+    // (every k list of more than 64 count bits: rebuilding three- and four-dword registers in the last unit measured
+    // the same -- profiles/r05/ksplit_fit_from_parts.txt -- and cost two more instantiations, both with spills; the
+    // two-dword register path stays for the shapes whose tiles are fitted from the LDS table)
+    if (p.k_split && (total_bits > 64 || (force_kpg > 0 && force_kpg < p.nk)))
+      return launch_v2<8, MODE, 2, true>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
+  }
   if (total_bits > 128 || (force_kpg > 0 && force_kpg < p.nk && !p.k_split))
     return launch_v2<8, MODE, 4, true>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
   if (total_bits <= 64) return launch_v2<8, MODE, 2>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
@@ -2385,7 +2504,6 @@ static int launch_dist_band(const ppk_db *ref, const ppk_db *qry_or_null, const 
   // of queries): one workgroup per (tile, k) instead of per tile -- nk times the parallelism, a
   // serial chain of s64 blocks instead of nk * s64 -- writing raw counts, then the regression pass.
   bool small = false;
-  const bool wide_list = p.nk * p.cnt_bits > 128;      // (small jobs: the two-pass form -- the counts never enter a register)
   if (!too_wide && !d_mask && !knn_args && p.bbits == 14 && p.nk >= 2) {
     const size_t rt = (ref->n + V2_RT - 1) / V2_RT, qt = (q_end - q_begin + 31) / 32;
     // default 1 200 tiles at 5 k since the one-launch form (round 4; profiles/r04/ksplit_threshold*.txt: it wins by
@@ -2413,11 +2531,11 @@ static int launch_dist_band(const ppk_db *ref, const ppk_db *qry_or_null, const 
     // tile-count rule above.
     if (ks > 0 && p.s64 >= 32 && ppk_config().ksplit_long.load() != 0) {
       const size_t rows = p.self ? (q_end * ref->n - (q_end * (q_end + 1)) / 2) - p.row_base : (q_end - q_begin) * ref->n;
-      const size_t scratch = wide_list ? rows * (size_t)p.nk * 4 : tiles * (size_t)p.nk * (16 << 10);
-      // (a wide list runs the two-pass form, whose fit pass -- nk table gathers per row with nothing to hide behind --
-      // costs 0.2 us per 1 000 rows at 10 k: it pays up to about 700 tiles, beyond that the wide tile kernel is faster:
-      // 10 000 genomes, k = 6..15: 66.6 ms against 57.0)
-      if (scratch <= ((size_t)4 << 30) && (p.s64 >= 64 || tiles <= 6600) && (!wide_list || tiles <= 700)) limit = tiles;
+      const bool one_launch = ppk_config().ksplit_fused.load() != 0 && 64 * (size_t)p.s64 < 65536;
+      const size_t scratch = one_launch ? tiles * (size_t)p.nk * (16 << 10) : rows * (size_t)p.nk * 4;
+      // (the two-pass form's fit pass -- nk table gathers per row with nothing to hide behind -- costs 0.2 us per
+      // 1 000 rows at 10 k: it pays up to about 700 tiles)
+      if (scratch <= ((size_t)4 << 30) && (p.s64 >= 64 || tiles <= 6600) && (one_launch || tiles <= 700)) limit = tiles;
     }
     small = tiles <= limit;
   }
@@ -2474,14 +2592,17 @@ static int launch_dist_band(const ppk_db *ref, const ppk_db *qry_or_null, const 
     // unit of ONE block has no block to re-fetch and would read the block behind its range -- for the last unit of
     // the last k, behind the array (found by the randomised campaign: s64 = 2 cut in two).  One launch needs units of
     // at least two blocks; single-block units (sketchsize64 1, or 2 cut in two) keep the two-pass path.
-    if (ppk_config().ksplit_fused.load() != 0 && !wide_list)
+    if (ppk_config().ksplit_fused.load() != 0)
       while (slices > 1 && p.s64 / slices < 2) slices /= 2;
     p.k_split = slices;
     p.ks_rows = rows;
     p.ks_blocks = p.s64 / slices;
     p.ks_units = (unsigned)(p.nk * slices);
     // ONE launch: every tile's last unit fits it (a unit's counts travel as 16-bit numbers)
-    if (ppk_config().ksplit_fused.load() != 0 && !wide_list && p.ks_blocks >= 2 && 64 * (size_t)p.ks_blocks < 65536)
+    // (a unit's counts travel as 16-bit numbers; fitted from the parts as they lie, a k's pieces are added in place)
+    const bool from_parts = p.nk * p.cnt_bits > 64 || (ppk_config().wide_kpg.load() > 0 && ppk_config().wide_kpg.load() < p.nk);
+    if (ppk_config().ksplit_fused.load() != 0 && p.ks_blocks >= 2 && 64 * (size_t)p.ks_blocks < 65536 &&
+        (!from_parts || 64 * (size_t)p.s64 < 65536))
       return launch_tiles_packed<MODE_DIST>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, nullptr, p, s);
     void *p_cnt = nullptr;
     int rc = ppk_scratch_get(ref->device, SLOT_ITER_A, rows * (size_t)p.nk * slices * 4 + 256, &p_cnt);

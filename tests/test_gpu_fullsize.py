@@ -158,7 +158,7 @@ def test_default_sketch_size_many_ref_tiles(nk, ppk_option):
     # long sketches take the k-split path at any size by default (round 5); the tile kernel itself with "ksplit_long" 0:
     # the same bits either way
     by_units, gf_u = engine.dist(db, None, kmers, tbl)
-    assert engine._lib.lib().ppk_last_kernel_name().decode().endswith("k-split fused>")
+    assert engine._lib.lib().ppk_last_kernel_name().decode().endswith("k-split fused,fit from parts>")
     ppk_option("ksplit_long", 0)
     whole, gf = engine.dist(db, None, kmers, tbl)
     assert engine._lib.lib().ppk_last_kernel_name().decode().endswith("lds-dma>")

@@ -303,7 +303,7 @@ def test_small_wide_jobs_take_the_k_split_path_and_return_the_tile_kernels_bits(
     for slices in (0, 1, 2, 4):
         ppk_option("ksplit_slices", slices)
         got, _ = engine.dist(sdb, None, kmers, tbl)
-        assert not name().endswith("wide>")
+        assert name().endswith("fit from parts>")
         assert torch_equal_bits(got, base), slices
     # ... long sketches take that path at any size its scratch allows (option "ksplit_long"); without it a job of
     # more than 215 * 5 / nk tiles (1 400 self: 176 tiles) is the tile kernel's
@@ -315,6 +315,22 @@ def test_small_wide_jobs_take_the_k_split_path_and_return_the_tile_kernels_bits(
     assert name().endswith("wide>")
     for db in (rdb, sdb, big):
         db.close()
+    # the same fit-from-parts unit kernel on a list the register holds (option "wide_kpg"): the register path's bits
+    k5 = np.asarray(synth.DEFAULT_KMERS, dtype=np.int32)
+    for s64_, n_ in ((156, 700), (16, 900)):
+        sk5, _ = synth.make_sketches(n_, k5, sketchsize64=s64_, bbits=14, cluster_size=20, seed=5)
+        sk5[3] = sk5[2]
+        t5 = _table(k5)
+        d5 = engine.SketchDB(sk5, s64_, 14)
+        ppk_option("wide_kpg", 0)
+        a, fa = engine.dist(d5, None, k5, t5)
+        assert name().endswith("k-split fused>") == (s64_ == 16)      # (70 count bits at s = 9 984: from the parts anyway)
+        ppk_option("wide_kpg", 2)
+        b, fb = engine.dist(d5, None, k5, t5)
+        assert name().endswith("fit from parts>")
+        ppk_option("wide_kpg", 0)
+        assert torch_equal_bits(a, b) and int(fa.item()) == int(fb.item())
+        d5.close()
 
 
 def torch_equal_bits(a, b):

@@ -28,11 +28,12 @@ for kmers in [np.arange(13, 30, 4), np.arange(13, 30, 2), np.arange(6, 16), np.a
         rt, qt = (n + 255) // 256, (n + 31) // 32
         tiles = rt * qt // 2 + qt
         res = []
-        for ks, ksw in ((0, 0), (100000, 100000)):
-            _lib.set_option("ksplit", ks); _lib.set_option("ksplit_wide", ksw)
+        for ks, ksw, kpg in ((0, 0, 0), (100000, 100000, 0), (100000, 100000, 1)):
+            _lib.set_option("ksplit", ks); _lib.set_option("ksplit_wide", ksw); _lib.set_option("wide_kpg", kpg)
             res.append(kms(lambda: engine.dist(db, None, kmers, tbl, out=out)))
-        print("s64=%d " % S64 + "nk=%2d n=%4d tiles=%4d (x5/nk: %4d)  tile kernel %8.3f ms   k-split %8.3f ms   %s" % (
-            len(kmers), n, tiles, tiles * len(kmers) // 5, res[0], res[1], "k-split" if res[1] < res[0] else "tile"), flush=True)
+        _lib.set_option("wide_kpg", 0)
+        print("s64=%d " % S64 + "nk=%2d n=%4d tiles=%4d (x5/nk: %4d)  tile kernel %8.3f ms   k-split %8.3f ms   k-split, fit from parts %8.3f ms   %s" % (
+            len(kmers), n, tiles, tiles * len(kmers) // 5, res[0], res[1], res[2], "k-split" if min(res[1], res[2]) < res[0] else "tile"), flush=True)
         db.close(); del out
     del allsk; torch.cuda.empty_cache()
 _lib.set_option("ksplit", 1200); _lib.set_option("ksplit_wide", 215)
