@@ -154,6 +154,7 @@ struct DistParams {
   int ks_blocks;          // KSPLIT: 64-bin blocks one workgroup compares (s64 / k_split)
   unsigned ks_units;      // KSPLIT, fused fit: workgroups per tile (nk * k_split = gridDim.y)
   size_t ks_part_off;     // KSPLIT, fused fit: byte offset of the partial counts behind the tile counters
+  unsigned *ks_tickets;   // KSPLIT, fused fit: one counter per tile (zero between launches)
   unsigned r_tiles, q_tiles;   // v2 tile grid
   unsigned n_strip_pad;        // n_strip rounded up to a multiple of 8 (keeps block % 8 = XCD for the rest)
   unsigned n_tiles;            // non-empty tiles of the triangle / rectangle part
@@ -879,7 +880,8 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
   // WIDE without KSPLIT: the tile kernel whose count register windows the k list (PackWide).  WIDE with KSPLIT: a
   // k-split unit (it counts ONE k, or a piece of one: W = 2 holds it) whose tile is fitted by its last unit straight
   // from the units' partial counts (PackParts) -- no count register is ever rebuilt, so any k list fits.
-  static_assert(!WIDE || (KSPLIT ? (W == 2 && MODE == MODE_DIST) : (W == 4 && (MODE == MODE_DIST || MODE == MODE_MASK || MODE == MODE_KNN))),
+  static_assert(!WIDE || (KSPLIT ? (W == 2 && (MODE == MODE_DIST || MODE == MODE_MASK))
+                                 : (W == 4 && (MODE == MODE_DIST || MODE == MODE_MASK || MODE == MODE_KNN))),
                 "the wide instantiations");
   constexpr bool WIDE_TILE = WIDE && !KSPLIT;
   const int ablate = EXP ? p.ablate : 0;
@@ -900,7 +902,9 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
   constexpr int TAB_U4 = 5 * 1024;
   // KS_FUSED: a k-split job whose tiles are fitted by their last workgroup (below); one more entry behind the
   // compare buffers holds the workgroup's grid position across the loop, in LDS instead of two SGPRs
-  constexpr bool KS_FUSED = KSPLIT && MODE == MODE_DIST;
+  // (the fused boundary mode only in the fit-from-parts form: its tiles take the general statement of the epilogue,
+  // which knows which pairs exist; the LDS-table statement of a k-split tile writes distances only)
+  constexpr bool KS_FUSED = KSPLIT && (MODE == MODE_DIST || (MODE == MODE_MASK && WIDE));
   constexpr bool KS_MEM = KS_FUSED && WIDE;
   constexpr int KS_SLOT = 2 * CHUNK_U4;      // (WIDE: the workgroup's spill slot index lives there)
   __shared__ u32x4 lds[LDS_TABLE && TAB_U4 > 2 * CHUNK_U4 + 1 ? TAB_U4 : 2 * CHUNK_U4 + (KS_FUSED || WIDE ? 1 : 0)];
@@ -1319,9 +1323,9 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
       const uint32_t tile = __builtin_amdgcn_readfirstlane(pos.x), unit = __builtin_amdgcn_readfirstlane(pos.y);
       const uint32_t units = pl.ks_units;
       const uint32_t tid = (uint32_t)wave * 64u + (uint32_t)lane_late;
-      unsigned *tickets = reinterpret_cast<unsigned *>(mask_out);
+      unsigned *tickets = pl.ks_tickets;
       // partial counts: uint64 [tile][unit][4][512 threads] -- a wavefront's store covers 512 consecutive bytes
-      uint64_t *part = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(mask_out) + pl.ks_part_off);
+      uint64_t *part = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(pl.ks_tickets) + pl.ks_part_off);
       // Visibility between workgroups, which may run on different XCDs (each with its own L2): every access to
       // the partial counts and to the ticket is an AGENT-scope atomic (relaxed: stores written through, loads
       // served coherently -- the sc1 forms), and the ticket is taken only after this wavefront's stores have
@@ -1365,7 +1369,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
         LateParams &pl = p_late;
         const int slices = pl.k_split, nkk = pl.nk, up = 32 - pl.cnt_bits;
         const uint32_t tid = (uint32_t)wave * 64u + (uint32_t)lane_late;
-        uint64_t *src = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(mask_out) + pl.ks_part_off) +
+        uint64_t *src = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(pl.ks_tickets) + pl.ks_part_off) +
                         (size_t)ks_tile * pl.ks_units * (4 * NW * 64) + tid;
 #pragma unroll
         for (int i = 0; i < W; ++i)
@@ -1670,7 +1674,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
     using EpiPack = std::conditional_t<WIDE_TILE, PackWide, std::conditional_t<KS_MEM, PackParts, PackT>>;
     const unsigned long long *parts_src = nullptr;      // KS_MEM: the lane's first partial-count word of this tile
     if constexpr (KS_MEM)
-      parts_src = reinterpret_cast<const unsigned long long *>(reinterpret_cast<const char *>(mask_out) + p.ks_part_off) +
+      parts_src = reinterpret_cast<const unsigned long long *>(reinterpret_cast<const char *>(p.ks_tickets) + p.ks_part_off) +
                   (size_t)ks_tile * p.ks_units * KS_UNIT_U64 + ((uint32_t)wave * 64u + (uint32_t)lane_late);
     auto batch_operands = [&](int bq, int br0, size_t (&cpo)[NRB], uint32_t (&loff)[NRB], EpiPack (&pk)[NRB]) {
       const size_t qq = qw0 + bq;
@@ -2249,10 +2253,10 @@ int launch_v2(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const f
   const size_t n_blocks = n_tri + p.n_strip_pad;
   if (n_blocks * (size_t)(NW * 64) >= ((size_t)1 << 32))
     return ppk_fail(PPK_ERR_ARG, "internal: tile grid too large for one launch (ppk_launch_dist splits bands before this)");
-  if (MODE == MODE_DIST && NW == 8 && p.k_split) {
+  if ((MODE == MODE_DIST || MODE == MODE_MASK) && NW == 8 && p.k_split) {
     // k-split job in one launch: ks_units workgroups per tile, the last one to finish fits it (KS_FUSED in the
     // kernel).  Scratch: one zero-initialised counter per tile; 32 bytes per (tile, unit, thread) of partial counts.
-    if constexpr (MODE == MODE_DIST && NW == 8 && W == 2) {
+    if constexpr (NW == 8 && W == 2 && (MODE == MODE_DIST || (MODE == MODE_MASK && WIDE))) {
       void *d_tickets = nullptr, *d_part = nullptr;
       const size_t ticket_bytes = (n_blocks * 4 + 255) / 256 * 256;
       int rc = ppk_scratch_get(ref->device, SLOT_TICKETS, ticket_bytes, &d_tickets);
@@ -2260,16 +2264,18 @@ int launch_v2(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const f
       rc = ppk_scratch_get(ref->device, SLOT_ITER_A, n_blocks * (size_t)p.ks_units * (NW * 64) * 32 + 256, &d_part);
       if (rc != PPK_OK) return rc;
       p.ks_part_off = (size_t)(static_cast<char *>(d_part) - static_cast<char *>(d_tickets));
+      p.ks_tickets = static_cast<unsigned *>(d_tickets);
       ppk_set_kernel_name(WIDE ? "dist_kernel_v2<256x32,lds-dma,k-split fused,fit from parts>" : "dist_kernel_v2<256x32,lds-dma,k-split fused>");
       ppk_prof_begin(s);
       hipLaunchKernelGGL((dist_kernel_v2<NW, MODE, W, true, WIDE>), dim3((unsigned)n_blocks, p.ks_units),
                          dim3(NW * 64), 0, s, ref->d_skT, qry->d_skT, d_lut,
                          use_clu ? ref->d_clu : nullptr, use_clu ? qry->d_clu : nullptr, d_rtab, d_out,
-                         d_n_failed, static_cast<uint64_t *>(d_tickets), p);
+                         d_n_failed, d_mask, p);
       ppk_prof_end(s);
       PPK_HIP(hipGetLastError());
       return PPK_OK;
     }
+    return ppk_fail(PPK_ERR_STATE, "internal: no k-split instantiation for this mode");
   }
   if constexpr (WIDE && W != 4) {
     return ppk_fail(PPK_ERR_STATE, "internal: the fit-from-parts instantiation is a k-split kernel");
@@ -2361,6 +2367,9 @@ int launch_tiles_packed(const ppk_db *ref, const ppk_db *qry, const double *d_lu
   }
   // (option "wide_kpg": a narrower window, i.e. the wide path on a k list the register would hold -- tests)
   const long long force_kpg = ppk_config().wide_kpg.load();
+  if constexpr (MODE == MODE_MASK) {
+    if (p.k_split) return launch_v2<8, MODE, 2, true>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
+  }
   if constexpr (MODE == MODE_DIST) {
     // a k-split job whose tiles are fitted from the units' partial counts as they lie (any k list)
     // (every k list of more than 64 count bits: rebuilding three- and four-dword registers in the last unit measured
@@ -2504,7 +2513,10 @@ static int launch_dist_band(const ppk_db *ref, const ppk_db *qry_or_null, const 
   // of queries): one workgroup per (tile, k) instead of per tile -- nk times the parallelism, a
   // serial chain of s64 blocks instead of nk * s64 -- writing raw counts, then the regression pass.
   bool small = false;
-  if (!too_wide && !d_mask && !knn_args && p.bbits == 14 && p.nk >= 2) {
+  // (the fused boundary mode takes the path in its one-launch form on long sketches only: edge_ks below)
+  const bool edge_ks = d_mask && p.s64 >= 32 && ppk_config().ksplit_long.load() != 0 && ppk_config().ksplit_fused.load() != 0 &&
+                       64 * (size_t)p.s64 < 65536 && p.s64 >= 2;
+  if (!too_wide && (!d_mask || edge_ks) && !knn_args && p.bbits == 14 && p.nk >= 2) {
     const size_t rt = (ref->n + V2_RT - 1) / V2_RT, qt = (q_end - q_begin + 31) / 32;
     // default 1 200 tiles at 5 k since the one-launch form (round 4; profiles/r04/ksplit_threshold*.txt: it wins by
     // 10 - 50 % up to 4 000 genomes / 1 125 tiles and ties from there to 1 800 tiles; 215 with the two-pass form)
@@ -2538,6 +2550,7 @@ static int launch_dist_band(const ppk_db *ref, const ppk_db *qry_or_null, const 
       if (scratch <= ((size_t)4 << 30) && (p.s64 >= 64 || tiles <= 6600) && (one_launch || tiles <= 700)) limit = tiles;
     }
     small = tiles <= limit;
+    if (d_mask && limit != tiles) small = false;      // (only what the long-sketch rule admitted)
   }
   if (too_wide && knn_args) return ppk_fail(PPK_ERR_ARG, "neighbours from tiles need bbits = 14");
   if (too_wide) {
@@ -2602,8 +2615,14 @@ static int launch_dist_band(const ppk_db *ref, const ppk_db *qry_or_null, const 
     // (a unit's counts travel as 16-bit numbers; fitted from the parts as they lie, a k's pieces are added in place)
     const bool from_parts = p.nk * p.cnt_bits > 64 || (ppk_config().wide_kpg.load() > 0 && ppk_config().wide_kpg.load() < p.nk);
     if (ppk_config().ksplit_fused.load() != 0 && p.ks_blocks >= 2 && 64 * (size_t)p.ks_blocks < 65536 &&
-        (!from_parts || 64 * (size_t)p.s64 < 65536))
+        (!from_parts || 64 * (size_t)p.s64 < 65536)) {
+      if (d_mask) return launch_tiles_packed<MODE_MASK>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
       return launch_tiles_packed<MODE_DIST>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, nullptr, p, s);
+    }
+    if (d_mask) {      // (cannot happen: edge_ks admits one-launch shapes only; stay on the tile kernel)
+      p.k_split = 0;
+      return launch_tiles_packed<MODE_MASK>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
+    }
     void *p_cnt = nullptr;
     int rc = ppk_scratch_get(ref->device, SLOT_ITER_A, rows * (size_t)p.nk * slices * 4 + 256, &p_cnt);
     if (rc != PPK_OK) return rc;

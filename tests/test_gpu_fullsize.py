@@ -169,8 +169,15 @@ def test_default_sketch_size_many_ref_tiles(nk, ppk_option):
     pieces = [engine.dist(db, None, kmers, tbl, q_begin=a, q_end=b)[0] for a, b in zip(cuts[:-1], cuts[1:])]
     assert torch.equal(torch.cat(pieces), whole)
     x_max, y_max = synth.boundary_for_quantile(want, 0.05)
-    e, _ = engine.dist_edges(db, None, kmers, tbl, slope=2, x_max=x_max, y_max=y_max)
+    e, _ = engine.dist_edges(db, None, kmers, tbl, slope=2, x_max=x_max, y_max=y_max)      # (the tile kernel: "ksplit_long" is 0)
     assert np.array_equal(e.cpu().numpy(), oracle.edge_threshold(want, 2, x_max, y_max))
+    # the fused edge list through the k-split path (long sketches: the default), whole and in bands
+    ppk_option("ksplit_long", 1)
+    e2, _ = engine.dist_edges(db, None, kmers, tbl, slope=2, x_max=x_max, y_max=y_max)
+    assert torch.equal(e, e2)
+    parts = [engine.dist_edges(db, None, kmers, tbl, slope=2, x_max=x_max, y_max=y_max, inclusive=False, q_begin=a, q_end=b)[0]
+             for a, b in zip(cuts[:-1], cuts[1:])]
+    assert np.array_equal(torch.cat(parts).cpu().numpy(), oracle.edge_threshold(want, 2, x_max, y_max, inclusive=False))
     db.close()
     nr = 1500
     got, gf2 = pp_sketchlib.query_arrays(sk[:nr], sk[nr:], kmers, 156, 14, tbl)
