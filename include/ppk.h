@@ -77,6 +77,10 @@ int ppk_device_count(int *n);
  *     "ksplit" (1200), "ksplit_wide" (215)  tile-count threshold (at 5 k) below which a job runs one workgroup per
  *                       (tile, k) -- the small-job path; the second applies to sketch shapes whose
  *                       tiles are not fitted from the LDS table; 0 = off
+ *     "ksplit_long" (1)    sketches of sketchsize64 >= 32 (PopPUNK's default is 156) take that path at ANY job size
+ *                          whose scratch stays below 4 GB -- one k at a time keeps a k of the database in the Infinity
+ *                          Cache and short units fill the last round of workgroup slots; distances and the fused
+ *                          edge list alike; 0 = the tile-count thresholds only
  *     "ksplit_fused" (1)   small jobs run ONE launch (the tile's last unit fits it); 0 = counts pass + fit pass
  *     "ksplit_slices" (0)  pieces each k is cut into on the small-job path (0 = from the job's size)
  *     "lds_table" (1)      interior tiles of the default shape (3-5 k, s = 1024) fit from the (E, F) table in LDS

@@ -38,7 +38,7 @@ extern "C" const char *ppk_last_error(void) { return g_err.c_str(); }
 #define PPK_SRC_HASH "unhashed"
 #endif
 // "... src:<hash>": sha256 (16 hex digits) of the library's sources at build time (csrc/Makefile HASHED)
-extern "C" const char *ppk_version(void) { return "poppunk_amd 0.4.0 (gfx950) src:" PPK_SRC_HASH; }
+extern "C" const char *ppk_version(void) { return "poppunk_amd 0.5.0 (gfx950) src:" PPK_SRC_HASH; }
 
 // ---- run-time options: PPK_* environment read once, then ppk_set_option only ------------------
 namespace {

@@ -44,7 +44,7 @@ from . import _lib, sketchdb
 # PopPUNK parses this as dotted integers (checkSketchlibVersion, PopPUNK/sketchlib.py:49-50) and wants
 # >= 2.0.1 (PopPUNK/__init__.py:9-11): plain numbers only.  The build of this package is `amd_build`.
 version = "2.1.4"
-amd_build = "poppunk_amd 0.4.0 (gfx950)"
+amd_build = "poppunk_amd 0.5.0 (gfx950)"
 
 
 class _Entry:

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Regenerates the measured artefacts of a round under gpurun_out/$ROUND (run through gpurun from the repo root):
-#   ROUND=r04 tools/collect_profiles.sh     then `ROUND=r04 python tools/update_profiles.py` copies into profiles/
+#   ROUND=r05 tools/collect_profiles.sh     then `ROUND=r05 python tools/update_profiles.py` copies into profiles/
 # FULL=1 adds the micro-benchmarks and host A/Bs of earlier rounds.
 set -u
-ROUND=${ROUND:-r04}
+ROUND=${ROUND:-r05}
 OUT=gpurun_out/$ROUND
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:-/root/repo}"
@@ -21,9 +21,10 @@ rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLE
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM GRBM_GUI_ACTIVE SQ_ACTIVE_INST_LDS --output-format csv -d $OUT/pmc_lds -o l -- $S > /dev/null 2>&1
 python tools/ab_smalljob.py > $OUT/smalljob.txt 2>&1
 python tools/ab_smalljob.py ksplit_fused=0 > $OUT/smalljob_two_pass.txt 2>&1
-python tools/stall_hunt.py 100000 30 > $OUT/stall_hunt.txt 2> /dev/null
 python tools/ab_pinning.py 2>&1 | grep -v amdgpu > $OUT/ab_pinning.txt
 python tools/latency_table.py 2>&1 | grep -v amdgpu > $OUT/latency_table.txt
+python tools/time_wide.py 2>&1 | grep -v amdgpu > $OUT/time_wide.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/k2 -o k2 -- python tools/k2_trace.py 200 > $OUT/k2_trace.txt 2>&1
 PPK_BENCH_ONE_GPU=1 PPK_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 2 --steps 5 --warmup 2 --config5-genomes 20000 --no-cpu > $OUT/two_ranks_one_gpu.json 2> $OUT/two_ranks_one_gpu.err
 if [ "${FULL:-0}" = "1" ]; then
   timeout 1500 python tools/measure_configs.py $OUT/configs.json > $OUT/configs.log 2>&1

@@ -15,7 +15,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = os.environ.get("ROUND", "r04")
+ROUND = os.environ.get("ROUND", "r05")
 SRC = os.path.join(ROOT, "gpurun_out", ROUND)
 DST = os.path.join(ROOT, "profiles", ROUND)
 KERNEL = "dist_kernel_v2"
@@ -36,9 +36,13 @@ def main():
         shutil.copy(ktc, os.path.join(DST, "configs_kernel_stats.csv"))
     for f in glob.glob(os.path.join(SRC, "ubench_*.txt")) + [os.path.join(SRC, x) for x in (
             "power_clocks.txt", "ab_host.txt", "ab_host_parts.txt", "knn_from_tiles.txt", "two_ranks_one_gpu.json",
-            "smalljob.txt", "smalljob_two_pass.txt", "stall_hunt.txt", "ab_pinning.txt", "latency_table.txt")]:
+            "smalljob.txt", "smalljob_two_pass.txt", "stall_hunt.txt", "ab_pinning.txt", "latency_table.txt", "time_wide.txt",
+            "k2_trace.txt")]:
         if os.path.exists(f):
             shutil.copy(f, DST)
+    k2 = glob.glob(os.path.join(SRC, "k2", "*", "k2_kernel_stats.csv")) + glob.glob(os.path.join(SRC, "k2", "k2_kernel_stats.csv"))
+    if k2:       # kernel 2 on rotating (cold-cache) matrices: per-kernel averages
+        shutil.copy(k2[0], os.path.join(DST, "kernel2_kernel_stats.csv"))
     counters = {}
     kname = None
     for d in sorted(glob.glob(os.path.join(SRC, "pmc_*"))):
