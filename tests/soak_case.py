@@ -1,6 +1,6 @@
 """One randomised differential case, GPU path (through the C ABI) vs the CPU oracle -- shared by
 tests/test_gpu_soak.py (the driver's GPU suite runs 600 + a few large ones) and tools/soak.py (the
-builder's longer campaigns): random n / split / bands, nk 2..11 (12..33: the wide-k tile kernel), sketchsize64 1..40, bbits in {14 (tile
+builder's longer campaigns): random n / split / bands, nk 2..11 (12..33: the wide-k tile kernel), sketchsize64 1..156, bbits in {14 (tile
 kernel), 8, 16 (generic kernel)}, multi-cluster random tables in random or contiguous runs, related /
 unrelated data, counts / jaccard / distance / fused-edge modes, neighbours from the tiles, both
 settings of the two [EXT] switches (kernel and oracle flipped together).
@@ -31,14 +31,14 @@ def soak_case(rng, big=False):
     """Runs one case drawn from `rng`; returns (description, list of mismatch messages)."""
     import torch
     bbits = int(rng.choice([14, 14, 14, 8, 16]))
-    s64 = int(rng.choice([1, 2, 3, 16, 16, 16, 5, 40]))
+    s64 = int(rng.choice([1, 2, 3, 16, 16, 16, 5, 40, 64, 156]))      # (32 and up: the long-sketch rule, k-split at any size)
     nk = int(rng.integers(2, 12))      # count registers of 2, 3 and 4 dwords
     wide_list = bbits == 14 and rng.integers(0, 5) == 0
     if wide_list:                      # the wide-k tile kernel: more than 128 count bits per pair
         nk = int(rng.integers(12, 34))
     k0 = int(rng.integers(9, 16)) if not wide_list else int(rng.integers(7, 12))
     kmers = (k0 + np.arange(nk) * (int(rng.integers(1, 5)) if not wide_list else int(rng.integers(1, 3)))).astype(np.int32)
-    n = int(rng.integers(2, 1400 if s64 <= 16 else 500))
+    n = int(rng.integers(2, 1400 if s64 <= 16 else (500 if s64 <= 64 else 320)))
     if big:        # many ref tiles: the default-shape kernel at scale
         bbits, s64 = 14, 16
         n = int(rng.integers(2000, 7000))
