@@ -76,7 +76,8 @@ int ppk_device_count(int *n);
  *   kernel 1
  *     "ksplit" (1200), "ksplit_wide" (215)  tile-count threshold (at 5 k) below which a job runs one workgroup per
  *                       (tile, k) -- the small-job path; the second applies to sketch shapes whose
- *                       tiles are not fitted from the LDS table; 0 = off
+ *                       tiles are not fitted from the LDS table (from sketchsize64 16 up the threshold is at least
+ *                       700 tiles whatever nk: measured, profiles/r05/ksplit_s1024_other_shapes.txt); 0 = off
  *     "ksplit_long" (1)    sketches of sketchsize64 >= 32 (PopPUNK's default is 156) take that path at ANY job size
  *                          whose scratch stays below 4 GB -- one k at a time keeps a k of the database in the Infinity
  *                          Cache and short units fill the last round of workgroup slots; distances and the fused

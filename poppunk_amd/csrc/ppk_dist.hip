@@ -2531,6 +2531,11 @@ static int launch_dist_band(const ppk_db *ref, const ppk_db *qry_or_null, const 
     long long ks = ppk_config().ksplit.load();   // tile-count threshold at 5 k, 0 = off
     if (!lds_fit && ks > ppk_config().ksplit_wide.load()) ks = ppk_config().ksplit_wide.load();
     size_t limit = ks > 0 ? (size_t)ks * 5 / (size_t)p.nk : 0;
+    // s = 1 024 with a k list the LDS table does not serve (6 k and up): in TILES the crossover does not move with
+    // nk -- profiles/r05/ksplit_s1024_other_shapes.txt: 9 / 10 / 17 / 21 lengths, tile kernel -> k-split, ms: 1 000
+    // genomes (96 tiles) 0.29 -> 0.17 / 0.34 -> 0.26 / 0.55 -> 0.29 / 0.76 -> 0.44; 3 000 (658 tiles) 0.71 -> 0.55 / 0.91 ->
+    // 0.81 / 1.36 -> 1.02 / 2.00 -> 1.88; level at 4 000 (1 125 tiles), behind from 6 000
+    if (!lds_fit && ks > 0 && p.s64 >= 16 && limit < 700 && ppk_config().ksplit_wide.load() >= 215) limit = 700;
     const size_t tiles = p.self ? rt * qt / 2 + qt : rt * qt;
     // LONG sketches (sketchsize64 >= 32; PopPUNK's default is 156): a pair tile is a serial chain of nk * s64 blocks --
     // 780 at the default, ~1 ms -- so whole tiles fill the last round of workgroup slots badly at ANY job size, and

@@ -155,11 +155,11 @@ def test_default_sketch_size_many_ref_tiles(nk, ppk_option):
     del counts
     want, wf = oracle.query(sk, None, kmers, 156, 14, tbl, threads=THREADS)
     db = engine.SketchDB(sk, 156, 14)
-    # long sketches take the k-split path at any size by default (round 5); the tile kernel itself with "ksplit_long" 0:
+    # long sketches take the k-split path at any size by default (round 5); the tile kernel itself with "ksplit" 0:
     # the same bits either way
     by_units, gf_u = engine.dist(db, None, kmers, tbl)
     assert engine._lib.lib().ppk_last_kernel_name().decode().endswith("k-split fused,fit from parts>")
-    ppk_option("ksplit_long", 0)
+    ppk_option("ksplit", 0)
     whole, gf = engine.dist(db, None, kmers, tbl)
     assert engine._lib.lib().ppk_last_kernel_name().decode().endswith("lds-dma>")
     assert int(gf.item()) == wf == int(gf_u.item()) and torch.equal(by_units.view(torch.int32), whole.view(torch.int32))
@@ -169,10 +169,10 @@ def test_default_sketch_size_many_ref_tiles(nk, ppk_option):
     pieces = [engine.dist(db, None, kmers, tbl, q_begin=a, q_end=b)[0] for a, b in zip(cuts[:-1], cuts[1:])]
     assert torch.equal(torch.cat(pieces), whole)
     x_max, y_max = synth.boundary_for_quantile(want, 0.05)
-    e, _ = engine.dist_edges(db, None, kmers, tbl, slope=2, x_max=x_max, y_max=y_max)      # (the tile kernel: "ksplit_long" is 0)
+    e, _ = engine.dist_edges(db, None, kmers, tbl, slope=2, x_max=x_max, y_max=y_max)      # (the tile kernel: "ksplit" is 0)
     assert np.array_equal(e.cpu().numpy(), oracle.edge_threshold(want, 2, x_max, y_max))
     # the fused edge list through the k-split path (long sketches: the default), whole and in bands
-    ppk_option("ksplit_long", 1)
+    ppk_option("ksplit", 1200)
     e2, _ = engine.dist_edges(db, None, kmers, tbl, slope=2, x_max=x_max, y_max=y_max)
     assert torch.equal(e, e2)
     parts = [engine.dist_edges(db, None, kmers, tbl, slope=2, x_max=x_max, y_max=y_max, inclusive=False, q_begin=a, q_end=b)[0]

@@ -62,10 +62,10 @@ def test_documented_k_lists_at_the_default_sketch_size(kmers, ppk_option):
     db = engine.SketchDB(sk, s64, 14, clusters=clu)
     d_ks, f_ks = engine.dist(db, None, kmers, tbl)          # default: one workgroup per (tile, k) + the fit pass
     assert not engine._lib.lib().ppk_last_kernel_name().decode().endswith("wide>")
-    ppk_option("ksplit_long", 0)
+    ppk_option("ksplit", 0)
     d, f = engine.dist(db, None, kmers, tbl)
     assert engine._lib.lib().ppk_last_kernel_name().decode().endswith("wide>")
-    ppk_option("ksplit_long", 1)
+    ppk_option("ksplit", 1200)
     assert int(f.item()) == wf == int(f_ks.item())
     assert np.array_equal(d.cpu().numpy().view(np.uint32), d_ks.cpu().numpy().view(np.uint32))
     _close(d.cpu().numpy(), want, "distances nk=%d" % len(kmers))
@@ -251,12 +251,12 @@ def test_one_100000_genome_band_with_ten_kmer_lengths():
     a = oracle.assign_threshold(rect, 2, x_max, y_max, threads=THREADS).reshape(qe - qb, n)
     d, f = engine.dist(db, None, kmers, tbl, q_begin=qb, q_end=qe)          # (a band of ~400 pair tiles: the k-split path's two-pass form)
     _lib_name = engine._lib.lib().ppk_last_kernel_name().decode()
-    engine._lib.set_option("ksplit_long", 0)
+    engine._lib.set_option("ksplit", 0)
     try:
         d2, _ = engine.dist(db, None, kmers, tbl, q_begin=qb, q_end=qe)
         assert engine._lib.lib().ppk_last_kernel_name().decode().endswith("wide>") and not _lib_name.endswith("wide>")
     finally:
-        engine._lib.set_option("ksplit_long", 1)
+        engine._lib.set_option("ksplit", 1200)
     assert np.array_equal(d.cpu().numpy().view(np.uint32), d2.cpu().numpy().view(np.uint32))
     got = d.cpu().numpy()
     rows = np.concatenate([rect.reshape(qe - qb, n, 2)[q - qb, q + 1:] for q in range(qb, qe)])
@@ -305,14 +305,18 @@ def test_small_wide_jobs_take_the_k_split_path_and_return_the_tile_kernels_bits(
         got, _ = engine.dist(sdb, None, kmers, tbl)
         assert name().endswith("fit from parts>")
         assert torch_equal_bits(got, base), slices
-    # ... long sketches take that path at any size its scratch allows (option "ksplit_long"); without it a job of
-    # more than 215 * 5 / nk tiles (1 400 self: 176 tiles) is the tile kernel's
+    # ... long sketches take that path at any size its scratch allows (option "ksplit_long"), other shapes up to 700
+    # tiles (1 400 self: 176 tiles); "ksplit" 0 is the tile kernel
     big = engine.SketchDB(sk, s64, 14, clusters=clu)
     engine.dist(big, None, kmers, tbl)
     assert not name().endswith("wide>")
     ppk_option("ksplit_long", 0)
     engine.dist(big, None, kmers, tbl)
+    assert not name().endswith("wide>")
+    ppk_option("ksplit", 0)
+    engine.dist(big, None, kmers, tbl)
     assert name().endswith("wide>")
+    ppk_option("ksplit", 1200)
     for db in (rdb, sdb, big):
         db.close()
     # the same fit-from-parts unit kernel on a list the register holds (option "wide_kpg"): the register path's bits
@@ -336,3 +340,25 @@ def test_small_wide_jobs_take_the_k_split_path_and_return_the_tile_kernels_bits(
 def torch_equal_bits(a, b):
     import torch
     return bool(torch.equal(a.view(torch.int32), b.view(torch.int32)))
+
+
+def test_long_sketch_rule_is_a_switch_and_changes_no_bit(ppk_option):
+    """sketchsize64 32, 4 000 genomes (1 125 pair tiles: beyond every tile-count threshold): "ksplit_long" 1 (default)
+    runs the k-split path, 0 the tile kernel; distances and the fused edge list agree bit for bit."""
+    k5 = np.asarray(synth.DEFAULT_KMERS, dtype=np.int32)
+    sk, _ = synth.make_sketches(4000, k5, sketchsize64=32, bbits=14, cluster_size=40, seed=8)
+    tbl = _table(k5)
+    db = engine.SketchDB(sk, 32, 14)
+    name = lambda: engine._lib.lib().ppk_last_kernel_name().decode()
+    a, fa = engine.dist(db, None, k5, tbl)
+    assert "k-split" in name()
+    x_max, y_max = synth.boundary_for_quantile(a[:200000].cpu().numpy(), 0.05)
+    ea, _ = engine.dist_edges(db, None, k5, tbl, slope=2, x_max=x_max, y_max=y_max)
+    ppk_option("ksplit_long", 0)
+    b, fb = engine.dist(db, None, k5, tbl)
+    assert name().endswith("lds-dma>")
+    eb, _ = engine.dist_edges(db, None, k5, tbl, slope=2, x_max=x_max, y_max=y_max)
+    assert torch_equal_bits(a, b) and int(fa.item()) == int(fb.item())
+    import torch
+    assert torch.equal(ea, eb) and len(ea) > 1000
+    db.close()

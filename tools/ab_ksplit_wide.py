@@ -17,7 +17,7 @@ def kms(fn, reps=5):
     ms, cnt = C.c_double(0), C.c_longlong(0); lib.ppk_prof_read(C.byref(ms), C.byref(cnt), 1)
     return ms.value / reps
 
-for kmers in [np.arange(13, 30, 4), np.arange(13, 30, 2), np.arange(6, 16), np.arange(13, 30)][int(os.environ.get('K0', 0)):int(os.environ.get('K1', 4))]:
+for kmers in [np.arange(13, 30, 4), np.arange(13, 30, 2), np.arange(6, 16), np.arange(13, 30), np.arange(11, 32)][int(os.environ.get('K0', 0)):int(os.environ.get('K1', 5))]:
     kmers = kmers.astype(np.int32)
     tbl = synth.random_match_table(kmers, genome_length=20000 if kmers[0] < 10 else 2000000)
     sizes = [int(x) for x in os.environ.get('SIZES', '600,1000,1400,1800,2200,2600,3000,3400').split(',')]
