@@ -1341,15 +1341,27 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
         const uint64_t v2 = (uint64_t)(pw[0][0][2] | (pw[0][1][2] << 16)) | ((uint64_t)(pw[0][2][2] | (pw[0][3][2] << 16)) << 32);
         const uint64_t v3 = (uint64_t)(pw[0][0][3] | (pw[0][1][3] << 16)) | ((uint64_t)(pw[0][2][3] | (pw[0][3][3] << 16)) << 32);
         uint64_t *mine = part + ((size_t)tile * units + unit) * (4 * NW * 64) + tid;
-        __hip_atomic_store(mine, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(mine + NW * 64, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(mine + 2 * NW * 64, v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(mine + 3 * NW * 64, v3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (EXP && (ablate & 256)) {
+          // (experiments build, bit 256, TIMING ONLY: the hand-over through the XCD's own L2 -- plain stores, an L2
+          // ticket, plain reloads -- which is right only if every unit of a tile runs on one XCD, something the
+          // dispatch order gives today and nothing promises: what trusting it could win)
+          mine[0] = v0;
+          mine[NW * 64] = v1;
+          mine[2 * NW * 64] = v2;
+          mine[3 * NW * 64] = v3;
+        } else {
+          __hip_atomic_store(mine, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(mine + NW * 64, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(mine + 2 * NW * 64, v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(mine + 3 * NW * 64, v3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wavefront's stores are done
       __syncthreads();
       if (tid == 0) {
-        const unsigned t = __hip_atomic_fetch_add(tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned t = (EXP && (ablate & 256))
+                               ? __hip_atomic_fetch_add(tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                               : __hip_atomic_fetch_add(tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *reinterpret_cast<volatile unsigned *>(&lds[KS_SLOT]) = t;
       }
       __syncthreads();
@@ -1391,8 +1403,9 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
     pw[0][2][q] += b_ & 0xffffu;                                         \
     pw[0][3][q] += b_ >> 16;                                             \
   }
-#define PPK_KS_LOAD(unit_, q) \
-  __hip_atomic_load(src + (size_t)(unit_) * (4 * NW * 64) + (q) * NW * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define PPK_KS_LOAD(unit_, q)                                                                          \
+  ((EXP && (ablate & 256)) ? src[(size_t)(unit_) * (4 * NW * 64) + (q) * NW * 64]                       \
+                           : __hip_atomic_load(src + (size_t)(unit_) * (4 * NW * 64) + (q) * NW * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
         if (nkk <= 5 && slices == 1) {
           uint64_t c[5][TQ];
 #pragma unroll
@@ -2267,6 +2280,18 @@ int launch_v2(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const f
       p.ks_tickets = static_cast<unsigned *>(d_tickets);
       ppk_set_kernel_name(WIDE ? "dist_kernel_v2<256x32,lds-dma,k-split fused,fit from parts>" : "dist_kernel_v2<256x32,lds-dma,k-split fused>");
       ppk_prof_begin(s);
+#ifdef PPK_EXPERIMENTS
+      if constexpr (!WIDE && MODE == MODE_DIST) {
+        if (p.ablate) {
+          hipLaunchKernelGGL((dist_kernel_v2<NW, MODE, W, true, false, true>), dim3((unsigned)n_blocks, p.ks_units),
+                             dim3(NW * 64), 0, s, ref->d_skT, qry->d_skT, d_lut, use_clu ? ref->d_clu : nullptr,
+                             use_clu ? qry->d_clu : nullptr, d_rtab, d_out, d_n_failed, d_mask, p);
+          ppk_prof_end(s);
+          PPK_HIP(hipGetLastError());
+          return PPK_OK;
+        }
+      }
+#endif
       hipLaunchKernelGGL((dist_kernel_v2<NW, MODE, W, true, WIDE>), dim3((unsigned)n_blocks, p.ks_units),
                          dim3(NW * 64), 0, s, ref->d_skT, qry->d_skT, d_lut,
                          use_clu ? ref->d_clu : nullptr, use_clu ? qry->d_clu : nullptr, d_rtab, d_out,
