@@ -902,9 +902,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
   constexpr int TAB_U4 = 5 * 1024;
   // KS_FUSED: a k-split job whose tiles are fitted by their last workgroup (below); one more entry behind the
   // compare buffers holds the workgroup's grid position across the loop, in LDS instead of two SGPRs
-  // (the fused boundary mode only in the fit-from-parts form: its tiles take the general statement of the epilogue,
-  // which knows which pairs exist; the LDS-table statement of a k-split tile writes distances only)
-  constexpr bool KS_FUSED = KSPLIT && (MODE == MODE_DIST || (MODE == MODE_MASK && WIDE));
+  constexpr bool KS_FUSED = KSPLIT && (MODE == MODE_DIST || MODE == MODE_MASK);
   constexpr bool KS_MEM = KS_FUSED && WIDE;
   constexpr int KS_SLOT = 2 * CHUNK_U4;      // (WIDE: the workgroup's spill slot index lives there)
   __shared__ u32x4 lds[LDS_TABLE && TAB_U4 > 2 * CHUNK_U4 + 1 ? TAB_U4 : 2 * CHUNK_U4 + (KS_FUSED || WIDE ? 1 : 0)];
@@ -1645,13 +1643,21 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
           }
         } else if constexpr (MODE == MODE_MASK) {
           uint64_t ball[R];
+          // (a k-split tile takes this statement wherever it lies: pairs that do not exist -- r <= q, padding,
+          // outside the band, the uncompared half of a half tile -- have no bit, like in the general statement)
+          const bool q_in_band_m = !KS_FUSED || (qq >= qb && qq < qe);      // wave-uniform
 #pragma unroll
           for (int rr = 0; rr < R; ++rr) {
             const float xs = __fdiv_rn(core[rr], p.scale_x), ys = __fdiv_rn(acc[rr], p.scale_y);
             const float sd = ppk_line_dist(xs, ys, p.x_max, p.y_max, p.slope);
-            ball[rr] = __ballot(p.inclusive ? (sd <= 0.0f) : (sd < 0.0f));
+            bool pred = p.inclusive ? (sd <= 0.0f) : (sd < 0.0f);
+            if constexpr (KS_FUSED) {
+              const uint32_t rf = (uint32_t)ref_of(rr), q32 = (uint32_t)qq;
+              pred = pred && !(half && rr < 2) && rf < (uint32_t)p.r_limit && (!p.self || rf > q32);
+            }
+            ball[rr] = __ballot(pred);
           }
-          if (lane_late == 0) {
+          if (lane_late == 0 && q_in_band_m) {
             uint64_t *mrow = mask_out + (qq - qb) * p.n_rtiles + rt * 4;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -2269,7 +2275,7 @@ int launch_v2(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const f
   if ((MODE == MODE_DIST || MODE == MODE_MASK) && NW == 8 && p.k_split) {
     // k-split job in one launch: ks_units workgroups per tile, the last one to finish fits it (KS_FUSED in the
     // kernel).  Scratch: one zero-initialised counter per tile; 32 bytes per (tile, unit, thread) of partial counts.
-    if constexpr (NW == 8 && W == 2 && (MODE == MODE_DIST || (MODE == MODE_MASK && WIDE))) {
+    if constexpr (NW == 8 && W == 2 && (MODE == MODE_DIST || MODE == MODE_MASK)) {
       void *d_tickets = nullptr, *d_part = nullptr;
       const size_t ticket_bytes = (n_blocks * 4 + 255) / 256 * 256;
       int rc = ppk_scratch_get(ref->device, SLOT_TICKETS, ticket_bytes, &d_tickets);
@@ -2392,16 +2398,14 @@ int launch_tiles_packed(const ppk_db *ref, const ppk_db *qry, const double *d_lu
   }
   // (option "wide_kpg": a narrower window, i.e. the wide path on a k list the register would hold -- tests)
   const long long force_kpg = ppk_config().wide_kpg.load();
-  if constexpr (MODE == MODE_MASK) {
-    if (p.k_split) return launch_v2<8, MODE, 2, true>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
-  }
-  if constexpr (MODE == MODE_DIST) {
+  if constexpr (MODE == MODE_DIST || MODE == MODE_MASK) {
     // a k-split job whose tiles are fitted from the units' partial counts as they lie (any k list)
     // (every k list of more than 64 count bits: rebuilding three- and four-dword registers in the last unit measured
     // the same -- profiles/r05/ksplit_fit_from_parts.txt -- and cost two more instantiations, both with spills; the
     // two-dword register path stays for the shapes whose tiles are fitted from the LDS table)
     if (p.k_split && (total_bits > 64 || (force_kpg > 0 && force_kpg < p.nk)))
       return launch_v2<8, MODE, 2, true>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
+    if (p.k_split) return launch_v2<8, MODE, 2>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
   }
   if (total_bits > 128 || (force_kpg > 0 && force_kpg < p.nk && !p.k_split))
     return launch_v2<8, MODE, 4, true>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
@@ -2538,9 +2542,8 @@ static int launch_dist_band(const ppk_db *ref, const ppk_db *qry_or_null, const 
   // of queries): one workgroup per (tile, k) instead of per tile -- nk times the parallelism, a
   // serial chain of s64 blocks instead of nk * s64 -- writing raw counts, then the regression pass.
   bool small = false;
-  // (the fused boundary mode takes the path in its one-launch form on long sketches only: edge_ks below)
-  const bool edge_ks = d_mask && p.s64 >= 32 && ppk_config().ksplit_long.load() != 0 && ppk_config().ksplit_fused.load() != 0 &&
-                       64 * (size_t)p.s64 < 65536 && p.s64 >= 2;
+  // (the fused boundary mode takes the path in its one-launch form only: edge_ks)
+  const bool edge_ks = d_mask && ppk_config().ksplit_fused.load() != 0 && 64 * (size_t)p.s64 < 65536 && p.s64 >= 2;
   if (!too_wide && (!d_mask || edge_ks) && !knn_args && p.bbits == 14 && p.nk >= 2) {
     const size_t rt = (ref->n + V2_RT - 1) / V2_RT, qt = (q_end - q_begin + 31) / 32;
     // default 1 200 tiles at 5 k since the one-launch form (round 4; profiles/r04/ksplit_threshold*.txt: it wins by
@@ -2580,7 +2583,6 @@ static int launch_dist_band(const ppk_db *ref, const ppk_db *qry_or_null, const 
       if (scratch <= ((size_t)4 << 30) && (p.s64 >= 64 || tiles <= 6600) && (one_launch || tiles <= 700)) limit = tiles;
     }
     small = tiles <= limit;
-    if (d_mask && limit != tiles) small = false;      // (only what the long-sketch rule admitted)
   }
   if (too_wide && knn_args) return ppk_fail(PPK_ERR_ARG, "neighbours from tiles need bbits = 14");
   if (too_wide) {

@@ -871,3 +871,48 @@ def test_bands_larger_than_one_dispatch_go_out_as_several_launches(ppk_option, b
                 assert out[key][1] == single[key][1], key
                 assert np.array_equal(out[key][0], single[key][0]), key
             assert len(single["e_self"][0]) > 100 and len(single["e_rq"][0]) > 10
+
+
+@pytest.mark.parametrize("s64,nk,n", [(16, 5, 1000), (16, 5, 3100), (16, 3, 700), (16, 8, 1300), (156, 5, 600), (40, 6, 900)])
+def test_fused_edge_list_through_the_k_split_path_equals_the_tile_kernels(ppk_option, s64, nk, n):
+    """Round 5: small fused distance -> boundary -> edge-list jobs run one workgroup per (tile, k) like small distance
+    jobs (the tile's last unit applies the boundary: from the LDS table at s = 1 024, from the units' parts
+    elsewhere).  Self with diagonal / strip tiles and bands, ref x query, several random-match clusters, both
+    predicates: the tile kernel's list, element for element, and the oracle's."""
+    import torch
+    from poppunk_amd import engine
+    kmers = np.round(np.linspace(13, 29, nk)).astype(np.int32)
+    sk, member = synth.make_sketches(n, kmers, sketchsize64=s64, bbits=14, cluster_size=25, seed=n + nk)
+    sk[7] = sk[6]
+    clu = np.sort((member % 3).astype(np.uint16))
+    rng = np.random.Generator(np.random.PCG64(5))
+    tbl = (synth.random_match_table(kmers, n_clu=3) * rng.uniform(0.5, 2.0, size=(nk, 3, 3))).astype(np.float32)
+    db = engine.SketchDB(sk, s64, 14, clusters=clu)
+    nr = n - n // 5
+    rdb, qdb = engine.SketchDB(sk[:nr], s64, 14, clusters=clu[:nr]), engine.SketchDB(sk[nr:], s64, 14, clusters=clu[nr:])
+    d, _ = engine.dist(db, None, kmers, tbl)
+    dn = d.cpu().numpy()
+    x_max, y_max = synth.boundary_for_quantile(dn, 0.1)
+    name = lambda: _lib.lib().ppk_last_kernel_name().decode()
+
+    def lists():
+        out = []
+        for inclusive in (True, False):
+            out.append(engine.dist_edges(db, None, kmers, tbl, slope=2, x_max=x_max, y_max=y_max, inclusive=inclusive)[0])
+            nm = name()
+            out.append(torch.cat([engine.dist_edges(db, None, kmers, tbl, slope=2, x_max=x_max, y_max=y_max, inclusive=inclusive,
+                                                    q_begin=a, q_end=b)[0] for a, b in ((0, 33), (33, n // 2 + 1), (n // 2 + 1, n))]))
+            out.append(engine.dist_edges(rdb, qdb, kmers, tbl, slope=1, x_max=x_max, y_max=y_max, inclusive=inclusive)[0])
+        return nm, out
+
+    nm_ks, ks = lists()
+    assert "k-split" in nm_ks, nm_ks
+    ppk_option("ksplit", 0)
+    nm_tile, tile = lists()
+    assert "k-split" not in nm_tile
+    for a, b in zip(ks, tile):
+        assert torch.equal(a, b)
+    assert np.array_equal(tile[0].cpu().numpy(), oracle.edge_threshold(dn, 2, x_max, y_max))
+    assert torch.equal(ks[0], ks[1]) and len(ks[0]) > 100
+    for x in (db, rdb, qdb):
+        x.close()
