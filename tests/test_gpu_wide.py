@@ -362,3 +362,34 @@ def test_long_sketch_rule_is_a_switch_and_changes_no_bit(ppk_option):
     import torch
     assert torch.equal(ea, eb) and len(ea) > 1000
     db.close()
+
+
+def test_wide_list_from_database_files_through_the_surface_popPUNK_calls(tmp_path):
+    """A documented wide list (k = 13..31 step 2: ten lengths) at the default sketch size, from reference-layout `.h5` databases
+    through `sketchlib.queryDatabase` (PopPUNK/sketchlib.py:475-632): self with the --plot-fit leg (ten Jaccards per
+    example pair) and ref x query; the fused edge call from the same files."""
+    import os
+    from poppunk_amd import h5lite, sketchdb, sketchlib
+    if not h5lite.available():
+        pytest.skip("libhdf5 not found")
+    kmers, s64 = K_STEP2, 156
+    sk, _ = synth.make_sketches(230, kmers, sketchsize64=s64, bbits=14, cluster_size=23, seed=4)
+    rn, qn = ["ref_%03d" % i for i in range(180)], ["qry_%02d" % i for i in range(50)]
+    tbl = _table(kmers)
+    rp, qp = str(tmp_path / "refdb"), str(tmp_path / "qrydb")
+    sketchdb.save_h5(rp + "/refdb", rn, kmers, sk[:180], s64, 14, random_table=tbl, clusters=np.zeros(180, dtype=np.uint16))
+    sketchdb.save_h5(qp + "/qrydb", qn, kmers, sk[180:], s64, 14)
+    pp_sketchlib.clear_cache()
+    assert list(sketchdb.getKmersFromReferenceDatabase(rp)) == kmers.tolist() and sketchdb.getSketchSize(rp)[0] == s64
+    d = sketchlib.queryDatabase(rn, rn, rp, rp, kmers, self=True, number_plot_fits=1)
+    want, wf = oracle.query(sk[:180], None, kmers, s64, 14, tbl, threads=THREADS)
+    assert wf == 0 and d.shape == (16110, 2) and np.abs(d - want).max() <= TOL
+    lines = open(rp + "/refdb_fit_example_1.tsv").read().strip().split("\n")
+    assert len(lines) == 3 + len(kmers)
+    d2 = sketchlib.queryDatabase(rn, qn, rp, qp, kmers, self=False)
+    want2, _ = oracle.query(sk[:180], sk[180:], kmers, s64, 14, tbl, threads=THREADS)
+    assert np.abs(d2 - want2).max() <= TOL
+    x_max, y_max = synth.boundary_for_quantile(d, 0.1)
+    e = pp_sketchlib.queryDatabaseEdges(rp + "/refdb", rp + "/refdb", rn, rn, kmers, 2, x_max, y_max, inclusive=True)
+    assert np.array_equal(e, oracle.edge_threshold(d, 2, x_max, y_max))
+    pp_sketchlib.clear_cache()
