@@ -218,7 +218,7 @@ long ppk_oracle_query(const uint64_t *ref_sk, size_t n_ref,
   const int want_j = flags & PPK_FLAG_JACCARD;
   const size_t ocols = want_j ? nk : 2;
   long failed = 0;
-  if (nk > 64) return -1;
+  if (nk > 128) return -1;      /* (PopPUNK accepts k = 3 .. 101: at most 99 lengths) */
   if (num_threads < 1) num_threads = 1;
   /* Cache blocking only (the arithmetic per pair is untouched): a thread takes QB consecutive
    * query samples and walks the refs in tiles of RB, so a ref tile (RB x stride x 8 B, ~570 KB at
@@ -237,7 +237,7 @@ long ppk_oracle_query(const uint64_t *ref_sk, size_t n_ref,
         if (r0 >= rt_hi) continue;
         size_t row = self ? q * n_ref - (q * (q + 1)) / 2 + (r0 - q - 1) : q * n_ref + r0;
         for (size_t r = r0; r < rt_hi; r++, row++) {
-          double jac[64];
+          double jac[128];
           for (size_t k = 0; k < nk; k++) {
             const uint32_t same =
                 match_count(ref_sk + r * stride + k * words,

@@ -393,3 +393,27 @@ def test_wide_list_from_database_files_through_the_surface_popPUNK_calls(tmp_pat
     e = pp_sketchlib.queryDatabaseEdges(rp + "/refdb", rp + "/refdb", rn, rn, kmers, 2, x_max, y_max, inclusive=True)
     assert np.array_equal(e, oracle.edge_threshold(d, 2, x_max, y_max))
     pp_sketchlib.clear_cache()
+
+
+@pytest.mark.parametrize("s64,kmers,n", [(16, np.arange(3, 102), 420), (156, np.arange(3, 102, 2), 120)])
+def test_the_longest_k_lists_the_reference_accepts(ppk_option, s64, kmers, n):
+    """PopPUNK takes k = 3 .. 101 (PopPUNK/__main__.py: min-k >= 3, max-k <= 101, k-step >= 1): 99 k-mer lengths at most --
+    nine windows of the count register at s = 1 024.  Distances by both routes, fused edges, neighbours."""
+    kmers = kmers.astype(np.int32)
+    sk, _ = synth.make_sketches(n, kmers, sketchsize64=s64, bbits=14, cluster_size=20, seed=1)
+    tbl = (np.zeros((len(kmers), 1, 1)) + 1e-4).astype(np.float32)
+    want, wf = oracle.query(sk, None, kmers, s64, 14, tbl, threads=THREADS)
+    db = engine.SketchDB(sk, s64, 14)
+    for ks in (1200, 0):
+        ppk_option("ksplit", ks)
+        d, f = engine.dist(db, None, kmers, tbl)
+        assert engine._lib.lib().ppk_last_kernel_name().decode().endswith("wide>" if ks == 0 else "parts>")
+        got = d.cpu().numpy()
+        assert int(f.item()) == wf and np.abs(got - want).max() <= TOL
+        x_max, y_max = synth.boundary_for_quantile(got, 0.1)
+        e, _ = engine.dist_edges(db, None, kmers, tbl, slope=2, x_max=x_max, y_max=y_max)
+        assert np.array_equal(e.cpu().numpy(), oracle.edge_threshold(got, 2, x_max, y_max))
+    gi, gj, gd = (x.cpu().numpy() for x in engine.knn_from_sketches(db, kmers, tbl, 4, method="tiles"))
+    wi, wj, wd = oracle.knn(oracle.long_to_square(got[:, 0]), 4)
+    assert np.array_equal(gj, wj) and np.array_equal(gd, wd)
+    db.close()
