@@ -42,6 +42,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 KMERS = [13, 17, 21, 25, 29]
+WIDE_KMERS = list(range(13, 32, 2))
 
 
 def log(msg=""):
@@ -73,12 +74,20 @@ def build_databases(out):
     sketchdb.save_h5(os.path.join(out, "gap"), names, KMERS, sk, s64, 14, lengths=np.full(n, 2_000_000),
                      sketch_version="pin_upstream")
     dbs["gap"] = (os.path.join(out, "gap"), names, sk, s64, None)
+    # "wide": a k list that does not fit the tile kernel's 128-bit count register (10 lengths x 14 count bits at
+    # PopPUNK's default sketch size; --k-step 2, docs/sketching.rst:152-156) -- the wide-k paths of round 5
+    n, s64 = 70, 156
+    sk, _ = synth.make_sketches(n, WIDE_KMERS, sketchsize64=s64, bbits=14, cluster_size=14, seed=15)
+    names = ["wide_%02d" % i for i in range(n)]
+    sketchdb.save_h5(os.path.join(out, "wide"), names, WIDE_KMERS, sk, s64, 14, lengths=np.full(n, 2_000_000),
+                     sketch_version="pin_upstream")
+    dbs["wide"] = (os.path.join(out, "wide"), names, sk, s64, None)
     return dbs
 
 
-def ours(sk, qry, s64, **kw):
+def ours(sk, qry, s64, klist=None, **kw):
     from poppunk_amd import pp_sketchlib
-    return pp_sketchlib.query_arrays(sk, qry, KMERS, s64, 14, **kw)[0]
+    return pp_sketchlib.query_arrays(sk, qry, klist or KMERS, s64, 14, **kw)[0]
 
 
 def compare(name, up, mine_by_setting, tol):
@@ -191,8 +200,8 @@ def main():
         else:
             log("  => [EXT] row %d (%s): upstream behaves like '%s', the default is '%s': FLIP IT" % (row, what, hit, default))
 
-    def upstream_query(db, rn, qn, correct, jaccard, db2=None):
-        return np.asarray(up.queryDatabase(db, db2 or db, rn, qn, KMERS, correct, jaccard, 4, False, 0))
+    def upstream_query(db, rn, qn, correct, jaccard, db2=None, klist=None):
+        return np.asarray(up.queryDatabase(db, db2 or db, rn, qn, klist or KMERS, correct, jaccard, 4, False, 0))
 
     # ---- rows 6 (bit-sliced layout) and 1 (collision adjustment): raw Jaccards -----------------------------
     for tag in ("s1024", "s19200"):
@@ -242,6 +251,23 @@ def main():
             "path Eigen/double [EXT])" % err)
         settle(5, "fp64 regression rounded to float32", "within 1e-6" if err <= 1e-6 else ("within 1e-5" if err <= 1e-5 else None),
                "within 1e-6")
+
+    # ---- a k list wider than the count register: the wide-k tile kernel and the k-split path, both against upstream
+    db, names, sk, s64, _ = dbs["wide"]
+    log("\n[wide] %d k-mer lengths at %d bins: distances and raw Jaccards by both routes" % (len(WIDE_KMERS), 64 * s64))
+    mine = {}
+    for ks in (1200, 0):
+        _lib.set_option("ksplit", ks)
+        mine["ksplit=%d (%s)" % (ks, "k-split units" if ks else "wide tile kernel")] = ours(sk, None, s64, klist=WIDE_KMERS, random_correct=False)
+    _lib.set_option("ksplit", 1200)
+    assert np.array_equal(*mine.values())
+    if up is not None:
+        u = upstream_query(db, names, names, False, False, klist=WIDE_KMERS)
+        hit = compare("wide", u, mine, 1e-6)
+        log("  => wide k list: %s" % ("matches upstream within 1e-6" if hit else "DIFFERS from upstream"))
+        uj = upstream_query(db, names, names, False, True, klist=WIDE_KMERS)
+        mj = ours(sk, None, s64, klist=WIDE_KMERS, random_correct=False, jaccard=True)
+        log("    raw Jaccards: max |ours - upstream| = %.3g" % float(np.abs(mj - uj).max()))
 
     # ---- rows 3 and 4: /random as upstream writes it, and corrected results ------------------------------------
     if up is not None:
