@@ -635,6 +635,12 @@ int ppk_prof_enable(int on);
 int ppk_prof_read(double *total_ms, long long *n_launches, int reset);
 /* name of the kernel variant the last ppk_dist*_dev call launched */
 const char *ppk_last_kernel_name(void);
+/* Named stages of the multi-kernel entry points (the sweeps of src/boundary.cpp:154-237, neighbours of
+ * src/extend.cpp:248-289, the QC lists of PopPUNK/qc.py:330-354, long <-> square): when enabled, one hipEvent between
+ * stages on the call's stream.  ppk_prof_stages_read writes "name<TAB>total ms<TAB>count" lines in first-seen order
+ * (synchronises the recorded events); PPK_ERR_CAPACITY when buf is too small (what fits is written). */
+int ppk_prof_stages_enable(int on);
+int ppk_prof_stages_read(char *buf, size_t cap, int reset);
 
 #ifdef __cplusplus
 }

@@ -11,6 +11,7 @@
 #include <unistd.h>
 #include <functional>
 #include <memory>
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -205,6 +206,90 @@ extern "C" int ppk_prof_enable(int on) {
   std::lock_guard<std::mutex> lk(g_prof.mu);
   g_prof.on = on != 0;
   return PPK_OK;
+}
+
+// ---- named stages (the multi-kernel entry points: sweeps, neighbours, QC lists, long <-> square) ----
+// ppk_prof_stage(name, s) records ONE event on s: it ends the stage before it and starts `name`
+// (nullptr: only ends).  Nothing is recorded unless ppk_prof_stages_enable(1).
+namespace {
+struct StageProf {
+  std::mutex mu;
+  bool on = false;
+  std::vector<hipEvent_t> ev;          // ev[i] .. ev[i + 1] brackets stage nm[i] ("" = not a stage)
+  std::vector<std::string> nm;
+  std::vector<std::string> order;      // first-seen order of the names
+  std::map<std::string, std::pair<double, long long>> acc;
+} g_stage;
+
+void stage_fold_locked() {
+  for (size_t i = 0; i + 1 < g_stage.ev.size(); ++i) {
+    if (g_stage.nm[i].empty()) continue;
+    float ms = 0.0f;
+    if (hipEventSynchronize(g_stage.ev[i + 1]) == hipSuccess &&
+        hipEventElapsedTime(&ms, g_stage.ev[i], g_stage.ev[i + 1]) == hipSuccess) {
+      auto it = g_stage.acc.find(g_stage.nm[i]);
+      if (it == g_stage.acc.end()) {
+        g_stage.order.push_back(g_stage.nm[i]);
+        it = g_stage.acc.emplace(g_stage.nm[i], std::make_pair(0.0, 0LL)).first;
+      }
+      it->second.first += ms;
+      it->second.second += 1;
+    }
+  }
+  // the last event may still open a stage: keep it
+  const bool open = !g_stage.nm.empty() && !g_stage.nm.back().empty();
+  const size_t keep = open ? g_stage.ev.size() - 1 : g_stage.ev.size();
+  for (size_t i = 0; i < keep; ++i) (void)hipEventDestroy(g_stage.ev[i]);
+  if (open) {
+    hipEvent_t e = g_stage.ev.back();
+    std::string n = g_stage.nm.back();
+    g_stage.ev.assign(1, e);
+    g_stage.nm.assign(1, n);
+  } else {
+    g_stage.ev.clear();
+    g_stage.nm.clear();
+  }
+}
+}  // namespace
+
+void ppk_prof_stage(const char *name, hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_stage.mu);
+  if (!g_stage.on) return;
+  if (g_stage.ev.size() >= 1024) stage_fold_locked();
+  if (!name && (g_stage.nm.empty() || g_stage.nm.back().empty())) return;      // nothing open
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return;
+  (void)hipEventRecord(e, s);
+  g_stage.ev.push_back(e);
+  g_stage.nm.push_back(name ? name : "");
+}
+
+extern "C" int ppk_prof_stages_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_stage.mu);
+  g_stage.on = on != 0;
+  return PPK_OK;
+}
+
+extern "C" int ppk_prof_stages_read(char *buf, size_t cap, int reset) {
+  std::lock_guard<std::mutex> lk(g_stage.mu);
+  stage_fold_locked();
+  std::string out;
+  for (const std::string &n : g_stage.order) {
+    const auto &a = g_stage.acc[n];
+    char line[256];
+    snprintf(line, sizeof line, "%s\t%.6f\t%lld\n", n.c_str(), a.first, a.second);
+    out += line;
+  }
+  if (buf && cap) {
+    const size_t k = out.size() < cap - 1 ? out.size() : cap - 1;
+    memcpy(buf, out.data(), k);
+    buf[k] = 0;
+  }
+  if (reset) {
+    g_stage.acc.clear();
+    g_stage.order.clear();
+  }
+  return out.size() + 1 > cap && buf ? ppk_fail(PPK_ERR_CAPACITY, "stage table does not fit the buffer") : (int)PPK_OK;
 }
 
 extern "C" int ppk_prof_read(double *total_ms, long long *n_launches, int reset) {

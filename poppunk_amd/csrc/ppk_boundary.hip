@@ -284,8 +284,11 @@ __device__ __forceinline__ size_t cond_row_idx(size_t k, size_t n) {
 // 3 052): `block_offsets` still holds the raw block COUNTS and every workgroup sums the ones before it itself (a few
 // coalesced reads of an L2-resident array) instead of a one-workgroup scan kernel running between the two passes -- one
 // launch and its gap less (4.7 + ~1.5 us of a ~90 us call); the last workgroup leaves the total in *n_edges.
+// SCAN 2 (EDGE_COO_SEGMENTS whose segments are whole compaction blocks, counts left by the mask's producer): the
+// offset is the total of the segments before this one (g.seg_totals, seg_totals_kernel) plus the self-scan inside the
+// segment -- the sweep's [offset][blocks] mask has 20 x 3 052 blocks, which one workgroup took 105 us to scan.
 constexpr size_t kSelfScanBlocks = 8192;
-template <bool SELF_SCAN>
+template <int SCAN>
 __global__ void __launch_bounds__(kBlock)
 mask_expand_kernel(const uint64_t *__restrict__ mask, size_t n_words,
                    const unsigned long long *__restrict__ block_offsets, EdgeGeom g,
@@ -293,9 +296,15 @@ mask_expand_kernel(const uint64_t *__restrict__ mask, size_t n_words,
   __shared__ unsigned sh_wave[kBlock / 64];
   __shared__ unsigned long long sh_pre[kBlock / 64];
   unsigned long long block_off = 0;
-  if constexpr (SELF_SCAN) {
+  if constexpr (SCAN != 0) {
     unsigned long long part = 0;
-    for (size_t b = threadIdx.x; b < blockIdx.x; b += kBlock) part += block_offsets[b];
+    if constexpr (SCAN == 2) {
+      const size_t seg = blockIdx.x / g.seg_blocks, b0 = seg * g.seg_blocks;
+      for (size_t sg = threadIdx.x; sg < seg; sg += kBlock) part += g.seg_totals[sg];
+      for (size_t b = b0 + threadIdx.x; b < blockIdx.x; b += kBlock) part += block_offsets[b];
+    } else {
+      for (size_t b = threadIdx.x; b < blockIdx.x; b += kBlock) part += block_offsets[b];
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
     if ((threadIdx.x & 63) == 0) sh_pre[threadIdx.x >> 6] = part;
@@ -429,6 +438,24 @@ mask_expand_kernel(const uint64_t *__restrict__ mask, size_t n_words,
         ++pos;
       }
     }
+  }
+}
+
+// one workgroup per segment: the sum of its compaction blocks' counts
+__global__ void __launch_bounds__(kBlock)
+seg_totals_kernel(const unsigned long long *__restrict__ block_sums, size_t seg_blocks,
+                  unsigned long long *__restrict__ seg_totals) {
+  __shared__ unsigned long long sh[kBlock / 64];
+  unsigned long long part = 0;
+  for (size_t b = threadIdx.x; b < seg_blocks; b += kBlock) part += block_sums[(size_t)blockIdx.x * seg_blocks + b];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+    for (int i = 0; i < kBlock / 64; ++i) t += sh[i];
+    seg_totals[blockIdx.x] = t;
   }
 }
 
@@ -587,12 +614,18 @@ int ppk_launch_compact(const uint64_t *d_mask, size_t n_words, const EdgeGeom &g
   if (!counted)      // (the mask's producer has left the block counts in d_ws already)
     hipLaunchKernelGGL(mask_count_kernel, dim3((unsigned)nb), dim3(kBlock), 0, s, d_mask, n_words,
                        block_sums);
-  if (nb <= kSelfScanBlocks) {
-    hipLaunchKernelGGL(mask_expand_kernel<true>, dim3((unsigned)nb), dim3(kBlock), 0, s, d_mask, n_words,
+  if (counted && g.layout == EDGE_COO_SEGMENTS && g.seg_blocks && g.seg_blocks <= kSelfScanBlocks &&
+      g.seg_words == g.seg_blocks * kWordsPerBlock && nb % g.seg_blocks == 0 && nb / g.seg_blocks <= 4096) {
+    hipLaunchKernelGGL(seg_totals_kernel, dim3((unsigned)(nb / g.seg_blocks)), dim3(kBlock), 0, s, block_sums,
+                       g.seg_blocks, g.seg_totals);
+    hipLaunchKernelGGL(mask_expand_kernel<2>, dim3((unsigned)nb), dim3(kBlock), 0, s, d_mask, n_words,
+                       block_sums, g, reinterpret_cast<longlong2 *>(d_edges), cap, d_n_edges);
+  } else if (nb <= kSelfScanBlocks) {
+    hipLaunchKernelGGL(mask_expand_kernel<1>, dim3((unsigned)nb), dim3(kBlock), 0, s, d_mask, n_words,
                        block_sums, g, reinterpret_cast<longlong2 *>(d_edges), cap, d_n_edges);
   } else {
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, block_sums, nb, d_n_edges);
-    hipLaunchKernelGGL(mask_expand_kernel<false>, dim3((unsigned)nb), dim3(kBlock), 0, s, d_mask, n_words,
+    hipLaunchKernelGGL(mask_expand_kernel<0>, dim3((unsigned)nb), dim3(kBlock), 0, s, d_mask, n_words,
                        block_sums, g, reinterpret_cast<longlong2 *>(d_edges), cap, d_n_edges);
   }
   PPK_HIP(hipGetLastError());

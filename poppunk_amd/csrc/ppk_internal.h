@@ -113,6 +113,7 @@ struct DeviceGuard {
 void ppk_prof_begin(hipStream_t s);
 void ppk_prof_end(hipStream_t s);
 void ppk_set_kernel_name(const char *name);
+void ppk_prof_stage(const char *name, hipStream_t s);      // named stages of the multi-kernel entry points (nullptr ends)
 
 // Kernel 2 / compaction (ppk_boundary.hip) ------------------------------------
 enum EdgeLayout {
@@ -135,6 +136,8 @@ struct EdgeGeom {
   size_t seg_words;         // EDGE_COO_SEGMENTS: mask words per segment
   long long *coo_j;         // EDGE_COO_SEGMENTS: second and third output arrays (first = d_edges)
   long long *coo_seg;
+  size_t seg_blocks;        // EDGE_COO_SEGMENTS with counts from the producer: compaction blocks per segment (seg_words / 256)
+  unsigned long long *seg_totals;      // ... and room for one total per segment (device)
   int pair_interleaved;     // linear layouts: the mask came from ppk_launch_mask_from_dist_counted (even / odd rows of 128 in word pairs)
 };
 

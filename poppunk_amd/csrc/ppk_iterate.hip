@@ -2,24 +2,31 @@
 //
 //  - ppk_threshold_iterate_1d_dev : src/boundary.cpp:154-210 (threshold_iterate_1D; binding
 //    thresholdIterate1D, src/python_bindings.cpp:49-60).  The reference sorts ALL rows by their
-//    distance to the first boundary and then walks that order once, emitting a row while it is
-//    within the current boundary.  Here:
-//      1. one streaming pass classifies every row: d0 = line_dist to boundary 0 and
-//         f = first offset whose boundary contains the row (n_off = never), and reduces
-//         m = max d0 over rows with f < n_off;
-//      2. only rows with d0 <= m can sit before the last emitted row in the reference's order,
-//         so only those "candidates" are compacted (stable, row order) and radix-sorted by d0
-//         (stable: ties keep row order, exactly the reference's parallel_stable_sort);
-//      3. the reference's sweep stops, for offset o, at the first sorted position whose row is
-//         not within boundary o: g[o] = min position with f > o (atomicMin), which is monotone
-//         in o, so position p is emitted with offset index min{o : p < g[o]}.
+//    distance to the first boundary (d0) and walks that order once, emitting a row while it is
+//    within the current boundary; the walk ends for good at the first row that is within NO
+//    boundary.  Here:
+//      1. ONE streaming pass over the matrix (ti1_classify_kernel) evaluates every boundary for
+//         every row, boundaries in SGPRs, four rows per lane: c = number of boundaries that hold
+//         the row.  Rows with c > 0 are the candidates: one mask bit, and one byte f = n_off - c
+//         (their first boundary, when "within" is monotone in the offset).  Rows with c = 0 can
+//         only END the walk: the pass keeps the smallest (d0, row) among them, the stop.
+//      2. the candidates alone -- the rows the reference can emit -- are compacted in row order
+//         with their key ord(d0) and value row | f << row_bits, and radix-sorted by key (stable,
+//         so equal distances keep row order like the reference's parallel_stable_sort);
+//      3. sorted position p is emitted iff (key, row) < stop, with offset index
+//         max(f(0..p)): the walk of offset o stops at the first position with f > o, so the
+//         offset a position leaves with is the running maximum of f (ti1_blockmax / ti1_emit).
+//    When some row is within a boundary but outside a later one (a shrinking sweep, or rounding on
+//    a row that sits on two boundaries) the closed form of 3 does not hold and one thread walks the
+//    sorted candidates exactly as the reference does (ti1_serial_kernel).
 //    The result equals the reference's (i, j, offset) vectors element for element, without
-//    sorting the 5e7..5e9 rows that are never emitted, and without the reference's read past
-//    the end of boundary_order (boundary.cpp:206).
+//    sorting the rows that are never emitted, and without the reference's read past the end of
+//    boundary_order (boundary.cpp:206).
 //  - ppk_threshold_iterate_2d_dev : src/boundary.cpp:212-237 (threshold_iterate_2D): one pass
 //    builds a ballot bitmask per offset (within boundary o and not within o-1), then the shared
 //    stable compaction emits (i, j, o) offset-major / row-minor like the reference's loops.
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include <cmath>
 #include <vector>
@@ -28,139 +35,492 @@
 
 namespace {
 
-// offsets per call: the sweep's sort carries a row's first offset in 10 bits of its 64-bit value
+// offsets per call
 constexpr int kMaxOff = 1023;
 
-struct Boundaries {
-  int n;
-  int slope;
-  const float2 *xy;      // device: (x_max, y_max) of every offset's boundary
-};
-
-// order-preserving float <-> uint32 (for atomicMax on floats)
+// order-preserving float -> uint32 (the sort key; unsigned compare == operator< on non-NaN floats)
 __device__ __forceinline__ unsigned f2ord(float f) {
   const unsigned u = __float_as_uint(f);
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
-__device__ __forceinline__ float ord2f(unsigned o) {
-  return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
-}
 
-__global__ void __launch_bounds__(256)
-ti1_classify_kernel(const float2 *__restrict__ dist, size_t n_rows, const Boundaries b,
-                    float *__restrict__ d0, unsigned short *__restrict__ first,
-                    unsigned *__restrict__ max_ord, unsigned *__restrict__ non_monotone) {
-  // the boundaries live in LDS: indexing the by-value struct with a runtime o is a dependent
-  // scalar load per boundary per row
-  __shared__ float2 sb[kMaxOff];
-  for (int o = threadIdx.x; o < b.n; o += 256) sb[o] = b.xy[o];
-  __syncthreads();
-  const size_t stride = (size_t)gridDim.x * 256;
-  unsigned local = 0;  // f2ord of -inf-ish: 0 is below every real value's code
-  for (size_t row = (size_t)blockIdx.x * 256 + threadIdx.x; row < n_rows; row += stride) {
-    const float2 d = dist[row];
-    float dd = ppk_line_dist(d.x, d.y, sb[0].x, sb[0].y, b.slope);
-    dd = dd + 0.0f;  // -0.0 -> +0.0 so that the radix order equals operator<
-    int f = b.n;
-    bool hole = false;   // within some boundary but outside a later one (rounding / shrinking sweep)
-#pragma unroll 4
-    for (int o = 0; o < b.n; ++o) {
-      const float2 xy = sb[o];
-      const bool within = ppk_line_dist(d.x, d.y, xy.x, xy.y, b.slope) <= 0.0f;
-      if (within && f == b.n) f = o;
-      hole = hole || (!within && f < b.n);
+// a boundary as the classify pass reads it (one s_load_dwordx4): x_max, y_max, fl(x_max * y_max)
+struct Bnd {
+  float xm, ym, c, pad;
+};
+
+// device-side control block of one call
+struct Ctrl {
+  unsigned long long n_cand;    // candidates (rows within some boundary)
+  unsigned long long stop_row;  // (stop_ord, stop_row): first row of the reference's order that no boundary holds
+  unsigned long long n_cut;     // sorted positions before the stop (min over positions at or after it)
+  unsigned stop_ord;
+  unsigned holes;               // some row is within a boundary and outside a later one
+};
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));      // (8-byte loads only: no packed arithmetic)
+
+constexpr int kUnitWords = 8;       // mask words (64 rows each) a wavefront classifies together: 8 rows per lane
+constexpr int kCbWords = 256;       // mask words per compaction block (one workgroup of the expand pass)
+
+// MODE 0 / 1: slope 0 / 1 (within <=> coordinate - max <= 0).  MODE 2: slope 2, no boundary on an axis
+// (line_dist = (y x_max + x y_max) - x_max y_max, un-fused, the product read from Bnd::c: the same IEEE
+// multiplication the reference does per row).  MODE 3: ppk_line_dist as it stands (a slope-2 boundary with
+// x_max = 0 or y_max = 0 takes the reference's sqrt branch, boundary.cpp:46-47).
+// The slope-2 evaluations of R rows per lane against n_pad boundaries (LDS broadcasts of (x_max, y_max, c)):
+// cnt[r] = boundaries that hold row r, and bit r of the result set when row r is within a boundary and outside a
+// later one.  Every operand in a VGPR (an SGPR source costs a VALU instruction ~4.2 instead of ~2.7 clocks here,
+// profiles/r02/ubench_valu.txt) and nothing on the scalar side: a row's verdicts are shifted into a register, one
+// bit per boundary, by v_alignbit -- bit = sign of t = c - fl(fl(y x_max) + fl(x y_max)), set <=> the sum exceeds c
+// <=> line_dist > 0 (the sign of the reference's rounded difference is the sign of the exact one: gradual underflow,
+// c finite).  Counts and the hole test are read off the 32-bit pattern once per 32 boundaries.  A NaN sum (NaN or
+// inf - inf coordinates; x_max, y_max are positive and finite in this mode, so it is NaN for every boundary or for
+// none) has an arbitrary sign: those rows are set to "within nothing", which is what every comparison of the
+// reference says.
+template <int R>
+__device__ __forceinline__ unsigned eval_rows_slope2(const float (&x)[R], const float (&y)[R],
+                                                     const float4 *__restrict__ sb, int n_pad, unsigned (&cnt)[R]) {
+  unsigned seen = 0, holes = 0;      // per lane: bit r <- row r has been within a boundary / has a hole
+#pragma unroll
+  for (int r = 0; r < R; ++r) cnt[r] = 0;
+  for (int o0 = 0; o0 < n_pad; o0 += 32) {
+    const int nb = n_pad - o0 < 32 ? n_pad - o0 : 32;      // wave-uniform, a multiple of 4
+    unsigned acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0;
+    for (int o = o0; o < o0 + nb; o += 4) {
+      float4 B[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) B[k] = sb[o + k];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const float t = __fsub_rn(B[k].z, __fadd_rn(__fmul_rn(y[r], B[k].x), __fmul_rn(x[r], B[k].y)));
+          acc[r] = __builtin_amdgcn_alignbit(acc[r], __float_as_uint(t), 31);      // acc << 1 | sign(t)
+        }
+      }
     }
-    if (hole) atomicOr(non_monotone, 1u);
-    d0[row] = dd;
-    first[row] = (unsigned short)f;
-    if (f < b.n) {
-      const unsigned c = f2ord(dd);
-      local = c > local ? c : local;
+    const unsigned low = nb == 32 ? 0xffffffffu : (1u << nb) - 1u;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const unsigned z = ~acc[r] & low;      // within, first boundary of the chunk at bit nb - 1
+      // no hole <=> outside ... outside within ... within: z = 2^b - 1, and all of it once a chunk before had any
+      const bool bad = (z & (z + 1u)) != 0u || (((seen >> r) & 1u) && z != low);
+      holes |= bad ? (1u << r) : 0u;
+      seen |= z ? (1u << r) : 0u;
+      cnt[r] += (unsigned)__popc(z);
     }
   }
+  const float4 b0 = sb[0];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const float a0 = __fadd_rn(__fmul_rn(y[r], b0.x), __fmul_rn(x[r], b0.y));
+    if (a0 != a0) {
+      cnt[r] = 0;
+      holes &= ~(1u << r);
+    }
+  }
+  return holes;
+}
+
+constexpr int kDenseRows = 2;      // rows per lane of one dense batch of the filtered form
+
+// FILTER (slope 2, every boundary inside the last one: x_max_o <= x_max_L, y_max_o <= y_max_L, all >= 2^-40): a row
+// with x, y >= 0 and fl(fl(y x_max_L) + fl(x y_max_L)) > c_L (1 + 2^-20) is outside EVERY boundary -- with
+// u = 2^-24, y / y_max_o + x / x_max_o >= y / y_max_L + x / x_max_L > 1 + 11 u, so the rounded sum of boundary o
+// exceeds x_max_o y_max_o (1 + 8 u) >= c_o (underflow moves either side by < 2^-148, the margin is > 2^-104) -- and
+// takes no further part.  The rest (the candidates and a fringe) are packed through LDS, 64 * kDenseRows at a time,
+// so that the n_pad evaluations per row run on full wavefronts: 17 % of the rows in the 10 000-genome sweep.
+template <int MODE, bool FILTER, typename F>
+__global__ void __launch_bounds__(256)
+ti1_classify_kernel(const float2 *__restrict__ dist, size_t n_rows, const Bnd *__restrict__ bnd, int n_pad,
+                    int slope, Bnd filt, F *__restrict__ first, uint64_t *__restrict__ mask, size_t n_words,
+                    unsigned long long *__restrict__ block_sums, ulonglong2 *__restrict__ stops,
+                    Ctrl *__restrict__ ctrl) {
+  static_assert(!FILTER || MODE == 2, "the filter is a slope-2 argument");
+  extern __shared__ float4 dyn_lds[];      // MODE 2: n_pad + 1 boundaries; FILTER: + per wavefront 512 (x, y) and 512 counts
+  float4 *sb = dyn_lds;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t n_units = (n_words + kUnitWords - 1) / kUnitWords;
+  const size_t n_waves = (size_t)gridDim.x * 4;
+  const size_t wv = (size_t)blockIdx.x * 4 + wave;
+  // a contiguous run of units per wavefront (balanced to one unit; stores and the per-block counts stay local)
+  const size_t u0 = (size_t)((unsigned __int128)n_units * wv / n_waves);
+  const size_t u1 = (size_t)((unsigned __int128)n_units * (wv + 1) / n_waves);
+  const Bnd b0 = bnd[0];
+  if constexpr (MODE == 2) {
+    for (int o = threadIdx.x; o < n_pad; o += 256) {
+      const Bnd b = bnd[o];
+      sb[o] = make_float4(b.xm, b.ym, b.c, 0.0f);
+    }
+    if (threadIdx.x == 0) sb[n_pad] = make_float4(filt.xm, filt.ym, filt.c, 0.0f);
+    __syncthreads();
+  }
+  constexpr int kUnitRows = kUnitWords * 64;
+  float2 *stage_xy = reinterpret_cast<float2 *>(dyn_lds + n_pad + 1) + (size_t)wave * kUnitRows;
+  unsigned *stage_cnt = reinterpret_cast<unsigned *>(reinterpret_cast<float2 *>(dyn_lds + n_pad + 1) + 4 * kUnitRows) +
+                        (size_t)wave * kUnitRows;
+  unsigned best_ord = 0xffffffffu;
+  unsigned best_rel = 0xffffffffu;        // the stop candidate's row, relative to this wavefront's first row
+  uint64_t hole = 0;                      // wave-uniform lane mask
+  unsigned bits = 0;                      // wave-uniform: candidates of the current compaction block
+  size_t cb_cur = u0 / (kCbWords / kUnitWords);
+  const f32x2 *rows = reinterpret_cast<const f32x2 *>(dist);
+  const size_t last_row = n_rows - 1;
+  // the rows of unit u: lane l holds rows (u * kUnitWords + r) * 64 + l; the address is clamped, not predicated,
+  // so that the loads of the NEXT unit can be issued before this unit's evaluations without a branch in between
+  f32x2 nxt[kUnitWords];
+  if (u0 < u1) {
+#pragma unroll
+    for (int r = 0; r < kUnitWords; ++r) {
+      const size_t row = (u0 * kUnitWords + r) * 64 + lane;
+      nxt[r] = __builtin_nontemporal_load(rows + (row < last_row ? row : last_row));
+    }
+  }
+  for (size_t u = u0; u < u1; ++u) {
+    float x[kUnitWords], y[kUnitWords];
+#pragma unroll
+    for (int r = 0; r < kUnitWords; ++r) {
+      x[r] = nxt[r].x;
+      y[r] = nxt[r].y;
+    }
+    if (u + 1 < u1) {
+#pragma unroll
+      for (int r = 0; r < kUnitWords; ++r) {
+        const size_t row = ((u + 1) * kUnitWords + r) * 64 + lane;
+        nxt[r] = __builtin_nontemporal_load(rows + (row < last_row ? row : last_row));
+      }
+    }
+    const bool full = (u + 1) * kUnitWords * 64 <= n_rows;      // wave-uniform: every row of the unit exists
+    // n_pad boundaries, a multiple of 4: the host repeats the last one, which neither makes nor hides a hole and
+    // adds the same number to every candidate's count when there is none (f = n_pad - cnt either way)
+    unsigned cnt[kUnitWords];
+#pragma unroll
+    for (int r = 0; r < kUnitWords; ++r) cnt[r] = 0;
+    if constexpr (MODE == 2 && FILTER) {
+      const float4 fl = sb[n_pad];      // (x_max_L, y_max_L, c_L (1 + 2^-20)) as a broadcast: VGPR operands
+      uint64_t nm[kUnitWords];          // rows that go on to the full evaluation
+      unsigned base[kUnitWords + 1];
+      base[0] = 0;
+#pragma unroll
+      for (int r = 0; r < kUnitWords; ++r) {
+        const float aL = __fadd_rn(__fmul_rn(y[r], fl.x), __fmul_rn(x[r], fl.y));
+        const bool skip = aL > fl.z && fminf(x[r], y[r]) >= 0.0f;      // (a NaN anywhere: not skipped)
+        const bool in = full || (u * kUnitWords + r) * 64 + lane < n_rows;
+        nm[r] = __ballot(in && !skip);
+        base[r + 1] = base[r] + (unsigned)__popcll(nm[r]);
+      }
+      const unsigned n_need = base[kUnitWords];      // wave-uniform
+      if (n_need) {
+        unsigned slot[kUnitWords];
+#pragma unroll
+        for (int r = 0; r < kUnitWords; ++r) {
+          slot[r] = base[r] + __builtin_amdgcn_mbcnt_hi((unsigned)(nm[r] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)nm[r], 0u));
+          if ((nm[r] >> lane) & 1) stage_xy[slot[r]] = make_float2(x[r], y[r]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (unsigned s0 = 0; s0 < n_need; s0 += 64 * kDenseRows) {
+          float dx[kDenseRows], dy[kDenseRows];
+          unsigned dc[kDenseRows];
+#pragma unroll
+          for (int q = 0; q < kDenseRows; ++q) {
+            const unsigned sl = s0 + q * 64 + lane;
+            const float2 v = stage_xy[sl < n_need ? sl : n_need - 1];      // (a repeat of the last packed row: no new hole)
+            dx[q] = v.x;
+            dy[q] = v.y;
+          }
+          const unsigned hb = eval_rows_slope2<kDenseRows>(dx, dy, sb, n_pad, dc);
+          hole |= __ballot(hb != 0u);
+#pragma unroll
+          for (int q = 0; q < kDenseRows; ++q) {
+            const unsigned sl = s0 + q * 64 + lane;
+            if (sl < n_need) stage_cnt[sl] = dc[q];
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < kUnitWords; ++r)
+          if ((nm[r] >> lane) & 1) cnt[r] = stage_cnt[slot[r]];
+        __builtin_amdgcn_wave_barrier();      // (the next unit's rows overwrite the staging)
+      }
+    } else if constexpr (MODE == 2) {
+      const unsigned hb = eval_rows_slope2<kUnitWords>(x, y, sb, n_pad, cnt);
+      // (a clamped duplicate of the last row past the end can only repeat that row's own pattern: no false hole)
+      hole |= __ballot(hb != 0u);
+    } else {
+      uint64_t prev[kUnitWords];      // lane masks (SGPR pairs): within the boundary before this one
+#pragma unroll
+      for (int r = 0; r < kUnitWords; ++r) prev[r] = 0;
+      for (int o = 0; o < n_pad; o += 4) {
+        Bnd B[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) B[k] = bnd[o + k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+          for (int r = 0; r < kUnitWords; ++r) {
+            bool w;
+            if constexpr (MODE == 0) w = __fsub_rn(x[r], B[k].xm) <= 0.0f;
+            else if constexpr (MODE == 1) w = __fsub_rn(y[r], B[k].ym) <= 0.0f;
+            else w = ppk_line_dist(x[r], y[r], B[k].xm, B[k].ym, slope) <= 0.0f;
+            const uint64_t wm = __ballot(w);
+            hole |= prev[r] & ~wm;
+            prev[r] = wm;
+            cnt[r] += w ? 1u : 0u;
+          }
+        }
+      }
+    }
+    const unsigned rel0 = (unsigned)(u - u0) * (kUnitWords * 64) + (unsigned)lane;
+#pragma unroll
+    for (int r = 0; r < kUnitWords; ++r) {
+      const size_t w_idx = u * kUnitWords + r;
+      if (!full && w_idx >= n_words) break;      // wave-uniform
+      const size_t row = w_idx * 64 + lane;
+      const bool in = full || row < n_rows;
+      const uint64_t m = __ballot(in && cnt[r] > 0);
+      if (lane == 0) mask[w_idx] = m;
+      bits += (unsigned)__popcll(m);
+      if (in) first[row] = (F)((unsigned)n_pad - cnt[r]);
+      // a row no boundary holds: the walk ends at the first of these in (d0, row) order.  NaN distances
+      // compare false everywhere and sort after everything (as they did in the reference's key order).
+      float d0;
+      if constexpr (MODE == 2) d0 = __fsub_rn(__fadd_rn(__fmul_rn(y[r], b0.xm), __fmul_rn(x[r], b0.ym)), b0.c);
+      else d0 = ppk_line_dist(x[r], y[r], b0.xm, b0.ym, slope);
+      d0 = d0 + 0.0f;      // -0.0 -> +0.0 so that the radix order equals operator<
+      const unsigned c = f2ord(d0);
+      // rows grow within a lane: strict < keeps the earliest
+      if (in && cnt[r] == 0 && d0 == d0 && c < best_ord) {
+        best_ord = c;
+        best_rel = rel0 + (unsigned)r * 64u;
+      }
+    }
+    const size_t cb_next = (u + 1) / (kCbWords / kUnitWords);
+    if (cb_next != cb_cur || u + 1 == u1) {
+      if (lane == 0 && bits) atomicAdd(&block_sums[cb_cur], (unsigned long long)bits);
+      bits = 0;
+      cb_cur = cb_next;
+    }
+  }
+  if (hole && lane == 0) atomicOr(&ctrl->holes, 1u);
+  // wavefront minimum of (ord, row)
+#pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
-    const unsigned v = __shfl_down(local, o, 64);
-    local = v > local ? v : local;
+    const unsigned oc = __shfl_down(best_ord, o, 64);
+    const unsigned orel = __shfl_down(best_rel, o, 64);
+    if (oc < best_ord || (oc == best_ord && orel < best_rel)) {
+      best_ord = oc;
+      best_rel = orel;
+    }
   }
-  if ((threadIdx.x & 63) == 0 && local) atomicMax(max_ord, local);
+  if (lane == 0)
+    stops[wv] = make_ulonglong2((unsigned long long)best_ord,
+                                best_ord == 0xffffffffu && best_rel == 0xffffffffu
+                                    ? ~0ull : (unsigned long long)u0 * (kUnitWords * 64) + best_rel);
 }
 
-__global__ void __launch_bounds__(256)
-ti1_candidate_mask_kernel(const float *__restrict__ d0, size_t n_rows,
-                          const unsigned *__restrict__ max_ord, uint64_t *__restrict__ mask,
-                          size_t n_words) {
-  const unsigned mo = *max_ord;
-  const bool any = mo != 0;
-  const float m = any ? ord2f(mo) : 0.0f;
-  const size_t wstride = (size_t)gridDim.x * 4;
-  const int lane = threadIdx.x & 63;
-  for (size_t w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); w < n_words; w += wstride) {
-    const size_t row = w * 64 + lane;
-    const bool pred = any && row < n_rows && d0[row] <= m;
-    const uint64_t bits = __ballot(pred);
-    if (lane == 0) mask[w] = bits;
+// One workgroup: (a) the stop = lexicographic minimum of the wavefronts' (ord, row); (b) exclusive scan of
+// the compaction blocks' candidate counts, total -> ctrl->n_cand and *n_out (the count-only answer's upper bound).
+__global__ void __launch_bounds__(1024)
+ti1_scan_kernel(unsigned long long *__restrict__ block_sums, size_t n_blocks, const ulonglong2 *__restrict__ stops,
+                size_t n_stops, Ctrl *__restrict__ ctrl) {
+  __shared__ unsigned long long wsum[16];
+  __shared__ unsigned long long sord[16], srow[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long bo = 0xffffffffull, br = ~0ull;
+  for (size_t k = threadIdx.x; k < n_stops; k += 1024) {
+    const ulonglong2 v = stops[k];
+    if (v.x < bo || (v.x == bo && v.y < br)) {
+      bo = v.x;
+      br = v.y;
+    }
   }
-}
-
-__global__ void __launch_bounds__(256)
-ti1_gather_keys_kernel(unsigned long long *__restrict__ rows, size_t n_cand,
-                       const float *__restrict__ d0, const unsigned short *__restrict__ first,
-                       float *__restrict__ keys) {
-  // key = distance to the first boundary; the row's `first` rides in bits 54.. of the sorted value
-  // (rows < 2^54), so the passes after the sort read it in order instead of gathering it
-  const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (p < n_cand) {
-    const unsigned long long row = rows[p];
-    keys[p] = d0[row];
-    rows[p] = row | ((unsigned long long)first[row] << 54);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long oc = __shfl_down(bo, o, 64), orow = __shfl_down(br, o, 64);
+    if (oc < bo || (oc == bo && orow < br)) {
+      bo = oc;
+      br = orow;
+    }
   }
-}
-
-__global__ void __launch_bounds__(256)
-ti1_stops_kernel(const unsigned long long *__restrict__ sorted_rows, size_t n_cand, int n_off,
-                 unsigned long long *__restrict__ g) {
-  // Position p stops the sweep of every offset o < f(p), so g[o] = min{p : f(p) > o}.  One
-  // conditional atomicMin per position on m[f] = min{p : f(p) = f} (held in g2[1..n_off]); the
-  // suffix minimum g[o] = min(m[o+1..n_off]) is taken by ti1_suffix_min_kernel.
-  // Per workgroup: LDS minima of the 256 positions by f, then one conditional global atomicMin per
-  // f that occurred (a per-position global atomic serialises on the ~40 hot addresses).
-  __shared__ unsigned ms[kMaxOff + 1];
-  for (int o = threadIdx.x; o <= n_off; o += 256) ms[o] = 0xffffffffu;
+  if (lane == 0) {
+    sord[wave] = bo;
+    srow[wave] = br;
+  }
+  const size_t per = (n_blocks + 1023) / 1024;
+  const size_t b0 = (size_t)threadIdx.x * per;
+  const size_t b1 = b0 + per < n_blocks ? b0 + per : n_blocks;
+  unsigned long long s = 0;
+  for (size_t b = b0; b < b1; ++b) s += block_sums[b];
+  unsigned long long inc = s;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned long long v = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += v;
+  }
+  if (lane == 63) wsum[wave] = inc;
   __syncthreads();
-  const size_t base = (size_t)blockIdx.x * 256;
-  const size_t p = base + threadIdx.x;
-  int f = 0;
-  if (p < n_cand) {
-    f = (int)(sorted_rows[p] >> 54);
-    if (f > n_off) f = n_off;
+  unsigned long long run = inc - s;
+  for (int i = 0; i < wave; ++i) run += wsum[i];
+  if (threadIdx.x == 1023) ctrl->n_cand = run + s;
+  for (size_t b = b0; b < b1; ++b) {
+    const unsigned long long v = block_sums[b];
+    block_sums[b] = run;
+    run += v;
   }
-  // positions are sorted by the distance `first` grows with, so runs of equal f are long: only the
-  // first lane of a run (within its wavefront) can be the minimum and touches the LDS
-  const int prev = __shfl_up(f, 1, 64);
-  if (f > 0 && ((threadIdx.x & 63) == 0 || prev != f)) atomicMin(&ms[f], (unsigned)threadIdx.x);
-  __syncthreads();
-  for (int o = 1 + threadIdx.x; o <= n_off; o += 256) {
-    const unsigned m = ms[o];
-    if (m != 0xffffffffu && g[n_off + o] > base + m) atomicMin(&g[n_off + o], (unsigned long long)(base + m));
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 16; ++i)
+      if (sord[i] < bo || (sord[i] == bo && srow[i] < br)) {
+        bo = sord[i];
+        br = srow[i];
+      }
+    ctrl->stop_ord = (unsigned)bo;
+    ctrl->stop_row = br;
   }
 }
 
-// g[0..n_off) <- suffix minima of m = g[n_off+1 .. 2 n_off]
-__global__ void __launch_bounds__(64)
-ti1_suffix_min_kernel(unsigned long long *__restrict__ g, int n_off) {
-  if (threadIdx.x != 0) return;
-  unsigned long long run = g[2 * n_off];
-  for (int o = n_off - 1; o >= 0; --o) {
-    const unsigned long long m = g[n_off + o + 1];
-    run = m < run ? m : run;
-    g[o] = run;
+constexpr int kExpandBatch = 8;      // mask words (rows per lane) in flight per wavefront of the expand pass
+
+// The candidates, in row order: key = ord(d0), value = row | f << row_bits.  A wavefront takes the 64 mask
+// words of its quarter of a compaction block, kExpandBatch at a time (lane = bit: coalesced reads of the rows' distances,
+// dense writes).
+// BY_OFFSET (the 2D sweep): key = f itself, value = the row; the distances are not read.
+template <bool BY_OFFSET, typename V, typename F>
+__global__ void __launch_bounds__(256)
+ti1_expand_kernel(const uint64_t *__restrict__ mask, size_t n_words, size_t n_rows,
+                  const unsigned long long *__restrict__ block_offsets, const float2 *__restrict__ dist, const F *__restrict__ first, const Bnd *__restrict__ bnd, int slope,
+                  int row_bits, unsigned *__restrict__ keys, V *__restrict__ vals) {
+  __shared__ unsigned sh_wave[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t w0 = (size_t)blockIdx.x * kCbWords + (size_t)wave * 64;
+  // candidates in this wavefront's 64 words (lane l counts word l)
+  unsigned c = 0;
+  if (w0 + lane < n_words) c = (unsigned)__popcll(mask[w0 + lane]);
+  unsigned inc = c;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned v = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += v;
   }
+  if (lane == 63) sh_wave[wave] = inc;
+  __syncthreads();
+  size_t base = (size_t)block_offsets[blockIdx.x];
+  for (int i = 0; i < wave; ++i) base += sh_wave[i];
+  const unsigned excl = inc - c;      // lane l: candidates in words before word l of this wavefront
+  const Bnd b0 = bnd[0];
+  const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
+  for (int g = 0; g < 64; g += kExpandBatch) {
+    if (w0 + g >= n_words) break;
+    float2 d[kExpandBatch];
+    unsigned f[kExpandBatch];
+    uint64_t m[kExpandBatch];
+    unsigned off[kExpandBatch];
+#pragma unroll
+    for (int k = 0; k < kExpandBatch; ++k) {
+      const size_t w = w0 + g + k;
+      m[k] = w < n_words ? mask[w] : 0ull;      // wave-uniform
+      off[k] = __shfl(excl, g + k, 64);
+      const size_t row = w * 64 + lane;
+      // every row's distance is fetched, candidate or not: the lines come in whole anyway, and loads that do not
+      // wait for the mask word are all in flight together
+      const size_t rr = row < n_rows ? row : n_rows - 1;
+      d[k] = make_float2(0.f, 0.f);
+      if constexpr (!BY_OFFSET) d[k] = dist[rr];
+      f[k] = first[rr];
+    }
+#pragma unroll
+    for (int k = 0; k < kExpandBatch; ++k) {
+      if (!((m[k] >> lane) & 1)) continue;
+      const size_t row = (w0 + g + k) * 64 + lane;
+      const size_t pos = base + off[k] + (unsigned)__popcll(m[k] & below);
+      if constexpr (BY_OFFSET) {
+        keys[pos] = f[k];
+        vals[pos] = (V)row;
+      } else {
+        float d0 = ppk_line_dist(d[k].x, d[k].y, b0.xm, b0.ym, slope);
+        d0 = d0 + 0.0f;
+        keys[pos] = f2ord(d0);
+        vals[pos] = (V)((unsigned long long)row | ((unsigned long long)f[k] << row_bits));
+      }
+    }
+  }
+}
+
+constexpr int kEmitBlock = 1024;      // sorted positions per workgroup of the two passes below
+
+// Per workgroup of sorted positions: the largest f, and the first position at or after the stop.
+template <typename V>
+__global__ void __launch_bounds__(kEmitBlock)
+ti1_blockmax_kernel(const unsigned *__restrict__ keys, const V *__restrict__ vals, size_t n_cand, int row_bits,
+                    unsigned *__restrict__ blockmax, Ctrl *__restrict__ ctrl) {
+  __shared__ unsigned sh[kEmitBlock / 64];
+  const size_t p = (size_t)blockIdx.x * kEmitBlock + threadIdx.x;
+  unsigned f = 0;
+  bool past = false;
+  if (p < n_cand) {
+    const unsigned long long v = vals[p];
+    f = (unsigned)(v >> row_bits);
+    const unsigned long long row = v & ((1ull << row_bits) - 1);
+    const unsigned key = keys[p];
+    past = key > ctrl->stop_ord || (key == ctrl->stop_ord && row > ctrl->stop_row);
+  }
+  const uint64_t pm = __ballot(past);
+  if (pm && (threadIdx.x & 63) == 0) {
+    // positions are sorted: the first lane past the stop is the minimum of this wavefront
+    const unsigned long long q = (unsigned long long)p + (unsigned)__builtin_ctzll(pm);
+    if (q < ctrl->n_cut) atomicMin(&ctrl->n_cut, q);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned v = __shfl_down(f, o, 64);
+    f = v > f ? v : f;
+  }
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = f;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned t = 0;
+    for (int i = 0; i < kEmitBlock / 64; ++i) t = sh[i] > t ? sh[i] : t;
+    blockmax[blockIdx.x] = t;
+  }
+}
+
+// exclusive running maximum of the workgroups' maxima (one workgroup), and the number emitted
+__global__ void __launch_bounds__(1024)
+ti1_prefix_max_kernel(unsigned *__restrict__ blockmax, size_t n_blocks, Ctrl *__restrict__ ctrl, size_t n_cand,
+                      unsigned long long *__restrict__ n_out) {
+  __shared__ unsigned wmax[16];
+  const size_t per = (n_blocks + 1023) / 1024;
+  const size_t b0 = (size_t)threadIdx.x * per;
+  const size_t b1 = b0 + per < n_blocks ? b0 + per : n_blocks;
+  unsigned s = 0;
+  for (size_t b = b0; b < b1; ++b) s = blockmax[b] > s ? blockmax[b] : s;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned inc = s;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned v = __shfl_up(inc, o, 64);
+    if (lane >= o) inc = v > inc ? v : inc;
+  }
+  if (lane == 63) wmax[wave] = inc;
+  __syncthreads();
+  unsigned run = __shfl_up(inc, 1, 64);
+  if (lane == 0) run = 0;
+  for (int i = 0; i < wave; ++i) run = wmax[i] > run ? wmax[i] : run;
+  for (size_t b = b0; b < b1; ++b) {
+    const unsigned v = blockmax[b];
+    blockmax[b] = run;
+    run = v > run ? v : run;
+  }
+  if (threadIdx.x == 0) *n_out = ctrl->n_cut < n_cand ? ctrl->n_cut : n_cand;
 }
 
 __device__ __forceinline__ size_t crow_start(size_t i, size_t n) { return i * n - (i * (i + 1)) / 2; }
+// (i of condensed row k, src/boundary.cpp:22-27) a float estimate of the reference's double expression, then
+// the integer fix-up that makes it exact for every n
 __device__ __forceinline__ size_t crow_idx(size_t k, size_t n) {
-  const double d = sqrt((double)(4 * n * (n - 1)) - 8.0 * (double)k - 7.0);
-  long long i = (long long)n - 2 - (long long)floor(d / 2.0 - 0.5);
+  const float d = __fsqrt_rn((float)(4 * n * (n - 1) - 8 * k - 7));
+  long long i = (long long)n - 2 - (long long)floorf(d * 0.5f - 0.5f);
   if (i < 0) i = 0;
   if (i > (long long)n - 2) i = (long long)n - 2;
   while (i > 0 && crow_start((size_t)i, n) > k) --i;
@@ -168,39 +528,107 @@ __device__ __forceinline__ size_t crow_idx(size_t k, size_t n) {
   return (size_t)i;
 }
 
-__global__ void __launch_bounds__(256)
-ti1_emit_kernel(const unsigned long long *__restrict__ sorted_rows, size_t n_cand, int n_off,
-                const unsigned long long *__restrict__ g, size_t n_samples,
-                long long *__restrict__ oi, long long *__restrict__ oj, long long *__restrict__ oo,
-                size_t cap, unsigned long long *__restrict__ n_out) {
-  const unsigned long long n_emit = g[n_off - 1] < n_cand ? g[n_off - 1] : n_cand;
-  const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (p == 0) *n_out = n_emit;
+// (i, j) with 32-bit arithmetic: 4 n (n - 1) fits when n <= 32 768
+__device__ __forceinline__ void crow_ij32(unsigned k, unsigned n, long long &oi, long long &oj) {
+  const float d = __fsqrt_rn((float)(4u * n * (n - 1u) - 8u * k - 7u));
+  int i = (int)n - 2 - (int)floorf(d * 0.5f - 0.5f);
+  if (i < 0) i = 0;
+  if (i > (int)n - 2) i = (int)n - 2;
+  auto start = [n](unsigned ii) { return ii * n - (ii * (ii + 1u)) / 2u; };
+  while (i > 0 && start((unsigned)i) > k) --i;
+  while ((unsigned)i + 2u < n && start((unsigned)i + 1u) <= k) ++i;
+  oi = i;
+  oj = (long long)(k - start((unsigned)i) + (unsigned)i + 1u);
+}
+
+template <typename V>
+__global__ void __launch_bounds__(kEmitBlock)
+ti1_emit_kernel(const V *__restrict__ vals, int row_bits, const unsigned *__restrict__ blockmax,
+                const unsigned long long *__restrict__ n_out, int n_off, size_t n_samples,
+                long long *__restrict__ oi, long long *__restrict__ oj, long long *__restrict__ oo, size_t cap) {
+  __shared__ unsigned sh[kEmitBlock / 64];
+  const unsigned long long n_emit = *n_out;
+  const size_t p = (size_t)blockIdx.x * kEmitBlock + threadIdx.x;
+  if ((size_t)blockIdx.x * kEmitBlock >= n_emit) return;      // workgroup-uniform
+  unsigned long long v = 0;
+  unsigned f = 0;
+  if (p < n_emit) {
+    v = vals[p];
+    f = (unsigned)(v >> row_bits);
+  }
+  // inclusive running maximum of f over the workgroup, seeded with the workgroups before it
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned inc = f;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc = t > inc ? t : inc;
+  }
+  if (lane == 63) sh[wave] = inc;
+  __syncthreads();
+  unsigned run = blockmax[blockIdx.x];
+  for (int i = 0; i < wave; ++i) run = sh[i] > run ? sh[i] : run;
+  const unsigned o = inc > run ? inc : run;
   if (p >= n_emit || p >= cap) return;
-  int o = 0;
-  while (o < n_off - 1 && p >= g[o]) ++o;
-  const size_t row = sorted_rows[p] & ((1ull << 54) - 1);
-  const size_t i = crow_idx(row, n_samples);
-  oi[p] = (long long)i;
-  oj[p] = (long long)(row - crow_start(i, n_samples) + i + 1);
-  oo[p] = o;
+  const size_t row = (size_t)(v & ((1ull << row_bits) - 1));
+  long long ii, jj;
+  if (n_samples <= 32768) {      // (uniform)
+    crow_ij32((unsigned)row, (unsigned)n_samples, ii, jj);
+  } else {
+    const size_t i = crow_idx(row, n_samples);
+    ii = (long long)i;
+    jj = (long long)(row - crow_start(i, n_samples) + i + 1);
+  }
+  __builtin_nontemporal_store(ii, oi + p);
+  __builtin_nontemporal_store(jj, oj + p);
+  __builtin_nontemporal_store((long long)(o < (unsigned)n_off ? o : (unsigned)n_off - 1), oo + p);
+}
+
+// 2D: (offset, row) pairs sorted by offset -> (i, j, offset); every candidate is listed
+template <typename V>
+__global__ void __launch_bounds__(256)
+ti2_emit_kernel(const unsigned *__restrict__ keys, const V *__restrict__ vals, size_t n_cand, size_t n_samples,
+                long long *__restrict__ oi, long long *__restrict__ oj, long long *__restrict__ oo, size_t cap,
+                unsigned long long *__restrict__ n_out) {
+  const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (p == 0) *n_out = n_cand;
+  if (p >= n_cand || p >= cap) return;
+  const size_t row = (size_t)vals[p];
+  long long ii, jj;
+  if (n_samples <= 32768) {      // (uniform)
+    crow_ij32((unsigned)row, (unsigned)n_samples, ii, jj);
+  } else {
+    const size_t i = crow_idx(row, n_samples);
+    ii = (long long)i;
+    jj = (long long)(row - crow_start(i, n_samples) + i + 1);
+  }
+  oi[p] = ii;
+  oj[p] = jj;
+  oo[p] = (long long)keys[p];
 }
 
 // Exact sequential sweep (boundary.cpp:192-207) over the sorted candidates by ONE thread: only
 // used when some row is within a boundary but outside a later one, where the closed form above
 // does not apply.  Candidates are few (the rows near the boundaries), so this stays cheap.
-__global__ void ti1_serial_kernel(const unsigned long long *__restrict__ sorted_rows, size_t n_cand,
-                                  const float2 *__restrict__ dist, const Boundaries b,
-                                  size_t n_samples, long long *__restrict__ oi,
-                                  long long *__restrict__ oj, long long *__restrict__ oo, size_t cap,
-                                  unsigned long long *__restrict__ n_out) {
+template <typename V>
+__global__ void ti1_serial_kernel(const unsigned *__restrict__ keys, const V *__restrict__ vals, size_t n_cand,
+                                  int row_bits, const float2 *__restrict__ dist, const Bnd *__restrict__ bnd,
+                                  int n_off, int slope, const Ctrl *__restrict__ ctrl, size_t n_samples,
+                                  long long *__restrict__ oi, long long *__restrict__ oj,
+                                  long long *__restrict__ oo, size_t cap, unsigned long long *__restrict__ n_out) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   size_t p = 0;
-  for (int o = 0; o < b.n && p < n_cand; ++o) {
+  bool stopped = false;
+  for (int o = 0; o < n_off && p < n_cand && !stopped; ++o) {
     while (p < n_cand) {
-      const size_t row = sorted_rows[p] & ((1ull << 54) - 1);
+      const size_t row = (size_t)((unsigned long long)vals[p] & ((1ull << row_bits) - 1));
+      // the reference's order holds every row: one that no boundary contains ends the walk here
+      if (keys[p] > ctrl->stop_ord || (keys[p] == ctrl->stop_ord && row > ctrl->stop_row)) {
+        stopped = true;
+        break;
+      }
       const float2 d = dist[row];
-      if (!(ppk_line_dist(d.x, d.y, b.xy[o].x, b.xy[o].y, b.slope) <= 0.0f)) break;
+      if (!(ppk_line_dist(d.x, d.y, bnd[o].xm, bnd[o].ym, slope) <= 0.0f)) break;
       if (p < cap) {
         const size_t i = crow_idx(row, n_samples);
         oi[p] = (long long)i;
@@ -213,32 +641,105 @@ __global__ void ti1_serial_kernel(const unsigned long long *__restrict__ sorted_
   *n_out = p;
 }
 
-__global__ void __launch_bounds__(256)
-fill_u64_kernel(unsigned long long *p, size_t n, unsigned long long v) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) p[i] = v;
-}
-
-// 2D: one ballot word per (offset, 64 rows)
-__global__ void __launch_bounds__(256)
-ti2_mask_kernel(const float2 *__restrict__ dist, size_t n_rows, const Boundaries b,
-                uint64_t *__restrict__ mask, size_t n_words) {
-  const size_t wstride = (size_t)gridDim.x * 4;
-  const int lane = threadIdx.x & 63;
-  for (size_t w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); w < n_words; w += wstride) {
-    const size_t row = w * 64 + lane;
-    float2 d = make_float2(0.f, 0.f);
-    const bool in = row < n_rows;
-    if (in) d = dist[row];
-    for (int o = 0; o < b.n; ++o) {
-      const float s = ppk_line_dist(d.x, d.y, b.xy[o].x, b.xy[0].y, 2);
-      const bool within = s <= 0.0f;
-      // boundary.cpp:221-226: within boundary o, and (o == 0 or line_dist(o-1) > 0)
+// 2D: one ballot word per (offset, 64 rows) (boundary.cpp:221-226: within boundary o, and o == 0 or
+// line_dist(o - 1) > 0).  The mask is laid out [offset][seg_words], seg_words = the row words rounded up to whole
+// compaction blocks, so that a workgroup owns compaction block cb of EVERY offset: it leaves the blocks' bit counts
+// with the words (no counting pass) and the expand pass finds its offset from per-offset totals (no scan pass).
+// A wavefront keeps the rows of 32 consecutive words in registers (one read of the matrix however many offsets),
+// takes the offsets kOffChunk at a time with their boundaries in SGPRs, gathers each offset's 32 ballots into lanes
+// 0..31 (lane k <- word k: one narrowing of exec per word, a v_mov per half) and stores them as one 256-byte run --
+// a store per ballot from lane 0, a scalar load per evaluation and a re-read of the rows per offset were what the
+// first form of this pass spent its time on (465 us for 20 offsets on 5e7 rows).
+// FAST: y_max != 0, no x_max == 0, every product finite: "within" is fl(fl(y x_max) + fl(x y_max)) <= c and
+// "outside" the same sum > c (the signs of the reference's rounded difference; NaN fails both, as there).
+constexpr int kOffChunk = 16;
+constexpr int kTi2Words = 32;      // words per wavefront; 8 wavefronts = one compaction block
+template <bool FAST>
+__global__ void __launch_bounds__(512)
+ti2_mask_kernel(const float2 *__restrict__ dist, size_t n_rows, const Bnd *__restrict__ bnd, int n_off,
+                uint64_t *__restrict__ mask, size_t n_words, size_t seg_words,
+                unsigned long long *__restrict__ block_sums, size_t seg_blocks) {
+  __shared__ unsigned sh[kOffChunk];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t cb = blockIdx.x;
+  const size_t w0 = cb * kCbWords + (size_t)wave * kTi2Words;
+  const size_t last_row = n_rows - 1;
+  float x[kTi2Words], y[kTi2Words];
+#pragma unroll
+  for (int k = 0; k < kTi2Words; ++k) {
+    const size_t row = (w0 + k) * 64 + lane;
+    const float2 d = dist[row < last_row ? row : last_row];
+    x[k] = d.x;
+    y[k] = d.y;
+  }
+  // lanes whose row exists (the clamped duplicates of the last row must not set a bit): one compare per word, and
+  // only in the wavefront that holds the end of the matrix
+  const bool full = (w0 + kTi2Words) * 64 <= n_rows;      // wave-uniform
+  const unsigned n_tail = full ? 0u : (unsigned)(n_rows > w0 * 64 ? n_rows - w0 * 64 : 0);      // rows of this wavefront
+  for (int o0 = 0; o0 < n_off; o0 += kOffChunk) {
+    const int oc = n_off - o0 < kOffChunk ? n_off - o0 : kOffChunk;      // workgroup-uniform
+    if (threadIdx.x < kOffChunk) sh[threadIdx.x] = 0;
+    __syncthreads();
+    Bnd B[kOffChunk];
+#pragma unroll
+    for (int j = 0; j < kOffChunk; ++j) B[j] = bnd[o0 + j < n_off ? o0 + j : n_off - 1];
+    const Bnd P = bnd[o0 ? o0 - 1 : 0];
+    unsigned rlo[kOffChunk], rhi[kOffChunk];
+#pragma unroll
+    for (int j = 0; j < kOffChunk; ++j) rlo[j] = rhi[j] = 0;
+    // (an SGPR zero the optimiser cannot see through: the 32 "lane == k" masks are then made where they are used,
+    // not hoisted out of this loop into 64 SGPRs that do not exist)
+    int zero = 0;
+    asm volatile("" : "+s"(zero));
+#pragma unroll
+    for (int k = 0; k < kTi2Words; ++k) {
+      // "the boundary before this chunk excludes the row": true before the first offset
       bool prev_out = true;
-      if (o > 0) prev_out = ppk_line_dist(d.x, d.y, b.xy[o - 1].x, b.xy[0].y, 2) > 0.0f;
-      const uint64_t bits = __ballot(in && within && prev_out);
-      if (lane == 0) mask[(size_t)o * n_words + w] = bits;
+      if (o0 > 0) {
+        if constexpr (FAST) prev_out = __fadd_rn(__fmul_rn(y[k], P.xm), __fmul_rn(x[k], P.ym)) > P.c;
+        else prev_out = ppk_line_dist(x[k], y[k], P.xm, P.ym, 2) > 0.0f;
+      }
+      const uint64_t valid = full ? ~0ull : __ballot((unsigned)(k * 64 + lane) < n_tail);
+      uint64_t pm = __ballot(prev_out) & valid;
+      uint64_t mm[kOffChunk];      // this word's ballots (SGPR pairs)
+#pragma unroll
+      for (int j = 0; j < kOffChunk; ++j) {
+        bool le, gt;
+        if constexpr (FAST) {
+          const float a = __fadd_rn(__fmul_rn(y[k], B[j].xm), __fmul_rn(x[k], B[j].ym));
+          le = a <= B[j].c;
+          gt = a > B[j].c;
+        } else {
+          const float sd = ppk_line_dist(x[k], y[k], B[j].xm, B[j].ym, 2);
+          le = sd <= 0.0f;
+          gt = sd > 0.0f;
+        }
+        mm[j] = __ballot(le) & pm;
+        pm = __ballot(gt) & valid;
+      }
+      if (lane == k + zero) {
+#pragma unroll
+        for (int j = 0; j < kOffChunk; ++j) {
+          rlo[j] = (unsigned)mm[j];
+          rhi[j] = (unsigned)(mm[j] >> 32);
+        }
+      }
+      // one word at a time: interleaving the words' ballots only lengthens the lives of 16 SGPR pairs each
+      __builtin_amdgcn_sched_barrier(0);
     }
+#pragma unroll
+    for (int j = 0; j < kOffChunk; ++j) {
+      if (j >= oc) break;      // workgroup-uniform
+      // (words past the rows' end are zero: no lane of theirs is valid)
+      if (lane < kTi2Words) mask[(size_t)(o0 + j) * seg_words + w0 + lane] = (uint64_t)rlo[j] | ((uint64_t)rhi[j] << 32);
+      unsigned c = (unsigned)__popc(rlo[j]) + (unsigned)__popc(rhi[j]);
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
+      if (lane == 0 && c) atomicAdd(&sh[j], c);
+    }
+    __syncthreads();
+    if (threadIdx.x < (unsigned)oc) block_sums[(size_t)(o0 + threadIdx.x) * seg_blocks + cb] = sh[threadIdx.x];
+    __syncthreads();
   }
 }
 
@@ -252,6 +753,265 @@ size_t samples_of(size_t n_rows) {
 inline unsigned nblk(size_t n, size_t per = 256) { return (unsigned)((n + per - 1) / per); }
 
 }  // namespace
+
+namespace {
+
+inline int bits_for(unsigned long long v) {      // bits that hold every value 0..v
+  int b = 1;
+  while (b < 64 && (v >> b)) ++b;
+  return b;
+}
+
+// workgroups of `threads` that the device holds at once for this kernel (occupancy x compute units)
+unsigned resident_workgroups(int dev, const void *kernel, int threads, size_t dyn_lds) {
+  int per_cu = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, dyn_lds) != hipSuccess || per_cu < 1) per_cu = 4;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+  return (unsigned)per_cu * (unsigned)cus;
+}
+
+// one pinned control block per device (the caller holds that device's PpkCall: one call at a time); kept for the
+// life of the process
+Ctrl *pinned_ctrl(int dev) {
+  static Ctrl *blocks[64] = {};
+  if (dev < 0 || dev >= 64) return nullptr;
+  if (!blocks[dev] && hipHostMalloc(reinterpret_cast<void **>(&blocks[dev]), 256, hipHostMallocDefault) != hipSuccess)
+    blocks[dev] = nullptr;
+  return blocks[dev];
+}
+
+// what the classify pass leaves on the device, and the control block as the host read it after its one sync
+template <typename F>
+struct Classified {
+  const Bnd *d_bnd = nullptr;
+  const F *first = nullptr;
+  const uint64_t *mask = nullptr;
+  const unsigned long long *block_offsets = nullptr;
+  Ctrl *ctrl = nullptr;
+  size_t n_words = 0, n_cblocks = 0;
+  Ctrl got = {};
+};
+
+// the fast slope-2 form wants positive finite intercepts (see ti1_classify_kernel); anything else -- a boundary on
+// an axis takes the reference's sqrt branch -- goes through ppk_line_dist as it stands
+int classify_mode(const std::vector<Bnd> &bnd, int slope) {
+  if (slope != 2) return slope;
+  for (const Bnd &b : bnd)
+    if (!(b.xm > 0.0f) || !(b.ym > 0.0f) || !std::isfinite(b.xm) || !std::isfinite(b.ym) || !std::isfinite(b.c)) return 3;
+  return 2;
+}
+
+// classify + scan, then ONE synchronisation: the candidate count sizes everything after it
+template <typename F>
+int ti_classify(int dev, hipStream_t s, const float2 *dist, size_t n_rows, const std::vector<Bnd> &bnd, int slope,
+                Classified<F> &out) {
+  std::vector<Bnd> padded(bnd);
+  while (padded.size() % 4) padded.push_back(bnd.back());
+  const int n_pad = (int)padded.size();
+  const size_t n_words = ppk_mask_words_linear(n_rows);
+  const size_t n_cblocks = (n_words + kCbWords - 1) / kCbWords;
+  const size_t n_units = (n_words + kUnitWords - 1) / kUnitWords;
+  const int mode = classify_mode(bnd, slope);
+  // the filter: one boundary that contains all the others (the last of an outward sweep), nothing tiny
+  Bnd filt = {};
+  bool filter = mode == 2;
+  if (filter) {
+    size_t L = 0;
+    for (size_t o = 1; o < bnd.size(); ++o)
+      if (bnd[o].xm > bnd[L].xm) L = o;
+    const float tiny = 9.094947e-13f;      // 2^-40
+    for (const Bnd &b : bnd) filter = filter && b.xm <= bnd[L].xm && b.ym <= bnd[L].ym && b.xm >= tiny && b.ym >= tiny;
+    volatile float t = bnd[L].c * 1.00000095367431640625f;      // c_L (1 + 2^-20), rounded once
+    filt = Bnd{bnd[L].xm, bnd[L].ym, t, 0.0f};
+    filter = filter && std::isfinite(filt.c);
+  }
+  size_t lds = 0;
+  if (mode == 2) lds = ((size_t)n_pad + 1) * sizeof(float4);
+  if (filter) lds += 4 * ((size_t)kUnitWords * 64 + 64) * (sizeof(float2) + sizeof(unsigned));
+  const void *kfn = mode == 0   ? reinterpret_cast<const void *>(&ti1_classify_kernel<0, false, F>)
+                    : mode == 1 ? reinterpret_cast<const void *>(&ti1_classify_kernel<1, false, F>)
+                    : mode == 3 ? reinterpret_cast<const void *>(&ti1_classify_kernel<3, false, F>)
+                    : filter    ? reinterpret_cast<const void *>(&ti1_classify_kernel<2, true, F>)
+                                : reinterpret_cast<const void *>(&ti1_classify_kernel<2, false, F>);
+  // exactly one round of resident workgroups (the rows are dealt out evenly whatever the grid; a second, partial
+  // round would only add a tail), fewer when there is less than a unit per wavefront
+  unsigned grid = resident_workgroups(dev, kfn, 256, lds);
+  if ((size_t)grid * 4 > n_units) grid = (unsigned)((n_units + 3) / 4);
+  const size_t n_stops = (size_t)grid * 4;
+
+  void *p_bnd = nullptr, *p_a = nullptr, *p_mask = nullptr, *p_ws = nullptr;
+  int rc = ppk_scratch_get(dev, SLOT_BOUNDS, padded.size() * sizeof(Bnd) + 256, &p_bnd);
+  if (rc != PPK_OK) return rc;
+  PPK_HIP(hipMemcpyAsync(p_bnd, padded.data(), padded.size() * sizeof(Bnd), hipMemcpyHostToDevice, s));
+  const Bnd *d_bnd = static_cast<const Bnd *>(p_bnd);
+  // A: ctrl | stops (16 B per wavefront of the classify pass) | first (F per row)
+  const size_t a_stops = 256, a_first = a_stops + ((n_stops * 16 + 255) & ~(size_t)255);
+  rc = ppk_scratch_get(dev, SLOT_ITER_A, a_first + n_rows * sizeof(F) + 256, &p_a);
+  if (rc == PPK_OK) rc = ppk_scratch_get(dev, SLOT_MASK, n_words * 8 + 8, &p_mask);
+  if (rc == PPK_OK) rc = ppk_scratch_get(dev, SLOT_WS, n_cblocks * 8 + 256, &p_ws);
+  if (rc != PPK_OK) return rc;
+  char *A = static_cast<char *>(p_a);
+  Ctrl *ctrl = reinterpret_cast<Ctrl *>(A);
+  ulonglong2 *stops = reinterpret_cast<ulonglong2 *>(A + a_stops);
+  F *first = reinterpret_cast<F *>(A + a_first);
+  uint64_t *mask = static_cast<uint64_t *>(p_mask);
+  unsigned long long *block_sums = static_cast<unsigned long long *>(p_ws);
+
+  Ctrl h = {};
+  h.n_cut = ~0ull;
+  h.stop_ord = 0xffffffffu;
+  h.stop_row = ~0ull;
+  ppk_prof_stage("classify", s);
+  PPK_HIP(hipMemcpyAsync(ctrl, &h, sizeof(Ctrl), hipMemcpyHostToDevice, s));      // (h is copied at the call: pageable)
+  PPK_HIP(hipMemsetAsync(block_sums, 0, n_cblocks * 8, s));
+#define PPK_TI1_CLASSIFY(M, FL)                                                                                     \
+  hipLaunchKernelGGL((ti1_classify_kernel<M, FL, F>), dim3(grid), dim3(256), lds, s, dist, n_rows, d_bnd, n_pad, slope, \
+                     filt, first, mask, n_words, block_sums, stops, ctrl)
+  if (mode == 0) PPK_TI1_CLASSIFY(0, false);
+  else if (mode == 1) PPK_TI1_CLASSIFY(1, false);
+  else if (mode == 3) PPK_TI1_CLASSIFY(3, false);
+  else if (filter) PPK_TI1_CLASSIFY(2, true);
+  else PPK_TI1_CLASSIFY(2, false);
+#undef PPK_TI1_CLASSIFY
+  ppk_prof_stage("scan", s);
+  hipLaunchKernelGGL(ti1_scan_kernel, dim3(1), dim3(1024), 0, s, block_sums, n_cblocks, stops, n_stops, ctrl);
+  ppk_prof_stage(nullptr, s);
+  PPK_HIP(hipGetLastError());
+  // (read back into pinned memory: a copy to pageable memory goes through a staging kernel of its own)
+  Ctrl *h_ctrl = pinned_ctrl(dev);
+  if (!h_ctrl) return ppk_fail(PPK_ERR_HIP, "hipHostMalloc failed");
+  PPK_HIP(hipMemcpyAsync(h_ctrl, ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, s));
+  PPK_HIP(hipStreamSynchronize(s));
+  out.got = *h_ctrl;
+  out.d_bnd = d_bnd;
+  out.first = first;
+  out.mask = mask;
+  out.block_offsets = block_sums;
+  out.ctrl = ctrl;
+  out.n_words = n_words;
+  out.n_cblocks = n_cblocks;
+  return PPK_OK;
+}
+
+// keys | keys' | values | values' | one uint32 per kEmitBlock sorted positions, then the radix sort (stable)
+template <typename V>
+struct SortBufs {
+  unsigned *keys_in, *keys_out, *blockmax;
+  V *vals_in, *vals_out;
+  size_t n_eblocks;
+};
+template <typename V>
+int sort_bufs(int dev, size_t n_cand, SortBufs<V> &b) {
+  b.n_eblocks = (n_cand + kEmitBlock - 1) / kEmitBlock;
+  const size_t kb = (n_cand * 4 + 255) & ~(size_t)255, vb = (n_cand * sizeof(V) + 255) & ~(size_t)255;
+  void *p_b = nullptr;
+  int rc = ppk_scratch_get(dev, SLOT_ITER_B, 2 * kb + 2 * vb + b.n_eblocks * 4 + 256, &p_b);
+  if (rc != PPK_OK) return rc;
+  char *B = static_cast<char *>(p_b);
+  b.keys_in = reinterpret_cast<unsigned *>(B);
+  b.keys_out = reinterpret_cast<unsigned *>(B + kb);
+  b.vals_in = reinterpret_cast<V *>(B + 2 * kb);
+  b.vals_out = reinterpret_cast<V *>(B + 2 * kb + vb);
+  b.blockmax = reinterpret_cast<unsigned *>(B + 2 * kb + 2 * vb);
+  return PPK_OK;
+}
+template <typename V>
+int sort_pairs(int dev, hipStream_t s, const SortBufs<V> &b, size_t n_cand, int end_bit) {
+  // Onesweep whatever the size: below a million items rocPRIM's default would be a merge sort, 131 us for the 2-D
+  // sweep's 617 000 (5-bit key, row) pairs where one radix pass takes a fifth of that
+  typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0> Cfg;
+  size_t tmp_bytes = 0;
+  void *p_c = nullptr;
+  PPK_HIP(rocprim::radix_sort_pairs<Cfg>(nullptr, tmp_bytes, b.keys_in, b.keys_out, b.vals_in, b.vals_out, n_cand, 0u,
+                                         (unsigned)end_bit, s));
+  int rc = ppk_scratch_get(dev, SLOT_ITER_C, tmp_bytes + 256, &p_c);
+  if (rc != PPK_OK) return rc;
+  PPK_HIP(rocprim::radix_sort_pairs<Cfg>(p_c, tmp_bytes, b.keys_in, b.keys_out, b.vals_in, b.vals_out, n_cand, 0u,
+                                         (unsigned)end_bit, s));
+  return PPK_OK;
+}
+
+template <typename V, typename F>
+int ti1_after_count(int dev, hipStream_t s, const float2 *dist, size_t n_rows, const Classified<F> &c, int n_off,
+                    int slope, int row_bits, size_t n_samples, long long *d_i, long long *d_j, long long *d_off,
+                    size_t cap, unsigned long long *d_n_out) {
+  const size_t n_cand = (size_t)c.got.n_cand;
+  SortBufs<V> b;
+  int rc = sort_bufs<V>(dev, n_cand, b);
+  if (rc != PPK_OK) return rc;
+  ppk_prof_stage("expand", s);
+  hipLaunchKernelGGL((ti1_expand_kernel<false, V, F>), dim3((unsigned)c.n_cblocks), dim3(256), 0, s, c.mask, c.n_words,
+                     n_rows, c.block_offsets, dist, c.first, c.d_bnd, slope, row_bits, b.keys_in, b.vals_in);
+  ppk_prof_stage("sort", s);
+  rc = sort_pairs<V>(dev, s, b, n_cand, 32);
+  if (rc != PPK_OK) return rc;
+  ppk_prof_stage(c.got.holes ? "serial walk" : "running max", s);
+  if (c.got.holes) {
+    hipLaunchKernelGGL((ti1_serial_kernel<V>), dim3(1), dim3(1), 0, s, b.keys_out, b.vals_out, n_cand, row_bits, dist,
+                       c.d_bnd, n_off, slope, c.ctrl, n_samples, d_i, d_j, d_off, cap, d_n_out);
+    ppk_prof_stage(nullptr, s);
+    PPK_HIP(hipGetLastError());
+    return PPK_OK;
+  }
+  hipLaunchKernelGGL((ti1_blockmax_kernel<V>), dim3((unsigned)b.n_eblocks), dim3(kEmitBlock), 0, s, b.keys_out,
+                     b.vals_out, n_cand, row_bits, b.blockmax, c.ctrl);
+  hipLaunchKernelGGL(ti1_prefix_max_kernel, dim3(1), dim3(1024), 0, s, b.blockmax, b.n_eblocks, c.ctrl, n_cand,
+                     d_n_out);
+  ppk_prof_stage("emit", s);
+  hipLaunchKernelGGL((ti1_emit_kernel<V>), dim3((unsigned)b.n_eblocks), dim3(kEmitBlock), 0, s, b.vals_out, row_bits,
+                     b.blockmax, d_n_out, n_off, n_samples, d_i, d_j, d_off, cap);
+  ppk_prof_stage(nullptr, s);
+  PPK_HIP(hipGetLastError());
+  return PPK_OK;
+}
+
+template <typename F>
+int ti1_run(int dev, hipStream_t s, const float2 *dist, size_t n_rows, const std::vector<Bnd> &bnd, int slope,
+            size_t n_samples, long long *d_i, long long *d_j, long long *d_off, size_t cap,
+            unsigned long long *d_n_out) {
+  const int n_off = (int)bnd.size();
+  Classified<F> c;
+  int rc = ti_classify<F>(dev, s, dist, n_rows, bnd, slope, c);
+  if (rc != PPK_OK) return rc;
+  if (c.got.n_cand == 0) {
+    PPK_HIP(hipMemsetAsync(d_n_out, 0, sizeof(unsigned long long), s));
+    return PPK_OK;
+  }
+  if (c.got.n_cand > 0x7fffffffull) return ppk_fail(PPK_ERR_ARG, "too many candidate rows for one sort");
+  const int row_bits = bits_for(n_rows - 1), f_bits = bits_for((unsigned long long)n_off);
+  if (row_bits + f_bits <= 32)
+    return ti1_after_count<uint32_t, F>(dev, s, dist, n_rows, c, n_off, slope, row_bits, n_samples, d_i, d_j, d_off, cap,
+                                        d_n_out);
+  return ti1_after_count<uint64_t, F>(dev, s, dist, n_rows, c, n_off, slope, row_bits, n_samples, d_i, d_j, d_off, cap,
+                                      d_n_out);
+}
+
+// 2D without holes: a row is listed once, at the first boundary that holds it -- the classify pass's f -- and the
+// reference's offset-major / row-minor order is the candidates, taken in row order, stably sorted by f.
+template <typename V, typename F>
+int ti2_after_count(int dev, hipStream_t s, size_t n_rows, const Classified<F> &c, int n_off, size_t n_samples,
+                    long long *d_i, long long *d_j, long long *d_off, size_t cap, unsigned long long *d_n_out) {
+  const size_t n_cand = (size_t)c.got.n_cand;
+  SortBufs<V> b;
+  int rc = sort_bufs<V>(dev, n_cand, b);
+  if (rc != PPK_OK) return rc;
+  ppk_prof_stage("expand", s);
+  hipLaunchKernelGGL((ti1_expand_kernel<true, V, F>), dim3((unsigned)c.n_cblocks), dim3(256), 0, s, c.mask, c.n_words,
+                     n_rows, c.block_offsets, static_cast<const float2 *>(nullptr), c.first, c.d_bnd, 2, 0, b.keys_in,
+                     b.vals_in);
+  ppk_prof_stage("sort", s);
+  rc = sort_pairs<V>(dev, s, b, n_cand, bits_for((unsigned long long)n_off));
+  if (rc != PPK_OK) return rc;
+  ppk_prof_stage("emit", s);
+  hipLaunchKernelGGL((ti2_emit_kernel<V>), dim3((unsigned)((n_cand + 255) / 256)), dim3(256), 0, s, b.keys_out,
+                     b.vals_out, n_cand, n_samples, d_i, d_j, d_off, cap, d_n_out);
+  ppk_prof_stage(nullptr, s);
+  PPK_HIP(hipGetLastError());
+  return PPK_OK;
+}
+
+}  // namespace
+
 
 extern "C" int ppk_threshold_iterate_1d_dev(const float *d_dist, size_t n_rows,
                                             const double *offsets, size_t n_off, int slope,
@@ -276,116 +1036,37 @@ extern "C" int ppk_threshold_iterate_1d_dev(const float *d_dist, size_t n_rows,
   if (n_rows >= (size_t)0x7fffffff * 64) return ppk_fail(PPK_ERR_ARG, "too many rows");
 
   // boundaries, with the arithmetic of boundary.cpp:161-186 (float/double mix kept as is)
-  std::vector<float2> bxy(n_off);
-  Boundaries b = {};
-  b.n = (int)n_off;
-  b.slope = slope;
+  std::vector<Bnd> bnd(n_off);
   const float dx = x1 - x0, dy = y1 - y0;
   const float ds = std::sqrt(dx * dx + dy * dy);
   const float gradient = dy / dx;
   for (size_t o = 0; o < n_off; ++o) {
     const float x_int = (float)((double)x0 + offsets[o] * (double)(dx / ds));
     const float y_int = (float)((double)y0 + offsets[o] * (double)(dy / ds));
+    Bnd &b = bnd[o];
     if (slope == 2) {
-      bxy[o].x = x_int + y_int * gradient;
-      bxy[o].y = y_int + x_int / gradient;
+      b.xm = x_int + y_int * gradient;
+      b.ym = y_int + x_int / gradient;
     } else if (slope == 0) {
-      bxy[o].x = x_int;
-      bxy[o].y = 0;
+      b.xm = x_int;
+      b.ym = 0;
     } else {
-      bxy[o].x = 0;
-      bxy[o].y = y_int;
+      b.xm = 0;
+      b.ym = y_int;
     }
+    // (a float product of two floats, rounded once: what line_dist computes per row, boundary.cpp:49)
+    volatile float prod = b.xm * b.ym;
+    b.c = prod;
+    b.pad = 0;
   }
 
   int dev = 0;
   PPK_HIP(hipGetDevice(&dev));
   PpkCall call(dev, s);
-  {
-    void *p_b = nullptr;     // the boundaries' own slot
-    int rcb = ppk_scratch_get(dev, SLOT_BOUNDS, n_off * sizeof(float2) + 256, &p_b);
-    if (rcb != PPK_OK) return rcb;
-    PPK_HIP(hipMemcpyAsync(p_b, bxy.data(), n_off * sizeof(float2), hipMemcpyHostToDevice, s));
-    b.xy = static_cast<const float2 *>(p_b);
-  }
-  const size_t n_words = ppk_mask_words_linear(n_rows);
-  void *p_a = nullptr, *p_mask = nullptr, *p_ws = nullptr;
-  // A: d0 (float) | first (u16) | max_ord (u32) | g (u64 x n_off)
-  const size_t a_d0 = 0, a_first = a_d0 + ((n_rows * 4 + 255) & ~(size_t)255);
-  const size_t a_max = a_first + ((n_rows * 2 + 255) & ~(size_t)255);
-  const size_t a_g = a_max + 256, a_end = a_g + (2 * n_off + 1) * 8 + 256;   // max_ord, non_monotone share a_max; g holds g[n_off] + m[n_off+1]
-  int rc = ppk_scratch_get(dev, SLOT_ITER_A, a_end, &p_a);
-  if (rc == PPK_OK) rc = ppk_scratch_get(dev, SLOT_MASK, n_words * 8 + 8, &p_mask);
-  if (rc == PPK_OK) rc = ppk_scratch_get(dev, SLOT_WS, ppk_compact_ws_bytes(n_words), &p_ws);
-  if (rc != PPK_OK) return rc;
-  char *A = static_cast<char *>(p_a);
-  float *d0 = reinterpret_cast<float *>(A + a_d0);
-  unsigned short *first = reinterpret_cast<unsigned short *>(A + a_first);
-  unsigned *max_ord = reinterpret_cast<unsigned *>(A + a_max);
-  unsigned long long *g = reinterpret_cast<unsigned long long *>(A + a_g);
-
-  unsigned *non_monotone = max_ord + 1;
-  PPK_HIP(hipMemsetAsync(max_ord, 0, 8, s));
-  hipLaunchKernelGGL(ti1_classify_kernel, dim3(std::min<unsigned>(nblk(n_rows), 4096)), dim3(256), 0,
-                     s, reinterpret_cast<const float2 *>(d_dist), n_rows, b, d0, first, max_ord,
-                     non_monotone);
-  hipLaunchKernelGGL(ti1_candidate_mask_kernel, dim3(std::min<unsigned>(nblk(n_words, 4), 4096)),
-                     dim3(256), 0, s, d0, n_rows, max_ord, static_cast<uint64_t *>(p_mask), n_words);
-  PPK_HIP(hipGetLastError());
-
-  // count candidates (cap 0), then size the sort buffers: the count is data dependent, so this
-  // entry point synchronises once here
-  EdgeGeom geo = {};
-  geo.layout = EDGE_ROWS;
-  geo.n_rows = n_rows;
-  rc = ppk_launch_compact(static_cast<uint64_t *>(p_mask), n_words, geo, p_ws, nullptr, 0, d_n_out, s);
-  if (rc != PPK_OK) return rc;
-  unsigned long long n_cand = 0;
-  unsigned holes = 0;
-  PPK_HIP(hipMemcpyAsync(&n_cand, d_n_out, 8, hipMemcpyDeviceToHost, s));
-  PPK_HIP(hipMemcpyAsync(&holes, non_monotone, 4, hipMemcpyDeviceToHost, s));
-  PPK_HIP(hipStreamSynchronize(s));
-  if (n_cand == 0) return PPK_OK;  // *d_n_out is already 0
-  if (n_cand > 0x7fffffffull) return ppk_fail(PPK_ERR_ARG, "too many candidate rows for one sort");
-
-  // B: rows_in (u64) | rows_out (u64) | keys_in (f32) | keys_out (f32) ; C: hipcub temp
-  void *p_b = nullptr, *p_c = nullptr;
-  const size_t b_rows_in = 0, b_rows_out = b_rows_in + n_cand * 8, b_keys_in = b_rows_out + n_cand * 8;
-  const size_t b_keys_out = b_keys_in + ((n_cand * 4 + 7) & ~(size_t)7), b_end = b_keys_out + n_cand * 4 + 8;
-  rc = ppk_scratch_get(dev, SLOT_ITER_B, b_end, &p_b);
-  if (rc != PPK_OK) return rc;
-  char *B = static_cast<char *>(p_b);
-  unsigned long long *rows_in = reinterpret_cast<unsigned long long *>(B + b_rows_in);
-  unsigned long long *rows_out = reinterpret_cast<unsigned long long *>(B + b_rows_out);
-  float *keys_in = reinterpret_cast<float *>(B + b_keys_in);
-  float *keys_out = reinterpret_cast<float *>(B + b_keys_out);
-  rc = ppk_launch_compact(static_cast<uint64_t *>(p_mask), n_words, geo, p_ws,
-                          reinterpret_cast<long long *>(rows_in), (size_t)n_cand, d_n_out, s);
-  if (rc != PPK_OK) return rc;
-  hipLaunchKernelGGL(ti1_gather_keys_kernel, dim3(nblk(n_cand)), dim3(256), 0, s, rows_in,
-                     (size_t)n_cand, d0, first, keys_in);
-  size_t tmp_bytes = 0;
-  PPK_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys_in, keys_out, rows_in, rows_out,
-                                             (int)n_cand, 0, 32, s));
-  rc = ppk_scratch_get(dev, SLOT_ITER_C, tmp_bytes + 256, &p_c);
-  if (rc != PPK_OK) return rc;
-  PPK_HIP(hipcub::DeviceRadixSort::SortPairs(p_c, tmp_bytes, keys_in, keys_out, rows_in, rows_out,
-                                             (int)n_cand, 0, 32, s));
-  if (holes) {
-    hipLaunchKernelGGL(ti1_serial_kernel, dim3(1), dim3(1), 0, s, rows_out, (size_t)n_cand,
-                       reinterpret_cast<const float2 *>(d_dist), b, n_samples, d_i, d_j, d_off, cap,
-                       d_n_out);
-    PPK_HIP(hipGetLastError());
-    return PPK_OK;
-  }
-  hipLaunchKernelGGL(fill_u64_kernel, dim3(nblk(2 * n_off + 1)), dim3(256), 0, s, g, 2 * n_off + 1, n_cand);
-  hipLaunchKernelGGL(ti1_stops_kernel, dim3(nblk(n_cand)), dim3(256), 0, s, rows_out, (size_t)n_cand,
-                     (int)n_off, g);
-  hipLaunchKernelGGL(ti1_suffix_min_kernel, dim3(1), dim3(64), 0, s, g, (int)n_off);
-  hipLaunchKernelGGL(ti1_emit_kernel, dim3(nblk(n_cand)), dim3(256), 0, s, rows_out, (size_t)n_cand,
-                     (int)n_off, g, n_samples, d_i, d_j, d_off, cap, d_n_out);
-  PPK_HIP(hipGetLastError());
-  return PPK_OK;
+  const float2 *dist = reinterpret_cast<const float2 *>(d_dist);
+  if (n_off <= 255)
+    return ti1_run<uint8_t>(dev, s, dist, n_rows, bnd, slope, n_samples, d_i, d_j, d_off, cap, d_n_out);
+  return ti1_run<uint16_t>(dev, s, dist, n_rows, bnd, slope, n_samples, d_i, d_j, d_off, cap, d_n_out);
 }
 
 extern "C" int ppk_threshold_iterate_2d_dev(const float *d_dist, size_t n_rows, const float *x_max,
@@ -405,39 +1086,86 @@ extern "C" int ppk_threshold_iterate_2d_dev(const float *d_dist, size_t n_rows, 
   const size_t n_samples = samples_of(n_rows);
   if (n_samples * (n_samples - 1) / 2 != n_rows)
     return ppk_fail(PPK_ERR_ARG, "row count is not n(n-1)/2 for any n (self/condensed matrix expected)");
-  std::vector<float2> bxy(n_off);
-  Boundaries b = {};
-  b.n = (int)n_off;
-  b.slope = 2;
-  for (size_t o = 0; o < n_off; ++o) bxy[o] = make_float2(x_max[o], y_max);
+  std::vector<Bnd> bnd(n_off);
+  bool fast = y_max != 0.0f;
+  for (size_t o = 0; o < n_off; ++o) {
+    volatile float prod = x_max[o] * y_max;
+    bnd[o] = Bnd{x_max[o], y_max, prod, 0.0f};
+    fast = fast && x_max[o] != 0.0f && std::isfinite((float)prod);
+  }
   int dev = 0;
   PPK_HIP(hipGetDevice(&dev));
   PpkCall call(dev, s);
+  // One pass of the 1-D sweep's classify kernel answers the common case: no row is within a boundary and outside a
+  // later one, so every listed row is listed once, at its first boundary.  Otherwise (or with a boundary on an axis)
+  // the ballot-per-offset pass below takes the reference's two comparisons as they stand.
+  if (classify_mode(bnd, 2) == 2 && n_rows < ((size_t)1 << 40)) {
+    const float2 *dist2 = reinterpret_cast<const float2 *>(d_dist);
+    int rc1 = PPK_OK;
+    unsigned long long n_cand = 0;
+    unsigned holes = 0;
+    auto run = [&](auto ftag) {
+      typedef decltype(ftag) F;
+      Classified<F> c;
+      rc1 = ti_classify<F>(dev, s, dist2, n_rows, bnd, 2, c);
+      if (rc1 != PPK_OK) return;
+      n_cand = c.got.n_cand;
+      holes = c.got.holes;
+      if (holes || n_cand == 0 || n_cand > 0x7fffffffull) return;
+      if (n_rows <= 0xffffffffull)
+        rc1 = ti2_after_count<uint32_t, F>(dev, s, n_rows, c, (int)n_off, n_samples, d_i, d_j, d_off, cap, d_n_out);
+      else
+        rc1 = ti2_after_count<uint64_t, F>(dev, s, n_rows, c, (int)n_off, n_samples, d_i, d_j, d_off, cap, d_n_out);
+    };
+    if (n_off <= 255) run((uint8_t)0);
+    else run((uint16_t)0);
+    if (rc1 != PPK_OK) return rc1;
+    if (!holes && n_cand <= 0x7fffffffull) {
+      if (n_cand == 0) PPK_HIP(hipMemsetAsync(d_n_out, 0, sizeof(unsigned long long), s));
+      return PPK_OK;
+    }
+  }
+  const Bnd *d_bnd = nullptr;
   {
     void *p_b = nullptr;
-    int rcb = ppk_scratch_get(dev, SLOT_BOUNDS, n_off * sizeof(float2) + 256, &p_b);
+    int rcb = ppk_scratch_get(dev, SLOT_BOUNDS, n_off * sizeof(Bnd) + 256, &p_b);
     if (rcb != PPK_OK) return rcb;
-    PPK_HIP(hipMemcpyAsync(p_b, bxy.data(), n_off * sizeof(float2), hipMemcpyHostToDevice, s));
-    b.xy = static_cast<const float2 *>(p_b);
+    PPK_HIP(hipMemcpyAsync(p_b, bnd.data(), n_off * sizeof(Bnd), hipMemcpyHostToDevice, s));
+    d_bnd = static_cast<const Bnd *>(p_b);
   }
   const size_t n_words = ppk_mask_words_linear(n_rows);
-  const size_t tot_words = n_words * n_off;
+  const size_t seg_blocks = (n_words + kCbWords - 1) / kCbWords, seg_words = seg_blocks * kCbWords;
+  const size_t tot_words = seg_words * n_off;
+  if (seg_blocks > 0x7fffffffull) return ppk_fail(PPK_ERR_ARG, "too many rows");
   void *p_mask = nullptr, *p_ws = nullptr;
+  const size_t ws_counts = (ppk_compact_ws_bytes(tot_words) + 255) & ~(size_t)255;
   int rc = ppk_scratch_get(dev, SLOT_MASK, tot_words * 8 + 8, &p_mask);
-  if (rc == PPK_OK) rc = ppk_scratch_get(dev, SLOT_WS, ppk_compact_ws_bytes(tot_words), &p_ws);
+  if (rc == PPK_OK) rc = ppk_scratch_get(dev, SLOT_WS, ws_counts + n_off * 8 + 256, &p_ws);
   if (rc != PPK_OK) return rc;
-  hipLaunchKernelGGL(ti2_mask_kernel, dim3(std::min<unsigned>(nblk(n_words, 4), 4096)), dim3(256), 0, s,
-                     reinterpret_cast<const float2 *>(d_dist), n_rows, b,
-                     static_cast<uint64_t *>(p_mask), n_words);
+  unsigned long long *block_sums = static_cast<unsigned long long *>(p_ws);
+  ppk_prof_stage("ballot per offset", s);
+  if (fast)
+    hipLaunchKernelGGL(ti2_mask_kernel<true>, dim3((unsigned)seg_blocks), dim3(512), 0, s,
+                       reinterpret_cast<const float2 *>(d_dist), n_rows, d_bnd, (int)n_off,
+                       static_cast<uint64_t *>(p_mask), n_words, seg_words, block_sums, seg_blocks);
+  else
+    hipLaunchKernelGGL(ti2_mask_kernel<false>, dim3((unsigned)seg_blocks), dim3(512), 0, s,
+                       reinterpret_cast<const float2 *>(d_dist), n_rows, d_bnd, (int)n_off,
+                       static_cast<uint64_t *>(p_mask), n_words, seg_words, block_sums, seg_blocks);
   PPK_HIP(hipGetLastError());
   EdgeGeom geo = {};
   geo.layout = EDGE_COO_SEGMENTS;
   geo.n_rows = n_rows;
   geo.n_samples = n_samples;
-  geo.seg_words = n_words;
+  geo.seg_words = seg_words;
+  geo.seg_blocks = seg_blocks;
+  geo.seg_totals = reinterpret_cast<unsigned long long *>(static_cast<char *>(p_ws) + ws_counts);
   geo.coo_j = d_j;
   geo.coo_seg = d_off;
-  return ppk_launch_compact(static_cast<uint64_t *>(p_mask), tot_words, geo, p_ws, d_i, cap, d_n_out, s);
+  ppk_prof_stage("compact", s);
+  rc = ppk_launch_compact(static_cast<uint64_t *>(p_mask), tot_words, geo, p_ws, d_i, cap, d_n_out, s, true);
+  ppk_prof_stage(nullptr, s);
+  return rc;
 }
 
 // ---- host-buffer wrappers (what the pybind functions of python_bindings.cpp:49-73 bind) ----
