@@ -32,7 +32,10 @@ Rank 0 prints ONE JSON line (see the driver contract) carrying
                  warm (packed sidecar), loaded -- each split into open / resident / query;
   `config2`, `config4`, `default_sketch`, `kernel2`   (N = 1) the other BASELINE configurations and kernel 2 on
                  this line, each with its own kernel, kernel_ms (HIP events) and roofline fraction, wall times as
-                 min / median / max.
+                 min / median / max;
+  `f_rows`       (N = 1) SURVEY 8(f) on the resident 10 000-genome matrix: thresholdIterate1D / 2D with the
+                 library's stage split, neighbours from the tiles and from the square matrix, long <-> square,
+                 qcDistMat's two edge lists -- each with a byte (or lane-op) model and the fraction it implies.
 N > 1: the two legs that need NO process group -- `multi_gpu.host_call` and `config5.host_call`, one process
 driving all N GPUs -- run on rank 0 BEFORE torch.distributed is initialised (the other ranks wait on a file),
 so a process group that never forms cannot lose them.
@@ -516,6 +519,191 @@ def kernel2_leg(lib, torch, dist_t, x_max, y_max, steps):
                     "every pass; frac_of_measured_stream is against the guide's 6.3 TB/s streaming ceiling"}
 
 
+
+def _stage_table(lib):
+    buf = C.create_string_buffer(16384)
+    lib.ppk_prof_stages_read(buf, 16384, 1)
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, ms, cnt = line.split("\t")
+        out[name] = {"ms": round(float(ms) / max(int(cnt), 1), 5), "calls": int(cnt)}
+    return out
+
+
+def _hbm_roof(nbytes, ms):
+    gbs = nbytes / ms / 1e6
+    return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_of_measured_stream": round(gbs / HBM_STREAM_GBS, 4),
+            "bytes": nbytes, "floor_ms_at_stream": round(nbytes / HBM_STREAM_GBS / 1e6, 5)}
+
+
+def f_rows_leg(lib, engine, torch, synth, ref10k, dist10k, kmers, tbl, steps=10):
+    """SURVEY 8(f) on the driver's clock, all on the resident 10 000-genome matrix (49 995 000 rows) or sketches:
+    the two boundary sweeps (src/boundary.cpp:154-237, caller PopPUNK/refine.py:190-200, :587-593), neighbours
+    (src/extend.cpp:248-289, caller PopPUNK/models.py:1213-1222), qcDistMat's two edge lists (PopPUNK/qc.py:330-354)
+    and long <-> square (PopPUNK/utils.py:393-405).  Each entry: wall per call (one device synchronisation after
+    it; outputs pre-sized, as a second call of the same job has them), HIP-event time, the library's own stage
+    split where the call has several kernels, a byte (or lane-op) model and the fraction of the roof it implies."""
+    import ctypes
+    dev = dist10k.device
+    n_rows = int(dist10k.shape[0])
+    n = ref10k.n
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    scale = dist10k.amax(dim=0)
+    xs = (dist10k / scale).contiguous()      # models.py:1085: the sweeps see the scaled matrix
+    sample = xs[::20].cpu().numpy()
+    m0 = np.quantile(sample, 0.01, axis=0)
+    m1 = np.quantile(sample, 0.30, axis=0)
+
+    def timed(fn, reps=steps, stages=False):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        if stages:
+            lib.ppk_prof_stages_enable(1)
+            _stage_table(lib)
+        wall, evs = [], []
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            a.record()
+            fn()
+            b.record()
+            torch.cuda.synchronize()
+            wall.append((time.perf_counter() - t0) * 1e3)
+            evs.append(a.elapsed_time(b))
+        res = {"wall": _stats(wall), "event_ms": round(sorted(evs)[len(evs) // 2], 5)}
+        if stages:
+            lib.ppk_prof_stages_enable(0)
+            res["stages"] = _stage_table(lib)
+            res["kernel_ms"] = round(sum(v["ms"] for v in res["stages"].values()), 5)
+        return res
+
+    out = {"rows": n_rows, "samples": n, "steps": steps}
+
+    # ---- thresholdIterate1D: 40 offsets from the within-cluster mean to the 30 % quantile point, slope 2 -----------
+    offs = np.ascontiguousarray(np.linspace(0.0, float(np.linalg.norm(m1 - m0)), 40), dtype=np.float64)
+    first = engine.threshold_iterate_1d_dev(xs, offs, 2, m0[0], m0[1], m1[0], m1[1])
+    n_emit = int(first[0].shape[0])
+    cap = n_emit + 1024
+    buf = torch.empty((3, cap), dtype=torch.int64, device=dev)
+    n_out = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def sweep1d():
+        rc = lib.ppk_threshold_iterate_1d_dev(C.c_void_p(xs.data_ptr()), n_rows, offs.ctypes.data_as(C.POINTER(C.c_double)),
+                                              offs.size, 2, float(m0[0]), float(m0[1]), float(m1[0]), float(m1[1]),
+                                              C.c_void_p(buf[0].data_ptr()), C.c_void_p(buf[1].data_ptr()),
+                                              C.c_void_p(buf[2].data_ptr()), cap, C.c_void_p(n_out.data_ptr()), stream)
+        assert rc == 0
+
+    r = timed(sweep1d, stages=True)
+    assert int(n_out.item()) == n_emit
+    sort_bytes = 4 * 16.0 * n_emit      # four 8-bit radix passes over (key, row) pairs: 8 B read + 8 B written each
+    r.update(offsets=40, emitted=n_emit, candidates_frac=round(n_emit / n_rows, 4),
+             roofline=_hbm_roof(8.0 * n_rows + 24.0 * n_emit, r["wall"]["median_ms"]),
+             model="algorithmic bytes = the matrix read once (8 B/row) + 24 B per listed row; the floor beside it "
+                   "adds what the method cannot avoid: the candidates' (key, row) pairs written and read (16 B) and "
+                   "a 32-bit radix sort of them (4 passes x 16 B)",
+             floor_ms=round((8.0 * n_rows + 24.0 * n_emit + 16.0 * n_emit + sort_bytes) / HBM_STREAM_GBS / 1e6, 5),
+             before_round_6_ms=2.05)
+    out["threshold_iterate_1d"] = r
+
+    # ---- thresholdIterate2D: 20 x_max values at one y_max (one of refine's per-y calls) -------------------------------
+    xm = np.ascontiguousarray(np.linspace(float(m0[0]), float(m1[0]) * 1.5, 20), dtype=np.float32)
+    ym = float(m1[1]) * 1.5
+    first2 = engine.threshold_iterate_2d_dev(xs, xm, ym)
+    n_emit2 = int(first2[0].shape[0])
+    cap2 = n_emit2 + 1024
+    buf2 = torch.empty((3, cap2), dtype=torch.int64, device=dev)
+
+    def sweep2d():
+        rc = lib.ppk_threshold_iterate_2d_dev(C.c_void_p(xs.data_ptr()), n_rows, xm.ctypes.data_as(C.POINTER(C.c_float)),
+                                              xm.size, ym, C.c_void_p(buf2[0].data_ptr()), C.c_void_p(buf2[1].data_ptr()),
+                                              C.c_void_p(buf2[2].data_ptr()), cap2, C.c_void_p(n_out.data_ptr()), stream)
+        assert rc == 0
+
+    r = timed(sweep2d, stages=True)
+    assert int(n_out.item()) == n_emit2
+    r.update(offsets=20, emitted=n_emit2, roofline=_hbm_roof(8.0 * n_rows + 24.0 * n_emit2, r["wall"]["median_ms"]),
+             model="the matrix read once + 24 B per listed row", before_round_6_ms=0.755)
+    out["threshold_iterate_2d"] = r
+    del buf, buf2, first, first2
+
+    # ---- neighbours: 10 per sample from kernel 1's tiles (no matrix), and get_kNN_distances on the square matrix ----
+    knn = 10
+    info = {}
+    r = timed(lambda: engine.knn_from_sketches(ref10k, kmers, tbl, knn, method="tiles", info=info), reps=max(3, steps // 2))
+    pairs = n * (n - 1) // 2
+    r.update(knn=knn, candidates=info.get("candidates"),
+             roofline=_valu_roof(pairs, VALU_OPS_PER_PAIR, r["event_ms"]),
+             model="the compare work of kernel 1 (2 400 lane-ops per pair, every pair once) against the VALU roof; the "
+                   "candidate list, its sort and the selection ride on top")
+    out["knn_from_tiles"] = r
+    sq = engine.long_to_square_dev(dist10k, 0, n)
+    oi = torch.empty(n * knn, dtype=torch.int64, device=dev)
+    oj = torch.empty(n * knn, dtype=torch.int64, device=dev)
+    od = torch.empty(n * knn, dtype=torch.float32, device=dev)
+
+    def knn_square():
+        rc = lib.ppk_knn_dev(C.c_void_p(sq.data_ptr()), n, knn, C.c_void_p(oi.data_ptr()), C.c_void_p(oj.data_ptr()),
+                             C.c_void_p(od.data_ptr()), stream)
+        assert rc == 0
+
+    r = timed(knn_square)
+    r.update(knn=knn, roofline=_hbm_roof(4.0 * n * n + 20.0 * n * knn, r["event_ms"]),
+             model="get_kNN_distances: the n x n float32 matrix read once + 20 B per neighbour")
+    out["knn_square_matrix"] = r
+
+    # ---- long <-> square ----------------------------------------------------------------------------------------------
+    def l2s():
+        rc = lib.ppk_long_to_square_dev(C.c_void_p(dist10k.data_ptr()), 2, 0, n, C.c_void_p(sq.data_ptr()), stream)
+        assert rc == 0
+
+    r = timed(l2s)
+    r.update(roofline=_hbm_roof(8.0 * n_rows + 4.0 * n * n, r["event_ms"]),
+             model="longToSquare of one column of the two-column matrix: its 8-byte rows come in whole (8 B/row), "
+                   "n x n floats go out")
+    out["long_to_square"] = r
+    lng = torch.empty(n_rows, dtype=torch.float32, device=dev)
+
+    def s2l():
+        rc = lib.ppk_square_to_long_dev(C.c_void_p(sq.data_ptr()), n, C.c_void_p(lng.data_ptr()), stream)
+        assert rc == 0
+
+    r = timed(s2l)
+    r.update(roofline=_hbm_roof(2.0 * n * n + 4.0 * n_rows, r["event_ms"]),
+             model="squareToLong: the upper triangle read (half of n x n floats) + 4 B per row written")
+    out["square_to_long"] = r
+    del sq, lng, oi, oj, od
+
+    # ---- qcDistMat's two lists --------------------------------------------------------------------------------------
+    d_host = dist10k[::50].cpu().numpy()
+    max_pi, max_a = float(np.quantile(d_host[:, 0], 0.999)), float(np.quantile(d_host[:, 1], 0.999))
+    e_long = engine.qc_edges_dev(dist10k, max_pi, max_a)
+    e_zero = engine.qc_edges_dev(dist10k, max_pi, max_a, zero=True)
+    capq = max(int(e_long.shape[0]), int(e_zero.shape[0])) + 1024
+    eb = torch.empty((capq, 2), dtype=torch.int64, device=dev)
+
+    def qc_both():
+        for zero in (0, 1):
+            rc = lib.ppk_qc_edges_dev(C.c_void_p(dist10k.data_ptr()), n_rows, 0, zero, max_pi, max_a,
+                                      C.c_void_p(eb.data_ptr()), capq, C.c_void_p(n_out.data_ptr()), stream)
+            assert rc == 0
+
+    r = timed(qc_both)
+    m_edges = int(e_long.shape[0]) + int(e_zero.shape[0])
+    r.update(long_edges=int(e_long.shape[0]), zero_edges=int(e_zero.shape[0]),
+             roofline=_hbm_roof(2 * (8.0 * n_rows + n_rows / 8.0 * 2) + 16.0 * m_edges, r["event_ms"]),
+             model="two predicate passes over the matrix (8 B/row each, the bit mask written and read) + 16 B per edge")
+    out["qc_edges_both_lists"] = r
+    out["note"] = ("wall = perf_counter around the call and one device synchronisation; event_ms = HIP events on the "
+                   "call's stream (torch's current stream, the one every launch here uses); stages = the library's own "
+                   "events between its kernels (ppk_prof_stages_*), kernel_ms their sum.  The 1-D sweep synchronises "
+                   "once inside (the candidate count sizes its sort), so its wall is the figure to quote.")
+    return out
+
+
 def other_configs(args, lib, engine, torch, synth, ref10k, dist10k, kmers, tbl, local_rank, f, rep):
     with timed_region("other_configs"):
         _other_configs(args, lib, engine, torch, synth, ref10k, dist10k, kmers, tbl, local_rank, f, rep)
@@ -529,7 +717,8 @@ def _other_configs(args, lib, engine, torch, synth, ref10k, dist10k, kmers, tbl,
             ("default_sketch", lambda: _default_sketch(lib, engine, torch, synth, kmers, dev, local_rank)),
             ("wide_k", lambda: _wide_k(lib, engine, torch, synth, dev, local_rank)),
             ("latency", lambda: _latency(engine, torch, synth, ref10k, kmers, tbl, dev, local_rank)),
-            ("kernel2", lambda: _kernel2(lib, torch, synth, dist10k)))
+            ("kernel2", lambda: _kernel2(lib, torch, synth, dist10k)),
+            ("f_rows", lambda: f_rows_leg(lib, engine, torch, synth, ref10k, dist10k, kmers, tbl)))
     for name, fn in legs:
         rep.enter(name)
         try:
@@ -1092,7 +1281,7 @@ def build_line(rep):
         "roofline": roof, "cpu_baseline": f.get("cpu"), "host_call": f.get("host_call"),
         "file_call": f.get("file_call"), "config2": f.get("config2"), "config4": f.get("config4"),
         "default_sketch": f.get("default_sketch"), "wide_k": f.get("wide_k"), "kernel2": f.get("kernel2"),
-        "latency": f.get("latency"), "config5": f.get("config5"),
+        "latency": f.get("latency"), "config5": f.get("config5"), "f_rows": f.get("f_rows"),
         "gc": gc_summary(),
     }
     if world > 1 and line["config5"] is None and f.get("config5_host_call_solo") is not None:

@@ -84,6 +84,9 @@ int ppk_device_count(int *n);
  *                          edge list alike; 0 = the tile-count thresholds only
  *     "ksplit_fused" (1)   small jobs run ONE launch (the tile's last unit fits it); 0 = counts pass + fit pass
  *     "ksplit_slices" (0)  pieces each k is cut into on the small-job path (0 = from the job's size)
+ *     "ks_grid_pad" (0)    1 = the one-launch k-split grid is one (empty) column wider: the workgroups of a tile
+ *                          then run on different XCDs, which is what its hand-over is written for and what the
+ *                          default, multiple-of-8 grid never does (tests; same results, no measurable cost)
  *     "lds_table" (1)      interior tiles of the default shape (3-5 k, s = 1024) fit from the (E, F) table in LDS
  *     "wide_kpg" (0)       k-mer lengths per window of the wide-k tile kernel (0 = as many as 128 count bits hold;
  *                          a smaller value sends narrower k lists through that kernel)
@@ -92,6 +95,8 @@ int ppk_device_count(int *n);
  *   neighbours from tiles
  *     "knn_list" (0 = sized from n and knn), "knn_warm" (32), "knn_cut" (4)  the candidate list, its staged
  *                          opening and where it is cut back to the best knn per sample
+ *     "knn_lane_lists" (0) 1 = ppk_knn_rect_dev / ppk_knn_dev select with one sorted list per LANE (the form before the
+ *                          one list per wavefront; kept so that the two can be timed side by side)
  *   host calls
  *     "chunk_rows" (8 Mi)  rows per sub-band of a host query (about an eighth of the job, at least 1 Mi, below 16 Mi
  *                          rows); also scales the pieces of the fused host edge call

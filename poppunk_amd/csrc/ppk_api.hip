@@ -67,6 +67,8 @@ const OptionEntry kOptions[] = {
     {"db_cache", "PPK_DB_CACHE", &PpkConfig::db_cache},
     {"progress", "PPK_PROGRESS", &PpkConfig::progress},
     {"launch_tiles", "PPK_LAUNCH_TILES", &PpkConfig::launch_tiles},
+    {"knn_lane_lists", "PPK_KNN_LANE_LISTS", &PpkConfig::knn_lane_lists},
+    {"ks_grid_pad", "PPK_KS_GRID_PAD", &PpkConfig::ks_grid_pad},
     {"knn_list", "PPK_KNN_LIST", &PpkConfig::knn_list},
     {"knn_warm", "PPK_KNN_WARM", &PpkConfig::knn_warm},
     {"knn_cut", "PPK_KNN_CUT", &PpkConfig::knn_cut},

@@ -984,7 +984,9 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
       unsigned sl = (blockIdx.x * 37u) & mask;
       for (;;) {
         const unsigned bit = 1u << (sl & 31u);
-        const unsigned old = __hip_atomic_fetch_or(p.wide_bitmap + (sl >> 5), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // acquire / release at agent scope around a slot's ownership: the next owner may run on another XCD.  (Once
+        // per workgroup, off the compare loop: the two cache operations the pair implies are not felt here.)
+        const unsigned old = __hip_atomic_fetch_or(p.wide_bitmap + (sl >> 5), bit, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
         if (!(old & bit)) break;
         sl = (sl + 1u) & mask;
         if ((sl & 31u) == 0) __builtin_amdgcn_s_sleep(8);
@@ -2004,7 +2006,7 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
       // every wavefront has read its counts back: the slot returns to the pool
       __syncthreads();
       if (threadIdx.x == 0)
-        __hip_atomic_fetch_and(p_late.wide_bitmap + (wide_slot >> 5), ~(1u << (wide_slot & 31u)), __ATOMIC_RELAXED,
+        __hip_atomic_fetch_and(p_late.wide_bitmap + (wide_slot >> 5), ~(1u << (wide_slot & 31u)), __ATOMIC_RELEASE,
                                __HIP_MEMORY_SCOPE_AGENT);
     } else {
       epilogue(p_late);
@@ -2298,7 +2300,12 @@ int launch_v2(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const f
         }
       }
 #endif
-      hipLaunchKernelGGL((dist_kernel_v2<NW, MODE, W, true, WIDE>), dim3((unsigned)n_blocks, p.ks_units),
+      // Option "ks_grid_pad": one more (empty) column of workgroups.  gridDim.x is otherwise a multiple of 8 and
+      // workgroups go to XCD (linear id mod 8), so the ks_units workgroups of a tile all run on ONE XCD and the
+      // hand-over below never crosses an L2; with an odd width unit y of tile x runs on XCD (x + y) mod 8
+      // (tools/ubench_grid_xcd.hip).  The extra workgroups return at once (their j is past tiles_per_xcd).
+      const unsigned grid_x = (unsigned)n_blocks + (ppk_config().ks_grid_pad.load() != 0 ? 1u : 0u);
+      hipLaunchKernelGGL((dist_kernel_v2<NW, MODE, W, true, WIDE>), dim3(grid_x, p.ks_units),
                          dim3(NW * 64), 0, s, ref->d_skT, qry->d_skT, d_lut,
                          use_clu ? ref->d_clu : nullptr, use_clu ? qry->d_clu : nullptr, d_rtab, d_out,
                          d_n_failed, d_mask, p);
@@ -2322,6 +2329,10 @@ int launch_v2(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const f
     if (rc != PPK_OK) return rc;
     p.wide_bitmap = static_cast<unsigned *>(pool);
     p.wide_slots = reinterpret_cast<unsigned long long *>(static_cast<char *>(pool) + 4096);
+    // every launch leaves the bitmap at zero -- unless one was aborted in a process that lives on: a bit left set
+    // would make a later workgroup wait for a slot nobody returns.  The pool is idle here (a scratch slot last used
+    // on another stream has been waited for), so the page is simply cleared again.
+    PPK_HIP(hipMemsetAsync(pool, 0, 4096, s));
     ppk_set_kernel_name("dist_kernel_v2<256x32,lds-dma,wide>");
     ppk_prof_begin(s);
     hipLaunchKernelGGL((dist_kernel_v2<NW, MODE, W, false, true>), dim3((unsigned)n_blocks), dim3(NW * 64), 0, s,

@@ -67,6 +67,8 @@ struct PpkConfig {
   std::atomic<long long> launch_tiles{8000000}; // PPK_LAUNCH_TILES: pair tiles per kernel launch (a dispatch holds < 2^32 work-items)
   std::atomic<long long> knn_warm{32};          // PPK_KNN_WARM: the neighbour mode opens with 1/knn_warm of its rows, then cuts the list (0 = off)
   std::atomic<long long> knn_cut{4};            // PPK_KNN_CUT: a staged neighbour job cuts its list at knn_cut * n * knn entries (0: only when half full)
+  std::atomic<long long> ks_grid_pad{0};        // PPK_KS_GRID_PAD: 1 = the one-launch k-split grid is one column wider, which puts the units of a tile on different XCDs (tests of the hand-over)
+  std::atomic<long long> knn_lane_lists{0};     // PPK_KNN_LANE_LISTS: 1 = the per-lane selection lists of ppk_knn_rect_dev (the form before the one list per wavefront; measurement)
   std::atomic<long long> knn_list{0};           // PPK_KNN_LIST: entries of the neighbour-candidate list (0 = sized from n and knn)
   std::atomic<long long> host_parts_rows{16 << 20};   // PPK_HOST_PARTS_ROWS: ... from this many rows up
   std::atomic<long long> host_parts{2};         // PPK_HOST_PARTS: worker threads of a one-device host query (>= 16 Mi rows)

@@ -219,6 +219,85 @@ knn_select_kernel(const float *__restrict__ src, size_t stride, size_t col, size
   }
 }
 
+
+// The same selection with ONE sorted list per wavefront -- lane j holds the j-th smallest key so far -- instead of
+// one list per lane: a row is read 64 columns at a time, a column is looked at again only if it beats the current
+// knn-th key (tau, wave-uniform), and an insertion is one shift of the lanes above it (DPP wave_shr:1).  About
+// knn (1 + ln(n / knn)) insertions per row (80 for 10 of 10 000) where the per-lane lists bubbled a few thousand
+// keys through 32 registers each: get_kNN_distances on the 10 000 x 10 000 matrix took 0.86 ms, thirteen times the
+// read of it.  knn <= 64.
+__device__ __forceinline__ uint64_t wave_shr1_u64(uint64_t v) {      // lane j <- lane j - 1 (lane 0 <- 0)
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, 0x138, 0xf, 0xf, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), 0x138, 0xf, 0xf, false);
+  return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+__device__ __forceinline__ uint64_t read_lane_u64(uint64_t v, int lane) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, lane);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), lane);
+  return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+
+__global__ void __launch_bounds__(256)
+knn_select_wave_kernel(const float *__restrict__ src, size_t stride, size_t col, size_t n_rows, size_t n_cols,
+                       size_t self_offset, int knn, long long *__restrict__ oi, long long *__restrict__ oj,
+                       float *__restrict__ od) {
+  const size_t i = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n_rows) return;
+  const int lane = threadIdx.x & 63;
+  const size_t self = self_offset + i;
+  constexpr uint64_t NONE = ~0ull;
+  uint64_t best = NONE;      // lane j: the j-th smallest key of the row so far
+  uint64_t tau = NONE;       // the knn-th smallest so far (wave-uniform)
+  const float *row = src + (i * n_cols) * stride + col;
+  constexpr int kBatch = 8;      // 64-column chunks per batch; the next batch's loads are issued before this one's
+                                 // keys are looked at (a wavefront otherwise waits a memory latency per 2 KB)
+  float nxt[kBatch];
+  auto load = [&](size_t c0) {
+#pragma unroll
+    for (int b = 0; b < kBatch; ++b) {
+      const size_t c = c0 + (size_t)b * 64 + lane;
+      nxt[b] = c < n_cols ? row[c * stride] : 0.0f;
+    }
+  };
+  load(0);
+  for (size_t c0 = 0; c0 < n_cols; c0 += 64 * kBatch) {
+    uint64_t x[kBatch];
+#pragma unroll
+    for (int b = 0; b < kBatch; ++b) {
+      const size_t c = c0 + (size_t)b * 64 + lane;
+      x[b] = (c < n_cols && c != self) ? (((uint64_t)knn_ord(nxt[b]) << 32) | (uint64_t)c) : NONE;
+    }
+    if (c0 + 64 * kBatch < n_cols) load(c0 + 64 * kBatch);
+#pragma unroll
+    for (int b = 0; b < kBatch; ++b) {
+      uint64_t m = __ballot(x[b] < tau);
+      while (m) {
+        const int l = __builtin_ctzll(m);
+        m &= m - 1;
+        const uint64_t cx = read_lane_u64(x[b], l);
+        if (cx < tau) {      // (tau may have fallen since the ballot)
+          const uint64_t up = wave_shr1_u64(best);
+          // keys are unique and the list ascends: the lanes whose key exceeds cx move up by one, cx lands below them
+          best = cx < best ? ((lane > 0 && cx < up) ? up : cx) : best;
+          tau = read_lane_u64(best, knn - 1);
+        }
+      }
+    }
+  }
+  if (lane < knn) {
+    const size_t o = i * (size_t)knn + lane;
+    oi[o] = (long long)self;
+    if (best == NONE) {
+      // fewer than knn other samples: the reference leaves i in i_vec and zeros elsewhere
+      oj[o] = 0;
+      od[o] = 0.0f;
+    } else {
+      oj[o] = (long long)(best & 0xffffffffull);
+      od[o] = knn_unord((unsigned)(best >> 32));
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int ppk_long_to_square_dev(const float *d_long, size_t stride, size_t col, size_t n,
@@ -267,8 +346,15 @@ extern "C" int ppk_knn_rect_dev(const float *d_block, size_t stride, size_t col,
   if (!d_block || !d_i || !d_j || !d_dist || stride == 0 || col >= stride)
     return ppk_fail(PPK_ERR_ARG, "ppk_knn_rect_dev: bad arguments");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (knn <= 32 && n_cols < 0xffffffffull) {
+  if (knn <= 64 && n_cols < 0xffffffffull && ppk_config().knn_lane_lists.load() == 0) {
     // selection (no sort, no scratch): the common case, lineage models use a handful of neighbours
+    hipLaunchKernelGGL(knn_select_wave_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, s, d_block, stride,
+                       col, n_rows, n_cols, self_offset, knn, d_i, d_j, d_dist);
+    PPK_HIP(hipGetLastError());
+    return PPK_OK;
+  }
+  if (knn <= 32 && n_cols < 0xffffffffull) {
+    // (option "knn_lane_lists" 1: the per-lane lists this replaced, kept for the measurement beside it)
     const dim3 grid((unsigned)((n_rows + 3) / 4));
     if (knn <= 8)
       hipLaunchKernelGGL(knn_select_kernel<8>, grid, dim3(256), 0, s, d_block, stride, col, n_rows, n_cols,

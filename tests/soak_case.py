@@ -5,6 +5,8 @@ kernel), 8, 16 (generic kernel)}, multi-cluster random tables in random or conti
 unrelated data, counts / jaccard / distance / fused-edge modes, neighbours from the tiles, both
 settings of the two [EXT] switches (kernel and oracle flipped together).
 """
+import os
+
 import numpy as np
 
 from oracle import oracle
@@ -17,6 +19,7 @@ def reset_options():
     _lib.set_option("ksplit", 1200)
     _lib.set_option("ksplit_slices", 0)
     _lib.set_option("ksplit_fused", 1)
+    _lib.set_option("ks_grid_pad", 0)
     _lib.set_option("launch_tiles", 8000000)
     _lib.set_option("knn_list", 0)
     _lib.set_option("chunk_rows", 8 << 20)
@@ -51,6 +54,13 @@ def soak_case(rng, big=False):
     # small jobs: ONE launch (round 4) with every way of cutting a k into pieces, now and then the two-pass path
     _lib.set_option("ksplit_slices", int(rng.choice([0, 0, 1, 2, 4])))
     _lib.set_option("ksplit_fused", int(rng.integers(0, 8) != 0))
+    # half of the cases put the units of a k-split tile on different XCDs (an odd grid width)
+    _lib.set_option("ks_grid_pad", int(rng.integers(0, 2)))
+    if os.environ.get("SOAK_KSPLIT"):
+        # the hand-over campaign: every case a one-launch k-split job whose tiles' units run on DIFFERENT XCDs
+        _lib.set_option("ksplit", 640)
+        _lib.set_option("ksplit_fused", 1)
+        _lib.set_option("ks_grid_pad", 1)
     _lib.set_option("ksplit_wide", int(rng.choice([215, 215, 0, 2000])))
     _lib.set_option("ksplit_long", int(rng.integers(0, 3) != 0))
     # every sixth case windows the count register narrower than it is (the wide-k path on short k lists); now and
@@ -97,9 +107,9 @@ def soak_case(rng, big=False):
     import sys
     trace = (lambda what: (sys.stderr.write("soak: %s\n" % what), sys.stderr.flush())) if os.environ.get("SOAK_TRACE") \
         else (lambda what: None)
-    trace("bbits=%d s64=%d nk=%d n=%d nr=%d clu=%d tbl=%d related=%d ext=%s tiny=%d ksplit=%d slices=%d fused=%d" % (
+    trace("bbits=%d s64=%d nk=%d n=%d nr=%d clu=%d tbl=%d related=%d ext=%s tiny=%d ksplit=%d slices=%d fused=%d pad=%d" % (
         bbits, s64, nk, n, nr, n_clu, use_tbl, related, ext, tiny, _lib.get_option("ksplit"),
-        _lib.get_option("ksplit_slices"), _lib.get_option("ksplit_fused")))
+        _lib.get_option("ksplit_slices"), _lib.get_option("ksplit_fused"), _lib.get_option("ks_grid_pad")))
     try:
         c, _ = pp_sketchlib.query_arrays(ref, qry, kmers, s64, bbits, counts=True)
         trace("counts done")

@@ -497,17 +497,21 @@ def test_small_jobs_in_one_launch_equal_the_two_pass_path_and_the_tile_kernel(pp
             a, f = fn()
             assert torch.equal(a, want[k][0]) and int(f) == want[k][1], ("two-pass", k)
         ppk_option("ksplit_fused", 1)
-        for slices in (0, 1, 2, 4):
+        # ks_grid_pad 1: an odd grid width, which puts the units of a tile on DIFFERENT XCDs (the default width is a
+        # multiple of 8: all of a tile's units on one) -- the case the hand-over's agent-scope atomics are there for
+        for pad, slices in ((p_, s_) for p_ in (0, 1) for s_ in (0, 1, 2, 4)):
             if slices and s64 % slices:
                 continue
+            ppk_option("ks_grid_pad", pad)
             ppk_option("ksplit_slices", slices)
-            for rep in range(3):                    # the tile counters must come back to zero after every launch
+            for rep in range(3 if pad == 0 else 2):     # the tile counters must come back to zero after every launch
                 for k, fn in jobs.items():
                     a, f = fn()
                     # (a unit needs two blocks: sketches of one block, or of two cut in two, keep the two-pass path)
                     nm = _lib.lib().ppk_last_kernel_name()       # (more than 64 count bits: fitted from the units' parts)
                     assert (nm.endswith(b"k-split fused>") or nm.endswith(b"fit from parts>")) == (s64 >= 2), k
-                    assert torch.equal(a, want[k][0]) and int(f) == want[k][1], ("fused", slices, rep, k)
+                    assert torch.equal(a, want[k][0]) and int(f) == want[k][1], ("fused", pad, slices, rep, k)
+        ppk_option("ks_grid_pad", 0)
         ppk_option("ksplit_slices", 0)
         ref_want, ref_failed = oracle.query(sk[:n - n_q], None, kmers, s64, 14, table,
                                             ref_clu=None if clusters is None else clusters[:n - n_q], threads=8)

@@ -40,9 +40,13 @@ def test_transform_errors():
         pp_sketchlib.squareToLong(np.zeros((2, 3), dtype=np.float32), 1)
 
 
+@pytest.mark.parametrize("lane_lists", [0, 1])
 @pytest.mark.parametrize("n,k", [(5, 2), (64, 3), (300, 10), (300, 1), (4, 7), (1000, 20), (70, 32),
-                                 (70, 33), (200, 40), (130, 8), (130, 9)])
-def test_knn(n, k):
+                                 (70, 33), (200, 40), (130, 8), (130, 9), (700, 64), (66, 65), (257, 5)])
+def test_knn(n, k, lane_lists, ppk_option):
+    """get_kNN_distances (src/extend.cpp:248-289): the one-list-per-wavefront selection (the default up to 64
+    neighbours), the per-lane lists before it (option knn_lane_lists) and the segmented sort beyond."""
+    ppk_option("knn_lane_lists", lane_lists)
     rng = np.random.Generator(np.random.PCG64(n + k))
     v = (rng.integers(0, 50, size=n * (n - 1) // 2) / 50.0).astype(np.float32)   # many ties
     sq = oracle.long_to_square(v)

@@ -342,6 +342,46 @@ def torch_equal_bits(a, b):
     return bool(torch.equal(a.view(torch.int32), b.view(torch.int32)))
 
 
+@pytest.mark.parametrize("shape", ["default sketch, 5 k", "default sketch, 10 k (fit from parts)", "s=1024, 5 k"])
+def test_ksplit_handover_with_a_tile_s_units_on_different_xcds(ppk_option, shape):
+    """The one-launch k-split path hands a tile's partial counts from its units to the unit that draws the last
+    ticket through agent-scope atomics (ppk_dist.hip, "Visibility between workgroups").  The product grid is a
+    multiple of 8 wide, so under today's dispatch (workgroup -> XCD = linear id mod 8, tools/ubench_grid_xcd.hip) all
+    units of a tile share one XCD's L2 and the protocol is never needed.  Option "ks_grid_pad" makes the grid one
+    empty column wider: unit y of tile x then runs on XCD (x + y) mod 8.  Distances (MODE_DIST) and the fused edge
+    list (MODE_MASK), repeated (the tickets must return to zero), against the tile kernel's bits and the oracle."""
+    if shape == "s=1024, 5 k":
+        kmers, s64, n = np.asarray(synth.DEFAULT_KMERS, dtype=np.int32), 16, 1500
+    elif shape == "default sketch, 5 k":
+        kmers, s64, n = np.asarray(synth.DEFAULT_KMERS, dtype=np.int32), 156, 700
+    else:
+        kmers, s64, n = K_CORONA, 156, 600
+    sk, member = synth.make_sketches(n, kmers, sketchsize64=s64, bbits=14, cluster_size=25, seed=77)
+    sk[5] = sk[4]
+    clu = (member % 2).astype(np.uint16)
+    tbl = _table(kmers, n_clu=2)
+    db = engine.SketchDB(sk, s64, 14, clusters=clu)
+    name = lambda: engine._lib.lib().ppk_last_kernel_name().decode()
+    ppk_option("ksplit", 0)
+    base, fb = engine.dist(db, None, kmers, tbl)
+    assert not name().endswith("fused>") and not name().endswith("parts>")
+    want, wf = oracle.query(sk, None, kmers, s64, 14, tbl, clu, threads=THREADS)
+    assert int(fb.item()) == wf and np.abs(base.cpu().numpy() - want).max() <= TOL
+    x_max, y_max = synth.boundary_for_quantile(want, 0.05)
+    e_base, _ = engine.dist_edges(db, None, kmers, tbl, slope=2, x_max=x_max, y_max=y_max)
+    ppk_option("ksplit", 1200)
+    ppk_option("ks_grid_pad", 1)
+    for slices in (0, 1, 2):
+        ppk_option("ksplit_slices", slices)
+        for rep in range(3):
+            got, fg = engine.dist(db, None, kmers, tbl)
+            assert name().endswith("fused>") or name().endswith("parts>"), name()
+            assert torch_equal_bits(got, base) and int(fg.item()) == int(fb.item()), (slices, rep)
+            e, _ = engine.dist_edges(db, None, kmers, tbl, slope=2, x_max=x_max, y_max=y_max)
+            assert np.array_equal(e.cpu().numpy(), e_base.cpu().numpy()), (slices, rep)
+    db.close()
+
+
 def test_long_sketch_rule_is_a_switch_and_changes_no_bit(ppk_option):
     """sketchsize64 32, 4 000 genomes (1 125 pair tiles: beyond every tile-count threshold): "ksplit_long" 1 (default)
     runs the k-split path, 0 the tile kernel; distances and the fused edge list agree bit for bit."""
