@@ -84,6 +84,9 @@ int ppk_device_count(int *n);
  *                          edge list alike; 0 = the tile-count thresholds only
  *     "ksplit_fused" (1)   small jobs run ONE launch (the tile's last unit fits it); 0 = counts pass + fit pass
  *     "ksplit_slices" (0)  pieces each k is cut into on the small-job path (0 = from the job's size)
+ *     "ksplit_scratch_mb" (2 048)  what the one-launch k-split path's partial counts may take (16 KB per tile and unit,
+ *                          kept per device); a job that would need more -- or that the device cannot give it -- runs
+ *                          through the tile kernel, which needs none
  *     "ks_grid_pad" (0)    1 = the one-launch k-split grid is one (empty) column wider: the workgroups of a tile
  *                          then run on different XCDs, which is what its hand-over is written for and what the
  *                          default, multiple-of-8 grid never does (tests; same results, no measurable cost)
@@ -640,6 +643,15 @@ int ppk_prof_enable(int on);
 int ppk_prof_read(double *total_ms, long long *n_launches, int reset);
 /* name of the kernel variant the last ppk_dist*_dev call launched */
 const char *ppk_last_kernel_name(void);
+/* The kernel shape a band of pair tiles would run through, as a pure function of the job (refs, query rows of the band,
+ * self, k-mer lengths, sketchsize64, bbits, fused-boundary / neighbour mode), the device (compute units, XCDs, resident
+ * 512-thread workgroups of the tile kernel: 256 / 8 / 512 on MI355X in SPX mode) and seven options in this order:
+ * ksplit, ksplit_wide, ksplit_long, ksplit_fused, ksplit_slices, wide_kpg, scratch bytes allowed.  No device is touched.
+ * route: 0 tile kernel, 1 k-split in one launch, 2 k-split counts pass + regression pass, 3 tile kernel with a windowed
+ * count register, 4 raw counts + generic regression.  (Replaces nothing of the reference: the dispatch of kernel 1.) */
+int ppk_choose_route(size_t n_ref, size_t q_rows, int self, int nk, int sketchsize64, int bbits, int mask, int knn,
+                     int cus, int xcds, int tile_slots, const long long *knobs, int *route, int *slices, size_t *tiles,
+                     size_t *limit);
 /* Named stages of the multi-kernel entry points (the sweeps of src/boundary.cpp:154-237, neighbours of
  * src/extend.cpp:248-289, the QC lists of PopPUNK/qc.py:330-354, long <-> square): when enabled, one hipEvent between
  * stages on the call's stream.  ppk_prof_stages_read writes "name<TAB>total ms<TAB>count" lines in first-seen order

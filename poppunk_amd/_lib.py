@@ -84,6 +84,9 @@ SIGNATURES = {
     "ppk_window_close": (C.c_int, [C.c_int, _vp]),
     "ppk_prof_enable": (C.c_int, [C.c_int]),
     "ppk_prof_read": (C.c_int, [C.POINTER(C.c_double), _llp, C.c_int]),
+    "ppk_choose_route": (C.c_int, [C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                   C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "ppk_prof_stages_enable": (C.c_int, [C.c_int]),
     "ppk_prof_stages_read": (C.c_int, [C.c_char_p, C.c_size_t, C.c_int]),
     "ppk_last_kernel_name": (C.c_char_p, []),

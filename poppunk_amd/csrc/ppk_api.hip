@@ -69,6 +69,7 @@ const OptionEntry kOptions[] = {
     {"launch_tiles", "PPK_LAUNCH_TILES", &PpkConfig::launch_tiles},
     {"knn_lane_lists", "PPK_KNN_LANE_LISTS", &PpkConfig::knn_lane_lists},
     {"ks_grid_pad", "PPK_KS_GRID_PAD", &PpkConfig::ks_grid_pad},
+    {"ksplit_scratch_mb", "PPK_KSPLIT_SCRATCH_MB", &PpkConfig::ksplit_scratch_mb},
     {"knn_list", "PPK_KNN_LIST", &PpkConfig::knn_list},
     {"knn_warm", "PPK_KNN_WARM", &PpkConfig::knn_warm},
     {"knn_cut", "PPK_KNN_CUT", &PpkConfig::knn_cut},

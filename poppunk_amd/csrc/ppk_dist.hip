@@ -34,6 +34,8 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include <mutex>
+
 #include "ppk_internal.h"
 #include "ppk_block_asm.inc"
 
@@ -123,6 +125,9 @@ struct KnnState {
   // uint32 thr[n] follows
 };
 
+// (internal) the one-launch k-split path could not get its scratch: the caller falls back to the tile kernel
+constexpr int kNoKsplitScratch = -7001;
+
 struct DistParams {
   size_t npad_r, npad_q;  // padded sample counts of the two resident arrays
   size_t n_ref;           // refs (lane axis)
@@ -147,6 +152,7 @@ struct DistParams {
   size_t strip_begin;     // first strip sample (= r_limit of the triangle part)
   size_t r_limit;         // triangle part: lane samples >= r_limit are left to the strip
   int xcd_map;            // 1: XCD-aware tile order (v2)
+  unsigned xcd_shift;     // log2 of the device's XCD count (PpkGeometry: 3 on MI355X in SPX mode, 0 on one XCD)
   int lut32;              // the whole fit table is addressable with 32-bit byte offsets
   size_t lut_total;       // doubles in the log-J table; the (E, F) table of the fast path follows it
   int k_split;            // > 0: the KSPLIT instantiation (gridDim.y = nk * k_split: one k, or a half / quarter of one, per workgroup)
@@ -928,13 +934,13 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
     if (blockIdx.x < p.n_strip_pad) return;
     const unsigned b = blockIdx.x - p.n_strip_pad;
     if (!EXP || p.xcd_map == 0) {
-      // Default order.  Workgroup b is dispatched to XCD b % 8 (observed; used for speed only) and
-      // every XCD has a private 4 MB L2.  The non-empty tiles, taken ref-tile-major, are cut into
-      // 8 equal contiguous runs, one per XCD: the ~64 workgroups resident on an XCD then work on
+      // Default order.  Workgroup b is dispatched to XCD b % (number of XCDs) (observed, tools/ubench_grid_xcd.hip;
+      // used for speed only) and every XCD has a private 4 MB L2.  The non-empty tiles, taken ref-tile-major, are
+      // cut into as many equal contiguous runs as the device has XCDs (ppk_geometry: 8 on MI355X), one per XCD: the ~64 workgroups resident on an XCD then work on
       // one or two ref tiles at a time (their rows are fetched into that L2 once per 64-bin block
       // and re-used by all of them), and the XCDs are balanced to one tile whatever the shape of
       // the job (in the triangular self job high ref tiles carry more query tiles than low ones).
-      const unsigned x = b & 7u, j = b >> 3;
+      const unsigned x = b & ((1u << p.xcd_shift) - 1u), j = b >> p.xcd_shift;
       const unsigned g = x * p.tiles_per_xcd + j;
       if (j >= p.tiles_per_xcd || g >= p.n_tiles) return;
       unsigned lo = 0, hi = p.r_tiles - 1;      // largest ref tile with tiles_before(rt) <= g
@@ -2259,17 +2265,20 @@ int launch_v2(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const f
   p.q_tiles = (unsigned)(r_tiles ? q_tiles : 0);
   p.xcd_map = (int)ppk_config().map.load();  // experiments build: A/B of tile orders; 0 = XCD-contiguous runs
   if (p.k_split || WIDE) p.xcd_map = 0;      // (the alternatives exist in the EXP instantiation only)
-  p.n_strip_pad = (p.n_strip + 7u) & ~7u;
+  const PpkGeometry &geo = ppk_geometry(ref->device);
+  const unsigned xcds = 1u << geo.xcd_shift;
+  p.xcd_shift = geo.xcd_shift;
+  p.n_strip_pad = (p.n_strip + xcds - 1u) & ~(xcds - 1u);
   p.tri_m = V2_RT / V2_QT;
   p.tri_c0 = p.tri_m - (int)p.q_tile0;
   const unsigned long long n_tiles64 = r_tiles ? tiles_before64(p.r_tiles, p.self, p.q_tiles, p.tri_m, p.tri_c0) : 0;
   if (n_tiles64 > 0x7ffffff0ull) return ppk_fail(PPK_ERR_ARG, "tile grid too large for one launch: split the query band");
   p.n_tiles = (unsigned)n_tiles64;
-  p.tiles_per_xcd = (p.n_tiles + 7u) / 8u;
+  p.tiles_per_xcd = (p.n_tiles + xcds - 1u) / xcds;
   // A/B orders: 1 = XCD-owned interleaved streams (each as long as the busiest XCD's list),
   // 2 = plain (ref tile fastest, skewed for the self job)
   const size_t per_xcd = ((r_tiles + 7) / 8) * q_tiles;
-  const size_t n_tri = !r_tiles ? 0 : p.xcd_map == 0 ? (size_t)p.tiles_per_xcd * 8
+  const size_t n_tri = !r_tiles ? 0 : p.xcd_map == 0 ? (size_t)p.tiles_per_xcd * xcds
                                   : p.xcd_map == 1 ? per_xcd * 8 : r_tiles * q_tiles;
   const size_t n_blocks = n_tri + p.n_strip_pad;
   if (n_blocks * (size_t)(NW * 64) >= ((size_t)1 << 32))
@@ -2281,9 +2290,9 @@ int launch_v2(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const f
       void *d_tickets = nullptr, *d_part = nullptr;
       const size_t ticket_bytes = (n_blocks * 4 + 255) / 256 * 256;
       int rc = ppk_scratch_get(ref->device, SLOT_TICKETS, ticket_bytes, &d_tickets);
-      if (rc != PPK_OK) return rc;
+      if (rc != PPK_OK) return kNoKsplitScratch;
       rc = ppk_scratch_get(ref->device, SLOT_ITER_A, n_blocks * (size_t)p.ks_units * (NW * 64) * 32 + 256, &d_part);
-      if (rc != PPK_OK) return rc;
+      if (rc != PPK_OK) return kNoKsplitScratch;
       p.ks_part_off = (size_t)(static_cast<char *>(d_part) - static_cast<char *>(d_tickets));
       p.ks_tickets = static_cast<unsigned *>(d_tickets);
       ppk_set_kernel_name(WIDE ? "dist_kernel_v2<256x32,lds-dma,k-split fused,fit from parts>" : "dist_kernel_v2<256x32,lds-dma,k-split fused>");
@@ -2322,7 +2331,9 @@ int launch_v2(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const f
     p.wide_kpg = 128 / p.cnt_bits;
     if (const long long force = ppk_config().wide_kpg.load(); force > 0 && force < p.wide_kpg) p.wide_kpg = (int)force;
     p.wide_groups = (p.nk + p.wide_kpg - 1) / p.wide_kpg;
-    p.wide_nslots = 1024;
+    // spill slots: a power of two, at least twice the workgroups the device holds at once
+    p.wide_nslots = 64;
+    while (p.wide_nslots < 2u * (unsigned)geo.tile_slots) p.wide_nslots *= 2;
     void *pool = nullptr;
     const size_t pool_bytes = 4096 + (size_t)p.wide_nslots * (size_t)p.wide_groups * WIDE_GROUP_U64 * 8;
     int rc = ppk_scratch_get(ref->device, SLOT_WIDE, pool_bytes, &pool);
@@ -2437,6 +2448,158 @@ int ppk_launch_transpose(const uint64_t *d_in, uint64_t *d_out, size_t n, size_t
 
 // Enqueue kernel 1 for one band.  d_scratch must hold lut_bytes (+ table).
 // mode_mask: d_mask non-null selects the fused boundary/bitmask output.
+// ---- device geometry -----------------------------------------------------------------------------------------------
+// Nothing below assumes a part: the compute units, the XCD count and the number of pair-tile workgroups the device
+// holds at once are read here, once per device.  (MI355X in SPX mode: 256 CUs, 8 XCDs, 2 workgroups of the tile
+// kernel per CU = 512 slots; in CPX mode one partition shows 32 CUs, 1 XCD, 64 slots.)
+const PpkGeometry &ppk_geometry(int dev) {
+  static PpkGeometry cache[64];
+  static std::atomic<int> ready[64];
+  static std::mutex mu;
+  static const PpkGeometry fallback = {256, 3, 512};
+  if (dev < 0 || dev >= 64) return fallback;
+  if (ready[dev].load(std::memory_order_acquire)) return cache[dev];
+  std::lock_guard<std::mutex> lk(mu);
+  if (ready[dev].load(std::memory_order_relaxed)) return cache[dev];
+  PpkGeometry g = fallback;
+  int v = 0;
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) g.cus = v;
+  unsigned shift = 0;
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeNumberOfXccs, dev) == hipSuccess && v > 0) {
+    while ((2u << shift) <= (unsigned)v) ++shift;
+  } else {
+    shift = g.cus >= 64 ? 3 : 0;      // (attribute missing: eight XCDs is what a whole MI300 / MI355X shows)
+  }
+  g.xcd_shift = shift;
+  int per_cu = 0;
+  DeviceGuard guard(dev);
+  if (guard.ok && hipOccupancyMaxActiveBlocksPerMultiprocessor(
+                      &per_cu, reinterpret_cast<const void *>(&dist_kernel_v2<8, MODE_DIST, 2, false, false>), 512, 0) == hipSuccess &&
+      per_cu > 0)
+    g.tile_slots = per_cu * g.cus;
+  else
+    g.tile_slots = 2 * g.cus;
+  cache[dev] = g;
+  ready[dev].store(1, std::memory_order_release);
+  return cache[dev];
+}
+
+// ---- the route of one band --------------------------------------------------------------------------------------------
+// A pure function of the job's shape, the device's geometry and the options: which of the kernel shapes of DESIGN.md
+// section 3.1 a band of pair tiles runs through.  Tile-count rules were measured on 512 workgroup slots (MI355X, SPX) and
+// are stated in those units; `rounds()` rescales them to the slots this device has.  tests/test_host_logic.py pins the
+// choices on MI355X for the shapes of profiles/r05/ksplit_*.txt and checks a CPX-shaped geometry picks sanely.
+PpkRouteChoice ppk_choose_route_impl(const PpkRouteShape &sh, const PpkGeometry &g, const PpkRouteKnobs &kn) {
+  PpkRouteChoice c = {};
+  c.route = PPK_ROUTE_TILE;
+  c.slices = 1;
+  auto rounds = [&](size_t tiles_at_512) { return tiles_at_512 * (size_t)g.tile_slots / 512; };
+  const size_t rt = (sh.n_ref + V2_RT - 1) / V2_RT, qt = (sh.q_rows + 31) / 32;
+  const size_t tiles = sh.self ? rt * qt / 2 + qt : rt * qt;
+  c.tiles = tiles;
+  // more than 128 count bits per pair: the tile kernel's WIDE instantiation (bbits = 14); other bbits (never
+  // written by PopPUNK: sketchlib fixes bbits = 14) keep the two-pass counts route for plain distances
+  const bool too_wide = sh.nk > PPK_MAX_NK || (sh.nk * sh.cnt_bits > 128 && sh.bbits != 14);
+  if (too_wide) {
+    c.route = PPK_ROUTE_COUNTS_UNFUSED;
+    return c;
+  }
+  const bool wide_tile = sh.nk * sh.cnt_bits > 128 || (kn.wide_kpg > 0 && kn.wide_kpg < sh.nk);
+  if (wide_tile && sh.bbits == 14) c.route = PPK_ROUTE_TILE_WIDE;
+  // Small jobs (up to about one round of pair tiles on the device's workgroup slots, e.g. 1 000 genomes or a handful
+  // of queries): one workgroup per (tile, k) instead of per tile -- nk times the parallelism, a serial chain of s64
+  // blocks instead of nk * s64.  (The fused boundary mode takes the path in its one-launch form only.)
+  const bool one_launch_ok = kn.ksplit_fused != 0 && 64 * (size_t)sh.s64 < 65536;
+  const bool edge_ks = sh.mask && one_launch_ok && sh.s64 >= 2;
+  if ((sh.mask && !edge_ks) || sh.knn || sh.bbits != 14 || sh.nk < 2) return c;
+  // default 1 200 tiles at 5 k since the one-launch form (round 4; profiles/r04/ksplit_threshold*.txt: it wins by
+  // 10 - 50 % up to 4 000 genomes / 1 125 tiles and ties from there to 1 800 tiles; 215 with the two-pass form),
+  // scaled by 5 / nk: the comparison is between nk * tiles short workgroups and `tiles` long ones.  The raised
+  // threshold holds where it was measured: sketches whose tiles are fitted from the LDS table -- 3 to 5 k of 11-bit
+  // counts, i.e. s = 1024.  Other shapes fit a tile with the general statement, a long tail for a k-split tile.
+  const bool lds_fit = sh.nk >= 3 && sh.nk <= 5 && sh.cnt_bits == 11;
+  long long ks = kn.ksplit;      // tile-count threshold at 5 k (for 512 slots), 0 = off
+  if (!lds_fit && ks > kn.ksplit_wide) ks = kn.ksplit_wide;
+  size_t limit = ks > 0 ? rounds((size_t)ks) * 5 / (size_t)sh.nk : 0;
+  // s = 1 024 with a k list the LDS table does not serve (6 k and up): in TILES the crossover does not move with nk
+  // (profiles/r05/ksplit_s1024_other_shapes.txt): level at 1 125 tiles, behind from 6 000 genomes
+  if (!lds_fit && ks > 0 && sh.s64 >= 16 && limit < rounds(700) && kn.ksplit_wide >= 215) limit = rounds(700);
+  // LONG sketches (sketchsize64 >= 32; PopPUNK's default is 156): a pair tile is a serial chain of nk * s64 blocks,
+  // so whole tiles fill the last round of workgroup slots badly at ANY job size, and they cycle through every k's
+  // rows while a k-split job works through the database one k at a time (profiles/r05/ksplit_long_sketches.txt).
+  // The path is taken whenever its scratch stays within `scratch_cap`: the partial counts, 16 KB per (tile, unit)
+  // with the grid's padding counted (a column per XCD and the ragged edge's strip), or 4 B per (row, k) in the
+  // two-pass form.  Option "ksplit_long" 0 restores the tile-count rule above.
+  int slices = 1;
+  {
+    // Very small jobs still leave workgroup slots empty with one workgroup per (tile, k): each k is cut into 2 or 4
+    // pieces of consecutive blocks as long as that stays within one round of the slots.
+    const size_t wgs = tiles * (size_t)sh.nk;
+    while (slices < 4 && wgs * (size_t)slices * 2 <= (size_t)g.tile_slots && sh.s64 % (slices * 2) == 0) slices *= 2;
+    if (kn.ksplit_slices > 0 && kn.ksplit_slices <= 4 && sh.s64 % kn.ksplit_slices == 0) slices = (int)kn.ksplit_slices;
+    // a unit of ONE block would re-fetch the block behind its range: one launch needs units of two blocks
+    if (kn.ksplit_fused != 0)
+      while (slices > 1 && sh.s64 / slices < 2) slices /= 2;
+  }
+  const size_t xcds = (size_t)1 << g.xcd_shift;
+  const size_t strip_tiles = sh.self ? (rt + 1) * ((V2_RT + 31) / 32) : 0;      // (upper bound: the strip of a ragged edge)
+  // (a band of the triangle can hold up to rt * qt tiles: the estimate above is for the whole triangle)
+  const size_t grid_cols = (sh.self && sh.q_rows >= sh.n_ref ? tiles : rt * qt) + 2 * xcds + strip_tiles + 1;
+  const size_t one_launch_scratch = grid_cols * (size_t)sh.nk * (size_t)slices * (16 << 10);
+  if (ks > 0 && sh.s64 >= 32 && kn.ksplit_long != 0) {
+    const size_t scratch = one_launch_ok ? one_launch_scratch : sh.rows * (size_t)sh.nk * 4;
+    // (the two-pass form's fit pass costs 0.2 us per 1 000 rows at 10 k: it pays up to about 700 tiles)
+    if (scratch <= kn.scratch_cap && (sh.s64 >= 64 || tiles <= rounds(6600)) && (one_launch_ok || tiles <= rounds(700)))
+      limit = tiles;
+  }
+  c.limit = limit;
+  if (tiles > limit) return c;
+  // ---- a k-split job ----
+  c.slices = slices;
+  const int ks_blocks = sh.s64 / slices;
+  c.from_parts = sh.nk * sh.cnt_bits > 64 || (kn.wide_kpg > 0 && kn.wide_kpg < sh.nk);
+  if (kn.ksplit_fused != 0 && ks_blocks >= 2 && 64 * (size_t)ks_blocks < 65536 &&
+      (!c.from_parts || 64 * (size_t)sh.s64 < 65536)) {
+    if (one_launch_scratch > kn.scratch_cap) return c;      // (does not fit what may be taken: the tile kernel needs none)
+    c.route = PPK_ROUTE_KSPLIT_ONE_LAUNCH;
+    c.scratch_bytes = one_launch_scratch;
+    return c;
+  }
+  if (sh.mask) return c;      // (cannot happen: edge_ks admits one-launch shapes only; stay on the tile kernel)
+  c.route = PPK_ROUTE_KSPLIT_TWO_PASS;
+  c.scratch_bytes = sh.rows * (size_t)sh.nk * (size_t)slices * 4;
+  return c;
+}
+
+// The same through the C ABI (tests on a machine without a GPU: nothing here touches a device)
+extern "C" int ppk_choose_route(size_t n_ref, size_t q_rows, int self, int nk, int sketchsize64, int bbits, int mask,
+                                int knn, int cus, int xcds, int tile_slots, const long long *knobs, int *route,
+                                int *slices, size_t *tiles, size_t *limit) {
+  if (!knobs || !route) return ppk_fail(PPK_ERR_ARG, "ppk_choose_route: NULL argument");
+  if (nk < 1 || sketchsize64 < 1 || cus < 1 || xcds < 1 || tile_slots < 1) return ppk_fail(PPK_ERR_ARG, "ppk_choose_route: bad shape");
+  PpkRouteShape sh = {};
+  sh.n_ref = n_ref;
+  sh.q_rows = q_rows;
+  sh.self = self;
+  sh.rows = self ? (q_rows * n_ref - q_rows * (q_rows + 1) / 2) : q_rows * n_ref;
+  sh.nk = nk;
+  sh.s64 = sketchsize64;
+  sh.bbits = bbits;
+  sh.cnt_bits = 1;
+  while ((1u << sh.cnt_bits) <= 64u * (unsigned)sketchsize64) ++sh.cnt_bits;
+  sh.mask = mask;
+  sh.knn = knn;
+  PpkGeometry g = {cus, 0, tile_slots};
+  while ((2u << g.xcd_shift) <= (unsigned)xcds) ++g.xcd_shift;
+  PpkRouteKnobs kn = {knobs[0], knobs[1], knobs[2], knobs[3], knobs[4], knobs[5], (size_t)knobs[6]};
+  const PpkRouteChoice c = ppk_choose_route_impl(sh, g, kn);
+  *route = c.route;
+  if (slices) *slices = c.slices;
+  if (tiles) *tiles = c.tiles;
+  if (limit) *limit = c.limit;
+  return PPK_OK;
+}
+
 static int launch_dist_band(const ppk_db *ref, const ppk_db *qry_or_null, const int32_t *kmers,
                             const float *d_rtab, size_t n_clu, int flags, size_t q_begin, size_t q_end,
                             void *d_out, unsigned long long *d_n_failed, uint64_t *d_mask, int slope,
@@ -2546,55 +2709,16 @@ static int launch_dist_band(const ppk_db *ref, const ppk_db *qry_or_null, const 
   if (want_jac)
     return launch_tiles_unpacked<MODE_JACCARD>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
 
-  // more than 128 count bits per pair: the tile kernel's WIDE instantiation (bbits = 14); other bbits (never
-  // written by PopPUNK: sketchlib fixes bbits = 14) keep the two-pass counts route for plain distances
-  const bool too_wide = p.nk > PPK_MAX_NK || (p.nk * p.cnt_bits > 128 && p.bbits != 14);
-  // Small jobs (up to about one round of pair tiles on the 512 workgroup slots, e.g. 1 000 genomes or a handful
-  // of queries): one workgroup per (tile, k) instead of per tile -- nk times the parallelism, a
-  // serial chain of s64 blocks instead of nk * s64 -- writing raw counts, then the regression pass.
-  bool small = false;
-  // (the fused boundary mode takes the path in its one-launch form only: edge_ks)
-  const bool edge_ks = d_mask && ppk_config().ksplit_fused.load() != 0 && 64 * (size_t)p.s64 < 65536 && p.s64 >= 2;
-  if (!too_wide && (!d_mask || edge_ks) && !knn_args && p.bbits == 14 && p.nk >= 2) {
-    const size_t rt = (ref->n + V2_RT - 1) / V2_RT, qt = (q_end - q_begin + 31) / 32;
-    // default 1 200 tiles at 5 k since the one-launch form (round 4; profiles/r04/ksplit_threshold*.txt: it wins by
-    // 10 - 50 % up to 4 000 genomes / 1 125 tiles and ties from there to 1 800 tiles; 215 with the two-pass form)
-    // (scaled by 5 / nk: the comparison is between nk * tiles short workgroups
-    // and `tiles` long ones).  Measured with the round-2 kernels, 5 k, s = 1024 (k-split vs tile
-    // kernel, us): 1 000 genomes / 80 tiles 81 vs 163; 1 500 / 200: 142 vs 158; 1 600 / 225: 168 vs 164;
-    // 1 800 / 285: 190 vs 149; 2 400 / 450: 276 vs 215; 2 600 / 533: 326 vs 214; 2 800 / 572: 332 vs 353
-    // (the raised threshold holds where it was measured: sketches whose tiles are fitted from the LDS table -- 3 to 5 k
-    // of 11-bit counts, i.e. s = 1024.  Other shapes fit a tile with the general statement, a long tail for a
-    // k-split tile; PopPUNK's default s = 9 984 at 540 tiles: 2.16 ms against 2.08 through the tile kernel)
-    const bool lds_fit = p.nk >= 3 && p.nk <= 5 && p.cnt_bits == 11;
-    long long ks = ppk_config().ksplit.load();   // tile-count threshold at 5 k, 0 = off
-    if (!lds_fit && ks > ppk_config().ksplit_wide.load()) ks = ppk_config().ksplit_wide.load();
-    size_t limit = ks > 0 ? (size_t)ks * 5 / (size_t)p.nk : 0;
-    // s = 1 024 with a k list the LDS table does not serve (6 k and up): in TILES the crossover does not move with
-    // nk -- profiles/r05/ksplit_s1024_other_shapes.txt: 9 / 10 / 17 / 21 lengths, tile kernel -> k-split, ms: 1 000
-    // genomes (96 tiles) 0.29 -> 0.17 / 0.34 -> 0.26 / 0.55 -> 0.29 / 0.76 -> 0.44; 3 000 (658 tiles) 0.71 -> 0.55 / 0.91 ->
-    // 0.81 / 1.36 -> 1.02 / 2.00 -> 1.88; level at 4 000 (1 125 tiles), behind from 6 000
-    if (!lds_fit && ks > 0 && p.s64 >= 16 && limit < 700 && ppk_config().ksplit_wide.load() >= 215) limit = 700;
-    const size_t tiles = p.self ? rt * qt / 2 + qt : rt * qt;
-    // LONG sketches (sketchsize64 >= 32; PopPUNK's default is 156): a pair tile is a serial chain of nk * s64 blocks --
-    // 780 at the default, ~1 ms -- so whole tiles fill the last round of workgroup slots badly at ANY job size, and
-    // they cycle through every k's rows while a k-split job works through the database one k at a time (a k of
-    // 10 000 default-size sketches is 175 MB: it stays in the 256 MB Infinity Cache, all five do not).  Measured
-    // (round 5, profiles/r05/ksplit_long_sketches.txt; tile kernel -> k-split, ms, same box): s = 9 984, 5 k: 1 000
-    // genomes 1.26 -> 0.44, 3 000: 3.74 -> 2.61, 10 000: 27.3 -> 25.9, 20 000: 105.0 -> 102.0; 9 k: 10 000: 50.2 ->
-    // 46.4; sketchsize64 64: ahead to 14 000 genomes, 32: to 10 000, level beyond.  The path is therefore taken whenever its scratch (partial counts: 16 KB per (tile,
-    // unit), or 4 B per (row, k) in the two-pass form) stays within 4 GB; option "ksplit_long" 0 restores the
-    // tile-count rule above.
-    if (ks > 0 && p.s64 >= 32 && ppk_config().ksplit_long.load() != 0) {
-      const size_t rows = p.self ? (q_end * ref->n - (q_end * (q_end + 1)) / 2) - p.row_base : (q_end - q_begin) * ref->n;
-      const bool one_launch = ppk_config().ksplit_fused.load() != 0 && 64 * (size_t)p.s64 < 65536;
-      const size_t scratch = one_launch ? tiles * (size_t)p.nk * (16 << 10) : rows * (size_t)p.nk * 4;
-      // (the two-pass form's fit pass -- nk table gathers per row with nothing to hide behind -- costs 0.2 us per
-      // 1 000 rows at 10 k: it pays up to about 700 tiles)
-      if (scratch <= ((size_t)4 << 30) && (p.s64 >= 64 || tiles <= 6600) && (one_launch || tiles <= 700)) limit = tiles;
-    }
-    small = tiles <= limit;
-  }
+  // which kernel shape this band runs through: a pure function of shape, geometry and options (ppk_choose_route_impl)
+  const size_t band_rows = p.self ? (q_end * ref->n - (q_end * (q_end + 1)) / 2) - p.row_base : (q_end - q_begin) * ref->n;
+  PpkRouteShape shape = {ref->n, q_end - q_begin, band_rows, p.self, p.nk, p.s64, p.cnt_bits, p.bbits, d_mask ? 1 : 0,
+                         knn_args ? 1 : 0};
+  PpkRouteKnobs knobs = {ppk_config().ksplit.load(), ppk_config().ksplit_wide.load(), ppk_config().ksplit_long.load(),
+                         ppk_config().ksplit_fused.load(), ppk_config().ksplit_slices.load(), ppk_config().wide_kpg.load(),
+                         (size_t)ppk_config().ksplit_scratch_mb.load() << 20};
+  PpkRouteChoice choice = ppk_choose_route_impl(shape, ppk_geometry(ref->device), knobs);
+  const bool too_wide = choice.route == PPK_ROUTE_COUNTS_UNFUSED;
+  bool small = choice.route == PPK_ROUTE_KSPLIT_ONE_LAUNCH || choice.route == PPK_ROUTE_KSPLIT_TWO_PASS;
   if (too_wide && knn_args) return ppk_fail(PPK_ERR_ARG, "neighbours from tiles need bbits = 14");
   if (too_wide) {
     // the packed per-pair state does not fit: raw counts to scratch, then a generic regression pass
@@ -2629,39 +2753,28 @@ static int launch_dist_band(const ppk_db *ref, const ppk_db *qry_or_null, const 
     PPK_HIP(hipGetLastError());
     ppk_lut_commit(ref->device, d_lut);
   }
+  const size_t rows = band_rows;
+  const int slices = choice.slices;      // pieces each k is cut into (ppk_choose_route_impl)
   if (small) {
     // one workgroup per (tile, k) -> raw counts; then the same per-pair fit as the tile epilogue
-    const size_t rows = p.self ? (q_end * ref->n - (q_end * (q_end + 1)) / 2) - p.row_base
-                               : (q_end - q_begin) * ref->n;
-    // Very small jobs still leave workgroup slots empty with one workgroup per (tile, k): each k is cut
-    // into 2 or 4 pieces of consecutive blocks as long as that stays within one round of the 512
-    // slots.  The kernel needs no change: the resident layout is [k][block][plane][sample], so "nk * S
-    // k-mer lengths of s64 / S blocks" addresses the same words; the regression pass adds the pieces.
-    int slices = 1;
-    {
-      const size_t rt = (ref->n + V2_RT - 1) / V2_RT, qt = (q_end - q_begin + 31) / 32;
-      const size_t wgs = (p.self ? rt * qt / 2 + qt : rt * qt) * (size_t)p.nk;
-      while (slices < 4 && wgs * (size_t)slices * 2 <= 512 && p.s64 % (slices * 2) == 0) slices *= 2;
-      if (const long long force = ppk_config().ksplit_slices.load(); force > 0 && force <= 4 && p.s64 % force == 0) slices = (int)force;
-    }
-    // The compare loop's in-stream copies always fetch "the next block"; after the last block they re-fetch it.  A
-    // unit of ONE block has no block to re-fetch and would read the block behind its range -- for the last unit of
-    // the last k, behind the array (found by the randomised campaign: s64 = 2 cut in two).  One launch needs units of
-    // at least two blocks; single-block units (sketchsize64 1, or 2 cut in two) keep the two-pass path.
-    if (ppk_config().ksplit_fused.load() != 0)
-      while (slices > 1 && p.s64 / slices < 2) slices /= 2;
     p.k_split = slices;
     p.ks_rows = rows;
     p.ks_blocks = p.s64 / slices;
     p.ks_units = (unsigned)(p.nk * slices);
     // ONE launch: every tile's last unit fits it (a unit's counts travel as 16-bit numbers)
     // (a unit's counts travel as 16-bit numbers; fitted from the parts as they lie, a k's pieces are added in place)
-    const bool from_parts = p.nk * p.cnt_bits > 64 || (ppk_config().wide_kpg.load() > 0 && ppk_config().wide_kpg.load() < p.nk);
-    if (ppk_config().ksplit_fused.load() != 0 && p.ks_blocks >= 2 && 64 * (size_t)p.ks_blocks < 65536 &&
-        (!from_parts || 64 * (size_t)p.s64 < 65536)) {
-      if (d_mask) return launch_tiles_packed<MODE_MASK>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);
-      return launch_tiles_packed<MODE_DIST>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, nullptr, p, s);
+    if (choice.route == PPK_ROUTE_KSPLIT_ONE_LAUNCH) {
+      const int rc1 = d_mask ? launch_tiles_packed<MODE_MASK>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s)
+                             : launch_tiles_packed<MODE_DIST>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, nullptr, p, s);
+      if (rc1 != kNoKsplitScratch) return rc1;
+      // the device could not give the partial counts their scratch: the band runs through the tile kernel, which
+      // needs none (a job that fits a nearly full GPU must not fail on a buffer that only buys speed)
+      (void)hipGetLastError();
+      p.k_split = 0;
+      small = false;
     }
+  }
+  if (small) {
     if (d_mask) {      // (cannot happen: edge_ks admits one-launch shapes only; stay on the tile kernel)
       p.k_split = 0;
       return launch_tiles_packed<MODE_MASK>(ref, qry, d_lut, d_rtab, d_out, d_n_failed, d_mask, p, s);

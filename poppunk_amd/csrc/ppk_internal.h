@@ -67,6 +67,7 @@ struct PpkConfig {
   std::atomic<long long> launch_tiles{8000000}; // PPK_LAUNCH_TILES: pair tiles per kernel launch (a dispatch holds < 2^32 work-items)
   std::atomic<long long> knn_warm{32};          // PPK_KNN_WARM: the neighbour mode opens with 1/knn_warm of its rows, then cuts the list (0 = off)
   std::atomic<long long> knn_cut{4};            // PPK_KNN_CUT: a staged neighbour job cuts its list at knn_cut * n * knn entries (0: only when half full)
+  std::atomic<long long> ksplit_scratch_mb{2048};   // PPK_KSPLIT_SCRATCH_MB: what the one-launch k-split path's partial counts may take (per device, kept); jobs that would need more run through the tile kernel
   std::atomic<long long> ks_grid_pad{0};        // PPK_KS_GRID_PAD: 1 = the one-launch k-split grid is one column wider, which puts the units of a tile on different XCDs (tests of the hand-over)
   std::atomic<long long> knn_lane_lists{0};     // PPK_KNN_LANE_LISTS: 1 = the per-lane selection lists of ppk_knn_rect_dev (the form before the one list per wavefront; measurement)
   std::atomic<long long> knn_list{0};           // PPK_KNN_LIST: entries of the neighbour-candidate list (0 = sized from n and knn)
@@ -110,6 +111,38 @@ struct DeviceGuard {
     if (prev >= 0) (void)hipSetDevice(prev);
   }
 };
+
+// Device geometry (ppk_dist.hip): read once per device, never assumed ----------
+struct PpkGeometry {
+  int cus;              // compute units (hipDeviceProp_t::multiProcessorCount)
+  unsigned xcd_shift;   // log2 of the XCD count (hipDeviceAttributeNumberOfXccs, rounded down to a power of two)
+  int tile_slots;       // 512-thread workgroups of the pair-tile kernel resident at once (occupancy x cus: 512 on
+                        // MI355X in SPX mode -- the "round" every tile-count rule of the route choice is stated in)
+};
+const PpkGeometry &ppk_geometry(int dev);
+
+// Route of one band of pair tiles (ppk_dist.hip: ppk_choose_route) -------------
+enum PpkRoute {
+  PPK_ROUTE_TILE = 0,                // one workgroup per 256 x 32 pair tile, fit in its epilogue
+  PPK_ROUTE_KSPLIT_ONE_LAUNCH = 1,   // nk * slices workgroups per tile, the last one fits it
+  PPK_ROUTE_KSPLIT_TWO_PASS = 2,     // counts pass + regression pass
+  PPK_ROUTE_TILE_WIDE = 3,           // the tile kernel with its count register windowed (more than 128 count bits)
+  PPK_ROUTE_COUNTS_UNFUSED = 4       // raw counts to scratch + generic regression (bbits != 14 with > 128 count bits)
+};
+struct PpkRouteShape {
+  size_t n_ref, q_rows, rows;   // refs, query rows of the band, distance rows of the band
+  int self, nk, s64, cnt_bits, bbits;
+  int mask, knn;                // fused boundary mode / neighbour mode
+};
+struct PpkRouteKnobs {          // ppk_set_option values (tile counts are stated for 512 workgroup slots)
+  long long ksplit, ksplit_wide, ksplit_long, ksplit_fused, ksplit_slices, wide_kpg;
+  size_t scratch_cap;           // bytes the k-split path's partial counts may take
+};
+struct PpkRouteChoice {
+  int route, slices, from_parts;
+  size_t tiles, limit, scratch_bytes;
+};
+PpkRouteChoice ppk_choose_route_impl(const PpkRouteShape &sh, const PpkGeometry &g, const PpkRouteKnobs &k);
 
 // Profiling hooks (ppk_prof_*) -------------------------------------------------
 void ppk_prof_begin(hipStream_t s);

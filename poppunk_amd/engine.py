@@ -945,6 +945,10 @@ class PeerStoreQuery:
     receive, nothing on the data path but the kernel; a step ends with every rank's stream drained and one
     barrier, after which the root holds the whole PopPUNK-ordered matrix.
 
+    UNVERIFIED ACROSS PHYSICAL DEVICES: the transport has run with two and four processes on ONE GPU only (no
+    multi-GPU box on the builder's side); `run` therefore checks its first step against a gathered matrix and raises
+    on a mismatch (see `run`, verify=).
+
     Bands are equal in pair count to begin with (a peer's 8 B per pair are far below what its link carries) and
     `rebalance` re-cuts them from measured per-rank times, like ShardedQuery's.  Collective calls: `open`, `run`,
     `rebalance`, `close`.  `open` raises RuntimeError ON EVERY RANK when any rank could not map the window
@@ -960,6 +964,7 @@ class PeerStoreQuery:
         self.window = None            # device pointer: the root's allocation, or this rank's mapping of it
         self.n_failed = None
         self._matrix = None
+        self._verified = False        # run(verify="first") has checked this window against a gathered matrix
         self._set_bounds(shard_bounds(ref.n, self.n_qry, self.world))
 
     def _set_bounds(self, bounds):
@@ -1034,18 +1039,63 @@ class PeerStoreQuery:
         dist(self.ref, self.qry, kmers, random_tbl, random_correct=random_correct, q_begin=self.bounds[self.rank],
              q_end=self.bounds[self.rank + 1], out=view, n_failed=self.n_failed)
 
-    def run(self, kmers=None, random_tbl=None, random_correct=True):
-        """One whole-job step; returns the matrix on rank 0 (None elsewhere) once EVERY rank's rows are in it."""
+    def run(self, kmers=None, random_tbl=None, random_correct=True, verify="first", _fault=None):
+        """One whole-job step; returns the matrix on rank 0 (None elsewhere) once EVERY rank's rows are in it.
+
+        verify: "first" (default) -- the first step of this object checks the transport against an independent one:
+        rank 0 fills the window with a sentinel, the step runs, every rank computes its band once more into a local
+        buffer and those are gathered to rank 0 through `gather_bands` (send / recv), and the window must equal the
+        gathered matrix bit for bit; RuntimeError on EVERY rank if it does not (the caller then uses ShardedQuery).
+        "always": every step; None / False: never.  The default stays "first" until a run on two or more PHYSICAL
+        GPUs has been recorded under profiles/ -- to date the peer stores have only crossed between two processes on
+        one GPU (tests/test_gpu_multirank.py), never an xGMI link.  Collective when on."""
         import torch.distributed as dist_
         torch = _torch()
         if self.window is None:
             raise RuntimeError("PeerStoreQuery.run before open()")
+        check = verify == "always" or (verify == "first" and not self._verified)
+        if check:
+            if self.rank == 0:
+                self._matrix.view(torch.int32).fill_(0x7fc0dead)      # a NaN no distance is: a row that never arrives shows
+                torch.cuda.current_stream(self.device).synchronize()
+            if self.world > 1:
+                dist_.barrier(self.group)
         self._launch(kmers, random_tbl, random_correct)
         torch.cuda.current_stream(self.device).synchronize()      # this rank's stores have left (kernel end = release)
         if self.world > 1:
             dist_.barrier(self.group)
             torch.cuda.current_stream(self.device).synchronize()
+        if check:
+            if _fault is not None:
+                _fault(self)          # (tests: damage the window between the step and the check)
+            self._check_against_gather(kmers, random_tbl, random_correct)
+            self._verified = True
         return self._matrix if self.rank == 0 else None
+
+    def _check_against_gather(self, kmers, random_tbl, random_correct):
+        import torch.distributed as dist_
+        torch = _torch()
+        rows = self.band_rows[self.rank]
+        local = torch.empty((max(rows, 1), self.cols), dtype=torch.float32, device=self.device)
+        if rows:
+            dist(self.ref, self.qry, kmers, random_tbl, random_correct=random_correct, q_begin=self.bounds[self.rank],
+                 q_end=self.bounds[self.rank + 1], out=local[:rows])
+        torch.cuda.current_stream(self.device).synchronize()
+        if self.world > 1:
+            whole = gather_bands(local[:rows], self.band_rows, self.cols, torch.float32, self.device, self.rank,
+                                 self.world, dst=0, group=self.group)
+        else:
+            whole = local[:rows]
+        ok = 1
+        if self.rank == 0:
+            ok = int(bool(torch.equal(whole.view(torch.int32), self._matrix.view(torch.int32))))
+        if self.world > 1:
+            flag = self.flag_tensor(ok)
+            dist_.all_reduce(flag, op=dist_.ReduceOp.MIN, group=self.group)
+            ok = int(flag.item())
+        if not ok:
+            raise RuntimeError("PeerStoreQuery: the matrix the ranks stored into the window differs from the gathered "
+                               "one (peer stores are unverified across physical devices): use ShardedQuery")
 
     def rebalance(self, kmers=None, random_tbl=None, random_correct=True, steps=2):
         """Re-cut the bands in proportion to each rank's measured pairs per second (its kernel INCLUDING its stores

@@ -103,7 +103,6 @@ def soak_case(rng, big=False):
     okw = dict(random_tbl=tbl if use_tbl else None, ref_clu=rclu if use_tbl else None,
                qry_clu=qclu if (use_tbl and qry is not None) else None, random_correct=use_tbl, threads=8)
     msgs = []
-    import os
     import sys
     trace = (lambda what: (sys.stderr.write("soak: %s\n" % what), sys.stderr.flush())) if os.environ.get("SOAK_TRACE") \
         else (lambda what: None)

@@ -30,6 +30,8 @@ def test_two_ranks_one_gpu_matches_single_launch():
     assert "PEERSTORE equal=True" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     # ... and the owner's own kernels re-read a window they had cached before the peers' stores (fine-grained window)
     assert "PEERSTORE_REREAD equal=True" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    # ... and PeerStoreQuery.run checks its first step against a gathered matrix: a damaged band raises on every rank
+    assert "PEERSTORE_VERIFY raised=True then_equal=True" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_window_entry_points_alone():

@@ -354,3 +354,73 @@ def test_stderr_redirected_is_fd_level(tmp_path, capfd):
             raise ValueError("restored on exceptions too")
     os.write(2, b"still there\n")
     assert "still there" in capfd.readouterr().err
+
+
+def _route(n_ref, nk, s64, q_rows=None, self_=1, mask=0, knn=0, geometry=(256, 8, 512), bbits=14,
+           knobs=(1200, 215, 1, 1, 0, 0, 2048 << 20)):
+    import ctypes as C
+    from poppunk_amd import _lib
+    kn = (C.c_longlong * 7)(*knobs)
+    route, slices = C.c_int(-1), C.c_int(-1)
+    tiles, limit = C.c_size_t(0), C.c_size_t(0)
+    rc = _lib.lib().ppk_choose_route(n_ref, n_ref if q_rows is None else q_rows, self_, nk, s64, bbits, mask, knn,
+                                     geometry[0], geometry[1], geometry[2], kn, C.byref(route), C.byref(slices),
+                                     C.byref(tiles), C.byref(limit))
+    assert rc == 0
+    return route.value, slices.value, tiles.value, limit.value
+
+
+def test_route_choice_is_a_pure_function_pinned_on_mi355x_and_sane_elsewhere():
+    """ppk_choose_route (ppk_dist.hip): the kernel shape a band runs through, from the job's shape, the device's
+    geometry (read from the device, never assumed) and the options.  Pinned: today's choices on MI355X in SPX mode
+    (256 CUs, 8 XCDs, 512 resident tile workgroups) for shapes measured in profiles/r05/ksplit_*.txt; and a
+    CPX-shaped device (32 CUs, one XCD, 64 slots) scales every tile-count rule by its slots.  No GPU is touched."""
+    TILE, ONE, TWO, WIDE, UNFUSED = 0, 1, 2, 3, 4
+    # s = 1 024, the default 5 k: tiles fitted from the LDS table, the one-launch form up to 1 200 tiles
+    assert _route(1000, 5, 16)[0] == ONE and _route(1000, 5, 16)[2] == 96
+    assert _route(4000, 5, 16)[0] == ONE and _route(4000, 5, 16)[2] == 1125
+    assert _route(10000, 5, 16) == (TILE, 1, 6573, 1200)
+    # tiny jobs cut every k into pieces while that stays within one round of slots
+    assert _route(300, 5, 16)[1] == 4 and _route(600, 5, 16)[1] == 2 and _route(1000, 5, 16)[1] == 1
+    # s = 1 024 with k lists the LDS table does not serve: level at 700 tiles whatever nk (ksplit_s1024_other_shapes)
+    assert _route(3000, 9, 16)[0] == ONE and _route(4000, 9, 16)[0] == TILE
+    assert _route(3000, 10, 16)[0] == ONE and _route(4000, 10, 16)[0] == TILE
+    assert _route(2000, 17, 16)[0] == ONE and _route(4000, 17, 16)[0] == WIDE      # 17 x 11 bits > 128
+    # PopPUNK's default sketch size: k-split at any size its scratch allows (ksplit_long_sketches)
+    for n in (600, 3000, 10000, 20000):
+        assert _route(n, 5, 156)[0] == ONE, n
+    assert _route(10000, 10, 156)[0] == ONE            # the bench's wide_k leg: fit from parts
+    assert _route(30000, 5, 156)[0] == TILE            # 58 000 tiles x 5 x 16 KB: beyond the 2 GB the path may take
+    assert _route(30000, 10, 156)[0] == WIDE
+    assert _route(3000, 5, 156, knobs=(1200, 215, 0, 1, 0, 0, 2048 << 20))[0] == ONE       # ksplit_long 0: 658 <= 700 tiles
+    assert _route(4000, 5, 156, knobs=(1200, 215, 0, 1, 0, 0, 2048 << 20))[0] == TILE
+    assert _route(10000, 5, 156, knobs=(1200, 215, 1, 1, 0, 0, 64 << 20))[0] == TILE       # a 64 MB allowance
+    # switches
+    assert _route(1000, 5, 16, knobs=(0, 215, 1, 1, 0, 0, 2048 << 20))[0] == TILE          # ksplit 0
+    assert _route(1000, 5, 16, knobs=(1200, 215, 1, 0, 0, 0, 2048 << 20))[0] == TWO        # ksplit_fused 0
+    assert _route(1000, 5, 16, knobs=(1200, 215, 1, 1, 2, 0, 2048 << 20))[1] == 2          # ksplit_slices 2
+    assert _route(1000, 5, 16, knobs=(1200, 215, 1, 1, 0, 2, 2048 << 20))[0] == ONE        # wide_kpg 2: from the parts
+    assert _route(10000, 5, 16, knobs=(1200, 215, 1, 1, 0, 2, 2048 << 20))[0] == WIDE
+    # modes: neighbours always the tile kernel; the fused boundary mode k-splits in its one-launch form only
+    assert _route(1000, 5, 16, knn=1)[0] == TILE
+    assert _route(1000, 5, 16, mask=1)[0] == ONE
+    assert _route(1000, 5, 16, mask=1, knobs=(1200, 215, 1, 0, 0, 0, 2048 << 20))[0] == TILE
+    assert _route(1000, 5, 1, mask=1)[0] == TILE                                           # one-block sketches
+    # ref x query: poppunk_assign's few queries against many refs
+    assert _route(10000, 5, 16, q_rows=64, self_=0)[0] == ONE
+    assert _route(10000, 5, 16, q_rows=50000, self_=0)[0] == TILE
+    # other bbits (never written by PopPUNK): the generic kernel; beyond 128 count bits the unfused counts route
+    assert _route(1000, 5, 16, bbits=8)[0] == TILE
+    assert _route(1000, 17, 16, bbits=8)[0] == UNFUSED
+    # a CPX-shaped partition: an eighth of the slots, an eighth of every tile-count threshold, no XCD padding
+    cpx = (32, 1, 64)
+    assert _route(1000, 5, 16, geometry=cpx) == (ONE, 1, 96, 150)
+    assert _route(2000, 5, 16, geometry=cpx)[0] == TILE
+    assert _route(300, 5, 16, geometry=cpx)[1] == 1 and _route(100, 5, 16, geometry=cpx)[1] == 2 and _route(50, 5, 16, geometry=cpx)[1] == 4
+    assert _route(1000, 9, 16, geometry=cpx)[3] == 87 and _route(1000, 9, 16, geometry=cpx)[0] == TILE
+    assert _route(3000, 5, 156, geometry=cpx)[0] == ONE
+    # bad arguments are errors, not routes
+    import ctypes as C
+    from poppunk_amd import _lib
+    assert _lib.lib().ppk_choose_route(10, 10, 1, 5, 16, 14, 0, 0, 0, 8, 512, (C.c_longlong * 7)(), C.byref(C.c_int()),
+                                       None, None, None) != 0

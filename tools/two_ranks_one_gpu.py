@@ -70,5 +70,29 @@ for rep in range(3):
 if rank == 0:
     print("PEERSTORE_REREAD equal=%s" % ok_rr)
 psq.close()
+# the engine's own check of the transport (run(verify="first"), on by default): a window in which one band is damaged
+# between the step and the check must raise on EVERY rank
+psq2 = engine.PeerStoreQuery(db, None, rank, world).open()
+
+
+def damage(q):
+    if q.rank == 0:
+        lo = q.band_off[world - 1]                  # the last band: rows another rank stored
+        q.matrix()[lo + 5:lo + 6].fill_(0.123)
+        torch.cuda.synchronize()
+    dist.barrier()
+
+
+raised = False
+try:
+    psq2.run(K, T, _fault=damage)
+except RuntimeError as e:
+    raised = "differs from the gathered" in str(e)
+flags = [None] * world
+dist.all_gather_object(flags, raised)
+m2 = psq2.run(K, T)          # (the failed check left it unverified: this step checks again, undamaged, and passes)
+if rank == 0:
+    print("PEERSTORE_VERIFY raised=%s then_equal=%s" % (all(flags), bool(torch.equal(m2, whole))))
+psq2.close()
 dist.barrier()
 dist.destroy_process_group()
