@@ -103,6 +103,7 @@ def soak_case(rng, big=False):
     okw = dict(random_tbl=tbl if use_tbl else None, ref_clu=rclu if use_tbl else None,
                qry_clu=qclu if (use_tbl and qry is not None) else None, random_correct=use_tbl, threads=8)
     msgs = []
+    route = "-"
     import sys
     trace = (lambda what: (sys.stderr.write("soak: %s\n" % what), sys.stderr.flush())) if os.environ.get("SOAK_TRACE") \
         else (lambda what: None)
@@ -115,6 +116,9 @@ def soak_case(rng, big=False):
         if not np.array_equal(c, oracle.match_counts(ref, qry, s64, bbits, threads=8)):
             msgs.append("counts differ")
         got, gf = pp_sketchlib.query_arrays(ref, qry, kmers, s64, bbits, **kw)
+        route = _lib.lib().ppk_last_kernel_name().decode()
+        route = ("ksplit1" if "k-split fused" in route else "ksplit2" if "k-split counts" in route else
+                 "wide" if route.endswith("wide>") else "tile" if "256x32" in route else "generic")
         trace("dist done")
         want, wf = oracle.query(ref, qry, kmers, s64, bbits, **okw)
         err = float(np.abs(got - want).max(initial=0))
@@ -200,6 +204,7 @@ def soak_case(rng, big=False):
             dbq.close()
     except Exception as e:  # noqa: BLE001
         msgs.append("EXCEPTION %r" % (e,))
-    desc = ("bbits=%2d s64=%2d nk=%d n=%4d nr=%4d clu=%d tbl=%d related=%d ext=%d%d tiny=%d"
-            % (bbits, s64, nk, n, nr, n_clu, use_tbl, related, ext[0], ext[1], int(tiny)))
+    desc = ("bbits=%2d s64=%2d nk=%d n=%4d nr=%4d clu=%d tbl=%d related=%d ext=%d%d tiny=%d pad=%d %s"
+            % (bbits, s64, nk, n, nr, n_clu, use_tbl, related, ext[0], ext[1], int(tiny), _lib.get_option("ks_grid_pad"),
+               route))
     return desc, msgs

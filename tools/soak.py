@@ -26,13 +26,17 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.Generator(np.random.PCG64(seed))
     bad = 0
+    routes = {}
     t_start = time.time()
     for case in range(n_cases):
         desc, msgs = soak_case(rng, big=bool(os.environ.get("SOAK_BIG")))
         status = "ok" if not msgs else "MISMATCH: " + "; ".join(msgs)
         bad += bool(msgs)
+        key = " ".join(desc.split()[-2:])          # "pad=<0|1> <route of the distance call>"
+        routes[key] = routes.get(key, 0) + 1
         print("case %3d %s  %s" % (case, desc, status), flush=True)
     reset_options()
+    print("distance calls by (grid pad, kernel shape):", ", ".join("%s: %d" % kv for kv in sorted(routes.items())))
     print("%d cases, %d mismatches, %.0f s" % (n_cases, bad, time.time() - t_start))
     sys.exit(1 if bad else 0)
 
