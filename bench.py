@@ -894,12 +894,30 @@ def _wide_k(lib, engine, torch, synth, dev, local_rank):
     db = engine.SketchDB(synth.make_sketches_device(n, kmers, sketchsize64=s64, device=dev, chunk=2048), s64, 14, device=local_rank)
     t1 = synth.random_match_table(kmers, genome_length=20_000)
     try:
-        return dist_leg(lib, engine, torch, db, None, kmers, t1, 3, len(kmers) * s64 * 30,
-                        "wide k list at PopPUNK's default sketch size: %d genomes self-vs-self, sketchsize64 = 156, "
-                        "k = 6..15 (10 lengths x 14 count bits > the 128-bit count register: the register windows the k "
-                        "list, full groups parked in spill slots)" % n, spin_ms=50.0)
+        res = dist_leg(lib, engine, torch, db, None, kmers, t1, 3, len(kmers) * s64 * 30,
+                       "wide k list at PopPUNK's default sketch size: %d genomes self-vs-self, sketchsize64 = 156, "
+                       "k = 6..15 (10 lengths x 14 count bits > the 128-bit count register: the register windows the k "
+                       "list, full groups parked in spill slots)" % n, spin_ms=50.0)
     finally:
         db.close()
+    torch.cuda.empty_cache()
+    # ... and at s = 1 024: 21 k-mer lengths (231 count bits), the windowed TILE kernel (too many tiles to k-split).
+    # Two lists of the same length: k = 15..35, and k = 11..31 whose three shortest lengths have random-match
+    # Jaccards of 0.44 / 0.12 / 0.03 on 2 Mb genomes -- a third of the pairs then fail their fit, which costs the
+    # default 5-k kernel the same 15 % (profiles/NOTES_r06.md section 5)
+    res["s1024_21_lengths"] = {}
+    for tag, k0 in (("k15_35", 15), ("k11_31", 11)):
+        km = np.arange(k0, k0 + 21, dtype=np.int32)
+        db2 = engine.SketchDB(synth.make_sketches_device(n, km, sketchsize64=16, device=dev, chunk=8192), 16, 14,
+                              device=local_rank)
+        try:
+            res["s1024_21_lengths"][tag] = dist_leg(lib, engine, torch, db2, None, km, synth.random_match_table(km), 3,
+                                                    len(km) * 16 * 30, "%d genomes self-vs-self, s = 1 024, k = %d..%d"
+                                                    % (n, k0, k0 + 20), spin_ms=30.0)
+        finally:
+            db2.close()
+        torch.cuda.empty_cache()
+    return res
 
 
 def _kernel2(lib, torch, synth, dist10k):

@@ -493,20 +493,29 @@ __device__ __forceinline__ PackW<4> wide_load(const PackWide &pk, int g) {
   return v;
 }
 
+// One scan in k order does what the register path does in two: it gathers log J for each k, accumulates the
+// least-squares sums while the fit is open and notes whether EVERY k was usable.  Only then (a related pair) are
+// the (E, F) products worth a second pass -- their bits are what the fast path returns; a pair with an unusable k
+// finishes from the sums, which are the general statement's, and in the default (truncating) mode the scan stops at
+// the first unusable k: an unrelated pair costs one or two gathers, not three passes over the list.  Same
+// expressions on the same values as fit_packed / fit_general of the register path, so the same bits.
 template <typename ParamsT>
-__device__ __forceinline__ void fit_general(const PackWide &pk, const double *__restrict__ lutp,
-                                            const ParamsT &p, float &core, float &acc, bool &failed) {
+__device__ __forceinline__ void fit_packed(const PackWide &pk, const double *__restrict__ lut, size_t cp_off,
+                                           const ParamsT &p, float &core, float &acc, bool &failed) {
   const uint32_t cmask = (1u << p.cnt_bits) - 1u;
+  const double *lutp = lut + cp_off;
   double sx = 0.0, sxx = 0.0, sy = 0.0, sxy = 0.0;
   int n = 0, k = 0;
-  bool open = true;
-  for (int g = 0; k < p.nk; ++g) {
+  bool open = true, all = true;
+  for (int g = 0; k < p.nk && (p.ext_skip || open); ++g) {
     const int m = p.nk - k < p.wide_kpg ? p.nk - k : p.wide_kpg;
     const PackW<4> v = wide_load(pk, g);
-    for (int i = 0; i < m; ++i, ++k) {
+    for (int i = 0; i < m && (p.ext_skip || open); ++i, ++k) {
       const uint32_t c = pack_get(v, i, p.cnt_bits, cmask, m);
       const double y = lutp[(size_t)k * p.lut_kstride + c];
-      open = (p.ext_skip || open) && !(y > 0.0);      // (NaN stays in: see the register version)
+      const bool usable = !(y > 0.0);      // (NaN stays in: see the register version)
+      all = all && usable;
+      open = (p.ext_skip || open) && usable;
       if (open) {
         const double x = (double)p.kmers[k];
         sx += x;
@@ -515,6 +524,26 @@ __device__ __forceinline__ void fit_general(const PackWide &pk, const double *__
         sxy = __builtin_fma(x, y, sxy);
         ++n;
       }
+    }
+  }
+  if (all && p.nk >= 2) {      // (every k usable: the scan ran to the end and the sums are complete)
+    const double *ef_base = lut + p.lut_total + 2 * cp_off;
+    double pe = 1.0, pf = 1.0;
+    int kk = 0;
+    for (int g = 0; kk < p.nk; ++g) {
+      const int m = p.nk - kk < p.wide_kpg ? p.nk - kk : p.wide_kpg;
+      const PackW<4> v = wide_load(pk, g);
+      for (int i = 0; i < m; ++i, ++kk) {
+        const uint32_t c = pack_get(v, i, p.cnt_bits, cmask, m);
+        const double *ef = ef_base + 2 * ((size_t)kk * p.lut_kstride + c);
+        pe = kk == 0 ? ef[0] : pe * ef[0];
+        pf = kk == 0 ? ef[1] : pf * ef[1];
+      }
+    }
+    if (pe == pe) {
+      fit_finish(pe, pf, core, acc);
+      failed = false;
+      return;
     }
   }
   if (n < 2) {
@@ -529,31 +558,6 @@ __device__ __forceinline__ void fit_general(const PackWide &pk, const double *__
   core = slope < 0.0 ? (float)(1.0 - exp_nonpos(slope)) : 0.0f;
   acc = icpt < 0.0 ? (float)(1.0 - exp_nonpos(icpt)) : 0.0f;
   failed = false;
-}
-
-template <typename ParamsT>
-__device__ __forceinline__ void fit_packed(const PackWide &pk, const double *__restrict__ lut, size_t cp_off,
-                                           const ParamsT &p, float &core, float &acc, bool &failed) {
-  const uint32_t cmask = (1u << p.cnt_bits) - 1u;
-  const double *ef_base = lut + p.lut_total + 2 * cp_off;
-  double pe = 1.0, pf = 1.0;
-  int k = 0;
-  for (int g = 0; k < p.nk; ++g) {
-    const int m = p.nk - k < p.wide_kpg ? p.nk - k : p.wide_kpg;
-    const PackW<4> v = wide_load(pk, g);
-    for (int i = 0; i < m; ++i, ++k) {
-      const uint32_t c = pack_get(v, i, p.cnt_bits, cmask, m);
-      const double *ef = ef_base + 2 * ((size_t)k * p.lut_kstride + c);
-      pe = k == 0 ? ef[0] : pe * ef[0];
-      pf = k == 0 ? ef[1] : pf * ef[1];
-    }
-  }
-  if (pe == pe && p.nk >= 2) {
-    fit_finish(pe, pf, core, acc);
-    failed = false;
-    return;
-  }
-  fit_general(pk, lut + cp_off, p, core, acc, failed);
 }
 
 template <typename PackT, int NR, typename ParamsT>
@@ -579,12 +583,15 @@ fit_rows_fast_anyk(const PackWide (&pk)[NR], const double *__restrict__ lut, con
         pe[r] = k == 0 ? e.x : pe[r] * e.x;
         pf[r] = k == 0 ? e.y : pf[r] * e.y;
       }
+      // a NaN factor stays NaN: the batch cannot take the fast path any more (most tiles hold an unrelated pair
+      // whose first k is already unusable -- there is no point in gathering the rest of the list for all of them)
+      bool nan = false;
+#pragma unroll
+      for (int r = 0; r < NR; ++r) nan = nan || (pe[r] != pe[r]);
+      if (__any(nan)) return false;
     }
   }
-  bool all_ok = p.nk >= 2;
-#pragma unroll
-  for (int r = 0; r < NR; ++r) all_ok = all_ok && (pe[r] == pe[r]);
-  if (!__all(all_ok)) return false;
+  if (p.nk < 2) return false;
 #pragma unroll
   for (int r = 0; r < NR; ++r) fit_finish(pe[r], pf[r], core[r], acc[r]);
   return true;
@@ -608,16 +615,20 @@ __device__ __forceinline__ unsigned long long parts_word(const PackParts &pk, in
     w += __hip_atomic_load(pk.src + (size_t)(k * p.k_split + h) * KS_UNIT_U64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return w;
 }
+// (one scan, then the products only for a pair whose every k is usable: see fit_packed(PackWide))
 template <typename ParamsT>
-__device__ __forceinline__ void fit_general(const PackParts &pk, const double *__restrict__ lutp, const ParamsT &p,
-                                            float &core, float &acc, bool &failed) {
+__device__ __forceinline__ void fit_packed(const PackParts &pk, const double *__restrict__ lut, size_t cp_off,
+                                           const ParamsT &p, float &core, float &acc, bool &failed) {
+  const double *lutp = lut + cp_off;
   double sx = 0.0, sxx = 0.0, sy = 0.0, sxy = 0.0;
   int n = 0;
-  bool open = true;
-  for (int k = 0; k < p.nk; ++k) {
+  bool open = true, all = true;
+  for (int k = 0; k < p.nk && (p.ext_skip || open); ++k) {
     const uint32_t c = (uint32_t)(parts_word(pk, k, p) >> pk.shift) & 0xffffu;
     const double y = lutp[(size_t)k * p.lut_kstride + c];
-    open = (p.ext_skip || open) && !(y > 0.0);
+    const bool usable = !(y > 0.0);
+    all = all && usable;
+    open = (p.ext_skip || open) && usable;
     if (open) {
       const double x = (double)p.kmers[k];
       sx += x;
@@ -625,6 +636,21 @@ __device__ __forceinline__ void fit_general(const PackParts &pk, const double *_
       sy += y;
       sxy = __builtin_fma(x, y, sxy);
       ++n;
+    }
+  }
+  if (all && p.nk >= 2) {
+    const double *ef_base = lut + p.lut_total + 2 * cp_off;
+    double pe = 1.0, pf = 1.0;
+    for (int k = 0; k < p.nk; ++k) {
+      const uint32_t c = (uint32_t)(parts_word(pk, k, p) >> pk.shift) & 0xffffu;
+      const double *ef = ef_base + 2 * ((size_t)k * p.lut_kstride + c);
+      pe = k == 0 ? ef[0] : pe * ef[0];
+      pf = k == 0 ? ef[1] : pf * ef[1];
+    }
+    if (pe == pe) {
+      fit_finish(pe, pf, core, acc);
+      failed = false;
+      return;
     }
   }
   if (n < 2) {
@@ -639,24 +665,6 @@ __device__ __forceinline__ void fit_general(const PackParts &pk, const double *_
   core = slope < 0.0 ? (float)(1.0 - exp_nonpos(slope)) : 0.0f;
   acc = icpt < 0.0 ? (float)(1.0 - exp_nonpos(icpt)) : 0.0f;
   failed = false;
-}
-template <typename ParamsT>
-__device__ __forceinline__ void fit_packed(const PackParts &pk, const double *__restrict__ lut, size_t cp_off,
-                                           const ParamsT &p, float &core, float &acc, bool &failed) {
-  const double *ef_base = lut + p.lut_total + 2 * cp_off;
-  double pe = 1.0, pf = 1.0;
-  for (int k = 0; k < p.nk; ++k) {
-    const uint32_t c = (uint32_t)(parts_word(pk, k, p) >> pk.shift) & 0xffffu;
-    const double *ef = ef_base + 2 * ((size_t)k * p.lut_kstride + c);
-    pe = k == 0 ? ef[0] : pe * ef[0];
-    pf = k == 0 ? ef[1] : pf * ef[1];
-  }
-  if (pe == pe && p.nk >= 2) {
-    fit_finish(pe, pf, core, acc);
-    failed = false;
-    return;
-  }
-  fit_general(pk, lut + cp_off, p, core, acc, failed);
 }
 // the NR refs of a batch share their query, i.e. their words: one load per (k, piece) serves all of them
 template <typename PackT, int NR, typename ParamsT>
@@ -676,11 +684,13 @@ fit_rows_fast_anyk(const PackParts (&pk)[NR], const double *__restrict__ lut, co
       pe[r] = k == 0 ? e.x : pe[r] * e.x;
       pf[r] = k == 0 ? e.y : pf[r] * e.y;
     }
-  }
-  bool all_ok = p.nk >= 2;
+    // (a NaN factor stays NaN: no fast path for this batch any more -- see the PackWide form)
+    bool nan = false;
 #pragma unroll
-  for (int r = 0; r < NR; ++r) all_ok = all_ok && (pe[r] == pe[r]);
-  if (!__all(all_ok)) return false;
+    for (int r = 0; r < NR; ++r) nan = nan || (pe[r] != pe[r]);
+    if (__any(nan)) return false;
+  }
+  if (p.nk < 2) return false;
 #pragma unroll
   for (int r = 0; r < NR; ++r) fit_finish(pe[r], pf[r], core[r], acc[r]);
   return true;

@@ -463,7 +463,7 @@ def knn_from_sketches(db, kmers, random_tbl, knn, dist_col=0, random_correct=Tru
     get_kNN_distances(longToSquare(queryDatabase(...)[:, dist_col])) gives, PopPUNK/models.py:
     1215-1222), entirely on the device.  Returns CUDA tensors (i, j, dist) of length n*knn.
 
-    method "tiles" (the default where it applies: bbits 14, knn <= 32, packed counts <= 128 bits):
+    method "tiles" (the default where it applies: bbits 14, knn <= 32, up to 128 k-mer lengths):
         kernel 1's tiles emit neighbour candidates under per-sample bounds and a sort + selection
         pass finishes (ppk_knn_sketches_dev): the upper triangle is compared once and no distance
         matrix -- long or square -- is ever built.  `info` (a dict) receives the candidate count.
@@ -479,10 +479,8 @@ def knn_from_sketches(db, kmers, random_tbl, knn, dist_col=0, random_correct=Tru
     oj = torch.empty(n * knn, dtype=torch.int64, device=dev)
     od = torch.empty(n * knn, dtype=torch.float32, device=dev)
     if method == "auto":
-        bits = 1
-        while (1 << bits) <= 64 * db.sketchsize64:
-            bits += 1
-        tiles_ok = db.bbits == 14 and 1 <= knn <= 32 and db.nk * bits <= 128 and db.nk <= 32 and n > 1
+        # (any k list the tile kernel takes: lists of more than 128 count bits run its windowed instantiation)
+        tiles_ok = db.bbits == 14 and 1 <= knn <= 32 and db.nk <= 128 and n > 1
         method = "tiles" if tiles_ok else ("square" if n * n <= band_items else "bands")
     if method == "tiles":
         kmers_a, random_tbl, tbl_ptr, n_clu = _prep_tables(kmers, random_tbl, db.nk)

@@ -26,7 +26,8 @@ sidecar    -- a packed image of the `.h5`'s sketches, written the first time (mo
     layout (little-endian)   0  magic "PPKSKDB2"      8  u64 body offset (4096-aligned)
       16 u64 h5 size        24  i64 h5 mtime_ns      32  u64 n          40 u64 nk
       48 u64 sketchsize64   56  u64 bbits            64  u64 names bytes
-      72 u64 flags (1: base_freq present for every sample; 2: the .h5 has a /random group)
+      72 u64 flags (1: the base_freq block is there -- a row is NaN where the sample has no such attribute, so a
+                    consumer checks the rows it selects; 2: the .h5 has a /random group)
       80 u64 random blob bytes (an .npz of the group's raw content)     88 u64 h5 inode
       96 u64 hash of the h5's first 4 KB
      104 int64 kmers[nk] | int64 length[n] | int64 missing_bases[n] | float64 base_freq[n][4]

@@ -11,8 +11,12 @@ if ROOT not in sys.path:
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
     # packed sketch images (poppunk_amd/h5bulk.py) go to the user's cache directory: the suite gets its own
+    import atexit
+    import shutil
     import tempfile
-    os.environ["XDG_CACHE_HOME"] = tempfile.mkdtemp(prefix="ppk_test_cache_")
+    cache = tempfile.mkdtemp(prefix="ppk_test_cache_")
+    atexit.register(shutil.rmtree, cache, ignore_errors=True)
+    os.environ["XDG_CACHE_HOME"] = cache
     os.environ.pop("PPK_SIDECAR_DIR", None)
 
 

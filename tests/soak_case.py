@@ -35,6 +35,9 @@ def soak_case(rng, big=False):
     import torch
     bbits = int(rng.choice([14, 14, 14, 8, 16]))
     s64 = int(rng.choice([1, 2, 3, 16, 16, 16, 5, 40, 64, 156]))      # (32 and up: the long-sketch rule, k-split at any size)
+    if os.environ.get("SOAK_KSPLIT"):      # the hand-over campaign: only shapes the one-launch k-split path takes
+        bbits = 14
+        s64 = int(rng.choice([2, 3, 16, 16, 16, 5, 40, 64, 156]))
     nk = int(rng.integers(2, 12))      # count registers of 2, 3 and 4 dwords
     wide_list = bbits == 14 and rng.integers(0, 5) == 0
     if wide_list:                      # the wide-k tile kernel: more than 128 count bits per pair
