@@ -2258,7 +2258,9 @@ int launch_v2(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const f
   const size_t rem = p.n_ref % V2_RT;
   if constexpr (MODE == MODE_DIST || MODE == MODE_MASK) {
     bool split = p.self && rem != 0 && rem <= 224 && p.n_ref > V2_RT;
+#ifdef PPK_EXPERIMENTS
     if (ppk_config().strip.load() == 0) split = false;
+#endif
     if (split) {
       p.r_limit = p.n_ref - rem;
       p.strip_begin = p.r_limit;
@@ -2273,7 +2275,10 @@ int launch_v2(const ppk_db *ref, const ppk_db *qry, const double *d_lut, const f
   const bool use_clu = p.random_correct && p.n_clu > 1;
   p.r_tiles = (unsigned)(r_tiles ? r_tiles : 1);
   p.q_tiles = (unsigned)(r_tiles ? q_tiles : 0);
-  p.xcd_map = (int)ppk_config().map.load();  // experiments build: A/B of tile orders; 0 = XCD-contiguous runs
+  p.xcd_map = 0;      // XCD-contiguous runs
+#ifdef PPK_EXPERIMENTS
+  p.xcd_map = (int)ppk_config().map.load();  // A/B of tile orders
+#endif
   if (p.k_split || WIDE) p.xcd_map = 0;      // (the alternatives exist in the EXP instantiation only)
   const PpkGeometry &geo = ppk_geometry(ref->device);
   const unsigned xcds = 1u << geo.xcd_shift;
@@ -2707,7 +2712,10 @@ static int launch_dist_band(const ppk_db *ref, const ppk_db *qry_or_null, const 
   p.lut32 = (p.lut_total * 16 < ((size_t)1 << 32)) ? 1 : 0;
   p.knn = knn_args ? knn_args[0] : 0;
   p.knn_col = knn_args ? knn_args[1] : 0;
-  p.ablate = (int)ppk_config().ablate.load();      // (only the experiments build can set it)
+  p.ablate = 0;
+#ifdef PPK_EXPERIMENTS
+  p.ablate = (int)ppk_config().ablate.load();
+#endif
   p.lds_table = ppk_config().lds_table.load() != 0 && !(p.ablate & 32) ? 1 : 0;
   p.ext_adjust = ppk_config().ext_collision_adjust.load() ? 1 : 0;
   p.ext_skip = ppk_config().ext_fit_skip.load() ? 1 : 0;

@@ -45,12 +45,14 @@ inline bool ppk_unfused(const ppk_db *db) {
 // two ext_* options select between the readings of pp-sketchlib behaviour that cannot be checked
 // in this tree (DESIGN.md "[EXT] assumptions").
 struct PpkConfig {
-  // -- experiments build only (make -C poppunk_amd/csrc experiments; tools/ab_*.py): the product library has no
-  //    option of these names and always runs the defaults
+#ifdef PPK_EXPERIMENTS
+  // -- experiments build only (make -C poppunk_amd/csrc experiments; tools/ab_*.py): the product library has neither
+  //    these fields nor options of these names
   std::atomic<long long> ablate{0};             // PPK_ABLATE: skip 1 epilogue, 2 compare, 4 DMA, 8 barriers, 16 first-copy wait, 64 the interior tiles' table copy, 128 stores; 32 LDS-table path off
   std::atomic<long long> map{0};                // PPK_MAP: tile order of dist_kernel_v2 (0 = XCD-contiguous runs)
   std::atomic<long long> strip{1};              // PPK_STRIP: strip tiles for the ragged right edge
   std::atomic<long long> edge_list_keep{1};     // PPK_EDGE_LIST_KEEP: the fused host edge call keeps its device list buffer between calls (0: allocate + free per call, measurement)
+#endif
   // -- product options
   std::atomic<long long> lds_table{1};          // PPK_LDS_TABLE: interior tiles of the default sketch shape fit from the (E, F) table in LDS (0: the general statement everywhere; same bits)
   std::atomic<long long> ksplit{1200};           // PPK_KSPLIT: tile-count threshold (at 5 k) of the small-job path
