@@ -253,3 +253,47 @@ def test_neighbours_of_40000_genomes_staged_flow_against_brute_force_rows(knn):
         order = order[order != r][:knn]
         assert np.array_equal(oj[r], order) and np.array_equal(od[r], col[order]), r
     db.close()
+
+
+def _mixture_matrix(n, seed):
+    """A distance matrix of n genomes' worth of rows with PopPUNK's shape: a tight within-strain cloud near the origin,
+    a broad between-strain cloud, a few exact repeats (ties) and exact zeros; float32, non-negative."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    rows = n * (n - 1) // 2
+    d = np.empty((rows, 2), dtype=np.float32)
+    step = 1 << 22
+    for lo in range(0, rows, step):
+        m = min(step, rows - lo)
+        near = rng.random(m) < 0.15
+        x = np.where(near, rng.random(m) * 0.004, 0.01 + rng.random(m) * 0.03)
+        y = np.where(near, rng.random(m) * 0.05, 0.1 + rng.random(m) * 0.4)
+        d[lo:lo + m, 0] = x
+        d[lo:lo + m, 1] = y
+    d[rng.integers(0, rows, 5000)] = 0.0
+    d[rng.integers(0, rows, 5000)] = d[rng.integers(0, rows, 1)]
+    return d
+
+
+@pytest.mark.parametrize("n", [10000, 12000])
+def test_boundary_sweeps_at_baseline_size_element_for_element(n):
+    """SURVEY 8(f1) at the size refine runs it: thresholdIterate1D (40 offsets) and thresholdIterate2D (20 offsets) on
+    the long matrix of 10 000 genomes (49 995 000 rows: 32-bit (row, first boundary) values, the filtered classify
+    pass, the radix sort of ~17 % of the rows) and of 12 000 genomes (71 994 000 rows: row and boundary index no longer
+    fit 32 bits, the 64-bit value path) against the oracle's restatement of src/boundary.cpp:154-237."""
+    import torch
+    d = _mixture_matrix(n, seed=n)
+    dt = torch.from_numpy(d).cuda()
+    m0, m1 = np.asarray([0.002, 0.02], dtype=np.float32), np.asarray([0.012, 0.14], dtype=np.float32)
+    offs = np.linspace(0.0, float(np.linalg.norm(m1 - m0)), 40)
+    gi, gj, go = engine.threshold_iterate_1d_dev(dt, offs, 2, m0[0], m0[1], m1[0], m1[1])
+    wi, wj, wo = oracle.threshold_iterate_1d(d, offs, 2, m0[0], m0[1], m1[0], m1[1])
+    assert len(wi) > len(d) // 10
+    assert np.array_equal(gi.cpu().numpy(), wi) and np.array_equal(gj.cpu().numpy(), wj) and np.array_equal(go.cpu().numpy(), wo)
+    del gi, gj, go
+    xm = np.linspace(0.003, 0.02, 20).astype(np.float32)
+    gi, gj, go = engine.threshold_iterate_2d_dev(dt, xm, 0.2)
+    wi, wj, wo = oracle.threshold_iterate_2d(d, xm, 0.2)
+    assert len(wi) > len(d) // 10
+    assert np.array_equal(gi.cpu().numpy(), wi) and np.array_equal(gj.cpu().numpy(), wj) and np.array_equal(go.cpu().numpy(), wo)
+    del dt, gi, gj, go
+    torch.cuda.empty_cache()
