@@ -424,3 +424,44 @@ def test_route_choice_is_a_pure_function_pinned_on_mi355x_and_sane_elsewhere():
     from poppunk_amd import _lib
     assert _lib.lib().ppk_choose_route(10, 10, 1, 5, 16, 14, 0, 0, 0, 8, 512, (C.c_longlong * 7)(), C.byref(C.c_int()),
                                        None, None, None) != 0
+
+
+def test_sweep_filter_rounding_argument_holds_on_float32():
+    """The boundary sweep's classify pass (ppk_iterate.hip, ti1_classify_kernel FILTER) drops a row after ONE evaluation
+    when x, y >= 0 and fl(fl(y x_L) + fl(x y_L)) > c_L (1 + 2^-20) for the outermost boundary L, claiming that every
+    boundary inside L (x_o <= x_L, y_o <= y_L, all >= 2^-40) then excludes it as well: fl(fl(y x_o) + fl(x y_o)) >
+    fl(x_o y_o).  Numpy float32 arithmetic is the same IEEE arithmetic, un-fused: 20 million rows placed within a few
+    ulps of the filter's threshold (where a wrong margin would show), across magnitudes from 2^-38 to 2^30, against 16
+    nested boundaries each -- no row the filter drops may be within any of them."""
+    rng = np.random.Generator(np.random.PCG64(20260929))
+    f32 = np.float32
+    worst = 0
+    for trial in range(40):
+        mag = f32(2.0) ** f32(rng.integers(-38, 31))
+        xL = f32(mag * f32(rng.uniform(0.5, 2.0)))
+        yL = f32(xL * f32(2.0) ** f32(rng.integers(-6, 7)) * f32(rng.uniform(0.5, 2.0)))
+        if not (np.isfinite(xL * yL) and xL >= f32(2.0) ** -40 and yL >= f32(2.0) ** -40):
+            continue
+        cL = f32(xL * yL)
+        thr = f32(cL * f32(1.00000095367431640625))
+        n = 500000
+        # points on the line y / yL + x / xL = 1 + e, e within +-2^-19 of the filter's margin and a few far ones
+        t = rng.random(n).astype(np.float64)
+        e = np.concatenate([rng.uniform(-2.0 ** -19, 2.0 ** -18, n - n // 10), rng.uniform(-0.5, 2.0, n // 10)])
+        x = (t * (1.0 + e) * float(xL)).astype(f32)
+        y = ((1.0 - t) * (1.0 + e) * float(yL)).astype(f32)
+        x[:50] = 0
+        y[50:100] = 0
+        aL = (y * xL).astype(f32) + (x * yL).astype(f32)
+        dropped = (aL > thr) & (x >= 0) & (y >= 0)
+        worst = max(worst, int(dropped.sum()))
+        for _ in range(16):
+            xo = f32(max(float(xL) * rng.uniform(2.0 ** -12, 1.0), 2.0 ** -40))
+            yo = f32(max(float(yL) * rng.uniform(2.0 ** -12, 1.0), 2.0 ** -40))
+            assert xo <= xL and yo <= yL
+            ao = (y * xo).astype(f32) + (x * yo).astype(f32)
+            within = ao <= f32(xo * yo)
+            assert not np.any(within & dropped), (trial, float(xL), float(yL), float(xo), float(yo))
+        # the same boundary itself
+        assert not np.any((aL <= cL) & dropped)
+    assert worst > 100000      # (the filter did drop rows in these trials: the check is not vacuous)
