@@ -324,7 +324,7 @@ ti1_classify_kernel(const float2 *__restrict__ dist, size_t n_rows, const Bnd *_
 // the compaction blocks' candidate counts, total -> ctrl->n_cand and *n_out (the count-only answer's upper bound).
 __global__ void __launch_bounds__(1024)
 ti1_scan_kernel(unsigned long long *__restrict__ block_sums, size_t n_blocks, const ulonglong2 *__restrict__ stops,
-                size_t n_stops, Ctrl *__restrict__ ctrl) {
+                size_t n_stops, Ctrl *__restrict__ ctrl, Ctrl *__restrict__ host_copy) {
   __shared__ unsigned long long wsum[16];
   __shared__ unsigned long long sord[16], srow[16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -377,6 +377,14 @@ ti1_scan_kernel(unsigned long long *__restrict__ block_sums, size_t n_blocks, co
       }
     ctrl->stop_ord = (unsigned)bo;
     ctrl->stop_row = br;
+  }
+  // the host reads the candidate count and the hole flag after this kernel: they go straight into its pinned block
+  // (host memory mapped into the device's address space) instead of through a copy of their own
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    Ctrl c = *ctrl;
+    *host_copy = c;
+    __threadfence_system();
   }
 }
 
@@ -840,29 +848,34 @@ int ti_classify(int dev, hipStream_t s, const float2 *dist, size_t n_rows, const
   const size_t n_stops = (size_t)grid * 4;
 
   void *p_bnd = nullptr, *p_a = nullptr, *p_mask = nullptr, *p_ws = nullptr;
-  int rc = ppk_scratch_get(dev, SLOT_BOUNDS, padded.size() * sizeof(Bnd) + 256, &p_bnd);
+  // SLOT_BOUNDS: the control block (256 B) | the boundaries -- written by ONE upload
+  int rc = ppk_scratch_get(dev, SLOT_BOUNDS, 256 + padded.size() * sizeof(Bnd) + 256, &p_bnd);
   if (rc != PPK_OK) return rc;
-  PPK_HIP(hipMemcpyAsync(p_bnd, padded.data(), padded.size() * sizeof(Bnd), hipMemcpyHostToDevice, s));
-  const Bnd *d_bnd = static_cast<const Bnd *>(p_bnd);
-  // A: ctrl | stops (16 B per wavefront of the classify pass) | first (F per row)
-  const size_t a_stops = 256, a_first = a_stops + ((n_stops * 16 + 255) & ~(size_t)255);
+  Ctrl *ctrl = static_cast<Ctrl *>(p_bnd);
+  const Bnd *d_bnd = reinterpret_cast<const Bnd *>(static_cast<char *>(p_bnd) + 256);
+  // A: stops (16 B per wavefront of the classify pass) | first (F per row)
+  const size_t a_first = (n_stops * 16 + 255) & ~(size_t)255;
   rc = ppk_scratch_get(dev, SLOT_ITER_A, a_first + n_rows * sizeof(F) + 256, &p_a);
   if (rc == PPK_OK) rc = ppk_scratch_get(dev, SLOT_MASK, n_words * 8 + 8, &p_mask);
   if (rc == PPK_OK) rc = ppk_scratch_get(dev, SLOT_WS, n_cblocks * 8 + 256, &p_ws);
   if (rc != PPK_OK) return rc;
   char *A = static_cast<char *>(p_a);
-  Ctrl *ctrl = reinterpret_cast<Ctrl *>(A);
-  ulonglong2 *stops = reinterpret_cast<ulonglong2 *>(A + a_stops);
+  ulonglong2 *stops = reinterpret_cast<ulonglong2 *>(A);
   F *first = reinterpret_cast<F *>(A + a_first);
   uint64_t *mask = static_cast<uint64_t *>(p_mask);
   unsigned long long *block_sums = static_cast<unsigned long long *>(p_ws);
+  Ctrl *h_ctrl = pinned_ctrl(dev);
+  if (!h_ctrl) return ppk_fail(PPK_ERR_HIP, "hipHostMalloc failed");
 
+  std::vector<char> up(256 + padded.size() * sizeof(Bnd), 0);
   Ctrl h = {};
   h.n_cut = ~0ull;
   h.stop_ord = 0xffffffffu;
   h.stop_row = ~0ull;
+  memcpy(up.data(), &h, sizeof(Ctrl));
+  memcpy(up.data() + 256, padded.data(), padded.size() * sizeof(Bnd));
   ppk_prof_stage("classify", s);
-  PPK_HIP(hipMemcpyAsync(ctrl, &h, sizeof(Ctrl), hipMemcpyHostToDevice, s));      // (h is copied at the call: pageable)
+  PPK_HIP(hipMemcpyAsync(p_bnd, up.data(), up.size(), hipMemcpyHostToDevice, s));      // (pageable: staged at the call)
   PPK_HIP(hipMemsetAsync(block_sums, 0, n_cblocks * 8, s));
 #define PPK_TI1_CLASSIFY(M, FL)                                                                                     \
   hipLaunchKernelGGL((ti1_classify_kernel<M, FL, F>), dim3(grid), dim3(256), lds, s, dist, n_rows, d_bnd, n_pad, slope, \
@@ -874,14 +887,10 @@ int ti_classify(int dev, hipStream_t s, const float2 *dist, size_t n_rows, const
   else PPK_TI1_CLASSIFY(2, false);
 #undef PPK_TI1_CLASSIFY
   ppk_prof_stage("scan", s);
-  hipLaunchKernelGGL(ti1_scan_kernel, dim3(1), dim3(1024), 0, s, block_sums, n_cblocks, stops, n_stops, ctrl);
+  hipLaunchKernelGGL(ti1_scan_kernel, dim3(1), dim3(1024), 0, s, block_sums, n_cblocks, stops, n_stops, ctrl, h_ctrl);
   ppk_prof_stage(nullptr, s);
   PPK_HIP(hipGetLastError());
-  // (read back into pinned memory: a copy to pageable memory goes through a staging kernel of its own)
-  Ctrl *h_ctrl = pinned_ctrl(dev);
-  if (!h_ctrl) return ppk_fail(PPK_ERR_HIP, "hipHostMalloc failed");
-  PPK_HIP(hipMemcpyAsync(h_ctrl, ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, s));
-  PPK_HIP(hipStreamSynchronize(s));
+  PPK_HIP(hipStreamSynchronize(s));      // (the scan kernel has left the control block in the pinned host block)
   out.got = *h_ctrl;
   out.d_bnd = d_bnd;
   out.first = first;
