@@ -1,36 +1,26 @@
-"""Variants of the sweep's classify pass, built as whole libraries under build/var/ (git-ignored, shipped by gpurun):
-occupancy bound, rows per dense batch, rows per lane.  usage: python tools/experiments/ti1_variants.py
-then  bash tools/experiments/ti1_variants_run.sh  (on the GPU box)"""
+"""Compile-time variants of the sweep kernels, built as whole libraries under build/var/ (git-ignored, shipped by
+gpurun).  usage: python tools/experiments/ti1_variants.py ; then bash tools/experiments/ti1_variants_run.sh on the GPU box"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 SRC = os.path.join(ROOT, "poppunk_amd", "csrc")
 OUT = os.path.join(ROOT, "build", "var")
 os.makedirs(OUT, exist_ok=True)
 base = open(os.path.join(SRC, "ppk_iterate.hip")).read()
-LB = "template <int MODE, bool FILTER, typename F>\n__global__ void __launch_bounds__(256)\nti1_classify_kernel("
-assert base.count(LB) == 1
 
 
-def lb(text, n):
-    return text.replace(LB, LB.replace("__launch_bounds__(256)", "__launch_bounds__(256, %d)" % n))
+def rep(text, a, b, count=1):
+    assert text.count(a) >= 1, a
+    return text.replace(a, b, count)
 
 
-def dense(text, n):
-    return text.replace("constexpr int kDenseRows = 2;", "constexpr int kDenseRows = %d;" % n)
-
-
-def unit(text, n):
-    return text.replace("constexpr int kUnitWords = 8;", "constexpr int kUnitWords = %d;" % n)
-
-
+NT_A = "      if constexpr (!BY_OFFSET) d[k] = dist[rr];"
+NT_B = "      if constexpr (!BY_OFFSET) { const f32x2 t_ = __builtin_nontemporal_load(reinterpret_cast<const f32x2 *>(dist) + rr); d[k] = make_float2(t_.x, t_.y); }"
 variants = {
     0: base,
-    1: lb(base, 5),
-    2: lb(base, 6),
-    3: lb(dense(base, 1), 6),
-    4: lb(dense(base, 4), 5),
-    5: lb(unit(base, 4), 6),
-    6: lb(unit(dense(base, 1), 4), 8),
+    1: rep(base, "constexpr int kExpandBatch = 8;", "constexpr int kExpandBatch = 16;"),
+    2: rep(base, NT_A, NT_B),
+    3: rep(rep(base, NT_A, NT_B), "constexpr int kExpandBatch = 8;", "constexpr int kExpandBatch = 16;"),
+    4: rep(base, "constexpr int kEmitBlock = 1024;", "constexpr int kEmitBlock = 256;"),
 }
 objs = [os.path.join(SRC, f) for f in ("ppk_api.o", "ppk_host.o", "ppk_dist.o", "ppk_boundary.o", "ppk_square.o", "ppk_sparse.o", "ppk_h5.o")]
 procs = []
