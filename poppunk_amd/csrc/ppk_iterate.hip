@@ -929,9 +929,16 @@ int sort_bufs(int dev, size_t n_cand, SortBufs<V> &b) {
 }
 template <typename V>
 int sort_pairs(int dev, hipStream_t s, const SortBufs<V> &b, size_t n_cand, int end_bit) {
-  // Onesweep whatever the size: below a million items rocPRIM's default would be a merge sort, 131 us for the 2-D
-  // sweep's 617 000 (5-bit key, row) pairs where one radix pass takes a fifth of that
-  typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0> Cfg;
+  // Onesweep whatever the size (below a million items rocPRIM's default would be a merge sort, 131 us for the 2-D
+  // sweep's 617 000 (5-bit key, row) pairs where one radix pass takes a quarter of that), and with 8 items per thread
+  // instead of the 16 its gfx950 table holds for 4-byte pairs: 8.46 M pairs, four passes: 360 -> 282 us
+  // (profiles/r06/rocprim_configs.txt; 4, 6, 10 and 16 items, 256 and 512 threads are all slower)
+  typedef rocprim::radix_sort_config<
+      rocprim::default_config, rocprim::default_config,
+      rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 16>, rocprim::kernel_config<1024, 8>, 8,
+                                          rocprim::block_radix_rank_algorithm::match>,
+      0>
+      Cfg;
   size_t tmp_bytes = 0;
   void *p_c = nullptr;
   PPK_HIP(rocprim::radix_sort_pairs<Cfg>(nullptr, tmp_bytes, b.keys_in, b.keys_out, b.vals_in, b.vals_out, n_cand, 0u,

@@ -13,14 +13,24 @@ def rep(text, a, b, count=1):
     return text.replace(a, b, count)
 
 
-NT_A = "      if constexpr (!BY_OFFSET) d[k] = dist[rr];"
-NT_B = "      if constexpr (!BY_OFFSET) { const f32x2 t_ = __builtin_nontemporal_load(reinterpret_cast<const f32x2 *>(dist) + rr); d[k] = make_float2(t_.x, t_.y); }"
+CFG = "  typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0> Cfg;"
+
+
+def cfg(bs, ipt, algo="match", hist=(256, 12)):
+    return rep(base, CFG, "  typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, "
+               "rocprim::radix_sort_onesweep_config<rocprim::kernel_config<%d, %d>, rocprim::kernel_config<%d, %d>, 8, "
+               "rocprim::block_radix_rank_algorithm::%s>, 0> Cfg;" % (hist[0], hist[1], bs, ipt, algo))
+
+
 variants = {
-    0: base,
-    1: rep(base, "constexpr int kExpandBatch = 8;", "constexpr int kExpandBatch = 16;"),
-    2: rep(base, NT_A, NT_B),
-    3: rep(rep(base, NT_A, NT_B), "constexpr int kExpandBatch = 8;", "constexpr int kExpandBatch = 16;"),
-    4: rep(base, "constexpr int kEmitBlock = 1024;", "constexpr int kEmitBlock = 256;"),
+    0: cfg(1024, 8, hist=(1024, 16)),
+    1: cfg(1024, 6, hist=(1024, 16)),
+    2: cfg(1024, 4, hist=(1024, 16)),
+    3: cfg(512, 8, hist=(1024, 16)),
+    4: cfg(1024, 8, hist=(1024, 8)),
+    5: cfg(1024, 8, hist=(512, 16)),
+    6: cfg(1024, 10, hist=(1024, 16)),
+    7: cfg(1024, 8, hist=(1024, 32)),
 }
 objs = [os.path.join(SRC, f) for f in ("ppk_api.o", "ppk_host.o", "ppk_dist.o", "ppk_boundary.o", "ppk_square.o", "ppk_sparse.o", "ppk_h5.o")]
 procs = []
