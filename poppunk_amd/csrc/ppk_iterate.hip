@@ -61,6 +61,7 @@ struct Ctrl {
 typedef float f32x2 __attribute__((ext_vector_type(2)));      // (8-byte loads only: no packed arithmetic)
 
 constexpr int kUnitWords = 8;       // mask words (64 rows each) a wavefront classifies together: 8 rows per lane
+constexpr int kUnitRowBits = 9;     // a row's place inside its unit (kUnitWords * 64 = 512 rows)
 constexpr int kCbWords = 256;       // mask words per compaction block (one workgroup of the expand pass)
 
 // MODE 0 / 1: slope 0 / 1 (within <=> coordinate - max <= 0).  MODE 2: slope 2, no boundary on an axis
@@ -135,7 +136,8 @@ constexpr int kDenseRows = 2;      // rows per lane of one dense batch of the fi
 template <int MODE, bool FILTER, typename F>
 __global__ void __launch_bounds__(256)
 ti1_classify_kernel(const float2 *__restrict__ dist, size_t n_rows, const Bnd *__restrict__ bnd, int n_pad,
-                    int slope, Bnd filt, F *__restrict__ first, uint64_t *__restrict__ mask, size_t n_words,
+                    int slope, Bnd filt, F *__restrict__ first, unsigned *__restrict__ cand_key, uint64_t *__restrict__ mask,
+                    size_t n_words,
                     unsigned long long *__restrict__ block_sums, ulonglong2 *__restrict__ stops,
                     Ctrl *__restrict__ ctrl) {
   static_assert(!FILTER || MODE == 2, "the filter is a slope-2 argument");
@@ -273,16 +275,24 @@ ti1_classify_kernel(const float2 *__restrict__ dist, size_t n_rows, const Bnd *_
       }
     }
     const unsigned rel0 = (unsigned)(u - u0) * (kUnitWords * 64) + (unsigned)lane;
+    // The unit's candidates leave here, packed to the front of the unit's own run of kUnitWords * 64 slots in row
+    // order: their key ord(d0) -- computed for every row anyway, the stop needs it -- and (row within the unit |
+    // first boundary f << kUnitRowBits).  The expand pass copies the runs end to end: a unit's count and place follow
+    // from its mask words, and the matrix is not read again.
+    size_t unit_slot = u * (size_t)(kUnitWords * 64);
 #pragma unroll
     for (int r = 0; r < kUnitWords; ++r) {
       const size_t w_idx = u * kUnitWords + r;
       if (!full && w_idx >= n_words) break;      // wave-uniform
       const size_t row = w_idx * 64 + lane;
       const bool in = full || row < n_rows;
-      const uint64_t m = __ballot(in && cnt[r] > 0);
+      const bool is_cand = in && cnt[r] > 0;
+      const uint64_t m = __ballot(is_cand);
       if (lane == 0) mask[w_idx] = m;
       bits += (unsigned)__popcll(m);
-      if (in) first[row] = (F)((unsigned)n_pad - cnt[r]);
+      const size_t slot = unit_slot + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+      unit_slot += (unsigned)__popcll(m);
+      if (is_cand) first[slot] = (F)((unsigned)(r * 64 + lane) | (((unsigned)n_pad - cnt[r]) << kUnitRowBits));
       // a row no boundary holds: the walk ends at the first of these in (d0, row) order.  NaN distances
       // compare false everywhere and sort after everything (as they did in the reference's key order).
       float d0;
@@ -290,6 +300,7 @@ ti1_classify_kernel(const float2 *__restrict__ dist, size_t n_rows, const Bnd *_
       else d0 = ppk_line_dist(x[r], y[r], b0.xm, b0.ym, slope);
       d0 = d0 + 0.0f;      // -0.0 -> +0.0 so that the radix order equals operator<
       const unsigned c = f2ord(d0);
+      if (is_cand) cand_key[slot] = c;
       // rows grow within a lane: strict < keeps the earliest
       if (in && cnt[r] == 0 && d0 == d0 && c < best_ord) {
         best_ord = c;
@@ -388,17 +399,18 @@ ti1_scan_kernel(unsigned long long *__restrict__ block_sums, size_t n_blocks, co
   }
 }
 
-constexpr int kExpandBatch = 8;      // mask words (rows per lane) in flight per wavefront of the expand pass
-
-// The candidates, in row order: key = ord(d0), value = row | f << row_bits.  A wavefront takes the 64 mask
-// words of its quarter of a compaction block, kExpandBatch at a time (lane = bit: coalesced reads of the rows' distances,
-// dense writes).
-// BY_OFFSET (the 2D sweep): key = f itself, value = the row; the distances are not read.
+// The candidates, in row order: key = ord(d0), value = row | f << row_bits.  The classify pass left every unit's
+// candidates (kUnitWords mask words = 512 rows) packed at the front of the unit's slots; a wavefront takes the 8 units
+// of its 64 mask words, whose counts say where each run starts in the dense list, and copies them end to end -- one
+// candidate per lane, every lane busy (a loop over the mask words with lane = row keeps one lane in six busy on the
+// 10 000-genome sweep and re-read the matrix for d0: 118 us; this copy: see profiles/NOTES_r06.md).
+// BY_OFFSET (the 2D sweep): key = f itself, value = the row.
 template <bool BY_OFFSET, typename V, typename F>
 __global__ void __launch_bounds__(256)
-ti1_expand_kernel(const uint64_t *__restrict__ mask, size_t n_words, size_t n_rows,
-                  const unsigned long long *__restrict__ block_offsets, const float2 *__restrict__ dist, const F *__restrict__ first, const Bnd *__restrict__ bnd, int slope,
-                  int row_bits, unsigned *__restrict__ keys, V *__restrict__ vals) {
+ti1_expand_kernel(const uint64_t *__restrict__ mask, size_t n_words, const unsigned long long *__restrict__ block_offsets,
+                  const unsigned *__restrict__ cand_key, const F *__restrict__ cand_meta, int row_bits,
+                  unsigned *__restrict__ keys, V *__restrict__ vals) {
+  static_assert(kUnitWords == 8 && (1 << kUnitRowBits) == kUnitWords * 64, "8 units per wavefront of 64 mask words");
   __shared__ unsigned sh_wave[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const size_t w0 = (size_t)blockIdx.x * kCbWords + (size_t)wave * 64;
@@ -415,45 +427,31 @@ ti1_expand_kernel(const uint64_t *__restrict__ mask, size_t n_words, size_t n_ro
   __syncthreads();
   size_t base = (size_t)block_offsets[blockIdx.x];
   for (int i = 0; i < wave; ++i) base += sh_wave[i];
-  const unsigned excl = inc - c;      // lane l: candidates in words before word l of this wavefront
-  const Bnd b0 = bnd[0];
-  const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
-  for (int g = 0; g < 64; g += kExpandBatch) {
-    if (w0 + g >= n_words) break;
-    float2 d[kExpandBatch];
-    unsigned f[kExpandBatch];
-    uint64_t m[kExpandBatch];
-    unsigned off[kExpandBatch];
+  const unsigned excl = inc - c;
+  const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)inc, 63);
+  unsigned start[8];      // wave-uniform: candidates before unit q of this wavefront
 #pragma unroll
-    for (int k = 0; k < kExpandBatch; ++k) {
-      const size_t w = w0 + g + k;
-      m[k] = w < n_words ? mask[w] : 0ull;      // wave-uniform
-      off[k] = __shfl(excl, g + k, 64);
-      const size_t row = w * 64 + lane;
-      // every row's distance is fetched, candidate or not: the lines come in whole anyway, and loads that do not
-      // wait for the mask word are all in flight together
-      const size_t rr = row < n_rows ? row : n_rows - 1;
-      d[k] = make_float2(0.f, 0.f);
-      if constexpr (!BY_OFFSET) {      // (streamed: nothing reads these lines again -- 127 -> 116 us)
-        const f32x2 t = __builtin_nontemporal_load(reinterpret_cast<const f32x2 *>(dist) + rr);
-        d[k] = make_float2(t.x, t.y);
-      }
-      f[k] = first[rr];
+  for (int q = 0; q < 8; ++q) start[q] = (unsigned)__builtin_amdgcn_readlane((int)excl, q * 8);
+  const size_t unit0 = w0 / kUnitWords;
+  for (unsigned j = lane; j < total; j += 64) {
+    unsigned q = 0, st = 0;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+      const bool ge = j >= start[k];      // (an empty unit shares its start with the next: the last one wins)
+      q = ge ? (unsigned)k : q;
+      st = ge ? start[k] : st;
     }
-#pragma unroll
-    for (int k = 0; k < kExpandBatch; ++k) {
-      if (!((m[k] >> lane) & 1)) continue;
-      const size_t row = (w0 + g + k) * 64 + lane;
-      const size_t pos = base + off[k] + (unsigned)__popcll(m[k] & below);
-      if constexpr (BY_OFFSET) {
-        keys[pos] = f[k];
-        vals[pos] = (V)row;
-      } else {
-        float d0 = ppk_line_dist(d[k].x, d[k].y, b0.xm, b0.ym, slope);
-        d0 = d0 + 0.0f;
-        keys[pos] = f2ord(d0);
-        vals[pos] = (V)((unsigned long long)row | ((unsigned long long)f[k] << row_bits));
-      }
+    const size_t unit_rows = (unit0 + q) << kUnitRowBits;
+    const size_t src = unit_rows + (j - st);
+    const unsigned meta = cand_meta[src];
+    const unsigned long long row = unit_rows + (meta & ((1u << kUnitRowBits) - 1u));
+    const unsigned f = meta >> kUnitRowBits;
+    if constexpr (BY_OFFSET) {
+      keys[base + j] = f;
+      vals[base + j] = (V)row;
+    } else {
+      keys[base + j] = __builtin_nontemporal_load(cand_key + src);
+      vals[base + j] = (V)(row | ((unsigned long long)f << row_bits));
     }
   }
 }
@@ -795,7 +793,8 @@ Ctrl *pinned_ctrl(int dev) {
 template <typename F>
 struct Classified {
   const Bnd *d_bnd = nullptr;
-  const F *first = nullptr;
+  const F *first = nullptr;              // per classify unit, packed: the candidates' (row in the unit | first boundary << 9)
+  const unsigned *cand_key = nullptr;    // ... and their keys
   const uint64_t *mask = nullptr;
   const unsigned long long *block_offsets = nullptr;
   Ctrl *ctrl = nullptr;
@@ -856,15 +855,19 @@ int ti_classify(int dev, hipStream_t s, const float2 *dist, size_t n_rows, const
   if (rc != PPK_OK) return rc;
   Ctrl *ctrl = static_cast<Ctrl *>(p_bnd);
   const Bnd *d_bnd = reinterpret_cast<const Bnd *>(static_cast<char *>(p_bnd) + 256);
-  // A: stops (16 B per wavefront of the classify pass) | first (F per row)
+  // A: stops (16 B per wavefront of the classify pass) | per unit of kUnitWords * 64 rows, packed to the front of the
+  // unit's slots: the candidates' (row in the unit | first boundary << 9) (F each) | their keys ord(d0) (4 bytes each)
+  const size_t n_slots = n_units * (size_t)(kUnitWords * 64);
   const size_t a_first = (n_stops * 16 + 255) & ~(size_t)255;
-  rc = ppk_scratch_get(dev, SLOT_ITER_A, a_first + n_rows * sizeof(F) + 256, &p_a);
+  const size_t a_keys = (a_first + n_slots * sizeof(F) + 255) & ~(size_t)255;
+  rc = ppk_scratch_get(dev, SLOT_ITER_A, a_keys + n_slots * sizeof(unsigned) + 256, &p_a);
   if (rc == PPK_OK) rc = ppk_scratch_get(dev, SLOT_MASK, n_words * 8 + 8, &p_mask);
   if (rc == PPK_OK) rc = ppk_scratch_get(dev, SLOT_WS, n_cblocks * 8 + 256, &p_ws);
   if (rc != PPK_OK) return rc;
   char *A = static_cast<char *>(p_a);
   ulonglong2 *stops = reinterpret_cast<ulonglong2 *>(A);
   F *first = reinterpret_cast<F *>(A + a_first);
+  unsigned *cand_key = reinterpret_cast<unsigned *>(A + a_keys);
   uint64_t *mask = static_cast<uint64_t *>(p_mask);
   unsigned long long *block_sums = static_cast<unsigned long long *>(p_ws);
   Ctrl *h_ctrl = pinned_ctrl(dev);
@@ -882,7 +885,7 @@ int ti_classify(int dev, hipStream_t s, const float2 *dist, size_t n_rows, const
   PPK_HIP(hipMemsetAsync(block_sums, 0, n_cblocks * 8, s));
 #define PPK_TI1_CLASSIFY(M, FL)                                                                                     \
   hipLaunchKernelGGL((ti1_classify_kernel<M, FL, F>), dim3(grid), dim3(256), lds, s, dist, n_rows, d_bnd, n_pad, slope, \
-                     filt, first, mask, n_words, block_sums, stops, ctrl)
+                     filt, first, cand_key, mask, n_words, block_sums, stops, ctrl)
   if (mode == 0) PPK_TI1_CLASSIFY(0, false);
   else if (mode == 1) PPK_TI1_CLASSIFY(1, false);
   else if (mode == 3) PPK_TI1_CLASSIFY(3, false);
@@ -897,6 +900,7 @@ int ti_classify(int dev, hipStream_t s, const float2 *dist, size_t n_rows, const
   out.got = *h_ctrl;
   out.d_bnd = d_bnd;
   out.first = first;
+  out.cand_key = cand_key;
   out.mask = mask;
   out.block_offsets = block_sums;
   out.ctrl = ctrl;
@@ -932,10 +936,12 @@ int sort_pairs(int dev, hipStream_t s, const SortBufs<V> &b, size_t n_cand, int 
   // Onesweep whatever the size (below a million items rocPRIM's default would be a merge sort, 131 us for the 2-D
   // sweep's 617 000 (5-bit key, row) pairs where one radix pass takes a quarter of that), and with 8 items per thread
   // instead of the 16 its gfx950 table holds for 4-byte pairs: 8.46 M pairs, four passes: 360 -> 282 us
-  // (profiles/r06/rocprim_configs.txt; 4, 6, 10 and 16 items, 256 and 512 threads are all slower)
+  // (profiles/r06/rocprim_configs.txt; 4, 6, 10 and 16 items, 256 and 512 threads are all slower), and with 9-bit
+  // digits -- 9 + 9 + 9 + 5 bits, the same four passes: 277 -> 256 us (10 and 11 bits: 360 and 420;
+  // tools/ubench_sort.hip)
   typedef rocprim::radix_sort_config<
       rocprim::default_config, rocprim::default_config,
-      rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 16>, rocprim::kernel_config<1024, 8>, 8,
+      rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 16>, rocprim::kernel_config<1024, 8>, 9,
                                           rocprim::block_radix_rank_algorithm::match>,
       0>
       Cfg;
@@ -960,7 +966,7 @@ int ti1_after_count(int dev, hipStream_t s, const float2 *dist, size_t n_rows, c
   if (rc != PPK_OK) return rc;
   ppk_prof_stage("expand", s);
   hipLaunchKernelGGL((ti1_expand_kernel<false, V, F>), dim3((unsigned)c.n_cblocks), dim3(256), 0, s, c.mask, c.n_words,
-                     n_rows, c.block_offsets, dist, c.first, c.d_bnd, slope, row_bits, b.keys_in, b.vals_in);
+                     c.block_offsets, c.cand_key, c.first, row_bits, b.keys_in, b.vals_in);
   ppk_prof_stage("sort", s);
   rc = sort_pairs<V>(dev, s, b, n_cand, 32);
   if (rc != PPK_OK) return rc;
@@ -1016,8 +1022,7 @@ int ti2_after_count(int dev, hipStream_t s, size_t n_rows, const Classified<F> &
   if (rc != PPK_OK) return rc;
   ppk_prof_stage("expand", s);
   hipLaunchKernelGGL((ti1_expand_kernel<true, V, F>), dim3((unsigned)c.n_cblocks), dim3(256), 0, s, c.mask, c.n_words,
-                     n_rows, c.block_offsets, static_cast<const float2 *>(nullptr), c.first, c.d_bnd, 2, 0, b.keys_in,
-                     b.vals_in);
+                     c.block_offsets, c.cand_key, c.first, 0, b.keys_in, b.vals_in);
   ppk_prof_stage("sort", s);
   rc = sort_pairs<V>(dev, s, b, n_cand, bits_for((unsigned long long)n_off));
   if (rc != PPK_OK) return rc;
@@ -1083,9 +1088,10 @@ extern "C" int ppk_threshold_iterate_1d_dev(const float *d_dist, size_t n_rows,
   PPK_HIP(hipGetDevice(&dev));
   PpkCall call(dev, s);
   const float2 *dist = reinterpret_cast<const float2 *>(d_dist);
-  if (n_off <= 255)
-    return ti1_run<uint8_t>(dev, s, dist, n_rows, bnd, slope, n_samples, d_i, d_j, d_off, cap, d_n_out);
-  return ti1_run<uint16_t>(dev, s, dist, n_rows, bnd, slope, n_samples, d_i, d_j, d_off, cap, d_n_out);
+  // (a candidate's row inside its unit, 9 bits, and its first boundary share one word: 16 bits up to 124 offsets)
+  if (n_off <= 124)
+    return ti1_run<uint16_t>(dev, s, dist, n_rows, bnd, slope, n_samples, d_i, d_j, d_off, cap, d_n_out);
+  return ti1_run<uint32_t>(dev, s, dist, n_rows, bnd, slope, n_samples, d_i, d_j, d_off, cap, d_n_out);
 }
 
 extern "C" int ppk_threshold_iterate_2d_dev(const float *d_dist, size_t n_rows, const float *x_max,
@@ -1136,8 +1142,8 @@ extern "C" int ppk_threshold_iterate_2d_dev(const float *d_dist, size_t n_rows, 
       else
         rc1 = ti2_after_count<uint64_t, F>(dev, s, n_rows, c, (int)n_off, n_samples, d_i, d_j, d_off, cap, d_n_out);
     };
-    if (n_off <= 255) run((uint8_t)0);
-    else run((uint16_t)0);
+    if (n_off <= 124) run((uint16_t)0);
+    else run((uint32_t)0);
     if (rc1 != PPK_OK) return rc1;
     if (!holes && n_cand <= 0x7fffffffull) {
       if (n_cand == 0) PPK_HIP(hipMemsetAsync(d_n_out, 0, sizeof(unsigned long long), s));
