@@ -36,7 +36,7 @@ def timed(fn, reps=20):
     out = fn()
     torch.cuda.synchronize()
     ts = []
-    _lib.lib().ppk_prof_stages_enable(1)
+    _lib.lib().ppk_prof_stages_enable(0 if "--plain" in sys.argv else 1)      # (--plain: wall time without the stage events)
     stages()
     for _ in range(reps):
         t0 = time.perf_counter()

@@ -1,6 +1,6 @@
 // Stand-alone bench of the sweep's sort: 8.46 M (u32 key, u32 / u64 value) pairs, stable, 32 key bits.
 // rocPRIM's onesweep (what ppk_iterate.hip called up to round 6) against the hand-written one in
-// ../poppunk_amd/csrc/ppk_sort.inc, checked against std::stable_sort on the host.
+// experiments/ppk_sort.inc, checked against std::stable_sort on the host.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 ubench_sort.hip -o /tmp/sortb && /tmp/sortb [n] [end_bit]
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -19,7 +19,7 @@
     }                                                                      \
   } while (0)
 
-#include "../poppunk_amd/csrc/ppk_sort.inc"
+#include "experiments/ppk_sort.inc"
 
 template <int BITS, int HT, int HI, int ST, int SI, typename V>
 float run_rocprim(const char *name, unsigned *kin, unsigned *kout, V *vin, V *vout, size_t n, int endbit) {
@@ -83,14 +83,21 @@ int bench(size_t n, int end_bit, int dist_kind) {
   run_rocprim<8, 1024, 16, 1024, 8, V>("rocPRIM onesweep 8 bits 1024x16 / 1024x8", kin, kout, vin, vout, n, end_bit);
 
   // hand-written
-  const size_t ws_bytes = ppk_sort::workspace_bytes(n, end_bit);
+  const size_t cap = n + n / 4 + 1000;      // the launch is sized for more than there is, as in the sweeps
+  const size_t ws_bytes = ppk_sort::workspace_bytes(cap, end_bit);
+  unsigned long long *n_dev = nullptr;
+  CK(hipMalloc(&n_dev, 8));
+  {
+    const unsigned long long nn = n;
+    CK(hipMemcpy(n_dev, &nn, 8, hipMemcpyHostToDevice));
+  }
   void *ws = nullptr;
   CK(hipMalloc(&ws, ws_bytes));
   hipEvent_t a, b;
   CK(hipEventCreate(&a));
   CK(hipEventCreate(&b));
   float best = 1e9;
-  bool in_out = false;
+  const bool in_out = ppk_sort::result_in_second(end_bit);
 #ifdef PPK_SORT_TRACE
   const int n_it = 1;
 #else
@@ -101,7 +108,7 @@ int bench(size_t n, int end_bit, int dist_kind) {
     CK(hipMemcpyAsync(vin, v.data(), n * sizeof(V), hipMemcpyHostToDevice, 0));
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(a, 0));
-    CK(ppk_sort::sort_pairs<V>(ws, ws_bytes, kin, kout, vin, vout, n, end_bit, 0, &in_out));
+    CK(ppk_sort::sort_pairs<V>(ws, ws_bytes, kin, kout, vin, vout, n_dev, cap, end_bit, 0));
     CK(hipEventRecord(b, 0));
     CK(hipEventSynchronize(b));
     float ms;
@@ -114,7 +121,7 @@ int bench(size_t n, int end_bit, int dist_kind) {
     hipEvent_t m[8];
     for (auto &ev : m) CK(hipEventCreate(&ev));
     CK(hipEventRecord(a, 0));
-    CK(ppk_sort::sort_pairs<V>(ws, ws_bytes, kin, kout, vin, vout, n, end_bit, 0, &in_out, m));
+    CK(ppk_sort::sort_pairs<V>(ws, ws_bytes, kin, kout, vin, vout, n_dev, cap, end_bit, 0, m));
     CK(hipDeviceSynchronize());
     float t[8];
     CK(hipEventElapsedTime(&t[0], a, m[0]));
@@ -126,7 +133,7 @@ int bench(size_t n, int end_bit, int dist_kind) {
     // (the data are sorted now: sort the original again so that the check below sees a real run)
     CK(hipMemcpy(kin, k.data(), n * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(vin, v.data(), n * sizeof(V), hipMemcpyHostToDevice));
-    CK(ppk_sort::sort_pairs<V>(ws, ws_bytes, kin, kout, vin, vout, n, end_bit, 0, &in_out));
+    CK(ppk_sort::sort_pairs<V>(ws, ws_bytes, kin, kout, vin, vout, n_dev, cap, end_bit, 0));
   }
 #ifdef PPK_SORT_TRACE
   {
@@ -169,6 +176,7 @@ int bench(size_t n, int end_bit, int dist_kind) {
     }
   printf("  check against std::stable_sort: %zu mismatches\n", bad);
   CK(hipFree(ws));
+  CK(hipFree(n_dev));
   CK(hipFree(kin));
   CK(hipFree(kout));
   CK(hipFree(vin));
