@@ -100,6 +100,10 @@ int ppk_device_count(int *n);
  *                          opening and where it is cut back to the best knn per sample
  *     "knn_lane_lists" (0) 1 = ppk_knn_rect_dev / ppk_knn_dev select with one sorted list per LANE (the form before the
  *                          one list per wavefront; kept so that the two can be timed side by side)
+ *   boundary sweeps
+ *     "sweep_window" (1)   the classify pass of ppk_threshold_iterate_1d/2d_dev finds how many boundaries hold a row by
+ *                          bisection when the boundaries are nested outwards (refine's sweeps are); 0 = every boundary
+ *                          is evaluated for every row the filter keeps (same results; the GPU suite runs both)
  *   host calls
  *     "chunk_rows" (8 Mi)  rows per sub-band of a host query (about an eighth of the job, at least 1 Mi, below 16 Mi
  *                          rows); also scales the pieces of the fused host edge call

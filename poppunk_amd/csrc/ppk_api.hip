@@ -73,6 +73,7 @@ const OptionEntry kOptions[] = {
     {"knn_list", "PPK_KNN_LIST", &PpkConfig::knn_list},
     {"knn_warm", "PPK_KNN_WARM", &PpkConfig::knn_warm},
     {"knn_cut", "PPK_KNN_CUT", &PpkConfig::knn_cut},
+    {"sweep_window", "PPK_SWEEP_WINDOW", &PpkConfig::sweep_window},
     {"host_parts", "PPK_HOST_PARTS", &PpkConfig::host_parts},
     {"host_parts_rows", "PPK_HOST_PARTS_ROWS", &PpkConfig::host_parts_rows},
     {"host_trace", "PPK_HOST_TRACE", &PpkConfig::host_trace},

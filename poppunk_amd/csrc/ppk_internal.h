@@ -72,6 +72,7 @@ struct PpkConfig {
   std::atomic<long long> ksplit_scratch_mb{2048};   // PPK_KSPLIT_SCRATCH_MB: what the one-launch k-split path's partial counts may take (per device, kept); jobs that would need more run through the tile kernel
   std::atomic<long long> ks_grid_pad{0};        // PPK_KS_GRID_PAD: 1 = the one-launch k-split grid is one column wider, which puts the units of a tile on different XCDs (tests of the hand-over)
   std::atomic<long long> knn_lane_lists{0};     // PPK_KNN_LANE_LISTS: 1 = the per-lane selection lists of ppk_knn_rect_dev (the form before the one list per wavefront; measurement)
+  std::atomic<long long> sweep_window{1};       // PPK_SWEEP_WINDOW: the boundary sweeps' classify pass finds a row's count by bisection over nested boundaries (0: every boundary evaluated for every row it keeps; same results)
   std::atomic<long long> knn_list{0};           // PPK_KNN_LIST: entries of the neighbour-candidate list (0 = sized from n and knn)
   std::atomic<long long> host_parts_rows{16 << 20};   // PPK_HOST_PARTS_ROWS: ... from this many rows up
   std::atomic<long long> host_parts{2};         // PPK_HOST_PARTS: worker threads of a one-device host query (>= 16 Mi rows)

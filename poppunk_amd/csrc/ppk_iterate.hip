@@ -127,13 +127,61 @@ __device__ __forceinline__ unsigned eval_rows_slope2(const float (&x)[R], const 
 
 constexpr int kDenseRows = 2;      // rows per lane of one dense batch of the filtered form
 
+// WINDOW (slope 2, the boundaries NESTED outwards: x_max and y_max non-decreasing in the offset, all >= 2^-40, finite --
+// an outward sweep, what refine.py passes): the count of a row by bisection instead of n_pad evaluations.  With
+// u = 2^-24, x, y >= 0 and a_o = fl(fl(y x_max_o) + fl(x y_max_o)):
+//   a_o > fl(c_o (1 + 2^-20))  =>  the row is outside boundary o and every boundary inside it (o' <= o): the argument
+//                                  of the filter below with L = o;
+//   a_o < fl(c_o (1 - 2^-20))  =>  the row is within boundary o and every boundary around it (o' >= o): the exact sum
+//                                  e_o <= a_o / (1 - u)^2 < x_max_o y_max_o (1 - 2^-20)(1 + u)^3 / (1 - u)^2, so
+//                                  y / y_max_o + x / x_max_o < 1 - 16 u + 5 u; the ratio does not grow outwards, hence
+//                                  a_o' <= e_o' (1 + u)^2 < x_max_o' y_max_o' (1 - 8 u) < fl(x_max_o' y_max_o') = c_o'.
+// The search keeps an index L that tested "safely outside" (or -1) and an index H that tested "safely within" (or
+// n_pad) and probes the middle: whatever the probes return, at H - L = 1 every verdict is known -- outside up to L,
+// within from H on, count = n_pad - H, no hole -- because both ends were TESTED, not inferred.  A probe that is
+// neither (the row lies within 2^-20 of that boundary, relatively), a negative or a NaN coordinate: the lane reports
+// it and the wavefront takes the full evaluation above.  bit-length(n_pad) probes of ~12 instructions per row against
+// n_pad evaluations of 5.
+template <int R>
+__device__ __forceinline__ bool probe_rows_slope2(const float (&x)[R], const float (&y)[R],
+                                                  const float4 *__restrict__ sw, int n_pad, int steps, unsigned (&cnt)[R]) {
+  int L[R], H[R];
+  bool ok[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    L[r] = -1;
+    H[r] = n_pad;
+    ok[r] = x[r] >= 0.0f && y[r] >= 0.0f;      // (false for a NaN)
+  }
+  for (int it = 0; it < steps; ++it) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const bool open = H[r] - L[r] > 1;
+      const int M = (L[r] + H[r]) >> 1;
+      const float4 B = sw[open ? M : 0];      // (x_max, y_max, c (1 - 2^-20), c (1 + 2^-20))
+      const float a = __fadd_rn(__fmul_rn(y[r], B.x), __fmul_rn(x[r], B.y));
+      const bool in = a < B.z, out = a > B.w;
+      H[r] = open && in ? M : H[r];
+      L[r] = open && !in && out ? M : L[r];
+      ok[r] = ok[r] && (!open || in || out);
+    }
+  }
+  bool all_ok = true;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    cnt[r] = (unsigned)(n_pad - H[r]);
+    all_ok = all_ok && ok[r];
+  }
+  return !all_ok;
+}
+
 // FILTER (slope 2, every boundary inside the last one: x_max_o <= x_max_L, y_max_o <= y_max_L, all >= 2^-40): a row
 // with x, y >= 0 and fl(fl(y x_max_L) + fl(x y_max_L)) > c_L (1 + 2^-20) is outside EVERY boundary -- with
 // u = 2^-24, y / y_max_o + x / x_max_o >= y / y_max_L + x / x_max_L > 1 + 11 u, so the rounded sum of boundary o
 // exceeds x_max_o y_max_o (1 + 8 u) >= c_o (underflow moves either side by < 2^-148, the margin is > 2^-104) -- and
 // takes no further part.  The rest (the candidates and a fringe) are packed through LDS, 64 * kDenseRows at a time,
 // so that the n_pad evaluations per row run on full wavefronts: 17 % of the rows in the 10 000-genome sweep.
-template <int MODE, bool FILTER, typename F>
+template <int MODE, bool FILTER, typename F, bool WINDOW = false>
 __global__ void __launch_bounds__(256)
 ti1_classify_kernel(const float2 *__restrict__ dist, size_t n_rows, const Bnd *__restrict__ bnd, int n_pad,
                     int slope, Bnd filt, F *__restrict__ first, unsigned *__restrict__ cand_key, uint64_t *__restrict__ mask,
@@ -141,8 +189,13 @@ ti1_classify_kernel(const float2 *__restrict__ dist, size_t n_rows, const Bnd *_
                     unsigned long long *__restrict__ block_sums, ulonglong2 *__restrict__ stops,
                     Ctrl *__restrict__ ctrl) {
   static_assert(!FILTER || MODE == 2, "the filter is a slope-2 argument");
-  extern __shared__ float4 dyn_lds[];      // MODE 2: n_pad + 1 boundaries; FILTER: + per wavefront 512 (x, y) and 512 counts
+  static_assert(!WINDOW || FILTER, "the bisection rides on the filtered form");
+  // MODE 2: n_pad + 1 boundaries; WINDOW: + n_pad probe records; FILTER: + per wavefront 512 (x, y) and 512 counts
+  extern __shared__ float4 dyn_lds[];
   float4 *sb = dyn_lds;
+  float4 *sw = dyn_lds + n_pad + 1;
+  const int n_head = n_pad + 1 + (WINDOW ? n_pad : 0);
+  const int steps = 32 - __builtin_clz((unsigned)n_pad);      // bit length of n_pad: probes until H - L = 1
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const size_t n_units = (n_words + kUnitWords - 1) / kUnitWords;
   const size_t n_waves = (size_t)gridDim.x * 4;
@@ -155,13 +208,15 @@ ti1_classify_kernel(const float2 *__restrict__ dist, size_t n_rows, const Bnd *_
     for (int o = threadIdx.x; o < n_pad; o += 256) {
       const Bnd b = bnd[o];
       sb[o] = make_float4(b.xm, b.ym, b.c, 0.0f);
+      if constexpr (WINDOW)
+        sw[o] = make_float4(b.xm, b.ym, __fmul_rn(b.c, 0.99999904632568359375f), __fmul_rn(b.c, 1.00000095367431640625f));
     }
     if (threadIdx.x == 0) sb[n_pad] = make_float4(filt.xm, filt.ym, filt.c, 0.0f);
     __syncthreads();
   }
   constexpr int kUnitRows = kUnitWords * 64;
-  float2 *stage_xy = reinterpret_cast<float2 *>(dyn_lds + n_pad + 1) + (size_t)wave * kUnitRows;
-  unsigned *stage_cnt = reinterpret_cast<unsigned *>(reinterpret_cast<float2 *>(dyn_lds + n_pad + 1) + 4 * kUnitRows) +
+  float2 *stage_xy = reinterpret_cast<float2 *>(dyn_lds + n_head) + (size_t)wave * kUnitRows;
+  unsigned *stage_cnt = reinterpret_cast<unsigned *>(reinterpret_cast<float2 *>(dyn_lds + n_head) + 4 * kUnitRows) +
                         (size_t)wave * kUnitRows;
   unsigned best_ord = 0xffffffffu;
   unsigned best_rel = 0xffffffffu;        // the stop candidate's row, relative to this wavefront's first row
@@ -232,8 +287,12 @@ ti1_classify_kernel(const float2 *__restrict__ dist, size_t n_rows, const Bnd *_
             dx[q] = v.x;
             dy[q] = v.y;
           }
-          const unsigned hb = eval_rows_slope2<kDenseRows>(dx, dy, sb, n_pad, dc);
-          hole |= __ballot(hb != 0u);
+          bool full_eval = true;
+          if constexpr (WINDOW) full_eval = __ballot(probe_rows_slope2<kDenseRows>(dx, dy, sw, n_pad, steps, dc)) != 0ull;
+          if (full_eval) {      // (wave-uniform)
+            const unsigned hb = eval_rows_slope2<kDenseRows>(dx, dy, sb, n_pad, dc);
+            hole |= __ballot(hb != 0u);
+          }
 #pragma unroll
           for (int q = 0; q < kDenseRows; ++q) {
             const unsigned sl = s0 + q * 64 + lane;
@@ -824,6 +883,10 @@ struct Classified {
   Ctrl got = {};
 };
 
+// option "sweep_window" 0: the classify pass evaluates every boundary for every row it keeps, as it did before the
+// bisection -- the GPU suite runs the sweeps both ways, and the two can be timed side by side
+bool ppk_sweep_window_off() { return ppk_config().sweep_window.load() == 0; }
+
 // the fast slope-2 form wants positive finite intercepts (see ti1_classify_kernel); anything else -- a boundary on
 // an axis takes the reference's sqrt branch -- goes through ppk_line_dist as it stands
 int classify_mode(const std::vector<Bnd> &bnd, int slope) {
@@ -857,12 +920,18 @@ int ti_classify(int dev, hipStream_t s, const float2 *dist, size_t n_rows, const
     filt = Bnd{bnd[L].xm, bnd[L].ym, t, 0.0f};
     filter = filter && std::isfinite(filt.c);
   }
+  // the bisection: boundaries nested outwards (see probe_rows_slope2); experiments may switch it off
+  bool window = filter;
+  for (size_t o = 1; o < bnd.size() && window; ++o)
+    window = bnd[o].xm >= bnd[o - 1].xm && bnd[o].ym >= bnd[o - 1].ym;
+  if (window && ppk_sweep_window_off()) window = false;
   size_t lds = 0;
-  if (mode == 2) lds = ((size_t)n_pad + 1) * sizeof(float4);
+  if (mode == 2) lds = ((size_t)n_pad + 1 + (window ? (size_t)n_pad : 0)) * sizeof(float4);
   if (filter) lds += 4 * ((size_t)kUnitWords * 64 + 64) * (sizeof(float2) + sizeof(unsigned));
   const void *kfn = mode == 0   ? reinterpret_cast<const void *>(&ti1_classify_kernel<0, false, F>)
                     : mode == 1 ? reinterpret_cast<const void *>(&ti1_classify_kernel<1, false, F>)
                     : mode == 3 ? reinterpret_cast<const void *>(&ti1_classify_kernel<3, false, F>)
+                    : window    ? reinterpret_cast<const void *>(&ti1_classify_kernel<2, true, F, true>)
                     : filter    ? reinterpret_cast<const void *>(&ti1_classify_kernel<2, true, F>)
                                 : reinterpret_cast<const void *>(&ti1_classify_kernel<2, false, F>);
   // exactly one round of resident workgroups (the rows are dealt out evenly whatever the grid; a second, partial
@@ -905,12 +974,13 @@ int ti_classify(int dev, hipStream_t s, const float2 *dist, size_t n_rows, const
   ppk_prof_stage("classify", s);
   PPK_HIP(hipMemcpyAsync(p_bnd, up.data(), up.size(), hipMemcpyHostToDevice, s));      // (pageable: staged at the call)
   PPK_HIP(hipMemsetAsync(block_sums, 0, n_cblocks * 8, s));
-#define PPK_TI1_CLASSIFY(M, FL)                                                                                     \
-  hipLaunchKernelGGL((ti1_classify_kernel<M, FL, F>), dim3(grid), dim3(256), lds, s, dist, n_rows, d_bnd, n_pad, slope, \
+#define PPK_TI1_CLASSIFY(M, FL, ...)                                                                                \
+  hipLaunchKernelGGL((ti1_classify_kernel<M, FL, F, ##__VA_ARGS__>), dim3(grid), dim3(256), lds, s, dist, n_rows, d_bnd, n_pad, slope, \
                      filt, first, cand_key, mask, n_words, block_sums, stops, ctrl)
   if (mode == 0) PPK_TI1_CLASSIFY(0, false);
   else if (mode == 1) PPK_TI1_CLASSIFY(1, false);
   else if (mode == 3) PPK_TI1_CLASSIFY(3, false);
+  else if (window) PPK_TI1_CLASSIFY(2, true, true);
   else if (filter) PPK_TI1_CLASSIFY(2, true);
   else PPK_TI1_CLASSIFY(2, false);
 #undef PPK_TI1_CLASSIFY

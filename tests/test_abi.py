@@ -79,7 +79,7 @@ def test_options_are_read_once_and_settable():
     ppk_set_option changes them (so a getenv never sits in a launch path)."""
     _lib.lib()
     for name, default in (("lds_table", 1), ("wide_kpg", 0), ("ksplit_long", 1), ("ksplit", 1200),
-                          ("chunk_rows", 8 << 20), ("launch_tiles", 8000000), ("knn_list", 0), ("knn_lane_lists", 0), ("ks_grid_pad", 0), ("ksplit_scratch_mb", 2048), ("knn_warm", 32), ("knn_cut", 4), ("prefault_threads", 8), ("db_cache", 1), ("progress", 1),
+                          ("chunk_rows", 8 << 20), ("launch_tiles", 8000000), ("knn_list", 0), ("knn_lane_lists", 0), ("ks_grid_pad", 0), ("ksplit_scratch_mb", 2048), ("knn_warm", 32), ("knn_cut", 4), ("sweep_window", 1), ("prefault_threads", 8), ("db_cache", 1), ("progress", 1),
                           ("ext_collision_adjust", 0), ("ext_fit_skip", 0)):
         env = "PPK_" + name.upper()
         if env not in os.environ:

@@ -196,9 +196,57 @@ def test_fused_edges_ref_query():
 
 # ---- "next" rows: the boundary sweeps ----------------------------------------
 
+@pytest.fixture(params=[1, 0], ids=["bisection", "every-boundary"])
+def sweep_window(request):
+    """The classify pass of the sweeps both ways: a row's count by bisection over nested boundaries (the default),
+    and by evaluating every boundary (option sweep_window 0)."""
+    from poppunk_amd import _lib
+    old = _lib.get_option("sweep_window")
+    _lib.set_option("sweep_window", request.param)
+    yield request.param
+    _lib.set_option("sweep_window", old)
+
+
+def test_threshold_iterate_rows_on_and_beside_nested_boundaries(sweep_window):
+    """40 nested boundaries (refine's outward sweep); rows planted ON every boundary, one and a few ulps either side of
+    it, and at relative distances around the bisection's 2^-20 margin -- where a probe must report "neither" and the
+    wavefront takes the full evaluation -- among random rows, negative coordinates included.  (No NaN rows: with a NaN
+    key the reference's comparator, boundary.hpp:35-37, is not a strict weak order and its sorted order is undefined.)"""
+    rng = np.random.Generator(np.random.PCG64(4242))
+    n = 900
+    rows = n * (n - 1) // 2
+    d = (rng.random((rows, 2)) * 0.5).astype(np.float32)
+    x0, y0, x1, y1 = 0.05, 0.06, 0.30, 0.34
+    offsets = np.linspace(0.0, float(np.hypot(x1 - x0, y1 - y0)), 40)
+    planted = []
+    for off in offsets:
+        xm, ym = oracle.boundary_of_offset(off, 2, x0, y0, x1, y1)
+        xm, ym = np.float32(xm), np.float32(ym)
+        for t in rng.random(24):
+            x = np.float32(t) * xm
+            y = np.float32((1.0 - float(x) / float(xm)) * float(ym))
+            for rel in (0.0, 6e-8, -6e-8, 2.4e-7, -2.4e-7, 9.0e-7, -9.0e-7, 9.6e-7, -9.6e-7, 1.1e-6, -1.1e-6, 3e-6, -3e-6):
+                planted.append((x, np.float32(float(y) * (1.0 + rel))))
+                planted.append((np.nextafter(x, np.float32(1)), np.float32(float(y) * (1.0 + rel))))
+    planted = np.asarray(planted, dtype=np.float32)
+    where = rng.choice(rows, size=len(planted), replace=False)
+    d[where] = planted
+    d[rng.choice(rows, 50, replace=False), 0] = np.float32(-0.01)
+    gi, gj, go = poppunk_refine.thresholdIterate1D_arrays(d, offsets, 2, x0, y0, x1, y1)
+    wi, wj, wo = oracle.threshold_iterate_1d(d, offsets, 2, x0, y0, x1, y1)
+    assert len(wi) > 10000
+    assert np.array_equal(gi, wi) and np.array_equal(gj, wj) and np.array_equal(go, wo)
+    # the 2-D sweep over x_max at one y_max is nested too
+    x_max = np.linspace(0.08, 0.4, 20).astype(np.float32)
+    gi, gj, go = poppunk_refine.thresholdIterate2D_arrays(d, x_max, 0.3)
+    wi, wj, wo = oracle.threshold_iterate_2d(d, x_max, 0.3)
+    assert len(wi) > 10000
+    assert np.array_equal(gi, wi) and np.array_equal(gj, wj) and np.array_equal(go, wo)
+
+
 @pytest.mark.parametrize("slope", [0, 1, 2])
 @pytest.mark.parametrize("samples", [3, 100, 700])
-def test_threshold_iterate_1d(samples, slope):
+def test_threshold_iterate_1d(samples, slope, sweep_window):
     """poppunk_refine.thresholdIterate1D (boundary.cpp:154-210) element for element, plus the
     reference test's own check (test/test-refine.py:84-110): edges with offset index <= o are
     exactly the rows assignThreshold puts within (<= 0) boundary o."""
@@ -221,7 +269,7 @@ def test_threshold_iterate_1d(samples, slope):
     assert li == gi.tolist() and lj == gj.tolist() and lo == go.tolist()
 
 
-def test_threshold_iterate_1d_edge_cases():
+def test_threshold_iterate_1d_edge_cases(sweep_window):
     rng = np.random.Generator(np.random.PCG64(99))
     d = (rng.random((4950, 2)) * 0.5).astype(np.float32)
     with pytest.raises(RuntimeError, match="must be sorted"):
@@ -246,7 +294,7 @@ def test_threshold_iterate_1d_edge_cases():
 
 
 @pytest.mark.parametrize("samples", [3, 100, 700])
-def test_threshold_iterate_2d(samples):
+def test_threshold_iterate_2d(samples, sweep_window):
     """poppunk_refine.thresholdIterate2D (boundary.cpp:212-237), and test-refine.py:112-138."""
     rng = np.random.Generator(np.random.PCG64(17 + samples))
     d = (rng.random((samples * (samples - 1) // 2, 2)) * 0.6).astype(np.float32)
@@ -262,7 +310,7 @@ def test_threshold_iterate_2d(samples):
         poppunk_refine.thresholdIterate2D(d, [0.2, 0.1], 0.2)
 
 
-def test_threshold_iterate_on_real_distances():
+def test_threshold_iterate_on_real_distances(sweep_window):
     """The --fit-model refine shape: 40 offsets over a resident distance matrix."""
     sk, _ = synth.make_sketches(3000, KMERS, cluster_size=30)
     tbl = synth.random_match_table(KMERS)
