@@ -599,7 +599,7 @@ def f_rows_leg(lib, engine, torch, synth, ref10k, dist10k, kmers, tbl, steps=10)
 
     r = timed(sweep1d, stages=True)
     assert int(n_out.item()) == n_emit
-    sort_bytes = 4 * 16.0 * n_emit      # four 8-bit radix passes over (key, row) pairs: 8 B read + 8 B written each
+    sort_bytes = 4 * 16.0 * n_emit      # four radix passes (9 + 9 + 9 + 5 bits) over (key, row) pairs: 8 B read + 8 B written each
     r.update(offsets=40, emitted=n_emit, candidates_frac=round(n_emit / n_rows, 4),
              roofline=_hbm_roof(8.0 * n_rows + 24.0 * n_emit, r["wall"]["median_ms"]),
              model="algorithmic bytes = the matrix read once (8 B/row) + 24 B per listed row; the floor beside it "
