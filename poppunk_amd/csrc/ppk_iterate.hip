@@ -181,7 +181,8 @@ __device__ __forceinline__ bool probe_rows_slope2(const float (&x)[R], const flo
 // exceeds x_max_o y_max_o (1 + 8 u) >= c_o (underflow moves either side by < 2^-148, the margin is > 2^-104) -- and
 // takes no further part.  The rest (the candidates and a fringe) are packed through LDS, 64 * kDenseRows at a time,
 // so that the n_pad evaluations per row run on full wavefronts: 17 % of the rows in the 10 000-genome sweep.
-template <int MODE, bool FILTER, typename F, bool WINDOW = false>
+// KEYS false (the 2-D sweep, which lists every candidate and has no stop): no d0, no key, no stop candidate.
+template <int MODE, bool FILTER, typename F, bool WINDOW = false, bool KEYS = true>
 __global__ void __launch_bounds__(256)
 ti1_classify_kernel(const float2 *__restrict__ dist, size_t n_rows, const Bnd *__restrict__ bnd, int n_pad,
                     int slope, Bnd filt, F *__restrict__ first, unsigned *__restrict__ cand_key, uint64_t *__restrict__ mask,
@@ -354,16 +355,18 @@ ti1_classify_kernel(const float2 *__restrict__ dist, size_t n_rows, const Bnd *_
       if (is_cand) first[slot] = (F)((unsigned)(r * 64 + lane) | (((unsigned)n_pad - cnt[r]) << kUnitRowBits));
       // a row no boundary holds: the walk ends at the first of these in (d0, row) order.  NaN distances
       // compare false everywhere and sort after everything (as they did in the reference's key order).
-      float d0;
-      if constexpr (MODE == 2) d0 = __fsub_rn(__fadd_rn(__fmul_rn(y[r], b0.xm), __fmul_rn(x[r], b0.ym)), b0.c);
-      else d0 = ppk_line_dist(x[r], y[r], b0.xm, b0.ym, slope);
-      d0 = d0 + 0.0f;      // -0.0 -> +0.0 so that the radix order equals operator<
-      const unsigned c = f2ord(d0);
-      if (is_cand) cand_key[slot] = c;
-      // rows grow within a lane: strict < keeps the earliest
-      if (in && cnt[r] == 0 && d0 == d0 && c < best_ord) {
-        best_ord = c;
-        best_rel = rel0 + (unsigned)r * 64u;
+      if constexpr (KEYS) {
+        float d0;
+        if constexpr (MODE == 2) d0 = __fsub_rn(__fadd_rn(__fmul_rn(y[r], b0.xm), __fmul_rn(x[r], b0.ym)), b0.c);
+        else d0 = ppk_line_dist(x[r], y[r], b0.xm, b0.ym, slope);
+        d0 = d0 + 0.0f;      // -0.0 -> +0.0 so that the radix order equals operator<
+        const unsigned c = f2ord(d0);
+        if (is_cand) cand_key[slot] = c;
+        // rows grow within a lane: strict < keeps the earliest
+        if (in && cnt[r] == 0 && d0 == d0 && c < best_ord) {
+          best_ord = c;
+          best_rel = rel0 + (unsigned)r * 64u;
+        }
       }
     }
     const size_t cb_next = (u + 1) / (kCbWords / kUnitWords);
@@ -899,7 +902,7 @@ int classify_mode(const std::vector<Bnd> &bnd, int slope) {
 // classify + scan, then ONE synchronisation: the candidate count sizes everything after it
 template <typename F>
 int ti_classify(int dev, hipStream_t s, const float2 *dist, size_t n_rows, const std::vector<Bnd> &bnd, int slope,
-                Classified<F> &out) {
+                Classified<F> &out, bool want_keys = true) {
   std::vector<Bnd> padded(bnd);
   while (padded.size() % 4) padded.push_back(bnd.back());
   const int n_pad = (int)padded.size();
@@ -931,6 +934,8 @@ int ti_classify(int dev, hipStream_t s, const float2 *dist, size_t n_rows, const
   const void *kfn = mode == 0   ? reinterpret_cast<const void *>(&ti1_classify_kernel<0, false, F>)
                     : mode == 1 ? reinterpret_cast<const void *>(&ti1_classify_kernel<1, false, F>)
                     : mode == 3 ? reinterpret_cast<const void *>(&ti1_classify_kernel<3, false, F>)
+                    : window && !want_keys ? reinterpret_cast<const void *>(&ti1_classify_kernel<2, true, F, true, false>)
+                    : filter && !want_keys ? reinterpret_cast<const void *>(&ti1_classify_kernel<2, true, F, false, false>)
                     : window    ? reinterpret_cast<const void *>(&ti1_classify_kernel<2, true, F, true>)
                     : filter    ? reinterpret_cast<const void *>(&ti1_classify_kernel<2, true, F>)
                                 : reinterpret_cast<const void *>(&ti1_classify_kernel<2, false, F>);
@@ -980,6 +985,8 @@ int ti_classify(int dev, hipStream_t s, const float2 *dist, size_t n_rows, const
   if (mode == 0) PPK_TI1_CLASSIFY(0, false);
   else if (mode == 1) PPK_TI1_CLASSIFY(1, false);
   else if (mode == 3) PPK_TI1_CLASSIFY(3, false);
+  else if (window && !want_keys) PPK_TI1_CLASSIFY(2, true, true, false);
+  else if (filter && !want_keys) PPK_TI1_CLASSIFY(2, true, false, false);
   else if (window) PPK_TI1_CLASSIFY(2, true, true);
   else if (filter) PPK_TI1_CLASSIFY(2, true);
   else PPK_TI1_CLASSIFY(2, false);
@@ -1227,7 +1234,7 @@ extern "C" int ppk_threshold_iterate_2d_dev(const float *d_dist, size_t n_rows, 
     auto run = [&](auto ftag) {
       typedef decltype(ftag) F;
       Classified<F> c;
-      rc1 = ti_classify<F>(dev, s, dist2, n_rows, bnd, 2, c);
+      rc1 = ti_classify<F>(dev, s, dist2, n_rows, bnd, 2, c, false);      // (no keys: every candidate is listed, nothing stops the sweep)
       if (rc1 != PPK_OK) return;
       n_cand = c.got.n_cand;
       holes = c.got.holes;
