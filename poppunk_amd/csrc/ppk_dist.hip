@@ -1935,6 +1935,9 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
           if (m == NONE) break;                        // fewer than knn pairs here: no bound from this tile
           kth = m;
           const bool pass = (uint32_t)(m >> 32) <= thr_q;    // minima ascend: the passing rounds are a prefix
+          // ... and once a minimum is above the bound no later one passes or lowers it: with settled bounds most
+          // (query, tile) pairs end here after one round instead of knn
+          if (!pass) break;
 #pragma unroll
           for (int r = 0; r < R; ++r)
             if (key[r] == m) {                         // keys are unique: one lane, one r
@@ -1958,6 +1961,13 @@ dist_kernel_v2(const uint64_t *__restrict__ refT, const uint64_t *__restrict__ q
       const uint32_t thr_r = rf2 < p.n_ref ? __hip_atomic_load(thr + rf2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
       uint32_t pass2 = 0;       // bit j: candidate j is among the k smallest of the 16 and passes the bound
       uint32_t kth2 = 0xffffffffu;
+      // a distance above the ref's bound neither passes nor changes the rank of one that does, and the knn-th smallest
+      // can only lower the bound if it is below it: a wavefront none of whose 64 x 16 distances is within its ref's
+      // bound has nothing to rank (the common case once the bounds have settled)
+      bool any_within = false;
+#pragma unroll
+      for (int a = 0; a < 16; ++a) any_within = any_within || bits2[a] <= thr_r;      // (no pair: 0xffffffff <= bound only while the bound is still open, where the ranking has to run anyway)
+      if (__ballot(any_within) != 0ull)
 #pragma unroll
       for (int a = 0; a < 16; ++a) {
         // rank of a = candidates with a smaller key; within one ref the query index orders ties, and

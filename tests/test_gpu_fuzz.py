@@ -113,3 +113,19 @@ def test_random_float_patterns_kernel2(seed):
     gi, gj, go = poppunk_refine.thresholdIterate1D_arrays(finite, offs, 2, 0.05, 0.07, 0.25, 0.3)
     wi, wj, wo = oracle.threshold_iterate_1d(finite, offs, 2, 0.05, 0.07, 0.25, 0.3)
     assert np.array_equal(gi, wi) and np.array_equal(gj, wj) and np.array_equal(go, wo)
+
+
+@pytest.mark.parametrize("seed", [3, 4])
+def test_random_boundary_sweeps(seed):
+    """tools/soak_sweeps.py's cases (thresholdIterate1D / 2D on random matrices, offsets, slopes and directions, rows
+    planted on the boundaries, with and without the classify pass's bisection) against the oracle, element for element."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "soak_sweeps", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "soak_sweeps.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    for _ in range(60):
+        desc, msgs = mod.case(rng)
+        assert not msgs, desc + ": " + "; ".join(msgs)
