@@ -791,6 +791,55 @@ extern "C" int ppk_dist_edges_dev(const ppk_db *ref, const ppk_db *qry, const in
 // -1: a mark the merge can see).
 // qry (nullable): a ref x query job -- the samples are the n_ref refs followed by the n_qry queries (sample
 // n_ref + q), every ref's neighbours are queries and every query's are refs; outputs hold (n_ref + n_qry) * knn.
+
+// A device word read back without draining the stream: a one-thread kernel copies it into a pinned block and leaves
+// the caller's ticket behind it; the host polls the ticket (a blocking synchronisation on torch's current stream
+// returned ~28 us after the work had ended: the sweeps, profiles/NOTES_r06.md section 6), for at most ~5 ms -- a piece of
+// a large neighbour job runs longer --, then waits for the stream as before.
+namespace {
+struct PinnedWord {
+  unsigned long long value, ticket;
+};
+__global__ void publish_word_kernel(const unsigned long long *__restrict__ src, PinnedWord *__restrict__ dst,
+                                    unsigned long long ticket) {
+  dst->value = *src;
+  __threadfence_system();
+  __hip_atomic_store(&dst->ticket, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+int read_device_word(int dev, const unsigned long long *d_word, unsigned long long *out, hipStream_t s) {
+  static PinnedWord *blocks[64] = {};
+  static unsigned long long tickets[64] = {};
+  PinnedWord *&b = blocks[dev & 63];      // (the caller holds the device's PpkCall)
+  if (!b) {
+    if (hipHostMalloc(reinterpret_cast<void **>(&b), 256, hipHostMallocCoherent) != hipSuccess) {
+      b = nullptr;
+      return ppk_fail(PPK_ERR_HIP, "hipHostMalloc failed");
+    }
+    memset(b, 0, 256);
+  }
+  const unsigned long long ticket = ++tickets[dev & 63];
+  hipLaunchKernelGGL(publish_word_kernel, dim3(1), dim3(1), 0, s, d_word, b, ticket);
+  PPK_HIP(hipGetLastError());
+  const volatile unsigned long long *word = &b->ticket;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spin = 0;; ++spin) {
+    if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == ticket) {
+      *out = b->value;
+      return PPK_OK;
+    }
+    if ((spin & 1023u) == 1023u) {
+      if (hipStreamQuery(s) != hipErrorNotReady) break;      // done, or failed: let the drain say which
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
+    }
+    __builtin_ia32_pause();
+  }
+  PPK_HIP(hipStreamSynchronize(s));
+  if (__atomic_load_n(word, __ATOMIC_ACQUIRE) != ticket) return ppk_fail(PPK_ERR_HIP, "the count did not arrive");
+  *out = b->value;
+  return PPK_OK;
+}
+}  // namespace
+
 int ppk_knn_band_dev(const ppk_db *db, const ppk_db *qry, const int32_t *kmers, const float *random_tbl, size_t n_clu,
                      int flags, int knn, int dist_col, size_t q_begin, size_t q_end, long long missing_j, long long *d_i,
                      long long *d_j, float *d_dist, unsigned long long *n_candidates, void *stream) {
@@ -853,9 +902,7 @@ int ppk_knn_band_dev(const ppk_db *db, const ppk_db *qry, const int32_t *kmers, 
   rc = ppk_launch_knn_state_init(d_state, n, cap, vals_off, 1, s);
   if (rc != PPK_OK) return rc;
   auto read_count = [&](unsigned long long *c) {
-    PPK_HIP(hipMemcpyAsync(c, d_state, sizeof(*c), hipMemcpyDeviceToHost, s));
-    PPK_HIP(hipStreamSynchronize(s));
-    return (int)PPK_OK;
+    return read_device_word(db->device, static_cast<const unsigned long long *>(d_state), c, s);
   };
   auto set_count = [&](unsigned long long c) {
     PPK_HIP(hipMemcpyAsync(d_state, &c, sizeof(c), hipMemcpyHostToDevice, s));
@@ -933,8 +980,25 @@ int ppk_knn_band_dev(const ppk_db *db, const ppk_db *qry, const int32_t *kmers, 
     }
     const bool opening = staged && lo == q_begin;
     const unsigned long long emitted = count - before;
+    const size_t lo_piece = lo;
     lo = hi;
-    if (emitted < (cap - (size_t)before) / 4 && cur < piece) cur = cur * 2 < piece ? cur * 2 : piece;
+    if (emitted < (cap - (size_t)before) / 4 && cur < piece) {
+      // The next piece: at least twice this one; after a piece that ran under real bounds, as many rows as -- at four
+      // times this piece's candidates per pair -- fill a quarter of the free room (the pieces of a staged job used to
+      // double one by one: six launches, each with its tail and its read-back, where three do).
+      size_t next = cur * 2;
+      if (!opening && hi > lo_piece) {
+        auto pairs_of = [&](size_t a, size_t b) {      // pairs of query rows [a, b)
+          return qry ? (double)(b - a) * (double)db->n : 0.5 * ((double)b * (double)(b - 1) - (double)a * (double)(a - 1));
+        };
+        const double rate = 4.0 * ((double)emitted + 1.0) / (pairs_of(lo_piece, hi) + 1.0);
+        const double room = 0.25 * (double)(cap - (size_t)count);
+        size_t rows = cur;
+        while (rows < piece && pairs_of(hi, hi + rows * 2 < q_end ? hi + rows * 2 : q_end) * rate < room) rows *= 2;
+        if (rows > next) next = rows;
+      }
+      cur = next < piece ? next : piece;
+    }
     // cut when the list is half full -- or, in a staged job, as soon as it holds 16 lists' worth: a cut costs a
     // sort of what is there and leaves every bound at the true k-th distance so far, after which a piece emits a
     // small fraction of what it did (1 M genomes: 300 M per 65 000 rows before the second cut, 5 M after)
