@@ -1081,8 +1081,8 @@ extern "C" int ppk_knn_candidates_dev(const ppk_db *db, const int32_t *kmers, co
                        static_cast<uint64_t *>(d_state), 2, 0.f, 0.f, 1.f, 1.f, 1, d_lut, s, knn_args, lut_ready);
   if (rc != PPK_OK) return rc;
   unsigned long long count = 0;
-  PPK_HIP(hipMemcpyAsync(&count, d_state, sizeof(count), hipMemcpyDeviceToHost, s));
-  PPK_HIP(hipStreamSynchronize(s));
+  rc = read_device_word(db->device, static_cast<const unsigned long long *>(d_state), &count, s);
+  if (rc != PPK_OK) return rc;
   *n_candidates = count;
   if (count > cap) return ppk_fail(PPK_ERR_CAPACITY, "candidate buffers too small: need " + std::to_string(count));
   return PPK_OK;
