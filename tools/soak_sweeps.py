@@ -69,7 +69,7 @@ def case(rng):
     msgs = []
     two_d = rng.random() < 0.35
     if two_d:
-        n_off = int(rng.choice([1, 2, 5, 20, 40, 126, 130]))
+        n_off = int(rng.choice([1, 2, 5, 20, 40, 61, 64, 65, 126, 130]))
         lo, hi = sorted(rng.random(2) * 0.6 + 0.01)
         x_max = np.sort((lo + (hi - lo) * rng.random(n_off))).astype(np.float32)
         if rng.random() < 0.1:
