@@ -5,14 +5,16 @@
 //    distance to the first boundary (d0) and walks that order once, emitting a row while it is
 //    within the current boundary; the walk ends for good at the first row that is within NO
 //    boundary.  Here:
-//      1. ONE streaming pass over the matrix (ti1_classify_kernel) evaluates every boundary for
-//         every row, boundaries in SGPRs, four rows per lane: c = number of boundaries that hold
-//         the row.  Rows with c > 0 are the candidates: one mask bit, and one byte f = n_off - c
-//         (their first boundary, when "within" is monotone in the offset).  Rows with c = 0 can
+//      1. ONE streaming pass over the matrix (ti1_classify_kernel), eight rows per lane: c = the number of
+//         boundaries that hold the row -- rows outside the outermost boundary by a margin leave after three
+//         operations (FILTER), for the rest c comes from a bisection over the nested boundaries (WINDOW) or,
+//         failing that, from evaluating every boundary.  Rows with c > 0 are the candidates: one mask bit, and per
+//         unit of 512 rows their key ord(d0) and (row in the unit | f << 9), f = n_off - c (their first boundary,
+//         when "within" is monotone in the offset), packed to the front of the unit's slots.  Rows with c = 0 can
 //         only END the walk: the pass keeps the smallest (d0, row) among them, the stop.
-//      2. the candidates alone -- the rows the reference can emit -- are compacted in row order
-//         with their key ord(d0) and value row | f << row_bits, and radix-sorted by key (stable,
-//         so equal distances keep row order like the reference's parallel_stable_sort);
+//      2. the candidates alone -- the rows the reference can emit -- are copied end to end in row order
+//         (ti1_expand_kernel; the matrix is not read again) as key ord(d0) and value row | f << row_bits, and
+//         radix-sorted by key (stable, so equal distances keep row order like the reference's parallel_stable_sort);
 //      3. sorted position p is emitted iff (key, row) < stop, with offset index
 //         max(f(0..p)): the walk of offset o stops at the first position with f > o, so the
 //         offset a position leaves with is the running maximum of f (ti1_blockmax / ti1_emit).
@@ -22,9 +24,13 @@
 //    The result equals the reference's (i, j, offset) vectors element for element, without
 //    sorting the rows that are never emitted, and without the reference's read past the end of
 //    boundary_order (boundary.cpp:206).
-//  - ppk_threshold_iterate_2d_dev : src/boundary.cpp:212-237 (threshold_iterate_2D): one pass
+//  - ppk_threshold_iterate_2d_dev : src/boundary.cpp:212-237 (threshold_iterate_2D): the same classify pass
+//    (without keys); when no row is within a boundary and outside a later one every listed row is listed once, at f,
+//    and the reference's offset-major / row-minor order is the candidates stably sorted by f.  Otherwise one pass
 //    builds a ballot bitmask per offset (within boundary o and not within o-1), then the shared
-//    stable compaction emits (i, j, o) offset-major / row-minor like the reference's loops.
+//    stable compaction emits (i, j, o) like the reference's loops.
+//  The call's one synchronisation (the candidate count sizes the sort) is a ticket the scan kernel leaves in a pinned
+//  block and the host polls (wait_for_ticket).
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -142,16 +148,41 @@ constexpr int kDenseRows = 2;      // rows per lane of one dense batch of the fi
 // neither (the row lies within 2^-20 of that boundary, relatively), a negative or a NaN coordinate: the lane reports
 // it and the wavefront takes the full evaluation above.  bit-length(n_pad) probes of ~12 instructions per row against
 // n_pad evaluations of 5.
+// GUESS (gp.pad > 0: the boundaries are parallel and evenly spaced -- a sweep over a linspace of offsets): boundary o
+// holds the row iff x + g y <= x_max_o up to rounding, so the first one that does is about
+// ceil((x + g y - x_max_0) / spacing): that index is TESTED "safely within" and the one before it "safely outside"; if
+// both hold the verdicts are known after two probes, otherwise (a row within 2^-20 of a boundary, a guess off by one)
+// the wavefront runs the bisection.  gp = (g, x_max_0, 1 / spacing, flag).
 template <int R>
 __device__ __forceinline__ bool probe_rows_slope2(const float (&x)[R], const float (&y)[R],
-                                                  const float4 *__restrict__ sw, int n_pad, int steps, unsigned (&cnt)[R]) {
+                                                  const float4 *__restrict__ sw, int n_pad, int steps, const Bnd gp,
+                                                  unsigned (&cnt)[R]) {
   int L[R], H[R];
   bool ok[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) ok[r] = x[r] >= 0.0f && y[r] >= 0.0f;      // (false for a NaN)
+  if (gp.pad > 0.0f) {      // (wave-uniform)
+    bool sure = true;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float t = ceilf((x[r] + gp.xm * y[r] - gp.ym) * gp.c);
+      int h = t >= (float)n_pad ? n_pad : (t > 0.0f ? (int)t : 0);      // (NaN: 0, and ok[r] is false)
+      const float4 Bh = sw[h < n_pad ? h : 0], Bl = sw[h > 0 ? h - 1 : 0];
+      const float ah = __fadd_rn(__fmul_rn(y[r], Bh.x), __fmul_rn(x[r], Bh.y));
+      const float al = __fadd_rn(__fmul_rn(y[r], Bl.x), __fmul_rn(x[r], Bl.y));
+      sure = sure && ok[r] && (h == n_pad || ah < Bh.z) && (h == 0 || al > Bl.w);
+      H[r] = h;
+    }
+    if (__ballot(!sure) == 0ull) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) cnt[r] = (unsigned)(n_pad - H[r]);
+      return false;
+    }
+  }
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     L[r] = -1;
     H[r] = n_pad;
-    ok[r] = x[r] >= 0.0f && y[r] >= 0.0f;      // (false for a NaN)
   }
   for (int it = 0; it < steps; ++it) {
 #pragma unroll
@@ -185,8 +216,8 @@ __device__ __forceinline__ bool probe_rows_slope2(const float (&x)[R], const flo
 template <int MODE, bool FILTER, typename F, bool WINDOW = false, bool KEYS = true>
 __global__ void __launch_bounds__(256)
 ti1_classify_kernel(const float2 *__restrict__ dist, size_t n_rows, const Bnd *__restrict__ bnd, int n_pad,
-                    int slope, Bnd filt, F *__restrict__ first, unsigned *__restrict__ cand_key, uint64_t *__restrict__ mask,
-                    size_t n_words,
+                    int slope, Bnd filt, Bnd guess, F *__restrict__ first, unsigned *__restrict__ cand_key,
+                    uint64_t *__restrict__ mask, size_t n_words,
                     unsigned long long *__restrict__ block_sums, ulonglong2 *__restrict__ stops,
                     Ctrl *__restrict__ ctrl) {
   static_assert(!FILTER || MODE == 2, "the filter is a slope-2 argument");
@@ -289,7 +320,7 @@ ti1_classify_kernel(const float2 *__restrict__ dist, size_t n_rows, const Bnd *_
             dy[q] = v.y;
           }
           bool full_eval = true;
-          if constexpr (WINDOW) full_eval = __ballot(probe_rows_slope2<kDenseRows>(dx, dy, sw, n_pad, steps, dc)) != 0ull;
+          if constexpr (WINDOW) full_eval = __ballot(probe_rows_slope2<kDenseRows>(dx, dy, sw, n_pad, steps, guess, dc)) != 0ull;
           if (full_eval) {      // (wave-uniform)
             const unsigned hb = eval_rows_slope2<kDenseRows>(dx, dy, sb, n_pad, dc);
             hole |= __ballot(hb != 0u);
@@ -928,6 +959,17 @@ int ti_classify(int dev, hipStream_t s, const float2 *dist, size_t n_rows, const
   for (size_t o = 1; o < bnd.size() && window; ++o)
     window = bnd[o].xm >= bnd[o - 1].xm && bnd[o].ym >= bnd[o - 1].ym;
   if (window && ppk_sweep_window_off()) window = false;
+  // the guess: parallel, evenly spaced boundaries (x_max / y_max one ratio, x_max linear in the offset's index)
+  Bnd guess = {};
+  if (window && want_keys && bnd.size() >= 3) {
+    const double g = (double)bnd[0].xm / (double)bnd[0].ym;
+    const double step = ((double)bnd.back().xm - (double)bnd[0].xm) / (double)(bnd.size() - 1);
+    bool even = step > 0.0 && std::isfinite(g) && std::isfinite(1.0 / step);
+    for (size_t o = 0; o < bnd.size() && even; ++o)
+      even = std::fabs((double)bnd[o].xm - ((double)bnd[0].xm + step * (double)o)) <= 1e-3 * step &&
+             std::fabs((double)bnd[o].xm / (double)bnd[o].ym - g) <= 1e-4 * g;
+    if (even) guess = Bnd{(float)g, bnd[0].xm, (float)(1.0 / step), 1.0f};
+  }
   size_t lds = 0;
   if (mode == 2) lds = ((size_t)n_pad + 1 + (window ? (size_t)n_pad : 0)) * sizeof(float4);
   if (filter) lds += 4 * ((size_t)kUnitWords * 64 + 64) * (sizeof(float2) + sizeof(unsigned));
@@ -981,7 +1023,7 @@ int ti_classify(int dev, hipStream_t s, const float2 *dist, size_t n_rows, const
   PPK_HIP(hipMemsetAsync(block_sums, 0, n_cblocks * 8, s));
 #define PPK_TI1_CLASSIFY(M, FL, ...)                                                                                \
   hipLaunchKernelGGL((ti1_classify_kernel<M, FL, F, ##__VA_ARGS__>), dim3(grid), dim3(256), lds, s, dist, n_rows, d_bnd, n_pad, slope, \
-                     filt, first, cand_key, mask, n_words, block_sums, stops, ctrl)
+                     filt, guess, first, cand_key, mask, n_words, block_sums, stops, ctrl)
   if (mode == 0) PPK_TI1_CLASSIFY(0, false);
   else if (mode == 1) PPK_TI1_CLASSIFY(1, false);
   else if (mode == 3) PPK_TI1_CLASSIFY(3, false);
