@@ -283,6 +283,12 @@ int ppk_qc_edges_dev(const float *d_dist, size_t n_rows, size_t n_ref, int mode,
  * (the intermediate candidate count sizes a sort).  At most 1023 offsets per call (the
  * reference's callers pass 40 and 20; its loops have no limit).
  */
+/* Which form of the sweeps' classify pass a list of boundaries (x_max[o], y_max[o]) takes; no device is touched (the
+ * unit test of that choice, tests/test_host_logic.py).  out = {mode (0 / 1: slope 0 / 1, 2: fast slope 2, 3: the
+ * reference's line_dist as it stands), early-exit filter, bisection over nested boundaries, guessed end indices (evenly
+ * spaced parallel boundaries, the 1-D sweep only: one_d != 0)}. */
+int ppk_sweep_plan(const float *x_max, const float *y_max, size_t n_off, int slope, int one_d, int out[4]);
+
 /* replaces poppunk_refine.thresholdIterate1D (src/python_bindings.cpp:49-60;
  * src/boundary.cpp:154-210; caller PopPUNK/refine.py:190-200).  `offsets`
  * (host, sorted ascending) are distances along the line (x0,y0)->(x1,y1). */

@@ -87,6 +87,7 @@ SIGNATURES = {
     "ppk_choose_route": (C.c_int, [C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                    C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "ppk_sweep_plan": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "ppk_prof_stages_enable": (C.c_int, [C.c_int]),
     "ppk_prof_stages_read": (C.c_int, [C.c_char_p, C.c_size_t, C.c_int]),
     "ppk_last_kernel_name": (C.c_char_p, []),

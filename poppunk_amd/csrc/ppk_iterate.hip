@@ -930,6 +930,49 @@ int classify_mode(const std::vector<Bnd> &bnd, int slope) {
   return 2;
 }
 
+// Which form of the classify pass a list of boundaries takes -- a pure function of the boundaries (ppk_sweep_plan
+// exposes it; tests/test_host_logic.py pins it without a device):
+//   mode    0 / 1: slope 0 / 1; 2: the fast slope-2 form; 3: ppk_line_dist as it stands (a boundary on an axis, ...)
+//   filter  one boundary contains all the others, nothing tiny: rows outside it by a margin leave early
+//   window  ... and the boundaries are nested outwards in their order: a row's count by bisection
+//   guess   ... and they are parallel and evenly spaced (1-D sweeps only): the bisection's end indices guessed and tested
+struct SweepPlan {
+  int mode = 0;
+  bool filter = false, window = false;
+  Bnd filt = {}, guess = {};      // guess.pad > 0: in effect
+};
+SweepPlan sweep_plan(const std::vector<Bnd> &bnd, int slope, bool want_keys, bool allow_window) {
+  SweepPlan p;
+  p.mode = classify_mode(bnd, slope);
+  // the filter: one boundary that contains all the others (the last of an outward sweep), nothing tiny
+  p.filter = p.mode == 2;
+  if (p.filter) {
+    size_t L = 0;
+    for (size_t o = 1; o < bnd.size(); ++o)
+      if (bnd[o].xm > bnd[L].xm) L = o;
+    const float tiny = 9.094947e-13f;      // 2^-40
+    for (const Bnd &b : bnd) p.filter = p.filter && b.xm <= bnd[L].xm && b.ym <= bnd[L].ym && b.xm >= tiny && b.ym >= tiny;
+    volatile float t = bnd[L].c * 1.00000095367431640625f;      // c_L (1 + 2^-20), rounded once
+    p.filt = Bnd{bnd[L].xm, bnd[L].ym, t, 0.0f};
+    p.filter = p.filter && std::isfinite(p.filt.c);
+  }
+  // the bisection: boundaries nested outwards (see probe_rows_slope2)
+  p.window = p.filter && allow_window;
+  for (size_t o = 1; o < bnd.size() && p.window; ++o)
+    p.window = bnd[o].xm >= bnd[o - 1].xm && bnd[o].ym >= bnd[o - 1].ym;
+  // the guess: parallel, evenly spaced boundaries (x_max / y_max one ratio, x_max linear in the offset's index)
+  if (p.window && want_keys && bnd.size() >= 3) {
+    const double g = (double)bnd[0].xm / (double)bnd[0].ym;
+    const double step = ((double)bnd.back().xm - (double)bnd[0].xm) / (double)(bnd.size() - 1);
+    bool even = step > 0.0 && std::isfinite(g) && std::isfinite(1.0 / step);
+    for (size_t o = 0; o < bnd.size() && even; ++o)
+      even = std::fabs((double)bnd[o].xm - ((double)bnd[0].xm + step * (double)o)) <= 1e-3 * step &&
+             std::fabs((double)bnd[o].xm / (double)bnd[o].ym - g) <= 1e-4 * g;
+    if (even) p.guess = Bnd{(float)g, bnd[0].xm, (float)(1.0 / step), 1.0f};
+  }
+  return p;
+}
+
 // classify + scan, then ONE synchronisation: the candidate count sizes everything after it
 template <typename F>
 int ti_classify(int dev, hipStream_t s, const float2 *dist, size_t n_rows, const std::vector<Bnd> &bnd, int slope,
@@ -940,36 +983,10 @@ int ti_classify(int dev, hipStream_t s, const float2 *dist, size_t n_rows, const
   const size_t n_words = ppk_mask_words_linear(n_rows);
   const size_t n_cblocks = (n_words + kCbWords - 1) / kCbWords;
   const size_t n_units = (n_words + kUnitWords - 1) / kUnitWords;
-  const int mode = classify_mode(bnd, slope);
-  // the filter: one boundary that contains all the others (the last of an outward sweep), nothing tiny
-  Bnd filt = {};
-  bool filter = mode == 2;
-  if (filter) {
-    size_t L = 0;
-    for (size_t o = 1; o < bnd.size(); ++o)
-      if (bnd[o].xm > bnd[L].xm) L = o;
-    const float tiny = 9.094947e-13f;      // 2^-40
-    for (const Bnd &b : bnd) filter = filter && b.xm <= bnd[L].xm && b.ym <= bnd[L].ym && b.xm >= tiny && b.ym >= tiny;
-    volatile float t = bnd[L].c * 1.00000095367431640625f;      // c_L (1 + 2^-20), rounded once
-    filt = Bnd{bnd[L].xm, bnd[L].ym, t, 0.0f};
-    filter = filter && std::isfinite(filt.c);
-  }
-  // the bisection: boundaries nested outwards (see probe_rows_slope2); experiments may switch it off
-  bool window = filter;
-  for (size_t o = 1; o < bnd.size() && window; ++o)
-    window = bnd[o].xm >= bnd[o - 1].xm && bnd[o].ym >= bnd[o - 1].ym;
-  if (window && ppk_sweep_window_off()) window = false;
-  // the guess: parallel, evenly spaced boundaries (x_max / y_max one ratio, x_max linear in the offset's index)
-  Bnd guess = {};
-  if (window && want_keys && bnd.size() >= 3) {
-    const double g = (double)bnd[0].xm / (double)bnd[0].ym;
-    const double step = ((double)bnd.back().xm - (double)bnd[0].xm) / (double)(bnd.size() - 1);
-    bool even = step > 0.0 && std::isfinite(g) && std::isfinite(1.0 / step);
-    for (size_t o = 0; o < bnd.size() && even; ++o)
-      even = std::fabs((double)bnd[o].xm - ((double)bnd[0].xm + step * (double)o)) <= 1e-3 * step &&
-             std::fabs((double)bnd[o].xm / (double)bnd[o].ym - g) <= 1e-4 * g;
-    if (even) guess = Bnd{(float)g, bnd[0].xm, (float)(1.0 / step), 1.0f};
-  }
+  const SweepPlan plan = sweep_plan(bnd, slope, want_keys, !ppk_sweep_window_off());
+  const int mode = plan.mode;
+  const bool filter = plan.filter, window = plan.window;
+  const Bnd filt = plan.filt, guess = plan.guess;
   size_t lds = 0;
   if (mode == 2) lds = ((size_t)n_pad + 1 + (window ? (size_t)n_pad : 0)) * sizeof(float4);
   if (filter) lds += 4 * ((size_t)kUnitWords * 64 + 64) * (sizeof(float2) + sizeof(unsigned));
@@ -1180,6 +1197,22 @@ int ti2_after_count(int dev, hipStream_t s, size_t n_rows, const Classified<F> &
 
 }  // namespace
 
+
+extern "C" int ppk_sweep_plan(const float *x_max, const float *y_max, size_t n_off, int slope, int one_d, int out[4]) {
+  if (!x_max || !y_max || !out || n_off == 0) return ppk_fail(PPK_ERR_ARG, "ppk_sweep_plan: null argument / no boundary");
+  if (slope < 0 || slope > 2) return ppk_fail(PPK_ERR_ARG, "slope must be 0, 1 or 2");
+  std::vector<Bnd> bnd(n_off);
+  for (size_t o = 0; o < n_off; ++o) {
+    volatile float prod = x_max[o] * y_max[o];
+    bnd[o] = Bnd{x_max[o], y_max[o], prod, 0.0f};
+  }
+  const SweepPlan p = sweep_plan(bnd, slope, one_d != 0, true);
+  out[0] = p.mode;
+  out[1] = p.filter ? 1 : 0;
+  out[2] = p.window ? 1 : 0;
+  out[3] = p.guess.pad > 0.0f ? 1 : 0;
+  return PPK_OK;
+}
 
 extern "C" int ppk_threshold_iterate_1d_dev(const float *d_dist, size_t n_rows,
                                             const double *offsets, size_t n_off, int slope,

@@ -465,3 +465,44 @@ def test_sweep_filter_rounding_argument_holds_on_float32():
         # the same boundary itself
         assert not np.any((aL <= cL) & dropped)
     assert worst > 100000      # (the filter did drop rows in these trials: the check is not vacuous)
+
+
+def _sweep_plan(x_max, y_max, slope=2, one_d=True):
+    import ctypes as C
+    from poppunk_amd import _lib
+    xm = np.ascontiguousarray(x_max, dtype=np.float32)
+    ym = np.ascontiguousarray(np.broadcast_to(np.asarray(y_max, dtype=np.float32), xm.shape))
+    out = (C.c_int * 4)()
+    rc = _lib.lib().ppk_sweep_plan(xm.ctypes.data_as(C.POINTER(C.c_float)), ym.ctypes.data_as(C.POINTER(C.c_float)), xm.size,
+                                   slope, 1 if one_d else 0, out)
+    assert rc == 0
+    return tuple(out)      # (mode, filter, window, guess)
+
+
+def test_sweep_plan_is_a_pure_function_of_the_boundaries():
+    """ppk_sweep_plan (ppk_iterate.hip): which form of the sweeps' classify pass a list of boundaries takes -- the early
+    exit (one boundary contains the rest), the bisection (nested outwards in order), the guessed end indices (parallel,
+    evenly spaced; the 1-D sweep only) -- decided on the host from the boundaries alone."""
+    g = 1.12
+    xm = np.linspace(0.117, 0.9, 40)
+    # refine's outward sweep over a linspace of offsets: everything on
+    assert _sweep_plan(xm, xm / g) == (2, 1, 1, 1)
+    # the 2-D sweep (one y_max, x_max ascending): nested, not parallel, and no keys -> no guess
+    assert _sweep_plan(xm, 0.3, one_d=False) == (2, 1, 1, 0)
+    assert _sweep_plan(xm, 0.3, one_d=True) == (2, 1, 1, 0)
+    # unevenly spaced offsets: bisection without the guess
+    un = np.sort(np.concatenate([xm[:20], xm[20:] ** 1.3]))
+    assert _sweep_plan(un, un / g) == (2, 1, 1, 0)
+    # an inward sweep: the first boundary contains the rest (filter), the order is not outwards (no bisection)
+    assert _sweep_plan(xm[::-1], xm[::-1] / g) == (2, 1, 0, 0)
+    # boundaries that cross (x_max grows, y_max shrinks): no boundary contains the others
+    assert _sweep_plan(xm, (xm / g)[::-1]) == (2, 0, 0, 0)
+    # a boundary on an axis, a tiny one, an infinite one: the reference's line_dist as it stands / no margin argument
+    assert _sweep_plan([0.0, 0.2, 0.3], [0.1, 0.2, 0.3])[0] == 3
+    assert _sweep_plan([1e-13, 0.2, 0.3], [1e-13, 0.2, 0.3]) == (2, 0, 0, 0)
+    assert _sweep_plan([0.1, 0.2, np.inf], [0.1, 0.2, 0.3])[0] == 3
+    # slopes 0 and 1 compare one coordinate: none of this applies
+    assert _sweep_plan(xm, xm / g, slope=0) == (0, 0, 0, 0)
+    assert _sweep_plan(xm, xm / g, slope=1) == (1, 0, 0, 0)
+    # two boundaries: too few for a spacing
+    assert _sweep_plan(xm[:2], xm[:2] / g) == (2, 1, 1, 0)
