@@ -889,6 +889,14 @@ Ctrl *pinned_ctrl(int dev) {
   return blocks[dev];
 }
 
+// The tickets of a device's calls: ONE counter per device for every instantiation of ti_classify (a counter of its own
+// per instantiation could hand out a number the pinned word still holds from the other one's last call, and the wait
+// below would return before the scan kernel had run).  The caller holds the device's PpkCall: one call at a time.
+unsigned long long next_ticket(int dev) {
+  static unsigned long long tickets[64] = {};
+  return ++tickets[dev & 63];
+}
+
 // Waits for the scan kernel's ticket in the pinned block (the word behind the control block), polling for up to about
 // 2 ms -- the classify pass of a 10 000-genome matrix takes 0.25 ms --, then, or when the stream reports an error,
 // by draining the stream.
@@ -1051,8 +1059,7 @@ int ti_classify(int dev, hipStream_t s, const float2 *dist, size_t n_rows, const
   else PPK_TI1_CLASSIFY(2, false);
 #undef PPK_TI1_CLASSIFY
   ppk_prof_stage("scan", s);
-  static unsigned long long tickets[64] = {};
-  const unsigned long long ticket = ++tickets[dev & 63];      // (the caller holds the device's PpkCall: one call at a time)
+  const unsigned long long ticket = next_ticket(dev);
   hipLaunchKernelGGL(ti1_scan_kernel, dim3(1), dim3(1024), 0, s, block_sums, n_cblocks, stops, n_stops, ctrl, h_ctrl, ticket);
   ppk_prof_stage(nullptr, s);
   PPK_HIP(hipGetLastError());

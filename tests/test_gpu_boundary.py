@@ -244,6 +244,32 @@ def test_threshold_iterate_rows_on_and_beside_nested_boundaries(sweep_window):
     assert np.array_equal(gi, wi) and np.array_equal(gj, wj) and np.array_equal(go, wo)
 
 
+def test_sweep_tickets_are_one_sequence_per_device():
+    """The host waits for the sweep's scan kernel by polling a ticket in pinned memory.  The first sweep of a process
+    with <= 124 offsets (16-bit packed words) followed by the first with more (32-bit words) are two instantiations of
+    the same host code: with a ticket counter each, the second call would wait for a number the pinned word already
+    holds and read the control block before its kernel had run.  A fresh process, exactly that order."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+from poppunk_amd import poppunk_refine
+from oracle import oracle
+rng = np.random.Generator(np.random.PCG64(5))
+n = 1500
+d = (rng.random((n * (n - 1) // 2, 2)) * 0.6).astype(np.float32)
+for n_off in (12, 130, 12, 130):
+    off = np.linspace(0.0, 0.4, n_off)
+    got = poppunk_refine.thresholdIterate1D_arrays(d, off, 2, 0.05, 0.06, 0.3, 0.34)
+    want = oracle.threshold_iterate_1d(d, off, 2, 0.05, 0.06, 0.3, 0.34)
+    assert len(want[0]) > 100000 and all(np.array_equal(g, w) for g, w in zip(got, want)), n_off
+print("ok")
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("slope", [0, 1, 2])
 @pytest.mark.parametrize("samples", [3, 100, 700])
 def test_threshold_iterate_1d(samples, slope, sweep_window):
