@@ -81,6 +81,16 @@ int bench(size_t n, int end_bit, int dist_kind) {
   CK(hipMemcpy(vin, v.data(), n * sizeof(V), hipMemcpyHostToDevice));
   printf("n = %zu, end_bit = %d, value bytes = %zu, keys kind %d\n", n, end_bit, sizeof(V), dist_kind);
   run_rocprim<8, 1024, 16, 1024, 8, V>("rocPRIM onesweep 8 bits 1024x16 / 1024x8", kin, kout, vin, vout, n, end_bit);
+#ifdef ROCPRIM_CONFIGS      // the 9-bit digits the sweeps use, other tile shapes
+  run_rocprim<9, 1024, 16, 1024, 8, V>("rocPRIM 9 bits 1024x16 / 1024x8 (the sweeps')", kin, kout, vin, vout, n, end_bit);
+  run_rocprim<9, 1024, 16, 1024, 6, V>("rocPRIM 9 bits 1024x16 / 1024x6", kin, kout, vin, vout, n, end_bit);
+  run_rocprim<9, 1024, 16, 1024, 10, V>("rocPRIM 9 bits 1024x16 / 1024x10", kin, kout, vin, vout, n, end_bit);
+  run_rocprim<9, 1024, 16, 1024, 12, V>("rocPRIM 9 bits 1024x16 / 1024x12", kin, kout, vin, vout, n, end_bit);
+  run_rocprim<9, 1024, 16, 512, 16, V>("rocPRIM 9 bits 1024x16 / 512x16", kin, kout, vin, vout, n, end_bit);
+  run_rocprim<9, 1024, 16, 512, 12, V>("rocPRIM 9 bits 1024x16 / 512x12", kin, kout, vin, vout, n, end_bit);
+  run_rocprim<9, 512, 16, 1024, 8, V>("rocPRIM 9 bits 512x16 / 1024x8", kin, kout, vin, vout, n, end_bit);
+  run_rocprim<9, 1024, 8, 1024, 8, V>("rocPRIM 9 bits 1024x8 / 1024x8", kin, kout, vin, vout, n, end_bit);
+#endif
 
   // hand-written
   const size_t cap = n + n / 4 + 1000;      // the launch is sized for more than there is, as in the sweeps
