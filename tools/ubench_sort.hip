@@ -81,6 +81,57 @@ int bench(size_t n, int end_bit, int dist_kind) {
   CK(hipMemcpy(vin, v.data(), n * sizeof(V), hipMemcpyHostToDevice));
   printf("n = %zu, end_bit = %d, value bytes = %zu, keys kind %d\n", n, end_bit, sizeof(V), dist_kind);
   run_rocprim<8, 1024, 16, 1024, 8, V>("rocPRIM onesweep 8 bits 1024x16 / 1024x8", kin, kout, vin, vout, n, end_bit);
+#ifdef ROCPRIM_KEYS64      // the pair as ONE 64-bit key (key << 32 | value), sorted by its upper half
+  if (sizeof(V) == 4) {
+    unsigned long long *a = nullptr, *b = nullptr;
+    CK(hipMalloc(&a, n * 8 + 64));
+    CK(hipMalloc(&b, n * 8 + 64));
+    std::vector<unsigned long long> kk(n);
+    for (size_t i = 0; i < n; i++) kk[i] = ((unsigned long long)k[i] << 32) | (unsigned long long)v[i];
+    CK(hipMemcpy(a, kk.data(), n * 8, hipMemcpyHostToDevice));
+    typedef rocprim::radix_sort_config<
+        rocprim::default_config, rocprim::default_config,
+        rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 16>, rocprim::kernel_config<1024, 8>, 9,
+                                            rocprim::block_radix_rank_algorithm::match>,
+        0>
+        Cfg;
+    size_t tb = 0;
+    void *tmp = nullptr;
+    CK(rocprim::radix_sort_keys<Cfg>(nullptr, tb, a, b, n, 32u, 64u, 0));
+    CK(hipMalloc(&tmp, tb));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    float best = 1e9;
+    for (int it = 0; it < 8; it++) {
+      CK(hipEventRecord(e0, 0));
+      CK(rocprim::radix_sort_keys<Cfg>(tmp, tb, a, b, n, 32u, 64u, 0));
+      CK(hipEventRecord(e1, 0));
+      CK(hipEventSynchronize(e1));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      best = std::min(best, ms);
+    }
+    printf("%-44s %8.1f us\n", "rocPRIM 9 bits, ONE 64-bit key per pair", best * 1000);
+    typedef rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0> Def;
+    best = 1e9;
+    size_t tb2 = 0;
+    CK(rocprim::radix_sort_keys<Def>(nullptr, tb2, a, b, n, 32u, 64u, 0));
+    void *tmp2 = nullptr;
+    CK(hipMalloc(&tmp2, tb2));
+    for (int it = 0; it < 8; it++) {
+      CK(hipEventRecord(e0, 0));
+      CK(rocprim::radix_sort_keys<Def>(tmp2, tb2, a, b, n, 32u, 64u, 0));
+      CK(hipEventRecord(e1, 0));
+      CK(hipEventSynchronize(e1));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      best = std::min(best, ms);
+    }
+    printf("%-44s %8.1f us\n", "rocPRIM default config, ONE 64-bit key", best * 1000);
+    CK(hipFree(a)); CK(hipFree(b)); CK(hipFree(tmp)); CK(hipFree(tmp2));
+  }
+#endif
 #ifdef ROCPRIM_CONFIGS      // the 9-bit digits the sweeps use, other tile shapes
   run_rocprim<9, 1024, 16, 1024, 8, V>("rocPRIM 9 bits 1024x16 / 1024x8 (the sweeps')", kin, kout, vin, vout, n, end_bit);
   run_rocprim<9, 1024, 16, 1024, 6, V>("rocPRIM 9 bits 1024x16 / 1024x6", kin, kout, vin, vout, n, end_bit);
