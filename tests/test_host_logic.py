@@ -467,6 +467,73 @@ def test_sweep_filter_rounding_argument_holds_on_float32():
     assert worst > 100000      # (the filter did drop rows in these trials: the check is not vacuous)
 
 
+def test_sweep_bisection_rounding_arguments_hold_on_float32():
+    """The bisection of the sweeps' classify pass (ppk_iterate.hip, probe_rows_slope2) rests on two claims about
+    a_o = fl(fl(y x_o) + fl(x y_o)) for x, y >= 0 and boundaries nested outwards (x_o, y_o non-decreasing, >= 2^-40):
+      a_o < fl(c_o (1 - 2^-20))  =>  the row is WITHIN every boundary o' around o:  a_o' <= c_o' = fl(x_o' y_o');
+      a_o > fl(c_o (1 + 2^-20))  =>  the row is OUTSIDE every boundary o' inside o:  a_o' >  c_o'
+    (the second is the filter's argument with L = o).  Numpy float32 is the same un-fused IEEE arithmetic: rows placed
+    within a few 2^-20 of boundary o, either side, across magnitudes, against 16 boundaries around it and 16 inside it."""
+    rng = np.random.Generator(np.random.PCG64(20260930))
+    f32 = np.float32
+    n_in = n_out = 0
+    for trial in range(40):
+        mag = f32(2.0) ** f32(rng.integers(-30, 25))
+        xo = f32(mag * f32(rng.uniform(0.5, 2.0)))
+        yo = f32(xo * f32(2.0) ** f32(rng.integers(-6, 7)) * f32(rng.uniform(0.5, 2.0)))
+        if not (np.isfinite(xo * yo) and xo >= f32(2.0) ** -40 and yo >= f32(2.0) ** -40):
+            continue
+        co = f32(xo * yo)
+        lo, hi = f32(co * f32(0.99999904632568359375)), f32(co * f32(1.00000095367431640625))
+        n = 400000
+        t = rng.random(n).astype(np.float64)
+        e = np.concatenate([rng.uniform(-2.0 ** -18, 2.0 ** -18, n - n // 10), rng.uniform(-0.9, 2.0, n // 10)])
+        x = (t * (1.0 + e) * float(xo)).astype(f32)
+        y = ((1.0 - t) * (1.0 + e) * float(yo)).astype(f32)
+        x[:50] = 0
+        y[50:100] = 0
+        a = (y * xo).astype(f32) + (x * yo).astype(f32)
+        safely_in, safely_out = a < lo, a > hi
+        n_in += int(safely_in.sum())
+        n_out += int(safely_out.sum())
+        # the boundary itself
+        assert np.all(a[safely_in] <= co) and np.all(a[safely_out] > co)
+        for _ in range(16):      # boundaries AROUND o (also barely around it: factors down to 1 + 2^-23)
+            fx = 1.0 + 2.0 ** rng.uniform(-23, 3)
+            fy = 1.0 + 2.0 ** rng.uniform(-23, 3)
+            x2, y2 = f32(float(xo) * fx), f32(float(yo) * fy)
+            if not (x2 >= xo and y2 >= yo and np.isfinite(x2 * y2)):
+                continue
+            a2 = (y * x2).astype(f32) + (x * y2).astype(f32)
+            assert np.all(a2[safely_in] <= f32(x2 * y2)), (trial, float(xo), float(yo), float(x2), float(y2))
+        for _ in range(16):      # boundaries INSIDE o
+            x1 = f32(max(float(xo) * (1.0 - 2.0 ** rng.uniform(-23, -0.01)), 2.0 ** -40))
+            y1 = f32(max(float(yo) * (1.0 - 2.0 ** rng.uniform(-23, -0.01)), 2.0 ** -40))
+            if not (x1 <= xo and y1 <= yo):
+                continue
+            a1 = (y * x1).astype(f32) + (x * y1).astype(f32)
+            assert np.all(a1[safely_out] > f32(x1 * y1)), (trial, float(xo), float(yo), float(x1), float(y1))
+    assert n_in > 1000000 and n_out > 1000000      # (not vacuous)
+    # ... and the margin is what carries them: with none (a_o <= c_o / a_o > c_o taken as "safely"), rounding does flip
+    # verdicts between boundaries that lie within 2^-18 of one another
+    flips = 0
+    for trial in range(10):
+        xo = f32(rng.uniform(0.05, 0.9))
+        yo = f32(float(xo) * rng.uniform(0.3, 3.0))
+        co = f32(xo * yo)
+        n = 400000
+        t = rng.random(n).astype(np.float64)
+        e = rng.uniform(-2.0 ** -22, 2.0 ** -22, n)
+        x = (t * (1.0 + e) * float(xo)).astype(f32)
+        y = ((1.0 - t) * (1.0 + e) * float(yo)).astype(f32)
+        a = (y * xo).astype(f32) + (x * yo).astype(f32)
+        for _ in range(8):
+            x2, y2 = f32(float(xo) * (1.0 + 2.0 ** rng.uniform(-23, -18))), f32(float(yo) * (1.0 + 2.0 ** rng.uniform(-23, -18)))
+            a2 = (y * x2).astype(f32) + (x * y2).astype(f32)
+            flips += int(np.sum(a2[a <= co] > f32(x2 * y2)))
+    assert flips > 0
+
+
 def _sweep_plan(x_max, y_max, slope=2, one_d=True):
     import ctypes as C
     from poppunk_amd import _lib
