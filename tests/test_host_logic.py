@@ -517,20 +517,27 @@ def test_sweep_bisection_rounding_arguments_hold_on_float32():
     # ... and the margin is what carries them: with none (a_o <= c_o / a_o > c_o taken as "safely"), rounding does flip
     # verdicts between boundaries that lie within 2^-18 of one another
     flips = 0
-    for trial in range(10):
-        xo = f32(rng.uniform(0.05, 0.9))
-        yo = f32(float(xo) * rng.uniform(0.3, 3.0))
+    rng2 = np.random.Generator(np.random.PCG64(1))
+    for trial in range(40):
+        mag = f32(2.0) ** f32(rng2.integers(-30, 25))
+        xo = f32(mag * f32(rng2.uniform(0.5, 2.0)))
+        yo = f32(xo * f32(2.0) ** f32(rng2.integers(-6, 7)) * f32(rng2.uniform(0.5, 2.0)))
         co = f32(xo * yo)
         n = 400000
-        t = rng.random(n).astype(np.float64)
-        e = rng.uniform(-2.0 ** -22, 2.0 ** -22, n)
+        t = rng2.random(n).astype(np.float64)
+        e = rng2.uniform(-2.0 ** -22, 2.0 ** -22, n)
         x = (t * (1.0 + e) * float(xo)).astype(f32)
         y = ((1.0 - t) * (1.0 + e) * float(yo)).astype(f32)
         a = (y * xo).astype(f32) + (x * yo).astype(f32)
-        for _ in range(8):
-            x2, y2 = f32(float(xo) * (1.0 + 2.0 ** rng.uniform(-23, -18))), f32(float(yo) * (1.0 + 2.0 ** rng.uniform(-23, -18)))
+        for _ in range(16):
+            x2 = f32(float(xo) * (1.0 + 2.0 ** rng2.uniform(-23, -18)))
+            y2 = f32(float(yo) * (1.0 + 2.0 ** rng2.uniform(-23, -18)))
             a2 = (y * x2).astype(f32) + (x * y2).astype(f32)
             flips += int(np.sum(a2[a <= co] > f32(x2 * y2)))
+            x1 = f32(float(xo) * (1.0 - 2.0 ** rng2.uniform(-23, -18)))
+            y1 = f32(float(yo) * (1.0 - 2.0 ** rng2.uniform(-23, -18)))
+            a1 = (y * x1).astype(f32) + (x * y1).astype(f32)
+            flips += int(np.sum(a1[a > co] <= f32(x1 * y1)))
     assert flips > 0
 
 
