@@ -25,7 +25,16 @@ import ctypes
 from poppunk_amd import _lib
 
 
+try:      # (an older build of the library, tools/ab_sweeps_builds.py: no stage timers)
+    _lib.lib().ppk_prof_stages_enable
+    HAVE_STAGES = True
+except AttributeError:
+    HAVE_STAGES = False
+
+
 def stages(reset=True):
+    if not HAVE_STAGES:
+        return []
     buf = ctypes.create_string_buffer(8192)
     _lib.lib().ppk_prof_stages_read(buf, 8192, 1 if reset else 0)
     rows = [l.split("\t") for l in buf.value.decode().splitlines()]
@@ -36,14 +45,16 @@ def timed(fn, reps=20):
     out = fn()
     torch.cuda.synchronize()
     ts = []
-    _lib.lib().ppk_prof_stages_enable(0 if "--plain" in sys.argv else 1)      # (--plain: wall time without the stage events)
+    if HAVE_STAGES:
+        _lib.lib().ppk_prof_stages_enable(0 if "--plain" in sys.argv else 1)      # (--plain: wall time without the stage events)
     stages()
     for _ in range(reps):
         t0 = time.perf_counter()
         out = fn()
         torch.cuda.synchronize()
         ts.append((time.perf_counter() - t0) * 1e3)
-    _lib.lib().ppk_prof_stages_enable(0)
+    if HAVE_STAGES:
+        _lib.lib().ppk_prof_stages_enable(0)
     for n, ms, c in stages():
         print("      stage %-16s %8.1f us  (x%d)" % (n, ms / max(c, 1) * 1e3, c))
     ts.sort()
